@@ -1,0 +1,256 @@
+"""Oracle (test infrastructure): DiT denoiser restated in plain PyTorch fp32.
+
+Follows /root/reference/DiT/models.py:
+  modulate :19-20, TimestepEmbedder :27-64, LabelEmbedder :67-94, DiTBlock :101-122,
+  FinalLayer :125-142, DiT :145-248, sin-cos table :274-321, registry :328-370.
+
+The three classes the reference takes from timm (models.py:16 -- PatchEmbed,
+Attention, Mlp; un-vendored, un-pinned => "parity unpinned" at that boundary)
+are restated from timm's published behaviour:
+  PatchEmbed = Conv2d(C, D, k=p, s=p, bias) -> flatten(2).transpose(1, 2)
+  Attention  = qkv Linear(D, 3D) reshaped [B,N,3,H,hd] -> permute(2,0,3,1,4);
+               softmax(q * hd^-0.5 @ k^T) @ v; proj Linear(D, D); dropouts 0
+  Mlp        = fc1 -> act -> fc2
+state_dict keys match the reference's.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+def modulate(x, shift, scale):
+    return x * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1)
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size, patch_size, in_chans, embed_dim, bias=True):
+        super().__init__()
+        self.patch_size = (patch_size, patch_size)
+        self.num_patches = (img_size // patch_size) ** 2
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=bias)
+
+    def forward(self, x):
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=True):
+        super().__init__()
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv.unbind(0)
+        attn = (q * self.scale) @ k.transpose(-2, -1)
+        attn = attn.softmax(dim=-1)
+        x = attn @ v
+        x = x.transpose(1, 2).reshape(B, N, C)
+        return self.proj(x)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features, act_layer, drop=0):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class TimestepEmbedder(nn.Module):
+    def __init__(self, hidden_size, frequency_embedding_size=256):
+        super().__init__()
+        self.mlp = nn.Sequential(
+            nn.Linear(frequency_embedding_size, hidden_size, bias=True),
+            nn.SiLU(),
+            nn.Linear(hidden_size, hidden_size, bias=True),
+        )
+        self.frequency_embedding_size = frequency_embedding_size
+
+    @staticmethod
+    def timestep_embedding(t, dim, max_period=10000):
+        half = dim // 2
+        freqs = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half)
+        args = t[:, None].float() * freqs[None]
+        embedding = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+        if dim % 2:
+            embedding = torch.cat([embedding, torch.zeros_like(embedding[:, :1])], dim=-1)
+        return embedding
+
+    def forward(self, t):
+        return self.mlp(self.timestep_embedding(t, self.frequency_embedding_size))
+
+
+class LabelEmbedder(nn.Module):
+    def __init__(self, num_classes, hidden_size, dropout_prob):
+        super().__init__()
+        use_cfg_embedding = dropout_prob > 0
+        self.embedding_table = nn.Embedding(num_classes + use_cfg_embedding, hidden_size)
+        self.num_classes = num_classes
+        self.dropout_prob = dropout_prob
+
+    def token_drop(self, labels, force_drop_ids=None):
+        if force_drop_ids is None:
+            drop_ids = torch.rand(labels.shape[0]) < self.dropout_prob
+        else:
+            drop_ids = force_drop_ids == 1
+        return torch.where(drop_ids, self.num_classes, labels)
+
+    def forward(self, labels, train, force_drop_ids=None):
+        use_dropout = self.dropout_prob > 0
+        if (train and use_dropout) or (force_drop_ids is not None):
+            labels = self.token_drop(labels, force_drop_ids)
+        return self.embedding_table(labels)
+
+
+class DiTBlock(nn.Module):
+    def __init__(self, hidden_size, num_heads, mlp_ratio=4.0):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6)
+        self.attn = Attention(hidden_size, num_heads=num_heads, qkv_bias=True)
+        self.norm2 = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6)
+        self.mlp = Mlp(hidden_size, int(hidden_size * mlp_ratio), lambda: nn.GELU(approximate="tanh"), drop=0)
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 6 * hidden_size, bias=True))
+
+    def forward(self, x, c):
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.adaLN_modulation(c).chunk(6, dim=1)
+        x = x + gate_msa.unsqueeze(1) * self.attn(modulate(self.norm1(x), shift_msa, scale_msa))
+        x = x + gate_mlp.unsqueeze(1) * self.mlp(modulate(self.norm2(x), shift_mlp, scale_mlp))
+        return x
+
+
+class FinalLayer(nn.Module):
+    def __init__(self, hidden_size, patch_size, out_channels):
+        super().__init__()
+        self.norm_final = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6)
+        self.linear = nn.Linear(hidden_size, patch_size * patch_size * out_channels, bias=True)
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 2 * hidden_size, bias=True))
+
+    def forward(self, x, c):
+        shift, scale = self.adaLN_modulation(c).chunk(2, dim=1)
+        return self.linear(modulate(self.norm_final(x), shift, scale))
+
+
+def get_1d_sincos(embed_dim, pos):
+    omega = np.arange(embed_dim // 2, dtype=np.float64)
+    omega /= embed_dim / 2.0
+    omega = 1.0 / 10000 ** omega
+    out = np.einsum("m,d->md", pos.reshape(-1), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def get_2d_sincos_pos_embed(embed_dim, grid_size):
+    # models.py:274-321 ("w goes first" in the meshgrid; emb = [emb(grid[0]), emb(grid[1])])
+    grid_h = np.arange(grid_size, dtype=np.float32)
+    grid_w = np.arange(grid_size, dtype=np.float32)
+    grid = np.stack(np.meshgrid(grid_w, grid_h), axis=0).reshape([2, 1, grid_size, grid_size])
+    emb_h = get_1d_sincos(embed_dim // 2, grid[0])
+    emb_w = get_1d_sincos(embed_dim // 2, grid[1])
+    return np.concatenate([emb_h, emb_w], axis=1)
+
+
+class DiT(nn.Module):
+    def __init__(self, input_size=32, patch_size=2, in_channels=4, hidden_size=1152, depth=28,
+                 num_heads=16, mlp_ratio=4.0, class_dropout_prob=0.1, num_classes=1000, learn_sigma=True):
+        super().__init__()
+        self.learn_sigma = learn_sigma
+        self.in_channels = in_channels
+        self.out_channels = in_channels * 2 if learn_sigma else in_channels
+        self.patch_size = patch_size
+        self.num_heads = num_heads
+        self.x_embedder = PatchEmbed(input_size, patch_size, in_channels, hidden_size, bias=True)
+        self.t_embedder = TimestepEmbedder(hidden_size)
+        self.y_embedder = LabelEmbedder(num_classes, hidden_size, class_dropout_prob)
+        num_patches = self.x_embedder.num_patches
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches, hidden_size), requires_grad=False)
+        self.blocks = nn.ModuleList([DiTBlock(hidden_size, num_heads, mlp_ratio=mlp_ratio) for _ in range(depth)])
+        self.final_layer = FinalLayer(hidden_size, patch_size, self.out_channels)
+        self.initialize_weights()
+
+    def initialize_weights(self):
+        # models.py:182-216
+        def _basic_init(module):
+            if isinstance(module, nn.Linear):
+                torch.nn.init.xavier_uniform_(module.weight)
+                if module.bias is not None:
+                    nn.init.constant_(module.bias, 0)
+        self.apply(_basic_init)
+        pos_embed = get_2d_sincos_pos_embed(self.pos_embed.shape[-1], int(self.x_embedder.num_patches ** 0.5))
+        self.pos_embed.data.copy_(torch.from_numpy(pos_embed).float().unsqueeze(0))
+        w = self.x_embedder.proj.weight.data
+        nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
+        nn.init.constant_(self.x_embedder.proj.bias, 0)
+        nn.init.normal_(self.y_embedder.embedding_table.weight, std=0.02)
+        nn.init.normal_(self.t_embedder.mlp[0].weight, std=0.02)
+        nn.init.normal_(self.t_embedder.mlp[2].weight, std=0.02)
+        for block in self.blocks:
+            nn.init.constant_(block.adaLN_modulation[-1].weight, 0)
+            nn.init.constant_(block.adaLN_modulation[-1].bias, 0)
+        nn.init.constant_(self.final_layer.adaLN_modulation[-1].weight, 0)
+        nn.init.constant_(self.final_layer.adaLN_modulation[-1].bias, 0)
+        nn.init.constant_(self.final_layer.linear.weight, 0)
+        nn.init.constant_(self.final_layer.linear.bias, 0)
+
+    def unpatchify(self, x):
+        c = self.out_channels
+        p = self.x_embedder.patch_size[0]
+        h = w = int(x.shape[1] ** 0.5)
+        x = x.reshape(shape=(x.shape[0], h, w, p, p, c))
+        x = torch.einsum("nhwpqc->nchpwq", x)
+        return x.reshape(shape=(x.shape[0], c, h * p, h * p))
+
+    def forward(self, x, t, y, force_drop_ids=None):
+        """models.py:233-248.  ``force_drop_ids`` (1 = drop) makes the label-dropout
+        draw an explicit input; when None and training, the draw is
+        torch.rand as in the reference (models.py:83)."""
+        x = self.x_embedder(x) + self.pos_embed
+        t = self.t_embedder(t)
+        y = self.y_embedder(y, self.training, force_drop_ids)
+        c = t + y
+        for block in self.blocks:
+            x = block(x, c)
+        x = self.final_layer(x, c)
+        return self.unpatchify(x)
+
+
+def randomize_zero_init(model, std=0.02, seed=0):
+    """a freshly built DiT has all-zero adaLN / final weights, so only
+    final_layer.linear gets gradient.  Synthetic parity/bench runs re-draw every all-zero
+    trainable tensor N(0, std) so every kernel sees non-degenerate data."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for _, p in model.named_parameters():
+            if p.requires_grad and not p.any():
+                p.copy_(torch.randn(p.shape, generator=g) * std)
+    return model
+
+
+DIT_CONFIGS = {
+    "DiT-XL/2": dict(depth=28, hidden_size=1152, patch_size=2, num_heads=16),
+    "DiT-XL/4": dict(depth=28, hidden_size=1152, patch_size=4, num_heads=16),
+    "DiT-XL/8": dict(depth=28, hidden_size=1152, patch_size=8, num_heads=16),
+    "DiT-L/2": dict(depth=24, hidden_size=1024, patch_size=2, num_heads=16),
+    "DiT-L/4": dict(depth=24, hidden_size=1024, patch_size=4, num_heads=16),
+    "DiT-L/8": dict(depth=24, hidden_size=1024, patch_size=8, num_heads=16),
+    "DiT-B/2": dict(depth=12, hidden_size=768, patch_size=2, num_heads=12),
+    "DiT-B/4": dict(depth=12, hidden_size=768, patch_size=4, num_heads=12),
+    "DiT-B/8": dict(depth=12, hidden_size=768, patch_size=8, num_heads=12),
+    "DiT-S/2": dict(depth=12, hidden_size=384, patch_size=2, num_heads=6),
+    "DiT-S/4": dict(depth=12, hidden_size=384, patch_size=4, num_heads=6),
+    "DiT-S/8": dict(depth=12, hidden_size=384, patch_size=8, num_heads=6),
+}
+
+
+def build(name, **kwargs):
+    cfg = dict(DIT_CONFIGS[name])
+    cfg.update(kwargs)
+    return DiT(**cfg)

@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference
+(/root/reference, build container only -- the reference never travels to the GPU box).
+
+Run:  python tests/golden/make_golden.py
+Outputs (small .npz files, inputs + expected outputs only -- no reference source text):
+  dit_diffusion.npz   tables + training_losses (loss/mse/vb + dL/d model_output) from
+                      DiT/diffusion (create_diffusion("")), incl. t=0, t=999, |x0|>0.999 rows
+  dit_model.npz       reference DiT class (DiT/models.py) forward + backward on a tiny config.
+                      The three timm classes are NOT in /root/reference (un-vendored, un-pinned):
+                      the harness supplies oracle.dit_ref.{PatchEmbed,Attention,Mlp} in their
+                      place, so this fixture pins everything in models.py EXCEPT those classes.
+  dit_sfron_traj.npz  3 SFR-on iterations composed from reference functions in the order of
+                      DiT/forget.py:256-322 (forget.py itself needs torchvision/diffusers/CUDA)
+  ddpm_loss.npz       DDPM/functions/losses.py (simple, adaptive), cosine schedule, EMAHelper
+  fisher_mask.npz     DiT/generate_mask.py main() run on synthetic Fisher files (0/0, int-0 entries)
+"""
+import argparse
+import importlib
+import importlib.util
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle import dit_ref  # noqa: E402  (stand-ins for the absent timm classes + weight generator)
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def import_ref_dit_diffusion():
+    sys.path.insert(0, os.path.join(REF, "DiT"))
+    import diffusion as ref_diffusion
+    return ref_diffusion
+
+
+def import_ref_dit_models():
+    vt = types.ModuleType("timm.models.vision_transformer")
+    vt.PatchEmbed, vt.Attention, vt.Mlp = dit_ref.PatchEmbed, dit_ref.Attention, dit_ref.Mlp
+    timm = types.ModuleType("timm")
+    timm_models = types.ModuleType("timm.models")
+    timm.models = timm_models
+    timm_models.vision_transformer = vt
+    sys.modules.update({"timm": timm, "timm.models": timm_models, "timm.models.vision_transformer": vt})
+    return _load("ref_dit_models", os.path.join(REF, "DiT", "models.py"))
+
+
+TINY = dict(input_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=2, num_heads=2, num_classes=10)
+
+
+def tiny_weights(seed=1234):
+    torch.manual_seed(seed)
+    m = dit_ref.DiT(**TINY)
+    dit_ref.randomize_zero_init(m, std=0.05, seed=seed + 1)
+    return m.state_dict()
+
+
+def gen_diffusion(ref_diffusion):
+    d = ref_diffusion.create_diffusion(timestep_respacing="")
+    g = torch.Generator().manual_seed(7)
+    N, C, H = 8, 4, 8
+    x0 = torch.randn(N, C, H, H, generator=g) * 0.7
+    x0[0, 0, 0, :4] = torch.tensor([-1.0, 1.0, -0.9995, 0.9995])   # discretized-NLL edge branches
+    x0[1, 1, 2, :2] = torch.tensor([-1.2, 1.3])
+    noise = torch.randn(N, C, H, H, generator=g)
+    t = torch.tensor([0, 0, 999, 1, 500, 37, 998, 250])
+    out = (torch.randn(N, 2 * C, H, H, generator=g) * 0.8).requires_grad_(True)
+    terms = d.training_losses(lambda x, ts, **kw: out, x0, t, model_kwargs={}, noise=noise)
+    terms["loss"].mean().backward()
+    x_t = d.q_sample(x0, t, noise=noise)
+    tabs = {k: getattr(d, k) for k in ["betas", "alphas_cumprod", "sqrt_alphas_cumprod",
+                                        "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+                                        "sqrt_recipm1_alphas_cumprod", "posterior_log_variance_clipped",
+                                        "posterior_mean_coef1", "posterior_mean_coef2"]}
+    np.savez_compressed(os.path.join(HERE, "dit_diffusion.npz"),
+                        x0=x0.numpy(), noise=noise.numpy(), t=t.numpy(), model_output=out.detach().numpy(),
+                        x_t=x_t.numpy(), loss=terms["loss"].detach().numpy(), mse=terms["mse"].detach().numpy(),
+                        vb=terms["vb"].detach().numpy(), dloss_dout=out.grad.numpy(),
+                        **{"tab_" + k: v for k, v in tabs.items()})
+    return d
+
+
+def gen_model(ref_models):
+    sd = tiny_weights()
+    m = ref_models.DiT(**TINY)
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 4, 8, 8, generator=g)
+    t = torch.tensor([3, 999, 421])
+    y = torch.tensor([1, 9, 4])
+    m.eval()
+    out_eval = m(x, t, y)
+    m.train()
+    torch.manual_seed(99)          # label-dropout draw inside LabelEmbedder.token_drop (models.py:83)
+    out_train = m(x, t, y)
+    w = torch.randn(out_eval.shape, generator=g)
+    m.zero_grad()
+    m.eval()
+    (m(x, t, y) * w).sum().backward()
+    grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    pick = ["x_embedder.proj.weight", "t_embedder.mlp.0.weight", "y_embedder.embedding_table.weight",
+            "blocks.0.attn.qkv.weight", "blocks.0.attn.qkv.bias", "blocks.0.adaLN_modulation.1.weight",
+            "blocks.1.mlp.fc1.weight", "blocks.1.mlp.fc2.bias", "final_layer.linear.weight",
+            "final_layer.adaLN_modulation.1.bias"]
+    np.savez_compressed(os.path.join(HERE, "dit_model.npz"),
+                        x=x.numpy(), t=t.numpy(), y=y.numpy(), w=w.numpy(), out_eval=out_eval.detach().numpy(),
+                        out_train_seed99=out_train.detach().numpy(),
+                        pos_embed=m.pos_embed.detach().numpy(),
+                        param_names=np.array(list(sd.keys())),
+                        param_sums=np.array([float(v.double().sum()) for v in sd.values()]),
+                        grad_norms=np.array([float(grads[n].double().norm()) if n in grads else -1.0
+                                             for n, _ in m.named_parameters()]),
+                        **{"grad::" + n: grads[n].numpy() for n in pick})
+
+
+def gen_traj(ref_models, ref_diffusion):
+    """DiT/forget.py:256-322 composed from reference DiT + reference diffusion + torch AdamW."""
+    from collections import OrderedDict
+    from copy import deepcopy
+    sd = tiny_weights()
+    model = ref_models.DiT(**TINY)
+    model.load_state_dict(sd)
+    ema = deepcopy(model)
+    diffusion = ref_diffusion.create_diffusion(timestep_respacing="")
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0)
+    gm = torch.Generator().manual_seed(5)
+    mask = {"module." + n: (torch.rand(p.shape, generator=gm) < 0.5) for n, p in model.named_parameters()
+            if p.requires_grad}
+    mask["module.pos_embed"] = 0
+    model.train()
+    forget_alpha, grad_clip, N = 0.5, 1.0, 4
+    g = torch.Generator().manual_seed(2024)
+    rec = {"forget_loss": [], "remain_loss": [], "forget_mse": [], "remain_mse": [], "gnorm": []}
+    inputs = {}
+    for step in range(3):
+        batch = {}
+        for stream in ("forget", "remain"):
+            batch[stream] = dict(
+                x0=torch.randn(N, 4, 8, 8, generator=g) * 0.8,
+                t=torch.randint(0, 1000, (N,), generator=g),
+                noise=torch.randn(N, 4, 8, 8, generator=g),
+                y=(torch.full((N,), 3) if stream == "forget" else torch.randint(0, 10, (N,), generator=g)),
+                drop=(torch.rand(N, generator=g) < 0.25).long())
+            for k, v in batch[stream].items():
+                inputs[f"s{step}_{stream}_{k}"] = v.numpy()
+        # the reference draws drop ids with torch.rand inside forward; to make them an explicit
+        # input we call the reference LabelEmbedder through its own force_drop_ids argument.
+        def run(b):
+            fd = b["drop"]
+            def fwd(x, ts, y):
+                xx = model.x_embedder(x) + model.pos_embed
+                c = model.t_embedder(ts) + model.y_embedder(y, model.training, force_drop_ids=fd)
+                for blk in model.blocks:
+                    xx = blk(xx, c)
+                return model.unpatchify(model.final_layer(xx, c))
+            return diffusion.training_losses(fwd, b["x0"], b["t"], dict(y=b["y"]), noise=b["noise"])
+        tf = run(batch["forget"])
+        ori_forget = -tf["loss"].mean()
+        opt.zero_grad()
+        (forget_alpha * ori_forget).backward()
+        for name, p in model.named_parameters():
+            if p.grad is not None:
+                p.grad *= mask["module." + name]
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip)
+        opt.step()
+        tr = run(batch["remain"])
+        ori_remain = tr["loss"].mean()
+        opt.zero_grad()
+        ori_remain.backward()
+        opt.step()
+        with torch.no_grad():
+            ep, mp = OrderedDict(ema.named_parameters()), OrderedDict(model.named_parameters())
+            for name, p in mp.items():
+                ep[name].mul_(0.9).add_(p.data, alpha=1 - 0.9)
+        rec["forget_loss"].append(ori_forget.item()); rec["remain_loss"].append(ori_remain.item())
+        rec["forget_mse"].append(float(tf["mse"].mean())); rec["remain_mse"].append(float(tr["mse"].mean()))
+        rec["gnorm"].append(float(gn))
+    names = [n for n, _ in model.named_parameters()]
+    np.savez_compressed(os.path.join(HERE, "dit_sfron_traj.npz"),
+                        names=np.array(names),
+                        final_param_sums=np.array([float(p.double().sum()) for _, p in model.named_parameters()]),
+                        final_param_abs=np.array([float(p.double().abs().sum()) for _, p in model.named_parameters()]),
+                        final_ema_sums=np.array([float(p.double().sum()) for _, p in ema.named_parameters()]),
+                        final_qkv0=dict(model.named_parameters())["blocks.0.attn.qkv.weight"].detach().numpy(),
+                        final_ema_fc1=dict(ema.named_parameters())["blocks.1.mlp.fc1.bias"].detach().numpy(),
+                        mask_seed=np.array(5), lr=np.array(1e-3), forget_alpha=np.array(forget_alpha),
+                        ema_decay=np.array(0.9),
+                        **{k: np.array(v) for k, v in rec.items()}, **inputs)
+
+
+def gen_ddpm():
+    losses = _load("ref_ddpm_losses", os.path.join(REF, "DDPM", "functions", "losses.py"))
+    ema_mod = _load("ref_ddpm_ema", os.path.join(REF, "DDPM", "models", "ema.py"))
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.SiLU(), torch.nn.Conv2d(8, 3, 3, padding=1))
+    emb = torch.nn.Embedding(10, 3)
+    params = list(net.parameters()) + list(emb.parameters())
+
+    def model(x, tf, c, cond_drop_prob=0.1, mode="train"):
+        return net(x) * (1 + 0.001 * tf.view(-1, 1, 1, 1)) + emb(c).view(-1, 3, 1, 1)
+
+    g = torch.Generator().manual_seed(17)
+    N = 6
+    x0 = torch.rand(N, 3, 8, 8, generator=g) * 2 - 1
+    e = torch.randn(N, 3, 8, 8, generator=g)
+    t = torch.tensor([0, 999, 5, 500, 250, 750])
+    c = torch.tensor([0, 1, 2, 3, 4, 5])
+    b = torch.from_numpy(np.linspace(1e-4, 2e-2, 1000, dtype=np.float64)).float()   # runners/diffusion.py:36-66,83
+    net_state0 = np.concatenate([p.detach().flatten().numpy().copy() for p in params])
+    simple = losses.loss_registry_conditional["simple"](model, x0, t, c, e, b)
+    per = losses.loss_registry_conditional["simple"](model, x0, t, c, e, b, keepdim=True)
+    ada = losses.adaptive_loss(losses.loss_registry_conditional["simple"], model, x0, t, c, e, b, lambd=0.5)
+    for p in params:
+        p.grad = None
+    (-ada).backward()
+    g_ada = torch.cat([p.grad.flatten() for p in params])
+    cos = np.array([losses.cosine_lr_scheduler(10.0, s, 50) for s in range(50)])
+    helper = ema_mod.EMAHelper(mu=1e-4)
+    helper.register(net)
+    before = {k: v.clone() for k, v in helper.shadow.items()}
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.01)
+    helper.update(net)
+    np.savez_compressed(os.path.join(HERE, "ddpm_loss.npz"),
+                        x0=x0.numpy(), e=e.numpy(), t=t.numpy(), c=c.numpy(), betas=b.numpy(),
+                        net_state=net_state0,
+                        simple=simple.detach().numpy(), per_sample=per.detach().numpy(),
+                        adaptive=ada.detach().numpy(), grad_neg_adaptive=g_ada.numpy(), cosine=cos,
+                        ema_before=np.concatenate([v.flatten().numpy() for v in before.values()]),
+                        ema_after=np.concatenate([v.flatten().numpy() for v in helper.shadow.values()]))
+
+
+def gen_mask():
+    gm = _load("ref_generate_mask", os.path.join(REF, "DiT", "generate_mask.py"))
+    g = torch.Generator().manual_seed(23)
+    ff = {"module.a": torch.rand(64, 33, generator=g) ** 4, "module.b": torch.rand(257, generator=g) * 1e-12,
+          "module.pos_embed": 0}
+    rf = {"module.a": torch.rand(64, 33, generator=g) ** 4, "module.b": torch.rand(257, generator=g) * 1e-12,
+          "module.pos_embed": 0}
+    ff["module.a"][0, :5] = 0.0
+    rf["module.a"][0, :3] = 0.0          # 0/0 and x/0 entries
+    rf["module.a"][1, :4] = 0.0
+    ff["module.b"][:7] = 0.0
+    ths = [0.5, 1.0, 3.0]
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "207"))
+        torch.save(ff, os.path.join(d, "207", "forget_fisher.pt"))
+        torch.save(rf, os.path.join(d, "207", "remain_fisher.pt"))
+        gm.main(argparse.Namespace(mask_path=d, forget_class=[207], thresholds=ths))
+        out = {}
+        for th in ths:
+            mk = torch.load(os.path.join(d, "207", f"fisher_{th}.pt"))
+            assert isinstance(mk["module.pos_embed"], int)
+            out[f"mask_a_{th}"] = mk["module.a"].numpy()
+            out[f"mask_b_{th}"] = mk["module.b"].numpy()
+    np.savez_compressed(os.path.join(HERE, "fisher_mask.npz"), ff_a=ff["module.a"].numpy(),
+                        rf_a=rf["module.a"].numpy(), ff_b=ff["module.b"].numpy(), rf_b=rf["module.b"].numpy(),
+                        ths=np.array(ths), **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    ref_diffusion = import_ref_dit_diffusion()
+    gen_diffusion(ref_diffusion)
+    ref_models = import_ref_dit_models()
+    gen_model(ref_models)
+    gen_traj(ref_models, ref_diffusion)
+    gen_ddpm()
+    gen_mask()
+    print("golden vectors written to", HERE)

@@ -1,0 +1,145 @@
+"""CPU: pin the oracle (oracle/*.py) against golden vectors produced by importing the
+reference (tests/golden/make_golden.py).  These run with -m "not gpu"."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import diffusion_ref as dref
+from oracle import dit_ref, sfron_ref, sweep_ref
+
+TINY = dict(input_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=2, num_heads=2, num_classes=10)
+
+
+def tiny_model(seed=1234):
+    torch.manual_seed(seed)
+    m = dit_ref.DiT(**TINY)
+    dit_ref.randomize_zero_init(m, std=0.05, seed=seed + 1)
+    return m
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_tables_bit_exact(golden_dir):
+    g = load(golden_dir, "dit_diffusion.npz")
+    tab = dref.DiffusionTables(1000)
+    for k in ["betas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+              "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_log_variance_clipped",
+              "posterior_mean_coef1", "posterior_mean_coef2"]:
+        assert np.array_equal(getattr(tab, k), g["tab_" + k]), k     # fp64, bit-exact
+    assert abs(tab.alphas_cumprod[999] - 4.0358e-5) < 1e-8
+
+
+def test_training_losses_match_reference(golden_dir):
+    g = load(golden_dir, "dit_diffusion.npz")
+    tab = dref.DiffusionTables(1000)
+    x0, noise, t = torch.from_numpy(g["x0"]), torch.from_numpy(g["noise"]), torch.from_numpy(g["t"])
+    out = torch.from_numpy(g["model_output"]).clone().requires_grad_(True)
+    x_t = dref.q_sample(tab, x0, t, noise)
+    assert np.array_equal(x_t.numpy(), g["x_t"])
+    terms = dref.training_losses(tab, lambda x, ts, **kw: out, x0, t, {}, noise)
+    terms["loss"].mean().backward()
+    for k in ("loss", "mse", "vb"):
+        np.testing.assert_allclose(terms[k].detach().numpy(), g[k], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(out.grad.numpy(), g["dloss_dout"], rtol=1e-5, atol=1e-9)
+    # d(loss.mean())/d eps_hat = 2 (eps_hat - eps) / (C*H*W*N) exactly (mse only)
+    N, C, H, W = x0.shape
+    np.testing.assert_allclose(out.grad[:, :C].numpy(), (2 * (out.detach()[:, :C] - noise) / (C * H * W * N)).numpy(),
+                               rtol=1e-6, atol=1e-10)
+
+
+def test_dit_forward_backward_match_reference(golden_dir):
+    g = load(golden_dir, "dit_model.npz")
+    m = tiny_model()
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g["param_names"])
+    np.testing.assert_allclose([float(v.double().sum()) for v in sd.values()], g["param_sums"], rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(m.pos_embed.detach().numpy(), g["pos_embed"])
+    x, t, y = torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["y"])
+    m.eval()
+    out = m(x, t, y)
+    np.testing.assert_allclose(out.detach().numpy(), g["out_eval"], rtol=1e-5, atol=1e-6)
+    m.train()
+    torch.manual_seed(99)
+    np.testing.assert_allclose(m(x, t, y).detach().numpy(), g["out_train_seed99"], rtol=1e-5, atol=1e-6)
+    m.eval()
+    m.zero_grad()
+    (m(x, t, y) * torch.from_numpy(g["w"])).sum().backward()
+    for key in g.files:
+        if key.startswith("grad::"):
+            p = dict(m.named_parameters())[key[6:]]
+            np.testing.assert_allclose(p.grad.numpy(), g[key], rtol=2e-4, atol=2e-5, err_msg=key)
+    norms = np.array([float(p.grad.double().norm()) if p.grad is not None else -1.0 for _, p in m.named_parameters()])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=1e-4, atol=1e-6)
+
+
+def test_sfron_trajectory_matches_reference(golden_dir):
+    g = load(golden_dir, "dit_sfron_traj.npz")
+    m = tiny_model()
+    gm = torch.Generator().manual_seed(int(g["mask_seed"]))
+    mask = {"module." + n: (torch.rand(p.shape, generator=gm) < 0.5) for n, p in m.named_parameters() if p.requires_grad}
+    mask["module.pos_embed"] = 0
+    orc = sfron_ref.DiTSfronOracle(m, dref.DiffusionTables(1000), lr=float(g["lr"]),
+                                   forget_alpha=float(g["forget_alpha"]), grad_clip=1.0,
+                                   ema_decay=float(g["ema_decay"]), mask=mask, unlearn_loss="ga")
+    for step in range(3):
+        b = {s: {k: torch.from_numpy(g[f"s{step}_{s}_{k}"]) for k in ("x0", "t", "noise", "y", "drop")}
+             for s in ("forget", "remain")}
+        r = orc.step(b["forget"], b["remain"])
+        assert r["forget_loss"] == pytest.approx(float(g["forget_loss"][step]), rel=2e-5, abs=1e-6)
+        assert r["remain_loss"] == pytest.approx(float(g["remain_loss"][step]), rel=2e-5, abs=1e-6)
+        assert r["forget_mse"] == pytest.approx(float(g["forget_mse"][step]), rel=2e-5)
+        assert r["forget_gnorm"] == pytest.approx(float(g["gnorm"][step]), rel=2e-4)
+    names = [n for n, _ in m.named_parameters()]
+    assert names == list(g["names"])
+    np.testing.assert_allclose([float(p.double().abs().sum()) for _, p in m.named_parameters()],
+                               g["final_param_abs"], rtol=2e-5)
+    np.testing.assert_allclose(dict(m.named_parameters())["blocks.0.attn.qkv.weight"].detach().numpy(),
+                               g["final_qkv0"], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(orc.ema["blocks.1.mlp.fc1.bias"].numpy(), g["final_ema_fc1"], rtol=0, atol=3e-5)
+    np.testing.assert_allclose([float(orc.ema[n].double().sum()) for n in names], g["final_ema_sums"],
+                               rtol=1e-4, atol=1e-4)
+
+
+def test_ddpm_losses_and_ema(golden_dir):
+    g = load(golden_dir, "ddpm_loss.npz")
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.SiLU(), torch.nn.Conv2d(8, 3, 3, padding=1))
+    emb = torch.nn.Embedding(10, 3)
+    params = list(net.parameters()) + list(emb.parameters())
+    np.testing.assert_array_equal(np.concatenate([p.detach().flatten().numpy() for p in params]), g["net_state"])
+    x0, e, t, c = (torch.from_numpy(g[k]) for k in ("x0", "e", "t", "c"))
+    b = sfron_ref.ddpm_get_betas()
+    np.testing.assert_array_equal(b.numpy(), g["betas"])
+    fn = lambda x, tf: net(x) * (1 + 0.001 * tf.view(-1, 1, 1, 1)) + emb(c).view(-1, 3, 1, 1)
+    per = sfron_ref.ddpm_loss_per_sample(fn, x0, t, e, b)
+    np.testing.assert_allclose(per.detach().numpy(), g["per_sample"], rtol=1e-6)
+    np.testing.assert_allclose(per.mean(dim=0).detach().numpy(), g["simple"], rtol=1e-6)
+    ada = sfron_ref.ddpm_adaptive_loss(per, 0.5)
+    np.testing.assert_allclose(ada.detach().numpy(), g["adaptive"], rtol=1e-6)
+    (-ada).backward()
+    np.testing.assert_allclose(torch.cat([p.grad.flatten() for p in params]).numpy(), g["grad_neg_adaptive"],
+                               rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose([sfron_ref.cosine_alpha(10.0, s, 50) for s in range(50)], g["cosine"], rtol=0, atol=0)
+    shadow = [p.detach().clone() for p in net.parameters()]
+    np.testing.assert_array_equal(np.concatenate([s.flatten().numpy() for s in shadow]), g["ema_before"])
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.01)
+    sweep_ref.ema_update_ddpm_(shadow, [p.data for p in net.parameters()], 1e-4)
+    np.testing.assert_array_equal(np.concatenate([s.flatten().numpy() for s in shadow]), g["ema_after"])
+
+
+def test_fisher_mask_bit_exact(golden_dir):
+    g = load(golden_dir, "fisher_mask.npz")
+    for th in g["ths"]:
+        for k in ("a", "b"):
+            got = sweep_ref.mask_from_fisher(torch.from_numpy(g[f"ff_{k}"]), torch.from_numpy(g[f"rf_{k}"]), float(th))
+            assert got.dtype == torch.bool
+            assert np.array_equal(got.numpy(), g[f"mask_{k}_{float(th)}"])
+    # 0/0 -> (1e-15)/(1e-15) = 1 >= th is True for th <= 1
+    z = torch.zeros(4)
+    assert sweep_ref.mask_from_fisher(z, z, 1.0).all() and not sweep_ref.mask_from_fisher(z, z, 3.0).any()
