@@ -1,0 +1,184 @@
+/* sfron.h -- C ABI of libsfron.so: the MI355X (gfx950) SFR-on unlearning hot path.
+ *
+ * The reference (K1nght/Unified-Unlearning-w-Remain-Geometry) is 100 % Python and has no FFI:
+ * its "operator interface" for this path is the PyTorch op sequences inside
+ *   DiT/forget.py:256-322, DiT/diffusion/gaussian_diffusion.py:715-787, DiT/models.py:233-248.
+ * Each entry point below replaces one of those sequences (cited per function) and is what a
+ * ctypes / cffi binding on the reference side would call (INTEGRATION.md shows the stubs).
+ *
+ * Conventions: plain pointers and sizes only (no torch types); every pointer is a DEVICE pointer
+ * unless stated; `stream` is a hipStream_t passed as void* (NULL = default stream); all launches
+ * are asynchronous on `stream`; return 0 on success, a hipError_t value or SFRON_ERR_* (>= 1001)
+ * on failure; nothing throws; no global state.  bf16 tensors are passed as uint16_t*.
+ */
+#ifndef SFRON_H
+#define SFRON_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ version / probing */
+int sfron_abi_version(void);            /* bumps when a signature changes */
+const char* sfron_build_arch(void);     /* "gfx950" */
+
+/* ------------------------------------------------------------------ parameter sweep (sweep.hip)
+ * Flat fp32 arenas: params, grads, exp_avg, exp_avg_sq, ema share offsets; mask is 1 byte/element
+ * (torch.bool storage, 0/1); w_bf16 is the bf16 shadow the GEMMs read. */
+
+/* length (in doubles) the `partials` scratch of sfron_sumsq_masked must have */
+int sfron_sweep_partials_len(void);
+
+/* partial sums of (mask ? g : 0)^2; first half of clip_grad_norm_ after `grad *= mask`
+ * (DiT/forget.py:289-298).  mask may be NULL.  *nblk_out (HOST int) = number of partials written. */
+int sfron_sumsq_masked(const float* g, const uint8_t* mask, int64_t n, double* partials, int* nblk_out, void* stream);
+
+/* stats[0] = ||g||_2, stats[1] = min(1, max_norm / (norm + 1e-6)), stats[2] = sum of squares
+ * (torch.nn.utils.clip_grad_norm_ semantics; DiT/forget.py:293-298) */
+int sfron_clip_coef(const double* partials, int nblk, float max_norm, float* stats, void* stream);
+
+/* fused: g' = (mask ? g : 0) * stats[1]; Adam/AdamW single-tensor update of (p, m, v) with
+ * host-computed (double, rounded to fp32 exactly where torch rounds) step_size = lr / (1 - beta1^step),
+ * bc2_sqrt = sqrt(1 - beta2^step),
+ * decay_mul = 1 - lr * weight_decay (1.0 for the reference's wd = 0); optional bf16 shadow write;
+ * optional fused EMA of the NEW p: ema_mode 0 none, 1 DiT (ema*d + (1-d)*p, DiT/forget.py:52-62),
+ * 2 DDPM ((1-mu)*p + mu*shadow, DDPM/models/ema.py:17-24).  mask / stats / w_bf16 / ema may be NULL.
+ * (DiT/forget.py:289-299,320; DDPM/runners/diffusion.py:1126-1138,1169-1180) */
+int sfron_masked_clip_adam(float* p, const float* g, float* m, float* v, const uint8_t* mask, const float* stats,
+                           int64_t n, double beta1, double beta2, double eps, double step_size, double bc2_sqrt,
+                           double decay_mul, uint16_t* w_bf16, float* ema, double ema_decay, int ema_mode, void* stream);
+
+/* stand-alone EMA (frozen parameters such as pos_embed; DiT/forget.py:60-62) */
+int sfron_ema_update(float* ema, const float* p, int64_t n, double decay, int ema_mode, void* stream);
+
+/* F += g^2 / n_iters (DiT/generate_fisher.py:236-239, on device instead of .cpu()) */
+int sfron_fisher_accum(float* fisher, const float* g, int64_t n, float n_iters, void* stream);
+
+/* mask = ((F_f + 1e-15) / (F_r + 1e-15)) >= th, IEEE fp32, bit-exact with torch
+ * (DiT/generate_mask.py:34-35, DDPM/generate_fisher_mask.py:39-46) */
+int sfron_mask_from_fisher(const float* forget_fisher, const float* remain_fisher, int64_t n, float th,
+                           uint8_t* mask, void* stream);
+
+/* fp32 -> bf16 (RNE) */
+int sfron_cast_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------ diffusion loss (loss.hip)
+ * tab: [T][8] fp32 rows = { sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod,
+ *   sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, posterior_mean_coef1,
+ *   posterior_mean_coef2, posterior_log_variance_clipped, log(betas) }
+ * (DiT/diffusion/gaussian_diffusion.py:167-201, gathered as fp32 like _extract_into_tensor :861-873) */
+#define SFRON_TAB_COLS 8
+
+/* x_t = sqrt_ac[t] * x0 + sqrt_1m_ac[t] * noise   (gaussian_diffusion.py:215-230); t is int64 [n] */
+int sfron_q_sample(const float* x0, const float* noise, const int64_t* t, const float* tab, int n, int chw, float* x_t,
+                   void* stream);
+
+/* model_out [n, 2c, hw] -> mse[n], vb[n] (loss = mse + vb) and
+ * d_model_out = d( grad_scale * sum_i loss_i ) / d model_out      (gaussian_diffusion.py:746-783, 682-713)
+ * grad_scale = (+/- forget_alpha or 1) / global_batch reproduces `(alpha * -loss.mean()).backward()`
+ * (DiT/forget.py:272,286-288,311). */
+int sfron_dit_loss_fwd_bwd(const float* x0, const float* noise, const float* model_out, const int64_t* t,
+                           const float* tab, int n, int c, int hw, float grad_scale, float* mse, float* vb,
+                           float* d_model_out, void* stream);
+
+/* ------------------------------------------------------------------ bf16 MFMA GEMM (gemm.hip)
+ * C[M,N] = alpha * op(A)[M,K] · op(B)[K,N] (+ bias[N]) with a fused epilogue; fp32 accumulation.
+ *   a_transposed = 0: A is [M][K] row-major (lda), contraction contiguous      (activations, forward / dgrad)
+ *   a_transposed = 1: A is [K][M] row-major (lda), i.e. the operand is A^T of a row-major tensor (wgrad)
+ *   b_transposed = 0: B is [N][K] row-major (ldb): nn.Linear weight layout, Y = X W^T
+ *   b_transposed = 1: B is [K][N] row-major (ldb): dgrad (dX = dY W) and wgrad (dW = dY^T X)
+ * Replaces the GEMMs behind nn.Linear / Conv2d(k=s=p) fwd+bwd of DiT/models.py:108-121,138-142,169.
+ * Requirements: K % 8 == 0, N % 4 == 0, lda/ldb % 8 == 0, 16-byte aligned A/B; transposed operands need
+ * their non-contraction extent % 8 == 0.  Rows/cols beyond M/N and k >= K are handled (zero-filled / masked). */
+enum {
+  SFRON_EPI_BF16 = 0,     /* c_bf16 = result                                                               */
+  SFRON_EPI_F32 = 1,      /* c_f32 = result (+= if accumulate)                  -- wgrad into the grad arena */
+  SFRON_EPI_GELU = 2,     /* aux = bf16(result) (pre-activation), c_bf16 = gelu_tanh(result)   -- Mlp.fc1+act */
+  SFRON_EPI_GATE_RES = 3, /* aux = bf16(result); c_f32[row,col] = resid[row,col] + gate[row/tokens, col] * result
+                             -- x = x + gate * branch(x)  (DiT/models.py:120-121)                          */
+  SFRON_EPI_DGELU = 4,    /* c_bf16 = result * gelu_tanh'(aux)                           -- fc2 dgrad + act' */
+  SFRON_EPI_POS = 5       /* c_f32 = result + pos[row % tokens, col]    -- x_embedder(x) + pos_embed (:240) */
+};
+typedef struct sfron_gemm_desc {
+  const uint16_t* A; const uint16_t* B;
+  int M, N, K, lda, ldb;
+  int a_transposed, b_transposed;
+  int epilogue;
+  float alpha;
+  const float* bias;                 /* [N] fp32 or NULL */
+  uint16_t* c_bf16; int ldc_bf16;
+  float* c_f32; int ldc_f32;
+  uint16_t* aux; int ldaux;
+  const float* gate; int ldgate;
+  const float* pos;
+  int tokens;                        /* tokens per sample (row -> sample / position) */
+  int accumulate;
+  const float* resid;                /* EPI_GATE_RES: c_f32 = resid + gate * result; NULL = in place (resid = c_f32) */
+  int split_k;                       /* > 1 (EPI_F32 only, no bias): split s writes its partial product to
+                                        c_f32 + s * split_stride; sum the slabs with sfron_reduce_chunks */
+  long split_stride;
+} sfron_gemm_desc;
+int sfron_gemm_bf16(const sfron_gemm_desc* desc /* HOST pointer */, void* stream);
+
+/* ------------------------------------------------------------------ adaLN-Zero elementwise (norm.hip)
+ * mod buffers are fp32 [batch][ldmod]; shift/scale/gate pointers already include the column offset of the
+ * chunk (DiT/models.py:119 .chunk(6, dim=1)).  `tokens` = tokens per sample (row / tokens = sample). */
+
+/* rows per reduction chunk used by the *_bwd kernels' partial buffers (0 if tokens is unsupported) */
+int sfron_rows_per_chunk(int tokens);
+
+/* out = bf16( LayerNorm(x; eps 1e-6, no affine) * (1 + scale) + shift ), saves mean / rstd per row
+ * (modulate(norm(x), shift, scale), DiT/models.py:19-20,120-121,139-140) */
+int sfron_ln_modulate_fwd(const float* x, const float* shift, const float* scale, int ldmod, int tokens, int M, int D,
+                          uint16_t* out, float* mean, float* rstd, void* stream);
+
+/* backward of the above: dx (+)= dLN; p_shift/p_scale [M / rows_per_chunk][D] = per-chunk column sums of
+ * d_out and d_out * xhat (finish with sfron_reduce_chunks -> d shift / d scale of the adaLN Linear) */
+int sfron_ln_modulate_bwd(const uint16_t* d_out, const float* x, const float* mean, const float* rstd, const float* scale,
+                          int ldmod, int tokens, int M, int D, float* dx, int dx_accumulate, float* p_shift,
+                          float* p_scale, void* stream);
+
+/* backward of x + gate * branch (DiT/models.py:120-121): d_branch = bf16(dy * gate);
+ * p_gate / p_dy [M / rows_per_chunk][D] = per-chunk column sums of dy * branch and of dy */
+int sfron_gate_bwd(const float* dy, const uint16_t* branch, const float* gate, int ldmod, int tokens, int M, int D,
+                   uint16_t* d_branch, float* p_gate, float* p_dy, void* stream);
+
+/* out[g * ldout + c] (+)= sum_{j < per_group} partials[(g * per_group + j) * D + c]   (fixed order, reproducible) */
+int sfron_reduce_chunks(const float* partials, int groups, int per_group, int D, float* out, int ldout, int accumulate,
+                        void* stream);
+/* out[c] = sum_g w[g * ldw + c] * sum_j partials[(g * per_group + j) * D + c]      (bias grad behind a gate) */
+int sfron_weighted_reduce(const float* partials, int groups, int per_group, int D, const float* w, int ldw, float* out,
+                          void* stream);
+/* out[c] = sum_r X[r][c]; X bf16 (is_bf16 = 1) or fp32; partials scratch [max_partials][N]      (bias grads) */
+int sfron_colsum(const void* X, int is_bf16, int M, int N, int ld, float* partials, int max_partials, float* out,
+                 void* stream);
+
+/* ------------------------------------------------------------------ conditioning / layout (embed.hip) */
+/* out[b] = bf16( cos(t*f) || sin(t*f) ), f_j = exp(-ln(1e4) j / (dim/2))    (DiT/models.py:41-59) */
+int sfron_timestep_embed(const int64_t* t, int n, int dim, uint16_t* out, int ld, void* stream);
+int sfron_silu_fwd(const float* x, int64_t n, uint16_t* y_bf16, void* stream);
+int sfron_silu_bwd(const float* dy, const float* x, int64_t n, uint16_t* dx_bf16, float* dx_f32, void* stream);
+/* c = t_emb + table[drop ? num_classes : y];  silu_c = bf16(silu(c))   (DiT/models.py:78-94,243; drop may be NULL) */
+int sfron_cond_fwd(const float* t_emb, const float* table, const int64_t* y, const uint8_t* drop, int num_classes, int n,
+                   int D, float* c, uint16_t* silu_c, void* stream);
+/* d_c = d_silu_c * silu'(c); d_table[label] += d_c  (d_table must be zeroed by the caller) */
+int sfron_cond_bwd(const float* d_silu_c, const float* c, const int64_t* y, const uint8_t* drop, int num_classes, int n,
+                   int D, float* d_c, float* d_table, void* stream);
+/* NCHW fp32 image -> bf16 token rows [n*T][C*p*p]; chan_last 0: k = c*p*p + ph*p + pw (Conv2d weight order,
+ * timm PatchEmbed); 1: k = (ph*p + pw)*C + c (unpatchify order, DiT/models.py:218-231) */
+int sfron_patchify(const float* img, int n, int C, int H, int W, int p, int chan_last, uint16_t* rows, int ld, void* stream);
+int sfron_unpatchify(const float* rows, int ld, int n, int C, int H, int W, int p, float* img, void* stream);
+
+/* ------------------------------------------------------------------ attention (attn.hip)
+ * qkv [B*T][3*H*hd] bf16 (column = which*D + head*hd + d), o / d_o [B*T][H*hd] bf16, lse [B][H][T] fp32.
+ * softmax(q k^T * hd^-0.5) v, non-causal (timm Attention as used at DiT/models.py:108,120).
+ * Supported: hd in {64, 72}, T % 64 == 0. */
+int sfron_attn_fwd(const uint16_t* qkv, uint16_t* o, float* lse, int B, int T, int H, int hd, void* stream);
+/* dqkv [B*T][3*H*hd] bf16 = gradient wrt qkv; delta_scratch fp32 [B*H*T] */
+int sfron_attn_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* delta_scratch,
+                   uint16_t* dqkv, int B, int T, int H, int hd, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFRON_H */

@@ -33,7 +33,7 @@ def clip_grad_norm_(grads, max_norm):
     coef = max_norm / (total + 1e-6) clamped to 1.0, g *= coef.  Returns total."""
     params = []
     for g in grads:
-        p = torch.nn.Parameter(torch.empty(0))
+        p = torch.nn.Parameter(torch.empty_like(g))
         p.grad = g
         params.append(p)
     # call the real thing on stand-in Parameters whose .grad are the given tensors

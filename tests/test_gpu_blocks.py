@@ -1,0 +1,136 @@
+"""GPU parity: adaLN elementwise kernels, conditioning/layout kernels and fused attention vs plain torch fp32
+(on the same bf16-rounded inputs), through the C ABI."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def close(a, b, rtol, atol):
+    np.testing.assert_allclose(a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy(), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("B,T,D", [(2, 64, 128), (3, 16, 144), (2, 256, 1152)])
+def test_ln_modulate_fwd_bwd(B, T, D):
+    from sfron import ops
+    gen = torch.Generator().manual_seed(B * T + D)
+    M = B * T
+    x = torch.randn(M, D, generator=gen) * 2 + 0.3
+    mod = torch.randn(B, 6 * D, generator=gen) * 0.5
+    shift, scale = mod[:, 3 * D:4 * D], mod[:, 4 * D:5 * D]
+    xr = x.clone().requires_grad_(True)
+    sh, sc = shift.clone().requires_grad_(True), scale.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (D,), eps=1e-6).view(B, T, D) * (1 + sc.unsqueeze(1)) + sh.unsqueeze(1)
+    dout = (torch.randn(M, D, generator=gen) * 0.1).to(torch.bfloat16)
+    ref.backward(dout.float().view(B, T, D))
+    xd, md = x.to(DEV), mod.to(DEV)
+    out, mean, rstd = ops.ln_modulate_fwd(xd, md[:, 3 * D:], md[:, 4 * D:], 6 * D, T)
+    close(out, ref.view(M, D), 1e-2, 1e-2)
+    dx = torch.full((M, D), 0.5, device=DEV)
+    ps, pc = ops.ln_modulate_bwd(dout.to(DEV), xd, mean, rstd, md[:, 4 * D:], 6 * D, T, dx, accumulate=True)
+    close(dx - 0.5, xr.grad, 1e-3, 2e-5)
+    dmod = torch.zeros(B, 6 * D, device=DEV)
+    per = T // ops.rows_per_chunk(T)
+    ops.reduce_chunks(ps, B, per, D, dmod[:, 3 * D:], 6 * D)
+    ops.reduce_chunks(pc, B, per, D, dmod[:, 4 * D:], 6 * D)
+    close(dmod[:, 3 * D:4 * D], sh.grad, 1e-4, 1e-4)
+    close(dmod[:, 4 * D:5 * D], sc.grad, 1e-4, 2e-4)
+    dx2 = torch.empty(M, D, device=DEV)
+    ops.ln_modulate_bwd(dout.to(DEV), xd, mean, rstd, md[:, 4 * D:], 6 * D, T, dx2, accumulate=False)
+    close(dx2, xr.grad, 1e-3, 2e-5)
+
+
+@pytest.mark.parametrize("B,T,D", [(2, 64, 128), (2, 256, 1152)])
+def test_gate_bwd_and_reductions(B, T, D):
+    from sfron import ops
+    gen = torch.Generator().manual_seed(D)
+    M = B * T
+    dy = torch.randn(M, D, generator=gen) * 0.1
+    br = (torch.randn(M, D, generator=gen)).to(torch.bfloat16)
+    mod = torch.randn(B, 6 * D, generator=gen)
+    gate = mod[:, 2 * D:3 * D]
+    d_branch, p_gate, p_dy = ops.gate_bwd(dy.to(DEV), br.to(DEV), mod.to(DEV)[:, 2 * D:], 6 * D, T)
+    close(d_branch, (dy.view(B, T, D) * gate.unsqueeze(1)).reshape(M, D), 1e-2, 1e-3)
+    per = T // ops.rows_per_chunk(T)
+    dgate = torch.empty(B, D, device=DEV)
+    ops.reduce_chunks(p_gate, B, per, D, dgate, D)
+    close(dgate, (dy * br.float()).view(B, T, D).sum(1), 1e-4, 1e-4)
+    dbias = torch.empty(D, device=DEV)
+    ops.weighted_reduce(p_dy, B, per, D, mod.to(DEV)[:, 2 * D:], 6 * D, dbias)
+    close(dbias, (dy.view(B, T, D) * gate.unsqueeze(1)).sum((0, 1)), 1e-4, 1e-4)
+    # colsum, both dtypes
+    close(ops.colsum(br.to(DEV)), br.float().sum(0), 1e-4, 1e-3)
+    close(ops.colsum(dy.to(DEV)), dy.sum(0), 1e-4, 1e-4)
+
+
+def test_conditioning_and_layout():
+    from sfron import ops
+    from oracle import dit_ref
+    gen = torch.Generator().manual_seed(1)
+    n, D, ncls = 5, 128, 10
+    t = torch.tensor([0, 1, 500, 999, 37])
+    emb = ops.timestep_embed(t.to(DEV), 256)
+    close(emb, dit_ref.TimestepEmbedder.timestep_embedding(t, 256), 1e-2, 1e-2)
+    t_emb = torch.randn(n, D, generator=gen)
+    table = torch.randn(ncls + 1, D, generator=gen)
+    y = torch.tensor([3, 3, 9, 0, 3])
+    drop = torch.tensor([0, 1, 0, 0, 1], dtype=torch.uint8)
+    c, sc = ops.cond_fwd(t_emb.to(DEV), table.to(DEV), y.to(DEV), drop.to(DEV), ncls)
+    lab = torch.where(drop.bool(), ncls, y)
+    c_ref = (t_emb + table[lab])
+    close(c, c_ref, 1e-6, 1e-6)
+    close(sc, F.silu(c_ref), 1e-2, 1e-2)
+    dsc = torch.randn(n, D, generator=gen)
+    cr = c_ref.clone().requires_grad_(True)
+    F.silu(cr).backward(dsc)
+    dtab = torch.zeros(ncls + 1, D, device=DEV)
+    d_c = ops.cond_bwd(dsc.to(DEV), c, y.to(DEV), drop.to(DEV), ncls, dtab)
+    close(d_c, cr.grad, 1e-4, 1e-5)
+    want = torch.zeros(ncls + 1, D).index_add_(0, lab, cr.grad)
+    close(dtab, want, 1e-4, 1e-5)
+    a, b = ops.silu_bwd(dsc.to(DEV), c, True, True)
+    close(b, cr.grad, 1e-4, 1e-5)
+    close(ops.silu_fwd(c), F.silu(c_ref), 1e-2, 1e-2)
+    # patchify == Conv2d(k=s=p) im2col; unpatchify == reference einsum
+    img = torch.randn(2, 4, 8, 8, generator=gen)
+    conv = torch.nn.Conv2d(4, 16, 2, 2)
+    rows = ops.patchify(img.to(DEV), 2).float().cpu()
+    ref = conv(img.to(torch.bfloat16).float()).flatten(2).transpose(1, 2).reshape(-1, 16)
+    close(rows @ conv.weight.view(16, -1).t() + conv.bias, ref, 1e-5, 1e-5)
+    m = dit_ref.DiT(input_size=8, patch_size=2, hidden_size=64, depth=1, num_heads=1, num_classes=2)
+    tok = torch.randn(2, 16, 2 * 2 * 8, generator=gen)
+    close(ops.unpatchify(tok.view(32, 32).to(DEV), 2, 8, 8, 8, 2), m.unpatchify(tok), 0, 0)
+    # chan_last patchify is the exact adjoint layout of unpatchify
+    im8 = torch.randn(2, 8, 8, 8, generator=gen)
+    r2 = ops.patchify(im8.to(DEV), 2, chan_last=True)
+    close(ops.unpatchify(r2.float(), 2, 8, 8, 8, 2), im8.to(torch.bfloat16).float(), 0, 0)
+
+
+@pytest.mark.parametrize("B,T,H,hd", [(2, 64, 2, 64), (1, 128, 3, 72), (2, 256, 2, 72), (1, 256, 4, 64), (1, 192, 1, 64)])
+def test_attention_fwd_bwd(B, T, H, hd):
+    from sfron import ops
+    gen = torch.Generator().manual_seed(T + H + hd)
+    D = H * hd
+    qkv = (torch.randn(B * T, 3 * D, generator=gen) * 1.5).to(torch.bfloat16)
+    qkv[0, :hd] *= 6.0            # a spiky query row: exercises the online-softmax rescale branch
+    qkv[5, D:D + hd] *= 6.0       # and a spiky key
+    d_o = (torch.randn(B * T, D, generator=gen) * 0.2).to(torch.bfloat16)
+    x = qkv.float().requires_grad_(True)
+    q, k, v = x.view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4).unbind(0)
+    att = ((q * hd ** -0.5) @ k.transpose(-2, -1)).softmax(-1)
+    ref = (att @ v).transpose(1, 2).reshape(B * T, D)
+    ref.backward(d_o.float())
+    o, lse = ops.attn_fwd(qkv.to(DEV), B, T, H, hd)
+    close(o, ref, 2e-2, 2e-2)
+    lse_ref = torch.logsumexp((q * hd ** -0.5) @ k.transpose(-2, -1), dim=-1)
+    close(lse, lse_ref, 1e-4, 1e-3)
+    dqkv = ops.attn_bwd(qkv.to(DEV), o, d_o.to(DEV), lse, B, T, H, hd)
+    g = x.grad
+    scale = g.abs().max().item()
+    close(dqkv, g, 5e-2, 2e-2 * scale)
+    # aggregate error must be far below bf16 rounding noise of the reference itself
+    err = (dqkv.float().cpu() - g).norm() / g.norm()
+    assert err < 2e-2, err

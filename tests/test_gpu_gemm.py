@@ -1,0 +1,129 @@
+"""GPU parity: bf16 MFMA GEMM (all three operand layouts + epilogues) vs torch fp32 on the same bf16 inputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rand(shape, gen, scale=1.0):
+    return (torch.randn(shape, generator=gen) * scale).to(torch.bfloat16)
+
+
+def test_fragment_layout_exact_integers():
+    """A = I with an ASYMMETRIC integer B catches swapped row/col maps and wrong transposed-read addressing:
+    all values are small integers, exactly representable, so the result must be bit-exact."""
+    from sfron import ops, _lib
+    M = N = K = 128
+    eye = torch.eye(K, dtype=torch.bfloat16, device=DEV)
+    r = torch.arange(N, dtype=torch.float32).view(N, 1)
+    c = torch.arange(K, dtype=torch.float32).view(1, K)
+    Bm = ((3 * r + 5 * c) % 61 - 30).to(torch.bfloat16).to(DEV)          # [N, K], asymmetric
+    # forward layout: C = A · B^T, A = I  ->  C = B^T
+    C = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(eye, Bm, M, N, K, epilogue=_lib.EPI_F32, c_f32=C)
+    assert torch.equal(C, Bm.float().t())
+    # dgrad layout: C = A · B (B stored [K][N]), A = I -> C = B
+    ops.gemm(eye, Bm, M, N, K, b_t=True, epilogue=_lib.EPI_F32, c_f32=C)
+    assert torch.equal(C, Bm.float())
+    # wgrad layout: C = A^T · B with A stored [K][M]; A = asymmetric, B = I -> C = A^T
+    ops.gemm(Bm, eye, M, N, K, a_t=True, b_t=True, epilogue=_lib.EPI_F32, c_f32=C)
+    assert torch.equal(C, Bm.float().t())
+    # wgrad with A = I, B asymmetric -> C = B
+    ops.gemm(eye, Bm, M, N, K, a_t=True, b_t=True, epilogue=_lib.EPI_F32, c_f32=C)
+    assert torch.equal(C, Bm.float())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (96, 160, 72), (32, 6912, 1152), (8192, 32, 1152),
+                                   (1024, 1152, 1152)])
+def test_forward_layout(M, N, K):
+    from sfron import ops, _lib
+    gen = torch.Generator().manual_seed(M + N + K)
+    A, B = _rand((M, K), gen), _rand((N, K), gen, 0.05)
+    bias = torch.randn(N, generator=gen)
+    want = A.float() @ B.float().t() + bias
+    Cb = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(A.to(DEV), B.to(DEV), M, N, K, bias=bias.to(DEV), c_bf16=Cb)
+    np.testing.assert_allclose(Cb.float().cpu().numpy(), want.numpy(), rtol=1e-2, atol=2e-2)
+    Cf = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(A.to(DEV), B.to(DEV), M, N, K, bias=bias.to(DEV), epilogue=_lib.EPI_F32, c_f32=Cf)
+    np.testing.assert_allclose(Cf.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4 * K ** 0.5)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (512, 1152, 3456), (96, 72, 32), (8192, 1152, 32)])
+def test_dgrad_layout(M, N, K):
+    """dX[M, N] = dY[M, K] · W[K, N]  (contraction K = forward out-features; W row-major [K][N])."""
+    from sfron import ops, _lib
+    gen = torch.Generator().manual_seed(M * 3 + N + K)
+    dY, W = _rand((M, K), gen), _rand((K, N), gen, 0.05)
+    want = dY.float() @ W.float()
+    Cf = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(dY.to(DEV), W.to(DEV), M, N, K, b_t=True, epilogue=_lib.EPI_F32, c_f32=Cf)
+    np.testing.assert_allclose(Cf.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4 * K ** 0.5)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 256), (1152, 1152, 2048), (3456, 1152, 512), (6912, 1152, 32), (32, 1152, 1024),
+                                   (72, 64, 40)])
+def test_wgrad_layout(M, N, K):
+    """dW[M, N] = dY[K, M]^T · X[K, N]  (contraction K = token rows)."""
+    from sfron import ops, _lib
+    gen = torch.Generator().manual_seed(M * 7 + N + K)
+    dY, X = _rand((K, M), gen, 0.1), _rand((K, N), gen)
+    want = dY.float().t() @ X.float()
+    Cf = torch.full((M, N), 7.0, dtype=torch.float32, device=DEV)
+    ops.gemm(dY.to(DEV), X.to(DEV), M, N, K, a_t=True, b_t=True, epilogue=_lib.EPI_F32, c_f32=Cf)
+    np.testing.assert_allclose(Cf.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4 * K ** 0.5)
+    ops.gemm(dY.to(DEV), X.to(DEV), M, N, K, a_t=True, b_t=True, epilogue=_lib.EPI_F32, c_f32=Cf, accumulate=True)
+    np.testing.assert_allclose(Cf.cpu().numpy(), 2 * want.numpy(), rtol=4e-4, atol=4e-4 * K ** 0.5)
+
+
+def test_epilogues():
+    from sfron import ops, _lib
+    gen = torch.Generator().manual_seed(5)
+    Bsz, T, D, Hd = 3, 64, 128, 256
+    M = Bsz * T
+    X, W1, W2 = _rand((M, D), gen), _rand((Hd, D), gen, 0.08), _rand((D, Hd), gen, 0.08)
+    b1, b2 = torch.randn(Hd, generator=gen) * 0.1, torch.randn(D, generator=gen) * 0.1
+    # GELU: aux = pre-activation, c = gelu_tanh
+    h_pre = X.float() @ W1.float().t() + b1
+    aux = torch.empty(M, Hd, dtype=torch.bfloat16, device=DEV)
+    H = torch.empty(M, Hd, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(X.to(DEV), W1.to(DEV), M, Hd, D, epilogue=_lib.EPI_GELU, bias=b1.to(DEV), c_bf16=H, aux=aux)
+    np.testing.assert_allclose(aux.float().cpu().numpy(), h_pre.numpy(), rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(H.float().cpu().numpy(), torch.nn.functional.gelu(h_pre, approximate="tanh").numpy(),
+                               rtol=1e-2, atol=1e-2)
+    # gated residual: x += gate[b] * (H W2^T + b2), aux = branch output
+    Hh = H.cpu()
+    gate = torch.randn(Bsz, 6 * D, generator=gen)
+    x0 = torch.randn(M, D, generator=gen)
+    branch = Hh.float() @ W2.float().t() + b2
+    want_x = x0 + gate[:, 2 * D:3 * D].repeat_interleave(T, dim=0) * branch
+    xd = x0.to(DEV)
+    a2 = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    gd = gate.to(DEV)
+    ops.gemm(H, W2.to(DEV), M, D, Hd, epilogue=_lib.EPI_GATE_RES, bias=b2.to(DEV), c_f32=xd, aux=a2,
+             gate=gd[:, 2 * D:], ldgate=6 * D, tokens=T)
+    np.testing.assert_allclose(xd.cpu().numpy(), want_x.numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(a2.float().cpu().numpy(), branch.numpy(), rtol=1e-2, atol=1e-2)
+    # dGELU: d_hpre = (dA W2) * gelu'(h_pre)
+    dA = _rand((M, D), gen, 0.1)
+    hp = aux.cpu().float().requires_grad_(True)
+    torch.nn.functional.gelu(hp, approximate="tanh").backward(dA.float() @ W2.float())
+    dH = torch.empty(M, Hd, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(dA.to(DEV), W2.to(DEV), M, Hd, D, b_t=True, epilogue=_lib.EPI_DGELU, c_bf16=dH, aux=aux)
+    np.testing.assert_allclose(dH.float().cpu().numpy(), hp.grad.numpy(), rtol=1e-2, atol=2e-3)
+    # POS: x = patches W^T + b + pos[row % T]
+    pos = torch.randn(T, D, generator=gen)
+    P, Wp = _rand((M, 64), gen), _rand((D, 64), gen, 0.1)
+    xo = torch.empty(M, D, dtype=torch.float32, device=DEV)
+    ops.gemm(P.to(DEV), Wp.to(DEV), M, D, 64, epilogue=_lib.EPI_POS, bias=b2.to(DEV), c_f32=xo, pos=pos.to(DEV), tokens=T)
+    want = P.float() @ Wp.float().t() + b2 + pos.repeat(Bsz, 1)
+    np.testing.assert_allclose(xo.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-3)
+
+
+def test_gemm_rejects_bad_args():
+    from sfron import ops, _lib
+    A = torch.zeros(128, 60, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(_lib.SfronError):
+        ops.gemm(A, A, 128, 128, 60, c_bf16=torch.zeros(128, 128, dtype=torch.bfloat16, device=DEV))   # K % 8 != 0

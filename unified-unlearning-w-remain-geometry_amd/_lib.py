@@ -1,0 +1,107 @@
+"""ctypes binding of libsfron.so (see include/sfron.h).  Fails loudly: no fallback path."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsfron.so")
+
+
+class SfronError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_P = c_void_p     # device pointer
+_S = c_void_p     # hipStream_t
+
+_PROTOS = {
+    "sfron_abi_version": (c_int, []),
+    "sfron_build_arch": (c_char_p, []),
+    "sfron_sweep_partials_len": (c_int, []),
+    "sfron_sumsq_masked": (c_int, [_P, _P, c_int64, _P, POINTER(c_int), _S]),
+    "sfron_clip_coef": (c_int, [_P, c_int, c_float, _P, _S]),
+    "sfron_masked_clip_adam": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_double,
+                                       c_double, _P, _P, c_double, c_int, _S]),
+    "sfron_ema_update": (c_int, [_P, _P, c_int64, c_double, c_int, _S]),
+    "sfron_fisher_accum": (c_int, [_P, _P, c_int64, c_float, _S]),
+    "sfron_mask_from_fisher": (c_int, [_P, _P, c_int64, c_float, _P, _S]),
+    "sfron_cast_bf16": (c_int, [_P, _P, c_int64, _S]),
+    "sfron_q_sample": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _S]),
+    "sfron_dit_loss_fwd_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _S]),
+}
+
+
+class GemmDesc(ctypes.Structure):
+    """Mirror of sfron_gemm_desc (include/sfron.h)."""
+    _fields_ = [("A", c_void_p), ("B", c_void_p),
+                ("M", c_int), ("N", c_int), ("K", c_int), ("lda", c_int), ("ldb", c_int),
+                ("a_transposed", c_int), ("b_transposed", c_int), ("epilogue", c_int), ("alpha", c_float),
+                ("bias", c_void_p), ("c_bf16", c_void_p), ("ldc_bf16", c_int), ("c_f32", c_void_p), ("ldc_f32", c_int),
+                ("aux", c_void_p), ("ldaux", c_int), ("gate", c_void_p), ("ldgate", c_int), ("pos", c_void_p),
+                ("tokens", c_int), ("accumulate", c_int), ("resid", c_void_p), ("split_k", c_int),
+                ("split_stride", ctypes.c_long)]
+
+
+EPI_BF16, EPI_F32, EPI_GELU, EPI_GATE_RES, EPI_DGELU, EPI_POS = range(6)
+
+_PROTOS["sfron_gemm_bf16"] = (c_int, [POINTER(GemmDesc), _S])
+_PROTOS.update({
+    "sfron_rows_per_chunk": (c_int, [c_int]),
+    "sfron_ln_modulate_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _S]),
+    "sfron_ln_modulate_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _S]),
+    "sfron_gate_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _S]),
+    "sfron_reduce_chunks": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, _S]),
+    "sfron_weighted_reduce": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, _S]),
+    "sfron_colsum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, _S]),
+    "sfron_timestep_embed": (c_int, [_P, c_int, c_int, _P, c_int, _S]),
+    "sfron_silu_fwd": (c_int, [_P, c_int64, _P, _S]),
+    "sfron_silu_bwd": (c_int, [_P, _P, c_int64, _P, _P, _S]),
+    "sfron_cond_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _S]),
+    "sfron_cond_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _S]),
+    "sfron_patchify": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _S]),
+    "sfron_unpatchify": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _S]),
+    "sfron_attn_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _S]),
+    "sfron_attn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _S]),
+})
+
+
+def declared_symbols():
+    return sorted(_PROTOS)
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise SfronError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise SfronError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             f"(make -C {os.path.join(_HERE, 'csrc')}). There is no fallback path.")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(h, name)      # AttributeError if the symbol is missing: loud by design
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise SfronError(f"{what} failed with status {status}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL).  Tensors must be contiguous and on the GPU."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SfronError("sfron ops need GPU tensors (no CPU fallback)")
+    if not t.is_contiguous():
+        raise SfronError("sfron ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,62 @@
+// Shared device helpers for the SFR-on HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SFRON_OK 0
+#define SFRON_ERR_ARG 1001      // bad argument (shape / alignment / null pointer)
+#define SFRON_ERR_UNSUPPORTED 1002
+
+#define SFRON_CHECK_ARG(cond) do { if (!(cond)) return SFRON_ERR_ARG; } while (0)
+#define SFRON_LAUNCH_STATUS() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef unsigned short bf16_raw;
+
+static constexpr int WAVE = 64;
+
+__device__ __forceinline__ float bf2f(__bf16 x) { return (float)x; }
+__device__ __forceinline__ __bf16 f2bf(float x) { return (__bf16)x; }   // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// tanh-approximate GELU exactly as torch.nn.GELU(approximate="tanh") computes it in fp32:
+//   0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))
+__device__ __forceinline__ float gelu_tanh(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_tanh_grad(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float x2 = x * x;
+  float u = k0 * (x + k1 * x * x2);
+  float t = tanhf(u);
+  float du = k0 * (1.0f + 3.0f * k1 * x2);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+}
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_grad(float x) {
+  float s = 1.0f / (1.0f + __expf(-x));
+  return s * (1.0f + x * (1.0f - s));
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,168 @@
+// Small conditioning / layout kernels of the DiT denoiser (negligible FLOPs, HBM / latency bound).
+//
+// Replaces the PyTorch op sequences of /root/reference/DiT/models.py:
+//   TimestepEmbedder.timestep_embedding .... :41-59 (cos || sin, freqs = exp(-ln(1e4) * i / half))
+//   nn.SiLU inside t_embedder / adaLN ...... :34,114,132
+//   LabelEmbedder (+ token_drop) ........... :78-94  (the drop mask is an explicit input)
+//   c = t + y ............................... :243
+//   PatchEmbed's im2col (Conv2d k = s = p) . :169,240 (timm PatchEmbed: flatten(2).transpose(1,2))
+//   unpatchify .............................. :218-231 ('nhwpqc->nchpwq')
+#include "common.h"
+#include "../../include/sfron.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+__global__ __launch_bounds__(TPB) void k_timestep_embed(const int64_t* __restrict__ t, int n, int dim, __bf16* __restrict__ out,
+                                                        int ld) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= n * half) return;
+  const int b = i / half, j = i % half;
+  const float freq = expf(-9.210340371976184f * (float)j / (float)half);    // -log(10000) * j / half, fp32 like torch
+  const float arg = (float)t[b] * freq;
+  out[(size_t)b * ld + j] = f2bf(cosf(arg));
+  out[(size_t)b * ld + half + j] = f2bf(sinf(arg));
+}
+
+// y = silu(x): writes bf16 (GEMM operand) and optionally keeps nothing else; x fp32 [n]
+__global__ __launch_bounds__(TPB) void k_silu_fwd(const float* __restrict__ x, int64_t n, __bf16* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) y[i] = f2bf(silu(x[i]));
+}
+// dx = dy * silu'(x);  dy fp32, out bf16 (next GEMM operand) and/or fp32
+__global__ __launch_bounds__(TPB) void k_silu_bwd(const float* __restrict__ dy, const float* __restrict__ x, int64_t n,
+                                                  __bf16* __restrict__ dx_bf16, float* __restrict__ dx_f32) {
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    const float g = dy[i] * silu_grad(x[i]);
+    if (dx_bf16) dx_bf16[i] = f2bf(g);
+    if (dx_f32) dx_f32[i] = g;
+  }
+}
+
+// c[b] = t_emb[b] + table[drop[b] ? num_classes : y[b]];  silu_c = bf16(silu(c))
+__global__ __launch_bounds__(TPB) void k_cond_fwd(const float* __restrict__ t_emb, const float* __restrict__ table,
+                                                  const int64_t* __restrict__ y, const uint8_t* __restrict__ drop,
+                                                  int num_classes, int D, float* __restrict__ c, __bf16* __restrict__ silu_c) {
+  const int b = blockIdx.y;
+  const int col = blockIdx.x * TPB + threadIdx.x;
+  if (col >= D) return;
+  const int64_t lab = (drop && drop[b]) ? num_classes : y[b];
+  const float v = t_emb[(size_t)b * D + col] + table[(size_t)lab * D + col];
+  c[(size_t)b * D + col] = v;
+  silu_c[(size_t)b * D + col] = f2bf(silu(v));
+}
+
+// d_c = d_silu_c * silu'(c); d_table[label] += d_c (serial over the batch per column: deterministic);
+// d_c is also the gradient of t_emb.
+__global__ __launch_bounds__(TPB) void k_cond_bwd(const float* __restrict__ d_silu_c, const float* __restrict__ c,
+                                                  const int64_t* __restrict__ y, const uint8_t* __restrict__ drop,
+                                                  int num_classes, int n, int D, float* __restrict__ d_c,
+                                                  float* __restrict__ d_table) {
+  const int col = blockIdx.x * TPB + threadIdx.x;
+  if (col >= D) return;
+  for (int b = 0; b < n; ++b) {
+    const float g = d_silu_c[(size_t)b * D + col] * silu_grad(c[(size_t)b * D + col]);
+    d_c[(size_t)b * D + col] = g;
+    const int64_t lab = (drop && drop[b]) ? num_classes : y[b];
+    d_table[(size_t)lab * D + col] += g;
+  }
+}
+
+// image [n][C][H][W] fp32 -> token rows [n*T][C*p*p] bf16.
+// chan_last = 0: column k = c*p*p + ph*p + pw   (Conv2d weight.view(D, -1) order, input patchify)
+// chan_last = 1: column k = (ph*p + pw)*C + c   (unpatchify's 'nhwpqc' order, used for d_out -> d_tokens)
+__global__ __launch_bounds__(TPB) void k_patchify(const float* __restrict__ img, int n, int C, int H, int W, int p,
+                                                  int chan_last, __bf16* __restrict__ rows, int ld) {
+  const int gw = W / p, gh = H / p, T = gw * gh, K = C * p * p;
+  const int64_t total = (int64_t)n * T * K;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
+    const int k = (int)(i % K);
+    const int64_t r = i / K;
+    const int tok = (int)(r % T), b = (int)(r / T);
+    const int th = tok / gw, tw = tok % gw;
+    int c, ph, pw;
+    if (chan_last) { c = k % C; const int pq = k / C; ph = pq / p; pw = pq % p; }
+    else { c = k / (p * p); const int pq = k % (p * p); ph = pq / p; pw = pq % p; }
+    rows[(size_t)r * ld + k] = f2bf(img[(((size_t)b * C + c) * H + th * p + ph) * W + tw * p + pw]);
+  }
+}
+
+// token rows [n*T][p*p*C] fp32 (chan_last order) -> image [n][C][H][W] fp32
+__global__ __launch_bounds__(TPB) void k_unpatchify(const float* __restrict__ rows, int ld, int n, int C, int H, int W, int p,
+                                                    float* __restrict__ img) {
+  const int gw = W / p, gh = H / p, T = gw * gh;
+  const int64_t total = (int64_t)n * C * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
+    const int w = (int)(i % W), h = (int)((i / W) % H), c = (int)((i / ((int64_t)W * H)) % C), b = (int)(i / ((int64_t)W * H * C));
+    const int th = h / p, ph = h % p, tw = w / p, pw = w % p;
+    img[i] = rows[((size_t)b * T + th * gw + tw) * ld + (ph * p + pw) * C + c];
+  }
+}
+
+inline int grid_for(int64_t n) {
+  int64_t b = (n + TPB - 1) / TPB;
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+int sfron_timestep_embed(const int64_t* t, int n, int dim, uint16_t* out, int ld, void* stream) {
+  SFRON_CHECK_ARG(t && out && n > 0 && dim > 0 && dim % 2 == 0 && ld >= dim);
+  hipLaunchKernelGGL(k_timestep_embed, dim3(cdiv((long)n * (dim / 2), TPB)), dim3(TPB), 0, (hipStream_t)stream, t, n, dim,
+                     (__bf16*)out, ld);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_silu_fwd(const float* x, int64_t n, uint16_t* y_bf16, void* stream) {
+  SFRON_CHECK_ARG(x && y_bf16 && n > 0);
+  hipLaunchKernelGGL(k_silu_fwd, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, x, n, (__bf16*)y_bf16);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_silu_bwd(const float* dy, const float* x, int64_t n, uint16_t* dx_bf16, float* dx_f32, void* stream) {
+  SFRON_CHECK_ARG(dy && x && n > 0 && (dx_bf16 || dx_f32));
+  hipLaunchKernelGGL(k_silu_bwd, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, dy, x, n, (__bf16*)dx_bf16, dx_f32);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_cond_fwd(const float* t_emb, const float* table, const int64_t* y, const uint8_t* drop, int num_classes, int n,
+                   int D, float* c, uint16_t* silu_c, void* stream) {
+  SFRON_CHECK_ARG(t_emb && table && y && c && silu_c && n > 0 && D > 0 && num_classes > 0);
+  hipLaunchKernelGGL(k_cond_fwd, dim3(cdiv(D, TPB), n), dim3(TPB), 0, (hipStream_t)stream, t_emb, table, y, drop, num_classes,
+                     D, c, (__bf16*)silu_c);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_cond_bwd(const float* d_silu_c, const float* c, const int64_t* y, const uint8_t* drop, int num_classes, int n,
+                   int D, float* d_c, float* d_table, void* stream) {
+  SFRON_CHECK_ARG(d_silu_c && c && y && d_c && d_table && n > 0 && D > 0);
+  hipLaunchKernelGGL(k_cond_bwd, dim3(cdiv(D, TPB)), dim3(TPB), 0, (hipStream_t)stream, d_silu_c, c, y, drop, num_classes, n,
+                     D, d_c, d_table);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_patchify(const float* img, int n, int C, int H, int W, int p, int chan_last, uint16_t* rows, int ld, void* stream) {
+  SFRON_CHECK_ARG(img && rows && n > 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0 && ld >= C * p * p);
+  hipLaunchKernelGGL(k_patchify, dim3(grid_for((int64_t)n * C * H * W)), dim3(TPB), 0, (hipStream_t)stream, img, n, C, H, W, p,
+                     chan_last, (__bf16*)rows, ld);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_unpatchify(const float* rows, int ld, int n, int C, int H, int W, int p, float* img, void* stream) {
+  SFRON_CHECK_ARG(img && rows && n > 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0 && ld >= C * p * p);
+  hipLaunchKernelGGL(k_unpatchify, dim3(grid_for((int64_t)n * C * H * W)), dim3(TPB), 0, (hipStream_t)stream, rows, ld, n, C, H,
+                     W, p, img);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,314 @@
+// bf16 MFMA GEMM for the DiT token GEMMs (forward, dgrad, wgrad) with fused epilogues.
+//
+// Replaces the cuBLAS calls behind nn.Linear / Conv2d(k=s=p) forward and backward on the
+// reference hot path (DiT/models.py:108-121,138-142,169 via timm Attention/Mlp/PatchEmbed):
+//   forward  Y[M,N]  = X[M,K]  · W[N,K]^T      A direct, B direct
+//   dgrad    dX[M,K] = dY[M,N] · W[N,K]        A direct, B transposed-read (contraction = rows of W)
+//   wgrad    dW[N,K] = dY[M,N]^T · X[M,K]      A and B transposed-read (contraction = token rows)
+// "transposed-read" operands stay row-major in HBM and in LDS; the MFMA fragment is gathered
+// with ds_read_b64_tr_b16, so no transposed copies of weights or activations exist anywhere.
+//
+// Tile 128x128x64, 4 waves (2x2), each wave 4x4 MFMA 16x16x32 bf16 tiles, fp32 accumulate.
+// The MFMA is issued as D^T = B^T·A^T so each lane ends up with 4 CONSECUTIVE output columns
+// (8-byte bf16 / 16-byte fp32 stores).  LDS: double-buffered, XOR-swizzled so that both the
+// ds_read_b128 row fragments and the transposed reads are bank-conflict free.
+#include "common.h"
+#include "../../include/sfron.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int NT = 256;
+constexpr int TILE_ELEMS = 128 * 64;   // both image kinds hold 8192 bf16 = 16 KiB
+
+enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_GATE_RES = 3, EPI_DGELU = 4, EPI_POS = 5 };
+
+struct GemmArgs {
+  const __bf16* A; const __bf16* B;
+  int M, N, K;              // output M x N, contraction K
+  int lda, ldb;
+  __bf16* Cb; int ldcb;     // bf16 output
+  float* Cf; int ldcf;      // fp32 output / residual stream (EPI_GATE_RES)
+  const float* bias;        // [N] fp32 or null
+  __bf16* aux; int ldaux;   // EPI_GELU: pre-activation out; EPI_GATE_RES: branch out; EPI_DGELU: pre-activation in
+  const float* gate; int ldgate;   // EPI_GATE_RES: gate[(row / T) * ldgate + col]
+  const float* pos;         // EPI_POS: pos[(row % T) * N + col]
+  int T;
+  float alpha;
+  int accumulate;           // EPI_F32: Cf += result
+  const float* resid;       // EPI_GATE_RES: Cf = resid + gate * result (resid may alias Cf)
+  int kchunk;               // split-K: contraction range per split (multiple of BK); K if no split
+  long split_stride;        // split-K: fp32 slab stride (elements) between splits
+  int ntm, ntn;
+};
+
+// ---- LDS images -------------------------------------------------------------------------------
+// direct image: [128 rows][64 k], 128-B rows, 16-B chunk c of row r stored at chunk c ^ (r & 7)
+__device__ __forceinline__ int off_direct(int row, int ch) { return row * 64 + ((ch ^ (row & 7)) << 3); }
+// transposed-read image: [64 k-rows][128 cols], 256-B rows, chunk c of row r at c ^ (((r&3)<<2)|((r>>2)&3))
+__device__ __forceinline__ int swz_tr(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+__device__ __forceinline__ int off_tr(int krow, int ch) { return krow * 128 + ((ch ^ swz_tr(krow)) << 3); }
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ bf16x8 frag_direct(const __bf16* img, int row, int kchunk) {
+  return *reinterpret_cast<const bf16x8*>(img + off_direct(row, kchunk));
+}
+// fragment for 16 consecutive columns starting at col0 (multiple of 16), k rows kr0 + 8*(lane>>4) + 0..7
+__device__ __forceinline__ bf16x8 frag_tr(const __bf16* img, int col0, int kr0, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const int ch = (col0 >> 3) + (p >> 1);
+  const int r0 = kr0 + 8 * g + q;
+  const __bf16* a0 = img + off_tr(r0, ch) + 4 * (p & 1);
+  const __bf16* a1 = img + off_tr(r0 + 4, ch) + 4 * (p & 1);
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a1);
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+// ---- global -> register staging --------------------------------------------------------------
+// direct operand: rows = output index (clamped), k contiguous
+template <bool TR>
+struct Stager {
+  const __bf16* base[4];
+  bool valid[4];           // static validity (column range for TR; always true for direct)
+  int kidx[4];             // direct: k offset of the chunk inside the tile; TR: k-row inside the tile
+  int lds_off[4];
+  int ld;
+  __device__ __forceinline__ void init(const __bf16* P, int ld_, int dim, int d0, int tid) {
+    ld = ld_;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + NT * i;
+      if (!TR) {
+        const int row = c >> 3, ch = c & 7;
+        int gr = d0 + row;
+        gr = gr < dim ? gr : dim - 1;
+        base[i] = P + (size_t)gr * ld + ch * 8;
+        kidx[i] = ch * 8;
+        valid[i] = true;
+        lds_off[i] = off_direct(row, ch);
+      } else {
+        const int krow = c >> 4, ch = c & 15;
+        const int col = d0 + ch * 8;
+        valid[i] = col < dim;
+        base[i] = P + (size_t)krow * ld + (valid[i] ? col : 0);
+        kidx[i] = krow;
+        lds_off[i] = off_tr(krow, ch);
+      }
+    }
+  }
+  __device__ __forceinline__ void load(uint4 (&r)[4], int k0, int K) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = valid[i] && (k0 + kidx[i] < K);
+      const __bf16* p = TR ? base[i] + (size_t)k0 * ld : base[i] + k0;
+      r[i] = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  __device__ __forceinline__ void store(__bf16* img, const uint4 (&r)[4]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(img + lds_off[i]) = r[i];
+  }
+};
+
+template <bool A_TR, bool B_TR, int EPI>
+__global__ __launch_bounds__(NT) void k_gemm(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+  __bf16* sA = smem;                       // [2][TILE_ELEMS]
+  __bf16* sB = smem + 2 * TILE_ELEMS;      // [2][TILE_ELEMS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (speed only); give each XCD a contiguous
+  // run of tiles so neighbouring tiles (same A row-panel) hit the same L2.
+  const int nblk = gridDim.x;
+  int id;
+  {
+    const int b = blockIdx.x, q = nblk >> 3, r = nblk & 7, x = b & 7, y = b >> 3;
+    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+  }
+  const int ntiles = g.ntm * g.ntn;
+  const int split = id / ntiles;
+  id -= split * ntiles;
+  const int tm = id / g.ntn, tn = id % g.ntn;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = split * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  if (EPI == EPI_F32) g.Cf += (size_t)split * g.split_stride;
+
+  Stager<A_TR> stA;
+  Stager<B_TR> stB;
+  stA.init(g.A, g.lda, g.M, m0, tid);
+  stB.init(g.B, g.ldb, g.N, n0, tid);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  uint4 ra[4], rb[4];
+  stA.load(ra, kbeg, kend);
+  stB.load(rb, kbeg, kend);
+  stA.store(sA, ra);
+  stB.store(sB, rb);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) {
+      stA.load(ra, kbeg + (kt + 1) * BK, kend);
+      stB.load(rb, kbeg + (kt + 1) * BK, kend);
+    }
+    const __bf16* iA = sA + cur * TILE_ELEMS;
+    const __bf16* iB = sB + cur * TILE_ELEMS;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        if (!A_TR) fa[mt] = frag_direct(iA, wm * 64 + mt * 16 + (lane & 15), ks * 4 + (lane >> 4));
+        else       fa[mt] = frag_tr(iA, wm * 64 + mt * 16, ks * 32, lane);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        if (!B_TR) fb[nt] = frag_direct(iB, wn * 64 + nt * 16 + (lane & 15), ks * 4 + (lane >> 4));
+        else       fb[nt] = frag_tr(iB, wn * 64 + nt * 16, ks * 32, lane);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+    }
+    if (more) {
+      stA.store(sA + (cur ^ 1) * TILE_ELEMS, ra);
+      stB.store(sB + (cur ^ 1) * TILE_ELEMS, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds C[m = mt*16 + (lane&15)][n = nt*16 + 4*(lane>>4) + 0..3]
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int row = m0 + wm * 64 + mt * 16 + (lane & 15);
+    if (row >= g.M) continue;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int col = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
+      if (col >= g.N) continue;
+      f32x4 v = acc[mt][nt] * g.alpha;
+      if (g.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(g.bias + col);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      if (EPI == EPI_BF16) {
+        bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *reinterpret_cast<bf16x4*>(g.Cb + (size_t)row * g.ldcb + col) = o;
+      } else if (EPI == EPI_F32) {
+        float4* dst = reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col);
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (g.accumulate) { const float4 c = *dst; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+        *dst = o;
+      } else if (EPI == EPI_GELU) {
+        bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col) = h;
+        bf16x4 o = {f2bf(gelu_tanh(v[0])), f2bf(gelu_tanh(v[1])), f2bf(gelu_tanh(v[2])), f2bf(gelu_tanh(v[3]))};
+        *reinterpret_cast<bf16x4*>(g.Cb + (size_t)row * g.ldcb + col) = o;
+      } else if (EPI == EPI_GATE_RES) {
+        bf16x4 a = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col) = a;
+        const float4 gt = *reinterpret_cast<const float4*>(g.gate + (size_t)(row / g.T) * g.ldgate + col);
+        float4* xp = reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col);
+        float4 x = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldcf + col);
+        x.x += gt.x * v[0]; x.y += gt.y * v[1]; x.z += gt.z * v[2]; x.w += gt.w * v[3];
+        *xp = x;
+      } else if (EPI == EPI_DGELU) {
+        const bf16x4 h = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)row * g.ldaux + col);
+        bf16x4 o = {f2bf(v[0] * gelu_tanh_grad(bf2f(h[0]))), f2bf(v[1] * gelu_tanh_grad(bf2f(h[1]))),
+                    f2bf(v[2] * gelu_tanh_grad(bf2f(h[2]))), f2bf(v[3] * gelu_tanh_grad(bf2f(h[3])))};
+        *reinterpret_cast<bf16x4*>(g.Cb + (size_t)row * g.ldcb + col) = o;
+      } else if (EPI == EPI_POS) {
+        const float4 pe = *reinterpret_cast<const float4*>(g.pos + (size_t)(row % g.T) * g.N + col);
+        *reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col) =
+            make_float4(v[0] + pe.x, v[1] + pe.y, v[2] + pe.z, v[3] + pe.w);
+      }
+    }
+  }
+}
+
+template <bool A_TR, bool B_TR, int EPI>
+int launch(const GemmArgs& g, hipStream_t s) {
+  const size_t lds = 4 * TILE_ELEMS * sizeof(__bf16);
+  const int splits = (g.K + g.kchunk - 1) / g.kchunk;
+  hipLaunchKernelGGL((k_gemm<A_TR, B_TR, EPI>), dim3(g.ntm * g.ntn * splits), dim3(NT), lds, s, g);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SFRON_OK : (int)e;
+}
+
+template <int EPI>
+int dispatch_layout(int a_tr, int b_tr, const GemmArgs& g, hipStream_t s) {
+  if (!a_tr && !b_tr) return launch<false, false, EPI>(g, s);
+  if (!a_tr && b_tr) return launch<false, true, EPI>(g, s);
+  if (a_tr && b_tr) return launch<true, true, EPI>(g, s);
+  return SFRON_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
+  SFRON_CHECK_ARG(d && d->A && d->B && d->M > 0 && d->N > 0 && d->K > 0);
+  SFRON_CHECK_ARG(d->K % 8 == 0 && d->N % 4 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0);
+  SFRON_CHECK_ARG((((uintptr_t)d->A | (uintptr_t)d->B) & 15) == 0);
+  if (d->a_transposed) SFRON_CHECK_ARG(d->M % 8 == 0);
+  if (d->b_transposed) SFRON_CHECK_ARG(d->N % 8 == 0);
+  GemmArgs g{};
+  g.A = (const __bf16*)d->A; g.B = (const __bf16*)d->B;
+  g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb;
+  g.Cb = (__bf16*)d->c_bf16; g.ldcb = d->ldc_bf16;
+  g.Cf = d->c_f32; g.ldcf = d->ldc_f32;
+  g.bias = d->bias;
+  g.aux = (__bf16*)d->aux; g.ldaux = d->ldaux;
+  g.gate = d->gate; g.ldgate = d->ldgate;
+  g.pos = d->pos; g.T = d->tokens > 0 ? d->tokens : 1;
+  g.alpha = d->alpha; g.accumulate = d->accumulate;
+  g.resid = d->resid ? d->resid : d->c_f32;
+  g.kchunk = d->K; g.split_stride = 0;
+  if (d->split_k > 1) {
+    SFRON_CHECK_ARG(d->epilogue == SFRON_EPI_F32 && !d->bias && !d->accumulate && d->split_stride >= (long)d->M * d->ldc_f32);
+    g.kchunk = cdiv(cdiv(d->K, d->split_k), BK) * BK;
+    g.split_stride = d->split_stride;
+  }
+  g.ntm = cdiv(d->M, BM); g.ntn = cdiv(d->N, BN);
+  hipStream_t s = (hipStream_t)stream;
+  switch (d->epilogue) {
+    case SFRON_EPI_BF16:
+      SFRON_CHECK_ARG(g.Cb && g.ldcb % 4 == 0);
+      return dispatch_layout<EPI_BF16>(d->a_transposed, d->b_transposed, g, s);
+    case SFRON_EPI_F32:
+      SFRON_CHECK_ARG(g.Cf && g.ldcf % 4 == 0);
+      return dispatch_layout<EPI_F32>(d->a_transposed, d->b_transposed, g, s);
+    case SFRON_EPI_GELU:
+      SFRON_CHECK_ARG(g.Cb && g.aux && g.ldcb % 4 == 0 && g.ldaux % 4 == 0 && !d->a_transposed && !d->b_transposed);
+      return launch<false, false, EPI_GELU>(g, s);
+    case SFRON_EPI_GATE_RES:
+      SFRON_CHECK_ARG(g.Cf && g.aux && g.gate && g.ldcf % 4 == 0 && g.ldaux % 4 == 0 && g.ldgate % 4 == 0 &&
+                      !d->a_transposed && !d->b_transposed);
+      return launch<false, false, EPI_GATE_RES>(g, s);
+    case SFRON_EPI_DGELU:
+      SFRON_CHECK_ARG(g.Cb && g.aux && g.ldcb % 4 == 0 && g.ldaux % 4 == 0 && !d->a_transposed && d->b_transposed);
+      return launch<false, true, EPI_DGELU>(g, s);
+    case SFRON_EPI_POS:
+      SFRON_CHECK_ARG(g.Cf && g.pos && g.ldcf % 4 == 0 && !d->a_transposed && !d->b_transposed);
+      return launch<false, false, EPI_POS>(g, s);
+    default:
+      return SFRON_ERR_UNSUPPORTED;
+  }
+}

@@ -1,0 +1,151 @@
+// Diffusion loss of the DiT path: q_sample, and the fused (mse + vb) forward + backward.
+//
+// Replaces the PyTorch op sequences of /root/reference/DiT/diffusion:
+//   q_sample ............. gaussian_diffusion.py:215-230 (tables gathered as fp32: :861-873)
+//   training_losses ...... gaussian_diffusion.py:746-783 (MSE loss, EPSILON mean, LEARNED_RANGE var)
+//   _vb_terms_bpd ........ gaussian_diffusion.py:682-713 with p_mean_variance :285-293,317-332,
+//                          q_posterior_mean_variance :232-252, _predict_xstart_from_eps :334-339
+//   normal_kl / cdf / nll  diffusion_utils.py:10-44,62-88
+// One pass reads (x0, noise, model_output) and writes per-sample mse / vb plus
+// dOut = d( grad_scale * sum_i loss_i ) / d model_output -- so the denoiser backward starts
+// from dOut with no autograd graph on the loss.  eps_hat is detached inside vb (reference
+// :758), so eps channels get only the mse gradient and var channels only the vb gradient.
+//
+// tab: [T][8] fp32 = sqrt_ac, sqrt_1m_ac, sqrt_recip_ac, sqrt_recipm1_ac, post_coef1, post_coef2,
+//      post_logvar_clipped, log_beta   (each = the fp64 table value rounded once to fp32).
+#include "common.h"
+#include "../../include/sfron.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+__global__ __launch_bounds__(TPB) void k_q_sample(const float* __restrict__ x0, const float* __restrict__ noise,
+                                                  const int64_t* __restrict__ t, const float* __restrict__ tab,
+                                                  int chw, float* __restrict__ xt) {
+  const int n = blockIdx.y;
+  const float* row = tab + (size_t)t[n] * 8;
+  const float a = row[0], b = row[1];
+  const size_t base = (size_t)n * chw;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < chw; i += gridDim.x * TPB)
+    xt[base + i] = a * x0[base + i] + b * noise[base + i];
+}
+
+__device__ __forceinline__ float cdf_approx(float x, float& dcdf) {
+  // 0.5*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3))) and its derivative
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float x2 = x * x;
+  float u = k0 * (x + k1 * x2 * x);
+  float th = tanhf(u);
+  dcdf = 0.5f * (1.0f - th * th) * k0 * (1.0f + 3.0f * k1 * x2);
+  return 0.5f * (1.0f + th);
+}
+
+// one workgroup per sample
+__global__ __launch_bounds__(TPB) void k_dit_loss(const float* __restrict__ x0, const float* __restrict__ noise,
+                                                  const float* __restrict__ out, const int64_t* __restrict__ t,
+                                                  const float* __restrict__ tab, int C, int hw, float grad_scale,
+                                                  float* __restrict__ mse_out, float* __restrict__ vb_out,
+                                                  float* __restrict__ dout) {
+  __shared__ double sh[2][TPB / 64];
+  const int n = blockIdx.x;
+  const int64_t tn = t[n];
+  const float* row = tab + (size_t)tn * 8;
+  const float sa = row[0], s1 = row[1], sra = row[2], srm1 = row[3], c1 = row[4], c2 = row[5];
+  const float min_log = row[6], max_log = row[7];
+  const int chw = C * hw;
+  const float inv_chw = 1.0f / (float)chw;
+  const float inv_ln2 = 1.4426950408889634f;
+  const size_t xb = (size_t)n * chw;
+  const size_t ob = (size_t)n * 2 * chw;
+  float acc_mse = 0.f, acc_vb = 0.f;
+  for (int i = threadIdx.x; i < chw; i += TPB) {
+    const float x = x0[xb + i], e = noise[xb + i];
+    const float eh = out[ob + i], vv = out[ob + chw + i];
+    const float xt = sa * x + s1 * e;
+    // ---- mse term
+    const float d = e - eh;
+    acc_mse += d * d;
+    const float g_eps = 2.0f * (eh - e) * inv_chw * grad_scale;
+    // ---- vb term
+    const float frac = (vv + 1.0f) / 2.0f;
+    const float lv = frac * max_log + (1.0f - frac) * min_log;
+    const float pred_x0 = sra * xt - srm1 * eh;
+    const float mu_t = c1 * pred_x0 + c2 * xt;      // model mean
+    const float mu_q = c1 * x + c2 * xt;            // true posterior mean
+    float term, dterm_dlv;
+    if (tn == 0) {
+      const float cx = x - mu_t;
+      const float inv_std = expf(-0.5f * lv);
+      const float plus_in = inv_std * (cx + 1.0f / 255.0f);
+      const float min_in = inv_std * (cx - 1.0f / 255.0f);
+      float dplus, dmin;
+      const float cdf_plus = cdf_approx(plus_in, dplus);
+      const float cdf_min = cdf_approx(min_in, dmin);
+      // d plus_in / d lv = -0.5 * plus_in
+      const float dp = dplus * (-0.5f * plus_in), dm = dmin * (-0.5f * min_in);
+      float logp, dlogp;
+      if (x < -0.999f) {
+        const float a = fmaxf(cdf_plus, 1e-12f);
+        logp = logf(a);
+        dlogp = (cdf_plus >= 1e-12f) ? dp / a : 0.f;
+      } else if (x > 0.999f) {
+        const float q = 1.0f - cdf_min;
+        const float a = fmaxf(q, 1e-12f);
+        logp = logf(a);
+        dlogp = (q >= 1e-12f) ? -dm / a : 0.f;
+      } else {
+        const float q = cdf_plus - cdf_min;
+        const float a = fmaxf(q, 1e-12f);
+        logp = logf(a);
+        dlogp = (q >= 1e-12f) ? (dp - dm) / a : 0.f;
+      }
+      term = -logp;
+      dterm_dlv = -dlogp;
+    } else {
+      const float dmu = mu_q - mu_t;
+      const float e1 = expf(min_log - lv), e2 = expf(-lv);
+      term = 0.5f * (-1.0f + lv - min_log + e1 + dmu * dmu * e2);
+      dterm_dlv = 0.5f * (1.0f - e1 - dmu * dmu * e2);
+    }
+    acc_vb += term;
+    const float g_var = dterm_dlv * (0.5f * (max_log - min_log)) * inv_chw * inv_ln2 * grad_scale;
+    dout[ob + i] = g_eps;
+    dout[ob + chw + i] = g_var;
+  }
+  double a = wave_sum_d((double)acc_mse), b = wave_sum_d((double)acc_vb);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ta = 0, tb = 0;
+    for (int i = 0; i < TPB / 64; ++i) { ta += sh[0][i]; tb += sh[1][i]; }
+    mse_out[n] = (float)(ta / chw);
+    vb_out[n] = (float)(tb / chw * 1.4426950408889634);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sfron_q_sample(const float* x0, const float* noise, const int64_t* t, const float* tab, int n, int chw, float* x_t,
+                   void* stream) {
+  SFRON_CHECK_ARG(x0 && noise && t && tab && x_t && n > 0 && chw > 0);
+  int gx = cdiv(chw, TPB);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(k_q_sample, dim3(gx, n), dim3(TPB), 0, (hipStream_t)stream, x0, noise, t, tab, chw, x_t);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_dit_loss_fwd_bwd(const float* x0, const float* noise, const float* model_out, const int64_t* t,
+                           const float* tab, int n, int c, int hw, float grad_scale, float* mse, float* vb,
+                           float* d_model_out, void* stream) {
+  SFRON_CHECK_ARG(x0 && noise && model_out && t && tab && mse && vb && d_model_out && n > 0 && c > 0 && hw > 0);
+  hipLaunchKernelGGL(k_dit_loss, dim3(n), dim3(TPB), 0, (hipStream_t)stream, x0, noise, model_out, t, tab, c, hw,
+                     grad_scale, mse, vb, d_model_out);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+}  // extern "C"

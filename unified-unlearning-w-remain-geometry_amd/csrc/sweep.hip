@@ -1,0 +1,252 @@
+// Parameter-side sweep of one SFR-on stage over flat fp32 arenas (HBM-bound kernels).
+//
+// Replaces the per-tensor PyTorch op sequences of the reference:
+//   mask ⊙ grad ............ DiT/forget.py:289-292, DDPM/runners/diffusion.py:1126-1129
+//   clip_grad_norm_ ........ DiT/forget.py:293-298, DDPM/runners/diffusion.py:1131-1136,1169-1174
+//   Adam / AdamW .step() ... DiT/forget.py:199,299,320, DDPM/functions/__init__.py:9-18
+//   update_ema / EMAHelper . DiT/forget.py:52-62, DDPM/models/ema.py:17-24
+//   Fisher, saliency mask .. DiT/generate_fisher.py:236-239, DiT/generate_mask.py:34-35
+//
+// Layout: every parameter tensor of the model lives at a fixed offset of ONE flat fp32 arena;
+// grad / exp_avg / exp_avg_sq / ema / byte-mask / bf16-shadow arenas share the same offsets, so a
+// stage is two streaming launches (norm pre-pass, fused update) instead of ~10 per tensor.
+// Arithmetic follows torch's single-tensor Adam: m = lerp(m, g, 1-b1); v = v*b2 + (1-b2)*g*g;
+// p += -step_size * m / (sqrt(v)/bc2_sqrt + eps).  A masked-out element takes g = 0 (it is NOT
+// skipped: momentum still moves it -- SURVEY.md section 9 Q7).
+#include "common.h"
+#include "../../include/sfron.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int MAX_GRID = 2048;
+
+__global__ __launch_bounds__(TPB) void k_sumsq_masked(const float* __restrict__ g, const uint8_t* __restrict__ mask,
+                                                       int64_t n, double* __restrict__ partials) {
+  __shared__ double sh[TPB / 64];
+  const int64_t n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  const uchar4* m4 = reinterpret_cast<const uchar4*>(mask);
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
+    float4 x = g4[i];
+    if (mask) {
+      uchar4 mk = m4[i];
+      x.x = mk.x ? x.x : 0.f; x.y = mk.y ? x.y : 0.f; x.z = mk.z ? x.z : 0.f; x.w = mk.w ? x.w : 0.f;
+    }
+    acc += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    int64_t i = (n4 << 2) + threadIdx.x;
+    float x = g[i];
+    if (mask && !mask[i]) x = 0.f;
+    acc += x * x;
+  }
+  double d = wave_sum_d((double)acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < TPB / 64; ++i) t += sh[i];
+    partials[blockIdx.x] = t;
+  }
+}
+
+// stats[0] = total L2 norm, stats[1] = clip coefficient min(1, max_norm/(norm+1e-6)), stats[2] = sum of squares
+__global__ __launch_bounds__(TPB) void k_clip_coef(const double* __restrict__ partials, int nblk, float max_norm,
+                                                   float* __restrict__ stats) {
+  __shared__ double sh[TPB / 64];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += TPB) acc += partials[i];
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < TPB / 64; ++i) t += sh[i];
+    float norm = (float)sqrt(t);
+    float coef = max_norm / (norm + 1e-6f);          // torch: clip_coef = max_norm / (total_norm + 1e-6)
+    coef = coef > 1.0f ? 1.0f : coef;                // torch.clamp(clip_coef, max=1.0)
+    stats[0] = norm; stats[1] = coef; stats[2] = (float)t;
+  }
+}
+
+struct AdamArgs {
+  float w1, beta2, w2, eps, step_size, bc2_sqrt, decay_mul;   // w1 = float(1-beta1), w2 = float(1-beta2) (from double, like torch)
+  float ema_decay, ema_w;   // ema_w = float(1 - ema_decay)
+  int ema_mode;      // 0 none, 1 DiT form ema*d + (1-d)*p, 2 DDPM form (1-mu)*p + mu*shadow (ema_decay = mu)
+};
+
+__device__ __forceinline__ float adam_one(float p, float g, float& m, float& v, const AdamArgs& a) {
+  p = p * a.decay_mul;
+  m = m + a.w1 * (g - m);                                   // exp_avg.lerp_(grad, 1-beta1), weight < 0.5 branch
+  v = v * a.beta2 + (a.w2 * g) * g;                         // exp_avg_sq.mul_(b2).addcmul_(g, g, value=1-b2)
+  float denom = sqrtf(v) / a.bc2_sqrt + a.eps;              // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+  return p + (-a.step_size * m) / denom;                    // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+__device__ __forceinline__ float ema_one(float e, float p, const AdamArgs& a) {
+  if (a.ema_mode == 1) return e * a.ema_decay + a.ema_w * p;
+  return a.ema_w * p + a.ema_decay * e;
+}
+
+__global__ __launch_bounds__(TPB) void k_masked_clip_adam(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v,
+                                                          const uint8_t* __restrict__ mask, const float* __restrict__ stats,
+                                                          int64_t n, AdamArgs a, uint16_t* __restrict__ wbf,
+                                                          float* __restrict__ ema) {
+  const float coef = stats ? stats[1] : 1.0f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    if (mask) {
+      uchar4 mk = reinterpret_cast<const uchar4*>(mask)[i];
+      gg.x = mk.x ? gg.x : 0.f; gg.y = mk.y ? gg.y : 0.f; gg.z = mk.z ? gg.z : 0.f; gg.w = mk.w ? gg.w : 0.f;
+    }
+    gg.x *= coef; gg.y *= coef; gg.z *= coef; gg.w *= coef;
+    pp.x = adam_one(pp.x, gg.x, mm.x, vv.x, a);
+    pp.y = adam_one(pp.y, gg.y, mm.y, vv.y, a);
+    pp.z = adam_one(pp.z, gg.z, mm.z, vv.z, a);
+    pp.w = adam_one(pp.w, gg.w, mm.w, vv.w, a);
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+    if (wbf) {
+      bf16x4 b = {f2bf(pp.x), f2bf(pp.y), f2bf(pp.z), f2bf(pp.w)};
+      reinterpret_cast<bf16x4*>(wbf)[i] = b;
+    }
+    if (a.ema_mode) {
+      float4 ee = reinterpret_cast<float4*>(ema)[i];
+      ee.x = ema_one(ee.x, pp.x, a); ee.y = ema_one(ee.y, pp.y, a);
+      ee.z = ema_one(ee.z, pp.z, a); ee.w = ema_one(ee.w, pp.w, a);
+      reinterpret_cast<float4*>(ema)[i] = ee;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    int64_t i = (n4 << 2) + threadIdx.x;
+    float gg = g[i];
+    if (mask && !mask[i]) gg = 0.f;
+    gg *= coef;
+    float mm = m[i], vv = v[i];
+    float pp = adam_one(p[i], gg, mm, vv, a);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+    if (wbf) reinterpret_cast<__bf16*>(wbf)[i] = f2bf(pp);
+    if (a.ema_mode) ema[i] = ema_one(ema[i], pp, a);
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_ema(float* __restrict__ ema, const float* __restrict__ p, int64_t n, AdamArgs a) {
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB)
+    ema[i] = ema_one(ema[i], p[i], a);
+}
+
+__global__ __launch_bounds__(TPB) void k_fisher_accum(float* __restrict__ F, const float* __restrict__ g, int64_t n, float n_iters) {
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    float x = g[i];
+    F[i] = F[i] + (x * x) / n_iters;             // forget_gradients[name] += (grad**2) / n_iters
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_mask_from_fisher(const float* __restrict__ ff, const float* __restrict__ rf,
+                                                          int64_t n, float th, uint8_t* __restrict__ mask) {
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    // IEEE fp32 add / divide / compare, no fast-math: bit-exact with torch ((F_f+1e-15)/(F_r+1e-15)) >= th
+    float a = __fadd_rn(ff[i], 1e-15f);
+    float b = __fadd_rn(rf[i], 1e-15f);
+    float q = __fdiv_rn(a, b);
+    mask[i] = (q >= th) ? 1 : 0;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_cast_bf16(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
+    float4 x = reinterpret_cast<const float4*>(src)[i];
+    bf16x4 b = {f2bf(x.x), f2bf(x.y), f2bf(x.z), f2bf(x.w)};
+    reinterpret_cast<bf16x4*>(dst)[i] = b;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    int64_t i = (n4 << 2) + threadIdx.x;
+    reinterpret_cast<__bf16*>(dst)[i] = f2bf(src[i]);
+  }
+}
+
+inline int grid_for(int64_t n_items) {
+  int64_t b = (n_items + TPB - 1) / TPB;
+  if (b < 1) b = 1;
+  return (int)(b > MAX_GRID ? MAX_GRID : b);
+}
+
+}  // namespace
+
+extern "C" {
+
+int sfron_sweep_partials_len(void) { return MAX_GRID; }
+
+int sfron_sumsq_masked(const float* g, const uint8_t* mask, int64_t n, double* partials, int* nblk_out, void* stream) {
+  SFRON_CHECK_ARG(g && partials && nblk_out && n >= 0);
+  SFRON_CHECK_ARG(((uintptr_t)g & 15) == 0 && (!mask || ((uintptr_t)mask & 3) == 0));
+  int grid = grid_for(n >> 2);
+  *nblk_out = grid;
+  hipLaunchKernelGGL(k_sumsq_masked, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, g, mask, n, partials);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_clip_coef(const double* partials, int nblk, float max_norm, float* stats, void* stream) {
+  SFRON_CHECK_ARG(partials && stats && nblk > 0);
+  hipLaunchKernelGGL(k_clip_coef, dim3(1), dim3(TPB), 0, (hipStream_t)stream, partials, nblk, max_norm, stats);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_masked_clip_adam(float* p, const float* g, float* m, float* v, const uint8_t* mask, const float* stats,
+                           int64_t n, double beta1, double beta2, double eps, double step_size, double bc2_sqrt,
+                           double decay_mul, uint16_t* w_bf16, float* ema, double ema_decay, int ema_mode, void* stream) {
+  SFRON_CHECK_ARG(p && g && m && v && n >= 0);
+  SFRON_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+  SFRON_CHECK_ARG(!mask || ((uintptr_t)mask & 3) == 0);
+  SFRON_CHECK_ARG(!w_bf16 || ((uintptr_t)w_bf16 & 7) == 0);
+  SFRON_CHECK_ARG(ema_mode == 0 || (ema && ((uintptr_t)ema & 15) == 0 && (ema_mode == 1 || ema_mode == 2)));
+  AdamArgs a{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)step_size, (float)bc2_sqrt,
+             (float)decay_mul, (float)ema_decay, (float)(1.0 - ema_decay), ema_mode};
+  hipLaunchKernelGGL(k_masked_clip_adam, dim3(grid_for(n >> 2)), dim3(TPB), 0, (hipStream_t)stream,
+                     p, g, m, v, mask, stats, n, a, w_bf16, ema);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_ema_update(float* ema, const float* p, int64_t n, double decay, int ema_mode, void* stream) {
+  SFRON_CHECK_ARG(ema && p && n >= 0 && (ema_mode == 1 || ema_mode == 2));
+  AdamArgs a{0, 0, 0, 0, 0, 1, 1, (float)decay, (float)(1.0 - decay), ema_mode};
+  hipLaunchKernelGGL(k_ema, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, ema, p, n, a);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_fisher_accum(float* fisher, const float* g, int64_t n, float n_iters, void* stream) {
+  SFRON_CHECK_ARG(fisher && g && n >= 0 && n_iters > 0);
+  hipLaunchKernelGGL(k_fisher_accum, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, fisher, g, n, n_iters);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_mask_from_fisher(const float* forget_fisher, const float* remain_fisher, int64_t n, float th, uint8_t* mask,
+                           void* stream) {
+  SFRON_CHECK_ARG(forget_fisher && remain_fisher && mask && n >= 0);
+  hipLaunchKernelGGL(k_mask_from_fisher, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, forget_fisher,
+                     remain_fisher, n, th, mask);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_cast_bf16(const float* src, uint16_t* dst, int64_t n, void* stream) {
+  SFRON_CHECK_ARG(src && dst && n >= 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0);
+  hipLaunchKernelGGL(k_cast_bf16, dim3(grid_for(n >> 2)), dim3(TPB), 0, (hipStream_t)stream, src, dst, n);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+"""Host side of the parameter sweep (csrc/sweep.hip): mask -> clip -> Adam(W) -> EMA on flat arenas.
+
+Mirrors what the reference does per tensor in DiT/forget.py:289-299,320,322 and
+DDPM/runners/diffusion.py:1126-1138,1169-1180, as two streaming launches per stage.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+
+class FlatAdam:
+    """Adam/AdamW state over one flat fp32 parameter arena, stepped by the HIP sweep kernel.
+
+    One optimizer, several ``step()`` per iteration on shared state (DiT/forget.py:199,299,320):
+    ``step_count`` advances once per call, exactly like torch.optim's per-parameter ``step``.
+    """
+
+    def __init__(self, params, grads, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adamw=True,
+                 mask=None, w_bf16=None):
+        assert params.dtype == torch.float32 and params.dim() == 1 and params.is_cuda
+        assert grads.shape == params.shape
+        if weight_decay != 0.0 and not adamw:
+            raise NotImplementedError("coupled (L2) weight decay is not used by the reference configs (wd=0)")
+        self.p, self.g = params, grads
+        self.m = torch.zeros_like(params)
+        self.v = torch.zeros_like(params)
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.mask = mask            # uint8/bool [n] or None, device resident (loaded once, not per step)
+        self.w_bf16 = w_bf16        # bf16 [n] shadow or None
+        self.step_count = 0
+        L = _lib.lib()
+        self._partials = torch.empty(L.sfron_sweep_partials_len(), dtype=torch.float64, device=params.device)
+        self.stats = torch.zeros(4, dtype=torch.float32, device=params.device)
+
+    def grad_norm_clip_coef(self, max_norm, use_mask):
+        """Launch the norm pre-pass; leaves (norm, coef, sumsq) in self.stats on device (no host sync)."""
+        L = _lib.lib()
+        n = self.p.numel()
+        nblk = ctypes.c_int(0)
+        mask = self.mask if use_mask else None
+        s = stream_ptr()
+        check(L.sfron_sumsq_masked(ptr(self.g), ptr(mask), n, ptr(self._partials), ctypes.byref(nblk), s), "sumsq_masked")
+        check(L.sfron_clip_coef(ptr(self._partials), nblk.value, float(max_norm), ptr(self.stats), s), "clip_coef")
+
+    def step(self, max_norm=None, use_mask=False, ema=None, ema_decay=0.0, ema_mode=0):
+        """One optimizer step on the current grads.  max_norm=None -> no clipping (DiT remain stage)."""
+        L = _lib.lib()
+        if use_mask and self.mask is None:
+            use_mask = False
+        if max_norm is not None:
+            self.grad_norm_clip_coef(max_norm, use_mask)
+        self.step_count += 1
+        b1, b2 = self.betas
+        bc1 = 1 - b1 ** self.step_count
+        bc2 = 1 - b2 ** self.step_count
+        step_size = self.lr / bc1
+        bc2_sqrt = math.sqrt(bc2)
+        decay_mul = 1.0 - self.lr * self.wd
+        check(L.sfron_masked_clip_adam(ptr(self.p), ptr(self.g), ptr(self.m), ptr(self.v),
+                                       ptr(self.mask if use_mask else None),
+                                       ptr(self.stats if max_norm is not None else None),
+                                       self.p.numel(), b1, b2, self.eps, step_size, bc2_sqrt, decay_mul,
+                                       ptr(self.w_bf16), ptr(ema), float(ema_decay), int(ema_mode if ema is not None else 0),
+                                       stream_ptr()), "masked_clip_adam")
+
+
+def ema_update(ema, p, decay, mode=1):
+    check(_lib.lib().sfron_ema_update(ptr(ema), ptr(p), p.numel(), float(decay), int(mode), stream_ptr()), "ema_update")
+
+
+def fisher_accum(fisher, g, n_iters):
+    check(_lib.lib().sfron_fisher_accum(ptr(fisher), ptr(g), g.numel(), float(n_iters), stream_ptr()), "fisher_accum")
+
+
+def mask_from_fisher(forget_fisher, remain_fisher, th):
+    """((F_f + 1e-15) / (F_r + 1e-15)) >= th as a torch.bool tensor (DiT/generate_mask.py:34-35)."""
+    ff = forget_fisher.contiguous().view(-1)
+    rf = remain_fisher.contiguous().view(-1)
+    out = torch.empty(ff.numel(), dtype=torch.uint8, device=ff.device)
+    check(_lib.lib().sfron_mask_from_fisher(ptr(ff), ptr(rf), ff.numel(), float(th), ptr(out), stream_ptr()),
+          "mask_from_fisher")
+    return out.view(forget_fisher.shape).to(torch.bool)
+
+
+def cast_bf16(src, dst=None):
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    check(_lib.lib().sfron_cast_bf16(ptr(src), ptr(dst), src.numel(), stream_ptr()), "cast_bf16")
+    return dst
