@@ -178,6 +178,39 @@ int sfron_attn_fwd(const uint16_t* qkv, uint16_t* o, float* lse, int B, int T, i
 int sfron_attn_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* delta_scratch,
                    uint16_t* dqkv, int B, int T, int H, int hd, void* stream);
 
+/* ------------------------------------------------------------------ whole-model DiT pass (dit_engine.hip)
+ * Replaces autograd over DiT.forward (DiT/models.py:233-248) inside the SFR-on step (DiT/forget.py:271-288,310-319).
+ * Parameters live in ONE arena (fp32 master, bf16 shadow and fp32 grads share offsets); sfron_dit_param_layout
+ * reports the offsets so the host can expose every tensor under its reference state_dict key. */
+typedef struct sfron_dit_cfg {
+  int batch;          /* per-GPU batch */
+  int in_channels;    /* 4 */
+  int input_size;     /* latent side, 32 for 256 px */
+  int patch;          /* 2 / 4 / 8 */
+  int hidden;         /* D */
+  int depth;          /* L */
+  int heads;          /* H; head_dim = D / H must be 64 or 72 */
+  int mlp_hidden;     /* 4 D */
+  int num_classes;    /* table has num_classes + 1 rows (CFG null class) */
+  int freq_dim;       /* 256 */
+  int out_channels;   /* 8 with learn_sigma */
+} sfron_dit_cfg;
+
+/* out[SFRON_DIT_LAYOUT_LEN] (element offsets into the arena): total, trainable, pe_w, pe_b, t0_w, t0_b, t2_w, t2_b,
+ * table, ada_w, ada_b, blocks, blk_stride, then offsets inside a block: qkv_w, qkv_b, proj_w, proj_b, fc1_w, fc1_b,
+ * fc2_w, fc2_b, then fin_w, fin_b, pos.  ada_w is [(6*depth+2)*D][D]: block l rows [6lD, 6(l+1)D), final layer last. */
+#define SFRON_DIT_LAYOUT_LEN 24
+int sfron_dit_param_layout(const sfron_dit_cfg* cfg, int64_t* out, int n_out);
+int64_t sfron_dit_workspace_bytes(const sfron_dit_cfg* cfg);   /* < 0 on unsupported cfg */
+
+/* out [B][out_channels][S][S] fp32 = DiT(x_t, t, y); drop [B] uint8 (1 = replace label by the null class) or NULL.
+ * Saves activations in `workspace` for sfron_dit_backward. */
+int sfron_dit_forward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
+                      const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out, void* stream);
+/* grads (arena layout, trainable part fully overwritten) = d loss / d params given d_out = d loss / d out */
+int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* d_out,
+                       const int64_t* y, const uint8_t* drop, void* workspace, float* grads, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

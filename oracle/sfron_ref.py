@@ -93,7 +93,7 @@ class DiTSfronOracle:
             for name, p in m.named_parameters():
                 self.ema[name].mul_(self.ema_decay).add_(p.data, alpha=1 - self.ema_decay)
         return {"forget_loss": ori_forget.item(), "remain_loss": ori_remain.item(),
-                "forget_mse": float(terms_f["mse"].mean()), "remain_mse": float(terms_r["mse"].mean()),
+                "forget_mse": terms_f["mse"].mean().item(), "remain_mse": terms_r["mse"].mean().item(),
                 "forget_gnorm": float(gnorm)}
 
 

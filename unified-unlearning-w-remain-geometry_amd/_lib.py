@@ -67,6 +67,21 @@ _PROTOS.update({
 })
 
 
+class DitCfg(ctypes.Structure):
+    """Mirror of sfron_dit_cfg (include/sfron.h)."""
+    _fields_ = [(n, c_int) for n in ("batch", "in_channels", "input_size", "patch", "hidden", "depth", "heads",
+                                     "mlp_hidden", "num_classes", "freq_dim", "out_channels")]
+
+
+DIT_LAYOUT_LEN = 24
+_PROTOS.update({
+    "sfron_dit_param_layout": (c_int, [POINTER(DitCfg), POINTER(c_int64), c_int]),
+    "sfron_dit_workspace_bytes": (c_int64, [POINTER(DitCfg)]),
+    "sfron_dit_forward": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _S]),
+    "sfron_dit_backward": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _S]),
+})
+
+
 def declared_symbols():
     return sorted(_PROTOS)
 

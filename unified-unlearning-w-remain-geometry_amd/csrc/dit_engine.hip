@@ -1,0 +1,357 @@
+// Whole-model DiT forward / backward: the launch sequence over the kernels of this library.
+//
+// Replaces autograd over /root/reference/DiT/models.py:233-248 (DiT.forward) for the training step of
+// DiT/forget.py:271-288,310-319.  One call enqueues the whole pass on a stream; nothing is allocated
+// here (the caller owns the parameter arenas and one workspace), so the sequence is graph-capturable.
+//
+// Parameter arena (fp32 master + bf16 shadow + grads share offsets), canonical order:
+//   patch-embed W,b | t_embedder W0,b0,W2,b2 | label table | adaLN weights of ALL blocks + final layer
+//   contiguous [(6L+2)D][D] | their biases [(6L+2)D] | per block: qkv W,b, proj W,b, fc1 W,b, fc2 W,b |
+//   final linear W,b | (frozen) pos_embed.
+// The adaLN weights are contiguous so that the modulation of every block is ONE GEMM
+// [B,D]x[D,(6L+2)D]: c = t_emb + y_emb is the same for all blocks (models.py:243-246).
+#include "common.h"
+#include "../../include/sfron.h"
+
+namespace {
+
+struct Dims {
+  int B, C, S, p, D, L, H, hd, F, ncls, fdim, Co;   // F = mlp hidden, Co = out channels
+  int g, T, M, Kp, Po, NM;                          // g = S/p, T tokens, M = B*T, Kp = C*p*p, Po = p*p*Co, NM = (6L+2)*D
+};
+
+inline int make_dims(const sfron_dit_cfg* c, Dims& d) {
+  if (!c) return SFRON_ERR_ARG;
+  d.B = c->batch; d.C = c->in_channels; d.S = c->input_size; d.p = c->patch; d.D = c->hidden; d.L = c->depth;
+  d.H = c->heads; d.F = c->mlp_hidden; d.ncls = c->num_classes; d.fdim = c->freq_dim; d.Co = c->out_channels;
+  if (d.B <= 0 || d.C <= 0 || d.S <= 0 || d.p <= 0 || d.D <= 0 || d.L <= 0 || d.H <= 0 || d.F <= 0 || d.ncls <= 0) return SFRON_ERR_ARG;
+  if (d.S % d.p || d.D % d.H || d.D % 8 || d.F % 8 || d.fdim % 8) return SFRON_ERR_ARG;
+  d.hd = d.D / d.H; d.g = d.S / d.p; d.T = d.g * d.g; d.M = d.B * d.T; d.Kp = d.C * d.p * d.p; d.Po = d.p * d.p * d.Co;
+  d.NM = (6 * d.L + 2) * d.D;
+  if (d.Kp % 8 || d.Po % 8 || d.T % 64) return SFRON_ERR_UNSUPPORTED;
+  if (d.hd != 64 && d.hd != 72) return SFRON_ERR_UNSUPPORTED;
+  return SFRON_OK;
+}
+
+// ---- parameter layout ---------------------------------------------------------------------------
+struct ParamLayout {
+  int64_t pe_w, pe_b, t0_w, t0_b, t2_w, t2_b, table, ada_w, ada_b, blocks, blk_stride, fin_w, fin_b, pos, total, trainable;
+  int64_t o_qkv_w, o_qkv_b, o_proj_w, o_proj_b, o_fc1_w, o_fc1_b, o_fc2_w, o_fc2_b;   // offsets inside a block
+};
+inline ParamLayout make_layout(const Dims& d) {
+  ParamLayout p{};
+  int64_t o = 0;
+  auto take = [&](int64_t n) { int64_t r = o; o += (n + 7) / 8 * 8; return r; };
+  p.pe_w = take((int64_t)d.D * d.Kp); p.pe_b = take(d.D);
+  p.t0_w = take((int64_t)d.D * d.fdim); p.t0_b = take(d.D);
+  p.t2_w = take((int64_t)d.D * d.D); p.t2_b = take(d.D);
+  p.table = take((int64_t)(d.ncls + 1) * d.D);
+  p.ada_w = take((int64_t)d.NM * d.D); p.ada_b = take(d.NM);
+  p.blocks = o;
+  int64_t b0 = o;
+  p.o_qkv_w = take((int64_t)3 * d.D * d.D) - b0; p.o_qkv_b = take(3 * d.D) - b0;
+  p.o_proj_w = take((int64_t)d.D * d.D) - b0; p.o_proj_b = take(d.D) - b0;
+  p.o_fc1_w = take((int64_t)d.F * d.D) - b0; p.o_fc1_b = take(d.F) - b0;
+  p.o_fc2_w = take((int64_t)d.D * d.F) - b0; p.o_fc2_b = take(d.D) - b0;
+  p.blk_stride = o - b0;
+  o = b0 + p.blk_stride * d.L;
+  p.fin_w = take((int64_t)d.Po * d.D); p.fin_b = take(d.Po);
+  p.trainable = o;
+  p.pos = take((int64_t)d.T * d.D);
+  p.total = o;
+  return p;
+}
+
+// ---- workspace layout ---------------------------------------------------------------------------
+struct Workspace {
+  // saved by forward, read by backward
+  __bf16 *patches, *tfreq, *h1s, *sc;
+  float *h1, *temb, *c, *mod;
+  float* xs;                 // [2L+1][M][D] residual stream checkpoints
+  __bf16 *xmod1, *qkv, *o, *a1, *xmod2, *hpre, *h, *a2;   // per block, stride below
+  float *mean, *rstd;        // [2L+1][M]
+  float* lse;                // [L][B*H*T]
+  __bf16* xmodf;
+  float* tok;
+  // backward temporaries
+  float *dx, *dmod, *d_sc, *d_c, *d_h1s, *delta, *part, *csum, *slabs;
+  __bf16 *d_tok, *d_br, *d_hpre, *d_xmod, *d_o, *dqkv, *dmod_bf, *d_c_bf, *d_h1_bf, *dx_bf;
+  size_t bytes;
+};
+constexpr int SPLIT_K_ADA = 64;
+constexpr int CSUM_PARTS = 64;
+
+inline Workspace make_ws(const Dims& d, char* base) {
+  Workspace w{};
+  size_t o = 0;
+  auto take = [&](size_t bytes) { char* r = base ? base + o : nullptr; o += (bytes + 255) / 256 * 256; return r; };
+  const size_t M = d.M, D = d.D, L = d.L, B = d.B;
+  w.patches = (__bf16*)take(M * d.Kp * 2);
+  w.tfreq = (__bf16*)take(B * d.fdim * 2);
+  w.h1 = (float*)take(B * D * 4); w.h1s = (__bf16*)take(B * D * 2);
+  w.temb = (float*)take(B * D * 4); w.c = (float*)take(B * D * 4); w.sc = (__bf16*)take(B * D * 2);
+  w.mod = (float*)take(B * (size_t)d.NM * 4);
+  w.xs = (float*)take((2 * L + 1) * M * D * 4);
+  w.xmod1 = (__bf16*)take(L * M * D * 2); w.qkv = (__bf16*)take(L * M * 3 * D * 2); w.o = (__bf16*)take(L * M * D * 2);
+  w.a1 = (__bf16*)take(L * M * D * 2); w.xmod2 = (__bf16*)take(L * M * D * 2);
+  w.hpre = (__bf16*)take(L * M * (size_t)d.F * 2); w.h = (__bf16*)take(L * M * (size_t)d.F * 2);
+  w.a2 = (__bf16*)take(L * M * D * 2);
+  w.mean = (float*)take((2 * L + 1) * M * 4); w.rstd = (float*)take((2 * L + 1) * M * 4);
+  w.lse = (float*)take(L * B * (size_t)d.H * d.T * 4);
+  w.xmodf = (__bf16*)take(M * D * 2);
+  w.tok = (float*)take(M * (size_t)d.Po * 4);
+  // backward
+  w.dx = (float*)take(M * D * 4);
+  w.dmod = (float*)take(B * (size_t)d.NM * 4); w.dmod_bf = (__bf16*)take(B * (size_t)d.NM * 2);
+  w.d_sc = (float*)take(B * D * 4); w.d_c = (float*)take(B * D * 4); w.d_c_bf = (__bf16*)take(B * D * 2);
+  w.d_h1s = (float*)take(B * D * 4); w.d_h1_bf = (__bf16*)take(B * D * 2);
+  w.delta = (float*)take(B * (size_t)d.H * d.T * 4);
+  w.part = (float*)take(4 * (M / 4) * D * 4);                       // 4 partial buffers, worst case 4 rows per chunk
+  const size_t widest = (size_t)(d.F > 3 * d.D ? d.F : 3 * d.D) > (size_t)d.NM ? (size_t)(d.F > 3 * d.D ? d.F : 3 * d.D) : (size_t)d.NM;
+  w.csum = (float*)take(CSUM_PARTS * widest * 4);
+  w.slabs = (float*)take((size_t)SPLIT_K_ADA * B * D * 4);
+  w.d_tok = (__bf16*)take(M * (size_t)d.Po * 2);
+  w.d_br = (__bf16*)take(M * D * 2); w.d_hpre = (__bf16*)take(M * (size_t)d.F * 2); w.d_xmod = (__bf16*)take(M * D * 2);
+  w.d_o = (__bf16*)take(M * D * 2); w.dqkv = (__bf16*)take(M * 3 * D * 2); w.dx_bf = (__bf16*)take(M * D * 2);
+  w.bytes = o;
+  return w;
+}
+
+#define RUN(expr) do { int rc__ = (expr); if (rc__ != SFRON_OK) return rc__; } while (0)
+
+inline sfron_gemm_desc gd(const void* A, int lda, const void* B, int ldb, int M, int N, int K) {
+  sfron_gemm_desc g{};
+  g.A = (const uint16_t*)A; g.B = (const uint16_t*)B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
+  g.alpha = 1.0f; g.tokens = 1; g.split_k = 1;
+  return g;
+}
+// Y[M,N] = X[M,K] W[N,K]^T
+inline sfron_gemm_desc fwd_desc(const void* X, const void* W, int M, int N, int K) { return gd(X, K, W, K, M, N, K); }
+// dX[M,K] = dY[M,N] W[N,K]
+inline sfron_gemm_desc dgrad_desc(const void* dY, const void* W, int M, int N, int K) {
+  sfron_gemm_desc g = gd(dY, N, W, K, M, K, N);
+  g.b_transposed = 1;
+  return g;
+}
+// dW[N,K] = dY[M,N]^T X[M,K] -> fp32 into the grad arena
+inline sfron_gemm_desc wgrad_desc(const void* dY, const void* X, int M, int N, int K, float* dW) {
+  sfron_gemm_desc g = gd(dY, N, X, K, N, K, M);
+  g.a_transposed = 1; g.b_transposed = 1; g.epilogue = SFRON_EPI_F32; g.c_f32 = dW; g.ldc_f32 = K;
+  return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sfron_dit_param_layout(const sfron_dit_cfg* cfg, int64_t* out, int n_out) {
+  Dims d;
+  RUN(make_dims(cfg, d));
+  ParamLayout p = make_layout(d);
+  const int64_t v[SFRON_DIT_LAYOUT_LEN] = {p.total, p.trainable, p.pe_w, p.pe_b, p.t0_w, p.t0_b, p.t2_w, p.t2_b, p.table,
+                                           p.ada_w, p.ada_b, p.blocks, p.blk_stride, p.o_qkv_w, p.o_qkv_b, p.o_proj_w,
+                                           p.o_proj_b, p.o_fc1_w, p.o_fc1_b, p.o_fc2_w, p.o_fc2_b, p.fin_w, p.fin_b, p.pos};
+  SFRON_CHECK_ARG(out && n_out >= SFRON_DIT_LAYOUT_LEN);
+  for (int i = 0; i < SFRON_DIT_LAYOUT_LEN; ++i) out[i] = v[i];
+  return SFRON_OK;
+}
+
+int64_t sfron_dit_workspace_bytes(const sfron_dit_cfg* cfg) {
+  Dims d;
+  if (make_dims(cfg, d) != SFRON_OK) return -1;
+  return (int64_t)make_ws(d, nullptr).bytes;
+}
+
+int sfron_dit_forward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
+                      const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out, void* stream) {
+  Dims d;
+  RUN(make_dims(cfg, d));
+  SFRON_CHECK_ARG(params && params_bf16 && x_t && t && y && workspace && out);
+  const ParamLayout P = make_layout(d);
+  Workspace w = make_ws(d, (char*)workspace);
+  const uint16_t* wb = params_bf16;
+  const int M = d.M, D = d.D, T = d.T, NM = d.NM;
+  sfron_gemm_desc g;
+
+  // x = x_embedder(x) + pos_embed                                        (models.py:240)
+  RUN(sfron_patchify(x_t, d.B, d.C, d.S, d.S, d.p, 0, (uint16_t*)w.patches, d.Kp, stream));
+  g = fwd_desc(w.patches, wb + P.pe_w, M, D, d.Kp);
+  g.epilogue = SFRON_EPI_POS; g.bias = params + P.pe_b; g.c_f32 = w.xs; g.ldc_f32 = D; g.pos = params + P.pos; g.tokens = T;
+  RUN(sfron_gemm_bf16(&g, stream));
+  // t = t_embedder(t)                                                    (models.py:61-64,241)
+  RUN(sfron_timestep_embed(t, d.B, d.fdim, (uint16_t*)w.tfreq, d.fdim, stream));
+  g = fwd_desc(w.tfreq, wb + P.t0_w, d.B, D, d.fdim);
+  g.epilogue = SFRON_EPI_F32; g.bias = params + P.t0_b; g.c_f32 = w.h1; g.ldc_f32 = D;
+  RUN(sfron_gemm_bf16(&g, stream));
+  RUN(sfron_silu_fwd(w.h1, (int64_t)d.B * D, (uint16_t*)w.h1s, stream));
+  g = fwd_desc(w.h1s, wb + P.t2_w, d.B, D, D);
+  g.epilogue = SFRON_EPI_F32; g.bias = params + P.t2_b; g.c_f32 = w.temb; g.ldc_f32 = D;
+  RUN(sfron_gemm_bf16(&g, stream));
+  // c = t + y_embedder(y); SiLU(c) feeds every adaLN_modulation           (models.py:242-243,114,132)
+  RUN(sfron_cond_fwd(w.temb, params + P.table, y, drop, d.ncls, d.B, D, w.c, (uint16_t*)w.sc, stream));
+  g = fwd_desc(w.sc, wb + P.ada_w, d.B, NM, D);
+  g.epilogue = SFRON_EPI_F32; g.bias = params + P.ada_b; g.c_f32 = w.mod; g.ldc_f32 = NM;
+  RUN(sfron_gemm_bf16(&g, stream));
+
+  for (int l = 0; l < d.L; ++l) {
+    const int64_t pb = P.blocks + (int64_t)l * P.blk_stride;
+    const float* mod = w.mod + (size_t)l * 6 * D;          // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+    float* x0 = w.xs + (size_t)(2 * l) * M * D;
+    float* x1 = x0 + (size_t)M * D;
+    float* x2 = x1 + (size_t)M * D;
+    __bf16* xmod1 = w.xmod1 + (size_t)l * M * D; __bf16* qkv = w.qkv + (size_t)l * M * 3 * D;
+    __bf16* o = w.o + (size_t)l * M * D; __bf16* a1 = w.a1 + (size_t)l * M * D;
+    __bf16* xmod2 = w.xmod2 + (size_t)l * M * D; __bf16* hpre = w.hpre + (size_t)l * M * d.F;
+    __bf16* h = w.h + (size_t)l * M * d.F; __bf16* a2 = w.a2 + (size_t)l * M * D;
+    // x = x + gate_msa * attn(modulate(norm1(x), shift_msa, scale_msa))   (models.py:120)
+    RUN(sfron_ln_modulate_fwd(x0, mod, mod + D, NM, T, M, D, (uint16_t*)xmod1, w.mean + (size_t)(2 * l) * M,
+                              w.rstd + (size_t)(2 * l) * M, stream));
+    g = fwd_desc(xmod1, wb + pb + P.o_qkv_w, M, 3 * D, D);
+    g.bias = params + pb + P.o_qkv_b; g.c_bf16 = (uint16_t*)qkv; g.ldc_bf16 = 3 * D;
+    RUN(sfron_gemm_bf16(&g, stream));
+    RUN(sfron_attn_fwd((const uint16_t*)qkv, (uint16_t*)o, w.lse + (size_t)l * d.B * d.H * T, d.B, T, d.H, d.hd, stream));
+    g = fwd_desc(o, wb + pb + P.o_proj_w, M, D, D);
+    g.epilogue = SFRON_EPI_GATE_RES; g.bias = params + pb + P.o_proj_b; g.c_f32 = x1; g.ldc_f32 = D; g.resid = x0;
+    g.aux = (uint16_t*)a1; g.ldaux = D; g.gate = mod + 2 * D; g.ldgate = NM; g.tokens = T;
+    RUN(sfron_gemm_bf16(&g, stream));
+    // x = x + gate_mlp * mlp(modulate(norm2(x), shift_mlp, scale_mlp))    (models.py:121)
+    RUN(sfron_ln_modulate_fwd(x1, mod + 3 * D, mod + 4 * D, NM, T, M, D, (uint16_t*)xmod2, w.mean + (size_t)(2 * l + 1) * M,
+                              w.rstd + (size_t)(2 * l + 1) * M, stream));
+    g = fwd_desc(xmod2, wb + pb + P.o_fc1_w, M, d.F, D);
+    g.epilogue = SFRON_EPI_GELU; g.bias = params + pb + P.o_fc1_b; g.c_bf16 = (uint16_t*)h; g.ldc_bf16 = d.F;
+    g.aux = (uint16_t*)hpre; g.ldaux = d.F;
+    RUN(sfron_gemm_bf16(&g, stream));
+    g = fwd_desc(h, wb + pb + P.o_fc2_w, M, D, d.F);
+    g.epilogue = SFRON_EPI_GATE_RES; g.bias = params + pb + P.o_fc2_b; g.c_f32 = x2; g.ldc_f32 = D; g.resid = x1;
+    g.aux = (uint16_t*)a2; g.ldaux = D; g.gate = mod + 5 * D; g.ldgate = NM; g.tokens = T;
+    RUN(sfron_gemm_bf16(&g, stream));
+  }
+  // final layer + unpatchify                                              (models.py:138-142,218-231,247-248)
+  const float* modf = w.mod + (size_t)6 * d.L * D;
+  float* xL = w.xs + (size_t)(2 * d.L) * M * D;
+  RUN(sfron_ln_modulate_fwd(xL, modf, modf + D, NM, T, M, D, (uint16_t*)w.xmodf, w.mean + (size_t)(2 * d.L) * M,
+                            w.rstd + (size_t)(2 * d.L) * M, stream));
+  g = fwd_desc(w.xmodf, wb + P.fin_w, M, d.Po, D);
+  g.epilogue = SFRON_EPI_F32; g.bias = params + P.fin_b; g.c_f32 = w.tok; g.ldc_f32 = d.Po;
+  RUN(sfron_gemm_bf16(&g, stream));
+  RUN(sfron_unpatchify(w.tok, d.Po, d.B, d.Co, d.S, d.S, d.p, out, stream));
+  return SFRON_OK;
+}
+
+int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* d_out,
+                       const int64_t* y, const uint8_t* drop, void* workspace, float* grads, void* stream) {
+  Dims d;
+  RUN(make_dims(cfg, d));
+  SFRON_CHECK_ARG(params && params_bf16 && d_out && y && workspace && grads);
+  const ParamLayout P = make_layout(d);
+  Workspace w = make_ws(d, (char*)workspace);
+  const uint16_t* wb = params_bf16;
+  const int M = d.M, D = d.D, T = d.T, NM = d.NM, B = d.B;
+  const int rpc = sfron_rows_per_chunk(T);
+  SFRON_CHECK_ARG(rpc > 0);
+  const int per = T / rpc, nch = M / rpc;
+  float* part0 = w.part; float* part1 = part0 + (size_t)nch * D;
+  hipStream_t hs = (hipStream_t)stream;
+  sfron_gemm_desc g;
+
+  // ---- final layer
+  RUN(sfron_patchify(d_out, B, d.Co, d.S, d.S, d.p, 1, (uint16_t*)w.d_tok, d.Po, stream));
+  RUN(sfron_colsum(w.d_tok, 1, M, d.Po, d.Po, w.csum, CSUM_PARTS, grads + P.fin_b, stream));
+  g = wgrad_desc(w.d_tok, w.xmodf, M, d.Po, D, grads + P.fin_w);
+  RUN(sfron_gemm_bf16(&g, stream));
+  g = dgrad_desc(w.d_tok, wb + P.fin_w, M, d.Po, D);
+  g.c_bf16 = (uint16_t*)w.d_xmod; g.ldc_bf16 = D;
+  RUN(sfron_gemm_bf16(&g, stream));
+  const float* modf = w.mod + (size_t)6 * d.L * D;
+  float* dmodf = w.dmod + (size_t)6 * d.L * D;
+  RUN(sfron_ln_modulate_bwd((const uint16_t*)w.d_xmod, w.xs + (size_t)(2 * d.L) * M * D, w.mean + (size_t)(2 * d.L) * M,
+                            w.rstd + (size_t)(2 * d.L) * M, modf + D, NM, T, M, D, w.dx, 0, part0, part1, stream));
+  RUN(sfron_reduce_chunks(part0, B, per, D, dmodf, NM, 0, stream));
+  RUN(sfron_reduce_chunks(part1, B, per, D, dmodf + D, NM, 0, stream));
+
+  for (int l = d.L - 1; l >= 0; --l) {
+    const int64_t pb = P.blocks + (int64_t)l * P.blk_stride;
+    const float* mod = w.mod + (size_t)l * 6 * D;
+    float* dmod = w.dmod + (size_t)l * 6 * D;
+    const float* x0 = w.xs + (size_t)(2 * l) * M * D;
+    const float* x1 = x0 + (size_t)M * D;
+    const __bf16* xmod1 = w.xmod1 + (size_t)l * M * D; const __bf16* qkv = w.qkv + (size_t)l * M * 3 * D;
+    const __bf16* o = w.o + (size_t)l * M * D; const __bf16* a1 = w.a1 + (size_t)l * M * D;
+    const __bf16* xmod2 = w.xmod2 + (size_t)l * M * D; const __bf16* hpre = w.hpre + (size_t)l * M * d.F;
+    const __bf16* h = w.h + (size_t)l * M * d.F; const __bf16* a2 = w.a2 + (size_t)l * M * D;
+    // ---- MLP branch: x2 = x1 + gate_mlp * (fc2(gelu(fc1(xmod2))))
+    RUN(sfron_gate_bwd(w.dx, (const uint16_t*)a2, mod + 5 * D, NM, T, M, D, (uint16_t*)w.d_br, part0, part1, stream));
+    RUN(sfron_reduce_chunks(part0, B, per, D, dmod + 5 * D, NM, 0, stream));
+    RUN(sfron_weighted_reduce(part1, B, per, D, mod + 5 * D, NM, grads + pb + P.o_fc2_b, stream));
+    g = wgrad_desc(w.d_br, h, M, D, d.F, grads + pb + P.o_fc2_w);
+    RUN(sfron_gemm_bf16(&g, stream));
+    g = dgrad_desc(w.d_br, wb + pb + P.o_fc2_w, M, D, d.F);
+    g.epilogue = SFRON_EPI_DGELU; g.c_bf16 = (uint16_t*)w.d_hpre; g.ldc_bf16 = d.F; g.aux = (uint16_t*)hpre; g.ldaux = d.F;
+    RUN(sfron_gemm_bf16(&g, stream));
+    RUN(sfron_colsum(w.d_hpre, 1, M, d.F, d.F, w.csum, CSUM_PARTS, grads + pb + P.o_fc1_b, stream));
+    g = wgrad_desc(w.d_hpre, xmod2, M, d.F, D, grads + pb + P.o_fc1_w);
+    RUN(sfron_gemm_bf16(&g, stream));
+    g = dgrad_desc(w.d_hpre, wb + pb + P.o_fc1_w, M, d.F, D);
+    g.c_bf16 = (uint16_t*)w.d_xmod; g.ldc_bf16 = D;
+    RUN(sfron_gemm_bf16(&g, stream));
+    RUN(sfron_ln_modulate_bwd((const uint16_t*)w.d_xmod, x1, w.mean + (size_t)(2 * l + 1) * M, w.rstd + (size_t)(2 * l + 1) * M,
+                              mod + 4 * D, NM, T, M, D, w.dx, 1, part0, part1, stream));
+    RUN(sfron_reduce_chunks(part0, B, per, D, dmod + 3 * D, NM, 0, stream));
+    RUN(sfron_reduce_chunks(part1, B, per, D, dmod + 4 * D, NM, 0, stream));
+    // ---- attention branch: x1 = x0 + gate_msa * proj(attn(qkv(xmod1)))
+    RUN(sfron_gate_bwd(w.dx, (const uint16_t*)a1, mod + 2 * D, NM, T, M, D, (uint16_t*)w.d_br, part0, part1, stream));
+    RUN(sfron_reduce_chunks(part0, B, per, D, dmod + 2 * D, NM, 0, stream));
+    RUN(sfron_weighted_reduce(part1, B, per, D, mod + 2 * D, NM, grads + pb + P.o_proj_b, stream));
+    g = wgrad_desc(w.d_br, o, M, D, D, grads + pb + P.o_proj_w);
+    RUN(sfron_gemm_bf16(&g, stream));
+    g = dgrad_desc(w.d_br, wb + pb + P.o_proj_w, M, D, D);
+    g.c_bf16 = (uint16_t*)w.d_o; g.ldc_bf16 = D;
+    RUN(sfron_gemm_bf16(&g, stream));
+    RUN(sfron_attn_bwd((const uint16_t*)qkv, (const uint16_t*)o, (const uint16_t*)w.d_o, w.lse + (size_t)l * B * d.H * T,
+                       w.delta, (uint16_t*)w.dqkv, B, T, d.H, d.hd, stream));
+    RUN(sfron_colsum(w.dqkv, 1, M, 3 * D, 3 * D, w.csum, CSUM_PARTS, grads + pb + P.o_qkv_b, stream));
+    g = wgrad_desc(w.dqkv, xmod1, M, 3 * D, D, grads + pb + P.o_qkv_w);
+    RUN(sfron_gemm_bf16(&g, stream));
+    g = dgrad_desc(w.dqkv, wb + pb + P.o_qkv_w, M, 3 * D, D);
+    g.c_bf16 = (uint16_t*)w.d_xmod; g.ldc_bf16 = D;
+    RUN(sfron_gemm_bf16(&g, stream));
+    RUN(sfron_ln_modulate_bwd((const uint16_t*)w.d_xmod, x0, w.mean + (size_t)(2 * l) * M, w.rstd + (size_t)(2 * l) * M,
+                              mod + D, NM, T, M, D, w.dx, 1, part0, part1, stream));
+    RUN(sfron_reduce_chunks(part0, B, per, D, dmod, NM, 0, stream));
+    RUN(sfron_reduce_chunks(part1, B, per, D, dmod + D, NM, 0, stream));
+  }
+  // ---- patch embed (pos_embed is frozen: no gradient)
+  RUN(sfron_cast_bf16(w.dx, (uint16_t*)w.dx_bf, (int64_t)M * D, stream));
+  RUN(sfron_colsum(w.dx, 0, M, D, D, w.csum, CSUM_PARTS, grads + P.pe_b, stream));
+  g = wgrad_desc(w.dx_bf, w.patches, M, D, d.Kp, grads + P.pe_w);
+  RUN(sfron_gemm_bf16(&g, stream));
+  // ---- adaLN modulation Linear of every block + final layer, as one problem
+  RUN(sfron_cast_bf16(w.dmod, (uint16_t*)w.dmod_bf, (int64_t)B * NM, stream));
+  RUN(sfron_colsum(w.dmod, 0, B, NM, NM, w.csum, CSUM_PARTS, grads + P.ada_b, stream));
+  g = wgrad_desc(w.dmod_bf, w.sc, B, NM, D, grads + P.ada_w);
+  RUN(sfron_gemm_bf16(&g, stream));
+  g = dgrad_desc(w.dmod_bf, wb + P.ada_w, B, NM, D);
+  g.epilogue = SFRON_EPI_F32; g.c_f32 = w.slabs; g.ldc_f32 = D; g.split_k = SPLIT_K_ADA; g.split_stride = (long)B * D;
+  RUN(sfron_gemm_bf16(&g, stream));
+  {
+    const int kchunk = cdiv(cdiv(NM, SPLIT_K_ADA), 64) * 64;
+    RUN(sfron_reduce_chunks(w.slabs, 1, cdiv(NM, kchunk), B * D, w.d_sc, B * D, 0, stream));
+  }
+  // ---- c = t_emb + y_emb: label table (scatter) and t_embedder MLP
+  if (hipMemsetAsync(grads + P.table, 0, (size_t)(d.ncls + 1) * D * sizeof(float), hs) != hipSuccess) return (int)hipGetLastError();
+  RUN(sfron_cond_bwd(w.d_sc, w.c, y, drop, d.ncls, B, D, w.d_c, grads + P.table, stream));
+  RUN(sfron_cast_bf16(w.d_c, (uint16_t*)w.d_c_bf, (int64_t)B * D, stream));
+  RUN(sfron_colsum(w.d_c, 0, B, D, D, w.csum, CSUM_PARTS, grads + P.t2_b, stream));
+  g = wgrad_desc(w.d_c_bf, w.h1s, B, D, D, grads + P.t2_w);
+  RUN(sfron_gemm_bf16(&g, stream));
+  g = dgrad_desc(w.d_c_bf, wb + P.t2_w, B, D, D);
+  g.epilogue = SFRON_EPI_F32; g.c_f32 = w.d_h1s; g.ldc_f32 = D;
+  RUN(sfron_gemm_bf16(&g, stream));
+  RUN(sfron_silu_bwd(w.d_h1s, w.h1, (int64_t)B * D, (uint16_t*)w.d_h1_bf, w.d_sc /* fp32 copy, d_sc is free now */, stream));
+  RUN(sfron_colsum(w.d_sc, 0, B, D, D, w.csum, CSUM_PARTS, grads + P.t0_b, stream));
+  g = wgrad_desc(w.d_h1_bf, w.tfreq, B, D, d.fdim, grads + P.t0_w);
+  RUN(sfron_gemm_bf16(&g, stream));
+  return SFRON_OK;
+}
+
+}  // extern "C"

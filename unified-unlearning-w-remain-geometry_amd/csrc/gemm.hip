@@ -265,7 +265,8 @@ int dispatch_layout(int a_tr, int b_tr, const GemmArgs& g, hipStream_t s) {
 
 extern "C" int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
   SFRON_CHECK_ARG(d && d->A && d->B && d->M > 0 && d->N > 0 && d->K > 0);
-  SFRON_CHECK_ARG(d->K % 8 == 0 && d->N % 4 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0);
+  SFRON_CHECK_ARG(d->N % 4 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0);
+  if (!d->a_transposed || !d->b_transposed) SFRON_CHECK_ARG(d->K % 8 == 0);   // k-contiguous operands are staged in 8-element chunks
   SFRON_CHECK_ARG((((uintptr_t)d->A | (uintptr_t)d->B) & 15) == 0);
   if (d->a_transposed) SFRON_CHECK_ARG(d->M % 8 == 0);
   if (d->b_transposed) SFRON_CHECK_ARG(d->N % 8 == 0);

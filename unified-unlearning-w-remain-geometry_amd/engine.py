@@ -1,0 +1,112 @@
+"""Host handle of the whole-model DiT pass (csrc/dit_engine.hip): arenas, name <-> offset map, workspace.
+
+The parameter arena is one flat fp32 GPU tensor; every reference state_dict key
+(/root/reference/DiT/models.py) is a view into it, so pretrained checkpoints load
+unchanged while the sweep kernels see one contiguous range.
+"""
+import ctypes
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+_LAYOUT_KEYS = ["total", "trainable", "pe_w", "pe_b", "t0_w", "t0_b", "t2_w", "t2_b", "table", "ada_w", "ada_b",
+                "blocks", "blk_stride", "qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+                "fin_w", "fin_b", "pos"]
+
+
+class DitEngine:
+    def __init__(self, batch, input_size=32, patch_size=2, in_channels=4, hidden_size=1152, depth=28, num_heads=16,
+                 mlp_ratio=4.0, num_classes=1000, learn_sigma=True, device="cuda"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.SfronError("DitEngine needs a GPU (no CPU fallback)")
+        c = _lib.DitCfg()
+        c.batch, c.in_channels, c.input_size, c.patch = batch, in_channels, input_size, patch_size
+        c.hidden, c.depth, c.heads = hidden_size, depth, num_heads
+        c.mlp_hidden, c.num_classes, c.freq_dim = int(hidden_size * mlp_ratio), num_classes, 256
+        c.out_channels = in_channels * 2 if learn_sigma else in_channels
+        self.cfg = c
+        L = _lib.lib()
+        lay = (ctypes.c_int64 * _lib.DIT_LAYOUT_LEN)()
+        check(L.sfron_dit_param_layout(ctypes.byref(c), lay, _lib.DIT_LAYOUT_LEN), "dit_param_layout (unsupported DiT config?)")
+        self.layout = dict(zip(_LAYOUT_KEYS, [int(v) for v in lay]))
+        self.n_total, self.n_trainable = self.layout["total"], self.layout["trainable"]
+        self.tokens = (input_size // patch_size) ** 2
+        self.index = self._build_index()
+        self.params = torch.zeros(self.n_total, dtype=torch.float32, device=self.device)
+        self.params_bf16 = torch.zeros(self.n_total, dtype=torch.bfloat16, device=self.device)
+        self.grads = torch.zeros(self.n_total, dtype=torch.float32, device=self.device)
+        ws = L.sfron_dit_workspace_bytes(ctypes.byref(c))
+        if ws < 0:
+            raise _lib.SfronError("unsupported DiT config")
+        self.workspace = torch.empty(ws, dtype=torch.uint8, device=self.device)
+        self.out_shape = (batch, c.out_channels, input_size, input_size)
+
+    # ------------------------------------------------------------------ names
+    def _build_index(self):
+        """OrderedDict name -> (offset, shape, trainable) in the reference's named_parameters() order."""
+        c, lay = self.cfg, self.layout
+        D, F, L, p = c.hidden, c.mlp_hidden, c.depth, c.patch
+        idx = OrderedDict()
+        idx["pos_embed"] = (lay["pos"], (1, self.tokens, D), False)
+        idx["x_embedder.proj.weight"] = (lay["pe_w"], (D, c.in_channels, p, p), True)
+        idx["x_embedder.proj.bias"] = (lay["pe_b"], (D,), True)
+        idx["t_embedder.mlp.0.weight"] = (lay["t0_w"], (D, c.freq_dim), True)
+        idx["t_embedder.mlp.0.bias"] = (lay["t0_b"], (D,), True)
+        idx["t_embedder.mlp.2.weight"] = (lay["t2_w"], (D, D), True)
+        idx["t_embedder.mlp.2.bias"] = (lay["t2_b"], (D,), True)
+        idx["y_embedder.embedding_table.weight"] = (lay["table"], (c.num_classes + 1, D), True)
+        for l in range(L):
+            b = lay["blocks"] + l * lay["blk_stride"]
+            pre = f"blocks.{l}."
+            idx[pre + "attn.qkv.weight"] = (b + lay["qkv_w"], (3 * D, D), True)
+            idx[pre + "attn.qkv.bias"] = (b + lay["qkv_b"], (3 * D,), True)
+            idx[pre + "attn.proj.weight"] = (b + lay["proj_w"], (D, D), True)
+            idx[pre + "attn.proj.bias"] = (b + lay["proj_b"], (D,), True)
+            idx[pre + "mlp.fc1.weight"] = (b + lay["fc1_w"], (F, D), True)
+            idx[pre + "mlp.fc1.bias"] = (b + lay["fc1_b"], (F,), True)
+            idx[pre + "mlp.fc2.weight"] = (b + lay["fc2_w"], (D, F), True)
+            idx[pre + "mlp.fc2.bias"] = (b + lay["fc2_b"], (D,), True)
+            idx[pre + "adaLN_modulation.1.weight"] = (lay["ada_w"] + l * 6 * D * D, (6 * D, D), True)
+            idx[pre + "adaLN_modulation.1.bias"] = (lay["ada_b"] + l * 6 * D, (6 * D,), True)
+        idx["final_layer.linear.weight"] = (lay["fin_w"], (p * p * c.out_channels, D), True)
+        idx["final_layer.linear.bias"] = (lay["fin_b"], (p * p * c.out_channels,), True)
+        idx["final_layer.adaLN_modulation.1.weight"] = (lay["ada_w"] + L * 6 * D * D, (2 * D, D), True)
+        idx["final_layer.adaLN_modulation.1.bias"] = (lay["ada_b"] + L * 6 * D, (2 * D,), True)
+        return idx
+
+    def view(self, arena, name):
+        off, shape, _ = self.index[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return arena[off:off + n].view(shape)
+
+    def arena_mask(self, valid_only=True):
+        """bool [n_total]: True on elements that belong to a named tensor (arena padding is False)."""
+        m = torch.zeros(self.n_total, dtype=torch.bool, device=self.device)
+        for name in self.index:
+            self.view(m, name).fill_(True)
+        return m
+
+    def sync_bf16(self):
+        check(_lib.lib().sfron_cast_bf16(ptr(self.params), ptr(self.params_bf16), self.n_total, stream_ptr()), "cast_bf16")
+
+    # ------------------------------------------------------------------ passes
+    def forward(self, x_t, t, y, drop=None, out=None):
+        if out is None:
+            out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
+        if x_t.shape[0] != self.cfg.batch:
+            raise _lib.SfronError(f"engine was built for batch {self.cfg.batch}, got {x_t.shape[0]}")
+        check(_lib.lib().sfron_dit_forward(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(x_t), ptr(t),
+                                           ptr(y), ptr(drop), ptr(self.workspace), ptr(out), stream_ptr()), "dit_forward")
+        return out
+
+    def backward(self, d_out, y, drop=None, grads=None):
+        g = self.grads if grads is None else grads
+        check(_lib.lib().sfron_dit_backward(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(d_out),
+                                            ptr(y), ptr(drop), ptr(self.workspace), ptr(g), stream_ptr()), "dit_backward")
+        return g

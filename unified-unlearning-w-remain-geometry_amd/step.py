@@ -1,0 +1,99 @@
+"""The SFR-on iteration for DiT class-forgetting, fast path (no autograd, no host syncs).
+
+One call = one iteration of /root/reference/DiT/forget.py:256-322 (method "ron"):
+  forget: q_sample -> DiT fwd -> fused loss fwd/bwd (alpha * -loss.mean() for "ga") -> DiT bwd ->
+          [DP: all-reduce grads] -> mask -> clip_grad_norm_(grad_clip) -> AdamW.step
+  remain: the same with +loss.mean(), no mask, no clip -> AdamW.step (same optimizer state)
+  EMA over all named parameters (decay 0.9999), fused into the second Adam sweep.
+Data-parallel: every rank holds full replicas (weights, Adam state, EMA, mask) and a shard of each
+minibatch; gradients are scaled by 1/global_batch in the loss kernel and SUM-all-reduced over RCCL.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _lib, sweep
+
+
+def build_mask_arena(engine, mask):
+    """Reference mask dict (name -> bool tensor, keys optionally 'module.'-prefixed, python int 0 for never-grad
+    params; DiT/forget.py:235-237,289-292) -> uint8 arena over the trainable range, loaded ONCE."""
+    arena = torch.ones(engine.n_trainable, dtype=torch.uint8, device=engine.device)
+    for name, (off, shape, trainable) in engine.index.items():
+        if not trainable:
+            continue
+        m = mask.get(name, mask.get("module." + name))
+        if m is None:
+            raise KeyError(f"saliency mask has no entry for {name}")
+        n = 1
+        for s in shape:
+            n *= s
+        if isinstance(m, int):
+            arena[off:off + n] = 1 if m else 0
+        else:
+            if tuple(m.shape) != tuple(shape):
+                raise ValueError(f"mask[{name}] has shape {tuple(m.shape)}, expected {tuple(shape)}")
+            arena[off:off + n] = m.reshape(-1).to(device=engine.device, dtype=torch.uint8)
+    return arena
+
+
+class DiTSFRon:
+    def __init__(self, model, diffusion, lr=1e-4, forget_alpha=1e-3, grad_clip=1.0, ema_decay=0.9999, mask=None,
+                 unlearn_loss="ga", forget_class=0, process_group=None, bucket_bytes=256 << 20):
+        if unlearn_loss not in ("ga", "rl"):
+            raise ValueError(f"unsupported unlearn_loss {unlearn_loss!r} (DiT/forget.py defines only 'ga' and 'rl')")
+        self.model, self.diffusion = model, diffusion
+        self.forget_alpha, self.grad_clip, self.ema_decay = forget_alpha, grad_clip, ema_decay
+        self.unlearn_loss, self.forget_class = unlearn_loss, forget_class
+        self.lr = lr
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self._bind(mask)
+
+    def _bind(self, mask):
+        eng = self.model.engine
+        nt = eng.n_trainable
+        self.mask_arena = build_mask_arena(eng, mask) if mask is not None else None
+        self.opt = sweep.FlatAdam(eng.params[:nt], eng.grads[:nt], lr=self.lr, weight_decay=0.0, adamw=True,
+                                  mask=self.mask_arena, w_bf16=eng.params_bf16[:nt])          # forget.py:199
+        self.ema = eng.params.clone()                                                      # forget.py:190,230
+
+    def _allreduce_grads(self):
+        if self.world == 1:
+            return
+        g = self.model.engine.grads[:self.model.engine.n_trainable]
+        for s in range(0, g.numel(), self.bucket_elems):
+            dist.all_reduce(g[s:s + self.bucket_elems], op=dist.ReduceOp.SUM, group=self.pg)
+
+    def _pass(self, batch, y, sign_alpha):
+        eng, diff = self.model.engine, self.diffusion
+        n_global = batch["x0"].shape[0] * self.world
+        x_t = diff.q_sample(batch["x0"], batch["t"], batch["noise"])
+        out = eng.forward(x_t, batch["t"], y, batch.get("drop"))
+        mse, vb, d_out = diff.loss_fwd_bwd(out, batch["x0"], batch["t"], batch["noise"], sign_alpha / n_global)
+        eng.backward(d_out, y, batch.get("drop"))
+        self._allreduce_grads()
+        return mse, vb
+
+    def step(self, forget, remain):
+        """forget / remain: dicts of GPU tensors x0 [N,4,S,S] fp32, y [N] int64, t [N] int64, noise, drop [N] uint8
+        (this rank's shard).  Returns per-sample mse / vb tensors (device; no host sync here)."""
+        eng = self.model.engine
+        self.model.set_batch_size(forget["x0"].shape[0])
+        if self.unlearn_loss == "ga":
+            y_f, sign = forget["y"], -1.0                                                   # forget.py:269-272
+        else:
+            y_f, sign = torch.full_like(forget["y"], (self.forget_class + 100) % 1000), 1.0  # forget.py:274-282
+        mse_f, vb_f = self._pass(forget, y_f, sign * self.forget_alpha)
+        self.opt.step(max_norm=self.grad_clip, use_mask=True)                               # forget.py:289-299
+        mse_r, vb_r = self._pass(remain, remain["y"], 1.0)
+        nt = eng.n_trainable
+        self.opt.step(max_norm=None, use_mask=False, ema=self.ema[:nt], ema_decay=self.ema_decay, ema_mode=1)  # :320,322
+        if eng.n_total > nt:
+            sweep.ema_update(self.ema[nt:], eng.params[nt:], self.ema_decay, mode=1)         # frozen pos_embed (:60-62)
+        return {"forget_mse": mse_f, "forget_vb": vb_f, "remain_mse": mse_r, "remain_vb": vb_r,
+                "forget_sign": sign, "stats": self.opt.stats}
+
+    def ema_state_dict(self):
+        eng = self.model.engine
+        return {name: eng.view(self.ema, name).clone() for name in eng.index}
