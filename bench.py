@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- SFR-on unlearning steps/sec, DiT-XL/2 256 px, batch 32 per GPU (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one full SFR-on iteration (DiT/forget.py:256-322): forget fwd/bwd -> mask -> clip -> AdamW,
+remain fwd/bwd -> AdamW, EMA; synthetic latents / labels / timesteps / noise already resident in HBM.
+Weak scaling: every rank runs batch 32 (global batch 32*N), gradients SUM-all-reduced over RCCL.
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  "roofline"     -- live HIP-event timing of the dominant kernel class (the Mlp.fc1 GEMM+GELU of block 0,
+                    [B*T x D] x [D x 4D], one sample per forward pass inside the timed region)
+  "cpu_baseline" -- the oracle (plain PyTorch fp32, CPU) timed on a bounded sample on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="DiT-XL/2")
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--image-size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2, help="batch of the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(model_name, latent, batch_full, cpu_batch):
+    """One SFR-on iteration of the ORACLE (CPU fp32 eager) at a reduced batch; cost is linear in batch to within
+    the optimizer sweep, which is included unscaled (so the scaled value slightly over-estimates CPU speed... it
+    is a baseline, not a target)."""
+    from oracle import diffusion_ref as dref
+    from oracle import dit_ref, sfron_ref
+    from sfron import data
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    t0 = time.time()
+    ref = dit_ref.build(model_name, input_size=latent)
+    dit_ref.randomize_zero_init(ref)
+    orc = sfron_ref.DiTSfronOracle(ref, dref.DiffusionTables(1000), lr=1e-4, forget_alpha=1e-3, mask=None)
+    build_s = time.time() - t0
+    kw = dict(global_batch=cpu_batch, input_size=latent)
+
+    def batch(i, s):
+        b = data.synthetic_batch(0, i, s, **kw)
+        b["drop"] = b["drop"].long()
+        return b
+    orc.step(batch(0, "forget"), batch(0, "remain"))        # warm-up (allocations, thread pools)
+    t0 = time.time()
+    orc.step(batch(1, "forget"), batch(1, "remain"))
+    dt = time.time() - t0
+    steps_per_s_full = (1.0 / dt) * (cpu_batch / batch_full)
+    return {"value": steps_per_s_full, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"1 timed SFR-on iteration of {model_name} (oracle, CPU fp32 eager, {cores} threads) at batch "
+                      f"{cpu_batch} took {dt:.2f} s; value = (1/t) * {cpu_batch}/{batch_full} (linear in batch); "
+                      f"model build {build_s:.1f} s not counted"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from sfron import data, diffusion, dit, step
+
+    latent = args.image_size // 8
+    model = dit.DiT_models[args.model](input_size=latent, num_classes=1000, batch_size=args.batch, device=dev)
+    torch.manual_seed(1234)          # identical replicas on every rank
+    model.initialize_weights()
+    dit.randomize_zero_init(model, std=0.02, seed=1)
+    model.train()
+    eng = model.engine
+    gm = torch.Generator().manual_seed(0)
+    mask_arena = (torch.rand(eng.n_trainable, generator=gm) < 0.5).to(torch.uint8).to(dev)     # 50 % synthetic saliency mask
+    diff = diffusion.create_diffusion("", device=dev)
+    runner = step.DiTSFRon(model, diff, lr=1e-4, forget_alpha=1e-3, grad_clip=1.0, ema_decay=0.9999, mask=None,
+                           unlearn_loss="ga", forget_class=207)
+    runner.mask_arena = mask_arena
+    runner.opt.mask = mask_arena
+
+    pool = 4
+    gb = args.batch * world
+    batches = [(data.synthetic_batch(0, i, "forget", gb, rank, world, input_size=latent, device=dev),
+                data.synthetic_batch(0, i, "remain", gb, rank, world, input_size=latent, device=dev)) for i in range(pool)]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        runner.step(*batches[i % pool])
+    eng.probe_enable(2 * args.steps + 4)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = runner.step(*batches[i % pool])
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+
+    loss_ok = bool(torch.isfinite(out["remain_mse"]).all().item() and torch.isfinite(out["forget_mse"]).all().item())
+    n_probe, probe_ms = eng.probe_read()
+    cfg = eng.cfg
+    M = args.batch * eng.tokens
+    fc1_flops = 2.0 * M * cfg.mlp_hidden * cfg.hidden
+    avg_ms = probe_ms / max(1, n_probe)
+    achieved = fc1_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    # algorithmic FLOPs of the whole step: 6 x forward
+    T, D, L, F = eng.tokens, cfg.hidden, cfg.depth, cfg.mlp_hidden
+    fwd_per_sample = L * (2 * T * D * (3 * D + D + 2 * F) + 4 * T * T * D + 2 * D * 6 * D)
+    step_flops = 6.0 * fwd_per_sample * args.batch
+    ms_per_step = elapsed / args.steps * 1e3
+
+    if rank == 0:
+        res = {
+            "metric": "SFR-on unlearning steps/sec, DiT-XL/2 256px bs32/GPU",
+            "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.model} {args.image_size}px SFR-on step (forget+remain fwd/bwd, masked clipped AdamW x2, EMA), "
+                                   f"batch {args.batch}/GPU, random-init weights (zero-init tensors re-drawn N(0,0.02)), 50% synthetic mask",
+                       "global_batch": gb, "tokens": T, "parallelism": f"dp{world}"},
+            "finite_losses": loss_ok,
+            "step_tflops_per_gpu": step_flops / (ms_per_step * 1e-3) / 1e12,
+            "step_frac_of_bf16_mfma_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "k_gemm<A direct, B direct, EPI_GELU> (Mlp.fc1 + GELU-tanh, "
+                         f"[{M}x{D}]x[{D}x{F}])", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "flops_per_launch": fc1_flops, "avg_launch_ms": avg_ms, "launches_timed": n_probe},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(args.model, latent, args.batch, args.cpu_batch)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

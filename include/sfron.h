@@ -207,6 +207,15 @@ int64_t sfron_dit_workspace_bytes(const sfron_dit_cfg* cfg);   /* < 0 on unsuppo
  * Saves activations in `workspace` for sfron_dit_backward. */
 int sfron_dit_forward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
                       const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out, void* stream);
+/* Same as sfron_dit_forward, with HIP events recorded (on `stream`) around the fc1 GEMM of block 0 -- the
+ * dominant kernel class -- into `probe` (may be NULL).  Used by bench.py for the live roofline measurement. */
+int sfron_dit_forward_probed(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
+                             const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
+                             void* probe, void* stream);
+int sfron_probe_create(int max_samples, void** probe /* HOST out */);
+int sfron_probe_reset(void* probe);
+int sfron_probe_read(void* probe, int* n_samples, double* total_ms);   /* synchronises on the recorded events */
+int sfron_probe_destroy(void* probe);
 /* grads (arena layout, trainable part fully overwritten) = d loss / d params given d_out = d loss / d out */
 int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* d_out,
                        const int64_t* y, const uint8_t* drop, void* workspace, float* grads, void* stream);

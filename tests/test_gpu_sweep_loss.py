@@ -117,7 +117,7 @@ def test_two_stage_sweep_vs_torch(dev, n):
     m_ref, v_ref, steps = ref.state(0)
     assert steps == opt.step_count == 6
     np.testing.assert_allclose(p.cpu().numpy(), ref.params[0].detach().numpy(), rtol=2e-6, atol=2e-7)
-    np.testing.assert_allclose(opt.m.cpu().numpy(), m_ref.numpy(), rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(opt.m.cpu().numpy(), m_ref.numpy(), rtol=2e-6, atol=1e-8)
     np.testing.assert_allclose(opt.v.cpu().numpy(), v_ref.numpy(), rtol=2e-6, atol=1e-12)
     np.testing.assert_allclose(ema.cpu().numpy(), ema_ref[0].numpy(), rtol=2e-6, atol=2e-7)
     assert torch.equal(wbf.cpu(), p.cpu().to(torch.bfloat16))

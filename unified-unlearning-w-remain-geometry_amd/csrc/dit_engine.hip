@@ -162,8 +162,51 @@ int64_t sfron_dit_workspace_bytes(const sfron_dit_cfg* cfg) {
   return (int64_t)make_ws(d, nullptr).bytes;
 }
 
+// ---- probe: HIP events around the fc1 GEMM of block 0 (the dominant kernel class), for bench.py's roofline
+struct Probe { hipEvent_t* ev; int cap, used; };
+
+int sfron_probe_create(int max_samples, void** probe) {
+  SFRON_CHECK_ARG(probe && max_samples > 0);
+  Probe* p = new Probe{new hipEvent_t[2 * max_samples], max_samples, 0};
+  for (int i = 0; i < 2 * max_samples; ++i)
+    if (hipEventCreate(&p->ev[i]) != hipSuccess) return (int)hipGetLastError();
+  *probe = p;
+  return SFRON_OK;
+}
+int sfron_probe_reset(void* probe) { SFRON_CHECK_ARG(probe); ((Probe*)probe)->used = 0; return SFRON_OK; }
+int sfron_probe_read(void* probe, int* n_samples, double* total_ms) {
+  SFRON_CHECK_ARG(probe && n_samples && total_ms);
+  Probe* p = (Probe*)probe;
+  double tot = 0;
+  for (int i = 0; i < p->used; ++i) {
+    float ms = 0;
+    if (hipEventSynchronize(p->ev[2 * i + 1]) != hipSuccess) return (int)hipGetLastError();
+    if (hipEventElapsedTime(&ms, p->ev[2 * i], p->ev[2 * i + 1]) != hipSuccess) return (int)hipGetLastError();
+    tot += ms;
+  }
+  *n_samples = p->used; *total_ms = tot;
+  return SFRON_OK;
+}
+int sfron_probe_destroy(void* probe) {
+  SFRON_CHECK_ARG(probe);
+  Probe* p = (Probe*)probe;
+  for (int i = 0; i < 2 * p->cap; ++i) hipEventDestroy(p->ev[i]);
+  delete[] p->ev; delete p;
+  return SFRON_OK;
+}
+
+int sfron_dit_forward_probed(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
+                             const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
+                             void* probe, void* stream);
+
 int sfron_dit_forward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
                       const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out, void* stream) {
+  return sfron_dit_forward_probed(cfg, params, params_bf16, x_t, t, y, drop, workspace, out, nullptr, stream);
+}
+
+int sfron_dit_forward_probed(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
+                             const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
+                             void* probe, void* stream) {
   Dims d;
   RUN(make_dims(cfg, d));
   SFRON_CHECK_ARG(params && params_bf16 && x_t && t && y && workspace && out);
@@ -220,7 +263,11 @@ int sfron_dit_forward(const sfron_dit_cfg* cfg, const float* params, const uint1
     g = fwd_desc(xmod2, wb + pb + P.o_fc1_w, M, d.F, D);
     g.epilogue = SFRON_EPI_GELU; g.bias = params + pb + P.o_fc1_b; g.c_bf16 = (uint16_t*)h; g.ldc_bf16 = d.F;
     g.aux = (uint16_t*)hpre; g.ldaux = d.F;
+    Probe* pr = (Probe*)probe;
+    const bool probing = pr && l == 0 && pr->used < pr->cap;
+    if (probing) hipEventRecord(pr->ev[2 * pr->used], (hipStream_t)stream);
     RUN(sfron_gemm_bf16(&g, stream));
+    if (probing) { hipEventRecord(pr->ev[2 * pr->used + 1], (hipStream_t)stream); pr->used++; }
     g = fwd_desc(h, wb + pb + P.o_fc2_w, M, D, d.F);
     g.epilogue = SFRON_EPI_GATE_RES; g.bias = params + pb + P.o_fc2_b; g.c_f32 = x2; g.ldc_f32 = D; g.resid = x1;
     g.aux = (uint16_t*)a2; g.ldaux = D; g.gate = mod + 5 * D; g.ldgate = NM; g.tokens = T;

@@ -121,7 +121,7 @@ class DiT(nn.Module):
             return
         old = self.engine
         new = DitEngine(batch_size, **self._engine_args)
-        new.params, new.params_bf16, new.grads = old.params, old.params_bf16, old.grads
+        new.params, new.params_bf16, new.grads, new.probe = old.params, old.params_bf16, old.grads, old.probe
         self.engine = new
 
     # ------------------------------------------------------------------ forward

@@ -44,6 +44,7 @@ class DitEngine:
             raise _lib.SfronError("unsupported DiT config")
         self.workspace = torch.empty(ws, dtype=torch.uint8, device=self.device)
         self.out_shape = (batch, c.out_channels, input_size, input_size)
+        self.probe = None
 
     # ------------------------------------------------------------------ names
     def _build_index(self):
@@ -101,9 +102,24 @@ class DitEngine:
             out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
         if x_t.shape[0] != self.cfg.batch:
             raise _lib.SfronError(f"engine was built for batch {self.cfg.batch}, got {x_t.shape[0]}")
-        check(_lib.lib().sfron_dit_forward(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(x_t), ptr(t),
-                                           ptr(y), ptr(drop), ptr(self.workspace), ptr(out), stream_ptr()), "dit_forward")
+        check(_lib.lib().sfron_dit_forward_probed(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(x_t),
+                                                  ptr(t), ptr(y), ptr(drop), ptr(self.workspace), ptr(out), self.probe,
+                                                  stream_ptr()), "dit_forward")
         return out
+
+    # ------------------------------------------------------------------ roofline probe (bench.py)
+    def probe_enable(self, max_samples):
+        h = ctypes.c_void_p()
+        check(_lib.lib().sfron_probe_create(int(max_samples), ctypes.byref(h)), "probe_create")
+        self.probe = h
+
+    def probe_reset(self):
+        check(_lib.lib().sfron_probe_reset(self.probe), "probe_reset")
+
+    def probe_read(self):
+        n, ms = ctypes.c_int(0), ctypes.c_double(0.0)
+        check(_lib.lib().sfron_probe_read(self.probe, ctypes.byref(n), ctypes.byref(ms)), "probe_read")
+        return n.value, ms.value
 
     def backward(self, d_out, y, drop=None, grads=None):
         g = self.grads if grads is None else grads
