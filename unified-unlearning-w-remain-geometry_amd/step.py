@@ -11,7 +11,7 @@ minibatch; gradients are scaled by 1/global_batch in the loss kernel and SUM-all
 import torch
 import torch.distributed as dist
 
-from . import _lib, sweep
+from . import _lib, dp, sweep
 
 
 def build_mask_arena(engine, mask):
@@ -46,7 +46,7 @@ class DiTSFRon:
         self.unlearn_loss, self.forget_class = unlearn_loss, forget_class
         self.lr = lr
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.world = dp.world_size(process_group)
         self.bucket_elems = max(1, bucket_bytes // 4)
         self._bind(mask)
 
@@ -59,11 +59,7 @@ class DiTSFRon:
         self.ema = eng.params.clone()                                                      # forget.py:190,230
 
     def _allreduce_grads(self):
-        if self.world == 1:
-            return
-        g = self.model.engine.grads[:self.model.engine.n_trainable]
-        for s in range(0, g.numel(), self.bucket_elems):
-            dist.all_reduce(g[s:s + self.bucket_elems], op=dist.ReduceOp.SUM, group=self.pg)
+        dp.allreduce_flat_(self.model.engine.grads[:self.model.engine.n_trainable], self.bucket_elems, self.pg)
 
     def _pass(self, batch, y, sign_alpha):
         eng, diff = self.model.engine, self.diffusion
