@@ -36,8 +36,20 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2, help="batch of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-batch", type=int, default=1, help="batch of the bounded CPU-baseline sample")
     return ap.parse_args()
+
+
+def host_cores():
+    """Threads for the CPU baseline: the box's CPU share (affinity, cgroup quota), at most 16 per GPU."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
 
 
 def cpu_baseline(model_name, latent, batch_full, cpu_batch):
@@ -47,8 +59,9 @@ def cpu_baseline(model_name, latent, batch_full, cpu_batch):
     from oracle import diffusion_ref as dref
     from oracle import dit_ref, sfron_ref
     from sfron import data
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: building {model_name} oracle on {cores} host threads ...", file=sys.stderr, flush=True)
     torch.manual_seed(0)
     t0 = time.time()
     ref = dit_ref.build(model_name, input_size=latent)
@@ -61,7 +74,9 @@ def cpu_baseline(model_name, latent, batch_full, cpu_batch):
         b = data.synthetic_batch(0, i, s, **kw)
         b["drop"] = b["drop"].long()
         return b
+    print(f"[bench] cpu_baseline: built in {build_s:.1f} s; warm-up iteration ...", file=sys.stderr, flush=True)
     orc.step(batch(0, "forget"), batch(0, "remain"))        # warm-up (allocations, thread pools)
+    print("[bench] cpu_baseline: timed iteration ...", file=sys.stderr, flush=True)
     t0 = time.time()
     orc.step(batch(1, "forget"), batch(1, "remain"))
     dt = time.time() - t0

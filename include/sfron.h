@@ -117,6 +117,7 @@ typedef struct sfron_gemm_desc {
   int split_k;                       /* > 1 (EPI_F32 only, no bias): split s writes its partial product to
                                         c_f32 + s * split_stride; sum the slabs with sfron_reduce_chunks */
   long split_stride;
+  int tile_hint;                     /* 0 = auto; -1 = generic kernel; fast tiles 1 = 128x128, 2 = 256x192, 3 = 256x256, 4 = 384x192 */
 } sfron_gemm_desc;
 int sfron_gemm_bf16(const sfron_gemm_desc* desc /* HOST pointer */, void* stream);
 

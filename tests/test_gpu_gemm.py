@@ -127,3 +127,30 @@ def test_gemm_rejects_bad_args():
     A = torch.zeros(128, 60, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(_lib.SfronError):
         ops.gemm(A, A, 128, 128, 60, c_bf16=torch.zeros(128, 128, dtype=torch.bfloat16, device=DEV))   # K % 8 != 0
+
+
+@pytest.mark.parametrize("hint", [1, 2, 3])
+@pytest.mark.parametrize("layout", ["fwd", "dgrad", "wgrad"])
+def test_fast_tiles_all_layouts(hint, layout):
+    """LDS-DMA fast path (tile_hint 1: 128x128, 2: 256x128, 3: 256x256) vs the generic kernel and torch."""
+    from sfron import ops, _lib
+    M, N, K = 512, 768, 320            # K/64 = 5 tiles: exercises the odd tail of the 2-deep ring
+    gen = torch.Generator().manual_seed(hint * 10 + len(layout))
+    if layout == "fwd":
+        A, B = _rand((M, K), gen), _rand((N, K), gen, 0.1)
+        want = A.float() @ B.float().t()
+        kw = dict()
+    elif layout == "dgrad":
+        A, B = _rand((M, K), gen), _rand((K, N), gen, 0.1)
+        want = A.float() @ B.float()
+        kw = dict(b_t=True)
+    else:
+        A, B = _rand((K, M), gen, 0.1), _rand((K, N), gen)
+        want = A.float().t() @ B.float()
+        kw = dict(a_t=True, b_t=True)
+    Cf = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    Cg = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(A.to(DEV), B.to(DEV), M, N, K, epilogue=_lib.EPI_F32, c_f32=Cf, tile_hint=hint, **kw)
+    ops.gemm(A.to(DEV), B.to(DEV), M, N, K, epilogue=_lib.EPI_F32, c_f32=Cg, tile_hint=-1, **kw)
+    np.testing.assert_allclose(Cf.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4 * K ** 0.5)
+    assert torch.equal(Cf, Cg), "fast and generic kernels accumulate in the same order: results must be identical"

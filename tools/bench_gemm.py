@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of sfron_gemm_bf16 on the DiT-XL/2 B=32 shapes (random bf16 data). GPU only."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from sfron import ops, _lib
+
+DEV = "cuda:0"
+HINT = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+M, D, F = 8192, 1152, 4608
+g = torch.Generator(device=DEV).manual_seed(0)
+def rnd(*s): return (torch.randn(*s, device=DEV, generator=g)).to(torch.bfloat16)
+
+def timeit(fn, iters=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+cases = []
+def fwd(name, N, K, epi=_lib.EPI_BF16):
+    A, B = rnd(M, K), rnd(N, K)
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    kw = {}
+    if epi == _lib.EPI_GELU: kw = dict(aux=torch.empty(M, N, dtype=torch.bfloat16, device=DEV))
+    cases.append((name, 2.0 * M * N * K, lambda: ops.gemm(A, B, M, N, K, epilogue=epi, c_bf16=C, tile_hint=HINT, **kw)))
+def dgrad(name, N, K):   # dX[M,K] = dY[M,N] W[N,K]
+    dY, W = rnd(M, N), rnd(N, K)
+    C = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
+    cases.append((name, 2.0 * M * N * K, lambda: ops.gemm(dY, W, M, K, N, b_t=True, c_bf16=C, tile_hint=HINT)))
+def wgrad(name, N, K):   # dW[N,K] = dY[M,N]^T X[M,K]
+    dY, X = rnd(M, N), rnd(M, K)
+    C = torch.empty(N, K, dtype=torch.float32, device=DEV)
+    cases.append((name, 2.0 * M * N * K, lambda: ops.gemm(dY, X, N, K, M, a_t=True, b_t=True, epilogue=_lib.EPI_F32, c_f32=C, tile_hint=HINT)))
+
+fwd("fwd qkv  N3456 K1152", 3 * D, D); fwd("fwd proj N1152 K1152", D, D)
+fwd("fwd fc1  N4608 K1152 gelu", F, D, _lib.EPI_GELU); fwd("fwd fc2  N1152 K4608", D, F)
+dgrad("dgrad qkv  N3456->1152", 3 * D, D); dgrad("dgrad proj N1152->1152", D, D)
+dgrad("dgrad fc1  N4608->1152", F, D); dgrad("dgrad fc2  N1152->4608", D, F)
+wgrad("wgrad qkv  3456x1152", 3 * D, D); wgrad("wgrad proj 1152x1152", D, D)
+wgrad("wgrad fc1  4608x1152", F, D); wgrad("wgrad fc2  1152x4608", D, F)
+tot_f = tot_t = 0
+for name, fl, fn in cases:
+    ms = timeit(fn)
+    tot_f += fl; tot_t += ms
+    print(f"{name:28s} {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s")
+print(f"hint {HINT} {'block total':21s} {tot_t*1e3:8.1f} us  {tot_f/tot_t/1e9:7.1f} TFLOP/s")

@@ -41,7 +41,7 @@ class GemmDesc(ctypes.Structure):
                 ("bias", c_void_p), ("c_bf16", c_void_p), ("ldc_bf16", c_int), ("c_f32", c_void_p), ("ldc_f32", c_int),
                 ("aux", c_void_p), ("ldaux", c_int), ("gate", c_void_p), ("ldgate", c_int), ("pos", c_void_p),
                 ("tokens", c_int), ("accumulate", c_int), ("resid", c_void_p), ("split_k", c_int),
-                ("split_stride", ctypes.c_long)]
+                ("split_stride", ctypes.c_long), ("tile_hint", c_int)]
 
 
 EPI_BF16, EPI_F32, EPI_GELU, EPI_GATE_RES, EPI_DGELU, EPI_POS = range(6)

@@ -38,20 +38,24 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// tanh-approximate GELU exactly as torch.nn.GELU(approximate="tanh") computes it in fp32:
-//   0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))
-__device__ __forceinline__ float gelu_tanh(float x) {
+// tanh-approximate GELU of torch.nn.GELU(approximate="tanh"): 0.5*x*(1+tanh(u)), u = sqrt(2/pi)*(x+0.044715*x^3).
+// Written through the identity 0.5*(1+tanh(u)) = sigmoid(2u): one v_exp + one v_rcp instead of a tanhf call
+// (the epilogue of the fc1 / fc2-dgrad GEMMs evaluates this 4 times per accumulator register).
+__device__ __forceinline__ float gelu_sig(float x, float& du) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float u = k0 * (x + k1 * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(u));
+  const float x2 = x * x;
+  const float u = k0 * (x + k1 * x * x2);
+  du = k0 * (1.0f + 3.0f * k1 * x2);
+  return __frcp_rn(1.0f + __expf(-2.0f * u));
+}
+__device__ __forceinline__ float gelu_tanh(float x) {
+  float du;
+  return x * gelu_sig(x, du);
 }
 __device__ __forceinline__ float gelu_tanh_grad(float x) {
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float x2 = x * x;
-  float u = k0 * (x + k1 * x * x2);
-  float t = tanhf(u);
-  float du = k0 * (1.0f + 3.0f * k1 * x2);
-  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+  float du;
+  const float s = gelu_sig(x, du);                // 0.5*(1+t); 1 - t^2 = 4 s (1 - s)
+  return s + 2.0f * x * s * (1.0f - s) * du;
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_grad(float x) {

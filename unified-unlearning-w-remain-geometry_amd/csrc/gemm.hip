@@ -15,14 +15,6 @@
 #include "common.h"
 #include "../../include/sfron.h"
 
-namespace {
-
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int NT = 256;
-constexpr int TILE_ELEMS = 128 * 64;   // both image kinds hold 8192 bf16 = 16 KiB
-
-enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_GATE_RES = 3, EPI_DGELU = 4, EPI_POS = 5 };
-
 struct GemmArgs {
   const __bf16* A; const __bf16* B;
   int M, N, K;              // output M x N, contraction K
@@ -40,7 +32,18 @@ struct GemmArgs {
   int kchunk;               // split-K: contraction range per split (multiple of BK); K if no split
   long split_stride;        // split-K: fp32 slab stride (elements) between splits
   int ntm, ntn;
+  int group_m;              // fast path: tile-rows per group of the grouped tile order
 };
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int NT = 256;
+constexpr int TILE_ELEMS = 128 * 64;   // both image kinds hold 8192 bf16 = 16 KiB
+
+enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_GATE_RES = 3, EPI_DGELU = 4, EPI_POS = 5 };
+
+
 
 // ---- LDS images -------------------------------------------------------------------------------
 // direct image: [128 rows][64 k], 128-B rows, 16-B chunk c of row r stored at chunk c ^ (r & 7)
@@ -114,6 +117,47 @@ struct Stager {
     for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(img + lds_off[i]) = r[i];
   }
 };
+
+
+// ---- fused epilogue for 4 consecutive output columns (row, col..col+3) -----------------------------
+template <int EPI>
+__device__ __forceinline__ void epilogue_store(const GemmArgs& g, int row, int col, f32x4 v) {
+  v = v * g.alpha;
+  if (g.bias) {
+    const float4 b = *reinterpret_cast<const float4*>(g.bias + col);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  if (EPI == EPI_BF16) {
+    bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+    *reinterpret_cast<bf16x4*>(g.Cb + (size_t)row * g.ldcb + col) = o;
+  } else if (EPI == EPI_F32) {
+    float4* dst = reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col);
+    float4 o = make_float4(v[0], v[1], v[2], v[3]);
+    if (g.accumulate) { const float4 c = *dst; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+    *dst = o;
+  } else if (EPI == EPI_GELU) {
+    bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+    *reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col) = h;
+    bf16x4 o = {f2bf(gelu_tanh(v[0])), f2bf(gelu_tanh(v[1])), f2bf(gelu_tanh(v[2])), f2bf(gelu_tanh(v[3]))};
+    *reinterpret_cast<bf16x4*>(g.Cb + (size_t)row * g.ldcb + col) = o;
+  } else if (EPI == EPI_GATE_RES) {
+    bf16x4 a = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+    *reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col) = a;
+    const float4 gt = *reinterpret_cast<const float4*>(g.gate + (size_t)(row / g.T) * g.ldgate + col);
+    float4 x = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldcf + col);
+    x.x += gt.x * v[0]; x.y += gt.y * v[1]; x.z += gt.z * v[2]; x.w += gt.w * v[3];
+    *reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col) = x;
+  } else if (EPI == EPI_DGELU) {
+    const bf16x4 h = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)row * g.ldaux + col);
+    bf16x4 o = {f2bf(v[0] * gelu_tanh_grad(bf2f(h[0]))), f2bf(v[1] * gelu_tanh_grad(bf2f(h[1]))),
+                f2bf(v[2] * gelu_tanh_grad(bf2f(h[2]))), f2bf(v[3] * gelu_tanh_grad(bf2f(h[3])))};
+    *reinterpret_cast<bf16x4*>(g.Cb + (size_t)row * g.ldcb + col) = o;
+  } else if (EPI == EPI_POS) {
+    const float4 pe = *reinterpret_cast<const float4*>(g.pos + (size_t)(row % g.T) * g.N + col);
+    *reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col) =
+        make_float4(v[0] + pe.x, v[1] + pe.y, v[2] + pe.z, v[3] + pe.w);
+  }
+}
 
 template <bool A_TR, bool B_TR, int EPI>
 __global__ __launch_bounds__(NT) void k_gemm(GemmArgs g) {
@@ -204,42 +248,7 @@ __global__ __launch_bounds__(NT) void k_gemm(GemmArgs g) {
     for (int nt = 0; nt < 4; ++nt) {
       const int col = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
       if (col >= g.N) continue;
-      f32x4 v = acc[mt][nt] * g.alpha;
-      if (g.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(g.bias + col);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      if (EPI == EPI_BF16) {
-        bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        *reinterpret_cast<bf16x4*>(g.Cb + (size_t)row * g.ldcb + col) = o;
-      } else if (EPI == EPI_F32) {
-        float4* dst = reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col);
-        float4 o = make_float4(v[0], v[1], v[2], v[3]);
-        if (g.accumulate) { const float4 c = *dst; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
-        *dst = o;
-      } else if (EPI == EPI_GELU) {
-        bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        *reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col) = h;
-        bf16x4 o = {f2bf(gelu_tanh(v[0])), f2bf(gelu_tanh(v[1])), f2bf(gelu_tanh(v[2])), f2bf(gelu_tanh(v[3]))};
-        *reinterpret_cast<bf16x4*>(g.Cb + (size_t)row * g.ldcb + col) = o;
-      } else if (EPI == EPI_GATE_RES) {
-        bf16x4 a = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        *reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col) = a;
-        const float4 gt = *reinterpret_cast<const float4*>(g.gate + (size_t)(row / g.T) * g.ldgate + col);
-        float4* xp = reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col);
-        float4 x = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldcf + col);
-        x.x += gt.x * v[0]; x.y += gt.y * v[1]; x.z += gt.z * v[2]; x.w += gt.w * v[3];
-        *xp = x;
-      } else if (EPI == EPI_DGELU) {
-        const bf16x4 h = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)row * g.ldaux + col);
-        bf16x4 o = {f2bf(v[0] * gelu_tanh_grad(bf2f(h[0]))), f2bf(v[1] * gelu_tanh_grad(bf2f(h[1]))),
-                    f2bf(v[2] * gelu_tanh_grad(bf2f(h[2]))), f2bf(v[3] * gelu_tanh_grad(bf2f(h[3])))};
-        *reinterpret_cast<bf16x4*>(g.Cb + (size_t)row * g.ldcb + col) = o;
-      } else if (EPI == EPI_POS) {
-        const float4 pe = *reinterpret_cast<const float4*>(g.pos + (size_t)(row % g.T) * g.N + col);
-        *reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col) =
-            make_float4(v[0] + pe.x, v[1] + pe.y, v[2] + pe.z, v[3] + pe.w);
-      }
+      epilogue_store<EPI>(g, row, col, acc[mt][nt]);
     }
   }
 }
@@ -253,11 +262,280 @@ int launch(const GemmArgs& g, hipStream_t s) {
   return e == hipSuccess ? SFRON_OK : (int)e;
 }
 
+
+// =================================================================================================
+// Fast path: full tiles only (M % BM == N % BN == K % 64 == 0).  LDS-DMA staging
+// (global_load_lds_dwordx4: no VGPR round trip, no ds_write, swizzle applied on the per-lane SOURCE
+// address), 2-deep LDS ring, one raw s_barrier per K-tile: tile t+1 streams in while tile t feeds
+// the matrix cores.  WM x WN waves, each MT x NT MFMA tiles.
+// =================================================================================================
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+// transposed-read image [64 k-rows][COLS]: XOR applied to the 16-B chunk index of row r.  Derived from the
+// ds_read_b64_tr_b16 bank rule (64 banks x 4 B, conflicts counted per 32-lane half = rows r..r+3 and r+8..r+11):
+//   COLS 128/256/384 (row stride = 0 mod 256 B): 4-bit XOR ((r&3)<<2)|((r>>2)&3) inside each 16-chunk group
+//   COLS 192 (row stride = 128 mod 256 B): 2-bit XOR on the chunk-pair index inside each 8-chunk group
+template <int COLS> __device__ __forceinline__ int swz_chunk(int r, int ch) {
+  if (COLS == 192) return ch ^ ((((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1);
+  return (ch & ~15) | ((ch & 15) ^ swz_tr(r));
+}
+
+// Per-lane source offsets (elements, 32-bit) of the wave's LDS-DMA instructions for one operand tile; the
+// per-K-tile advance is wave-uniform, so the loads use the saddr + voffset form (no 64-bit VGPR addresses).
+// LDS image is lane-linear (1 KiB per wave-instruction); the swizzle lives in the SOURCE address.
+template <int EXT, bool TR, int NW>
+struct GldsPlan {
+  static constexpr int CPR = TR ? EXT / 8 : 8;              // 16-B chunks per image row
+  static constexpr int NINSTR = (TR ? 64 : EXT) * CPR / 64; // wave-instructions per tile
+  static constexpr int PER_WAVE = NINSTR / NW;
+  static_assert(NINSTR % NW == 0, "tile must split evenly over the waves");
+  int off[PER_WAVE];        // byte offsets (voffset of the buffer load)
+  __device__ __forceinline__ void init(int ld, int d0, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int e = (wave + i * NW) * 64 + lane;            // linear chunk index inside the image
+      const int row = e / CPR, p = e % CPR;
+      if (!TR) off[i] = 2 * ((d0 + row) * ld + ((p ^ (row & 7)) << 3));
+      else     off[i] = 2 * (row * ld + d0 + (swz_chunk<EXT>(row, p) << 3));
+    }
+  }
+  // buffer_load_dwordx4 ... offen lds: SRD (uniform) + per-lane voffset (loop invariant) + uniform soffset (K advance)
+  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rsrc, int soff_bytes, __bf16* img, int wave) const {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t*)(img + (wave + i * NW) * 512), 16, off[i], soff_bytes, 0, 0);
+  }
+};
+
+template <int COLS>
+__device__ __forceinline__ bf16x8 frag_tr_w(const __bf16* img, int col0, int kr0, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const int ch = (col0 >> 3) + (p >> 1);
+  const int r0 = kr0 + 8 * g + q;
+  const int o0 = r0 * COLS + (swz_chunk<COLS>(r0, ch) << 3) + 4 * (p & 1);
+  const int o1 = (r0 + 4) * COLS + (swz_chunk<COLS>(r0 + 4, ch) << 3) + 4 * (p & 1);
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + o0));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + o1));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+}  // namespace  (kernel templates get external linkage: hipcc does not emit the kernel handle of an
+   //             internal-linkage template instantiation that is only referenced through a launch)
+
+template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void k_gemm_fast(GemmArgs g) {
+  constexpr int FBM = WM * MT * 16, FBN = WN * NT * 16, NW = WM * WN;
+  constexpr int A_ELEMS = FBM * 64, B_ELEMS = FBN * 64;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+  __bf16* sA0 = smem;
+  __bf16* sA1 = smem + A_ELEMS;
+  __bf16* sB0 = smem + 2 * A_ELEMS;
+  __bf16* sB1 = smem + 2 * A_ELEMS + B_ELEMS;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int nblk = gridDim.x;
+  int id;
+  {
+    const int b = blockIdx.x, q = nblk >> 3, r = nblk & 7, x = b & 7, y = b >> 3;
+    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+  }
+  // grouped order: ids sweep GROUP_M tile-rows x all tile-columns, so the ~n/8 consecutive tiles one XCD owns
+  // form a 2-D block whose A row-panels and B column-panels are both re-used out of that XCD's L2
+  const int per_group = g.group_m * g.ntn;
+  const int first_m = (id / per_group) * g.group_m;
+  const int gsz = min(g.ntm - first_m, g.group_m);
+  const int tm = first_m + (id % per_group) % gsz, tn = (id % per_group) / gsz;
+  const int m0 = tm * FBM, n0 = tn * FBN;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  GldsPlan<FBM, A_TR, NW> planA;
+  GldsPlan<FBN, B_TR, NW> planB;
+  planA.init(g.lda, m0, wave, lane);
+  planB.init(g.ldb, n0, wave, lane);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, 0x7fffffff, 0x00020000);
+  auto stage = [&](__bf16* iA, __bf16* iB, int k0) {
+    planA.issue(rsA, 2 * (A_TR ? k0 * g.lda : k0), iA, wave);
+    planB.issue(rsB, 2 * (B_TR ? k0 * g.ldb : k0), iB, wave);
+  };
+  auto load_a = [&](const __bf16* iA, int mt, int ks) -> bf16x8 {
+    if (!A_TR) return frag_direct(iA, wm * MT * 16 + mt * 16 + (lane & 15), ks * 4 + (lane >> 4));
+    return frag_tr_w<FBM>(iA, wm * MT * 16 + mt * 16, ks * 32, lane);
+  };
+  auto load_b = [&](const __bf16* iB, int nt, int ks) -> bf16x8 {
+    if (!B_TR) return frag_direct(iB, wn * NT * 16 + nt * 16 + (lane & 15), ks * 4 + (lane >> 4));
+    return frag_tr_w<FBN>(iB, wn * NT * 16 + nt * 16, ks * 32, lane);
+  };
+  // hold the operand with fewer fragments in registers, stream the other: bounded live ranges (acc dominates)
+  auto compute = [&](const __bf16* iA, const __bf16* iB) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (NT <= MT) {
+        bf16x8 fb[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) fb[nt] = load_b(iB, nt, ks);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const bf16x8 fa = load_a(iA, mt, ks);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa, acc[mt][nt], 0, 0, 0);
+        }
+      } else {
+        bf16x8 fa[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) fa[mt] = load_a(iA, mt, ks);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const bf16x8 fb = load_b(iB, nt, ks);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[mt], acc[mt][nt], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  const int nk = g.K / BK;
+  stage(sA0, sB0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int kt = 0;
+  for (; kt + 2 <= nk - 1; kt += 2) {
+    stage(sA1, sB1, (kt + 1) * BK);
+    compute(sA0, sB0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    stage(sA0, sB0, (kt + 2) * BK);
+    compute(sA1, sB1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  if (kt + 1 <= nk - 1) {          // two tiles left: kt (in buffer 0) and kt+1
+    stage(sA1, sB1, (kt + 1) * BK);
+    compute(sA0, sB0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    compute(sA1, sB1);
+  } else {                          // one tile left, in buffer 0
+    compute(sA0, sB0);
+  }
+
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = m0 + wm * MT * 16 + mt * 16 + (lane & 15);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = n0 + wn * NT * 16 + nt * 16 + 4 * (lane >> 4);
+      epilogue_store<EPI>(g, row, col, acc[mt][nt]);
+    }
+  }
+}
+
+
+// explicit instantiations (hipcc / ROCm 7.2 does not reliably instantiate a kernel template that is only reached
+// through a nested host template; without these the host stubs of some tiles are missing at dlopen time)
+#define SFRON_INST_TILE(WM, WN, MT, NT)                                              \
+  template __global__ void k_gemm_fast<WM, WN, MT, NT, false, false, 0>(GemmArgs);  \
+  template __global__ void k_gemm_fast<WM, WN, MT, NT, false, false, 1>(GemmArgs);  \
+  template __global__ void k_gemm_fast<WM, WN, MT, NT, false, false, 2>(GemmArgs);  \
+  template __global__ void k_gemm_fast<WM, WN, MT, NT, false, false, 3>(GemmArgs);  \
+  template __global__ void k_gemm_fast<WM, WN, MT, NT, false, false, 5>(GemmArgs);  \
+  template __global__ void k_gemm_fast<WM, WN, MT, NT, false, true, 0>(GemmArgs);   \
+  template __global__ void k_gemm_fast<WM, WN, MT, NT, false, true, 1>(GemmArgs);   \
+  template __global__ void k_gemm_fast<WM, WN, MT, NT, false, true, 4>(GemmArgs);   \
+  template __global__ void k_gemm_fast<WM, WN, MT, NT, true, true, 0>(GemmArgs);    \
+  template __global__ void k_gemm_fast<WM, WN, MT, NT, true, true, 1>(GemmArgs);
+SFRON_INST_TILE(2, 2, 4, 4)
+SFRON_INST_TILE(4, 2, 4, 6)
+SFRON_INST_TILE(2, 4, 8, 4)
+SFRON_INST_TILE(4, 2, 6, 6)
+SFRON_INST_TILE(4, 2, 3, 6)
+SFRON_INST_TILE(2, 2, 8, 6)
+SFRON_INST_TILE(2, 2, 6, 6)
+#undef SFRON_INST_TILE
+
+namespace {
+
+template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI>
+int launch_fast(GemmArgs g, hipStream_t s) {
+  constexpr int FBM = WM * MT * 16, FBN = WN * NT * 16;
+  g.ntm = g.M / FBM; g.ntn = g.N / FBN;
+  {
+    // an XCD owns ~tiles/8 consecutive ids: make that run a near-square (in bytes) block of gm x gn tiles
+    const double per_xcd = (double)g.ntm * g.ntn / 8.0;
+    int gm = 1;
+    while (gm * 2 <= g.ntm && (double)(gm * 2) * (gm * 2) * FBM <= per_xcd * FBN * 1.5) gm *= 2;
+    g.group_m = gm;
+  }
+  const size_t lds = 2 * (FBM + FBN) * 64 * sizeof(__bf16);
+  if (lds > 65536) {
+    static bool done = false;      // per instantiation
+    if (!done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_fast<WM, WN, MT, NT, A_TR, B_TR, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return (int)hipGetLastError();
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL((k_gemm_fast<WM, WN, MT, NT, A_TR, B_TR, EPI>), dim3(g.ntm * g.ntn), dim3(WM * WN * 64), lds, s, g);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SFRON_OK : (int)e;
+}
+
+// fast tiles: 1 = 128x128 (4 waves), 2 = 256x192, 3 = 256x256, 4 = 384x192 (8 waves); 0 = generic kernel.
+// 8-wave tiles halve the L1->LDS bytes per FLOP of the 128x128 tile (which is vector-memory bound at ~600 TF).
+constexpr int N_TILES = 8;
+static const int TILE_BM[N_TILES] = {0, 128, 256, 256, 384, 192, 256, 192};
+static const int TILE_BN[N_TILES] = {0, 128, 192, 256, 192, 192, 192, 192};
+inline bool tile_fits(const GemmArgs& g, int t) {
+  return t >= 1 && t < N_TILES && g.M % TILE_BM[t] == 0 && g.N % TILE_BN[t] == 0;
+}
+inline int pick_fast_tile(const GemmArgs& g, int force) {
+  if (g.K % 64 || g.kchunk != g.K || force < 0) return 0;
+  if (force > 0) return tile_fits(g, force) ? force : 0;
+  // prefer the 8-wave tile with the best last-round occupancy of the 256 CUs; small problems keep 128x128
+  int best = 0; double best_eff = 0.0;
+  for (int t = 2; t <= 2; ++t) {
+    if (!tile_fits(g, t)) continue;
+    const long tiles = (long)(g.M / TILE_BM[t]) * (g.N / TILE_BN[t]);
+    const double eff = (double)tiles / (double)(((tiles + 255) / 256) * 256);
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = t; }
+  }
+  if (best && best_eff >= 0.5) return best;
+  return tile_fits(g, 1) ? 1 : 0;
+}
+
+template <bool A_TR, bool B_TR, int EPI>
+int launch_any(const GemmArgs& g, hipStream_t s, int force) {
+  switch (pick_fast_tile(g, force)) {
+    case 1: return launch_fast<2, 2, 4, 4, A_TR, B_TR, EPI>(g, s);
+    case 2: return launch_fast<4, 2, 4, 6, A_TR, B_TR, EPI>(g, s);
+    case 3: return launch_fast<2, 4, 8, 4, A_TR, B_TR, EPI>(g, s);
+    case 4: return launch_fast<4, 2, 6, 6, A_TR, B_TR, EPI>(g, s);
+    case 5: return launch_fast<4, 2, 3, 6, A_TR, B_TR, EPI>(g, s);
+    case 6: return launch_fast<2, 2, 8, 6, A_TR, B_TR, EPI>(g, s);
+    case 7: return launch_fast<2, 2, 6, 6, A_TR, B_TR, EPI>(g, s);
+    default: return launch<A_TR, B_TR, EPI>(g, s);
+  }
+}
+
 template <int EPI>
-int dispatch_layout(int a_tr, int b_tr, const GemmArgs& g, hipStream_t s) {
-  if (!a_tr && !b_tr) return launch<false, false, EPI>(g, s);
-  if (!a_tr && b_tr) return launch<false, true, EPI>(g, s);
-  if (a_tr && b_tr) return launch<true, true, EPI>(g, s);
+int dispatch_layout(int a_tr, int b_tr, const GemmArgs& g, hipStream_t s, int force) {
+  if (!a_tr && !b_tr) return launch_any<false, false, EPI>(g, s, force);
+  if (!a_tr && b_tr) return launch_any<false, true, EPI>(g, s, force);
+  if (a_tr && b_tr) return launch_any<true, true, EPI>(g, s, force);
   return SFRON_ERR_UNSUPPORTED;
 }
 
@@ -289,26 +567,27 @@ extern "C" int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
   }
   g.ntm = cdiv(d->M, BM); g.ntn = cdiv(d->N, BN);
   hipStream_t s = (hipStream_t)stream;
+  const int force = d->tile_hint;   // 0 auto, -1 generic kernel, 1/2/3 force a fast tile (tests, tuning)
   switch (d->epilogue) {
     case SFRON_EPI_BF16:
       SFRON_CHECK_ARG(g.Cb && g.ldcb % 4 == 0);
-      return dispatch_layout<EPI_BF16>(d->a_transposed, d->b_transposed, g, s);
+      return dispatch_layout<EPI_BF16>(d->a_transposed, d->b_transposed, g, s, force);
     case SFRON_EPI_F32:
       SFRON_CHECK_ARG(g.Cf && g.ldcf % 4 == 0);
-      return dispatch_layout<EPI_F32>(d->a_transposed, d->b_transposed, g, s);
+      return dispatch_layout<EPI_F32>(d->a_transposed, d->b_transposed, g, s, force);
     case SFRON_EPI_GELU:
       SFRON_CHECK_ARG(g.Cb && g.aux && g.ldcb % 4 == 0 && g.ldaux % 4 == 0 && !d->a_transposed && !d->b_transposed);
-      return launch<false, false, EPI_GELU>(g, s);
+      return launch_any<false, false, EPI_GELU>(g, s, force);
     case SFRON_EPI_GATE_RES:
       SFRON_CHECK_ARG(g.Cf && g.aux && g.gate && g.ldcf % 4 == 0 && g.ldaux % 4 == 0 && g.ldgate % 4 == 0 &&
                       !d->a_transposed && !d->b_transposed);
-      return launch<false, false, EPI_GATE_RES>(g, s);
+      return launch_any<false, false, EPI_GATE_RES>(g, s, force);
     case SFRON_EPI_DGELU:
       SFRON_CHECK_ARG(g.Cb && g.aux && g.ldcb % 4 == 0 && g.ldaux % 4 == 0 && !d->a_transposed && d->b_transposed);
-      return launch<false, true, EPI_DGELU>(g, s);
+      return launch_any<false, true, EPI_DGELU>(g, s, force);
     case SFRON_EPI_POS:
       SFRON_CHECK_ARG(g.Cf && g.pos && g.ldcf % 4 == 0 && !d->a_transposed && !d->b_transposed);
-      return launch<false, false, EPI_POS>(g, s);
+      return launch_any<false, false, EPI_POS>(g, s, force);
     default:
       return SFRON_ERR_UNSUPPORTED;
   }

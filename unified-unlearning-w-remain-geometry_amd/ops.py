@@ -9,7 +9,7 @@ from ._lib import check, ptr, stream_ptr
 
 
 def gemm(A, B, M, N, K, *, a_t=False, b_t=False, epilogue=_lib.EPI_BF16, alpha=1.0, bias=None, c_bf16=None,
-         c_f32=None, aux=None, gate=None, pos=None, tokens=1, accumulate=False, resid=None, split_k=1, split_stride=0,
+         c_f32=None, aux=None, gate=None, pos=None, tokens=1, accumulate=False, resid=None, split_k=1, split_stride=0, tile_hint=0,
          lda=None, ldb=None, ldc_bf16=None, ldc_f32=None, ldaux=None, ldgate=None):
     """C[M,N] = alpha * op(A) op(B) with the epilogues of include/sfron.h.  A/B are bf16 2-D tensors (or views
     described by explicit leading dimensions)."""
@@ -34,7 +34,7 @@ def gemm(A, B, M, N, K, *, a_t=False, b_t=False, epilogue=_lib.EPI_BF16, alpha=1
     d.tokens, d.accumulate = tokens, int(accumulate)
     if resid is not None:
         d.resid = resid.data_ptr()
-    d.split_k, d.split_stride = split_k, split_stride
+    d.split_k, d.split_stride, d.tile_hint = split_k, split_stride, tile_hint
     for t in (A, B, c_bf16, c_f32, aux, gate, pos):
         if t is not None and not t.is_cuda:
             raise _lib.SfronError("sfron ops need GPU tensors (no CPU fallback)")
