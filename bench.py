@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=1, help="batch of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-batch", type=int, default=8, help="batch of the bounded CPU-baseline sample")
     return ap.parse_args()
 
 

@@ -147,6 +147,14 @@ int sfron_gate_bwd(const float* dy, const uint16_t* branch, const float* gate, i
 /* out[g * ldout + c] (+)= sum_{j < per_group} partials[(g * per_group + j) * D + c]   (fixed order, reproducible) */
 int sfron_reduce_chunks(const float* partials, int groups, int per_group, int D, float* out, int ldout, int accumulate,
                         void* stream);
+/* two partial buffers in one launch: out0[g*ld0 + c] = sum_j p0[(g*per_group + j)*D + c], out1 likewise from p1 */
+int sfron_reduce2(const float* p0, const float* p1, int groups, int per_group, int D, float* out0, int ld0, float* out1,
+                  int ld1, void* stream);
+/* bias gradients behind the adaLN gates of all blocks at once (proj.bias: which = 0, fc2.bias: which = 1):
+ * out[l*out_stride + out_which{0,1} + c] = sum_b gate[b*ldg + l*gate_stride + which*gate_which + c] * S[((2l+which)*B + b)*D + c]
+ * where S holds the per-sample token sums of the upstream gradient (second output of sfron_gate_bwd, reduced). */
+int sfron_gated_bias_grads(const float* S, const float* gate, int ldg, long gate_stride, long gate_which, int layers, int B,
+                           int D, float* out, long out_stride, long out_which0, long out_which1, void* stream);
 /* out[c] = sum_g w[g * ldw + c] * sum_j partials[(g * per_group + j) * D + c]      (bias grad behind a gate) */
 int sfron_weighted_reduce(const float* partials, int groups, int per_group, int D, const float* w, int ldw, float* out,
                           void* stream);

@@ -54,6 +54,9 @@ _PROTOS.update({
     "sfron_gate_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _S]),
     "sfron_reduce_chunks": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, _S]),
     "sfron_weighted_reduce": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, _S]),
+    "sfron_reduce2": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _S]),
+    "sfron_gated_bias_grads": (c_int, [_P, _P, c_int, ctypes.c_long, ctypes.c_long, c_int, c_int, c_int, _P, ctypes.c_long,
+                                       ctypes.c_long, ctypes.c_long, _S]),
     "sfron_colsum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, _S]),
     "sfron_timestep_embed": (c_int, [_P, c_int, c_int, _P, c_int, _S]),
     "sfron_silu_fwd": (c_int, [_P, c_int64, _P, _S]),

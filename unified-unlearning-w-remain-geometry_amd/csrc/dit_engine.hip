@@ -74,7 +74,7 @@ struct Workspace {
   __bf16* xmodf;
   float* tok;
   // backward temporaries
-  float *dx, *dmod, *d_sc, *d_c, *d_h1s, *delta, *part, *csum, *slabs;
+  float *dx, *dmod, *d_sc, *d_c, *d_h1s, *delta, *part, *csum, *slabs, *dysum;
   __bf16 *d_tok, *d_br, *d_hpre, *d_xmod, *d_o, *dqkv, *dmod_bf, *d_c_bf, *d_h1_bf, *dx_bf;
   size_t bytes;
 };
@@ -110,6 +110,7 @@ inline Workspace make_ws(const Dims& d, char* base) {
   const size_t widest = (size_t)(d.F > 3 * d.D ? d.F : 3 * d.D) > (size_t)d.NM ? (size_t)(d.F > 3 * d.D ? d.F : 3 * d.D) : (size_t)d.NM;
   w.csum = (float*)take(CSUM_PARTS * widest * 4);
   w.slabs = (float*)take((size_t)SPLIT_K_ADA * B * D * 4);
+  w.dysum = (float*)take(L * 2 * B * D * 4);                       // [L][proj|fc2][B][D] token sums of dy (gated bias grads)
   w.d_tok = (__bf16*)take(M * (size_t)d.Po * 2);
   w.d_br = (__bf16*)take(M * D * 2); w.d_hpre = (__bf16*)take(M * (size_t)d.F * 2); w.d_xmod = (__bf16*)take(M * D * 2);
   w.d_o = (__bf16*)take(M * D * 2); w.dqkv = (__bf16*)take(M * 3 * D * 2); w.dx_bf = (__bf16*)take(M * D * 2);
@@ -313,8 +314,7 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
   float* dmodf = w.dmod + (size_t)6 * d.L * D;
   RUN(sfron_ln_modulate_bwd((const uint16_t*)w.d_xmod, w.xs + (size_t)(2 * d.L) * M * D, w.mean + (size_t)(2 * d.L) * M,
                             w.rstd + (size_t)(2 * d.L) * M, modf + D, NM, T, M, D, w.dx, 0, part0, part1, stream));
-  RUN(sfron_reduce_chunks(part0, B, per, D, dmodf, NM, 0, stream));
-  RUN(sfron_reduce_chunks(part1, B, per, D, dmodf + D, NM, 0, stream));
+  RUN(sfron_reduce2(part0, part1, B, per, D, dmodf, NM, dmodf + D, NM, stream));
 
   for (int l = d.L - 1; l >= 0; --l) {
     const int64_t pb = P.blocks + (int64_t)l * P.blk_stride;
@@ -328,8 +328,7 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
     const __bf16* h = w.h + (size_t)l * M * d.F; const __bf16* a2 = w.a2 + (size_t)l * M * D;
     // ---- MLP branch: x2 = x1 + gate_mlp * (fc2(gelu(fc1(xmod2))))
     RUN(sfron_gate_bwd(w.dx, (const uint16_t*)a2, mod + 5 * D, NM, T, M, D, (uint16_t*)w.d_br, part0, part1, stream));
-    RUN(sfron_reduce_chunks(part0, B, per, D, dmod + 5 * D, NM, 0, stream));
-    RUN(sfron_weighted_reduce(part1, B, per, D, mod + 5 * D, NM, grads + pb + P.o_fc2_b, stream));
+    RUN(sfron_reduce2(part0, part1, B, per, D, dmod + 5 * D, NM, w.dysum + ((size_t)(2 * l + 1) * B) * D, D, stream));
     g = wgrad_desc(w.d_br, h, M, D, d.F, grads + pb + P.o_fc2_w);
     RUN(sfron_gemm_bf16(&g, stream));
     g = dgrad_desc(w.d_br, wb + pb + P.o_fc2_w, M, D, d.F);
@@ -343,12 +342,10 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
     RUN(sfron_gemm_bf16(&g, stream));
     RUN(sfron_ln_modulate_bwd((const uint16_t*)w.d_xmod, x1, w.mean + (size_t)(2 * l + 1) * M, w.rstd + (size_t)(2 * l + 1) * M,
                               mod + 4 * D, NM, T, M, D, w.dx, 1, part0, part1, stream));
-    RUN(sfron_reduce_chunks(part0, B, per, D, dmod + 3 * D, NM, 0, stream));
-    RUN(sfron_reduce_chunks(part1, B, per, D, dmod + 4 * D, NM, 0, stream));
+    RUN(sfron_reduce2(part0, part1, B, per, D, dmod + 3 * D, NM, dmod + 4 * D, NM, stream));
     // ---- attention branch: x1 = x0 + gate_msa * proj(attn(qkv(xmod1)))
     RUN(sfron_gate_bwd(w.dx, (const uint16_t*)a1, mod + 2 * D, NM, T, M, D, (uint16_t*)w.d_br, part0, part1, stream));
-    RUN(sfron_reduce_chunks(part0, B, per, D, dmod + 2 * D, NM, 0, stream));
-    RUN(sfron_weighted_reduce(part1, B, per, D, mod + 2 * D, NM, grads + pb + P.o_proj_b, stream));
+    RUN(sfron_reduce2(part0, part1, B, per, D, dmod + 2 * D, NM, w.dysum + ((size_t)(2 * l) * B) * D, D, stream));
     g = wgrad_desc(w.d_br, o, M, D, D, grads + pb + P.o_proj_w);
     RUN(sfron_gemm_bf16(&g, stream));
     g = dgrad_desc(w.d_br, wb + pb + P.o_proj_w, M, D, D);
@@ -364,9 +361,11 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
     RUN(sfron_gemm_bf16(&g, stream));
     RUN(sfron_ln_modulate_bwd((const uint16_t*)w.d_xmod, x0, w.mean + (size_t)(2 * l) * M, w.rstd + (size_t)(2 * l) * M,
                               mod + D, NM, T, M, D, w.dx, 1, part0, part1, stream));
-    RUN(sfron_reduce_chunks(part0, B, per, D, dmod, NM, 0, stream));
-    RUN(sfron_reduce_chunks(part1, B, per, D, dmod + D, NM, 0, stream));
+    RUN(sfron_reduce2(part0, part1, B, per, D, dmod, NM, dmod + D, NM, stream));
   }
+  // proj.bias / fc2.bias gradients of every block: sum_b gate[b] * (sum_t dy[b,t])
+  RUN(sfron_gated_bias_grads(w.dysum, w.mod + 2 * D, NM, 6 * D, 3 * D, d.L, B, D, grads + P.blocks, P.blk_stride, P.o_proj_b,
+                             P.o_fc2_b, stream));
   // ---- patch embed (pos_embed is frozen: no gradient)
   RUN(sfron_cast_bf16(w.dx, (uint16_t*)w.dx_bf, (int64_t)M * D, stream));
   RUN(sfron_colsum(w.dx, 0, M, D, D, w.csum, CSUM_PARTS, grads + P.pe_b, stream));

@@ -247,6 +247,34 @@ __global__ __launch_bounds__(TPB) void k_weighted_reduce(const float* __restrict
   out[c] = tot;
 }
 
+// two partial buffers at once: out0[g*ld0 + c] = sum_j P0[(g*per+j)*D + c]; out1 likewise from P1
+__global__ __launch_bounds__(TPB) void k_reduce2(const float* __restrict__ P0, const float* __restrict__ P1, int per_group, int D,
+                                                 float* __restrict__ out0, int ld0, float* __restrict__ out1, int ld1) {
+  const int g = blockIdx.y;
+  const int c = blockIdx.x * TPB + threadIdx.x;
+  if (c >= D) return;
+  const size_t base = (size_t)g * per_group * D + c;
+  float s0 = 0.f, s1 = 0.f;
+  for (int j = 0; j < per_group; ++j) { s0 += P0[base + (size_t)j * D]; s1 += P1[base + (size_t)j * D]; }
+  out0[(size_t)g * ld0 + c] = s0;
+  out1[(size_t)g * ld1 + c] = s1;
+}
+
+// bias gradients behind the gates of every block in one launch:
+//   out[l * out_stride + which * out_which + c] = sum_b gate[b * ldg + l * gate_stride + which * gate_which + c] * S[((l*2+which)*B + b) * D + c]
+__global__ __launch_bounds__(TPB) void k_gated_bias_grads(const float* __restrict__ S, const float* __restrict__ gate, int ldg,
+                                                          long gate_stride, long gate_which, int B, int D, float* __restrict__ out,
+                                                          long out_stride, long out_which0, long out_which1) {
+  const int l = blockIdx.y >> 1, which = blockIdx.y & 1;
+  const int c = blockIdx.x * TPB + threadIdx.x;
+  if (c >= D) return;
+  const float* s = S + ((size_t)(l * 2 + which) * B) * D + c;
+  const float* gt = gate + (size_t)l * gate_stride + (which ? gate_which : 0) + c;
+  float t = 0.f;
+  for (int b = 0; b < B; ++b) t += gt[(size_t)b * ldg] * s[(size_t)b * D];
+  out[(size_t)l * out_stride + (which ? out_which1 : out_which0) + c] = t;
+}
+
 // column sums of a [M][N] matrix: stage 1 writes partials[chunk][N]; the caller finishes with k_reduce_chunks
 template <typename T>
 __global__ __launch_bounds__(TPB) void k_colsum_partial(const T* __restrict__ X, int M, int N, int ld, int rows_per_block,
@@ -276,9 +304,11 @@ __global__ __launch_bounds__(TPB) void k_colsum_partial(const T* __restrict__ X,
   }
 }
 
+// rows per wave of the backward elementwise kernels: 2 (8 rows per workgroup -> M/8 workgroups keep every CU's
+// memory pipeline full; 32-row workgroups left the chip at 1 workgroup per CU and ~2.2 TB/s)
 inline int pick_rpw(int T) {
-  for (int r = 8; r >= 1; r >>= 1)
-    if (T % (4 * r) == 0) return r;
+  if (T % 8 == 0) return 2;
+  if (T % 4 == 0) return 1;
   return 0;
 }
 
@@ -331,6 +361,24 @@ int sfron_reduce_chunks(const float* partials, int groups, int per_group, int D,
   SFRON_CHECK_ARG(partials && out && groups > 0 && per_group > 0 && D > 0);
   hipLaunchKernelGGL(k_reduce_chunks, dim3(cdiv(D, TPB), groups), dim3(TPB), 0, (hipStream_t)stream, partials, per_group, D,
                      out, ldout, accumulate);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_reduce2(const float* p0, const float* p1, int groups, int per_group, int D, float* out0, int ld0, float* out1,
+                  int ld1, void* stream) {
+  SFRON_CHECK_ARG(p0 && p1 && out0 && out1 && groups > 0 && per_group > 0 && D > 0);
+  hipLaunchKernelGGL(k_reduce2, dim3(cdiv(D, TPB), groups), dim3(TPB), 0, (hipStream_t)stream, p0, p1, per_group, D, out0, ld0,
+                     out1, ld1);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_gated_bias_grads(const float* S, const float* gate, int ldg, long gate_stride, long gate_which, int layers, int B,
+                           int D, float* out, long out_stride, long out_which0, long out_which1, void* stream) {
+  SFRON_CHECK_ARG(S && gate && out && layers > 0 && B > 0 && D > 0);
+  hipLaunchKernelGGL(k_gated_bias_grads, dim3(cdiv(D, TPB), 2 * layers), dim3(TPB), 0, (hipStream_t)stream, S, gate, ldg,
+                     gate_stride, gate_which, B, D, out, out_stride, out_which0, out_which1);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }
