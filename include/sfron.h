@@ -225,9 +225,13 @@ int sfron_probe_create(int max_samples, void** probe /* HOST out */);
 int sfron_probe_reset(void* probe);
 int sfron_probe_read(void* probe, int* n_samples, double* total_ms);   /* synchronises on the recorded events */
 int sfron_probe_destroy(void* probe);
-/* grads (arena layout, trainable part fully overwritten) = d loss / d params given d_out = d loss / d out */
+/* grads (arena layout, trainable part fully overwritten) = d loss / d params given d_out = d loss / d out.
+ * aux (from sfron_aux_create, may be NULL): a side HIP stream + events; the weight-gradient GEMMs and bias column
+ * sums then run concurrently with the dgrad / elementwise chain and join `stream` before the call's work ends. */
 int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* d_out,
-                       const int64_t* y, const uint8_t* drop, void* workspace, float* grads, void* stream);
+                       const int64_t* y, const uint8_t* drop, void* workspace, float* grads, void* aux, void* stream);
+int sfron_aux_create(void** aux /* HOST out */);
+int sfron_aux_destroy(void* aux);
 
 #ifdef __cplusplus
 }

@@ -81,7 +81,9 @@ _PROTOS.update({
     "sfron_dit_param_layout": (c_int, [POINTER(DitCfg), POINTER(c_int64), c_int]),
     "sfron_dit_workspace_bytes": (c_int64, [POINTER(DitCfg)]),
     "sfron_dit_forward": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _S]),
-    "sfron_dit_backward": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _S]),
+    "sfron_dit_backward": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _S]),
+    "sfron_aux_create": (c_int, [POINTER(c_void_p)]),
+    "sfron_aux_destroy": (c_int, [c_void_p]),
     "sfron_dit_forward_probed": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_probe_create": (c_int, [c_int, POINTER(c_void_p)]),
     "sfron_probe_reset": (c_int, [c_void_p]),

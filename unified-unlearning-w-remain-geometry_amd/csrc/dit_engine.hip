@@ -74,8 +74,8 @@ struct Workspace {
   __bf16* xmodf;
   float* tok;
   // backward temporaries
-  float *dx, *dmod, *d_sc, *d_c, *d_h1s, *delta, *part, *csum, *slabs, *dysum;
-  __bf16 *d_tok, *d_br, *d_hpre, *d_xmod, *d_o, *dqkv, *dmod_bf, *d_c_bf, *d_h1_bf, *dx_bf;
+  float *dx, *dmod, *d_sc, *d_c, *d_h1s, *delta, *part, *csum, *csum2, *slabs, *dysum;
+  __bf16 *d_tok, *d_br, *d_br2, *d_hpre, *d_xmod, *d_o, *dqkv, *dmod_bf, *d_c_bf, *d_h1_bf, *dx_bf;
   size_t bytes;
 };
 constexpr int SPLIT_K_ADA = 64;
@@ -109,10 +109,11 @@ inline Workspace make_ws(const Dims& d, char* base) {
   w.part = (float*)take(4 * (M / 4) * D * 4);                       // 4 partial buffers, worst case 4 rows per chunk
   const size_t widest = (size_t)(d.F > 3 * d.D ? d.F : 3 * d.D) > (size_t)d.NM ? (size_t)(d.F > 3 * d.D ? d.F : 3 * d.D) : (size_t)d.NM;
   w.csum = (float*)take(CSUM_PARTS * widest * 4);
+  w.csum2 = (float*)take(CSUM_PARTS * (size_t)(d.F > 3 * d.D ? d.F : 3 * d.D) * 4);   // side-stream colsum scratch
   w.slabs = (float*)take((size_t)SPLIT_K_ADA * B * D * 4);
   w.dysum = (float*)take(L * 2 * B * D * 4);                       // [L][proj|fc2][B][D] token sums of dy (gated bias grads)
   w.d_tok = (__bf16*)take(M * (size_t)d.Po * 2);
-  w.d_br = (__bf16*)take(M * D * 2); w.d_hpre = (__bf16*)take(M * (size_t)d.F * 2); w.d_xmod = (__bf16*)take(M * D * 2);
+  w.d_br = (__bf16*)take(M * D * 2); w.d_br2 = (__bf16*)take(M * D * 2); w.d_hpre = (__bf16*)take(M * (size_t)d.F * 2); w.d_xmod = (__bf16*)take(M * D * 2);
   w.d_o = (__bf16*)take(M * D * 2); w.dqkv = (__bf16*)take(M * 3 * D * 2); w.dx_bf = (__bf16*)take(M * D * 2);
   w.bytes = o;
   return w;
@@ -161,6 +162,32 @@ int64_t sfron_dit_workspace_bytes(const sfron_dit_cfg* cfg) {
   Dims d;
   if (make_dims(cfg, d) != SFRON_OK) return -1;
   return (int64_t)make_ws(d, nullptr).bytes;
+}
+
+// ---- aux: a side stream + events so the weight-gradient GEMMs (which nothing downstream in the backward chain
+// depends on) run concurrently with the dgrad / elementwise chain and fill the CUs its tile counts leave idle
+struct Aux { hipStream_t side; hipEvent_t produced[4], consumed[4], done; };
+
+int sfron_aux_create(void** aux) {
+  SFRON_CHECK_ARG(aux);
+  Aux* a = new Aux{};
+  if (hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking) != hipSuccess) return (int)hipGetLastError();
+  for (int i = 0; i < 4; ++i) {
+    if (hipEventCreateWithFlags(&a->produced[i], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+    if (hipEventCreateWithFlags(&a->consumed[i], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+  }
+  if (hipEventCreateWithFlags(&a->done, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+  *aux = a;
+  return SFRON_OK;
+}
+int sfron_aux_destroy(void* aux) {
+  SFRON_CHECK_ARG(aux);
+  Aux* a = (Aux*)aux;
+  for (int i = 0; i < 4; ++i) { (void)hipEventDestroy(a->produced[i]); (void)hipEventDestroy(a->consumed[i]); }
+  (void)hipEventDestroy(a->done);
+  (void)hipStreamDestroy(a->side);
+  delete a;
+  return SFRON_OK;
 }
 
 // ---- probe: HIP events around the fc1 GEMM of block 0 (the dominant kernel class), for bench.py's roofline
@@ -287,7 +314,7 @@ int sfron_dit_forward_probed(const sfron_dit_cfg* cfg, const float* params, cons
 }
 
 int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* d_out,
-                       const int64_t* y, const uint8_t* drop, void* workspace, float* grads, void* stream) {
+                       const int64_t* y, const uint8_t* drop, void* workspace, float* grads, void* aux, void* stream) {
   Dims d;
   RUN(make_dims(cfg, d));
   SFRON_CHECK_ARG(params && params_bf16 && d_out && y && workspace && grads);
@@ -301,6 +328,15 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
   float* part0 = w.part; float* part1 = part0 + (size_t)nch * D;
   hipStream_t hs = (hipStream_t)stream;
   sfron_gemm_desc g;
+  // side stream for weight/bias gradients (falls back to the main stream without an aux handle)
+  Aux* ax = (Aux*)aux;
+  void* side = ax ? (void*)ax->side : stream;
+  // buffer i (0 d_br mlp, 1 d_hpre, 2 d_br attn, 3 dqkv): main records produced[i] after writing it, the side stream
+  // waits for it before reading; the side stream records consumed[i], main waits for it before overwriting.
+  auto produced = [&](int i) { if (ax) { (void)hipEventRecord(ax->produced[i], hs); (void)hipStreamWaitEvent(ax->side, ax->produced[i], 0); } };
+  auto consumed = [&](int i) { if (ax) (void)hipEventRecord(ax->consumed[i], ax->side); };
+  auto before_overwrite = [&](int i, bool first) { if (ax && !first) (void)hipStreamWaitEvent(hs, ax->consumed[i], 0); };
+  if (ax) { (void)hipEventRecord(ax->done, hs); (void)hipStreamWaitEvent(ax->side, ax->done, 0); }   // side starts after everything before us
 
   // ---- final layer
   RUN(sfron_patchify(d_out, B, d.Co, d.S, d.S, d.p, 1, (uint16_t*)w.d_tok, d.Po, stream));
@@ -326,17 +362,24 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
     const __bf16* o = w.o + (size_t)l * M * D; const __bf16* a1 = w.a1 + (size_t)l * M * D;
     const __bf16* xmod2 = w.xmod2 + (size_t)l * M * D; const __bf16* hpre = w.hpre + (size_t)l * M * d.F;
     const __bf16* h = w.h + (size_t)l * M * d.F; const __bf16* a2 = w.a2 + (size_t)l * M * D;
+    const bool first = (l == d.L - 1);
     // ---- MLP branch: x2 = x1 + gate_mlp * (fc2(gelu(fc1(xmod2))))
+    before_overwrite(0, first);
     RUN(sfron_gate_bwd(w.dx, (const uint16_t*)a2, mod + 5 * D, NM, T, M, D, (uint16_t*)w.d_br, part0, part1, stream));
-    RUN(sfron_reduce2(part0, part1, B, per, D, dmod + 5 * D, NM, w.dysum + ((size_t)(2 * l + 1) * B) * D, D, stream));
+    produced(0);
     g = wgrad_desc(w.d_br, h, M, D, d.F, grads + pb + P.o_fc2_w);
-    RUN(sfron_gemm_bf16(&g, stream));
+    RUN(sfron_gemm_bf16(&g, side));
+    consumed(0);
+    RUN(sfron_reduce2(part0, part1, B, per, D, dmod + 5 * D, NM, w.dysum + ((size_t)(2 * l + 1) * B) * D, D, stream));
+    before_overwrite(1, first);
     g = dgrad_desc(w.d_br, wb + pb + P.o_fc2_w, M, D, d.F);
     g.epilogue = SFRON_EPI_DGELU; g.c_bf16 = (uint16_t*)w.d_hpre; g.ldc_bf16 = d.F; g.aux = (uint16_t*)hpre; g.ldaux = d.F;
     RUN(sfron_gemm_bf16(&g, stream));
-    RUN(sfron_colsum(w.d_hpre, 1, M, d.F, d.F, w.csum, CSUM_PARTS, grads + pb + P.o_fc1_b, stream));
+    produced(1);
+    RUN(sfron_colsum(w.d_hpre, 1, M, d.F, d.F, ax ? w.csum2 : w.csum, CSUM_PARTS, grads + pb + P.o_fc1_b, side));
     g = wgrad_desc(w.d_hpre, xmod2, M, d.F, D, grads + pb + P.o_fc1_w);
-    RUN(sfron_gemm_bf16(&g, stream));
+    RUN(sfron_gemm_bf16(&g, side));
+    consumed(1);
     g = dgrad_desc(w.d_hpre, wb + pb + P.o_fc1_w, M, d.F, D);
     g.c_bf16 = (uint16_t*)w.d_xmod; g.ldc_bf16 = D;
     RUN(sfron_gemm_bf16(&g, stream));
@@ -344,18 +387,24 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
                               mod + 4 * D, NM, T, M, D, w.dx, 1, part0, part1, stream));
     RUN(sfron_reduce2(part0, part1, B, per, D, dmod + 3 * D, NM, dmod + 4 * D, NM, stream));
     // ---- attention branch: x1 = x0 + gate_msa * proj(attn(qkv(xmod1)))
-    RUN(sfron_gate_bwd(w.dx, (const uint16_t*)a1, mod + 2 * D, NM, T, M, D, (uint16_t*)w.d_br, part0, part1, stream));
+    before_overwrite(2, first);
+    RUN(sfron_gate_bwd(w.dx, (const uint16_t*)a1, mod + 2 * D, NM, T, M, D, (uint16_t*)w.d_br2, part0, part1, stream));
+    produced(2);
+    g = wgrad_desc(w.d_br2, o, M, D, D, grads + pb + P.o_proj_w);
+    RUN(sfron_gemm_bf16(&g, side));
+    consumed(2);
     RUN(sfron_reduce2(part0, part1, B, per, D, dmod + 2 * D, NM, w.dysum + ((size_t)(2 * l) * B) * D, D, stream));
-    g = wgrad_desc(w.d_br, o, M, D, D, grads + pb + P.o_proj_w);
-    RUN(sfron_gemm_bf16(&g, stream));
-    g = dgrad_desc(w.d_br, wb + pb + P.o_proj_w, M, D, D);
+    g = dgrad_desc(w.d_br2, wb + pb + P.o_proj_w, M, D, D);
     g.c_bf16 = (uint16_t*)w.d_o; g.ldc_bf16 = D;
     RUN(sfron_gemm_bf16(&g, stream));
+    before_overwrite(3, first);
     RUN(sfron_attn_bwd((const uint16_t*)qkv, (const uint16_t*)o, (const uint16_t*)w.d_o, w.lse + (size_t)l * B * d.H * T,
                        w.delta, (uint16_t*)w.dqkv, B, T, d.H, d.hd, stream));
-    RUN(sfron_colsum(w.dqkv, 1, M, 3 * D, 3 * D, w.csum, CSUM_PARTS, grads + pb + P.o_qkv_b, stream));
+    produced(3);
+    RUN(sfron_colsum(w.dqkv, 1, M, 3 * D, 3 * D, ax ? w.csum2 : w.csum, CSUM_PARTS, grads + pb + P.o_qkv_b, side));
     g = wgrad_desc(w.dqkv, xmod1, M, 3 * D, D, grads + pb + P.o_qkv_w);
-    RUN(sfron_gemm_bf16(&g, stream));
+    RUN(sfron_gemm_bf16(&g, side));
+    consumed(3);
     g = dgrad_desc(w.dqkv, wb + pb + P.o_qkv_w, M, 3 * D, D);
     g.c_bf16 = (uint16_t*)w.d_xmod; g.ldc_bf16 = D;
     RUN(sfron_gemm_bf16(&g, stream));
@@ -363,6 +412,7 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
                               mod + D, NM, T, M, D, w.dx, 1, part0, part1, stream));
     RUN(sfron_reduce2(part0, part1, B, per, D, dmod, NM, dmod + D, NM, stream));
   }
+  if (ax) { (void)hipEventRecord(ax->done, ax->side); (void)hipStreamWaitEvent(hs, ax->done, 0); }   // join
   // proj.bias / fc2.bias gradients of every block: sum_b gate[b] * (sum_t dy[b,t])
   RUN(sfron_gated_bias_grads(w.dysum, w.mod + 2 * D, NM, 6 * D, 3 * D, d.L, B, D, grads + P.blocks, P.blk_stride, P.o_proj_b,
                              P.o_fc2_b, stream));

@@ -122,6 +122,7 @@ class DiT(nn.Module):
         old = self.engine
         new = DitEngine(batch_size, **self._engine_args)
         new.params, new.params_bf16, new.grads, new.probe = old.params, old.params_bf16, old.grads, old.probe
+        _lib.lib().sfron_aux_destroy(old.aux)
         self.engine = new
 
     # ------------------------------------------------------------------ forward

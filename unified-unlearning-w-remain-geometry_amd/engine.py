@@ -45,6 +45,9 @@ class DitEngine:
         self.workspace = torch.empty(ws, dtype=torch.uint8, device=self.device)
         self.out_shape = (batch, c.out_channels, input_size, input_size)
         self.probe = None
+        h = ctypes.c_void_p()
+        check(L.sfron_aux_create(ctypes.byref(h)), "aux_create")     # side stream + events for concurrent wgrads
+        self.aux = h
 
     # ------------------------------------------------------------------ names
     def _build_index(self):
@@ -124,5 +127,5 @@ class DitEngine:
     def backward(self, d_out, y, drop=None, grads=None):
         g = self.grads if grads is None else grads
         check(_lib.lib().sfron_dit_backward(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(d_out),
-                                            ptr(y), ptr(drop), ptr(self.workspace), ptr(g), stream_ptr()), "dit_backward")
+                                            ptr(y), ptr(drop), ptr(self.workspace), ptr(g), self.aux, stream_ptr()), "dit_backward")
         return g
