@@ -432,14 +432,57 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_fast(GemmArgs g) {
     compute(sA0, sB0);
   }
 
+  // epilogues that READ a tensor (pre-activation / residual stream) issue all their loads first, so the 24..36
+  // dependent load->math->store chains of one lane overlap instead of serialising on memory latency
+  const int row_b = m0 + wm * MT * 16 + (lane & 15), col_b = n0 + wn * NT * 16 + 4 * (lane >> 4);
+  if constexpr (EPI == EPI_DGELU) {
+    bf16x4 hx[MT][NT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int row = m0 + wm * MT * 16 + mt * 16 + (lane & 15);
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int col = n0 + wn * NT * 16 + nt * 16 + 4 * (lane >> 4);
-      epilogue_store<EPI>(g, row, col, acc[mt][nt]);
+      for (int nt = 0; nt < NT; ++nt)
+        hx[mt][nt] = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)(row_b + mt * 16) * g.ldaux + col_b + nt * 16);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 v = acc[mt][nt] * g.alpha;
+        const bf16x4 h = hx[mt][nt];
+        bf16x4 o = {f2bf(v[0] * gelu_tanh_grad(bf2f(h[0]))), f2bf(v[1] * gelu_tanh_grad(bf2f(h[1]))),
+                    f2bf(v[2] * gelu_tanh_grad(bf2f(h[2]))), f2bf(v[3] * gelu_tanh_grad(bf2f(h[3])))};
+        *reinterpret_cast<bf16x4*>(g.Cb + (size_t)(row_b + mt * 16) * g.ldcb + col_b + nt * 16) = o;
+      }
+  } else if constexpr (EPI == EPI_GATE_RES) {
+    float4 gt[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)      // all rows of a tile belong to one sample when tokens % tile rows == 0; else per row
+      gt[nt] = *reinterpret_cast<const float4*>(g.gate + (size_t)(row_b / g.T) * g.ldgate + col_b + nt * 16);
+    const bool uniform_sample = (g.T % FBM) == 0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = row_b + mt * 16;
+      float4 xr[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) xr[nt] = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldcf + col_b + nt * 16);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = col_b + nt * 16;
+        f32x4 v = acc[mt][nt] * g.alpha;
+        if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+        bf16x4 a = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col) = a;
+        const float4 gg = uniform_sample ? gt[nt] : *reinterpret_cast<const float4*>(g.gate + (size_t)(row / g.T) * g.ldgate + col);
+        float4 x = xr[nt];
+        x.x += gg.x * v[0]; x.y += gg.y * v[1]; x.z += gg.z * v[2]; x.w += gg.w * v[3];
+        *reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col) = x;
+      }
     }
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        epilogue_store<EPI>(g, row_b + mt * 16, col_b + nt * 16, acc[mt][nt]);
   }
 }
 
@@ -502,7 +545,7 @@ static const int TILE_BN[N_TILES] = {0, 128, 192, 256, 192, 192, 192, 192};
 inline bool tile_fits(const GemmArgs& g, int t) {
   return t >= 1 && t < N_TILES && g.M % TILE_BM[t] == 0 && g.N % TILE_BN[t] == 0;
 }
-inline int pick_fast_tile(const GemmArgs& g, int force) {
+inline int pick_fast_tile(const GemmArgs& g, int force, int transposed_operands) {
   if (g.K % 64 || g.kchunk != g.K || force < 0) return 0;
   if (force > 0) return tile_fits(g, force) ? force : 0;
   // prefer the 8-wave tile with the best last-round occupancy of the 256 CUs; small problems keep 128x128
@@ -514,12 +557,12 @@ inline int pick_fast_tile(const GemmArgs& g, int force) {
     if (eff > best_eff + 1e-9) { best_eff = eff; best = t; }
   }
   if (best && best_eff >= 0.5) return best;
-  return tile_fits(g, 1) ? 1 : 0;
+  return (transposed_operands == 0 && tile_fits(g, 1)) ? 1 : 0;   // with transposed reads the generic kernel beats the 4-wave tile
 }
 
 template <bool A_TR, bool B_TR, int EPI>
 int launch_any(const GemmArgs& g, hipStream_t s, int force) {
-  switch (pick_fast_tile(g, force)) {
+  switch (pick_fast_tile(g, force, (A_TR ? 1 : 0) + (B_TR ? 1 : 0))) {
     case 1: return launch_fast<2, 2, 4, 4, A_TR, B_TR, EPI>(g, s);
     case 2: return launch_fast<4, 2, 4, 6, A_TR, B_TR, EPI>(g, s);
     case 3: return launch_fast<2, 4, 8, 4, A_TR, B_TR, EPI>(g, s);
