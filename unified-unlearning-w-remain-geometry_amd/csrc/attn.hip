@@ -12,54 +12,65 @@
 // (ds_read_b64_tr_b16) from ONE swizzled LDS image.
 //   forward : grid (T / (64*QT), B*H); wave = 16*QT queries, streams 64-key chunks of K,V
 //   dQ      : same decomposition; recomputes P from LSE
-//   dK,dV   : wave = 16*KT keys, streams 64-query chunks of Q,dO; no cross-workgroup reduction
-// head_dim 64 -> HDP 64, 2 k-steps, 4 d-tiles; head_dim 72 (DiT-XL) -> HDP 128 image rows, 3 k-steps
-// (zero padded to 96), 5 d-tiles (80).
+//   dK,dV   : wave = 16 keys, streams 64-query chunks of Q,dO; no cross-workgroup reduction
+// 64-row chunks arrive by LDS-DMA (buffer_load ... lds, swizzle on the source address, pad columns never
+// written) into a 3-slot ring: chunk c+2 is in flight while chunk c feeds the matrix cores, one raw
+// s_barrier per chunk, counted vmcnt.
+// head_dim 64 -> 128-B image rows, 2 k-steps, 4 d-tiles; head_dim 72 (DiT-XL) -> 192-B rows (96 columns,
+// zero padded), 3 k-steps, 5 d-tiles.
 #include "common.h"
 #include "../../include/sfron.h"
 
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = 256, NWAVE = 4, NSLOT = 3;
 constexpr float LOG2E = 1.4426950408889634f;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef __attribute__((address_space(3))) void lptr_t;
 
+// chunk-index XOR of image row r (bank rules of MI355X_MICROARCH.md section LDS; both the ds_read_b128 row
+// fragments and the transposed reads are conflict-free):
+//   HDP 64 (128-B rows, 8 chunks):  ((r>>1)&3)<<1
+//   HDP 96 (192-B rows, 12 chunks): perm[(r>>2)&3], perm = {0,2,3,1}  (stays inside each 4-chunk group)
 template <int HDP> __device__ __forceinline__ int aswz(int row) {
-  return HDP == 64 ? (((row >> 1) & 3) << 1) : ((row & 7) << 1);
+  if (HDP == 64) return ((row >> 1) & 3) << 1;
+  return (0x1320 >> (((row >> 2) & 3) * 4)) & 3;
 }
 template <int HDP> __device__ __forceinline__ int aoff(int row, int ch) { return row * HDP + ((ch ^ aswz<HDP>(row)) << 3); }
 
-// stage a [64 rows][hd] bf16 chunk (row stride ld in global) into the swizzled image; columns >= hd stay zero
+// LDS-DMA plan for one [64 rows][hd] chunk: per-lane byte offsets (loop invariant) + validity (pad chunks are
+// never written: the images are zeroed once).  One wave-instruction fills 1 KiB of the lane-linear image.
 template <int HDP>
-struct ChunkStager {
-  static constexpr int NL = HDP / 32 + 1;
-  uint4 r[NL];
-  __device__ __forceinline__ void load(const __bf16* src, int ld, int ch_per_row, int tid) {
+struct ChunkDma {
+  static constexpr int CPR = HDP / 8;                  // 16-B chunk positions per image row
+  static constexpr int PER_WAVE = CPR / NWAVE;         // 64 rows * CPR chunks / 64 lanes / 4 waves
+  static_assert(CPR % NWAVE == 0, "image rows must split over the waves");
+  int off[PER_WAVE];
+  bool valid[PER_WAVE];
+  __device__ __forceinline__ void init(int ld, int hd, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int c = tid + NT * i;
-      if (c < 64 * ch_per_row) {
-        const int row = c / ch_per_row, ch = c % ch_per_row;
-        r[i] = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + ch * 8);
-      }
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int e = (wave + i * NWAVE) * 64 + lane;
+      const int row = e / CPR, p = e % CPR;
+      const int c = p ^ aswz<HDP>(row);                // source chunk that lives at position p
+      valid[i] = c * 8 < hd;
+      off[i] = 2 * (row * ld + c * 8);
     }
   }
-  __device__ __forceinline__ void store(__bf16* img, int ch_per_row, int tid) const {
+  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rsrc, int soff_bytes, __bf16* img, int wave) const {
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int c = tid + NT * i;
-      if (c < 64 * ch_per_row) {
-        const int row = c / ch_per_row, ch = c % ch_per_row;
-        *reinterpret_cast<uint4*>(img + aoff<HDP>(row, ch)) = r[i];
-      }
-    }
+    for (int i = 0; i < PER_WAVE; ++i)
+      if (valid[i])
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t*)(img + (wave + i * NWAVE) * 512), 16, off[i], soff_bytes, 0, 0);
   }
 };
 
-template <int HDP> __device__ __forceinline__ void zero_image(__bf16* img, int n_images, int tid) {
-  uint4 z = make_uint4(0, 0, 0, 0);
-  for (int i = tid; i < n_images * 64 * HDP / 8; i += NT) reinterpret_cast<uint4*>(img)[i] = z;
+__device__ __forceinline__ void zero_lds(__bf16* p, int n_elems, int tid) {
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < n_elems / 8; i += NT) reinterpret_cast<uint4*>(p)[i] = z;
 }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // row fragment: lane holds X[row0 + (lane&15)][32*ks + 8*(lane>>4) + 0..7]
 template <int HDP> __device__ __forceinline__ bf16x8 frag_rows(const __bf16* img, int row0, int ks, int lane) {
@@ -101,35 +112,53 @@ __device__ __forceinline__ float group_sum(float v) {
   v += __shfl_xor(v, 16, 64);
   return v + __shfl_xor(v, 32, 64);
 }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// Ring driver shared by the three kernels.  Two images (X0, X1) per slot.  Usage per chunk c:
+//   ring_wait<...>(c, n) ; barrier ; ring_issue(c + 2) ; compute(slot c % 3)
+template <int HDP>
+struct Ring {
+  static constexpr int IMG = 64 * HDP;                 // elements per image
+  static constexpr int PER_CHUNK = 2 * ChunkDma<HDP>::PER_WAVE;   // DMA instructions per wave per chunk (2 images)
+  __bf16* base;
+  __device__ __forceinline__ __bf16* img(int slot, int which) const { return base + (slot * 2 + which) * IMG; }
+};
+
+}  // namespace (kernel templates have external linkage + explicit instantiations below: see gemm.hip)
 
 // ------------------------------------------------------------------------------------- forward
 template <int HDP, int KS, int NDT, int QT>
 __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv, __bf16* __restrict__ o,
                                                  float* __restrict__ lse, int T, int H, int hd, float scale) {
   extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
-  __bf16* sK = smem;                     // [2][64*HDP]
-  __bf16* sV = smem + 2 * 64 * HDP;      // [2][64*HDP]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  Ring<HDP> ring{smem};
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.y, b = bh / H, h = bh % H;
-  const int D = H * hd, ld = 3 * D, chpr = hd / 8;
+  const int D = H * hd, ld = 3 * D;
   const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
   const __bf16* base = qkv + (size_t)b * T * ld + h * hd;
   const float c = scale * LOG2E;
+  const int nchunk = T / 64;
 
-  zero_image<HDP>(smem, 4, tid);
+  zero_lds(smem, NSLOT * 2 * Ring<HDP>::IMG, tid);
+  ChunkDma<HDP> dma;
+  dma.init(ld, hd, wave, lane);
+  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(base + D), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(base + 2 * D), 0, 0x7fffffff, 0x00020000);
+  auto issue = [&](int ch) {
+    const int slot = ch % NSLOT, soff = ch * 64 * ld * 2;
+    dma.issue(rsK, soff, ring.img(slot, 0), wave);
+    dma.issue(rsV, soff, ring.img(slot, 1), wave);
+  };
   bf16x8 fq[QT][KS];
 #pragma unroll
   for (int qi = 0; qi < QT; ++qi)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) fq[qi][ks] = frag_rows_global(base, ld, q0 + 16 * qi, ks, hd, lane);
-  __syncthreads();
-
-  ChunkStager<HDP> stK, stV;
-  stK.load(base + D, ld, chpr, tid);
-  stV.load(base + 2 * D, ld, chpr, tid);
-  stK.store(sK, chpr, tid);
-  stV.store(sV, chpr, tid);
-  __syncthreads();
+  __syncthreads();                       // zeros visible before any DMA lands
+  issue(0);
+  if (nchunk > 1) issue(1);
 
   f32x4 oacc[QT][NDT];
   float m[QT], l[QT];
@@ -140,16 +169,12 @@ __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv,
     for (int dt = 0; dt < NDT; ++dt) oacc[qi][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  const int nchunk = T / 64;
   for (int kc = 0; kc < nchunk; ++kc) {
-    const int cur = kc & 1;
-    const bool more = kc + 1 < nchunk;
-    if (more) {
-      stK.load(base + D + (size_t)(kc + 1) * 64 * ld, ld, chpr, tid);
-      stV.load(base + 2 * D + (size_t)(kc + 1) * 64 * ld, ld, chpr, tid);
-    }
-    const __bf16* iK = sK + cur * 64 * HDP;
-    const __bf16* iV = sV + cur * 64 * HDP;
+    if (kc + 1 < nchunk) wait_vmcnt<Ring<HDP>::PER_CHUNK>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kc + 2 < nchunk) issue(kc + 2);
+    const __bf16* iK = ring.img(kc % NSLOT, 0);
+    const __bf16* iV = ring.img(kc % NSLOT, 1);
     f32x4 s[QT][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -174,14 +199,15 @@ __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv,
         for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[qi][kt][j]);
       mx = group_max(mx);
       const float mn = fmaxf(m[qi], mx);
-      const float alpha = exp2f((m[qi] - mn) * c);
+      const float alpha = fast_exp2((m[qi] - mn) * c);
       m[qi] = mn;
+      const float mc = mn * c;
       float ps = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float p = exp2f((s[qi][kt][j] - mn) * c);
+          const float p = fast_exp2(__builtin_fmaf(s[qi][kt][j], c, -mc));
           s[qi][kt][j] = p;
           ps += p;
         }
@@ -200,11 +226,6 @@ __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv,
         for (int qi = 0; qi < QT; ++qi)
           oacc[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, pf[qi][s2], oacc[qi][dt], 0, 0, 0);
       }
-    if (more) {
-      stK.store(sK + (cur ^ 1) * 64 * HDP, chpr, tid);
-      stV.store(sV + (cur ^ 1) * 64 * HDP, chpr, tid);
-    }
-    __syncthreads();
   }
 #pragma unroll
   for (int qi = 0; qi < QT; ++qi) {
@@ -251,17 +272,27 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dq(const __bf16* __restrict__ q
                                                     const float* __restrict__ lse, const float* __restrict__ delta,
                                                     __bf16* __restrict__ dqkv, int T, int H, int hd, float scale) {
   extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
-  __bf16* sK = smem;
-  __bf16* sV = smem + 2 * 64 * HDP;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  Ring<HDP> ring{smem};
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.y, b = bh / H, h = bh % H;
-  const int D = H * hd, ld = 3 * D, chpr = hd / 8;
+  const int D = H * hd, ld = 3 * D;
   const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
   const __bf16* base = qkv + (size_t)b * T * ld + h * hd;
   const __bf16* dob = d_o + (size_t)b * T * D + h * hd;
   const float c = scale * LOG2E;
+  const int nchunk = T / 64;
 
-  zero_image<HDP>(smem, 4, tid);
+  zero_lds(smem, NSLOT * 2 * Ring<HDP>::IMG, tid);
+  ChunkDma<HDP> dma;
+  dma.init(ld, hd, wave, lane);
+  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(base + D), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(base + 2 * D), 0, 0x7fffffff, 0x00020000);
+  auto issue = [&](int ch) {
+    const int slot = ch % NSLOT, soff = ch * 64 * ld * 2;
+    dma.issue(rsK, soff, ring.img(slot, 0), wave);
+    dma.issue(rsV, soff, ring.img(slot, 1), wave);
+  };
   bf16x8 fq[QT][KS], fdo[QT][KS];
   float nl[QT], dl[QT];
 #pragma unroll
@@ -276,12 +307,8 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dq(const __bf16* __restrict__ q
     dl[qi] = delta[(size_t)bh * T + q];
   }
   __syncthreads();
-  ChunkStager<HDP> stK, stV;
-  stK.load(base + D, ld, chpr, tid);
-  stV.load(base + 2 * D, ld, chpr, tid);
-  stK.store(sK, chpr, tid);
-  stV.store(sV, chpr, tid);
-  __syncthreads();
+  issue(0);
+  if (nchunk > 1) issue(1);
 
   f32x4 dq[QT][NDT];
 #pragma unroll
@@ -289,16 +316,12 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dq(const __bf16* __restrict__ q
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) dq[qi][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nchunk = T / 64;
   for (int kc = 0; kc < nchunk; ++kc) {
-    const int cur = kc & 1;
-    const bool more = kc + 1 < nchunk;
-    if (more) {
-      stK.load(base + D + (size_t)(kc + 1) * 64 * ld, ld, chpr, tid);
-      stV.load(base + 2 * D + (size_t)(kc + 1) * 64 * ld, ld, chpr, tid);
-    }
-    const __bf16* iK = sK + cur * 64 * HDP;
-    const __bf16* iV = sV + cur * 64 * HDP;
+    if (kc + 1 < nchunk) wait_vmcnt<Ring<HDP>::PER_CHUNK>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kc + 2 < nchunk) issue(kc + 2);
+    const __bf16* iK = ring.img(kc % NSLOT, 0);
+    const __bf16* iV = ring.img(kc % NSLOT, 1);
     bf16x8 ds[QT][2];
     f32x4 t[QT][4];
 #pragma unroll
@@ -316,7 +339,7 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dq(const __bf16* __restrict__ q
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float pr = exp2f(a[j] * c + nl[qi]);
+          const float pr = fast_exp2(__builtin_fmaf(a[j], c, nl[qi]));
           a[j] = pr * (p[j] - dl[qi]) * scale;                                             // dS (incl. softmax scale)
         }
         t[qi][kt] = a;
@@ -333,11 +356,6 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dq(const __bf16* __restrict__ q
         for (int qi = 0; qi < QT; ++qi)
           dq[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fkt, ds[qi][s2], dq[qi][dt], 0, 0, 0);
       }
-    if (more) {
-      stK.store(sK + (cur ^ 1) * 64 * HDP, chpr, tid);
-      stV.store(sV + (cur ^ 1) * 64 * HDP, chpr, tid);
-    }
-    __syncthreads();
   }
 #pragma unroll
   for (int qi = 0; qi < QT; ++qi) {
@@ -362,19 +380,31 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dkv(const __bf16* __restrict__ 
                                                      const float* __restrict__ lse, const float* __restrict__ delta,
                                                      __bf16* __restrict__ dqkv, int T, int H, int hd, float scale) {
   extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
-  __bf16* sQ = smem;
-  __bf16* sO = smem + 2 * 64 * HDP;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  Ring<HDP> ring{smem};
+  float* s_lse = reinterpret_cast<float*>(smem + NSLOT * 2 * Ring<HDP>::IMG);     // [T] -lse*log2e, then [T] delta
+  float* s_del = s_lse + T;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.y, b = bh / H, h = bh % H;
-  const int D = H * hd, ld = 3 * D, chpr = hd / 8;
+  const int D = H * hd, ld = 3 * D;
   const int k0 = blockIdx.x * (64 * KT) + wave * (16 * KT);
   const __bf16* base = qkv + (size_t)b * T * ld + h * hd;
   const __bf16* dob = d_o + (size_t)b * T * D + h * hd;
-  const float* lrow = lse + (size_t)bh * T;
-  const float* drow = delta + (size_t)bh * T;
   const float c = scale * LOG2E;
+  const int nchunk = T / 64;
 
-  zero_image<HDP>(smem, 4, tid);
+  zero_lds(smem, NSLOT * 2 * Ring<HDP>::IMG, tid);
+  for (int i = tid; i < T; i += NT) { s_lse[i] = -lse[(size_t)bh * T + i] * LOG2E; s_del[i] = delta[(size_t)bh * T + i]; }
+  ChunkDma<HDP> dmaQ, dmaO;
+  dmaQ.init(ld, hd, wave, lane);
+  dmaO.init(D, hd, wave, lane);
+  const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, 0x7fffffff, 0x00020000);
+  auto issue = [&](int ch) {
+    const int slot = ch % NSLOT;
+    dmaQ.issue(rsQ, ch * 64 * ld * 2, ring.img(slot, 0), wave);
+    dmaO.issue(rsO, ch * 64 * D * 2, ring.img(slot, 1), wave);
+  };
   bf16x8 fk[KT][KS], fv[KT][KS];
 #pragma unroll
   for (int ki = 0; ki < KT; ++ki)
@@ -384,12 +414,8 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dkv(const __bf16* __restrict__ 
       fv[ki][ks] = frag_rows_global(base + 2 * D, ld, k0 + 16 * ki, ks, hd, lane);
     }
   __syncthreads();
-  ChunkStager<HDP> stQ, stO;
-  stQ.load(base, ld, chpr, tid);
-  stO.load(dob, D, chpr, tid);
-  stQ.store(sQ, chpr, tid);
-  stO.store(sO, chpr, tid);
-  __syncthreads();
+  issue(0);
+  if (nchunk > 1) issue(1);
 
   f32x4 dk[KT][NDT], dv[KT][NDT];
 #pragma unroll
@@ -397,24 +423,20 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dkv(const __bf16* __restrict__ 
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) { dk[ki][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[ki][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  const int nchunk = T / 64;
   for (int qc = 0; qc < nchunk; ++qc) {
-    const int cur = qc & 1;
-    const bool more = qc + 1 < nchunk;
-    if (more) {
-      stQ.load(base + (size_t)(qc + 1) * 64 * ld, ld, chpr, tid);
-      stO.load(dob + (size_t)(qc + 1) * 64 * D, D, chpr, tid);
-    }
-    const __bf16* iQ = sQ + cur * 64 * HDP;
-    const __bf16* iO = sO + cur * 64 * HDP;
+    if (qc + 1 < nchunk) wait_vmcnt<Ring<HDP>::PER_CHUNK>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (qc + 2 < nchunk) issue(qc + 2);
+    const __bf16* iQ = ring.img(qc % NSLOT, 0);
+    const __bf16* iO = ring.img(qc % NSLOT, 1);
     f32x4 pt[KT][4], st[KT][4];
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
       bf16x8 fqr[KS], fdr[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) { fqr[ks] = frag_rows<HDP>(iQ, qt * 16, ks, lane); fdr[ks] = frag_rows<HDP>(iO, qt * 16, ks, lane); }
-      const float4 l4 = *reinterpret_cast<const float4*>(lrow + qc * 64 + qt * 16 + 4 * g);
-      const float4 d4 = *reinterpret_cast<const float4*>(drow + qc * 64 + qt * 16 + 4 * g);
+      const float4 l4 = *reinterpret_cast<const float4*>(s_lse + qc * 64 + qt * 16 + 4 * g);
+      const float4 d4 = *reinterpret_cast<const float4*>(s_del + qc * 64 + qt * 16 + 4 * g);
       const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq_[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
       for (int ki = 0; ki < KT; ++ki) {
@@ -426,7 +448,7 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dkv(const __bf16* __restrict__ 
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float pr = exp2f(a[j] * c - lq[j] * LOG2E);
+          const float pr = fast_exp2(__builtin_fmaf(a[j], c, lq[j]));
           a[j] = pr;
           p[j] = pr * (p[j] - dq_[j]) * scale;
         }
@@ -452,11 +474,6 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dkv(const __bf16* __restrict__ 
           dk[ki][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqt, sp[ki][s2], dk[ki][dt], 0, 0, 0);
         }
       }
-    if (more) {
-      stQ.store(sQ + (cur ^ 1) * 64 * HDP, chpr, tid);
-      stO.store(sO + (cur ^ 1) * 64 * HDP, chpr, tid);
-    }
-    __syncthreads();
   }
 #pragma unroll
   for (int ki = 0; ki < KT; ++ki) {
@@ -476,14 +493,36 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dkv(const __bf16* __restrict__ 
   }
 }
 
-template <int HDP> size_t lds_bytes() { return 4 * 64 * HDP * sizeof(__bf16); }
+#define SFRON_INST_ATTN(HDP, KS, NDT)                                                                              \
+  template __global__ void k_attn_fwd<HDP, KS, NDT, 1>(const __bf16*, __bf16*, float*, int, int, int, float);      \
+  template __global__ void k_attn_fwd<HDP, KS, NDT, 2>(const __bf16*, __bf16*, float*, int, int, int, float);      \
+  template __global__ void k_attn_bwd_dq<HDP, KS, NDT, 1>(const __bf16*, const __bf16*, const float*, const float*, __bf16*, int, int, int, float); \
+  template __global__ void k_attn_bwd_dq<HDP, KS, NDT, 2>(const __bf16*, const __bf16*, const float*, const float*, __bf16*, int, int, int, float); \
+  template __global__ void k_attn_bwd_dkv<HDP, KS, NDT, 1>(const __bf16*, const __bf16*, const float*, const float*, __bf16*, int, int, int, float);
+SFRON_INST_ATTN(64, 2, 4)
+SFRON_INST_ATTN(96, 3, 5)
+#undef SFRON_INST_ATTN
+
+namespace {
+
+template <int HDP> size_t lds_bytes(int extra_floats) { return NSLOT * 2 * 64 * HDP * sizeof(__bf16) + extra_floats * sizeof(float); }
+
+template <typename K> int set_lds(K kern, size_t lds) {
+  if (lds > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return (int)hipGetLastError();
+  return SFRON_OK;
+}
 
 template <int HDP, int KS, int NDT>
 int launch_fwd(const __bf16* qkv, __bf16* o, float* lse, int B, int T, int H, int hd, float scale, hipStream_t s) {
-  if (T % 128 == 0)
-    hipLaunchKernelGGL((k_attn_fwd<HDP, KS, NDT, 2>), dim3(T / 128, B * H), dim3(NT), lds_bytes<HDP>(), s, qkv, o, lse, T, H, hd, scale);
-  else
-    hipLaunchKernelGGL((k_attn_fwd<HDP, KS, NDT, 1>), dim3(T / 64, B * H), dim3(NT), lds_bytes<HDP>(), s, qkv, o, lse, T, H, hd, scale);
+  const size_t lds = lds_bytes<HDP>(0);
+  if (T % 128 == 0) {
+    int rc = set_lds(&k_attn_fwd<HDP, KS, NDT, 2>, lds); if (rc) return rc;
+    hipLaunchKernelGGL((k_attn_fwd<HDP, KS, NDT, 2>), dim3(T / 128, B * H), dim3(NT), lds, s, qkv, o, lse, T, H, hd, scale);
+  } else {
+    int rc = set_lds(&k_attn_fwd<HDP, KS, NDT, 1>, lds); if (rc) return rc;
+    hipLaunchKernelGGL((k_attn_fwd<HDP, KS, NDT, 1>), dim3(T / 64, B * H), dim3(NT), lds, s, qkv, o, lse, T, H, hd, scale);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
 }
@@ -491,11 +530,16 @@ template <int HDP, int KS, int NDT>
 int launch_bwd(const __bf16* qkv, const __bf16* o, const __bf16* d_o, const float* lse, float* delta, __bf16* dqkv, int B,
                int T, int H, int hd, float scale, hipStream_t s) {
   hipLaunchKernelGGL(k_attn_delta, dim3(cdiv((long)B * T * H, NT)), dim3(NT), 0, s, o, d_o, delta, B, T, H, hd);
-  if (T % 128 == 0)
-    hipLaunchKernelGGL((k_attn_bwd_dq<HDP, KS, NDT, 2>), dim3(T / 128, B * H), dim3(NT), lds_bytes<HDP>(), s, qkv, d_o, lse, delta, dqkv, T, H, hd, scale);
-  else
-    hipLaunchKernelGGL((k_attn_bwd_dq<HDP, KS, NDT, 1>), dim3(T / 64, B * H), dim3(NT), lds_bytes<HDP>(), s, qkv, d_o, lse, delta, dqkv, T, H, hd, scale);
-  hipLaunchKernelGGL((k_attn_bwd_dkv<HDP, KS, NDT, 1>), dim3(T / 64, B * H), dim3(NT), lds_bytes<HDP>(), s, qkv, d_o, lse, delta, dqkv, T, H, hd, scale);
+  const size_t lds = lds_bytes<HDP>(0), lds2 = lds_bytes<HDP>(2 * T);
+  if (T % 128 == 0) {
+    int rc = set_lds(&k_attn_bwd_dq<HDP, KS, NDT, 2>, lds); if (rc) return rc;
+    hipLaunchKernelGGL((k_attn_bwd_dq<HDP, KS, NDT, 2>), dim3(T / 128, B * H), dim3(NT), lds, s, qkv, d_o, lse, delta, dqkv, T, H, hd, scale);
+  } else {
+    int rc = set_lds(&k_attn_bwd_dq<HDP, KS, NDT, 1>, lds); if (rc) return rc;
+    hipLaunchKernelGGL((k_attn_bwd_dq<HDP, KS, NDT, 1>), dim3(T / 64, B * H), dim3(NT), lds, s, qkv, d_o, lse, delta, dqkv, T, H, hd, scale);
+  }
+  int rc = set_lds(&k_attn_bwd_dkv<HDP, KS, NDT, 1>, lds2); if (rc) return rc;
+  hipLaunchKernelGGL((k_attn_bwd_dkv<HDP, KS, NDT, 1>), dim3(T / 64, B * H), dim3(NT), lds2, s, qkv, d_o, lse, delta, dqkv, T, H, hd, scale);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
 }
@@ -510,7 +554,7 @@ int sfron_attn_fwd(const uint16_t* qkv, uint16_t* o, float* lse, int B, int T, i
   const float scale = 1.0f / sqrtf((float)hd);
   hipStream_t s = (hipStream_t)stream;
   if (hd == 64) return launch_fwd<64, 2, 4>((const __bf16*)qkv, (__bf16*)o, lse, B, T, H, hd, scale, s);
-  if (hd == 72) return launch_fwd<128, 3, 5>((const __bf16*)qkv, (__bf16*)o, lse, B, T, H, hd, scale, s);
+  if (hd == 72) return launch_fwd<96, 3, 5>((const __bf16*)qkv, (__bf16*)o, lse, B, T, H, hd, scale, s);
   return SFRON_ERR_UNSUPPORTED;
 }
 
@@ -523,7 +567,7 @@ int sfron_attn_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, 
   if (hd == 64)
     return launch_bwd<64, 2, 4>((const __bf16*)qkv, (const __bf16*)o, (const __bf16*)d_o, lse, delta_scratch, (__bf16*)dqkv, B, T, H, hd, scale, s);
   if (hd == 72)
-    return launch_bwd<128, 3, 5>((const __bf16*)qkv, (const __bf16*)o, (const __bf16*)d_o, lse, delta_scratch, (__bf16*)dqkv, B, T, H, hd, scale, s);
+    return launch_bwd<96, 3, 5>((const __bf16*)qkv, (const __bf16*)o, (const __bf16*)d_o, lse, delta_scratch, (__bf16*)dqkv, B, T, H, hd, scale, s);
   return SFRON_ERR_UNSUPPORTED;
 }
 
