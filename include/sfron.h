@@ -125,7 +125,7 @@ int sfron_gemm_bf16(const sfron_gemm_desc* desc /* HOST pointer */, void* stream
  * mod buffers are fp32 [batch][ldmod]; shift/scale/gate pointers already include the column offset of the
  * chunk (DiT/models.py:119 .chunk(6, dim=1)).  `tokens` = tokens per sample (row / tokens = sample). */
 
-/* rows per reduction chunk used by the *_bwd kernels' partial buffers (0 if tokens is unsupported) */
+/* rows per reduction chunk (= rows one wave handles) of the *_bwd kernels' partial buffers */
 int sfron_rows_per_chunk(int tokens);
 
 /* out = bf16( LayerNorm(x; eps 1e-6, no affine) * (1 + scale) + shift ), saves mean / rstd per row
@@ -155,6 +155,12 @@ int sfron_reduce2(const float* p0, const float* p1, int groups, int per_group, i
  * where S holds the per-sample token sums of the upstream gradient (second output of sfron_gate_bwd, reduced). */
 int sfron_gated_bias_grads(const float* S, const float* gate, int ldg, long gate_stride, long gate_which, int layers, int B,
                            int D, float* out, long out_stride, long out_which0, long out_which1, void* stream);
+/* Deferred reduction of a whole backward pass in ONE launch.  parts holds n_slots slots of slot_stride floats; slot
+ * s = layer*8 + kind*2 + buf is a [groups*per_group][D] partial buffer written by sfron_gate_bwd / sfron_ln_modulate_bwd.
+ * out: dst_base[kind*2+buf][layer*dst_layer_stride[..] + g*dst_ld[..] + c] = sum_j slot[(g*per_group + j)*D + c].
+ * The three arrays are HOST arrays of length 8. */
+int sfron_reduce_slots(const float* parts, long slot_stride, int n_slots, int groups, int per_group, int D,
+                       float* const* dst_base, const long* dst_layer_stride, const int* dst_ld, void* stream);
 /* out[c] = sum_g w[g * ldw + c] * sum_j partials[(g * per_group + j) * D + c]      (bias grad behind a gate) */
 int sfron_weighted_reduce(const float* partials, int groups, int per_group, int D, const float* w, int ldw, float* out,
                           void* stream);

@@ -54,6 +54,8 @@ _PROTOS.update({
     "sfron_gate_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _S]),
     "sfron_reduce_chunks": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, _S]),
     "sfron_weighted_reduce": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, _S]),
+    "sfron_reduce_slots": (c_int, [_P, ctypes.c_long, c_int, c_int, c_int, c_int, POINTER(c_void_p), POINTER(ctypes.c_long),
+                                   POINTER(c_int), _S]),
     "sfron_reduce2": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _S]),
     "sfron_gated_bias_grads": (c_int, [_P, _P, c_int, ctypes.c_long, ctypes.c_long, c_int, c_int, c_int, _P, ctypes.c_long,
                                        ctypes.c_long, ctypes.c_long, _S]),

@@ -106,12 +106,12 @@ inline Workspace make_ws(const Dims& d, char* base) {
   w.d_sc = (float*)take(B * D * 4); w.d_c = (float*)take(B * D * 4); w.d_c_bf = (__bf16*)take(B * D * 2);
   w.d_h1s = (float*)take(B * D * 4); w.d_h1_bf = (__bf16*)take(B * D * 2);
   w.delta = (float*)take(B * (size_t)d.H * d.T * 4);
-  w.part = (float*)take(4 * (M / 4) * D * 4);                       // 4 partial buffers, worst case 4 rows per chunk
+  w.part = (float*)take((L + 1) * 8 * (size_t)(M / sfron_rows_per_chunk(d.T)) * D * 4);   // [L+1][kind 4][buf 2][chunks][D] partial slots
   const size_t widest = (size_t)(d.F > 3 * d.D ? d.F : 3 * d.D) > (size_t)d.NM ? (size_t)(d.F > 3 * d.D ? d.F : 3 * d.D) : (size_t)d.NM;
   w.csum = (float*)take(CSUM_PARTS * widest * 4);
   w.csum2 = (float*)take(CSUM_PARTS * (size_t)(d.F > 3 * d.D ? d.F : 3 * d.D) * 4);   // side-stream colsum scratch
   w.slabs = (float*)take((size_t)SPLIT_K_ADA * B * D * 4);
-  w.dysum = (float*)take(L * 2 * B * D * 4);                       // [L][proj|fc2][B][D] token sums of dy (gated bias grads)
+  w.dysum = (float*)take((L + 1) * 2 * B * D * 4);                       // [L][proj|fc2][B][D] token sums of dy (gated bias grads)
   w.d_tok = (__bf16*)take(M * (size_t)d.Po * 2);
   w.d_br = (__bf16*)take(M * D * 2); w.d_br2 = (__bf16*)take(M * D * 2); w.d_hpre = (__bf16*)take(M * (size_t)d.F * 2); w.d_xmod = (__bf16*)take(M * D * 2);
   w.d_o = (__bf16*)take(M * D * 2); w.dqkv = (__bf16*)take(M * 3 * D * 2); w.dx_bf = (__bf16*)take(M * D * 2);
@@ -325,7 +325,10 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
   const int rpc = sfron_rows_per_chunk(T);
   SFRON_CHECK_ARG(rpc > 0);
   const int per = T / rpc, nch = M / rpc;
-  float* part0 = w.part; float* part1 = part0 + (size_t)nch * D;
+  const long slot_stride = (long)nch * D;
+  // slot (layer, kind, buf): kind 0 = MLP gate, 1 = MLP LN, 2 = attention gate, 3 = attention LN; the final layer's LN is
+  // (layer L, kind 3).  All token reductions are deferred to ONE k_reduce_slots launch after the last block.
+  auto slot = [&](int layer, int kind, int buf) { return w.part + ((size_t)layer * 8 + kind * 2 + buf) * slot_stride; };
   hipStream_t hs = (hipStream_t)stream;
   sfron_gemm_desc g;
   // side stream for weight/bias gradients (falls back to the main stream without an aux handle)
@@ -349,8 +352,7 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
   const float* modf = w.mod + (size_t)6 * d.L * D;
   float* dmodf = w.dmod + (size_t)6 * d.L * D;
   RUN(sfron_ln_modulate_bwd((const uint16_t*)w.d_xmod, w.xs + (size_t)(2 * d.L) * M * D, w.mean + (size_t)(2 * d.L) * M,
-                            w.rstd + (size_t)(2 * d.L) * M, modf + D, NM, T, M, D, w.dx, 0, part0, part1, stream));
-  RUN(sfron_reduce2(part0, part1, B, per, D, dmodf, NM, dmodf + D, NM, stream));
+                            w.rstd + (size_t)(2 * d.L) * M, modf + D, NM, T, M, D, w.dx, 0, slot(d.L, 3, 0), slot(d.L, 3, 1), stream));
 
   for (int l = d.L - 1; l >= 0; --l) {
     const int64_t pb = P.blocks + (int64_t)l * P.blk_stride;
@@ -365,12 +367,11 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
     const bool first = (l == d.L - 1);
     // ---- MLP branch: x2 = x1 + gate_mlp * (fc2(gelu(fc1(xmod2))))
     before_overwrite(0, first);
-    RUN(sfron_gate_bwd(w.dx, (const uint16_t*)a2, mod + 5 * D, NM, T, M, D, (uint16_t*)w.d_br, part0, part1, stream));
+    RUN(sfron_gate_bwd(w.dx, (const uint16_t*)a2, mod + 5 * D, NM, T, M, D, (uint16_t*)w.d_br, slot(l, 0, 0), slot(l, 0, 1), stream));
     produced(0);
     g = wgrad_desc(w.d_br, h, M, D, d.F, grads + pb + P.o_fc2_w);
     RUN(sfron_gemm_bf16(&g, side));
     consumed(0);
-    RUN(sfron_reduce2(part0, part1, B, per, D, dmod + 5 * D, NM, w.dysum + ((size_t)(2 * l + 1) * B) * D, D, stream));
     before_overwrite(1, first);
     g = dgrad_desc(w.d_br, wb + pb + P.o_fc2_w, M, D, d.F);
     g.epilogue = SFRON_EPI_DGELU; g.c_bf16 = (uint16_t*)w.d_hpre; g.ldc_bf16 = d.F; g.aux = (uint16_t*)hpre; g.ldaux = d.F;
@@ -384,16 +385,14 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
     g.c_bf16 = (uint16_t*)w.d_xmod; g.ldc_bf16 = D;
     RUN(sfron_gemm_bf16(&g, stream));
     RUN(sfron_ln_modulate_bwd((const uint16_t*)w.d_xmod, x1, w.mean + (size_t)(2 * l + 1) * M, w.rstd + (size_t)(2 * l + 1) * M,
-                              mod + 4 * D, NM, T, M, D, w.dx, 1, part0, part1, stream));
-    RUN(sfron_reduce2(part0, part1, B, per, D, dmod + 3 * D, NM, dmod + 4 * D, NM, stream));
+                              mod + 4 * D, NM, T, M, D, w.dx, 1, slot(l, 1, 0), slot(l, 1, 1), stream));
     // ---- attention branch: x1 = x0 + gate_msa * proj(attn(qkv(xmod1)))
     before_overwrite(2, first);
-    RUN(sfron_gate_bwd(w.dx, (const uint16_t*)a1, mod + 2 * D, NM, T, M, D, (uint16_t*)w.d_br2, part0, part1, stream));
+    RUN(sfron_gate_bwd(w.dx, (const uint16_t*)a1, mod + 2 * D, NM, T, M, D, (uint16_t*)w.d_br2, slot(l, 2, 0), slot(l, 2, 1), stream));
     produced(2);
     g = wgrad_desc(w.d_br2, o, M, D, D, grads + pb + P.o_proj_w);
     RUN(sfron_gemm_bf16(&g, side));
     consumed(2);
-    RUN(sfron_reduce2(part0, part1, B, per, D, dmod + 2 * D, NM, w.dysum + ((size_t)(2 * l) * B) * D, D, stream));
     g = dgrad_desc(w.d_br2, wb + pb + P.o_proj_w, M, D, D);
     g.c_bf16 = (uint16_t*)w.d_o; g.ldc_bf16 = D;
     RUN(sfron_gemm_bf16(&g, stream));
@@ -409,8 +408,18 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
     g.c_bf16 = (uint16_t*)w.d_xmod; g.ldc_bf16 = D;
     RUN(sfron_gemm_bf16(&g, stream));
     RUN(sfron_ln_modulate_bwd((const uint16_t*)w.d_xmod, x0, w.mean + (size_t)(2 * l) * M, w.rstd + (size_t)(2 * l) * M,
-                              mod + D, NM, T, M, D, w.dx, 1, part0, part1, stream));
-    RUN(sfron_reduce2(part0, part1, B, per, D, dmod, NM, dmod + D, NM, stream));
+                              mod + D, NM, T, M, D, w.dx, 1, slot(l, 3, 0), slot(l, 3, 1), stream));
+  }
+  {
+    // deferred token reductions of the whole pass: d(shift, scale, gate) of every block + the dy token sums
+    float* const dst_base[8] = {w.dmod + 5 * D, w.dysum + (size_t)B * D,          // MLP gate:  d gate_mlp | sum_t dy (fc2.bias)
+                                w.dmod + 3 * D, w.dmod + 4 * D,                    // MLP LN:    d shift_mlp | d scale_mlp
+                                w.dmod + 2 * D, w.dysum,                           // attn gate: d gate_msa | sum_t dy (proj.bias)
+                                w.dmod, w.dmod + D};                               // attn LN:   d shift_msa | d scale_msa (final layer: layer L)
+    const long dst_stride[8] = {6L * D, 2L * B * D, 6L * D, 6L * D, 6L * D, 2L * B * D, 6L * D, 6L * D};
+    const int dst_ld[8] = {NM, D, NM, NM, NM, D, NM, NM};
+    RUN(sfron_reduce_slots(w.part, slot_stride, d.L * 8, B, per, D, dst_base, dst_stride, dst_ld, stream));
+    RUN(sfron_reduce2(slot(d.L, 3, 0), slot(d.L, 3, 1), B, per, D, dmodf, NM, dmodf + D, NM, stream));   // final layer's LN
   }
   if (ax) { (void)hipEventRecord(ax->done, ax->side); (void)hipStreamWaitEvent(hs, ax->done, 0); }   // join
   // proj.bias / fc2.bias gradients of every block: sum_b gate[b] * (sum_t dy[b,t])

@@ -81,35 +81,17 @@ __global__ __launch_bounds__(TPB) void k_ln_mod_fwd(const float* __restrict__ x,
   }
 }
 
-// cross-wave reduction of per-lane column partials through LDS; result written by wave 0
+// each wave stores its own column partials (row-chunk = the rpw rows of one wave); the sums over the chunks of a
+// sample are taken later in ONE launch for the whole backward pass (k_reduce_slots): no LDS, no barrier here
 template <int NACC>
-__device__ __forceinline__ void block_col_reduce_store(float4 (&acc)[NACC][NCH], float* lds, int D4, int lane, int wave,
-                                                       float* const (&dst)[NACC]) {
-  // lds layout: [wave 1..3][NACC][NCH*64] float4
-  float4* l4 = reinterpret_cast<float4*>(lds);
-  if (wave > 0) {
+__device__ __forceinline__ void wave_partial_store(const float4 (&acc)[NACC][NCH], int D4, int lane, float* const (&dst)[NACC]) {
 #pragma unroll
-    for (int a = 0; a < NACC; ++a)
+  for (int a = 0; a < NACC; ++a)
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) l4[((wave - 1) * NACC + a) * (NCH * 64) + i * 64 + lane] = acc[a][i];
-  }
-  __syncthreads();
-  if (wave == 0) {
-#pragma unroll
-    for (int a = 0; a < NACC; ++a)
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        const int c = lane + 64 * i;
-        if (c < D4) {
-          float4 t = acc[a][i];
-          for (int w = 0; w < 3; ++w) {
-            const float4 o = l4[(w * NACC + a) * (NCH * 64) + i * 64 + lane];
-            t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
-          }
-          reinterpret_cast<float4*>(dst[a])[c] = t;
-        }
-      }
-  }
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D4) reinterpret_cast<float4*>(dst[a])[c] = acc[a][i];
+    }
 }
 
 // ---------------------------------------------------------------- LN + modulate backward
@@ -119,11 +101,12 @@ __global__ __launch_bounds__(TPB) void k_ln_mod_bwd(const __bf16* __restrict__ d
                                                     const float* __restrict__ scale, int ldmod, int T, int M, int D,
                                                     int rpw, float* __restrict__ dx, int dx_accumulate,
                                                     float* __restrict__ p_shift, float* __restrict__ p_scale) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D4 = D >> 2;
-  const int row0 = blockIdx.x * (4 * rpw);
-  const int b = row0 / T;                        // all rows of a block belong to one sample (T % (4*rpw) == 0)
+  const int chunk = blockIdx.x * 4 + wave;       // one chunk = the rpw consecutive rows of this wave
+  const int row0 = chunk * rpw;
+  if (row0 >= M) return;
+  const int b = row0 / T;                        // all rows of a chunk belong to one sample (T % rpw == 0)
   float4 gs[NCH];                                // 1 + scale
   const float* sc = scale + (size_t)b * ldmod;
 #pragma unroll
@@ -136,8 +119,7 @@ __global__ __launch_bounds__(TPB) void k_ln_mod_bwd(const __bf16* __restrict__ d
 #pragma unroll
   for (int i = 0; i < NCH; ++i) { acc[0][i] = make_float4(0, 0, 0, 0); acc[1][i] = make_float4(0, 0, 0, 0); }
   for (int rr = 0; rr < rpw; ++rr) {
-    const int row = row0 + wave * rpw + rr;
-    if (row >= M) break;
+    const int row = row0 + rr;
     RowRegs xr, dr;
     load_row_f32(x + (size_t)row * D, D4, lane, xr);
     load_row_bf16(dxmod + (size_t)row * D, D4, lane, dr);
@@ -171,8 +153,8 @@ __global__ __launch_bounds__(TPB) void k_ln_mod_bwd(const __bf16* __restrict__ d
       }
     }
   }
-  float* const dst[2] = {p_shift + (size_t)blockIdx.x * D, p_scale + (size_t)blockIdx.x * D};
-  block_col_reduce_store<2>(acc, lds, D4, lane, wave, dst);
+  float* const dst[2] = {p_shift + (size_t)chunk * D, p_scale + (size_t)chunk * D};
+  wave_partial_store<2>(acc, D4, lane, dst);
 }
 
 // ---------------------------------------------------------------- gated-residual backward
@@ -181,10 +163,11 @@ __global__ __launch_bounds__(TPB) void k_gate_bwd(const float* __restrict__ dy, 
                                                   const float* __restrict__ gate, int ldmod, int T, int M, int D, int rpw,
                                                   __bf16* __restrict__ d_branch, float* __restrict__ p_gate,
                                                   float* __restrict__ p_dy) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D4 = D >> 2;
-  const int row0 = blockIdx.x * (4 * rpw);
+  const int chunk = blockIdx.x * 4 + wave;
+  const int row0 = chunk * rpw;
+  if (row0 >= M) return;
   const int b = row0 / T;
   float4 gt[NCH];
   const float* gp = gate + (size_t)b * ldmod;
@@ -197,8 +180,7 @@ __global__ __launch_bounds__(TPB) void k_gate_bwd(const float* __restrict__ dy, 
 #pragma unroll
   for (int i = 0; i < NCH; ++i) { acc[0][i] = make_float4(0, 0, 0, 0); acc[1][i] = make_float4(0, 0, 0, 0); }
   for (int rr = 0; rr < rpw; ++rr) {
-    const int row = row0 + wave * rpw + rr;
-    if (row >= M) break;
+    const int row = row0 + rr;
     RowRegs dr, br;
     load_row_f32(dy + (size_t)row * D, D4, lane, dr);
     load_row_bf16(branch + (size_t)row * D, D4, lane, br);
@@ -214,8 +196,8 @@ __global__ __launch_bounds__(TPB) void k_gate_bwd(const float* __restrict__ dy, 
       }
     }
   }
-  float* const dst[2] = {p_gate + (size_t)blockIdx.x * D, p_dy + (size_t)blockIdx.x * D};
-  block_col_reduce_store<2>(acc, lds, D4, lane, wave, dst);
+  float* const dst[2] = {p_gate + (size_t)chunk * D, p_dy + (size_t)chunk * D};
+  wave_partial_store<2>(acc, D4, lane, dst);
 }
 
 // ---------------------------------------------------------------- small fixed-order reductions
@@ -304,19 +286,35 @@ __global__ __launch_bounds__(TPB) void k_colsum_partial(const T* __restrict__ X,
   }
 }
 
-// rows per wave of the backward elementwise kernels: 2 (8 rows per workgroup -> M/8 workgroups keep every CU's
-// memory pipeline full; 32-row workgroups left the chip at 1 workgroup per CU and ~2.2 TB/s)
+// rows per wave (= rows per partial chunk) of the backward elementwise kernels
 inline int pick_rpw(int T) {
-  if (T % 8 == 0) return 2;
-  if (T % 4 == 0) return 1;
-  return 0;
+  if (T % 4 == 0) return 4;
+  if (T % 2 == 0) return 2;
+  return 1;
+}
+
+struct SlotDst { float* base; long layer_stride; int ld; };
+struct SlotArgs { SlotDst dst[8]; };      // [kind 0..3][buf 0..1]
+
+// One launch for the whole backward pass: slot s = (layer, kind, buf) holds per-chunk partials [B*per][D];
+// out[dst(kind,buf).base + layer*stride + b*ld + c] = sum_j partial[(b*per + j)*D + c]
+__global__ __launch_bounds__(TPB) void k_reduce_slots(const float* __restrict__ parts, long slot_stride, int per, int D, SlotArgs a) {
+  const int slot = blockIdx.z, b = blockIdx.y;
+  const int c = blockIdx.x * TPB + threadIdx.x;
+  if (c >= D) return;
+  const int layer = slot >> 3, kb = slot & 7;
+  const float* p = parts + (size_t)slot * slot_stride + (size_t)b * per * D + c;
+  float s = 0.f;
+  for (int j = 0; j < per; ++j) s += p[(size_t)j * D];
+  const SlotDst d = a.dst[kb];
+  d.base[(size_t)layer * d.layer_stride + (size_t)b * d.ld + c] = s;
 }
 
 }  // namespace
 
 extern "C" {
 
-int sfron_rows_per_chunk(int tokens) { int r = pick_rpw(tokens); return r ? 4 * r : 0; }
+int sfron_rows_per_chunk(int tokens) { return tokens > 0 ? pick_rpw(tokens) : 0; }
 
 int sfron_ln_modulate_fwd(const float* x, const float* shift, const float* scale, int ldmod, int tokens, int M, int D,
                           uint16_t* out, float* mean, float* rstd, void* stream) {
@@ -335,9 +333,8 @@ int sfron_ln_modulate_bwd(const uint16_t* d_out, const float* x, const float* me
   SFRON_CHECK_ARG(d_out && x && mean && rstd && scale && dx && p_shift && p_scale && M > 0);
   SFRON_CHECK_ARG(D % 4 == 0 && D <= 64 * 4 * NCH && ldmod % 4 == 0);
   const int rpw = pick_rpw(tokens);
-  SFRON_CHECK_ARG(rpw > 0 && M % tokens == 0);
-  const size_t lds = 3 * 2 * NCH * 64 * sizeof(float4);
-  hipLaunchKernelGGL(k_ln_mod_bwd, dim3(M / (4 * rpw)), dim3(TPB), lds, (hipStream_t)stream, (const __bf16*)d_out, x, mean,
+  SFRON_CHECK_ARG(M % tokens == 0);
+  hipLaunchKernelGGL(k_ln_mod_bwd, dim3(cdiv(M / rpw, 4)), dim3(TPB), 0, (hipStream_t)stream, (const __bf16*)d_out, x, mean,
                      rstd, scale, ldmod, tokens, M, D, rpw, dx, dx_accumulate, p_shift, p_scale);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
@@ -348,9 +345,8 @@ int sfron_gate_bwd(const float* dy, const uint16_t* branch, const float* gate, i
   SFRON_CHECK_ARG(dy && branch && gate && d_branch && p_gate && p_dy && M > 0);
   SFRON_CHECK_ARG(D % 4 == 0 && D <= 64 * 4 * NCH && ldmod % 4 == 0);
   const int rpw = pick_rpw(tokens);
-  SFRON_CHECK_ARG(rpw > 0 && M % tokens == 0);
-  const size_t lds = 3 * 2 * NCH * 64 * sizeof(float4);
-  hipLaunchKernelGGL(k_gate_bwd, dim3(M / (4 * rpw)), dim3(TPB), lds, (hipStream_t)stream, dy, (const __bf16*)branch, gate,
+  SFRON_CHECK_ARG(M % tokens == 0);
+  hipLaunchKernelGGL(k_gate_bwd, dim3(cdiv(M / rpw, 4)), dim3(TPB), 0, (hipStream_t)stream, dy, (const __bf16*)branch, gate,
                      ldmod, tokens, M, D, rpw, (__bf16*)d_branch, p_gate, p_dy);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
@@ -379,6 +375,17 @@ int sfron_gated_bias_grads(const float* S, const float* gate, int ldg, long gate
   SFRON_CHECK_ARG(S && gate && out && layers > 0 && B > 0 && D > 0);
   hipLaunchKernelGGL(k_gated_bias_grads, dim3(cdiv(D, TPB), 2 * layers), dim3(TPB), 0, (hipStream_t)stream, S, gate, ldg,
                      gate_stride, gate_which, B, D, out, out_stride, out_which0, out_which1);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_reduce_slots(const float* parts, long slot_stride, int n_slots, int groups, int per_group, int D,
+                       float* const* dst_base, const long* dst_layer_stride, const int* dst_ld, void* stream) {
+  SFRON_CHECK_ARG(parts && dst_base && dst_layer_stride && dst_ld && n_slots > 0 && groups > 0 && per_group > 0 && D > 0);
+  SlotArgs a;
+  for (int i = 0; i < 8; ++i) a.dst[i] = SlotDst{dst_base[i], dst_layer_stride[i], dst_ld[i]};
+  hipLaunchKernelGGL(k_reduce_slots, dim3(cdiv(D, TPB), groups, n_slots), dim3(TPB), 0, (hipStream_t)stream, parts, slot_stride,
+                     per_group, D, a);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }
