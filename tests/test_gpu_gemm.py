@@ -129,7 +129,7 @@ def test_gemm_rejects_bad_args():
         ops.gemm(A, A, 128, 128, 60, c_bf16=torch.zeros(128, 128, dtype=torch.bfloat16, device=DEV))   # K % 8 != 0
 
 
-@pytest.mark.parametrize("hint", [1, 2, 3])
+@pytest.mark.parametrize("hint", [1, 2, 3, 12, 13])
 @pytest.mark.parametrize("layout", ["fwd", "dgrad", "wgrad"])
 def test_fast_tiles_all_layouts(hint, layout):
     """LDS-DMA fast path (tile_hint 1: 128x128, 2: 256x128, 3: 256x256) vs the generic kernel and torch."""
@@ -154,3 +154,27 @@ def test_fast_tiles_all_layouts(hint, layout):
     ops.gemm(A.to(DEV), B.to(DEV), M, N, K, epilogue=_lib.EPI_F32, c_f32=Cg, tile_hint=-1, **kw)
     np.testing.assert_allclose(Cf.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4 * K ** 0.5)
     assert torch.equal(Cf, Cg), "fast and generic kernels accumulate in the same order: results must be identical"
+
+
+@pytest.mark.parametrize("layout", ["fwd", "dgrad", "wgrad"])
+def test_ring_tile_192(layout):
+    """192x192 ring tile (hint 15) on a 384 x 576 output, K = 96 (3 stages < ring depth) and K = 1024."""
+    from sfron import ops, _lib
+    for K in (96, 1024):
+        M, N = 384, 576
+        gen = torch.Generator().manual_seed(K + len(layout))
+        if layout == "fwd":
+            A, B, kw = _rand((M, K), gen), _rand((N, K), gen, 0.1), dict()
+            want = A.float() @ B.float().t()
+        elif layout == "dgrad":
+            A, B, kw = _rand((M, K), gen), _rand((K, N), gen, 0.1), dict(b_t=True)
+            want = A.float() @ B.float()
+        else:
+            A, B, kw = _rand((K, M), gen, 0.1), _rand((K, N), gen), dict(a_t=True, b_t=True)
+            want = A.float().t() @ B.float()
+        Cf = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+        Cg = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+        ops.gemm(A.to(DEV), B.to(DEV), M, N, K, epilogue=_lib.EPI_F32, c_f32=Cf, tile_hint=15, **kw)
+        ops.gemm(A.to(DEV), B.to(DEV), M, N, K, epilogue=_lib.EPI_F32, c_f32=Cg, tile_hint=-1, **kw)
+        np.testing.assert_allclose(Cf.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4 * K ** 0.5)
+        assert torch.equal(Cf, Cg)

@@ -300,6 +300,9 @@ struct GldsPlan {
       else     off[i] = 2 * (row * ld + d0 + (swz_chunk<EXT>(row, p) << 3));
     }
   }
+  __device__ __forceinline__ void issue_one(__amdgpu_buffer_rsrc_t rsrc, int soff_bytes, __bf16* img, int wave, int i) const {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t*)(img + (wave + i * NW) * 512), 16, off[i], soff_bytes, 0, 0);
+  }
   // buffer_load_dwordx4 ... offen lds: SRD (uniform) + per-lane voffset (loop invariant) + uniform soffset (K advance)
   __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rsrc, int soff_bytes, __bf16* img, int wave) const {
 #pragma unroll
@@ -326,7 +329,7 @@ __device__ __forceinline__ bf16x8 frag_tr_w(const __bf16* img, int col0, int kr0
 }  // namespace  (kernel templates get external linkage: hipcc does not emit the kernel handle of an
    //             internal-linkage template instantiation that is only referenced through a launch)
 
-template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI>
+template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI, int DBG = 0>   // DBG: 1 = no MFMA, 2 = no DMA in the loop (timing ablations)
 __global__ __launch_bounds__(WM * WN * 64) void k_gemm_fast(GemmArgs g) {
   constexpr int FBM = WM * MT * 16, FBN = WN * NT * 16, NW = WM * WN;
   constexpr int A_ELEMS = FBM * 64, B_ELEMS = FBN * 64;
@@ -366,6 +369,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_fast(GemmArgs g) {
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, 0x7fffffff, 0x00020000);
   auto stage = [&](__bf16* iA, __bf16* iB, int k0) {
+    if (DBG == 2 && k0 > 0) return;
     planA.issue(rsA, 2 * (A_TR ? k0 * g.lda : k0), iA, wave);
     planB.issue(rsB, 2 * (B_TR ? k0 * g.ldb : k0), iB, wave);
   };
@@ -377,32 +381,68 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_fast(GemmArgs g) {
     if (!B_TR) return frag_direct(iB, wn * NT * 16 + nt * 16 + (lane & 15), ks * 4 + (lane >> 4));
     return frag_tr_w<FBN>(iB, wn * NT * 16 + nt * 16, ks * 32, lane);
   };
-  // hold the operand with fewer fragments in registers, stream the other: bounded live ranges (acc dominates)
-  auto compute = [&](const __bf16* iA, const __bf16* iB) {
+  // One K-tile of work, software pipelined by hand:
+  //  * the operand with fewer fragments per k-step is HELD (loaded one k-step ahead), the other is STREAMED one
+  //    fragment ahead of the MFMAs that consume it, so an LDS read is always in flight under the matrix pipe;
+  //  * the LDS-DMA instructions of the NEXT tile are issued one per MFMA group instead of as a burst at the
+  //    start of the tile (smoother L2 -> LDS traffic).
+  constexpr int HELD = (NT <= MT) ? NT : MT, STRM = (NT <= MT) ? MT : NT;
+  constexpr bool HOLD_B = NT <= MT;
+  auto load_held = [&](const __bf16* iA, const __bf16* iB, int i, int ks) { return HOLD_B ? load_b(iB, i, ks) : load_a(iA, i, ks); };
+  auto load_strm = [&](const __bf16* iA, const __bf16* iB, int i, int ks) { return HOLD_B ? load_a(iA, i, ks) : load_b(iB, i, ks); };
+  constexpr int NDMA_A = decltype(planA)::PER_WAVE, NDMA = NDMA_A + decltype(planB)::PER_WAVE;
+  constexpr bool PIPE = !A_TR && !B_TR;     // hand pipelining pays for row-fragment (ds_read_b128) operands only
+  auto compute = [&](const __bf16* iA, const __bf16* iB, bool prefetch, __bf16* nA, __bf16* nB, int k_next) {
+    if (DBG == 1) { if (prefetch) stage(nA, nB, k_next); return; }
+    if constexpr (!PIPE) {
+      if (prefetch) stage(nA, nB, k_next);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 hd[HELD];
+#pragma unroll
+        for (int i = 0; i < HELD; ++i) hd[i] = load_held(iA, iB, i, ks);
+#pragma unroll
+        for (int j = 0; j < STRM; ++j) {
+          const bf16x8 f = load_strm(iA, iB, j, ks);
+#pragma unroll
+          for (int i = 0; i < HELD; ++i) {
+            if (HOLD_B) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hd[i], f, acc[j][i], 0, 0, 0);
+            else        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, hd[i], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+      return;
+    }
+    const int soffA = 2 * (A_TR ? k_next * g.lda : k_next), soffB = 2 * (B_TR ? k_next * g.ldb : k_next);
+    bf16x8 held[2][HELD];
+#pragma unroll
+    for (int i = 0; i < HELD; ++i) held[0][i] = load_held(iA, iB, i, 0);
+    bf16x8 cur = load_strm(iA, iB, 0, 0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      if (NT <= MT) {
-        bf16x8 fb[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) fb[nt] = load_b(iB, nt, ks);
+      for (int j = 0; j < STRM; ++j) {
+        const int step = ks * STRM + j;
+        // next streamed fragment (possibly of the next k-step) goes out before this group's MFMAs
+        bf16x8 nxt = cur;
+        if (j + 1 < STRM) nxt = load_strm(iA, iB, j + 1, ks);
+        else if (ks == 0) nxt = load_strm(iA, iB, 0, 1);
+        if (ks == 0 && j == STRM - 1) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const bf16x8 fa = load_a(iA, mt, ks);
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa, acc[mt][nt], 0, 0, 0);
+          for (int i = 0; i < HELD; ++i) held[1][i] = load_held(iA, iB, i, 1);
         }
-      } else {
-        bf16x8 fa[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) fa[mt] = load_a(iA, mt, ks);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const bf16x8 fb = load_b(iB, nt, ks);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[mt], acc[mt][nt], 0, 0, 0);
+        if (DBG != 2 && prefetch && step < NDMA) {
+          if (step < NDMA_A) planA.issue_one(rsA, soffA, nA, wave, step);
+          else               planB.issue_one(rsB, soffB, nB, wave, step - NDMA_A);
         }
+        __builtin_amdgcn_sched_barrier(0);      // keep the reads above ahead of this group's MFMAs (hipcc sinks them otherwise)
+#pragma unroll
+        for (int i = 0; i < HELD; ++i) {
+          if (HOLD_B) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(held[ks][i], cur, acc[j][i], 0, 0, 0);
+          else        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur, held[ks][i], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
       }
     }
   };
@@ -413,23 +453,20 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_fast(GemmArgs g) {
   __builtin_amdgcn_s_barrier();
   int kt = 0;
   for (; kt + 2 <= nk - 1; kt += 2) {
-    stage(sA1, sB1, (kt + 1) * BK);
-    compute(sA0, sB0);
+    compute(sA0, sB0, true, sA1, sB1, (kt + 1) * BK);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    stage(sA0, sB0, (kt + 2) * BK);
-    compute(sA1, sB1);
+    compute(sA1, sB1, true, sA0, sB0, (kt + 2) * BK);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
   if (kt + 1 <= nk - 1) {          // two tiles left: kt (in buffer 0) and kt+1
-    stage(sA1, sB1, (kt + 1) * BK);
-    compute(sA0, sB0);
+    compute(sA0, sB0, true, sA1, sB1, (kt + 1) * BK);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    compute(sA1, sB1);
+    compute(sA1, sB1, false, sA0, sB0, 0);
   } else {                          // one tile left, in buffer 0
-    compute(sA0, sB0);
+    compute(sA0, sB0, false, sA1, sB1, 0);
   }
 
   // epilogues that READ a tensor (pre-activation / residual stream) issue all their loads first, so the 24..36
@@ -508,10 +545,12 @@ SFRON_INST_TILE(4, 2, 3, 6)
 SFRON_INST_TILE(2, 2, 8, 6)
 SFRON_INST_TILE(2, 2, 6, 6)
 #undef SFRON_INST_TILE
+template __global__ void k_gemm_fast<4, 2, 4, 6, false, false, 0, 1>(GemmArgs);
+template __global__ void k_gemm_fast<4, 2, 4, 6, false, false, 0, 2>(GemmArgs);
 
 namespace {
 
-template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI>
+template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI, int DBG = 0>
 int launch_fast(GemmArgs g, hipStream_t s) {
   constexpr int FBM = WM * MT * 16, FBN = WN * NT * 16;
   g.ntm = g.M / FBM; g.ntn = g.N / FBN;
@@ -526,16 +565,243 @@ int launch_fast(GemmArgs g, hipStream_t s) {
   if (lds > 65536) {
     static bool done = false;      // per instantiation
     if (!done) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_fast<WM, WN, MT, NT, A_TR, B_TR, EPI>),
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_fast<WM, WN, MT, NT, A_TR, B_TR, EPI, DBG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return (int)hipGetLastError();
       done = true;
     }
   }
-  hipLaunchKernelGGL((k_gemm_fast<WM, WN, MT, NT, A_TR, B_TR, EPI>), dim3(g.ntm * g.ntn), dim3(WM * WN * 64), lds, s, g);
+  hipLaunchKernelGGL((k_gemm_fast<WM, WN, MT, NT, A_TR, B_TR, EPI, DBG>), dim3(g.ntm * g.ntn), dim3(WM * WN * 64), lds, s, g);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
 }
+
+}  // namespace
+
+// =================================================================================================
+// Ring path: the same 8-wave tiles with BK = 32 stages in an NSTAGE-deep LDS ring and COUNTED vmcnt.
+// The 2-stage kernel above keeps at most one tile (56 KB per CU) of LDS-DMA in flight and is bound by
+// bytes-in-flight / load latency (~41 GB/s per CU measured); here NSTAGE-1 stages are in flight, vmcnt never
+// drains in the steady state and there is one raw s_barrier per stage.
+// =================================================================================================
+// direct image [ROWS][32]: 64-B rows, chunk c of row r stored at c ^ (((r>>3)&1)<<1)   (conflict-free ds_read_b128)
+__device__ __forceinline__ int swz32(int row) { return ((row >> 3) & 1) << 1; }
+
+template <int FBM, int FBN, bool A_TR, bool B_TR, int NW>
+struct RingPlan {
+  static constexpr int NA = A_TR ? 32 * (FBM / 8) / 64 : FBM * 4 / 64;    // wave-instructions of the A image
+  static constexpr int NB = B_TR ? 32 * (FBN / 8) / 64 : FBN * 4 / 64;
+  static constexpr int NI = NA + NB;
+  static constexpr int PER_HI = (NI + NW - 1) / NW, PER_LO = NI / NW;      // instructions of waves < NI % NW, and of the rest
+  static constexpr int A_ELEMS = FBM * 32, B_ELEMS = FBN * 32, STAGE_ELEMS = A_ELEMS + B_ELEMS;
+  int off[PER_HI];
+  template <int EXT, bool TR> static __device__ __forceinline__ int lane_off(int j, int lane, int ld, int d0) {
+    constexpr int CPR = TR ? EXT / 8 : 4;
+    const int e = j * 64 + lane, row = e / CPR, p = e % CPR;
+    if (!TR) return 2 * ((d0 + row) * ld + ((p ^ swz32(row)) << 3));
+    return 2 * (row * ld + d0 + (swz_chunk<EXT>(row, p) << 3));
+  }
+  __device__ __forceinline__ void init(int lda, int ldb, int m0, int n0, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < PER_HI; ++i) {
+      const int j = wave + i * NW;
+      off[i] = j < NA ? lane_off<FBM, A_TR>(j, lane, lda, m0) : lane_off<FBN, B_TR>(j - NA, lane, ldb, n0);
+    }
+  }
+  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, int soffA, int soffB,
+                                        __bf16* stage, int wave) const {
+#pragma unroll
+    for (int i = 0; i < PER_HI; ++i) {
+      const int j = wave + i * NW;
+      if (j < NI) {
+        if (j < NA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t*)(stage + j * 512), 16, off[i], soffA, 0, 0);
+        else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t*)(stage + A_ELEMS + (j - NA) * 512), 16, off[i], soffB, 0, 0);
+      }
+    }
+  }
+};
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI, int NSTAGE>
+__global__ __launch_bounds__(WM * WN * 64) void k_gemm_ring(GemmArgs g) {
+  constexpr int FBM = WM * MT * 16, FBN = WN * NT * 16, NW = WM * WN;
+  using Plan = RingPlan<FBM, FBN, A_TR, B_TR, NW>;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int nblk = gridDim.x;
+  int id;
+  {
+    const int b = blockIdx.x, q = nblk >> 3, r = nblk & 7, x = b & 7, y = b >> 3;
+    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+  }
+  const int per_group = g.group_m * g.ntn;
+  const int first_m = (id / per_group) * g.group_m;
+  const int gsz = min(g.ntm - first_m, g.group_m);
+  const int tm = first_m + (id % per_group) % gsz, tn = (id % per_group) / gsz;
+  const int m0 = tm * FBM, n0 = tn * FBN;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  Plan plan;
+  plan.init(g.lda, g.ldb, m0, n0, wave, lane);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, 0x7fffffff, 0x00020000);
+  const int kstepA = 2 * (A_TR ? 32 * g.lda : 32), kstepB = 2 * (B_TR ? 32 * g.ldb : 32);   // bytes per stage
+  auto issue = [&](int st) { plan.issue(rsA, rsB, st * kstepA, st * kstepB, smem + (st % NSTAGE) * Plan::STAGE_ELEMS, wave); };
+
+  auto compute = [&](const __bf16* iA, const __bf16* iB) {
+    auto load_a = [&](int mt) -> bf16x8 {
+      const int row = wm * MT * 16 + mt * 16 + (lane & 15);
+      if (!A_TR) return *reinterpret_cast<const bf16x8*>(iA + row * 32 + (((lane >> 4) ^ swz32(row)) << 3));
+      return frag_tr_w<FBM>(iA, wm * MT * 16 + mt * 16, 0, lane);
+    };
+    auto load_b = [&](int nt) -> bf16x8 {
+      const int row = wn * NT * 16 + nt * 16 + (lane & 15);
+      if (!B_TR) return *reinterpret_cast<const bf16x8*>(iB + row * 32 + (((lane >> 4) ^ swz32(row)) << 3));
+      return frag_tr_w<FBN>(iB, wn * NT * 16 + nt * 16, 0, lane);
+    };
+    if (NT <= MT) {
+      bf16x8 fb[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) fb[nt] = load_b(nt);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const bf16x8 fa = load_a(mt);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa, acc[mt][nt], 0, 0, 0);
+      }
+    } else {
+      bf16x8 fa[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) fa[mt] = load_a(mt);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bf16x8 fb = load_b(nt);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[mt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+  };
+
+  const int ns = g.K / 32;                       // stages of this tile
+  const bool hi = wave < (Plan::NI % NW);        // this wave issues PER_HI (else PER_LO) DMA instructions per stage
+#pragma unroll
+  for (int st = 0; st < NSTAGE - 1; ++st)
+    if (st < ns) issue(st);
+  for (int st = 0; st < ns; ++st) {
+    // stage `st` must have landed; in the steady state NSTAGE-2 younger stages stay in flight
+    if (st + NSTAGE - 2 < ns) {
+      if (Plan::PER_HI != Plan::PER_LO && !hi) wait_vm<(NSTAGE - 2) * Plan::PER_LO>(); else wait_vm<(NSTAGE - 2) * Plan::PER_HI>();
+    } else {
+      wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (st + NSTAGE - 1 < ns) issue(st + NSTAGE - 1);
+    const __bf16* sbase = smem + (st % NSTAGE) * Plan::STAGE_ELEMS;
+    compute(sbase, sbase + Plan::A_ELEMS);
+  }
+
+  const int row_b = m0 + wm * MT * 16 + (lane & 15), col_b = n0 + wn * NT * 16 + 4 * (lane >> 4);
+  if constexpr (EPI == EPI_DGELU) {
+    bf16x4 hx[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        hx[mt][nt] = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)(row_b + mt * 16) * g.ldaux + col_b + nt * 16);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 v = acc[mt][nt] * g.alpha;
+        const bf16x4 h = hx[mt][nt];
+        bf16x4 o = {f2bf(v[0] * gelu_tanh_grad(bf2f(h[0]))), f2bf(v[1] * gelu_tanh_grad(bf2f(h[1]))),
+                    f2bf(v[2] * gelu_tanh_grad(bf2f(h[2]))), f2bf(v[3] * gelu_tanh_grad(bf2f(h[3])))};
+        *reinterpret_cast<bf16x4*>(g.Cb + (size_t)(row_b + mt * 16) * g.ldcb + col_b + nt * 16) = o;
+      }
+  } else if constexpr (EPI == EPI_GATE_RES) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = row_b + mt * 16;
+      float4 xr[NT], gt[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        xr[nt] = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldcf + col_b + nt * 16);
+        gt[nt] = *reinterpret_cast<const float4*>(g.gate + (size_t)(row / g.T) * g.ldgate + col_b + nt * 16);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = col_b + nt * 16;
+        f32x4 v = acc[mt][nt] * g.alpha;
+        if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+        bf16x4 a = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col) = a;
+        float4 x = xr[nt];
+        x.x += gt[nt].x * v[0]; x.y += gt[nt].y * v[1]; x.z += gt[nt].z * v[2]; x.w += gt[nt].w * v[3];
+        *reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col) = x;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        epilogue_store<EPI>(g, row_b + mt * 16, col_b + nt * 16, acc[mt][nt]);
+  }
+}
+
+#define SFRON_INST_RING(WM, WN, MT, NT, NS)                                              \
+  template __global__ void k_gemm_ring<WM, WN, MT, NT, false, false, 0, NS>(GemmArgs);  \
+  template __global__ void k_gemm_ring<WM, WN, MT, NT, false, false, 1, NS>(GemmArgs);  \
+  template __global__ void k_gemm_ring<WM, WN, MT, NT, false, false, 2, NS>(GemmArgs);  \
+  template __global__ void k_gemm_ring<WM, WN, MT, NT, false, false, 3, NS>(GemmArgs);  \
+  template __global__ void k_gemm_ring<WM, WN, MT, NT, false, false, 5, NS>(GemmArgs);  \
+  template __global__ void k_gemm_ring<WM, WN, MT, NT, false, true, 0, NS>(GemmArgs);   \
+  template __global__ void k_gemm_ring<WM, WN, MT, NT, false, true, 1, NS>(GemmArgs);   \
+  template __global__ void k_gemm_ring<WM, WN, MT, NT, false, true, 4, NS>(GemmArgs);   \
+  template __global__ void k_gemm_ring<WM, WN, MT, NT, true, true, 0, NS>(GemmArgs);    \
+  template __global__ void k_gemm_ring<WM, WN, MT, NT, true, true, 1, NS>(GemmArgs);
+SFRON_INST_RING(4, 2, 4, 6, 5)
+SFRON_INST_RING(2, 4, 8, 4, 4)
+SFRON_INST_RING(4, 2, 3, 6, 6)
+#undef SFRON_INST_RING
+
+namespace {
+
+template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI, int NSTAGE>
+int launch_ring(GemmArgs g, hipStream_t s) {
+  constexpr int FBM = WM * MT * 16, FBN = WN * NT * 16;
+  g.ntm = g.M / FBM; g.ntn = g.N / FBN;
+  {
+    const double per_xcd = (double)g.ntm * g.ntn / 8.0;
+    int gm = 1;
+    while (gm * 2 <= g.ntm && (double)(gm * 2) * (gm * 2) * FBM <= per_xcd * FBN * 1.5) gm *= 2;
+    g.group_m = gm;
+  }
+  const size_t lds = (size_t)NSTAGE * (FBM + FBN) * 32 * sizeof(__bf16);
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<WM, WN, MT, NT, A_TR, B_TR, EPI, NSTAGE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return (int)hipGetLastError();
+    done = true;
+  }
+  hipLaunchKernelGGL((k_gemm_ring<WM, WN, MT, NT, A_TR, B_TR, EPI, NSTAGE>), dim3(g.ntm * g.ntn), dim3(WM * WN * 64), lds, s, g);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SFRON_OK : (int)e;
+}
+
+}  // namespace
+
+namespace {
 
 // fast tiles: 1 = 128x128 (4 waves), 2 = 256x192, 3 = 256x256, 4 = 384x192 (8 waves); 0 = generic kernel.
 // 8-wave tiles halve the L1->LDS bytes per FLOP of the 128x128 tile (which is vector-memory bound at ~600 TF).
@@ -547,6 +813,8 @@ inline bool tile_fits(const GemmArgs& g, int t) {
 }
 inline int pick_fast_tile(const GemmArgs& g, int force, int transposed_operands) {
   if (g.K % 64 || g.kchunk != g.K || force < 0) return 0;
+  if (force == 21 || force == 22) return tile_fits(g, 2) ? force : 0;            // timing ablations of tile 2
+  if (force > 10) return (g.K % 32 == 0 && tile_fits(g, force - 10)) ? force : 0;   // ring variants of tiles 2, 3, 5
   if (force > 0) return tile_fits(g, force) ? force : 0;
   // prefer the 8-wave tile with the best last-round occupancy of the 256 CUs; small problems keep 128x128
   int best = 0; double best_eff = 0.0;
@@ -570,6 +838,11 @@ int launch_any(const GemmArgs& g, hipStream_t s, int force) {
     case 5: return launch_fast<4, 2, 3, 6, A_TR, B_TR, EPI>(g, s);
     case 6: return launch_fast<2, 2, 8, 6, A_TR, B_TR, EPI>(g, s);
     case 7: return launch_fast<2, 2, 6, 6, A_TR, B_TR, EPI>(g, s);
+    case 21: if constexpr (!A_TR && !B_TR && EPI == EPI_BF16) return launch_fast<4, 2, 4, 6, false, false, 0, 1>(g, s); else return SFRON_ERR_UNSUPPORTED;
+    case 22: if constexpr (!A_TR && !B_TR && EPI == EPI_BF16) return launch_fast<4, 2, 4, 6, false, false, 0, 2>(g, s); else return SFRON_ERR_UNSUPPORTED;
+    case 12: return launch_ring<4, 2, 4, 6, A_TR, B_TR, EPI, 5>(g, s);
+    case 13: return launch_ring<2, 4, 8, 4, A_TR, B_TR, EPI, 4>(g, s);
+    case 15: return launch_ring<4, 2, 3, 6, A_TR, B_TR, EPI, 6>(g, s);
     default: return launch<A_TR, B_TR, EPI>(g, s);
   }
 }
