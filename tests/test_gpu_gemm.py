@@ -129,7 +129,7 @@ def test_gemm_rejects_bad_args():
         ops.gemm(A, A, 128, 128, 60, c_bf16=torch.zeros(128, 128, dtype=torch.bfloat16, device=DEV))   # K % 8 != 0
 
 
-@pytest.mark.parametrize("hint", [1, 2, 3, 12, 13])
+@pytest.mark.parametrize("hint", [1, 2, 3, 12, 13, 32])
 @pytest.mark.parametrize("layout", ["fwd", "dgrad", "wgrad"])
 def test_fast_tiles_all_layouts(hint, layout):
     """LDS-DMA fast path (tile_hint 1: 128x128, 2: 256x128, 3: 256x256) vs the generic kernel and torch."""
@@ -175,6 +175,10 @@ def test_ring_tile_192(layout):
         Cf = torch.zeros(M, N, dtype=torch.float32, device=DEV)
         Cg = torch.zeros(M, N, dtype=torch.float32, device=DEV)
         ops.gemm(A.to(DEV), B.to(DEV), M, N, K, epilogue=_lib.EPI_F32, c_f32=Cf, tile_hint=15, **kw)
+        Cp = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+        ops.gemm(A.to(DEV), B.to(DEV), M, N, K, epilogue=_lib.EPI_F32, c_f32=Cp, tile_hint=35, **kw)
         ops.gemm(A.to(DEV), B.to(DEV), M, N, K, epilogue=_lib.EPI_F32, c_f32=Cg, tile_hint=-1, **kw)
         np.testing.assert_allclose(Cf.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4 * K ** 0.5)
         assert torch.equal(Cf, Cg)
+        if K % 64 == 0:
+            assert torch.equal(Cp, Cg), "hand-pipelined 192x192 tile"

@@ -15,3 +15,9 @@ for name,N,K in (("fc2 N1152 K4608",D,F),("qkv N3456 K1152",3*D,D),("fc1 N4608 K
     for h,lab in ((2,"full"),(21,"no-mfma"),(22,"no-dma")):
         ms=timeit(lambda: ops.gemm(A,B,M,N,K,c_bf16=C,tile_hint=h))
         print(f"{name} {lab:8s} {ms*1e3:8.1f} us")
+
+# wgrad fc1: dW[4608,1152] = dY[8192,4608]^T X[8192,1152]
+dY, X = rnd(M, F), rnd(M, D); C = torch.empty(F, D, dtype=torch.float32, device=DEV)
+for h, lab in ((2, "full"), (21, "no-mfma"), (22, "no-dma"), (-1, "generic"), (32, "pipe")):
+    ms = timeit(lambda: ops.gemm(dY, X, F, D, M, a_t=True, b_t=True, epilogue=_lib.EPI_F32, c_f32=C, tile_hint=h))
+    print(f"wgrad fc1 (108 tiles of 256x192, K=8192) {lab:8s} {ms*1e3:8.1f} us")

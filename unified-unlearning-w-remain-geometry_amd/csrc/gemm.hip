@@ -104,12 +104,17 @@ struct Stager {
       }
     }
   }
+  template <bool FULL>
   __device__ __forceinline__ void load(uint4 (&r)[4], int k0, int K) const {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bool ok = valid[i] && (k0 + kidx[i] < K);
       const __bf16* p = TR ? base[i] + (size_t)k0 * ld : base[i] + k0;
-      r[i] = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+      if (FULL) {               // whole tile in range: no predication (each predicated load costs an exec-mask branch)
+        r[i] = *reinterpret_cast<const uint4*>(p);
+      } else {
+        const bool ok = valid[i] && (k0 + kidx[i] < K);
+        r[i] = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+      }
     }
   }
   __device__ __forceinline__ void store(__bf16* img, const uint4 (&r)[4]) const {
@@ -159,7 +164,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int row, int c
   }
 }
 
-template <bool A_TR, bool B_TR, int EPI>
+template <bool A_TR, bool B_TR, int EPI, bool FULL>
 __global__ __launch_bounds__(NT) void k_gemm(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
   __bf16* sA = smem;                       // [2][TILE_ELEMS]
@@ -198,8 +203,8 @@ __global__ __launch_bounds__(NT) void k_gemm(GemmArgs g) {
 
   const int nk = (kend - kbeg + BK - 1) / BK;
   uint4 ra[4], rb[4];
-  stA.load(ra, kbeg, kend);
-  stB.load(rb, kbeg, kend);
+  stA.template load<FULL>(ra, kbeg, kend);
+  stB.template load<FULL>(rb, kbeg, kend);
   stA.store(sA, ra);
   stB.store(sB, rb);
   __syncthreads();
@@ -208,11 +213,12 @@ __global__ __launch_bounds__(NT) void k_gemm(GemmArgs g) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nk;
     if (more) {
-      stA.load(ra, kbeg + (kt + 1) * BK, kend);
-      stB.load(rb, kbeg + (kt + 1) * BK, kend);
+      stA.template load<FULL>(ra, kbeg + (kt + 1) * BK, kend);
+      stB.template load<FULL>(rb, kbeg + (kt + 1) * BK, kend);
     }
     const __bf16* iA = sA + cur * TILE_ELEMS;
     const __bf16* iB = sB + cur * TILE_ELEMS;
+    if (FULL) __builtin_amdgcn_sched_barrier(0);     // keep the staging loads ahead of this tile's MFMAs
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 fa[4], fb[4];
@@ -232,6 +238,7 @@ __global__ __launch_bounds__(NT) void k_gemm(GemmArgs g) {
         for (int nt = 0; nt < 4; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
     }
+    if (FULL) __builtin_amdgcn_sched_barrier(0);     // ... and the ds_writes of the next tile behind them
     if (more) {
       stA.store(sA + (cur ^ 1) * TILE_ELEMS, ra);
       stB.store(sB + (cur ^ 1) * TILE_ELEMS, rb);
@@ -257,7 +264,13 @@ template <bool A_TR, bool B_TR, int EPI>
 int launch(const GemmArgs& g, hipStream_t s) {
   const size_t lds = 4 * TILE_ELEMS * sizeof(__bf16);
   const int splits = (g.K + g.kchunk - 1) / g.kchunk;
-  hipLaunchKernelGGL((k_gemm<A_TR, B_TR, EPI>), dim3(g.ntm * g.ntn * splits), dim3(NT), lds, s, g);
+  // FULL = true (unpredicated staging loads) measured 2.7x SLOWER on gfx950/ROCm 7.2: hipcc then sinks the loads next
+  // to their ds_write and serialises load -> wait -> store -> compute; the predicated form keeps them a tile ahead.
+  // FULL = true (unpredicated staging loads) measured 2.7x SLOWER on gfx950 / ROCm 7.2: without the predication
+  // branches hipcc parks the staged tile in SCRATCH (scratch_store behind a vmcnt wait per load); kept off.
+  const bool full = false;
+  if (full) hipLaunchKernelGGL((k_gemm<A_TR, B_TR, EPI, true>), dim3(g.ntm * g.ntn * splits), dim3(NT), lds, s, g);
+  else      hipLaunchKernelGGL((k_gemm<A_TR, B_TR, EPI, false>), dim3(g.ntm * g.ntn * splits), dim3(NT), lds, s, g);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
 }
@@ -547,6 +560,8 @@ SFRON_INST_TILE(2, 2, 6, 6)
 #undef SFRON_INST_TILE
 template __global__ void k_gemm_fast<4, 2, 4, 6, false, false, 0, 1>(GemmArgs);
 template __global__ void k_gemm_fast<4, 2, 4, 6, false, false, 0, 2>(GemmArgs);
+template __global__ void k_gemm_fast<4, 2, 4, 6, true, true, 1, 1>(GemmArgs);
+template __global__ void k_gemm_fast<4, 2, 4, 6, true, true, 1, 2>(GemmArgs);
 
 namespace {
 
@@ -801,6 +816,244 @@ int launch_ring(GemmArgs g, hipStream_t s) {
 
 }  // namespace
 
+
+// =================================================================================================
+// Pipelined path ("k_gemm_pipe"): same tiles / LDS images / DMA as k_gemm_fast, but the fragment reads are
+// software pipelined BY HAND one k-step ahead of the MFMAs that consume them, and the transposed reads are
+// issued through inline asm.  Reason (measured): while an LDS-DMA is in flight hipcc puts `s_waitcnt vmcnt(0)`
+// in front of every __builtin ds_read_tr16_b64 (it cannot prove the DMA does not alias the read), which
+// serialises load and compute for the dgrad / wgrad layouts (wgrad fc1: 181 us = 112 us DMA-only + 125 us
+// compute-only with almost no overlap).  An asm read is invisible to that bookkeeping; its completion is waited
+// for explicitly (`s_waitcnt lgkmcnt(0)` + sched_barrier, cdna_hip_programming.md section 5.7 rule 18).
+// =================================================================================================
+__device__ __forceinline__ unsigned lds_addr(const __bf16* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(const void*)p;
+}
+__device__ __forceinline__ bf16x4 asm_read_tr(unsigned addr) {
+  bf16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
+  return r;
+}
+__device__ __forceinline__ bf16x8 asm_read_b128(unsigned addr) {
+  bf16x8 r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
+  return r;
+}
+__device__ __forceinline__ void lds_reads_done() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
+  constexpr int FBM = WM * MT * 16, FBN = WN * NT * 16, NW = WM * WN;
+  constexpr int A_ELEMS = FBM * 64, B_ELEMS = FBN * 64;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+  auto sAp = [&](int b) { return smem + b * A_ELEMS; };
+  auto sBp = [&](int b) { return smem + 2 * A_ELEMS + b * B_ELEMS; };
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int nblk = gridDim.x;
+  int id;
+  {
+    const int b = blockIdx.x, q = nblk >> 3, r = nblk & 7, x = b & 7, y = b >> 3;
+    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+  }
+  const int per_group = g.group_m * g.ntn;
+  const int first_m = (id / per_group) * g.group_m;
+  const int gsz = min(g.ntm - first_m, g.group_m);
+  const int tm = first_m + (id % per_group) % gsz, tn = (id % per_group) / gsz;
+  const int m0 = tm * FBM, n0 = tn * FBN;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  GldsPlan<FBM, A_TR, NW> planA;
+  GldsPlan<FBN, B_TR, NW> planB;
+  planA.init(g.lda, m0, wave, lane);
+  planB.init(g.ldb, n0, wave, lane);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, 0x7fffffff, 0x00020000);
+  auto stage = [&](int buf, int k0) {
+    planA.issue(rsA, 2 * (A_TR ? k0 * g.lda : k0), sAp(buf), wave);
+    planB.issue(rsB, 2 * (B_TR ? k0 * g.ldb : k0), sBp(buf), wave);
+  };
+
+  // per-lane LDS byte addresses of the fragments of buffer 0, k-step 0 (other buffer / k-step: + constant)
+  unsigned adA[MT][A_TR ? 2 : 1], adB[NT][B_TR ? 2 : 1];
+  {
+    const int gq = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (!A_TR) {
+        const int row = wm * MT * 16 + mt * 16 + i;
+        adA[mt][0] = lds_addr(sAp(0)) + 2 * (row * 64 + ((gq ^ (row & 7)) << 3));
+      } else {
+        const int ch = ((wm * MT * 16 + mt * 16) >> 3) + (pp >> 1), r0 = 8 * gq + q;
+        adA[mt][0] = lds_addr(sAp(0)) + 2 * (r0 * FBM + (swz_chunk<FBM>(r0, ch) << 3) + 4 * (pp & 1));
+        adA[mt][1] = lds_addr(sAp(0)) + 2 * ((r0 + 4) * FBM + (swz_chunk<FBM>(r0 + 4, ch) << 3) + 4 * (pp & 1));
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (!B_TR) {
+        const int row = wn * NT * 16 + nt * 16 + i;
+        adB[nt][0] = lds_addr(sBp(0)) + 2 * (row * 64 + ((gq ^ (row & 7)) << 3));
+      } else {
+        const int ch = ((wn * NT * 16 + nt * 16) >> 3) + (pp >> 1), r0 = 8 * gq + q;
+        adB[nt][0] = lds_addr(sBp(0)) + 2 * (r0 * FBN + (swz_chunk<FBN>(r0, ch) << 3) + 4 * (pp & 1));
+        adB[nt][1] = lds_addr(sBp(0)) + 2 * ((r0 + 4) * FBN + (swz_chunk<FBN>(r0 + 4, ch) << 3) + 4 * (pp & 1));
+      }
+    }
+  }
+  // k-step 1 of a direct image flips chunk bit 2 (XOR 4 chunks = 64 B); of a transposed image it is 32 rows further
+  struct Frags { bf16x8 a[MT], b[NT]; };
+  auto read_frags = [&](Frags& f, int buf, int ks) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (!A_TR) {
+        f.a[mt] = asm_read_b128((adA[mt][0] ^ (ks ? 64u : 0u)) + buf * (2 * A_ELEMS));
+      } else {
+        const unsigned o = buf * (2 * A_ELEMS) + ks * (2 * 32 * FBM);
+        const bf16x4 lo = asm_read_tr(adA[mt][0] + o), hi = asm_read_tr(adA[mt][1] + o);
+        f.a[mt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (!B_TR) {
+        f.b[nt] = asm_read_b128((adB[nt][0] ^ (ks ? 64u : 0u)) + buf * (2 * B_ELEMS));
+      } else {
+        const unsigned o = buf * (2 * B_ELEMS) + ks * (2 * 32 * FBN);
+        const bf16x4 lo = asm_read_tr(adB[nt][0] + o), hi = asm_read_tr(adB[nt][1] + o);
+        f.b[nt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    }
+  };
+  auto mfmas = [&](const Frags& f) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[nt], f.a[mt], acc[mt][nt], 0, 0, 0);
+  };
+
+  const int nk = g.K / BK;
+  Frags f0, f1;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile kt has landed
+    __builtin_amdgcn_s_barrier();                           // ... everybody's has; buffer buf^1 is free (its reads were waited for)
+    if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(f0, buf, 0);                                 // k-step 0 of this tile goes out ...
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt > 0) mfmas(f1);                                  // ... under the MFMAs of k-step 1 of the previous tile
+    lds_reads_done();
+    read_frags(f1, buf, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(f0);
+    lds_reads_done();
+  }
+  mfmas(f1);
+
+  const int row_b = m0 + wm * MT * 16 + (lane & 15), col_b = n0 + wn * NT * 16 + 4 * (lane >> 4);
+  if constexpr (EPI == EPI_DGELU) {
+    bf16x4 hx[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        hx[mt][nt] = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)(row_b + mt * 16) * g.ldaux + col_b + nt * 16);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 v = acc[mt][nt] * g.alpha;
+        const bf16x4 h = hx[mt][nt];
+        bf16x4 o = {f2bf(v[0] * gelu_tanh_grad(bf2f(h[0]))), f2bf(v[1] * gelu_tanh_grad(bf2f(h[1]))),
+                    f2bf(v[2] * gelu_tanh_grad(bf2f(h[2]))), f2bf(v[3] * gelu_tanh_grad(bf2f(h[3])))};
+        *reinterpret_cast<bf16x4*>(g.Cb + (size_t)(row_b + mt * 16) * g.ldcb + col_b + nt * 16) = o;
+      }
+  } else if constexpr (EPI == EPI_GATE_RES) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = row_b + mt * 16;
+      float4 xr[NT], gt[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        xr[nt] = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldcf + col_b + nt * 16);
+        gt[nt] = *reinterpret_cast<const float4*>(g.gate + (size_t)(row / g.T) * g.ldgate + col_b + nt * 16);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = col_b + nt * 16;
+        f32x4 v = acc[mt][nt] * g.alpha;
+        if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+        bf16x4 a = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col) = a;
+        float4 x = xr[nt];
+        x.x += gt[nt].x * v[0]; x.y += gt[nt].y * v[1]; x.z += gt[nt].z * v[2]; x.w += gt[nt].w * v[3];
+        *reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col) = x;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        epilogue_store<EPI>(g, row_b + mt * 16, col_b + nt * 16, acc[mt][nt]);
+  }
+}
+
+#define SFRON_INST_PIPE(WM, WN, MT, NT)                                              \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, false, false, 0>(GemmArgs);  \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, false, false, 1>(GemmArgs);  \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, false, false, 2>(GemmArgs);  \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, false, false, 3>(GemmArgs);  \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, false, false, 5>(GemmArgs);  \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, false, true, 0>(GemmArgs);   \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, false, true, 1>(GemmArgs);   \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, false, true, 4>(GemmArgs);   \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, true, true, 0>(GemmArgs);    \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, true, true, 1>(GemmArgs);
+SFRON_INST_PIPE(4, 2, 4, 6)
+SFRON_INST_PIPE(4, 2, 3, 6)
+#undef SFRON_INST_PIPE
+
+namespace {
+
+template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI>
+int launch_pipe(GemmArgs g, hipStream_t s) {
+  constexpr int FBM = WM * MT * 16, FBN = WN * NT * 16;
+  g.ntm = g.M / FBM; g.ntn = g.N / FBN;
+  {
+    const double per_xcd = (double)g.ntm * g.ntn / 8.0;
+    int gm = 1;
+    while (gm * 2 <= g.ntm && (double)(gm * 2) * (gm * 2) * FBM <= per_xcd * FBN * 1.5) gm *= 2;
+    g.group_m = gm;
+  }
+  const size_t lds = 2 * (FBM + FBN) * 64 * sizeof(__bf16);
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pipe<WM, WN, MT, NT, A_TR, B_TR, EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return (int)hipGetLastError();
+    done = true;
+  }
+  hipLaunchKernelGGL((k_gemm_pipe<WM, WN, MT, NT, A_TR, B_TR, EPI>), dim3(g.ntm * g.ntn), dim3(WM * WN * 64), lds, s, g);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SFRON_OK : (int)e;
+}
+
+}  // namespace
+
 namespace {
 
 // fast tiles: 1 = 128x128 (4 waves), 2 = 256x192, 3 = 256x256, 4 = 384x192 (8 waves); 0 = generic kernel.
@@ -814,17 +1067,21 @@ inline bool tile_fits(const GemmArgs& g, int t) {
 inline int pick_fast_tile(const GemmArgs& g, int force, int transposed_operands) {
   if (g.K % 64 || g.kchunk != g.K || force < 0) return 0;
   if (force == 21 || force == 22) return tile_fits(g, 2) ? force : 0;            // timing ablations of tile 2
+  if (force == 32 || force == 35) return tile_fits(g, force - 30) ? force : 0;     // hand-pipelined variants of tiles 2, 5
   if (force > 10) return (g.K % 32 == 0 && tile_fits(g, force - 10)) ? force : 0;   // ring variants of tiles 2, 3, 5
   if (force > 0) return tile_fits(g, force) ? force : 0;
-  // prefer the 8-wave tile with the best last-round occupancy of the 256 CUs; small problems keep 128x128
-  int best = 0; double best_eff = 0.0;
-  for (int t = 2; t <= 2; ++t) {
-    if (!tile_fits(g, t)) continue;
+  // Measured policy (tools/bench_gemm.py, DiT-XL/2 B=32 shapes, random data):
+  //   both operands k-contiguous (forward)   -> 256x192 k_gemm_fast  (streamed row fragments, 760-950 TF)
+  //   B transposed-read (dgrad)              -> 256x192 k_gemm_pipe  (asm transposed reads, 650-900 TF)
+  //   both transposed-read (wgrad)           -> 192x192 k_gemm_pipe  (4.2 TF per CU vs 3.65 of the generic kernel)
+  // a tile is used when it fills at least half of the last round of 256 CUs (wgrad runs beside the dgrad chain
+  // on a side stream, so its own tile count does not have to fill the chip).
+  auto eff = [&](int t) {
     const long tiles = (long)(g.M / TILE_BM[t]) * (g.N / TILE_BN[t]);
-    const double eff = (double)tiles / (double)(((tiles + 255) / 256) * 256);
-    if (eff > best_eff + 1e-9) { best_eff = eff; best = t; }
-  }
-  if (best && best_eff >= 0.5) return best;
+    return (double)tiles / (double)(((tiles + 255) / 256) * 256);
+  };
+  if (transposed_operands == 2) return tile_fits(g, 5) ? 35 : 0;
+  if (tile_fits(g, 2) && eff(2) >= 0.5) return transposed_operands == 1 ? 32 : 2;
   return (transposed_operands == 0 && tile_fits(g, 1)) ? 1 : 0;   // with transposed reads the generic kernel beats the 4-wave tile
 }
 
@@ -838,8 +1095,12 @@ int launch_any(const GemmArgs& g, hipStream_t s, int force) {
     case 5: return launch_fast<4, 2, 3, 6, A_TR, B_TR, EPI>(g, s);
     case 6: return launch_fast<2, 2, 8, 6, A_TR, B_TR, EPI>(g, s);
     case 7: return launch_fast<2, 2, 6, 6, A_TR, B_TR, EPI>(g, s);
-    case 21: if constexpr (!A_TR && !B_TR && EPI == EPI_BF16) return launch_fast<4, 2, 4, 6, false, false, 0, 1>(g, s); else return SFRON_ERR_UNSUPPORTED;
-    case 22: if constexpr (!A_TR && !B_TR && EPI == EPI_BF16) return launch_fast<4, 2, 4, 6, false, false, 0, 2>(g, s); else return SFRON_ERR_UNSUPPORTED;
+    case 21: if constexpr (!A_TR && !B_TR && EPI == EPI_BF16) return launch_fast<4, 2, 4, 6, false, false, 0, 1>(g, s);
+             else if constexpr (A_TR && B_TR && EPI == EPI_F32) return launch_fast<4, 2, 4, 6, true, true, 1, 1>(g, s); else return SFRON_ERR_UNSUPPORTED;
+    case 22: if constexpr (!A_TR && !B_TR && EPI == EPI_BF16) return launch_fast<4, 2, 4, 6, false, false, 0, 2>(g, s);
+             else if constexpr (A_TR && B_TR && EPI == EPI_F32) return launch_fast<4, 2, 4, 6, true, true, 1, 2>(g, s); else return SFRON_ERR_UNSUPPORTED;
+    case 32: return launch_pipe<4, 2, 4, 6, A_TR, B_TR, EPI>(g, s);
+    case 35: return launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI>(g, s);
     case 12: return launch_ring<4, 2, 4, 6, A_TR, B_TR, EPI, 5>(g, s);
     case 13: return launch_ring<2, 4, 8, 4, A_TR, B_TR, EPI, 4>(g, s);
     case 15: return launch_ring<4, 2, 3, 6, A_TR, B_TR, EPI, 6>(g, s);
