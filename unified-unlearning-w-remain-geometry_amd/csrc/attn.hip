@@ -65,9 +65,16 @@ struct ChunkDma {
   }
 };
 
-__device__ __forceinline__ void zero_lds(__bf16* p, int n_elems, int tid) {
+// Zero the PAD chunk positions of n_img images (source chunk index >= hd/8).  The DMA never writes them and writes
+// nothing else than the valid positions, so zeroing and DMA touch disjoint LDS bytes and need no ordering between them.
+template <int HDP> __device__ __forceinline__ void zero_pads(__bf16* p, int n_img, int hd, int tid) {
+  constexpr int CPR = HDP / 8;
+  if (hd >= HDP) return;
   const uint4 z = make_uint4(0, 0, 0, 0);
-  for (int i = tid; i < n_elems / 8; i += NT) reinterpret_cast<uint4*>(p)[i] = z;
+  for (int e = tid; e < n_img * 64 * CPR; e += NT) {
+    const int row = (e / CPR) & 63, pos = e % CPR;
+    if (((pos ^ aswz<HDP>(row)) << 3) >= hd) reinterpret_cast<uint4*>(p)[e] = z;
+  }
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -88,6 +95,30 @@ template <int HDP> __device__ __forceinline__ bf16x8 frag_cols_perm(const __bf16
   r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
   r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
   return r;
+}
+// The same column fragment through inline asm.  While an LDS-DMA is in flight hipcc drains vmcnt(0) in front of every
+// ds_read_tr16_b64 BUILTIN (it cannot prove the DMA does not alias it), which would serialise the 3-slot ring;
+// an asm read is invisible to that bookkeeping.  The caller must run lds_reads_done() before using the result.
+__device__ __forceinline__ unsigned lds_addr(const __bf16* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(const void*)p;
+}
+__device__ __forceinline__ bf16x4 asm_read_tr(unsigned addr) {
+  bf16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
+  return r;
+}
+__device__ __forceinline__ void lds_reads_done() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int HDP> __device__ __forceinline__ bf16x8 frag_cols_perm_asm(const __bf16* img, int rbase, int col0, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const int ch = (col0 >> 3) + (p >> 1);
+  const int r0 = rbase + 4 * g + q;
+  const unsigned base = lds_addr(img);
+  const bf16x4 lo = asm_read_tr(base + 2 * (aoff<HDP>(r0, ch) + 4 * (p & 1)));
+  const bf16x4 hi = asm_read_tr(base + 2 * (aoff<HDP>(r0 + 16, ch) + 4 * (p & 1)));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 __device__ __forceinline__ bf16x8 pack_perm(const f32x4& a, const f32x4& b) {
   bf16x8 r;
@@ -141,7 +172,6 @@ __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv,
   const float c = scale * LOG2E;
   const int nchunk = T / 64;
 
-  zero_lds(smem, NSLOT * 2 * Ring<HDP>::IMG, tid);
   ChunkDma<HDP> dma;
   dma.init(ld, hd, wave, lane);
   const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(base + D), 0, 0x7fffffff, 0x00020000);
@@ -151,14 +181,15 @@ __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv,
     dma.issue(rsK, soff, ring.img(slot, 0), wave);
     dma.issue(rsV, soff, ring.img(slot, 1), wave);
   };
+  issue(0);                              // first two chunks stream in while Q is fetched and the pads are zeroed
+  if (nchunk > 1) issue(1);
   bf16x8 fq[QT][KS];
 #pragma unroll
   for (int qi = 0; qi < QT; ++qi)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) fq[qi][ks] = frag_rows_global(base, ld, q0 + 16 * qi, ks, hd, lane);
-  __syncthreads();                       // zeros visible before any DMA lands
-  issue(0);
-  if (nchunk > 1) issue(1);
+  zero_pads<HDP>(smem, NSLOT * 2, hd, tid);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // pad zeros written before the first barrier of the loop
 
   f32x4 oacc[QT][NDT];
   float m[QT], l[QT];
@@ -190,6 +221,11 @@ __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv,
       }
     }
     bf16x8 pf[QT][2];
+    bf16x8 fv0[NDT], fv1[NDT];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) fv0[dt] = frag_cols_perm_asm<HDP>(iV, 0, dt * 16, lane);   // in flight under the softmax
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int qi = 0; qi < QT; ++qi) {
       float mx = -INFINITY;
@@ -217,15 +253,21 @@ __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv,
       pf[qi][0] = pack_perm(s[qi][0], s[qi][1]);
       pf[qi][1] = pack_perm(s[qi][2], s[qi][3]);
     }
+    lds_reads_done();
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) fv1[dt] = frag_cols_perm_asm<HDP>(iV, 32, dt * 16, lane);  // ... and under the first PV half
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 fv = frag_cols_perm<HDP>(iV, 32 * s2, dt * 16, lane);
+      for (int qi = 0; qi < QT; ++qi)
+        oacc[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0[dt], pf[qi][0], oacc[qi][dt], 0, 0, 0);
+    lds_reads_done();
 #pragma unroll
-        for (int qi = 0; qi < QT; ++qi)
-          oacc[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, pf[qi][s2], oacc[qi][dt], 0, 0, 0);
-      }
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int qi = 0; qi < QT; ++qi)
+        oacc[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1[dt], pf[qi][1], oacc[qi][dt], 0, 0, 0);
   }
 #pragma unroll
   for (int qi = 0; qi < QT; ++qi) {
@@ -283,7 +325,6 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dq(const __bf16* __restrict__ q
   const float c = scale * LOG2E;
   const int nchunk = T / 64;
 
-  zero_lds(smem, NSLOT * 2 * Ring<HDP>::IMG, tid);
   ChunkDma<HDP> dma;
   dma.init(ld, hd, wave, lane);
   const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(base + D), 0, 0x7fffffff, 0x00020000);
@@ -293,6 +334,8 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dq(const __bf16* __restrict__ q
     dma.issue(rsK, soff, ring.img(slot, 0), wave);
     dma.issue(rsV, soff, ring.img(slot, 1), wave);
   };
+  issue(0);
+  if (nchunk > 1) issue(1);
   bf16x8 fq[QT][KS], fdo[QT][KS];
   float nl[QT], dl[QT];
 #pragma unroll
@@ -306,9 +349,8 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dq(const __bf16* __restrict__ q
     nl[qi] = -lse[(size_t)bh * T + q] * LOG2E;
     dl[qi] = delta[(size_t)bh * T + q];
   }
-  __syncthreads();
-  issue(0);
-  if (nchunk > 1) issue(1);
+  zero_pads<HDP>(smem, NSLOT * 2, hd, tid);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   f32x4 dq[QT][NDT];
 #pragma unroll
@@ -347,15 +389,27 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dq(const __bf16* __restrict__ q
     }
 #pragma unroll
     for (int qi = 0; qi < QT; ++qi) { ds[qi][0] = pack_perm(t[qi][0], t[qi][1]); ds[qi][1] = pack_perm(t[qi][2], t[qi][3]); }
+    {
+      bf16x8 fk0[NDT], fk1[NDT];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
+      for (int dt = 0; dt < NDT; ++dt) fk0[dt] = frag_cols_perm_asm<HDP>(iK, 0, dt * 16, lane);
+      lds_reads_done();
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 fkt = frag_cols_perm<HDP>(iK, 32 * s2, dt * 16, lane);
+      for (int dt = 0; dt < NDT; ++dt) fk1[dt] = frag_cols_perm_asm<HDP>(iK, 32, dt * 16, lane);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int qi = 0; qi < QT; ++qi)
-          dq[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fkt, ds[qi][s2], dq[qi][dt], 0, 0, 0);
-      }
+          dq[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk0[dt], ds[qi][0], dq[qi][dt], 0, 0, 0);
+      lds_reads_done();
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int qi = 0; qi < QT; ++qi)
+          dq[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk1[dt], ds[qi][1], dq[qi][dt], 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int qi = 0; qi < QT; ++qi) {
@@ -393,8 +447,6 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dkv(const __bf16* __restrict__ 
   const float c = scale * LOG2E;
   const int nchunk = T / 64;
 
-  zero_lds(smem, NSLOT * 2 * Ring<HDP>::IMG, tid);
-  for (int i = tid; i < T; i += NT) { s_lse[i] = -lse[(size_t)bh * T + i] * LOG2E; s_del[i] = delta[(size_t)bh * T + i]; }
   ChunkDma<HDP> dmaQ, dmaO;
   dmaQ.init(ld, hd, wave, lane);
   dmaO.init(D, hd, wave, lane);
@@ -405,6 +457,8 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dkv(const __bf16* __restrict__ 
     dmaQ.issue(rsQ, ch * 64 * ld * 2, ring.img(slot, 0), wave);
     dmaO.issue(rsO, ch * 64 * D * 2, ring.img(slot, 1), wave);
   };
+  issue(0);
+  if (nchunk > 1) issue(1);
   bf16x8 fk[KT][KS], fv[KT][KS];
 #pragma unroll
   for (int ki = 0; ki < KT; ++ki)
@@ -413,9 +467,9 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dkv(const __bf16* __restrict__ 
       fk[ki][ks] = frag_rows_global(base + D, ld, k0 + 16 * ki, ks, hd, lane);
       fv[ki][ks] = frag_rows_global(base + 2 * D, ld, k0 + 16 * ki, ks, hd, lane);
     }
-  __syncthreads();
-  issue(0);
-  if (nchunk > 1) issue(1);
+  for (int i = tid; i < T; i += NT) { s_lse[i] = -lse[(size_t)bh * T + i] * LOG2E; s_del[i] = delta[(size_t)bh * T + i]; }
+  zero_pads<HDP>(smem, NSLOT * 2, hd, tid);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   f32x4 dk[KT][NDT], dv[KT][NDT];
 #pragma unroll
@@ -462,18 +516,34 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dkv(const __bf16* __restrict__ 
       pp[ki][0] = pack_perm(pt[ki][0], pt[ki][1]); pp[ki][1] = pack_perm(pt[ki][2], pt[ki][3]);
       sp[ki][0] = pack_perm(st[ki][0], st[ki][1]); sp[ki][1] = pack_perm(st[ki][2], st[ki][3]);
     }
+    {
+      bf16x8 cot[2], cqt[2], not_[2], nqt[2];       // dO^T / Q^T fragments of the current and the next d-tile
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
+      for (int s2 = 0; s2 < 2; ++s2) { cot[s2] = frag_cols_perm_asm<HDP>(iO, 32 * s2, 0, lane); cqt[s2] = frag_cols_perm_asm<HDP>(iQ, 32 * s2, 0, lane); }
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 fot = frag_cols_perm<HDP>(iO, 32 * s2, dt * 16, lane);    // dO^T
-        const bf16x8 fqt = frag_cols_perm<HDP>(iQ, 32 * s2, dt * 16, lane);    // Q^T
+      for (int dt = 0; dt < NDT; ++dt) {
+        lds_reads_done();
+        if (dt + 1 < NDT) {
 #pragma unroll
-        for (int ki = 0; ki < KT; ++ki) {
-          dv[ki][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fot, pp[ki][s2], dv[ki][dt], 0, 0, 0);
-          dk[ki][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqt, sp[ki][s2], dk[ki][dt], 0, 0, 0);
+          for (int s2 = 0; s2 < 2; ++s2) {
+            not_[s2] = frag_cols_perm_asm<HDP>(iO, 32 * s2, (dt + 1) * 16, lane);
+            nqt[s2] = frag_cols_perm_asm<HDP>(iQ, 32 * s2, (dt + 1) * 16, lane);
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int ki = 0; ki < KT; ++ki) {
+            dv[ki][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cot[s2], pp[ki][s2], dv[ki][dt], 0, 0, 0);
+            dk[ki][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cqt[s2], sp[ki][s2], dk[ki][dt], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) { cot[s2] = not_[s2]; cqt[s2] = nqt[s2]; }
       }
+    }
   }
 #pragma unroll
   for (int ki = 0; ki < KT; ++ki) {
