@@ -79,7 +79,7 @@ struct Workspace {
   size_t bytes;
 };
 constexpr int SPLIT_K_ADA = 64;
-constexpr int CSUM_PARTS = 64;
+constexpr int CSUM_PARTS = 16;     // row chunks of the bias column sums (stage 2 reads CSUM_PARTS x N floats with N/256 workgroups)
 
 inline Workspace make_ws(const Dims& d, char* base) {
   Workspace w{};
