@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--micro-batches", type=int, default=1, help="independent half-batch chains per pass (1 or 2)")
     ap.add_argument("--cpu-batch", type=int, default=8, help="batch of the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -114,7 +115,7 @@ def main():
     mask_arena = (torch.rand(eng.n_trainable, generator=gm) < 0.5).to(torch.uint8).to(dev)     # 50 % synthetic saliency mask
     diff = diffusion.create_diffusion("", device=dev)
     runner = step.DiTSFRon(model, diff, lr=1e-4, forget_alpha=1e-3, grad_clip=1.0, ema_decay=0.9999, mask=None,
-                           unlearn_loss="ga", forget_class=207)
+                           unlearn_loss="ga", forget_class=207, micro_batches=args.micro_batches)
     runner.mask_arena = mask_arena
     runner.opt.mask = mask_arena
 
@@ -155,6 +156,13 @@ def main():
     step_flops = 6.0 * fwd_per_sample * args.batch
     ms_per_step = elapsed / args.steps * 1e3
 
+    # HBM traffic of the probed kernel: PMC counters need their own rocprofv3 passes (FETCH_SIZE, WRITE_SIZE), so the
+    # number is measured offline on this same command and committed under profiles/ (see the json's "note")
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_fc1_traffic.json")
+    if args.model == "DiT-XL/2" and args.batch == 32 and os.path.isfile(tpath):
+        traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
+
     if rank == 0:
         res = {
             "metric": "SFR-on unlearning steps/sec, DiT-XL/2 256px bs32/GPU",
@@ -169,7 +177,7 @@ def main():
             "step_frac_of_bf16_mfma_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
             "roofline": {"bound": "mfma", "kernel": "k_gemm_fast<4,2,4,6,false,false,2,0> = 256x192 tile, Mlp.fc1 + GELU-tanh, "
                          f"[{M}x{D}]x[{D}x{F}] (block 0 of every forward pass)", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                          "flops_per_launch": fc1_flops, "avg_launch_ms": avg_ms, "launches_timed": n_probe},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -30,8 +30,11 @@ const char* sfron_build_arch(void);     /* "gfx950" */
 int sfron_sweep_partials_len(void);
 
 /* partial sums of (mask ? g : 0)^2; first half of clip_grad_norm_ after `grad *= mask`
- * (DiT/forget.py:289-298).  mask may be NULL.  *nblk_out (HOST int) = number of partials written. */
-int sfron_sumsq_masked(const float* g, const uint8_t* mask, int64_t n, double* partials, int* nblk_out, void* stream);
+ * (DiT/forget.py:289-298).  mask may be NULL.  *nblk_out (HOST int) = number of partials written.
+ * g2 (may be NULL): a second gradient arena added element-wise first (g + g2): the two micro-batch chains of a
+ * step write disjoint arenas so they never have to order their weight-gradient GEMMs against each other. */
+int sfron_sumsq_masked(const float* g, const float* g2, const uint8_t* mask, int64_t n, double* partials, int* nblk_out,
+                       void* stream);
 
 /* stats[0] = ||g||_2, stats[1] = min(1, max_norm / (norm + 1e-6)), stats[2] = sum of squares
  * (torch.nn.utils.clip_grad_norm_ semantics; DiT/forget.py:293-298) */
@@ -44,7 +47,8 @@ int sfron_clip_coef(const double* partials, int nblk, float max_norm, float* sta
  * optional fused EMA of the NEW p: ema_mode 0 none, 1 DiT (ema*d + (1-d)*p, DiT/forget.py:52-62),
  * 2 DDPM ((1-mu)*p + mu*shadow, DDPM/models/ema.py:17-24).  mask / stats / w_bf16 / ema may be NULL.
  * (DiT/forget.py:289-299,320; DDPM/runners/diffusion.py:1126-1138,1169-1180) */
-int sfron_masked_clip_adam(float* p, const float* g, float* m, float* v, const uint8_t* mask, const float* stats,
+int sfron_masked_clip_adam(float* p, const float* g, const float* g2 /* NULL or second arena, see above */, float* m, float* v,
+                           const uint8_t* mask, const float* stats,
                            int64_t n, double beta1, double beta2, double eps, double step_size, double bc2_sqrt,
                            double decay_mul, uint16_t* w_bf16, float* ema, double ema_decay, int ema_mode, void* stream);
 

@@ -80,8 +80,8 @@ def test_dit_matches_golden_reference_output(golden_dir):
     np.testing.assert_array_equal(pe.astype(np.float32)[None], g["pos_embed"])
 
 
-@pytest.mark.parametrize("case,loss", [("hd64", "ga"), ("hd72", "ga"), ("hd64_nc200", "rl")])
-def test_sfron_iterations_vs_oracle(case, loss):
+@pytest.mark.parametrize("case,loss,micro", [("hd64", "ga", 1), ("hd72", "ga", 1), ("hd64_nc200", "rl", 1), ("hd72", "ga", 2)])
+def test_sfron_iterations_vs_oracle(case, loss, micro):
     from oracle import diffusion_ref as dref
     from oracle import sfron_ref
     from sfron import data, diffusion, step
@@ -94,7 +94,7 @@ def test_sfron_iterations_vs_oracle(case, loss):
     mask["module.pos_embed"] = 0
     hp = dict(lr=2e-4, forget_alpha=0.3, grad_clip=1.0, ema_decay=0.99, mask=mask, unlearn_loss=loss, forget_class=3)
     orc = sfron_ref.DiTSfronOracle(ref, dref.DiffusionTables(1000), **hp)
-    runner = step.DiTSFRon(model, diffusion.create_diffusion(""), **hp)
+    runner = step.DiTSFRon(model, diffusion.create_diffusion(""), micro_batches=micro, **hp)
     p0 = {n: p.detach().clone() for n, p in ref.named_parameters()}
     kw = dict(global_batch=B, num_classes=cfg["num_classes"], forget_class=3, input_size=cfg["input_size"])
     for it in range(3):

@@ -42,6 +42,19 @@ dgrad("dgrad qkv  N3456->1152", 3 * D, D); dgrad("dgrad proj N1152->1152", D, D)
 dgrad("dgrad fc1  N4608->1152", F, D); dgrad("dgrad fc2  N1152->4608", D, F)
 wgrad("wgrad qkv  3456x1152", 3 * D, D); wgrad("wgrad proj 1152x1152", D, D)
 wgrad("wgrad fc1  4608x1152", F, D); wgrad("wgrad fc2  1152x4608", D, F)
+# epilogue variants used by the engine
+def dgelu(name, N, K):
+    dY, W = rnd(M, N), rnd(N, K)
+    C = torch.empty(M, K, dtype=torch.bfloat16, device=DEV); aux = rnd(M, K)
+    cases.append((name, 2.0 * M * N * K, lambda: ops.gemm(dY, W, M, K, N, b_t=True, epilogue=_lib.EPI_DGELU, c_bf16=C, aux=aux, tile_hint=HINT)))
+def gate_res(name, N, K):
+    A, B = rnd(M, K), rnd(N, K)
+    x0 = torch.randn(M, N, device=DEV); x1 = torch.empty_like(x0); aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    gate = torch.randn(32, 6 * N, device=DEV); bias = torch.randn(N, device=DEV)
+    cases.append((name, 2.0 * M * N * K, lambda: ops.gemm(A, B, M, N, K, epilogue=_lib.EPI_GATE_RES, bias=bias, c_f32=x1, resid=x0, aux=aux,
+                                                         gate=gate[:, 2 * N:], ldgate=6 * N, tokens=256, tile_hint=HINT)))
+dgelu("dgrad fc2 + GELU'  ->4608", D, F)
+gate_res("fwd proj + gate-res N1152", D, D); gate_res("fwd fc2 + gate-res K4608", D, F)
 tot_f = tot_t = 0
 for name, fl, fn in cases:
     ms = timeit(fn)

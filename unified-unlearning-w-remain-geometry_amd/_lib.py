@@ -20,9 +20,9 @@ _PROTOS = {
     "sfron_abi_version": (c_int, []),
     "sfron_build_arch": (c_char_p, []),
     "sfron_sweep_partials_len": (c_int, []),
-    "sfron_sumsq_masked": (c_int, [_P, _P, c_int64, _P, POINTER(c_int), _S]),
+    "sfron_sumsq_masked": (c_int, [_P, _P, _P, c_int64, _P, POINTER(c_int), _S]),
     "sfron_clip_coef": (c_int, [_P, c_int, c_float, _P, _S]),
-    "sfron_masked_clip_adam": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_double,
+    "sfron_masked_clip_adam": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_double,
                                        c_double, _P, _P, c_double, c_int, _S]),
     "sfron_ema_update": (c_int, [_P, _P, c_int64, c_double, c_int, _S]),
     "sfron_fisher_accum": (c_int, [_P, _P, c_int64, c_float, _S]),

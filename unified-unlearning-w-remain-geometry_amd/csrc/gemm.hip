@@ -1025,6 +1025,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
   template __global__ void k_gemm_pipe<WM, WN, MT, NT, true, true, 1>(GemmArgs);
 SFRON_INST_PIPE(4, 2, 4, 6)
 SFRON_INST_PIPE(4, 2, 3, 6)
+SFRON_INST_PIPE(2, 2, 8, 6)
 #undef SFRON_INST_PIPE
 
 namespace {
@@ -1067,7 +1068,7 @@ inline bool tile_fits(const GemmArgs& g, int t) {
 inline int pick_fast_tile(const GemmArgs& g, int force, int transposed_operands) {
   if (g.K % 64 || g.kchunk != g.K || force < 0) return 0;
   if (force == 21 || force == 22) return tile_fits(g, 2) ? force : 0;            // timing ablations of tile 2
-  if (force == 32 || force == 35) return tile_fits(g, force - 30) ? force : 0;     // hand-pipelined variants of tiles 2, 5
+  if (force == 32 || force == 35 || force == 36) return tile_fits(g, force - 30) ? force : 0;   // hand-pipelined variants of tiles 2, 5, 6
   if (force > 10) return (g.K % 32 == 0 && tile_fits(g, force - 10)) ? force : 0;   // ring variants of tiles 2, 3, 5
   if (force > 0) return tile_fits(g, force) ? force : 0;
   // Measured policy (tools/bench_gemm.py, DiT-XL/2 B=32 shapes, random data):
@@ -1101,6 +1102,7 @@ int launch_any(const GemmArgs& g, hipStream_t s, int force) {
              else if constexpr (A_TR && B_TR && EPI == EPI_F32) return launch_fast<4, 2, 4, 6, true, true, 1, 2>(g, s); else return SFRON_ERR_UNSUPPORTED;
     case 32: return launch_pipe<4, 2, 4, 6, A_TR, B_TR, EPI>(g, s);
     case 35: return launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI>(g, s);
+    case 36: return launch_pipe<2, 2, 8, 6, A_TR, B_TR, EPI>(g, s);
     case 12: return launch_ring<4, 2, 4, 6, A_TR, B_TR, EPI, 5>(g, s);
     case 13: return launch_ring<2, 4, 8, 4, A_TR, B_TR, EPI, 4>(g, s);
     case 15: return launch_ring<4, 2, 3, 6, A_TR, B_TR, EPI, 6>(g, s);

@@ -21,8 +21,8 @@ namespace {
 constexpr int TPB = 256;
 constexpr int MAX_GRID = 2048;
 
-__global__ __launch_bounds__(TPB) void k_sumsq_masked(const float* __restrict__ g, const uint8_t* __restrict__ mask,
-                                                       int64_t n, double* __restrict__ partials) {
+__global__ __launch_bounds__(TPB) void k_sumsq_masked(const float* __restrict__ g, const float* __restrict__ g2,
+                                                       const uint8_t* __restrict__ mask, int64_t n, double* __restrict__ partials) {
   __shared__ double sh[TPB / 64];
   const int64_t n4 = n >> 2;
   const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -30,6 +30,7 @@ __global__ __launch_bounds__(TPB) void k_sumsq_masked(const float* __restrict__ 
   float acc = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
     float4 x = g4[i];
+    if (g2) { const float4 y = reinterpret_cast<const float4*>(g2)[i]; x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w; }
     if (mask) {
       uchar4 mk = m4[i];
       x.x = mk.x ? x.x : 0.f; x.y = mk.y ? x.y : 0.f; x.z = mk.z ? x.z : 0.f; x.w = mk.w ? x.w : 0.f;
@@ -39,6 +40,7 @@ __global__ __launch_bounds__(TPB) void k_sumsq_masked(const float* __restrict__ 
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     int64_t i = (n4 << 2) + threadIdx.x;
     float x = g[i];
+    if (g2) x += g2[i];
     if (mask && !mask[i]) x = 0.f;
     acc += x * x;
   }
@@ -90,7 +92,7 @@ __device__ __forceinline__ float ema_one(float e, float p, const AdamArgs& a) {
 }
 
 __global__ __launch_bounds__(TPB) void k_masked_clip_adam(float* __restrict__ p, const float* __restrict__ g,
-                                                          float* __restrict__ m, float* __restrict__ v,
+                                                          const float* __restrict__ g2, float* __restrict__ m, float* __restrict__ v,
                                                           const uint8_t* __restrict__ mask, const float* __restrict__ stats,
                                                           int64_t n, AdamArgs a, uint16_t* __restrict__ wbf,
                                                           float* __restrict__ ema) {
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(TPB) void k_masked_clip_adam(float* __restrict__ p,
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
     float4 gg = reinterpret_cast<const float4*>(g)[i];
+    if (g2) { const float4 y = reinterpret_cast<const float4*>(g2)[i]; gg.x += y.x; gg.y += y.y; gg.z += y.z; gg.w += y.w; }
     float4 mm = reinterpret_cast<float4*>(m)[i];
     float4 vv = reinterpret_cast<float4*>(v)[i];
     if (mask) {
@@ -127,6 +130,7 @@ __global__ __launch_bounds__(TPB) void k_masked_clip_adam(float* __restrict__ p,
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     int64_t i = (n4 << 2) + threadIdx.x;
     float gg = g[i];
+    if (g2) gg += g2[i];
     if (mask && !mask[i]) gg = 0.f;
     gg *= coef;
     float mm = m[i], vv = v[i];
@@ -185,12 +189,13 @@ extern "C" {
 
 int sfron_sweep_partials_len(void) { return MAX_GRID; }
 
-int sfron_sumsq_masked(const float* g, const uint8_t* mask, int64_t n, double* partials, int* nblk_out, void* stream) {
+int sfron_sumsq_masked(const float* g, const float* g2, const uint8_t* mask, int64_t n, double* partials, int* nblk_out,
+                       void* stream) {
   SFRON_CHECK_ARG(g && partials && nblk_out && n >= 0);
-  SFRON_CHECK_ARG(((uintptr_t)g & 15) == 0 && (!mask || ((uintptr_t)mask & 3) == 0));
+  SFRON_CHECK_ARG(((uintptr_t)g & 15) == 0 && ((uintptr_t)g2 & 15) == 0 && (!mask || ((uintptr_t)mask & 3) == 0));
   int grid = grid_for(n >> 2);
   *nblk_out = grid;
-  hipLaunchKernelGGL(k_sumsq_masked, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, g, mask, n, partials);
+  hipLaunchKernelGGL(k_sumsq_masked, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, g, g2, mask, n, partials);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }
@@ -202,18 +207,18 @@ int sfron_clip_coef(const double* partials, int nblk, float max_norm, float* sta
   return SFRON_OK;
 }
 
-int sfron_masked_clip_adam(float* p, const float* g, float* m, float* v, const uint8_t* mask, const float* stats,
+int sfron_masked_clip_adam(float* p, const float* g, const float* g2, float* m, float* v, const uint8_t* mask, const float* stats,
                            int64_t n, double beta1, double beta2, double eps, double step_size, double bc2_sqrt,
                            double decay_mul, uint16_t* w_bf16, float* ema, double ema_decay, int ema_mode, void* stream) {
   SFRON_CHECK_ARG(p && g && m && v && n >= 0);
-  SFRON_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+  SFRON_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)g2 | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
   SFRON_CHECK_ARG(!mask || ((uintptr_t)mask & 3) == 0);
   SFRON_CHECK_ARG(!w_bf16 || ((uintptr_t)w_bf16 & 7) == 0);
   SFRON_CHECK_ARG(ema_mode == 0 || (ema && ((uintptr_t)ema & 15) == 0 && (ema_mode == 1 || ema_mode == 2)));
   AdamArgs a{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)step_size, (float)bc2_sqrt,
              (float)decay_mul, (float)ema_decay, (float)(1.0 - ema_decay), ema_mode};
   hipLaunchKernelGGL(k_masked_clip_adam, dim3(grid_for(n >> 2)), dim3(TPB), 0, (hipStream_t)stream,
-                     p, g, m, v, mask, stats, n, a, w_bf16, ema);
+                     p, g, g2, m, v, mask, stats, n, a, w_bf16, ema);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

@@ -120,8 +120,8 @@ class DiT(nn.Module):
         if batch_size == self.engine.cfg.batch:
             return
         old = self.engine
-        new = DitEngine(batch_size, **self._engine_args)
-        new.params, new.params_bf16, new.grads, new.probe = old.params, old.params_bf16, old.grads, old.probe
+        new = DitEngine(batch_size, share=old, **self._engine_args)
+        new.grads, new.probe = old.grads, old.probe
         _lib.lib().sfron_aux_destroy(old.aux)
         self.engine = new
 

@@ -19,7 +19,11 @@ _LAYOUT_KEYS = ["total", "trainable", "pe_w", "pe_b", "t0_w", "t0_b", "t2_w", "t
 
 class DitEngine:
     def __init__(self, batch, input_size=32, patch_size=2, in_channels=4, hidden_size=1152, depth=28, num_heads=16,
-                 mlp_ratio=4.0, num_classes=1000, learn_sigma=True, device="cuda"):
+                 mlp_ratio=4.0, num_classes=1000, learn_sigma=True, device="cuda", share=None):
+        """share: another DitEngine whose parameter arenas (fp32 + bf16) this one uses (own workspace, grads, aux)."""
+        self._ctor = dict(input_size=input_size, patch_size=patch_size, in_channels=in_channels, hidden_size=hidden_size,
+                          depth=depth, num_heads=num_heads, mlp_ratio=mlp_ratio, num_classes=num_classes,
+                          learn_sigma=learn_sigma, device=device)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.SfronError("DitEngine needs a GPU (no CPU fallback)")
@@ -36,8 +40,12 @@ class DitEngine:
         self.n_total, self.n_trainable = self.layout["total"], self.layout["trainable"]
         self.tokens = (input_size // patch_size) ** 2
         self.index = self._build_index()
-        self.params = torch.zeros(self.n_total, dtype=torch.float32, device=self.device)
-        self.params_bf16 = torch.zeros(self.n_total, dtype=torch.bfloat16, device=self.device)
+        if share is None:
+            self.params = torch.zeros(self.n_total, dtype=torch.float32, device=self.device)
+            self.params_bf16 = torch.zeros(self.n_total, dtype=torch.bfloat16, device=self.device)
+        else:
+            assert share.n_total == self.n_total
+            self.params, self.params_bf16 = share.params, share.params_bf16
         self.grads = torch.zeros(self.n_total, dtype=torch.float32, device=self.device)
         ws = L.sfron_dit_workspace_bytes(ctypes.byref(c))
         if ws < 0:
@@ -48,6 +56,10 @@ class DitEngine:
         h = ctypes.c_void_p()
         check(L.sfron_aux_create(ctypes.byref(h)), "aux_create")     # side stream + events for concurrent wgrads
         self.aux = h
+
+    def sibling(self, batch):
+        """A second engine over the SAME parameters (own workspace / gradient arena / side stream) for a micro-batch chain."""
+        return DitEngine(batch, share=self, **self._ctor)
 
     # ------------------------------------------------------------------ names
     def _build_index(self):

@@ -38,7 +38,10 @@ def build_mask_arena(engine, mask):
 
 class DiTSFRon:
     def __init__(self, model, diffusion, lr=1e-4, forget_alpha=1e-3, grad_clip=1.0, ema_decay=0.9999, mask=None,
-                 unlearn_loss="ga", forget_class=0, process_group=None, bucket_bytes=256 << 20):
+                 unlearn_loss="ga", forget_class=0, process_group=None, bucket_bytes=256 << 20, micro_batches=1):
+        """micro_batches = 2: each forward/backward pass runs as TWO independent half-batch chains on two HIP streams
+        (own workspace, own gradient arena, own side stream); the latency-bound kernels of one chain (attention,
+        LayerNorm / gate backward) then run under the GEMMs of the other.  The optimizer sweep sums the two arenas."""
         if unlearn_loss not in ("ga", "rl"):
             raise ValueError(f"unsupported unlearn_loss {unlearn_loss!r} (DiT/forget.py defines only 'ga' and 'rl')")
         self.model, self.diffusion = model, diffusion
@@ -48,6 +51,10 @@ class DiTSFRon:
         self.pg = process_group
         self.world = dp.world_size(process_group)
         self.bucket_elems = max(1, bucket_bytes // 4)
+        if micro_batches not in (1, 2):
+            raise ValueError("micro_batches must be 1 or 2")
+        self.micro = micro_batches
+        self._chains = None
         self._bind(mask)
 
     def _bind(self, mask):
@@ -61,7 +68,52 @@ class DiTSFRon:
     def _allreduce_grads(self):
         dp.allreduce_flat_(self.model.engine.grads[:self.model.engine.n_trainable], self.bucket_elems, self.pg)
 
+    # ------------------------------------------------------------------ two-chain (micro-batch) pass
+    def _setup_chains(self, n_local):
+        half = n_local // 2
+        self.model.set_batch_size(half)
+        e0 = self.model.engine
+        e1 = e0.sibling(half)
+        self._chains = (e0, e1, torch.cuda.Stream(), torch.cuda.Stream())
+        self.opt.g = e0.grads[:e0.n_trainable]
+        self.opt.g2 = e1.grads[:e1.n_trainable]
+
+    def _pass2(self, batch, y, sign_alpha):
+        n_local = batch["x0"].shape[0]
+        if n_local % 2:
+            raise ValueError("micro_batches=2 needs an even per-GPU batch")
+        if self._chains is None or self._chains[0].cfg.batch != n_local // 2:
+            self._setup_chains(n_local)
+        e0, e1, s0, s1 = self._chains
+        diff = self.diffusion
+        n_global = n_local * self.world
+        half = n_local // 2
+        cur = torch.cuda.current_stream()
+        outs = []
+        for eng, st, sl in ((e0, s0, slice(0, half)), (e1, s1, slice(half, n_local))):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                x0, t, noise, yy = batch["x0"][sl], batch["t"][sl], batch["noise"][sl], y[sl]
+                drop = batch["drop"][sl] if batch.get("drop") is not None else None
+                x_t = diff.q_sample(x0, t, noise)
+                out = eng.forward(x_t, t, yy, drop)
+                mse, vb, d_out = diff.loss_fwd_bwd(out, x0, t, noise, sign_alpha / n_global)
+                eng.backward(d_out, yy, drop)
+                outs.append((mse, vb))
+        cur.wait_stream(s0)
+        cur.wait_stream(s1)
+        if self.world > 1:                       # one arena to exchange: fold the second chain's gradients in
+            nt = e0.n_trainable
+            e0.grads[:nt].add_(e1.grads[:nt])
+            self.opt.g2 = None
+            dp.allreduce_flat_(e0.grads[:nt], self.bucket_elems, self.pg)
+        else:
+            self.opt.g2 = e1.grads[:e1.n_trainable]
+        return torch.cat([outs[0][0], outs[1][0]]), torch.cat([outs[0][1], outs[1][1]])
+
     def _pass(self, batch, y, sign_alpha):
+        if self.micro == 2:
+            return self._pass2(batch, y, sign_alpha)
         eng, diff = self.model.engine, self.diffusion
         n_global = batch["x0"].shape[0] * self.world
         x_t = diff.q_sample(batch["x0"], batch["t"], batch["noise"])
@@ -74,8 +126,9 @@ class DiTSFRon:
     def step(self, forget, remain):
         """forget / remain: dicts of GPU tensors x0 [N,4,S,S] fp32, y [N] int64, t [N] int64, noise, drop [N] uint8
         (this rank's shard).  Returns per-sample mse / vb tensors (device; no host sync here)."""
+        if self.micro == 1:
+            self.model.set_batch_size(forget["x0"].shape[0])
         eng = self.model.engine
-        self.model.set_batch_size(forget["x0"].shape[0])
         if self.unlearn_loss == "ga":
             y_f, sign = forget["y"], -1.0                                                   # forget.py:269-272
         else:

@@ -32,6 +32,7 @@ class FlatAdam:
         self.mask = mask            # uint8/bool [n] or None, device resident (loaded once, not per step)
         self.w_bf16 = w_bf16        # bf16 [n] shadow or None
         self.step_count = 0
+        self.g2 = None              # optional second gradient arena (micro-batch chains), summed inside the kernels
         L = _lib.lib()
         self._partials = torch.empty(L.sfron_sweep_partials_len(), dtype=torch.float64, device=params.device)
         self.stats = torch.zeros(4, dtype=torch.float32, device=params.device)
@@ -43,7 +44,7 @@ class FlatAdam:
         nblk = ctypes.c_int(0)
         mask = self.mask if use_mask else None
         s = stream_ptr()
-        check(L.sfron_sumsq_masked(ptr(self.g), ptr(mask), n, ptr(self._partials), ctypes.byref(nblk), s), "sumsq_masked")
+        check(L.sfron_sumsq_masked(ptr(self.g), ptr(self.g2), ptr(mask), n, ptr(self._partials), ctypes.byref(nblk), s), "sumsq_masked")
         check(L.sfron_clip_coef(ptr(self._partials), nblk.value, float(max_norm), ptr(self.stats), s), "clip_coef")
 
     def step(self, max_norm=None, use_mask=False, ema=None, ema_decay=0.0, ema_mode=0):
@@ -60,7 +61,7 @@ class FlatAdam:
         step_size = self.lr / bc1
         bc2_sqrt = math.sqrt(bc2)
         decay_mul = 1.0 - self.lr * self.wd
-        check(L.sfron_masked_clip_adam(ptr(self.p), ptr(self.g), ptr(self.m), ptr(self.v),
+        check(L.sfron_masked_clip_adam(ptr(self.p), ptr(self.g), ptr(self.g2), ptr(self.m), ptr(self.v),
                                        ptr(self.mask if use_mask else None),
                                        ptr(self.stats if max_norm is not None else None),
                                        self.p.numel(), b1, b2, self.eps, step_size, bc2_sqrt, decay_mul,
