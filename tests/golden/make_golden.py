@@ -14,6 +14,8 @@ Outputs (small .npz files, inputs + expected outputs only -- no reference source
                       DiT/forget.py:256-322 (forget.py itself needs torchvision/diffusers/CUDA)
   ddpm_loss.npz       DDPM/functions/losses.py (simple, adaptive), cosine schedule, EMAHelper
   fisher_mask.npz     DiT/generate_mask.py main() run on synthetic Fisher files (0/0, int-0 entries)
+  ddpm_model.npz      DDPM/models/diffusion.py Conditional_Model forward/backward (tiny config) + a 2-iteration SFR-on
+                      trajectory composed from DDPM/functions/losses.py, models/ema.py in runners/diffusion.py order
 """
 import argparse
 import importlib
@@ -273,6 +275,101 @@ def gen_mask():
                         ths=np.array(ths), **out)
 
 
+DDPM_TINY = dict(ch=128, out_ch=3, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(4,), dropout=0.1, in_channels=3,
+                 resolution=8, resamp_with_conv=True, n_classes=10, cond_drop_prob=0.1)   # ch must be 128 (reference quirk)
+
+
+def ddpm_ref_config(kw):
+    ns = argparse.Namespace
+    return ns(model=ns(ch=kw["ch"], out_ch=kw["out_ch"], ch_mult=list(kw["ch_mult"]), num_res_blocks=kw["num_res_blocks"],
+                       attn_resolutions=list(kw["attn_resolutions"]), dropout=kw["dropout"], in_channels=kw["in_channels"],
+                       resamp_with_conv=kw["resamp_with_conv"], type="simple", cond_drop_prob=kw["cond_drop_prob"]),
+              data=ns(image_size=kw["resolution"], n_classes=kw["n_classes"]),
+              diffusion=ns(num_diffusion_timesteps=1000))
+
+
+def gen_ddpm_model():
+    """DDPM/models/diffusion.py Conditional_Model: forward (train with seeded RNG, test with cond_scale), backward,
+    and 2 SFR-on iterations composed from reference functions in the order of DDPM/runners/diffusion.py:1075-1180."""
+    from oracle import ddpm_ref
+    ref_mod = _load("ref_ddpm_model", os.path.join(REF, "DDPM", "models", "diffusion.py"))
+    losses = _load("ref_ddpm_losses2", os.path.join(REF, "DDPM", "functions", "losses.py"))
+    ema_mod = _load("ref_ddpm_ema2", os.path.join(REF, "DDPM", "models", "ema.py"))
+    torch.manual_seed(77)
+    mine = ddpm_ref.ConditionalUNet(**DDPM_TINY)
+    sd = mine.state_dict()
+    model = ref_mod.Conditional_Model(ddpm_ref_config(DDPM_TINY))
+    model.load_state_dict(sd, strict=True)                       # identical key set
+    full = ref_mod.Conditional_Model(ddpm_ref_config(dict(DDPM_TINY, ch=128, ch_mult=(1, 2, 2, 2), num_res_blocks=2,
+                                                          attn_resolutions=(16,), resolution=32)))
+    n_full = sum(p.numel() for p in full.parameters())
+    g = torch.Generator().manual_seed(21)
+    N = 4
+    x = torch.rand(N, 3, 8, 8, generator=g) * 2 - 1
+    t = torch.tensor([0, 999, 17, 500])
+    c = torch.tensor([3, 3, 1, 9])
+    model.train()
+    torch.manual_seed(5)
+    out_train = model(x, t.float(), c, mode="train", cond_drop_prob=0.5)
+    model.eval()
+    out_test = model(x, t.float(), c, mode="test", cond_scale=2.0)
+    w = torch.randn(out_test.shape, generator=g)
+    model.zero_grad()
+    (model(x, t.float(), c, mode="train", cond_drop_prob=0.0) * w).sum().backward()
+    pick = ["conv_in.weight", "down.0.block.0.temb_cemb_proj.bias", "down.1.attn.0.q.bias", "mid.attn_1.proj_out.bias",
+            "up.0.block.1.nin_shortcut.bias", "classes_emb.weight", "norm_out.weight"]
+    grads = {n: p.grad.clone() for n, p in model.named_parameters() if n in pick}
+    # ---- 2 SFR-on iterations, adaga, cosine alpha, clip in both stages, EMAHelper (runners/diffusion.py:1075-1180)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), amsgrad=False, eps=1e-8)
+    helper = ema_mod.EMAHelper(mu=1e-4)
+    helper.register(model)
+    b = torch.from_numpy(np.linspace(1e-4, 2e-2, 1000, dtype=np.float64)).float()
+    gm = torch.Generator().manual_seed(8)
+    mask = {n: (torch.rand(p.shape, generator=gm) < 0.5) for n, p in model.named_parameters()}
+    rec = {"forget": [], "remain": [], "alpha": []}
+    inputs = {}
+    n_iters, forget_alpha = 2, 10.0
+    for step in range(n_iters):
+        alpha = losses.cosine_lr_scheduler(forget_alpha, step, n_iters)
+        fx = torch.rand(N, 3, 8, 8, generator=g) * 2 - 1
+        fe = torch.randn(N, 3, 8, 8, generator=g)
+        ft = torch.randint(0, 1000, (N // 2 + 1,), generator=g)
+        ft = torch.cat([ft, 1000 - ft - 1], dim=0)[:N]
+        fc = torch.zeros(N, dtype=torch.long)
+        rx = torch.rand(N, 3, 8, 8, generator=g) * 2 - 1
+        re_ = torch.randn(N, 3, 8, 8, generator=g)
+        rt = torch.randint(0, 1000, (N // 2 + 1,), generator=g)
+        rt = torch.cat([rt, 1000 - rt - 1], dim=0)[:N]
+        rc = torch.randint(1, 10, (N,), generator=g)
+        for k, v in dict(fx=fx, fe=fe, ft=ft, fc=fc, rx=rx, re=re_, rt=rt, rc=rc).items():
+            inputs[f"s{step}_{k}"] = v.numpy()
+        torch.manual_seed(100 + step)
+        ori_forget = -losses.adaptive_loss(losses.loss_registry_conditional["simple"], model, fx, ft, fc, fe, b, lambd=0.5)
+        opt.zero_grad()
+        (alpha * ori_forget).backward()
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                p.grad *= mask[n]
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        ori_remain = losses.loss_registry_conditional["simple"](model, rx, rt, rc, re_, b)
+        opt.zero_grad()
+        (1.0 * ori_remain).backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        helper.update(model)
+        rec["forget"].append(ori_forget.item()); rec["remain"].append(ori_remain.item()); rec["alpha"].append(alpha)
+    np.savez_compressed(os.path.join(HERE, "ddpm_model.npz"),
+                        x=x.numpy(), t=t.numpy(), c=c.numpy(), w=w.numpy(), n_params_full=np.array(n_full),
+                        keys=np.array(list(sd.keys())), out_train_seed5=out_train.detach().numpy(),
+                        out_test_scale2=out_test.detach().numpy(),
+                        traj_forget=np.array(rec["forget"]), traj_remain=np.array(rec["remain"]), traj_alpha=np.array(rec["alpha"]),
+                        final_conv_in=model.conv_in.weight.detach().numpy(),
+                        final_shadow_conv_out=helper.shadow["conv_out.weight"].numpy(),
+                        **{"grad::" + n: grads[n].numpy() for n in pick}, **inputs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     ref_diffusion = import_ref_dit_diffusion()
@@ -282,4 +379,5 @@ if __name__ == "__main__":
     gen_traj(ref_models, ref_diffusion)
     gen_ddpm()
     gen_mask()
+    gen_ddpm_model()
     print("golden vectors written to", HERE)

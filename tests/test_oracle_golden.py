@@ -143,3 +143,64 @@ def test_fisher_mask_bit_exact(golden_dir):
     # 0/0 -> (1e-15)/(1e-15) = 1 >= th is True for th <= 1
     z = torch.zeros(4)
     assert sweep_ref.mask_from_fisher(z, z, 1.0).all() and not sweep_ref.mask_from_fisher(z, z, 3.0).any()
+
+
+# ------------------------------------------------------------------ DDPM (BASELINE config 0: CPU plumbing)
+DDPM_TINY = dict(ch=128, out_ch=3, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(4,), dropout=0.1, in_channels=3,
+                 resolution=8, resamp_with_conv=True, n_classes=10, cond_drop_prob=0.1)
+
+
+def test_ddpm_unet_matches_reference(golden_dir):
+    from oracle import ddpm_ref
+    g = load(golden_dir, "ddpm_model.npz")
+    torch.manual_seed(77)
+    m = ddpm_ref.ConditionalUNet(**DDPM_TINY)
+    assert list(m.state_dict().keys()) == list(g["keys"])
+    full = ddpm_ref.ConditionalUNet()          # cifar10_sfron.yml shape
+    assert sum(p.numel() for p in full.parameters()) == int(g["n_params_full"]) == 38_632_323
+    x, t, c, w = (torch.from_numpy(g[k]) for k in ("x", "t", "c", "w"))
+    m.train()
+    torch.manual_seed(5)
+    out = m(x, t.float(), c, mode="train", cond_drop_prob=0.5)
+    np.testing.assert_allclose(out.detach().numpy(), g["out_train_seed5"], rtol=1e-5, atol=1e-5)
+    m.eval()
+    np.testing.assert_allclose(m(x, t.float(), c, mode="test", cond_scale=2.0).detach().numpy(), g["out_test_scale2"],
+                               rtol=1e-5, atol=2e-5)
+    m.zero_grad()
+    (m(x, t.float(), c, mode="train", cond_drop_prob=0.0) * w).sum().backward()
+    for key in g.files:
+        if key.startswith("grad::"):
+            np.testing.assert_allclose(dict(m.named_parameters())[key[6:]].grad.numpy(), g[key], rtol=2e-4, atol=2e-5, err_msg=key)
+
+
+def test_ddpm_sfron_trajectory_matches_reference(golden_dir):
+    """BASELINE config 0 in miniature: SFR-on on the DDPM U-Net (adaga, cosine alpha, clip in both stages, EMAHelper),
+    oracle vs the trajectory composed from the reference's own functions."""
+    from oracle import ddpm_ref
+    g = load(golden_dir, "ddpm_model.npz")
+    torch.manual_seed(77)
+    m = ddpm_ref.ConditionalUNet(**DDPM_TINY)
+    gm = torch.Generator().manual_seed(8)
+    mask = {n: (torch.rand(p.shape, generator=gm) < 0.5) for n, p in m.named_parameters()}
+
+    class Wrapped(torch.nn.Module):             # DDPMSfronOracle calls model(x, t_float, c, drop); RNG order as the reference
+        def __init__(self, net):
+            super().__init__()
+            self.net = net
+
+        def forward(self, x, tf, c, drop=None):
+            return self.net(x, tf, c, mode="train", cond_drop_prob=0.1)
+    wm = Wrapped(m)
+    orc = sfron_ref.DDPMSfronOracle(wm, sfron_ref.ddpm_get_betas(), lr=1e-3, forget_alpha=10.0, remain_alpha=1.0, grad_clip=1.0,
+                                    ema_mu=1e-4, mask={"net." + k: v for k, v in mask.items()}, unlearn_loss="adaga",
+                                    lambd=0.5, n_iters=2, decay_forget_alpha=True)
+    for step in range(2):
+        gt = lambda k: torch.from_numpy(g[f"s{step}_{k}"])
+        torch.manual_seed(100 + step)
+        r = orc.step(step, dict(x0=gt("fx"), e=gt("fe"), t=gt("ft"), c=gt("fc"), drop=None),
+                     dict(x0=gt("rx"), e=gt("re"), t=gt("rt"), c=gt("rc"), drop=None))
+        assert r["alpha"] == pytest.approx(float(g["traj_alpha"][step]))
+        assert r["forget_loss"] == pytest.approx(float(g["traj_forget"][step]), rel=1e-4)
+        assert r["remain_loss"] == pytest.approx(float(g["traj_remain"][step]), rel=1e-4)
+    np.testing.assert_allclose(m.conv_in.weight.detach().numpy(), g["final_conv_in"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(orc.shadow["net.conv_out.weight"].numpy(), g["final_shadow_conv_out"], rtol=0, atol=2e-5)
