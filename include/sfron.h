@@ -129,7 +129,7 @@ int sfron_gemm_bf16(const sfron_gemm_desc* desc /* HOST pointer */, void* stream
  * mod buffers are fp32 [batch][ldmod]; shift/scale/gate pointers already include the column offset of the
  * chunk (DiT/models.py:119 .chunk(6, dim=1)).  `tokens` = tokens per sample (row / tokens = sample). */
 
-/* rows per reduction chunk (= rows one wave handles) of the *_bwd kernels' partial buffers */
+/* rows per reduction chunk of the *_bwd kernels' partial buffers (one workgroup's rows: 16 when 16 | tokens) */
 int sfron_rows_per_chunk(int tokens);
 
 /* out = bf16( LayerNorm(x; eps 1e-6, no affine) * (1 + scale) + shift ), saves mean / rstd per row
@@ -147,6 +147,13 @@ int sfron_ln_modulate_bwd(const uint16_t* d_out, const float* x, const float* me
  * p_gate / p_dy [M / rows_per_chunk][D] = per-chunk column sums of dy * branch and of dy */
 int sfron_gate_bwd(const float* dy, const uint16_t* branch, const float* gate, int ldmod, int tokens, int M, int D,
                    uint16_t* d_branch, float* p_gate, float* p_dy, void* stream);
+
+/* sfron_ln_modulate_bwd followed by sfron_gate_bwd of the NEXT (earlier) branch on the freshly accumulated dx rows, in
+ * one pass (saves the fp32 re-read of dx): DiT/models.py:120-121 backward, branch k's LN + branch k-1's gate. */
+int sfron_ln_gate_bwd(const uint16_t* d_out, const float* x, const float* mean, const float* rstd, const float* scale,
+                      int ldmod, int tokens, int M, int D, float* dx, int dx_accumulate, float* p_shift, float* p_scale,
+                      const uint16_t* branch, const float* gate, int ldgate, uint16_t* d_branch, float* p_gate, float* p_dy,
+                      void* stream);
 
 /* out[g * ldout + c] (+)= sum_{j < per_group} partials[(g * per_group + j) * D + c]   (fixed order, reproducible) */
 int sfron_reduce_chunks(const float* partials, int groups, int per_group, int D, float* out, int ldout, int accumulate,

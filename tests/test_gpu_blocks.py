@@ -13,7 +13,7 @@ def close(a, b, rtol, atol):
     np.testing.assert_allclose(a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy(), rtol=rtol, atol=atol)
 
 
-@pytest.mark.parametrize("B,T,D", [(2, 64, 128), (3, 16, 144), (2, 256, 1152)])
+@pytest.mark.parametrize("B,T,D", [(2, 64, 128), (3, 16, 144), (3, 6, 144), (2, 12, 64), (2, 256, 1152)])
 def test_ln_modulate_fwd_bwd(B, T, D):
     from sfron import ops
     gen = torch.Generator().manual_seed(B * T + D)
@@ -64,6 +64,30 @@ def test_gate_bwd_and_reductions(B, T, D):
     # colsum, both dtypes
     close(ops.colsum(br.to(DEV)), br.float().sum(0), 1e-4, 1e-3)
     close(ops.colsum(dy.to(DEV)), dy.sum(0), 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("B,T,D", [(2, 64, 128), (3, 6, 144), (2, 12, 64), (3, 24, 144), (2, 256, 1152)])
+def test_ln_gate_bwd_fused_equals_separate(B, T, D):
+    """The fused LN-backward + gate-backward pass is bit-identical to the two separate kernels (same per-row arithmetic,
+    same fixed-order partial sums), for every chunking plan (16 / 8 / 4 rows combined, 2 rows per wave)."""
+    from sfron import ops
+    gen = torch.Generator().manual_seed(B * T * D)
+    M = B * T
+    x = (torch.randn(M, D, generator=gen) * 2 + 0.3).to(DEV)
+    mod = (torch.randn(B, 6 * D, generator=gen) * 0.5).to(DEV)
+    dout = (torch.randn(M, D, generator=gen) * 0.1).to(torch.bfloat16).to(DEV)
+    br = torch.randn(M, D, generator=gen).to(torch.bfloat16).to(DEV)
+    dx0 = (torch.randn(M, D, generator=gen) * 0.1).to(DEV)
+    _, mean, rstd = ops.ln_modulate_fwd(x, mod[:, 3 * D:], mod[:, 4 * D:], 6 * D, T)
+    for acc in (True, False):
+        dxa = dx0.clone()
+        ps, pc = ops.ln_modulate_bwd(dout, x, mean, rstd, mod[:, 4 * D:], 6 * D, T, dxa, accumulate=acc)
+        db, pg, pd = ops.gate_bwd(dxa, br, mod[:, 2 * D:], 6 * D, T)
+        dxb = dx0.clone()
+        ps2, pc2, db2, pg2, pd2 = ops.ln_gate_bwd(dout, x, mean, rstd, mod[:, 4 * D:], 6 * D, T, dxb, acc, br, mod[:, 2 * D:], 6 * D)
+        for u, v in ((dxa, dxb), (ps, ps2), (pc, pc2), (db, db2), (pg, pg2), (pd, pd2)):
+            assert torch.equal(u, v)
+        assert ps.shape[0] == M // ops.rows_per_chunk(T)
 
 
 def test_conditioning_and_layout():

@@ -129,12 +129,13 @@ def test_gemm_rejects_bad_args():
         ops.gemm(A, A, 128, 128, 60, c_bf16=torch.zeros(128, 128, dtype=torch.bfloat16, device=DEV))   # K % 8 != 0
 
 
-@pytest.mark.parametrize("hint", [1, 2, 3, 12, 13, 32])
+@pytest.mark.parametrize("hint", [1, 2, 3, 12, 13, 32, 42])
 @pytest.mark.parametrize("layout", ["fwd", "dgrad", "wgrad"])
 def test_fast_tiles_all_layouts(hint, layout):
     """LDS-DMA fast path (tile_hint 1: 128x128, 2: 256x128, 3: 256x256) vs the generic kernel and torch."""
     from sfron import ops, _lib
-    M, N, K = 512, 768, 320            # K/64 = 5 tiles: exercises the odd tail of the 2-deep ring
+    # K/64 = 5 tiles: exercises the odd tail of the 2-deep ring; the interleaved schedule (42) needs an even tile count
+    M, N, K = 512, 768, (384 if hint == 42 else 320)
     gen = torch.Generator().manual_seed(hint * 10 + len(layout))
     if layout == "fwd":
         A, B = _rand((M, K), gen), _rand((N, K), gen, 0.1)
@@ -182,3 +183,35 @@ def test_ring_tile_192(layout):
         assert torch.equal(Cf, Cg)
         if K % 64 == 0:
             assert torch.equal(Cp, Cg), "hand-pipelined 192x192 tile"
+            for Kx in (K, 64, 128, 192, 256):                  # interleaved schedule: 2, 4, 16 K tiles; odd counts fall back
+                Ci = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+                Cr = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+                Ax = A[:, :Kx].contiguous() if layout != "wgrad" else A[:Kx].contiguous()
+                Bx = B[:, :Kx].contiguous() if layout == "fwd" else B[:Kx].contiguous()
+                ops.gemm(Ax.to(DEV), Bx.to(DEV), M, N, Kx, epilogue=_lib.EPI_F32, c_f32=Ci, tile_hint=45, **kw)
+                ops.gemm(Ax.to(DEV), Bx.to(DEV), M, N, Kx, epilogue=_lib.EPI_F32, c_f32=Cr, tile_hint=-1, **kw)
+                assert torch.equal(Ci, Cr), f"interleaved 192x192 tile, K={Kx}"
+
+
+@pytest.mark.parametrize("M,N,K,splits,hint", [(384, 192, 2048, 4, 0), (192, 384, 1024 + 64, 4, 0), (192, 192, 512, 3, 35),
+                                               (160, 96, 512, 4, 0)])
+def test_wgrad_split_k_slabs(M, N, K, splits, hint):
+    """split-K weight gradient: every split writes its own fp32 slab (pipelined 192x192 tile when the shape fits, generic
+    kernel otherwise, uneven last split included); the fixed-order slab sum equals the unsplit product."""
+    from sfron import ops, _lib
+    gen = torch.Generator().manual_seed(M + N + K)
+    A, Bm = _rand((K, M), gen).to(DEV), _rand((K, N), gen).to(DEV)          # C[M,N] = A^T B
+    slabs = torch.full((splits, M, N), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm(A, Bm, M, N, K, a_t=True, b_t=True, epilogue=_lib.EPI_F32, c_f32=slabs, ldc_f32=N, split_k=splits,
+             split_stride=M * N, tile_hint=hint)
+    kchunk = -(-(-(-K // splits)) // 64) * 64          # ceil(ceil(K / splits) / 64) * 64, as the library plans it
+    used = -(-K // kchunk)
+    ref = A.float().t() @ Bm.float()
+    got = slabs[:used].sum(0)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-3, atol=2e-2)
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.reduce_chunks(slabs, 1, used, M * N, out, M * N)
+    s = slabs[0].clone()
+    for j in range(1, used):
+        s += slabs[j]
+    assert torch.equal(out, s)

@@ -23,7 +23,7 @@ dx = torch.randn(M, D, device=DEV, generator=g)
 br = torch.randn(M, D, device=DEV, generator=g).to(torch.bfloat16)
 dh = torch.randn(M, F, device=DEV, generator=g).to(torch.bfloat16)
 out, mean, rstd = ops.ln_modulate_fwd(x, mod[:, 3 * D:], mod[:, 4 * D:], 6 * D, T)
-def rep(name, ms, mbytes): print(f"{name:22s} {ms*1e3:8.1f} us  {mbytes/ms/1e6:6.2f} TB/s ({mbytes:.0f} MB)")
+def rep(name, ms, mbytes): print(f"{name:22s} {ms*1e3:8.1f} us  {mbytes/ms/1e3:6.2f} TB/s ({mbytes:.0f} MB)")
 rep("ln_modulate_fwd", timeit(lambda: ops.ln_modulate_fwd(x, mod[:, 3 * D:], mod[:, 4 * D:], 6 * D, T)), M * D * 6 / 1e6)
 rep("ln_modulate_bwd", timeit(lambda: ops.ln_modulate_bwd(dxm, x, mean, rstd, mod[:, 4 * D:], 6 * D, T, dx, True)), M * D * 14 / 1e6)
 rep("gate_bwd", timeit(lambda: ops.gate_bwd(dx, br, mod[:, 2 * D:], 6 * D, T)), M * D * 8 / 1e6)

@@ -52,6 +52,7 @@ _PROTOS.update({
     "sfron_ln_modulate_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _S]),
     "sfron_ln_modulate_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _S]),
     "sfron_gate_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _S]),
+    "sfron_ln_gate_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _S]),
     "sfron_reduce_chunks": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, _S]),
     "sfron_weighted_reduce": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, _S]),
     "sfron_reduce_slots": (c_int, [_P, ctypes.c_long, c_int, c_int, c_int, c_int, POINTER(c_void_p), POINTER(ctypes.c_long),

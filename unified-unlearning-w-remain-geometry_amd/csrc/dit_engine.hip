@@ -74,12 +74,26 @@ struct Workspace {
   __bf16* xmodf;
   float* tok;
   // backward temporaries
-  float *dx, *dmod, *d_sc, *d_c, *d_h1s, *delta, *part, *csum, *csum2, *slabs, *dysum;
-  __bf16 *d_tok, *d_br, *d_br2, *d_hpre, *d_xmod, *d_o, *dqkv, *dmod_bf, *d_c_bf, *d_h1_bf, *dx_bf;
+  float *dx, *dmod, *d_sc, *d_c, *d_h1s, *delta, *part, *csum, *csum2, *slabs, *wslab, *dysum;
+  __bf16 *d_tok, *d_xmod, *d_o, *dmod_bf, *d_c_bf, *d_h1_bf, *dx_bf;
+  __bf16 *d_br[2], *d_br2[2], *d_hpre[2], *dqkv[2];   // read by the side stream: double-buffered by block parity so the
+                                                       // dgrad chain may run one block ahead of the weight gradients
   size_t bytes;
 };
 constexpr int SPLIT_K_ADA = 64;
-constexpr int CSUM_PARTS = 16;     // row chunks of the bias column sums (stage 2 reads CSUM_PARTS x N floats with N/256 workgroups)
+constexpr int CSUM_PARTS = 64;     // row chunks of the bias column sums (stage 2 reads CSUM_PARTS x N floats with N/256 workgroups)
+
+// Weight gradients dW[N][K] = dY[M][N]^T X[M][K] have few 192x192 output tiles and a long reduction (M = batch*tokens):
+// split the reduction so that one GEMM offers about 150-250 workgroups (the side stream it runs on is otherwise the
+// critical path of the backward pass).  1 = no split.
+inline int wgrad_splits(int N, int K, int Mred) {
+  if (N % 192 || K % 192 || Mred % 64) return 1;
+  const int tiles = (N / 192) * (K / 192);
+  int s = 224 / tiles;
+  if (s > 4) s = 4;
+  while (s > 1 && (Mred / 64) % s) --s;
+  return s < 1 ? 1 : s;
+}
 
 inline Workspace make_ws(const Dims& d, char* base) {
   Workspace w{};
@@ -111,10 +125,19 @@ inline Workspace make_ws(const Dims& d, char* base) {
   w.csum = (float*)take(CSUM_PARTS * widest * 4);
   w.csum2 = (float*)take(CSUM_PARTS * (size_t)(d.F > 3 * d.D ? d.F : 3 * d.D) * 4);   // side-stream colsum scratch
   w.slabs = (float*)take((size_t)SPLIT_K_ADA * B * D * 4);
+  {                                                                       // split-K slabs of the block weight gradients
+    const size_t shapes[4][2] = {{3 * D, D}, {D, D}, {(size_t)d.F, D}, {D, (size_t)d.F}};
+    size_t mx = 0;
+    for (auto& sh : shapes) { const size_t n = wgrad_splits((int)sh[0], (int)sh[1], (int)M) * sh[0] * sh[1]; mx = n > mx ? n : mx; }
+    w.wslab = (float*)take(mx * 4);
+  }
   w.dysum = (float*)take((L + 1) * 2 * B * D * 4);                       // [L][proj|fc2][B][D] token sums of dy (gated bias grads)
   w.d_tok = (__bf16*)take(M * (size_t)d.Po * 2);
-  w.d_br = (__bf16*)take(M * D * 2); w.d_br2 = (__bf16*)take(M * D * 2); w.d_hpre = (__bf16*)take(M * (size_t)d.F * 2); w.d_xmod = (__bf16*)take(M * D * 2);
-  w.d_o = (__bf16*)take(M * D * 2); w.dqkv = (__bf16*)take(M * 3 * D * 2); w.dx_bf = (__bf16*)take(M * D * 2);
+  for (int i = 0; i < 2; ++i) {
+    w.d_br[i] = (__bf16*)take(M * D * 2); w.d_br2[i] = (__bf16*)take(M * D * 2);
+    w.d_hpre[i] = (__bf16*)take(M * (size_t)d.F * 2); w.dqkv[i] = (__bf16*)take(M * 3 * D * 2);
+  }
+  w.d_xmod = (__bf16*)take(M * D * 2); w.d_o = (__bf16*)take(M * D * 2); w.dx_bf = (__bf16*)take(M * D * 2);
   w.bytes = o;
   return w;
 }
@@ -166,17 +189,17 @@ int64_t sfron_dit_workspace_bytes(const sfron_dit_cfg* cfg) {
 
 // ---- aux: a side stream + events so the weight-gradient GEMMs (which nothing downstream in the backward chain
 // depends on) run concurrently with the dgrad / elementwise chain and fill the CUs its tile counts leave idle
-struct Aux { hipStream_t side; hipEvent_t produced[4], consumed[4], done; };
+struct Aux { hipStream_t side; hipEvent_t produced[4], consumed[8], done; };
 
 int sfron_aux_create(void** aux) {
   SFRON_CHECK_ARG(aux);
   Aux* a = new Aux{};
   // equal priority with the caller's stream measured best (89.8 ms/step; lowest priority 92.8, highest 95.1)
   if (hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking) != hipSuccess) return (int)hipGetLastError();
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 4; ++i)
     if (hipEventCreateWithFlags(&a->produced[i], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+  for (int i = 0; i < 8; ++i)
     if (hipEventCreateWithFlags(&a->consumed[i], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
-  }
   if (hipEventCreateWithFlags(&a->done, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
   *aux = a;
   return SFRON_OK;
@@ -184,7 +207,8 @@ int sfron_aux_create(void** aux) {
 int sfron_aux_destroy(void* aux) {
   SFRON_CHECK_ARG(aux);
   Aux* a = (Aux*)aux;
-  for (int i = 0; i < 4; ++i) { (void)hipEventDestroy(a->produced[i]); (void)hipEventDestroy(a->consumed[i]); }
+  for (int i = 0; i < 4; ++i) (void)hipEventDestroy(a->produced[i]);
+  for (int i = 0; i < 8; ++i) (void)hipEventDestroy(a->consumed[i]);
   (void)hipEventDestroy(a->done);
   (void)hipStreamDestroy(a->side);
   delete a;
@@ -314,6 +338,13 @@ int sfron_dit_forward_probed(const sfron_dit_cfg* cfg, const float* params, cons
   return SFRON_OK;
 }
 
+// SFRON_ABLATE (debug / A-B measurement only): bit 0 = run LN backward and gate backward as separate kernels,
+// bit 1 = no split-K in the block weight gradients
+static int ablate_mask() {
+  static const int m = [] { const char* e = getenv("SFRON_ABLATE"); return e ? atoi(e) : 0; }();
+  return m;
+}
+
 int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* d_out,
                        const int64_t* y, const uint8_t* drop, void* workspace, float* grads, void* aux, void* stream) {
   Dims d;
@@ -332,14 +363,34 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
   auto slot = [&](int layer, int kind, int buf) { return w.part + ((size_t)layer * 8 + kind * 2 + buf) * slot_stride; };
   hipStream_t hs = (hipStream_t)stream;
   sfron_gemm_desc g;
+  const bool fuse = !(ablate_mask() & 1);
   // side stream for weight/bias gradients (falls back to the main stream without an aux handle)
   Aux* ax = (Aux*)aux;
   void* side = ax ? (void*)ax->side : stream;
-  // buffer i (0 d_br mlp, 1 d_hpre, 2 d_br attn, 3 dqkv): main records produced[i] after writing it, the side stream
-  // waits for it before reading; the side stream records consumed[i], main waits for it before overwriting.
+  // block weight gradient on the side stream, reduction split per wgrad_splits() into fp32 slabs + fixed-order sum
+  auto wgrad_side = [&](const void* dY, const void* X, int N, int K, float* dW) -> int {
+    sfron_gemm_desc q = wgrad_desc(dY, X, M, N, K, dW);
+    const int sp = (ablate_mask() & 2) ? 1 : wgrad_splits(N, K, M);
+    if (sp > 1) { q.c_f32 = w.wslab; q.split_k = sp; q.split_stride = (long)N * K; }
+    RUN(sfron_gemm_bf16(&q, side));
+    if (sp > 1) RUN(sfron_reduce_chunks(w.wslab, 1, sp, N * K, dW, N * K, 0, side));
+    return SFRON_OK;
+  };
+  // LN backward of one branch + gate backward of the branch before it, on the same dx rows
+  auto ln_gate = [&](const float* x, const float* mean, const float* rstd, const float* scale, int acc, float* ps, float* pc,
+                     const __bf16* branch, const float* gate, __bf16* d_branch, float* pg, float* pd) -> int {
+    if (fuse)
+      return sfron_ln_gate_bwd((const uint16_t*)w.d_xmod, x, mean, rstd, scale, NM, T, M, D, w.dx, acc, ps, pc,
+                               (const uint16_t*)branch, gate, NM, (uint16_t*)d_branch, pg, pd, stream);
+    RUN(sfron_ln_modulate_bwd((const uint16_t*)w.d_xmod, x, mean, rstd, scale, NM, T, M, D, w.dx, acc, ps, pc, stream));
+    return sfron_gate_bwd(w.dx, (const uint16_t*)branch, gate, NM, T, M, D, (uint16_t*)d_branch, pg, pd, stream);
+  };
+  // buffer i (0 d_br mlp, 1 d_hpre, 2 d_br attn, 3 dqkv) of block l lives in copy l & 1: main records produced[i] after
+  // writing it, the side stream waits for it before reading; the side stream records consumed[i][l & 1], and main waits
+  // for that before block l - 2 overwrites the copy -- so main stalls only when the side stream is a whole block behind.
   auto produced = [&](int i) { if (ax) { (void)hipEventRecord(ax->produced[i], hs); (void)hipStreamWaitEvent(ax->side, ax->produced[i], 0); } };
-  auto consumed = [&](int i) { if (ax) (void)hipEventRecord(ax->consumed[i], ax->side); };
-  auto before_overwrite = [&](int i, bool first) { if (ax && !first) (void)hipStreamWaitEvent(hs, ax->consumed[i], 0); };
+  auto consumed = [&](int i, int l) { if (ax) (void)hipEventRecord(ax->consumed[2 * i + (l & 1)], ax->side); };
+  auto before_overwrite = [&](int i, int l) { if (ax && l + 2 <= d.L - 1) (void)hipStreamWaitEvent(hs, ax->consumed[2 * i + (l & 1)], 0); };
   if (ax) { (void)hipEventRecord(ax->done, hs); (void)hipStreamWaitEvent(ax->side, ax->done, 0); }   // side starts after everything before us
 
   // ---- final layer
@@ -352,8 +403,15 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
   RUN(sfron_gemm_bf16(&g, stream));
   const float* modf = w.mod + (size_t)6 * d.L * D;
   float* dmodf = w.dmod + (size_t)6 * d.L * D;
-  RUN(sfron_ln_modulate_bwd((const uint16_t*)w.d_xmod, w.xs + (size_t)(2 * d.L) * M * D, w.mean + (size_t)(2 * d.L) * M,
-                            w.rstd + (size_t)(2 * d.L) * M, modf + D, NM, T, M, D, w.dx, 0, slot(d.L, 3, 0), slot(d.L, 3, 1), stream));
+  // every LN backward is fused with the gate backward of the branch that precedes it in the forward order: the final
+  // layer's LN with the last block's MLP gate, a block's MLP LN with its attention gate, its attention LN with the
+  // previous block's MLP gate (only block 0's attention LN stands alone).
+  {
+    const int l = d.L - 1;
+    RUN(ln_gate(w.xs + (size_t)(2 * d.L) * M * D, w.mean + (size_t)(2 * d.L) * M, w.rstd + (size_t)(2 * d.L) * M, modf + D, 0,
+                slot(d.L, 3, 0), slot(d.L, 3, 1), w.a2 + (size_t)l * M * D, w.mod + (size_t)l * 6 * D + 5 * D, w.d_br[l & 1],
+                slot(l, 0, 0), slot(l, 0, 1)));
+  }
 
   for (int l = d.L - 1; l >= 0; --l) {
     const int64_t pb = P.blocks + (int64_t)l * P.blk_stride;
@@ -367,49 +425,50 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
     const __bf16* h = w.h + (size_t)l * M * d.F; const __bf16* a2 = w.a2 + (size_t)l * M * D;
     const bool first = (l == d.L - 1);
     // ---- MLP branch: x2 = x1 + gate_mlp * (fc2(gelu(fc1(xmod2))))
-    before_overwrite(0, first);
-    RUN(sfron_gate_bwd(w.dx, (const uint16_t*)a2, mod + 5 * D, NM, T, M, D, (uint16_t*)w.d_br, slot(l, 0, 0), slot(l, 0, 1), stream));
-    produced(0);
-    g = wgrad_desc(w.d_br, h, M, D, d.F, grads + pb + P.o_fc2_w);
-    RUN(sfron_gemm_bf16(&g, side));
-    consumed(0);
-    before_overwrite(1, first);
-    g = dgrad_desc(w.d_br, wb + pb + P.o_fc2_w, M, D, d.F);
-    g.epilogue = SFRON_EPI_DGELU; g.c_bf16 = (uint16_t*)w.d_hpre; g.ldc_bf16 = d.F; g.aux = (uint16_t*)hpre; g.ldaux = d.F;
+    produced(0);                                  // d_br was written by the fused LN+gate kernel just before this block
+    const int pl = l & 1;
+    RUN(wgrad_side(w.d_br[pl], h, D, d.F, grads + pb + P.o_fc2_w));
+    consumed(0, l);
+    before_overwrite(1, l);
+    g = dgrad_desc(w.d_br[pl], wb + pb + P.o_fc2_w, M, D, d.F);
+    g.epilogue = SFRON_EPI_DGELU; g.c_bf16 = (uint16_t*)w.d_hpre[pl]; g.ldc_bf16 = d.F; g.aux = (uint16_t*)hpre; g.ldaux = d.F;
     RUN(sfron_gemm_bf16(&g, stream));
     produced(1);
-    RUN(sfron_colsum(w.d_hpre, 1, M, d.F, d.F, ax ? w.csum2 : w.csum, CSUM_PARTS, grads + pb + P.o_fc1_b, side));
-    g = wgrad_desc(w.d_hpre, xmod2, M, d.F, D, grads + pb + P.o_fc1_w);
-    RUN(sfron_gemm_bf16(&g, side));
-    consumed(1);
-    g = dgrad_desc(w.d_hpre, wb + pb + P.o_fc1_w, M, d.F, D);
+    RUN(sfron_colsum(w.d_hpre[pl], 1, M, d.F, d.F, ax ? w.csum2 : w.csum, CSUM_PARTS, grads + pb + P.o_fc1_b, side));
+    RUN(wgrad_side(w.d_hpre[pl], xmod2, d.F, D, grads + pb + P.o_fc1_w));
+    consumed(1, l);
+    g = dgrad_desc(w.d_hpre[pl], wb + pb + P.o_fc1_w, M, d.F, D);
     g.c_bf16 = (uint16_t*)w.d_xmod; g.ldc_bf16 = D;
     RUN(sfron_gemm_bf16(&g, stream));
-    RUN(sfron_ln_modulate_bwd((const uint16_t*)w.d_xmod, x1, w.mean + (size_t)(2 * l + 1) * M, w.rstd + (size_t)(2 * l + 1) * M,
-                              mod + 4 * D, NM, T, M, D, w.dx, 1, slot(l, 1, 0), slot(l, 1, 1), stream));
     // ---- attention branch: x1 = x0 + gate_msa * proj(attn(qkv(xmod1)))
-    before_overwrite(2, first);
-    RUN(sfron_gate_bwd(w.dx, (const uint16_t*)a1, mod + 2 * D, NM, T, M, D, (uint16_t*)w.d_br2, slot(l, 2, 0), slot(l, 2, 1), stream));
+    before_overwrite(2, l);
+    RUN(ln_gate(x1, w.mean + (size_t)(2 * l + 1) * M, w.rstd + (size_t)(2 * l + 1) * M, mod + 4 * D, 1, slot(l, 1, 0),
+                slot(l, 1, 1), a1, mod + 2 * D, w.d_br2[pl], slot(l, 2, 0), slot(l, 2, 1)));
     produced(2);
-    g = wgrad_desc(w.d_br2, o, M, D, D, grads + pb + P.o_proj_w);
-    RUN(sfron_gemm_bf16(&g, side));
-    consumed(2);
-    g = dgrad_desc(w.d_br2, wb + pb + P.o_proj_w, M, D, D);
+    RUN(wgrad_side(w.d_br2[pl], o, D, D, grads + pb + P.o_proj_w));
+    consumed(2, l);
+    g = dgrad_desc(w.d_br2[pl], wb + pb + P.o_proj_w, M, D, D);
     g.c_bf16 = (uint16_t*)w.d_o; g.ldc_bf16 = D;
     RUN(sfron_gemm_bf16(&g, stream));
-    before_overwrite(3, first);
+    before_overwrite(3, l);
     RUN(sfron_attn_bwd((const uint16_t*)qkv, (const uint16_t*)o, (const uint16_t*)w.d_o, w.lse + (size_t)l * B * d.H * T,
-                       w.delta, (uint16_t*)w.dqkv, B, T, d.H, d.hd, stream));
+                       w.delta, (uint16_t*)w.dqkv[pl], B, T, d.H, d.hd, stream));
     produced(3);
-    RUN(sfron_colsum(w.dqkv, 1, M, 3 * D, 3 * D, ax ? w.csum2 : w.csum, CSUM_PARTS, grads + pb + P.o_qkv_b, side));
-    g = wgrad_desc(w.dqkv, xmod1, M, 3 * D, D, grads + pb + P.o_qkv_w);
-    RUN(sfron_gemm_bf16(&g, side));
-    consumed(3);
-    g = dgrad_desc(w.dqkv, wb + pb + P.o_qkv_w, M, 3 * D, D);
+    RUN(sfron_colsum(w.dqkv[pl], 1, M, 3 * D, 3 * D, ax ? w.csum2 : w.csum, CSUM_PARTS, grads + pb + P.o_qkv_b, side));
+    RUN(wgrad_side(w.dqkv[pl], xmod1, 3 * D, D, grads + pb + P.o_qkv_w));
+    consumed(3, l);
+    g = dgrad_desc(w.dqkv[pl], wb + pb + P.o_qkv_w, M, 3 * D, D);
     g.c_bf16 = (uint16_t*)w.d_xmod; g.ldc_bf16 = D;
     RUN(sfron_gemm_bf16(&g, stream));
-    RUN(sfron_ln_modulate_bwd((const uint16_t*)w.d_xmod, x0, w.mean + (size_t)(2 * l) * M, w.rstd + (size_t)(2 * l) * M,
-                              mod + D, NM, T, M, D, w.dx, 1, slot(l, 3, 0), slot(l, 3, 1), stream));
+    if (l > 0) {
+      before_overwrite(0, l - 1);
+      RUN(ln_gate(x0, w.mean + (size_t)(2 * l) * M, w.rstd + (size_t)(2 * l) * M, mod + D, 1, slot(l, 3, 0), slot(l, 3, 1),
+                  w.a2 + (size_t)(l - 1) * M * D, w.mod + (size_t)(l - 1) * 6 * D + 5 * D, w.d_br[(l - 1) & 1], slot(l - 1, 0, 0),
+                  slot(l - 1, 0, 1)));
+    } else {
+      RUN(sfron_ln_modulate_bwd((const uint16_t*)w.d_xmod, x0, w.mean, w.rstd, mod + D, NM, T, M, D, w.dx, 1, slot(0, 3, 0),
+                                slot(0, 3, 1), stream));
+    }
   }
   {
     // deferred token reductions of the whole pass: d(shift, scale, gate) of every block + the dy token sums

@@ -839,12 +839,32 @@ __device__ __forceinline__ bf16x8 asm_read_b128(unsigned addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
   return r;
 }
+template <int OFF>
+__device__ __forceinline__ bf16x4 asm_read_tr_off(unsigned addr) {
+  bf16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 asm_read_b128_off(unsigned addr) {
+  bf16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 __device__ __forceinline__ void lds_reads_done() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI>
+// SCHED 1 ("interleaved"): the same pipeline, but the LDS-DMA issues and fragment reads of a segment are pinned BETWEEN
+// the MFMAs they overlap with (one MFMA, then 1-2 memory instructions, sched_barrier), so their issue slots hide under
+// the 16-cycle MFMA occupancy instead of forming an MFMA-free bubble after every barrier; buffer select and k-step are
+// immediate ds offsets (K loop unrolled by two).
+template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI, int SCHED = 0>
 __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
   constexpr int FBM = WM * MT * 16, FBN = WN * NT * 16, NW = WM * WN;
   constexpr int A_ELEMS = FBM * 64, B_ELEMS = FBN * 64;
@@ -872,13 +892,24 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (SCHED == 1) {
+    // pin the zero-initialisation HERE: hipcc otherwise sinks each v_mov next to the first (asm) MFMA that reads the
+    // accumulator, and the VALU-write -> MFMA-SrcC-read wait states it would add for a builtin MFMA are then missing
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) { f32x4& c = acc[i][j]; asm volatile("" : "+v"(c)); }
+  }
 
   GldsPlan<FBM, A_TR, NW> planA;
   GldsPlan<FBN, B_TR, NW> planB;
   planA.init(g.lda, m0, wave, lane);
   planB.init(g.ldb, n0, wave, lane);
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, 0x7fffffff, 0x00020000);
+  // num_records = the operand's exact extent: loads past it (the "next tile" request of the last iteration) fetch nothing
+  const int bytesA = 2 * (((A_TR ? g.K : g.M) - 1) * g.lda + (A_TR ? g.M : g.K));
+  const int bytesB = 2 * (((B_TR ? g.K : g.N) - 1) * g.ldb + (B_TR ? g.N : g.K));
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, SCHED == 1 ? bytesA : 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, SCHED == 1 ? bytesB : 0x7fffffff, 0x00020000);
   auto stage = [&](int buf, int k0) {
     planA.issue(rsA, 2 * (A_TR ? k0 * g.lda : k0), sAp(buf), wave);
     planB.issue(rsB, 2 * (B_TR ? k0 * g.ldb : k0), sBp(buf), wave);
@@ -943,14 +974,110 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[nt], f.a[mt], acc[mt][nt], 0, 0, 0);
   };
 
-  const int nk = g.K / BK;
+  // split-K: blockIdx.y owns k in [kbeg, kbeg + kchunk) and writes its own fp32 slab (summed later in a fixed order)
+  const int kbeg = blockIdx.y * g.kchunk;
+  const int nk = (min(g.K, kbeg + g.kchunk) - kbeg) / BK;
+  if constexpr (EPI == EPI_F32) g.Cf += (size_t)blockIdx.y * g.split_stride;
   Frags f0, f1;
-  stage(0, 0);
+  stage(0, kbeg);
+  if constexpr (SCHED == 1) {
+    constexpr int NM = MT * NT;
+    constexpr int NDA = GldsPlan<FBM, A_TR, NW>::PER_WAVE, NDB = GldsPlan<FBN, B_TR, NW>::PER_WAVE;
+    constexpr int NRA = MT * (A_TR ? 2 : 1), NRB = NT * (B_TR ? 2 : 1);
+    unsigned adA1[A_TR ? 1 : MT], adB1[B_TR ? 1 : NT];         // direct images: k-step 1 flips chunk bit 2
+    if constexpr (!A_TR) static_for<MT>([&](auto i) { adA1[i] = adA[i][0] ^ 64u; });
+    if constexpr (!B_TR) static_for<NT>([&](auto i) { adB1[i] = adB[i][0] ^ 64u; });
+    auto read = [&](auto bufc, auto ksc, Frags& f, auto rc) {
+      constexpr int BUF = decltype(bufc)::value, KS = decltype(ksc)::value, r = decltype(rc)::value;
+      if constexpr (r < NRA) {
+        if constexpr (!A_TR) {
+          f.a[r] = asm_read_b128_off<BUF * 2 * A_ELEMS>(KS ? adA1[r] : adA[r][0]);
+        } else {
+          constexpr int mt = r >> 1, h = r & 1;
+          const bf16x4 t = asm_read_tr_off<BUF * 2 * A_ELEMS + KS * 64 * FBM>(adA[mt][h]);
+          f.a[mt][4 * h] = t[0]; f.a[mt][4 * h + 1] = t[1]; f.a[mt][4 * h + 2] = t[2]; f.a[mt][4 * h + 3] = t[3];
+        }
+      } else {
+        constexpr int q = r - NRA;
+        if constexpr (!B_TR) {
+          f.b[q] = asm_read_b128_off<BUF * 2 * B_ELEMS>(KS ? adB1[q] : adB[q][0]);
+        } else {
+          constexpr int nt = q >> 1, h = q & 1;
+          const bf16x4 t = asm_read_tr_off<BUF * 2 * B_ELEMS + KS * 64 * FBN>(adB[nt][h]);
+          f.b[nt][4 * h] = t[0]; f.b[nt][4 * h + 1] = t[1]; f.b[nt][4 * h + 2] = t[2]; f.b[nt][4 * h + 3] = t[3];
+        }
+      }
+    };
+    auto mfma1 = [&](const Frags& f, auto ic) {
+      constexpr int mt = decltype(ic)::value / NT, nt = decltype(ic)::value % NT;
+      // asm, accumulating in place: through the builtin hipcc renames every accumulator here (vdst != srcC) and spills ~150 VGPRs
+      f32x4& c = acc[mt][nt];
+      const bf16x8 fb = f.b[nt], fa = f.a[mt];
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(fb), "v"(fa));
+    };
+    // one K tile held by BUF; FIRST = nothing to multiply yet in segment 1.  The next tile is always requested: past the
+    // end of the k range the request goes through a descriptor with num_records = 0, which makes every lane out of
+    // range (an out-of-range raw buffer load fetches nothing), so every iteration runs the same straight-line code.
+    const int kend = kbeg + nk * BK;
+    auto body = [&](auto bufc, auto firstc, int kt) {
+      constexpr int BUF = decltype(bufc)::value;
+      constexpr bool FIRST = decltype(firstc)::value;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile kt has landed
+      __builtin_amdgcn_s_barrier();                           // everybody's has; buffer BUF^1 is free
+      __builtin_amdgcn_sched_barrier(0);
+      const int knext = kbeg + (kt + 1) * BK;
+      const bool more = knext < kend;
+      const int soA = 2 * (A_TR ? knext * g.lda : knext), soB = 2 * (B_TR ? knext * g.ldb : knext);
+      const __amdgpu_buffer_rsrc_t rqA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, more ? bytesA : 0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rqB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, more ? bytesB : 0, 0x00020000);
+      constexpr int NDMA = NDA + NDB;
+      constexpr int NOPS1 = NDMA + NRA + NRB;
+      auto op1 = [&](auto kc) {                               // DMA of the next tile first, then k-step 0 of this one
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k < NDMA) {
+          if constexpr (k < NDA) planA.issue_one(rqA, soA, sAp(BUF ^ 1), wave, k);
+          else planB.issue_one(rqB, soB, sBp(BUF ^ 1), wave, k - NDA);
+        } else {
+          read(bufc, std::integral_constant<int, 0>{}, f0, std::integral_constant<int, k - NDMA>{});
+        }
+      };
+      if constexpr (FIRST) {
+        static_for<NOPS1>(op1);
+      } else {
+        static_for<NM>([&](auto ic) {
+          constexpr int i = decltype(ic)::value, lo = i * NOPS1 / NM, hi = (i + 1) * NOPS1 / NM;
+          mfma1(f1, ic);                                       // k-step 1 of the previous tile
+          static_for<hi - lo>([&](auto jc) { op1(std::integral_constant<int, lo + decltype(jc)::value>{}); });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+      lds_reads_done();
+      constexpr int NOPS2 = NRA + NRB;
+      static_for<NM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value, lo = i * NOPS2 / NM, hi = (i + 1) * NOPS2 / NM;
+        mfma1(f0, ic);
+        static_for<hi - lo>([&](auto jc) {
+          read(bufc, std::integral_constant<int, 1>{}, f1, std::integral_constant<int, lo + decltype(jc)::value>{});
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      lds_reads_done();
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    // nk is even and >= 2 here (the launcher routes other k ranges to the plain schedule): no conditional tail, whose
+    // control-flow merge made hipcc spill fragment registers that an asynchronous ds_read had not filled yet
+    body(I0{}, std::true_type{}, 0);
+    body(I1{}, std::false_type{}, 1);
+    for (int kt = 2; kt < nk; kt += 2) { body(I0{}, std::false_type{}, kt); body(I1{}, std::false_type{}, kt + 1); }
+    static_for<NM>([&](auto ic) { mfma1(f1, ic); });
+    // the asm MFMAs are invisible to hipcc's hazard recogniser: let the last results land before the epilogue reads them
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  } else
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile kt has landed
     __builtin_amdgcn_s_barrier();                           // ... everybody's has; buffer buf^1 is free (its reads were waited for)
-    if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);
+    if (kt + 1 < nk) stage(buf ^ 1, kbeg + (kt + 1) * BK);
     __builtin_amdgcn_sched_barrier(0);
     read_frags(f0, buf, 0);                                 // k-step 0 of this tile goes out ...
     __builtin_amdgcn_sched_barrier(0);
@@ -961,7 +1088,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
     mfmas(f0);
     lds_reads_done();
   }
-  mfmas(f1);
+  if constexpr (SCHED == 0) mfmas(f1);
 
   const int row_b = m0 + wm * MT * 16 + (lane & 15), col_b = n0 + wn * NT * 16 + 4 * (lane >> 4);
   if constexpr (EPI == EPI_DGELU) {
@@ -1027,10 +1154,24 @@ SFRON_INST_PIPE(4, 2, 4, 6)
 SFRON_INST_PIPE(4, 2, 3, 6)
 SFRON_INST_PIPE(2, 2, 8, 6)
 #undef SFRON_INST_PIPE
+#define SFRON_INST_PIPE1(WM, WN, MT, NT)                                                \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, false, false, 0, 1>(GemmArgs);  \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, false, false, 1, 1>(GemmArgs);  \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, false, false, 2, 1>(GemmArgs);  \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, false, false, 3, 1>(GemmArgs);  \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, false, false, 5, 1>(GemmArgs);  \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, false, true, 0, 1>(GemmArgs);   \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, false, true, 1, 1>(GemmArgs);   \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, false, true, 4, 1>(GemmArgs);   \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, true, true, 0, 1>(GemmArgs);    \
+  template __global__ void k_gemm_pipe<WM, WN, MT, NT, true, true, 1, 1>(GemmArgs);
+SFRON_INST_PIPE1(4, 2, 4, 6)
+SFRON_INST_PIPE1(4, 2, 3, 6)
+#undef SFRON_INST_PIPE1
 
 namespace {
 
-template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI>
+template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI, int SCHED = 0>
 int launch_pipe(GemmArgs g, hipStream_t s) {
   constexpr int FBM = WM * MT * 16, FBN = WN * NT * 16;
   g.ntm = g.M / FBM; g.ntn = g.N / FBN;
@@ -1043,12 +1184,12 @@ int launch_pipe(GemmArgs g, hipStream_t s) {
   const size_t lds = 2 * (FBM + FBN) * 64 * sizeof(__bf16);
   static bool done = false;
   if (!done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pipe<WM, WN, MT, NT, A_TR, B_TR, EPI>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pipe<WM, WN, MT, NT, A_TR, B_TR, EPI, SCHED>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return (int)hipGetLastError();
     done = true;
   }
-  hipLaunchKernelGGL((k_gemm_pipe<WM, WN, MT, NT, A_TR, B_TR, EPI>), dim3(g.ntm * g.ntn), dim3(WM * WN * 64), lds, s, g);
+  hipLaunchKernelGGL((k_gemm_pipe<WM, WN, MT, NT, A_TR, B_TR, EPI, SCHED>), dim3(g.ntm * g.ntn, cdiv(g.K, g.kchunk)), dim3(WM * WN * 64), lds, s, g);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
 }
@@ -1066,23 +1207,32 @@ inline bool tile_fits(const GemmArgs& g, int t) {
   return t >= 1 && t < N_TILES && g.M % TILE_BM[t] == 0 && g.N % TILE_BN[t] == 0;
 }
 inline int pick_fast_tile(const GemmArgs& g, int force, int transposed_operands) {
-  if (g.K % 64 || g.kchunk != g.K || force < 0) return 0;
+  if (g.K % 64 || force < 0) return 0;
+  if (g.kchunk != g.K) {       // split-K: only the pipelined tiles take a k range
+    if (force == 32 || force == 35) return tile_fits(g, force - 30) ? force : 0;
+    if (force != 0) return 0;
+    if (transposed_operands == 2 && tile_fits(g, 5)) return 45;      // 42 / 45 fall back to 32 / 35 for odd tile counts
+    if (transposed_operands == 1 && tile_fits(g, 2)) return 42;
+    return 0;
+  }
   if (force == 21 || force == 22) return tile_fits(g, 2) ? force : 0;            // timing ablations of tile 2
   if (force == 32 || force == 35 || force == 36) return tile_fits(g, force - 30) ? force : 0;   // hand-pipelined variants of tiles 2, 5, 6
+  if (force == 42 || force == 45) return tile_fits(g, force - 40) ? force : 0;                  // ... with the interleaved schedule
   if (force > 10) return (g.K % 32 == 0 && tile_fits(g, force - 10)) ? force : 0;   // ring variants of tiles 2, 3, 5
   if (force > 0) return tile_fits(g, force) ? force : 0;
   // Measured policy (tools/bench_gemm.py, DiT-XL/2 B=32 shapes, random data):
-  //   both operands k-contiguous (forward)   -> 256x192 k_gemm_fast  (streamed row fragments, 760-950 TF)
-  //   B transposed-read (dgrad)              -> 256x192 k_gemm_pipe  (asm transposed reads, 650-900 TF)
-  //   both transposed-read (wgrad)           -> 192x192 k_gemm_pipe  (4.2 TF per CU vs 3.65 of the generic kernel)
+  //   both operands k-contiguous (forward)   -> 256x192 k_gemm_pipe, interleaved schedule (800-980 TF; k_gemm_fast 760-950)
+  //   B transposed-read (dgrad)              -> 256x192 k_gemm_pipe, interleaved schedule (735-1040 TF; plain schedule 630-885)
+  //   both transposed-read (wgrad)           -> 192x192 k_gemm_pipe, interleaved schedule (5.5 TF per CU; plain 4.2, generic 3.65)
   // a tile is used when it fills at least half of the last round of 256 CUs (wgrad runs beside the dgrad chain
   // on a side stream, so its own tile count does not have to fill the chip).
   auto eff = [&](int t) {
     const long tiles = (long)(g.M / TILE_BM[t]) * (g.N / TILE_BN[t]);
     return (double)tiles / (double)(((tiles + 255) / 256) * 256);
   };
-  if (transposed_operands == 2) return tile_fits(g, 5) ? 35 : 0;
-  if (tile_fits(g, 2) && eff(2) >= 0.5) return transposed_operands == 1 ? 32 : 2;
+  const bool even_nk = g.K % 128 == 0;       // the interleaved schedule's requirement
+  if (transposed_operands == 2) return tile_fits(g, 5) ? 45 : 0;
+  if (tile_fits(g, 2) && eff(2) >= 0.5) return (transposed_operands == 1 || even_nk) ? 42 : 2;
   return (transposed_operands == 0 && tile_fits(g, 1)) ? 1 : 0;   // with transposed reads the generic kernel beats the 4-wave tile
 }
 
@@ -1103,6 +1253,11 @@ int launch_any(const GemmArgs& g, hipStream_t s, int force) {
     case 32: return launch_pipe<4, 2, 4, 6, A_TR, B_TR, EPI>(g, s);
     case 35: return launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI>(g, s);
     case 36: return launch_pipe<2, 2, 8, 6, A_TR, B_TR, EPI>(g, s);
+    // interleaved schedule: needs an even number (>= 2) of 64-deep k tiles per split, else the plain schedule
+    case 42: return (g.kchunk % 128 == 0 && g.K % g.kchunk == 0) ? launch_pipe<4, 2, 4, 6, A_TR, B_TR, EPI, 1>(g, s)
+                                                                  : launch_pipe<4, 2, 4, 6, A_TR, B_TR, EPI>(g, s);
+    case 45: return (g.kchunk % 128 == 0 && g.K % g.kchunk == 0) ? launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI, 1>(g, s)
+                                                                  : launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI>(g, s);
     case 12: return launch_ring<4, 2, 4, 6, A_TR, B_TR, EPI, 5>(g, s);
     case 13: return launch_ring<2, 4, 8, 4, A_TR, B_TR, EPI, 4>(g, s);
     case 15: return launch_ring<4, 2, 3, 6, A_TR, B_TR, EPI, 6>(g, s);

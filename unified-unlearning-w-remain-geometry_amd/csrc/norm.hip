@@ -81,123 +81,125 @@ __global__ __launch_bounds__(TPB) void k_ln_mod_fwd(const float* __restrict__ x,
   }
 }
 
-// each wave stores its own column partials (row-chunk = the rpw rows of one wave); the sums over the chunks of a
-// sample are taken later in ONE launch for the whole backward pass (k_reduce_slots): no LDS, no barrier here
-template <int NACC>
-__device__ __forceinline__ void wave_partial_store(const float4 (&acc)[NACC][NCH], int D4, int lane, float* const (&dst)[NACC]) {
-#pragma unroll
-  for (int a = 0; a < NACC; ++a)
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
-      if (c < D4) reinterpret_cast<float4*>(dst[a])[c] = acc[a][i];
-    }
-}
+// ---------------------------------------------------------------- row-wise backward (LN+modulate, gated residual, or both)
+// One wave walks `rpw` consecutive token rows; a workgroup = 4 waves = one partial chunk of 4*rpw rows when `combine`
+// (the four waves' column partials are summed through LDS in a fixed order), else one chunk per wave.  The sums over the
+// chunks of a sample are taken later in ONE launch for the whole backward pass (k_reduce_slots): no float atomics.
+//   LN   : dx (fp32, in/out) (+)= d LN-path of dxmod;  p_shift[chunk][D] = sum_rows dxmod, p_scale = sum_rows dxmod*xhat
+//   GATE : d_branch (bf16) = dx * gate[b];              p_gate[chunk][D] = sum_rows dx*branch, p_dy = sum_rows dx
+// LN && GATE is the fusion of "LN backward of branch k" with "gate backward of branch k-1" on the freshly accumulated dx
+// row, which saves the re-read of dx (fp32 [M][D]) between the two.
+struct RowBwdArgs {
+  const __bf16* dxmod; const float* x; const float* mean; const float* rstd; const float* scale;
+  float* p_shift; float* p_scale; int dx_accumulate;
+  const __bf16* branch; const float* gate; __bf16* d_branch; float* p_gate; float* p_dy;
+  float* dx;                      // LN: in/out; GATE only: read
+  int ldmod_ln, ldmod_gate, T, M, D, rpw, combine;
+};
 
-// ---------------------------------------------------------------- LN + modulate backward
-// dx (fp32, in/out) += d LN-path;  partials: p_shift[chunk][D] = sum_rows dxmod, p_scale[chunk][D] = sum_rows dxmod*xhat
-__global__ __launch_bounds__(TPB) void k_ln_mod_bwd(const __bf16* __restrict__ dxmod, const float* __restrict__ x,
-                                                    const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
-                                                    const float* __restrict__ scale, int ldmod, int T, int M, int D,
-                                                    int rpw, float* __restrict__ dx, int dx_accumulate,
-                                                    float* __restrict__ p_shift, float* __restrict__ p_scale) {
+template <bool LN, bool GATE>
+__global__ __launch_bounds__(TPB) void k_row_bwd(const RowBwdArgs a) {
+  constexpr int NACC = (LN ? 2 : 0) + (GATE ? 2 : 0);
+  __shared__ float4 sh[4][64 * NCH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int D4 = D >> 2;
-  const int chunk = blockIdx.x * 4 + wave;       // one chunk = the rpw consecutive rows of this wave
-  const int row0 = chunk * rpw;
-  if (row0 >= M) return;
-  const int b = row0 / T;                        // all rows of a chunk belong to one sample (T % rpw == 0)
-  float4 gs[NCH];                                // 1 + scale
-  const float* sc = scale + (size_t)b * ldmod;
+  const int D = a.D, D4 = D >> 2;
+  const int wchunk = blockIdx.x * 4 + wave;      // the rpw consecutive rows of this wave
+  const int row0 = wchunk * a.rpw;
+  if (!a.combine && row0 >= a.M) return;         // combine: M % (4*rpw) == 0, every wave has rows
+  const int b = row0 / a.T;                      // all rows of a chunk belong to one sample
+  float4 acc[NACC][NCH];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i;
-    float4 g = c < D4 ? reinterpret_cast<const float4*>(sc)[c] : make_float4(0, 0, 0, 0);
-    gs[i] = make_float4(1.0f + g.x, 1.0f + g.y, 1.0f + g.z, 1.0f + g.w);
-  }
-  float4 acc[2][NCH];
+  for (int k = 0; k < NACC; ++k)
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) { acc[0][i] = make_float4(0, 0, 0, 0); acc[1][i] = make_float4(0, 0, 0, 0); }
-  for (int rr = 0; rr < rpw; ++rr) {
+    for (int i = 0; i < NCH; ++i) acc[k][i] = make_float4(0, 0, 0, 0);
+  const float* sc = LN ? a.scale + (size_t)b * a.ldmod_ln : nullptr;
+  const float* gp = GATE ? a.gate + (size_t)b * a.ldmod_gate : nullptr;
+  for (int rr = 0; rr < a.rpw; ++rr) {
     const int row = row0 + rr;
-    RowRegs xr, dr;
-    load_row_f32(x + (size_t)row * D, D4, lane, xr);
-    load_row_bf16(dxmod + (size_t)row * D, D4, lane, dr);
-    const float mean = mean_in[row], rstd = rstd_in[row];
-    float s1 = 0.f, s2 = 0.f;
+    RowRegs cur;                                 // the dx row the gate part sees
+    if constexpr (LN) {
+      RowRegs xr;
+      load_row_f32(a.x + (size_t)row * D, D4, lane, xr);
+      load_row_bf16(a.dxmod + (size_t)row * D, D4, lane, cur);
+      RowRegs prev;
+      if (a.dx_accumulate) load_row_f32(a.dx + (size_t)row * D, D4, lane, prev);
+      const float mean = a.mean[row], rstd = a.rstd[row];
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      if (lane + 64 * i < D4) {
-        float4& xv = xr.v[i];
-        xv.x = (xv.x - mean) * rstd; xv.y = (xv.y - mean) * rstd; xv.z = (xv.z - mean) * rstd; xv.w = (xv.w - mean) * rstd;
-        const float4 d = dr.v[i];
-        acc[0][i].x += d.x; acc[0][i].y += d.y; acc[0][i].z += d.z; acc[0][i].w += d.w;
-        acc[1][i].x += d.x * xv.x; acc[1][i].y += d.y * xv.y; acc[1][i].z += d.z * xv.z; acc[1][i].w += d.w * xv.w;
-        float4& g = dr.v[i];                      // g = dxmod * (1 + scale)
-        g.x *= gs[i].x; g.y *= gs[i].y; g.z *= gs[i].z; g.w *= gs[i].w;
-        s1 += g.x + g.y + g.z + g.w;
-        s2 += g.x * xv.x + g.y * xv.y + g.z * xv.z + g.w * xv.w;
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D4) {
+          float4& xv = xr.v[i];
+          xv.x = (xv.x - mean) * rstd; xv.y = (xv.y - mean) * rstd; xv.z = (xv.z - mean) * rstd; xv.w = (xv.w - mean) * rstd;
+          float4& g = cur.v[i];
+          acc[0][i].x += g.x; acc[0][i].y += g.y; acc[0][i].z += g.z; acc[0][i].w += g.w;
+          acc[1][i].x += g.x * xv.x; acc[1][i].y += g.y * xv.y; acc[1][i].z += g.z * xv.z; acc[1][i].w += g.w * xv.w;
+          const float4 s4 = reinterpret_cast<const float4*>(sc)[c];      // g = dxmod * (1 + scale); L1/L2-resident
+          g.x *= 1.0f + s4.x; g.y *= 1.0f + s4.y; g.z *= 1.0f + s4.z; g.w *= 1.0f + s4.w;
+          s1 += g.x + g.y + g.z + g.w;
+          s2 += g.x * xv.x + g.y * xv.y + g.z * xv.z + g.w * xv.w;
+        }
       }
-    }
-    const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+      const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
-      if (c < D4) {
-        const float4 g = dr.v[i], xh = xr.v[i];
-        float4 o = make_float4(rstd * (g.x - m1 - xh.x * m2), rstd * (g.y - m1 - xh.y * m2),
-                               rstd * (g.z - m1 - xh.z * m2), rstd * (g.w - m1 - xh.w * m2));
-        float4* dp = reinterpret_cast<float4*>(dx + (size_t)row * D) + c;
-        if (dx_accumulate) { const float4 p = *dp; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
-        *dp = o;
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D4) {
+          const float4 g = cur.v[i], xh = xr.v[i];
+          float4 o = make_float4(rstd * (g.x - m1 - xh.x * m2), rstd * (g.y - m1 - xh.y * m2),
+                                 rstd * (g.z - m1 - xh.z * m2), rstd * (g.w - m1 - xh.w * m2));
+          if (a.dx_accumulate) { const float4 p = prev.v[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+          reinterpret_cast<float4*>(a.dx + (size_t)row * D)[c] = o;
+          cur.v[i] = o;
+        }
       }
+    } else {
+      load_row_f32(a.dx + (size_t)row * D, D4, lane, cur);
     }
-  }
-  float* const dst[2] = {p_shift + (size_t)chunk * D, p_scale + (size_t)chunk * D};
-  wave_partial_store<2>(acc, D4, lane, dst);
-}
-
-// ---------------------------------------------------------------- gated-residual backward
-// d_branch (bf16) = dy * gate[b];  partials: p_gate[chunk][D] = sum_rows dy * branch, p_dy[chunk][D] = sum_rows dy
-__global__ __launch_bounds__(TPB) void k_gate_bwd(const float* __restrict__ dy, const __bf16* __restrict__ branch,
-                                                  const float* __restrict__ gate, int ldmod, int T, int M, int D, int rpw,
-                                                  __bf16* __restrict__ d_branch, float* __restrict__ p_gate,
-                                                  float* __restrict__ p_dy) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int D4 = D >> 2;
-  const int chunk = blockIdx.x * 4 + wave;
-  const int row0 = chunk * rpw;
-  if (row0 >= M) return;
-  const int b = row0 / T;
-  float4 gt[NCH];
-  const float* gp = gate + (size_t)b * ldmod;
+    if constexpr (GATE) {
+      constexpr int G0 = LN ? 2 : 0;
+      RowRegs br;
+      load_row_bf16(a.branch + (size_t)row * D, D4, lane, br);
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i;
-    gt[i] = c < D4 ? reinterpret_cast<const float4*>(gp)[c] : make_float4(0, 0, 0, 0);
-  }
-  float4 acc[2][NCH];
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) { acc[0][i] = make_float4(0, 0, 0, 0); acc[1][i] = make_float4(0, 0, 0, 0); }
-  for (int rr = 0; rr < rpw; ++rr) {
-    const int row = row0 + rr;
-    RowRegs dr, br;
-    load_row_f32(dy + (size_t)row * D, D4, lane, dr);
-    load_row_bf16(branch + (size_t)row * D, D4, lane, br);
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
-      if (c < D4) {
-        const float4 d = dr.v[i], a = br.v[i];
-        acc[0][i].x += d.x * a.x; acc[0][i].y += d.y * a.y; acc[0][i].z += d.z * a.z; acc[0][i].w += d.w * a.w;
-        acc[1][i].x += d.x; acc[1][i].y += d.y; acc[1][i].z += d.z; acc[1][i].w += d.w;
-        bf16x4 o = {f2bf(d.x * gt[i].x), f2bf(d.y * gt[i].y), f2bf(d.z * gt[i].z), f2bf(d.w * gt[i].w)};
-        reinterpret_cast<bf16x4*>(d_branch + (size_t)row * D)[c] = o;
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D4) {
+          const float4 d = cur.v[i], h = br.v[i];
+          acc[G0][i].x += d.x * h.x; acc[G0][i].y += d.y * h.y; acc[G0][i].z += d.z * h.z; acc[G0][i].w += d.w * h.w;
+          acc[G0 + 1][i].x += d.x; acc[G0 + 1][i].y += d.y; acc[G0 + 1][i].z += d.z; acc[G0 + 1][i].w += d.w;
+          const float4 gt = reinterpret_cast<const float4*>(gp)[c];
+          bf16x4 o = {f2bf(d.x * gt.x), f2bf(d.y * gt.y), f2bf(d.z * gt.z), f2bf(d.w * gt.w)};
+          reinterpret_cast<bf16x4*>(a.d_branch + (size_t)row * D)[c] = o;
+        }
       }
     }
   }
-  float* const dst[2] = {p_gate + (size_t)chunk * D, p_dy + (size_t)chunk * D};
-  wave_partial_store<2>(acc, D4, lane, dst);
+  float* dst[4];
+  if constexpr (LN) { dst[0] = a.p_shift; dst[1] = a.p_scale; }
+  if constexpr (GATE) { dst[LN ? 2 : 0] = a.p_gate; dst[LN ? 3 : 1] = a.p_dy; }
+  if (!a.combine) {
+#pragma unroll
+    for (int k = 0; k < NACC; ++k)
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D4) reinterpret_cast<float4*>(dst[k] + (size_t)wchunk * D)[c] = acc[k][i];
+      }
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) {
+    if (k) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) sh[wave][lane + 64 * i] = acc[k][i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < D4; c += TPB) {
+      const float4 p0 = sh[0][c], p1 = sh[1][c], p2 = sh[2][c], p3 = sh[3][c];
+      reinterpret_cast<float4*>(dst[k] + (size_t)blockIdx.x * D)[c] =
+          make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z,
+                      ((p0.w + p1.w) + p2.w) + p3.w);
+    }
+  }
 }
 
 // ---------------------------------------------------------------- small fixed-order reductions
@@ -209,7 +211,15 @@ __global__ __launch_bounds__(TPB) void k_reduce_chunks(const float* __restrict__
   if (c >= D) return;
   const float* p = P + (size_t)g * per_group * D + c;
   float s = 0.f;
-  for (int j = 0; j < per_group; ++j) s += p[(size_t)j * D];
+  int j = 0;
+  for (; j + 8 <= per_group; j += 8) {            // 8 loads in flight, summed in index order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(j + u) * D];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; j < per_group; ++j) s += p[(size_t)j * D];
   float* o = out + (size_t)g * ldout + c;
   *o = accumulate ? *o + s : s;
 }
@@ -257,40 +267,87 @@ __global__ __launch_bounds__(TPB) void k_gated_bias_grads(const float* __restric
   out[(size_t)l * out_stride + (which ? out_which1 : out_which0) + c] = t;
 }
 
-// column sums of a [M][N] matrix: stage 1 writes partials[chunk][N]; the caller finishes with k_reduce_chunks
-template <typename T>
+// column sums of a [M][N] matrix: stage 1 writes partials[chunk][N]; the caller finishes with k_reduce_chunks.
+// A lane owns VEC consecutive columns (one 16-byte load per row for bf16 VEC = 8 / fp32 VEC = 4), the 4 waves of a
+// workgroup take rows r0+wave, +4, ... with 4 loads in flight each, and combine through LDS in a fixed order.
+template <typename T, int VEC>
 __global__ __launch_bounds__(TPB) void k_colsum_partial(const T* __restrict__ X, int M, int N, int ld, int rows_per_block,
                                                         float* __restrict__ partials) {
-  __shared__ float4 sh[3][64];
+  __shared__ float sh[3][VEC][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c4 = blockIdx.x * 64 + lane;            // group of 4 columns
+  const int col = (blockIdx.x * 64 + lane) * VEC;
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
-  float4 acc = make_float4(0, 0, 0, 0);
-  if (c4 * 4 < N) {
-    for (int r = r0 + wave; r < r1; r += 4) {
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+  typedef __attribute__((ext_vector_type(VEC))) __bf16 bvec;
+  typedef __attribute__((ext_vector_type(VEC))) float fvec;
+  if (col < N) {
+    const T* p = X + col;
+    int r = r0 + wave;
+    for (; r + 12 < r1; r += 16) {
       if constexpr (sizeof(T) == 2) {
-        const bf16x4 b = *reinterpret_cast<const bf16x4*>(X + (size_t)r * ld + c4 * 4);
-        acc.x += bf2f(b[0]); acc.y += bf2f(b[1]); acc.z += bf2f(b[2]); acc.w += bf2f(b[3]);
+        bvec q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const bvec*>(p + (size_t)(r + 4 * u) * ld);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[v] += bf2f(q[u][v]);
       } else {
-        const float4 b = *reinterpret_cast<const float4*>(X + (size_t)r * ld + c4 * 4);
-        acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+        fvec q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const fvec*>(p + (size_t)(r + 4 * u) * ld);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[v] += q[u][v];
+      }
+    }
+    for (; r < r1; r += 4) {
+      if constexpr (sizeof(T) == 2) {
+        const bvec q = *reinterpret_cast<const bvec*>(p + (size_t)r * ld);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += bf2f(q[v]);
+      } else {
+        const fvec q = *reinterpret_cast<const fvec*>(p + (size_t)r * ld);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += q[v];
       }
     }
   }
-  if (wave > 0) sh[wave - 1][lane] = acc;
+  if (wave > 0) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) sh[wave - 1][v][lane] = acc[v];
+  }
   __syncthreads();
-  if (wave == 0 && c4 * 4 < N) {
-    for (int w = 0; w < 3; ++w) { acc.x += sh[w][lane].x; acc.y += sh[w][lane].y; acc.z += sh[w][lane].z; acc.w += sh[w][lane].w; }
-    *reinterpret_cast<float4*>(partials + (size_t)blockIdx.y * N + c4 * 4) = acc;
+  if (wave == 0 && col < N) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      acc[v] = ((acc[v] + sh[0][v][lane]) + sh[1][v][lane]) + sh[2][v][lane];
+      partials[(size_t)blockIdx.y * N + col + v] = acc[v];
+    }
   }
 }
 
-// rows per wave (= rows per partial chunk) of the backward elementwise kernels
-inline int pick_rpw(int T) {
-  if (T % 4 == 0) return 4;
-  if (T % 2 == 0) return 2;
-  return 1;
+// rows per wave and whether the 4 waves of a workgroup combine their partials (needs 4*rpw | T)
+struct ChunkPlan { int rpw, combine, rows; };
+inline ChunkPlan pick_chunk(int T) {
+  if (T % 16 == 0) return {4, 1, 16};
+  if (T % 8 == 0) return {2, 1, 8};
+  if (T % 4 == 0) return {1, 1, 4};
+  if (T % 2 == 0) return {2, 0, 2};
+  return {1, 0, 1};
+}
+
+template <bool LN, bool GATE>
+int launch_row_bwd(RowBwdArgs a, void* stream) {
+  const ChunkPlan cp = pick_chunk(a.T);
+  a.rpw = cp.rpw; a.combine = cp.combine;
+  hipLaunchKernelGGL((k_row_bwd<LN, GATE>), dim3(cdiv(a.M / cp.rpw, 4)), dim3(TPB), 0, (hipStream_t)stream, a);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
 }
 
 struct SlotDst { float* base; long layer_stride; int ld; };
@@ -314,7 +371,7 @@ __global__ __launch_bounds__(TPB) void k_reduce_slots(const float* __restrict__ 
 
 extern "C" {
 
-int sfron_rows_per_chunk(int tokens) { return tokens > 0 ? pick_rpw(tokens) : 0; }
+int sfron_rows_per_chunk(int tokens) { return tokens > 0 ? pick_chunk(tokens).rows : 0; }
 
 int sfron_ln_modulate_fwd(const float* x, const float* shift, const float* scale, int ldmod, int tokens, int M, int D,
                           uint16_t* out, float* mean, float* rstd, void* stream) {
@@ -330,26 +387,37 @@ int sfron_ln_modulate_fwd(const float* x, const float* shift, const float* scale
 int sfron_ln_modulate_bwd(const uint16_t* d_out, const float* x, const float* mean, const float* rstd, const float* scale,
                           int ldmod, int tokens, int M, int D, float* dx, int dx_accumulate, float* p_shift,
                           float* p_scale, void* stream) {
-  SFRON_CHECK_ARG(d_out && x && mean && rstd && scale && dx && p_shift && p_scale && M > 0);
-  SFRON_CHECK_ARG(D % 4 == 0 && D <= 64 * 4 * NCH && ldmod % 4 == 0);
-  const int rpw = pick_rpw(tokens);
-  SFRON_CHECK_ARG(M % tokens == 0);
-  hipLaunchKernelGGL(k_ln_mod_bwd, dim3(cdiv(M / rpw, 4)), dim3(TPB), 0, (hipStream_t)stream, (const __bf16*)d_out, x, mean,
-                     rstd, scale, ldmod, tokens, M, D, rpw, dx, dx_accumulate, p_shift, p_scale);
-  SFRON_LAUNCH_STATUS();
-  return SFRON_OK;
+  SFRON_CHECK_ARG(d_out && x && mean && rstd && scale && dx && p_shift && p_scale && M > 0 && tokens > 0);
+  SFRON_CHECK_ARG(D % 4 == 0 && D <= 64 * 4 * NCH && ldmod % 4 == 0 && M % tokens == 0);
+  RowBwdArgs a{};
+  a.dxmod = (const __bf16*)d_out; a.x = x; a.mean = mean; a.rstd = rstd; a.scale = scale; a.p_shift = p_shift; a.p_scale = p_scale;
+  a.dx_accumulate = dx_accumulate; a.dx = dx; a.ldmod_ln = ldmod; a.T = tokens; a.M = M; a.D = D;
+  return launch_row_bwd<true, false>(a, stream);
 }
 
 int sfron_gate_bwd(const float* dy, const uint16_t* branch, const float* gate, int ldmod, int tokens, int M, int D,
                    uint16_t* d_branch, float* p_gate, float* p_dy, void* stream) {
-  SFRON_CHECK_ARG(dy && branch && gate && d_branch && p_gate && p_dy && M > 0);
-  SFRON_CHECK_ARG(D % 4 == 0 && D <= 64 * 4 * NCH && ldmod % 4 == 0);
-  const int rpw = pick_rpw(tokens);
-  SFRON_CHECK_ARG(M % tokens == 0);
-  hipLaunchKernelGGL(k_gate_bwd, dim3(cdiv(M / rpw, 4)), dim3(TPB), 0, (hipStream_t)stream, dy, (const __bf16*)branch, gate,
-                     ldmod, tokens, M, D, rpw, (__bf16*)d_branch, p_gate, p_dy);
-  SFRON_LAUNCH_STATUS();
-  return SFRON_OK;
+  SFRON_CHECK_ARG(dy && branch && gate && d_branch && p_gate && p_dy && M > 0 && tokens > 0);
+  SFRON_CHECK_ARG(D % 4 == 0 && D <= 64 * 4 * NCH && ldmod % 4 == 0 && M % tokens == 0);
+  RowBwdArgs a{};
+  a.branch = (const __bf16*)branch; a.gate = gate; a.d_branch = (__bf16*)d_branch; a.p_gate = p_gate; a.p_dy = p_dy;
+  a.dx = const_cast<float*>(dy); a.ldmod_gate = ldmod; a.T = tokens; a.M = M; a.D = D;
+  return launch_row_bwd<false, true>(a, stream);
+}
+
+int sfron_ln_gate_bwd(const uint16_t* d_out, const float* x, const float* mean, const float* rstd, const float* scale,
+                      int ldmod, int tokens, int M, int D, float* dx, int dx_accumulate, float* p_shift, float* p_scale,
+                      const uint16_t* branch, const float* gate, int ldgate, uint16_t* d_branch, float* p_gate, float* p_dy,
+                      void* stream) {
+  SFRON_CHECK_ARG(d_out && x && mean && rstd && scale && dx && p_shift && p_scale && M > 0 && tokens > 0);
+  SFRON_CHECK_ARG(branch && gate && d_branch && p_gate && p_dy);
+  SFRON_CHECK_ARG(D % 4 == 0 && D <= 64 * 4 * NCH && ldmod % 4 == 0 && ldgate % 4 == 0 && M % tokens == 0);
+  RowBwdArgs a{};
+  a.dxmod = (const __bf16*)d_out; a.x = x; a.mean = mean; a.rstd = rstd; a.scale = scale; a.p_shift = p_shift; a.p_scale = p_scale;
+  a.dx_accumulate = dx_accumulate; a.dx = dx; a.ldmod_ln = ldmod; a.T = tokens; a.M = M; a.D = D;
+  a.branch = (const __bf16*)branch; a.gate = gate; a.d_branch = (__bf16*)d_branch; a.p_gate = p_gate; a.p_dy = p_dy;
+  a.ldmod_gate = ldgate;
+  return launch_row_bwd<true, true>(a, stream);
 }
 
 int sfron_reduce_chunks(const float* partials, int groups, int per_group, int D, float* out, int ldout, int accumulate,
@@ -402,17 +470,20 @@ int sfron_weighted_reduce(const float* partials, int groups, int per_group, int 
 int sfron_colsum(const void* X, int is_bf16, int M, int N, int ld, float* partials, int max_partials, float* out,
                  void* stream) {
   SFRON_CHECK_ARG(X && partials && out && M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0 && max_partials > 0);
-  int chunks = cdiv(M, 128);
+  SFRON_CHECK_ARG(((uintptr_t)X & 15) == 0);
+  int chunks = cdiv(M, 32);
   if (chunks > max_partials) chunks = max_partials;
   const int rpb = cdiv(M, chunks);
   chunks = cdiv(M, rpb);
-  dim3 grid(cdiv(N, 256), chunks);
-  if (is_bf16)
-    hipLaunchKernelGGL(k_colsum_partial<__bf16>, grid, dim3(TPB), 0, (hipStream_t)stream, (const __bf16*)X, M, N, ld, rpb, partials);
+  hipStream_t hs = (hipStream_t)stream;
+  if (is_bf16 && N % 8 == 0 && ld % 8 == 0)
+    hipLaunchKernelGGL((k_colsum_partial<__bf16, 8>), dim3(cdiv(N, 512), chunks), dim3(TPB), 0, hs, (const __bf16*)X, M, N, ld, rpb, partials);
+  else if (is_bf16)
+    hipLaunchKernelGGL((k_colsum_partial<__bf16, 4>), dim3(cdiv(N, 256), chunks), dim3(TPB), 0, hs, (const __bf16*)X, M, N, ld, rpb, partials);
   else
-    hipLaunchKernelGGL(k_colsum_partial<float>, grid, dim3(TPB), 0, (hipStream_t)stream, (const float*)X, M, N, ld, rpb, partials);
+    hipLaunchKernelGGL((k_colsum_partial<float, 4>), dim3(cdiv(N, 256), chunks), dim3(TPB), 0, hs, (const float*)X, M, N, ld, rpb, partials);
   SFRON_LAUNCH_STATUS();
-  hipLaunchKernelGGL(k_reduce_chunks, dim3(cdiv(N, TPB), 1), dim3(TPB), 0, (hipStream_t)stream, partials, chunks, N, out, N, 0);
+  hipLaunchKernelGGL(k_reduce_chunks, dim3(cdiv(N, TPB), 1), dim3(TPB), 0, hs, partials, chunks, N, out, N, 0);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

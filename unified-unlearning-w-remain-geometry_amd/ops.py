@@ -83,6 +83,18 @@ def gate_bwd(dy, branch, gate, ldmod, tokens):
     return d_branch, p_gate, p_dy
 
 
+def ln_gate_bwd(d_out, x, mean, rstd, scale, ldmod, tokens, dx, accumulate, branch, gate, ldgate):
+    """ln_modulate_bwd then gate_bwd of the next branch on the updated dx rows, one pass."""
+    M, D = x.shape
+    nch = M // rows_per_chunk(tokens)
+    parts = [torch.empty(nch, D, dtype=torch.float32, device=x.device) for _ in range(4)]
+    d_branch = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+    check(_L().sfron_ln_gate_bwd(ptr(d_out), ptr(x), ptr(mean), ptr(rstd), scale.data_ptr(), ldmod, tokens, M, D, ptr(dx),
+                                 int(accumulate), ptr(parts[0]), ptr(parts[1]), ptr(branch), gate.data_ptr(), ldgate,
+                                 ptr(d_branch), ptr(parts[2]), ptr(parts[3]), stream_ptr()), "ln_gate_bwd")
+    return parts[0], parts[1], d_branch, parts[2], parts[3]
+
+
 def reduce_chunks(partials, groups, per_group, D, out, ldout, accumulate=False):
     check(_L().sfron_reduce_chunks(ptr(partials), groups, per_group, D, out.data_ptr(), ldout, int(accumulate), stream_ptr()),
           "reduce_chunks")
