@@ -191,6 +191,15 @@ def test_ring_tile_192(layout):
                 ops.gemm(Ax.to(DEV), Bx.to(DEV), M, N, Kx, epilogue=_lib.EPI_F32, c_f32=Ci, tile_hint=45, **kw)
                 ops.gemm(Ax.to(DEV), Bx.to(DEV), M, N, Kx, epilogue=_lib.EPI_F32, c_f32=Cr, tile_hint=-1, **kw)
                 assert torch.equal(Ci, Cr), f"interleaved 192x192 tile, K={Kx}"
+            if layout == "wgrad":                              # three LDS slots: 2 + 3j tiles (K = 128, 320, 512), else falls back
+                for Kx in (128, 320, 512, 1024):
+                    g3 = torch.Generator().manual_seed(Kx)
+                    A3, B3 = _rand((Kx, M), g3, 0.1).to(DEV), _rand((Kx, N), g3).to(DEV)
+                    C3 = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+                    Cr = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+                    ops.gemm(A3, B3, M, N, Kx, epilogue=_lib.EPI_F32, c_f32=C3, tile_hint=55, **kw)
+                    ops.gemm(A3, B3, M, N, Kx, epilogue=_lib.EPI_F32, c_f32=Cr, tile_hint=-1, **kw)
+                    assert torch.equal(C3, Cr), f"three-slot 192x192 tile, K={Kx}"
 
 
 @pytest.mark.parametrize("M,N,K,splits,hint", [(384, 192, 2048, 4, 0), (192, 384, 1024 + 64, 4, 0), (192, 192, 512, 3, 35),

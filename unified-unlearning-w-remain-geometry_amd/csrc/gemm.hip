@@ -869,8 +869,10 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
   constexpr int FBM = WM * MT * 16, FBN = WN * NT * 16, NW = WM * WN;
   constexpr int A_ELEMS = FBM * 64, B_ELEMS = FBN * 64;
   extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+  constexpr int NS = SCHED == 2 ? 3 : 2;                  // LDS slots (64-deep tiles); SCHED 2 = interleaved schedule, 3 slots
+  static_assert(NS == 2 || (2 * 2 * A_ELEMS + 64 * FBM < 65536 && 2 * 2 * B_ELEMS + 64 * FBN < 65536), "ds offset field");
   auto sAp = [&](int b) { return smem + b * A_ELEMS; };
-  auto sBp = [&](int b) { return smem + 2 * A_ELEMS + b * B_ELEMS; };
+  auto sBp = [&](int b) { return smem + NS * A_ELEMS + b * B_ELEMS; };
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -892,7 +894,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if constexpr (SCHED == 1) {
+  if constexpr (SCHED >= 1) {
     // pin the zero-initialisation HERE: hipcc otherwise sinks each v_mov next to the first (asm) MFMA that reads the
     // accumulator, and the VALU-write -> MFMA-SrcC-read wait states it would add for a builtin MFMA are then missing
 #pragma unroll
@@ -908,8 +910,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
   // num_records = the operand's exact extent: loads past it (the "next tile" request of the last iteration) fetch nothing
   const int bytesA = 2 * (((A_TR ? g.K : g.M) - 1) * g.lda + (A_TR ? g.M : g.K));
   const int bytesB = 2 * (((B_TR ? g.K : g.N) - 1) * g.ldb + (B_TR ? g.N : g.K));
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, SCHED == 1 ? bytesA : 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, SCHED == 1 ? bytesB : 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, SCHED >= 1 ? bytesA : 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, SCHED >= 1 ? bytesB : 0x7fffffff, 0x00020000);
   auto stage = [&](int buf, int k0) {
     planA.issue(rsA, 2 * (A_TR ? k0 * g.lda : k0), sAp(buf), wave);
     planB.issue(rsB, 2 * (B_TR ? k0 * g.ldb : k0), sBp(buf), wave);
@@ -980,13 +982,17 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
   if constexpr (EPI == EPI_F32) g.Cf += (size_t)blockIdx.y * g.split_stride;
   Frags f0, f1;
   stage(0, kbeg);
-  if constexpr (SCHED == 1) {
+  if constexpr (NS == 3) stage(1, kbeg + BK);              // three slots: two tiles in flight (nk >= 2 guaranteed by the launcher)
+  if constexpr (SCHED >= 1) {
     constexpr int NM = MT * NT;
     constexpr int NDA = GldsPlan<FBM, A_TR, NW>::PER_WAVE, NDB = GldsPlan<FBN, B_TR, NW>::PER_WAVE;
     constexpr int NRA = MT * (A_TR ? 2 : 1), NRB = NT * (B_TR ? 2 : 1);
     unsigned adA1[A_TR ? 1 : MT], adB1[B_TR ? 1 : NT];         // direct images: k-step 1 flips chunk bit 2
     if constexpr (!A_TR) static_for<MT>([&](auto i) { adA1[i] = adA[i][0] ^ 64u; });
     if constexpr (!B_TR) static_for<NT>([&](auto i) { adB1[i] = adB[i][0] ^ 64u; });
+    // (Tried and removed: an L2 prefetch stream, one dword per 128-B line per lane three tiles ahead of the LDS-DMA, for
+    // operands that are cold in L2 / Infinity Cache.  64 distinct lines per wave-instruction cost the texture path as
+    // much as eight 16-B-per-lane DMA instructions: hot GEMMs lost 12 %, cold ones 5 %, the step 6 %.)
     auto read = [&](auto bufc, auto ksc, Frags& f, auto rc) {
       constexpr int BUF = decltype(bufc)::value, KS = decltype(ksc)::value, r = decltype(rc)::value;
       if constexpr (r < NRA) {
@@ -1022,10 +1028,13 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
     auto body = [&](auto bufc, auto firstc, int kt) {
       constexpr int BUF = decltype(bufc)::value;
       constexpr bool FIRST = decltype(firstc)::value;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile kt has landed
-      __builtin_amdgcn_s_barrier();                           // everybody's has; buffer BUF^1 is free
+      // this wave's share of tile kt has landed
+      if constexpr (NS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDA + NDB) : "memory");   // the younger tile may still be in flight
+      __builtin_amdgcn_s_barrier();                           // everybody's has; the slot of tile kt-1 is free
       __builtin_amdgcn_sched_barrier(0);
-      const int knext = kbeg + (kt + 1) * BK;
+      constexpr int TGT = (BUF + NS - 1) % NS;                // slot the request of this iteration goes to
+      const int knext = kbeg + (kt + NS - 1) * BK;
       const bool more = knext < kend;
       const int soA = 2 * (A_TR ? knext * g.lda : knext), soB = 2 * (B_TR ? knext * g.ldb : knext);
       const __amdgpu_buffer_rsrc_t rqA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, more ? bytesA : 0, 0x00020000);
@@ -1035,8 +1044,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
       auto op1 = [&](auto kc) {                               // DMA of the next tile first, then k-step 0 of this one
         constexpr int k = decltype(kc)::value;
         if constexpr (k < NDMA) {
-          if constexpr (k < NDA) planA.issue_one(rqA, soA, sAp(BUF ^ 1), wave, k);
-          else planB.issue_one(rqB, soB, sBp(BUF ^ 1), wave, k - NDA);
+          if constexpr (k < NDA) planA.issue_one(rqA, soA, sAp(TGT), wave, k);
+          else planB.issue_one(rqB, soB, sBp(TGT), wave, k - NDA);
         } else {
           read(bufc, std::integral_constant<int, 0>{}, f0, std::integral_constant<int, k - NDMA>{});
         }
@@ -1068,7 +1077,14 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
     // control-flow merge made hipcc spill fragment registers that an asynchronous ds_read had not filled yet
     body(I0{}, std::true_type{}, 0);
     body(I1{}, std::false_type{}, 1);
-    for (int kt = 2; kt < nk; kt += 2) { body(I0{}, std::false_type{}, kt); body(I1{}, std::false_type{}, kt + 1); }
+    if constexpr (NS == 2) {
+      for (int kt = 2; kt < nk; kt += 2) { body(I0{}, std::false_type{}, kt); body(I1{}, std::false_type{}, kt + 1); }
+    } else {                                                  // (nk - 2) % 3 == 0 guaranteed by the launcher
+      using I2 = std::integral_constant<int, 2>;
+      for (int kt = 2; kt < nk; kt += 3) {
+        body(I2{}, std::false_type{}, kt); body(I0{}, std::false_type{}, kt + 1); body(I1{}, std::false_type{}, kt + 2);
+      }
+    }
     static_for<NM>([&](auto ic) { mfma1(f1, ic); });
     // the asm MFMAs are invisible to hipcc's hazard recogniser: let the last results land before the epilogue reads them
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -1168,6 +1184,8 @@ SFRON_INST_PIPE(2, 2, 8, 6)
 SFRON_INST_PIPE1(4, 2, 4, 6)
 SFRON_INST_PIPE1(4, 2, 3, 6)
 #undef SFRON_INST_PIPE1
+template __global__ void k_gemm_pipe<4, 2, 3, 6, true, true, 0, 2>(GemmArgs);    // 192x192, three slots: weight gradients
+template __global__ void k_gemm_pipe<4, 2, 3, 6, true, true, 1, 2>(GemmArgs);
 
 namespace {
 
@@ -1181,7 +1199,7 @@ int launch_pipe(GemmArgs g, hipStream_t s) {
     while (gm * 2 <= g.ntm && (double)(gm * 2) * (gm * 2) * FBM <= per_xcd * FBN * 1.5) gm *= 2;
     g.group_m = gm;
   }
-  const size_t lds = 2 * (FBM + FBN) * 64 * sizeof(__bf16);
+  const size_t lds = (SCHED == 2 ? 3 : 2) * (FBM + FBN) * 64 * sizeof(__bf16);
   static bool done = false;
   if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pipe<WM, WN, MT, NT, A_TR, B_TR, EPI, SCHED>),
@@ -1211,19 +1229,24 @@ inline int pick_fast_tile(const GemmArgs& g, int force, int transposed_operands)
   if (g.kchunk != g.K) {       // split-K: only the pipelined tiles take a k range
     if (force == 32 || force == 35) return tile_fits(g, force - 30) ? force : 0;
     if (force != 0) return 0;
-    if (transposed_operands == 2 && tile_fits(g, 5)) return 45;      // 42 / 45 fall back to 32 / 35 for odd tile counts
+    if (transposed_operands == 2 && tile_fits(g, 5)) return 55;      // 55 -> 45 -> 35 and 42 -> 32 fall back by k-tile count
     if (transposed_operands == 1 && tile_fits(g, 2)) return 42;
     return 0;
   }
   if (force == 21 || force == 22) return tile_fits(g, 2) ? force : 0;            // timing ablations of tile 2
   if (force == 32 || force == 35 || force == 36) return tile_fits(g, force - 30) ? force : 0;   // hand-pipelined variants of tiles 2, 5, 6
   if (force == 42 || force == 45) return tile_fits(g, force - 40) ? force : 0;                  // ... with the interleaved schedule
+  if (force == 55) return tile_fits(g, 5) ? force : 0;                                          // ... and three LDS slots
   if (force > 10) return (g.K % 32 == 0 && tile_fits(g, force - 10)) ? force : 0;   // ring variants of tiles 2, 3, 5
   if (force > 0) return tile_fits(g, force) ? force : 0;
   // Measured policy (tools/bench_gemm.py, DiT-XL/2 B=32 shapes, random data):
   //   both operands k-contiguous (forward)   -> 256x192 k_gemm_pipe, interleaved schedule (800-980 TF; k_gemm_fast 760-950)
   //   B transposed-read (dgrad)              -> 256x192 k_gemm_pipe, interleaved schedule (735-1040 TF; plain schedule 630-885)
-  //   both transposed-read (wgrad)           -> 192x192 k_gemm_pipe, interleaved schedule (5.5 TF per CU; plain 4.2, generic 3.65)
+  //   both transposed-read (wgrad)           -> 192x192 k_gemm_pipe, interleaved schedule, THREE LDS slots: two tiles
+  //                                             (96 KB) in flight per CU hide the HBM latency of operands that are not
+  //                                             in the 256 MB Infinity Cache -- saved activations, as in the real step:
+  //                                             fc1 93 us hot / 113 us cold, against 104 / 155 us with two slots
+  //                                             (tools/bench_cold.py, tools/bench_cold2.py)
   // a tile is used when it fills at least half of the last round of 256 CUs (wgrad runs beside the dgrad chain
   // on a side stream, so its own tile count does not have to fill the chip).
   auto eff = [&](int t) {
@@ -1231,7 +1254,7 @@ inline int pick_fast_tile(const GemmArgs& g, int force, int transposed_operands)
     return (double)tiles / (double)(((tiles + 255) / 256) * 256);
   };
   const bool even_nk = g.K % 128 == 0;       // the interleaved schedule's requirement
-  if (transposed_operands == 2) return tile_fits(g, 5) ? 45 : 0;
+  if (transposed_operands == 2) return tile_fits(g, 5) ? 55 : 0;
   if (tile_fits(g, 2) && eff(2) >= 0.5) return (transposed_operands == 1 || even_nk) ? 42 : 2;
   return (transposed_operands == 0 && tile_fits(g, 1)) ? 1 : 0;   // with transposed reads the generic kernel beats the 4-wave tile
 }
@@ -1258,6 +1281,12 @@ int launch_any(const GemmArgs& g, hipStream_t s, int force) {
                                                                   : launch_pipe<4, 2, 4, 6, A_TR, B_TR, EPI>(g, s);
     case 45: return (g.kchunk % 128 == 0 && g.K % g.kchunk == 0) ? launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI, 1>(g, s)
                                                                   : launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI>(g, s);
+    case 55:   // 192x192 with three LDS slots (weight-gradient layouts only): needs nk = 2 + 3j tiles per split
+      if constexpr (A_TR && B_TR && (EPI == EPI_BF16 || EPI == EPI_F32)) {
+        if (g.K % g.kchunk == 0 && (g.kchunk / 64) >= 2 && ((g.kchunk / 64) - 2) % 3 == 0) return launch_pipe<4, 2, 3, 6, true, true, EPI, 2>(g, s);
+      }
+      return (g.kchunk % 128 == 0 && g.K % g.kchunk == 0) ? launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI, 1>(g, s)
+                                                           : launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI>(g, s);
     case 12: return launch_ring<4, 2, 4, 6, A_TR, B_TR, EPI, 5>(g, s);
     case 13: return launch_ring<2, 4, 8, 4, A_TR, B_TR, EPI, 4>(g, s);
     case 15: return launch_ring<4, 2, 3, 6, A_TR, B_TR, EPI, 6>(g, s);
