@@ -85,6 +85,24 @@ int sfron_dit_loss_fwd_bwd(const float* x0, const float* noise, const float* mod
                            const float* tab, int n, int c, int hw, float grad_scale, float* mse, float* vb,
                            float* d_model_out, void* stream);
 
+/* ---- DDPM (CIFAR-10) epsilon loss: DDPM/functions/losses.py:22-38 (sum over C,H,W, mean over the batch), :49-69 (adaptive
+ * "adaga" weights), :32 (alphas_cumprod recomputed from fp32 betas). */
+/* abar[t] = prod_{s<=t} (1 - betas[s]), running product in double, rounded to fp32 per entry (= torch CPU cumprod) */
+int sfron_ddpm_alphas_cumprod(const float* betas, int T, float* abar, void* stream);
+/* x_t = x0 * sqrt(abar[t]) + e * sqrt(1 - abar[t])   (correctly rounded sqrt; losses.py:33-34) */
+int sfron_ddpm_q_sample(const float* x0, const float* e, const int64_t* t, const float* abar, int n, int chw, float* x_t,
+                        void* stream);
+/* per_sample[i] = sum_{chw} (e - model_out)^2         (losses.py:36-38 with keepdim=True) */
+int sfron_ddpm_sample_loss(const float* e, const float* model_out, int n, int chw, float* per_sample, void* stream);
+/* mode 0 "simple": loss = sum_local(per)/n_global, coef_i = 2*scale/n_global.
+ * mode 1 "adaga":  w_i = 1/(per_i^lambd + 1e-8); W = sum_i w_i, written to *wsum (use_wsum = 0) or taken from *wsum
+ *                  (use_wsum = 1: the caller all-reduced it over the data-parallel ranks); loss = sum_local(w_i per_i)/W,
+ *                  coef_i = 2*scale*w_i/W.     d(scale*loss)/d model_out_i = coef_i * (model_out_i - e_i) */
+int sfron_ddpm_loss_coef(const float* per_sample, int n, int mode, float lambd, float scale, int n_global, float* wsum,
+                         int use_wsum, float* coef, float* loss, void* stream);
+int sfron_ddpm_loss_bwd(const float* e, const float* model_out, const float* coef, int n, int chw, float* d_model_out,
+                        void* stream);
+
 /* ------------------------------------------------------------------ bf16 MFMA GEMM (gemm.hip)
  * C[M,N] = alpha * op(A)[M,K] · op(B)[K,N] (+ bias[N]) with a fused epilogue; fp32 accumulation.
  *   a_transposed = 0: A is [M][K] row-major (lda), contraction contiguous      (activations, forward / dgrad)

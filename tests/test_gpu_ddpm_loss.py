@@ -1,0 +1,87 @@
+"""GPU parity: DDPM epsilon loss (sum over pixels), adaptive "adaga" weights and cosine alpha through the C ABI vs the
+oracle's restatement of DDPM/functions/losses.py (itself pinned against the imported reference in tests/golden)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_alphas_cumprod_and_q_sample_bit_exact():
+    from sfron import ddpm
+    from oracle import sfron_ref
+    b = sfron_ref.ddpm_get_betas()
+    a_ref = sfron_ref.ddpm_alphas_cumprod_fp32(b)
+    bd = ddpm.get_beta_schedule(device=DEV)
+    assert torch.equal(bd.cpu(), b)
+    a = ddpm.alphas_cumprod(bd)
+    assert torch.equal(a.cpu(), a_ref)
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.rand(6, 3, 32, 32, generator=g) * 2 - 1
+    e = torch.randn(6, 3, 32, 32, generator=g)
+    t = torch.tensor([0, 999, 1, 500, 37, 998])
+    ar = a_ref.index_select(0, t).view(-1, 1, 1, 1)
+    got = ddpm.q_sample(x0.to(DEV), e.to(DEV), t.to(DEV), a).cpu()
+    # torch's vectorised CPU fp32 sqrt is 1 ulp off for some of these values (0.006352818571 vs the exact 0.006352818105),
+    # the kernel's sqrt is correctly rounded: bit-exact against the correctly rounded form, 1-ulp close to the oracle's
+    exact = x0 * ar.double().sqrt().float() + e * (1.0 - ar).double().sqrt().float()
+    assert torch.equal(got, exact)
+    np.testing.assert_allclose(got.numpy(), (x0 * ar.sqrt() + e * (1.0 - ar).sqrt()).numpy(), rtol=3e-7, atol=3e-7)
+
+
+@pytest.mark.parametrize("kind", ["simple", "ga", "adaga"])
+def test_ddpm_loss_and_grad_match_oracle(kind):
+    from sfron import ddpm
+    from oracle import sfron_ref
+    g = torch.Generator().manual_seed(11)
+    N = 8
+    x0 = torch.rand(N, 3, 32, 32, generator=g) * 2 - 1
+    e = torch.randn(N, 3, 32, 32, generator=g)
+    t = torch.randint(0, 1000, (N,), generator=g)
+    c = torch.randint(0, 10, (N,), generator=g)
+    W = torch.randn(3, 3, generator=g) * 0.3                       # stub denoiser: a 1x1 channel mix of x_t (+ t, c ignored)
+    b = sfron_ref.ddpm_get_betas()
+    alpha = ddpm.cosine_lr_scheduler(10.0, 3, 50)
+    assert alpha == pytest.approx(sfron_ref.cosine_alpha(10.0, 3, 50))
+
+    def run(Wp, dev, loss_mod):
+        seen = {}
+
+        def model(x, tf, cc, cond_drop_prob=0.1, mode="train"):
+            seen["t"] = tf
+            return torch.einsum("oc,nchw->nohw", Wp, x)
+        if loss_mod is ddpm:
+            args = (x0.to(dev), t.to(dev), c.to(dev), e.to(dev), ddpm.get_beta_schedule(device=dev))
+            if kind == "simple":
+                loss = ddpm.loss_registry_conditional["simple"](model, *args)
+            elif kind == "ga":
+                loss = -ddpm.loss_registry_conditional["simple"](model, *args)
+            else:
+                loss = -ddpm.adaptive_loss(ddpm.loss_registry_conditional["simple"], model, *args, lambd=0.5)
+        else:
+            per = sfron_ref.ddpm_loss_per_sample(lambda x, tf: model(x, tf, c), x0, t, e, b)
+            loss = per.mean(0) if kind == "simple" else -per.mean(0) if kind == "ga" else -sfron_ref.ddpm_adaptive_loss(per, 0.5)
+        (alpha * loss).backward()
+        assert seen["t"].dtype == torch.float32
+        return loss.detach().cpu(), Wp.grad.detach().cpu()
+
+    Wc = W.clone().requires_grad_(True)
+    Wg = W.clone().to(DEV).requires_grad_(True)
+    l_ref, g_ref = run(Wc, "cpu", None)
+    l_got, g_got = run(Wg, DEV, ddpm)
+    np.testing.assert_allclose(l_got.numpy(), l_ref.numpy(), rtol=2e-6)
+    np.testing.assert_allclose(g_got.numpy(), g_ref.numpy(), rtol=2e-5, atol=1e-4)
+
+
+def test_ddpm_per_sample_keepdim():
+    from sfron import ddpm
+    from oracle import sfron_ref
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.rand(4, 3, 8, 8, generator=g) * 2 - 1
+    e = torch.randn(4, 3, 8, 8, generator=g)
+    t = torch.tensor([3, 400, 999, 0])
+    model = lambda x, tf, cc, cond_drop_prob=0.1, mode="train": 0.5 * x
+    per = ddpm.noise_estimation_loss_conditional(model, x0.to(DEV), t.to(DEV), None, e.to(DEV), ddpm.get_beta_schedule(device=DEV), keepdim=True)
+    want = sfron_ref.ddpm_loss_per_sample(lambda x, tf: 0.5 * x, x0, t, e, sfron_ref.ddpm_get_betas())
+    np.testing.assert_allclose(per.cpu().numpy(), want.numpy(), rtol=2e-6)

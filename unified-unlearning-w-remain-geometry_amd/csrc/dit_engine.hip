@@ -187,6 +187,13 @@ int64_t sfron_dit_workspace_bytes(const sfron_dit_cfg* cfg) {
   return (int64_t)make_ws(d, nullptr).bytes;
 }
 
+// SFRON_ABLATE (debug / A-B measurement only): bit 0 = run LN backward and gate backward as separate kernels,
+// bit 1 = no split-K in the block weight gradients, bit 2 = side stream at the lowest priority
+static int ablate_mask() {
+  static const int m = [] { const char* e = getenv("SFRON_ABLATE"); return e ? atoi(e) : 0; }();
+  return m;
+}
+
 // ---- aux: a side stream + events so the weight-gradient GEMMs (which nothing downstream in the backward chain
 // depends on) run concurrently with the dgrad / elementwise chain and fill the CUs its tile counts leave idle
 struct Aux { hipStream_t side; hipEvent_t produced[4], consumed[8], done; };
@@ -195,7 +202,11 @@ int sfron_aux_create(void** aux) {
   SFRON_CHECK_ARG(aux);
   Aux* a = new Aux{};
   // equal priority with the caller's stream measured best (89.8 ms/step; lowest priority 92.8, highest 95.1)
-  if (hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking) != hipSuccess) return (int)hipGetLastError();
+  if (ablate_mask() & 4) {       // A-B knob: side stream at the lowest priority
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&a->side, hipStreamNonBlocking, lo) != hipSuccess) return (int)hipGetLastError();
+  } else if (hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking) != hipSuccess) return (int)hipGetLastError();
   for (int i = 0; i < 4; ++i)
     if (hipEventCreateWithFlags(&a->produced[i], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
   for (int i = 0; i < 8; ++i)
@@ -336,13 +347,6 @@ int sfron_dit_forward_probed(const sfron_dit_cfg* cfg, const float* params, cons
   RUN(sfron_gemm_bf16(&g, stream));
   RUN(sfron_unpatchify(w.tok, d.Po, d.B, d.Co, d.S, d.S, d.p, out, stream));
   return SFRON_OK;
-}
-
-// SFRON_ABLATE (debug / A-B measurement only): bit 0 = run LN backward and gate backward as separate kernels,
-// bit 1 = no split-K in the block weight gradients
-static int ablate_mask() {
-  static const int m = [] { const char* e = getenv("SFRON_ABLATE"); return e ? atoi(e) : 0; }();
-  return m;
 }
 
 int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* d_out,

@@ -124,6 +124,87 @@ __global__ __launch_bounds__(TPB) void k_dit_loss(const float* __restrict__ x0, 
   }
 }
 
+
+// ---------------------------------------------------------------- DDPM (CIFAR-10) epsilon loss
+// Replaces /root/reference/DDPM/functions/losses.py:
+//   noise_estimation_loss_conditional :22-38  a = (1-b).cumprod(0)[t]; x = x0*sqrt(a) + e*sqrt(1-a);
+//                                             loss_i = sum_{chw} (e - model(x, t, c))^2   (a SUM over pixels)
+//   adaptive_loss :49-69                      w_i = 1/(loss_i^lambd + 1e-8) (detached); mean_i(w_i/sum(w) * loss_i * N)
+// alphas_cumprod follows torch's CPU cumprod: the running product is kept in double and rounded to fp32 per entry
+// (bit-exact with the oracle; the reference's device scan may differ in the last ulp).
+__global__ void k_ddpm_abar(const float* __restrict__ betas, int T, float* __restrict__ abar) {
+  if (threadIdx.x || blockIdx.x) return;
+  double a = 1.0;
+  for (int t = 0; t < T; ++t) { a *= (double)(1.0f - betas[t]); abar[t] = (float)a; }
+}
+
+__global__ __launch_bounds__(TPB) void k_ddpm_q_sample(const float* __restrict__ x0, const float* __restrict__ e,
+                                                       const int64_t* __restrict__ t, const float* __restrict__ abar,
+                                                       int chw, float* __restrict__ xt) {
+  const int n = blockIdx.y;
+  const float a = abar[t[n]];
+  // sqrt in double, rounded to fp32: equals the correctly rounded fp32 sqrt (53 >= 2*24 + 2 bits)
+  const float sa = (float)sqrt((double)a), sb = (float)sqrt((double)(1.0f - a));
+  const size_t base = (size_t)n * chw;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < chw; i += gridDim.x * TPB) xt[base + i] = x0[base + i] * sa + e[base + i] * sb;
+}
+
+// one workgroup per sample: per[n] = sum_{chw} (e - out)^2
+__global__ __launch_bounds__(TPB) void k_ddpm_sample_loss(const float* __restrict__ e, const float* __restrict__ out, int chw,
+                                                          float* __restrict__ per) {
+  __shared__ double sh[TPB / 64];
+  const size_t base = (size_t)blockIdx.x * chw;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < chw; i += TPB) { const float d = e[base + i] - out[base + i]; acc += d * d; }
+  const double w = wave_sum_d((double)acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0;
+    for (int i = 0; i < TPB / 64; ++i) s += sh[i];
+    per[blockIdx.x] = (float)s;
+  }
+}
+
+// single workgroup.  mode 0 ("simple", :38): loss = sum_local(per)/n_global, coef_i = 2*scale/n_global.
+// mode 1 (adaga): w_i = 1/(per_i^lambd + 1e-8); W = sum w (local, or *wsum when use_wsum: the all-reduced global sum);
+//                 loss = sum_local(w_i*per_i)/W, coef_i = 2*scale*w_i/W.      d loss / d out_i = coef_i * (out_i - e_i)
+__global__ __launch_bounds__(TPB) void k_ddpm_loss_coef(const float* __restrict__ per, int n, int mode, float lambd, float scale,
+                                                        int n_global, float* __restrict__ wsum, int use_wsum,
+                                                        float* __restrict__ coef, float* __restrict__ loss) {
+  __shared__ double sh[2][TPB / 64];
+  double sw = 0, swl = 0;
+  for (int i = threadIdx.x; i < n; i += TPB) {
+    const float l = per[i];
+    const float w = mode == 1 ? 1.0f / (powf(l, lambd) + 1e-8f) : 1.0f;
+    coef[i] = w;
+    sw += (double)w; swl += (double)w * (double)l;
+  }
+  sw = wave_sum_d(sw); swl = wave_sum_d(swl);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = sw; sh[1][threadIdx.x >> 6] = swl; }
+  __syncthreads();
+  double W = 0, WL = 0;
+  for (int i = 0; i < TPB / 64; ++i) { W += sh[0][i]; WL += sh[1][i]; }
+  if (mode == 1) {
+    if (use_wsum) W = (double)*wsum;
+    else if (threadIdx.x == 0) *wsum = (float)W;
+  } else {
+    W = (double)n_global;
+  }
+  __syncthreads();
+  const float fW = (float)W;
+  for (int i = threadIdx.x; i < n; i += TPB) coef[i] = 2.0f * scale * (coef[i] / fW);
+  if (threadIdx.x == 0) *loss = (float)(WL / W);
+}
+
+__global__ __launch_bounds__(TPB) void k_ddpm_loss_bwd(const float* __restrict__ e, const float* __restrict__ out,
+                                                       const float* __restrict__ coef, int chw, float* __restrict__ dout) {
+  const int n = blockIdx.y;
+  const float c = coef[n];
+  const size_t base = (size_t)n * chw;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < chw; i += gridDim.x * TPB) dout[base + i] = c * (out[base + i] - e[base + i]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -144,6 +225,50 @@ int sfron_dit_loss_fwd_bwd(const float* x0, const float* noise, const float* mod
   SFRON_CHECK_ARG(x0 && noise && model_out && t && tab && mse && vb && d_model_out && n > 0 && c > 0 && hw > 0);
   hipLaunchKernelGGL(k_dit_loss, dim3(n), dim3(TPB), 0, (hipStream_t)stream, x0, noise, model_out, t, tab, c, hw,
                      grad_scale, mse, vb, d_model_out);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_ddpm_alphas_cumprod(const float* betas, int T, float* abar, void* stream) {
+  SFRON_CHECK_ARG(betas && abar && T > 0);
+  hipLaunchKernelGGL(k_ddpm_abar, dim3(1), dim3(64), 0, (hipStream_t)stream, betas, T, abar);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_ddpm_q_sample(const float* x0, const float* e, const int64_t* t, const float* abar, int n, int chw, float* x_t,
+                        void* stream) {
+  SFRON_CHECK_ARG(x0 && e && t && abar && x_t && n > 0 && chw > 0);
+  int gx = cdiv(chw, TPB);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(k_ddpm_q_sample, dim3(gx, n), dim3(TPB), 0, (hipStream_t)stream, x0, e, t, abar, chw, x_t);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_ddpm_sample_loss(const float* e, const float* model_out, int n, int chw, float* per_sample, void* stream) {
+  SFRON_CHECK_ARG(e && model_out && per_sample && n > 0 && chw > 0);
+  hipLaunchKernelGGL(k_ddpm_sample_loss, dim3(n), dim3(TPB), 0, (hipStream_t)stream, e, model_out, chw, per_sample);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_ddpm_loss_coef(const float* per_sample, int n, int mode, float lambd, float scale, int n_global, float* wsum,
+                         int use_wsum, float* coef, float* loss, void* stream) {
+  SFRON_CHECK_ARG(per_sample && coef && loss && n > 0 && n_global >= n && (mode == 0 || mode == 1));
+  SFRON_CHECK_ARG(mode == 0 || wsum);
+  hipLaunchKernelGGL(k_ddpm_loss_coef, dim3(1), dim3(TPB), 0, (hipStream_t)stream, per_sample, n, mode, lambd, scale, n_global,
+                     wsum, use_wsum, coef, loss);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_ddpm_loss_bwd(const float* e, const float* model_out, const float* coef, int n, int chw, float* d_model_out,
+                        void* stream) {
+  SFRON_CHECK_ARG(e && model_out && coef && d_model_out && n > 0 && chw > 0);
+  int gx = cdiv(chw, TPB);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(k_ddpm_loss_bwd, dim3(gx, n), dim3(TPB), 0, (hipStream_t)stream, e, model_out, coef, chw, d_model_out);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

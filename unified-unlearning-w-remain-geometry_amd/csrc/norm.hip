@@ -100,7 +100,10 @@ struct RowBwdArgs {
 template <bool LN, bool GATE>
 __global__ __launch_bounds__(TPB) void k_row_bwd(const RowBwdArgs a) {
   constexpr int NACC = (LN ? 2 : 0) + (GATE ? 2 : 0);
-  __shared__ float4 sh[4][64 * NCH];
+  // 12 KB of LDS, so that a workgroup still fits on a CU next to a weight-gradient GEMM workgroup (3 x 48 KB slots):
+  // these kernels run beside the side stream's GEMMs and are memory-bound, extra resident waves are what they need
+  constexpr int HALF = 3;                          // chunks 0..2 (192 float4 per wave) then chunks 3..4
+  __shared__ float4 sh[4][64 * HALF];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D = a.D, D4 = D >> 2;
   const int wchunk = blockIdx.x * 4 + wave;      // the rpw consecutive rows of this wave
@@ -189,15 +192,20 @@ __global__ __launch_bounds__(TPB) void k_row_bwd(const RowBwdArgs a) {
   }
 #pragma unroll
   for (int k = 0; k < NACC; ++k) {
-    if (k) __syncthreads();
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) sh[wave][lane + 64 * i] = acc[k][i];
-    __syncthreads();
-    for (int c = threadIdx.x; c < D4; c += TPB) {
-      const float4 p0 = sh[0][c], p1 = sh[1][c], p2 = sh[2][c], p3 = sh[3][c];
-      reinterpret_cast<float4*>(dst[k] + (size_t)blockIdx.x * D)[c] =
-          make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z,
-                      ((p0.w + p1.w) + p2.w) + p3.w);
+    for (int h = 0; h < 2; ++h) {                  // two passes through the 12 KB buffer
+      constexpr int I0[2] = {0, HALF}, I1[2] = {HALF, NCH};
+      if (k || h) __syncthreads();
+#pragma unroll
+      for (int i = I0[h]; i < I1[h]; ++i) sh[wave][lane + 64 * (i - I0[h])] = acc[k][i];
+      __syncthreads();
+      const int c0 = 64 * I0[h], c1 = min(D4, 64 * I1[h]);
+      for (int c = c0 + threadIdx.x; c < c1; c += TPB) {
+        const float4 p0 = sh[0][c - c0], p1 = sh[1][c - c0], p2 = sh[2][c - c0], p3 = sh[3][c - c0];
+        reinterpret_cast<float4*>(dst[k] + (size_t)blockIdx.x * D)[c] =
+            make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z,
+                        ((p0.w + p1.w) + p2.w) + p3.w);
+      }
     }
   }
 }
