@@ -85,6 +85,15 @@ int sfron_dit_loss_fwd_bwd(const float* x0, const float* noise, const float* mod
                            const float* tab, int n, int c, int hw, float grad_scale, float* mse, float* vb,
                            float* d_model_out, void* stream);
 
+/* One ancestral sampling step, gaussian_diffusion.py:376-421 over :254-332 (LEARNED_RANGE variance, EPSILON mean):
+ * sample = posterior_mean(pred_x0, x) + (t != 0) * exp(0.5 * log_var) * noise; pred_xstart may be NULL.  t indexes `tab`
+ * (the respaced schedule); model_out [n][2c][hw] was evaluated by the caller at the mapped original timestep. */
+int sfron_p_sample(const float* x, const float* model_out, const int64_t* t, const float* tab, const float* noise, int n, int c,
+                   int hw, int clip_denoised, float* sample, float* pred_xstart, void* stream);
+/* classifier-free guidance mix of DiT.forward_with_cfg (DiT/models.py:258-266), in place on model_out [n_total][cout][hw]:
+ * for the first n_guided channels, rows i and i + n_total/2 both become uncond + cfg_scale * (cond - uncond). */
+int sfron_cfg_combine(float* model_out, int n_total, int cout, int hw, int n_guided, float cfg_scale, void* stream);
+
 /* ---- DDPM (CIFAR-10) epsilon loss: DDPM/functions/losses.py:22-38 (sum over C,H,W, mean over the batch), :49-69 (adaptive
  * "adaga" weights), :32 (alphas_cumprod recomputed from fp32 betas). */
 /* abar[t] = prod_{s<=t} (1 - betas[s]), running product in double, rounded to fp32 per entry (= torch CPU cumprod) */

@@ -9,6 +9,9 @@ Follows /root/reference/DiT/diffusion:
   * vb term ........... gaussian_diffusion.py:232-252,285-293,334-339,682-713
   * normal_kl / cdf ... diffusion_utils.py:10-44,62-88
   * training_losses ... gaussian_diffusion.py:715-787 (MSE + LEARNED_RANGE branch)
+  * sampling .......... respace.py:12-62 (space_timesteps), :65-129 (SpacedDiffusion tables, timestep map, wrapped
+                        model), gaussian_diffusion.py:254-332 (p_mean_variance, LEARNED_RANGE / EPSILON),
+                        :376-421 (p_sample), :423-511 (p_sample_loop)
 
 Plain PyTorch fp32 on CPU; no reference code is imported here.
 """
@@ -18,21 +21,49 @@ import numpy as np
 import torch as th
 
 
-class DiffusionTables:
-    """fp64 numpy tables exactly as create_diffusion("") builds them."""
+def space_timesteps(num_timesteps, section_counts):
+    """respace.py:12-62: the retained original timesteps, as a sorted list."""
+    if isinstance(section_counts, str):
+        if section_counts.startswith("ddim"):
+            want = int(section_counts[4:])
+            for stride in range(1, num_timesteps):
+                if len(range(0, num_timesteps, stride)) == want:
+                    return sorted(range(0, num_timesteps, stride))
+            raise ValueError(f"cannot create exactly {num_timesteps} steps with an integer stride")
+        section_counts = [int(x) for x in section_counts.split(",")]
+    size_per, extra = divmod(num_timesteps, len(section_counts))
+    start, steps = 0, []
+    for i, count in enumerate(section_counts):
+        size = size_per + (1 if i < extra else 0)
+        if size < count:
+            raise ValueError(f"cannot divide section of {size} steps into {count}")
+        stride = 1 if count <= 1 else (size - 1) / (count - 1)
+        cur = 0.0
+        for _ in range(count):
+            steps.append(start + round(cur))
+            cur += stride
+        start += size
+    return sorted(set(steps))
 
-    def __init__(self, num_timesteps=1000):
+
+class DiffusionTables:
+    """fp64 numpy tables exactly as create_diffusion(timestep_respacing) builds them ("" = all steps kept)."""
+
+    def __init__(self, num_timesteps=1000, timestep_respacing=""):
         # gaussian_diffusion.py:98-115 : linear schedule, scale = 1000/T
         scale = 1000 / num_timesteps
         base_betas = np.linspace(scale * 0.0001, scale * 0.02, num_timesteps, dtype=np.float64)
         # respace.py:70-87 : SpacedDiffusion recomputes betas from the cumprod even
         # when every step is kept (not bit-identical to base_betas in fp64).
         base_ac = np.cumprod(1.0 - base_betas, axis=0)
+        use = set(range(num_timesteps)) if timestep_respacing in ("", None) else set(space_timesteps(num_timesteps, timestep_respacing))
         last = 1.0
-        new_betas = []
-        for ac in base_ac:
-            new_betas.append(1 - ac / last)
-            last = ac
+        new_betas, self.timestep_map = [], []
+        for i, ac in enumerate(base_ac):
+            if i in use:
+                new_betas.append(1 - ac / last)
+                last = ac
+                self.timestep_map.append(i)
         betas = np.array(new_betas, dtype=np.float64)
         self.set_betas(betas)
 
@@ -149,3 +180,41 @@ def training_losses(tab, model, x_start, t, model_kwargs=None, noise=None):
     x_t = q_sample(tab, x_start, t, noise)
     model_output = model(x_t, t, **model_kwargs)
     return training_losses_from_output(tab, model_output, x_start, x_t, t, noise)
+
+
+# ----------------------------------------------------------------------------- sampling
+def p_mean_variance(tab, model, x, t, clip_denoised=True, model_kwargs=None):
+    """gaussian_diffusion.py:254-332 for LEARNED_RANGE / EPSILON; `model` sees ORIGINAL timesteps (respace.py:117-129)."""
+    B, C = x.shape[:2]
+    ts = th.tensor(tab.timestep_map, dtype=t.dtype)[t]
+    model_output = model(x, ts, **(model_kwargs or {}))
+    assert model_output.shape == (B, C * 2, *x.shape[2:])
+    eps, var_values = th.split(model_output, C, dim=1)
+    min_log = _extract(tab.posterior_log_variance_clipped, t, x.shape)
+    max_log = _extract(tab.log_betas, t, x.shape)
+    frac = (var_values + 1) / 2
+    log_variance = frac * max_log + (1 - frac) * min_log
+    pred_xstart = _extract(tab.sqrt_recip_alphas_cumprod, t, x.shape) * x - _extract(tab.sqrt_recipm1_alphas_cumprod, t, x.shape) * eps
+    if clip_denoised:
+        pred_xstart = pred_xstart.clamp(-1, 1)
+    mean = _extract(tab.posterior_mean_coef1, t, x.shape) * pred_xstart + _extract(tab.posterior_mean_coef2, t, x.shape) * x
+    return {"mean": mean, "log_variance": log_variance, "pred_xstart": pred_xstart}
+
+
+def p_sample(tab, model, x, t, clip_denoised=True, model_kwargs=None, noise=None):
+    """gaussian_diffusion.py:376-421 (cond_fn None); noise defaults to th.randn_like(x), the reference's draw."""
+    out = p_mean_variance(tab, model, x, t, clip_denoised, model_kwargs)
+    if noise is None:
+        noise = th.randn_like(x)
+    nonzero = (t != 0).float().view(-1, *([1] * (x.dim() - 1)))
+    return {"sample": out["mean"] + nonzero * th.exp(0.5 * out["log_variance"]) * noise, "pred_xstart": out["pred_xstart"]}
+
+
+def p_sample_loop(tab, model, shape, noise=None, clip_denoised=True, model_kwargs=None, step_noise=None):
+    """gaussian_diffusion.py:423-511.  step_noise[k] (optional) replaces the k-th randn_like draw (k = 0 at t = T-1)."""
+    img = noise if noise is not None else th.randn(*shape)
+    with th.no_grad():
+        for k, i in enumerate(reversed(range(tab.num_timesteps))):
+            t = th.tensor([i] * shape[0])
+            img = p_sample(tab, model, img, t, clip_denoised, model_kwargs, None if step_noise is None else step_noise[k])["sample"]
+    return img

@@ -221,6 +221,16 @@ class DiT(nn.Module):
         x = self.final_layer(x, c)
         return self.unpatchify(x)
 
+    def forward_with_cfg(self, x, t, y, cfg_scale):
+        # DiT/models.py:250-266: guidance on the first THREE channels only (the reference's "exact reproducibility" choice)
+        half = x[: len(x) // 2]
+        out = self.forward(torch.cat([half, half], dim=0), t, y)
+        eps, rest = out[:, :3], out[:, 3:]
+        cond, uncond = torch.split(eps, len(eps) // 2, dim=0)
+        half_eps = uncond + cfg_scale * (cond - uncond)
+        return torch.cat([torch.cat([half_eps, half_eps], dim=0), rest], dim=1)
+
+
 
 def randomize_zero_init(model, std=0.02, seed=0):
     """a freshly built DiT has all-zero adaLN / final weights, so only

@@ -370,6 +370,57 @@ def gen_ddpm_model():
                         **{"grad::" + n: grads[n].numpy() for n in pick}, **inputs)
 
 
+def gen_sampling(ref_models, ref_diffusion):
+    """Sampling path: space_timesteps / respaced tables, p_sample_loop on a stub model (clip on and off), and
+    the DiT's forward_with_cfg driven through p_sample_loop as DiT/forget.py:114-145 does (clip_denoised=False, cfg 4.0)."""
+    from diffusion.respace import space_timesteps
+    out = {}
+    for name, (T, spec) in {"s250": (1000, "250"), "sddim25": (1000, "ddim25"), "s10": (1000, "10"), "ssec": (300, "10,15,20")}.items():
+        out["steps_" + name] = np.array(sorted(space_timesteps(T, spec)))
+    d = ref_diffusion.create_diffusion(timestep_respacing="10")
+    out["map10"] = np.array(d.timestep_map)
+    for k in ["betas", "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2", "sqrt_recip_alphas_cumprod",
+              "sqrt_recipm1_alphas_cumprod"]:
+        out["tab10_" + k] = getattr(d, k)
+    g = torch.Generator().manual_seed(31)
+    N, C, H = 4, 4, 8
+    z = torch.randn(N, C, H, H, generator=g)
+    A = torch.randn(2 * C, C, generator=g) * 0.4
+
+    def stub(x, ts, **kw):                       # sees ORIGINAL timesteps through the wrapped model
+        return torch.einsum("oc,nchw->nohw", A, x) * torch.cos(ts.float() / 300.0).view(-1, 1, 1, 1) + 0.05
+    out.update(z=z.numpy(), A=A.numpy())
+    for clip in (True, False):
+        torch.manual_seed(77)
+        out[f"stub_clip{int(clip)}"] = d.p_sample_loop(stub, z.shape, z, clip_denoised=clip, model_kwargs={}, device="cpu").numpy()
+    one = d.p_sample(stub, z, torch.tensor([0, 9, 3, 0]), clip_denoised=False, model_kwargs={})
+    torch.manual_seed(5)
+    one = d.p_sample(stub, z, torch.tensor([0, 9, 3, 0]), clip_denoised=False, model_kwargs={})
+    out["one_sample_seed5"] = one["sample"].numpy(); out["one_pred_xstart"] = one["pred_xstart"].numpy()
+    # the real model + classifier-free guidance, 5 steps
+    m = ref_models.DiT(**TINY)
+    m.load_state_dict(tiny_weights())
+    m.eval()
+    d5 = ref_diffusion.create_diffusion(timestep_respacing="5")
+    n = 3
+    zz = torch.randn(n, 4, 8, 8, generator=g)
+    y = torch.tensor([1, 9, 4])
+    zc, yc = torch.cat([zz, zz], 0), torch.cat([y, torch.tensor([10] * n)], 0)
+    noises = torch.randn(5, 2 * n, 4, 8, 8, generator=g)
+    it = iter(noises)
+    orig = torch.randn_like
+    torch.randn_like = lambda x, *a, **k: next(it)          # explicit per-step noise (same tensors are stored in the fixture)
+    try:
+        with torch.no_grad():
+            smp = d5.p_sample_loop(m.forward_with_cfg, zc.shape, zc, clip_denoised=False, model_kwargs=dict(y=yc, cfg_scale=4.0), device="cpu")
+            cfg_out = m.forward_with_cfg(zc, torch.tensor([999, 0, 500, 999, 0, 500]), yc, 4.0)
+    finally:
+        torch.randn_like = orig
+    out.update(cfg_z=zz.numpy(), cfg_y=y.numpy(), cfg_step_noise=noises.numpy(), cfg_samples=smp.numpy(), cfg_forward=cfg_out.numpy(),
+               map5=np.array(d5.timestep_map))
+    np.savez_compressed(os.path.join(HERE, "dit_sampling.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     ref_diffusion = import_ref_dit_diffusion()
@@ -380,4 +431,5 @@ if __name__ == "__main__":
     gen_ddpm()
     gen_mask()
     gen_ddpm_model()
+    gen_sampling(ref_models, ref_diffusion)
     print("golden vectors written to", HERE)

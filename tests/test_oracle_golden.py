@@ -204,3 +204,48 @@ def test_ddpm_sfron_trajectory_matches_reference(golden_dir):
         assert r["remain_loss"] == pytest.approx(float(g["traj_remain"][step]), rel=1e-4)
     np.testing.assert_allclose(m.conv_in.weight.detach().numpy(), g["final_conv_in"], rtol=0, atol=2e-5)
     np.testing.assert_allclose(orc.shadow["net.conv_out.weight"].numpy(), g["final_shadow_conv_out"], rtol=0, atol=2e-5)
+
+
+# ------------------------------------------------------------------ sampling path
+def test_sampling_restatement_matches_reference(golden_dir):
+    g = load(golden_dir, "dit_sampling.npz")
+    for name, (T, spec) in {"s250": (1000, "250"), "sddim25": (1000, "ddim25"), "s10": (1000, "10"), "ssec": (300, "10,15,20")}.items():
+        assert dref.space_timesteps(T, spec) == list(g["steps_" + name])
+    tab = dref.DiffusionTables(1000, "10")
+    assert tab.timestep_map == list(g["map10"])
+    for k in ["betas", "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2", "sqrt_recip_alphas_cumprod",
+              "sqrt_recipm1_alphas_cumprod"]:
+        np.testing.assert_array_equal(getattr(tab, k if k != "betas" else "betas"), g["tab10_" + k])
+    z, A = torch.from_numpy(g["z"]), torch.from_numpy(g["A"])
+    stub = lambda x, ts, **kw: torch.einsum("oc,nchw->nohw", A, x) * torch.cos(ts.float() / 300.0).view(-1, 1, 1, 1) + 0.05
+    for clip in (True, False):
+        torch.manual_seed(77)
+        got = dref.p_sample_loop(tab, stub, z.shape, z, clip_denoised=clip, model_kwargs={})
+        np.testing.assert_allclose(got.numpy(), g[f"stub_clip{int(clip)}"], rtol=1e-6, atol=1e-6)
+    torch.manual_seed(5)
+    one = dref.p_sample(tab, stub, z, torch.tensor([0, 9, 3, 0]), clip_denoised=False, model_kwargs={})
+    np.testing.assert_allclose(one["sample"].numpy(), g["one_sample_seed5"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(one["pred_xstart"].numpy(), g["one_pred_xstart"], rtol=1e-6, atol=1e-6)
+
+
+def test_forward_with_cfg_and_guided_sampling_match_reference(golden_dir):
+    g = load(golden_dir, "dit_sampling.npz")
+    gm = load(golden_dir, "dit_model.npz")
+    m = dit_ref.DiT(**TINY)
+    torch.manual_seed(1234)
+    m2 = dit_ref.DiT(**TINY)
+    dit_ref.randomize_zero_init(m2, std=0.05, seed=1235)
+    m.load_state_dict(m2.state_dict())
+    np.testing.assert_allclose([float(v.double().sum()) for v in m.state_dict().values()], gm["param_sums"], rtol=1e-12)
+    m.eval()
+    zz, y = torch.from_numpy(g["cfg_z"]), torch.from_numpy(g["cfg_y"])
+    n = zz.shape[0]
+    zc, yc = torch.cat([zz, zz], 0), torch.cat([y, torch.tensor([10] * n)], 0)
+    with torch.no_grad():
+        out = m.forward_with_cfg(zc, torch.tensor([999, 0, 500, 999, 0, 500]), yc, 4.0)
+    np.testing.assert_allclose(out.numpy(), g["cfg_forward"], rtol=1e-5, atol=1e-5)
+    tab = dref.DiffusionTables(1000, "5")
+    assert tab.timestep_map == list(g["map5"])
+    smp = dref.p_sample_loop(tab, m.forward_with_cfg, zc.shape, zc, clip_denoised=False, model_kwargs=dict(y=yc, cfg_scale=4.0),
+                                      step_noise=torch.from_numpy(g["cfg_step_noise"]))
+    np.testing.assert_allclose(smp.numpy(), g["cfg_samples"], rtol=1e-4, atol=1e-4)

@@ -125,6 +125,46 @@ __global__ __launch_bounds__(TPB) void k_dit_loss(const float* __restrict__ x0, 
 }
 
 
+// ---------------------------------------------------------------- ancestral sampling step + classifier-free guidance
+// p_sample (gaussian_diffusion.py:376-421) over p_mean_variance (:254-332) for the LEARNED_RANGE / EPSILON model:
+//   log_var = frac*log(beta_t) + (1-frac)*posterior_log_variance_clipped_t, frac = (v+1)/2
+//   pred_x0 = sqrt_recip_ac*x - sqrt_recipm1_ac*eps   (clamped to [-1,1] when clip_denoised)
+//   sample  = coef1*pred_x0 + coef2*x + (t != 0) * exp(0.5*log_var) * noise
+// t indexes the (possibly respaced) table; the model was evaluated at timestep_map[t] by the host.
+__global__ __launch_bounds__(TPB) void k_p_sample(const float* __restrict__ x, const float* __restrict__ out,
+                                                  const int64_t* __restrict__ t, const float* __restrict__ tab,
+                                                  const float* __restrict__ noise, int chw, int clip,
+                                                  float* __restrict__ sample, float* __restrict__ pred) {
+  const int n = blockIdx.y;
+  const float* row = tab + (size_t)t[n] * 8;
+  const float sra = row[2], srm1 = row[3], c1 = row[4], c2 = row[5], min_log = row[6], max_log = row[7];
+  const float nz = t[n] != 0 ? 1.0f : 0.0f;
+  const size_t xb = (size_t)n * chw, ob = (size_t)n * 2 * chw;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < chw; i += gridDim.x * TPB) {
+    const float xv = x[xb + i], eps = out[ob + i], v = out[ob + chw + i];
+    const float frac = (v + 1.0f) / 2.0f;
+    const float lv = frac * max_log + (1.0f - frac) * min_log;
+    float px = sra * xv - srm1 * eps;
+    if (clip) px = fminf(fmaxf(px, -1.0f), 1.0f);
+    const float mean = c1 * px + c2 * xv;
+    sample[xb + i] = mean + (nz * expf(0.5f * lv)) * noise[xb + i];
+    if (pred) pred[xb + i] = px;
+  }
+}
+
+// forward_with_cfg's guidance mix (DiT/models.py:258-266), in place on model_out [2*half][cout][hw]:
+// channels < n_guided of sample i and i+half both become uncond + s*(cond - uncond); the rest is untouched
+__global__ __launch_bounds__(TPB) void k_cfg_combine(float* __restrict__ out, int half, int cout, int hw, int n_guided, float s) {
+  const int n = blockIdx.y;
+  const size_t cb = (size_t)n * cout * hw, ub = (size_t)(n + half) * cout * hw;
+  const int tot = n_guided * hw;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < tot; i += gridDim.x * TPB) {
+    const float c = out[cb + i], u = out[ub + i];
+    const float h = u + s * (c - u);
+    out[cb + i] = h; out[ub + i] = h;
+  }
+}
+
 // ---------------------------------------------------------------- DDPM (CIFAR-10) epsilon loss
 // Replaces /root/reference/DDPM/functions/losses.py:
 //   noise_estimation_loss_conditional :22-38  a = (1-b).cumprod(0)[t]; x = x0*sqrt(a) + e*sqrt(1-a);
@@ -269,6 +309,28 @@ int sfron_ddpm_loss_bwd(const float* e, const float* model_out, const float* coe
   int gx = cdiv(chw, TPB);
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(k_ddpm_loss_bwd, dim3(gx, n), dim3(TPB), 0, (hipStream_t)stream, e, model_out, coef, chw, d_model_out);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_p_sample(const float* x, const float* model_out, const int64_t* t, const float* tab, const float* noise, int n, int c,
+                   int hw, int clip_denoised, float* sample, float* pred_xstart, void* stream) {
+  SFRON_CHECK_ARG(x && model_out && t && tab && noise && sample && n > 0 && c > 0 && hw > 0);
+  const int chw = c * hw;
+  int gx = cdiv(chw, TPB);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(k_p_sample, dim3(gx, n), dim3(TPB), 0, (hipStream_t)stream, x, model_out, t, tab, noise, chw, clip_denoised,
+                     sample, pred_xstart);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_cfg_combine(float* model_out, int n_total, int cout, int hw, int n_guided, float cfg_scale, void* stream) {
+  SFRON_CHECK_ARG(model_out && n_total > 0 && n_total % 2 == 0 && cout > 0 && hw > 0 && n_guided > 0 && n_guided <= cout);
+  int gx = cdiv(n_guided * hw, TPB);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(k_cfg_combine, dim3(gx, n_total / 2), dim3(TPB), 0, (hipStream_t)stream, model_out, n_total / 2, cout, hw,
+                     n_guided, cfg_scale);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

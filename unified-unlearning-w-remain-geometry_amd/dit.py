@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from ._lib import check, ptr, stream_ptr
 from .engine import DitEngine
 
 
@@ -143,15 +144,15 @@ class DiT(nn.Module):
         return self.engine.forward(x.contiguous(), t.contiguous(), y.contiguous(), drop)
 
     def forward_with_cfg(self, x, t, y, cfg_scale):
-        # models.py:250-266 (guidance on the first three channels, as the reference does)
+        # models.py:250-266 (guidance on the first three channels, as the reference does); the mix runs in place on the
+        # model output through sfron_cfg_combine
         half = x[: len(x) // 2]
         combined = torch.cat([half, half], dim=0)
-        model_out = self.forward(combined, t, y)
-        eps, rest = model_out[:, :3], model_out[:, 3:]
-        cond_eps, uncond_eps = torch.split(eps, len(eps) // 2, dim=0)
-        half_eps = uncond_eps + cfg_scale * (cond_eps - uncond_eps)
-        eps = torch.cat([half_eps, half_eps], dim=0)
-        return torch.cat([eps, rest], dim=1)
+        with torch.no_grad():
+            out = self.forward(combined, t, y).contiguous()
+            check(_lib.lib().sfron_cfg_combine(ptr(out), out.shape[0], out.shape[1], out[0, 0].numel(), 3, float(cfg_scale),
+                                               stream_ptr()), "cfg_combine")
+        return out
 
 
 def _cfg(depth, hidden_size, patch_size, num_heads):
