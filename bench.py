@@ -175,7 +175,7 @@ def main():
             "finite_losses": loss_ok,
             "step_tflops_per_gpu": step_flops / (ms_per_step * 1e-3) / 1e12,
             "step_frac_of_bf16_mfma_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-            "roofline": {"bound": "mfma", "kernel": "k_gemm_fast<4,2,4,6,false,false,2,0> = 256x192 tile, Mlp.fc1 + GELU-tanh, "
+            "roofline": {"bound": "mfma", "kernel": "k_gemm_pipe<4,2,4,6,false,false,2,1> = 256x192 tile, interleaved MFMA/LDS-DMA schedule, Mlp.fc1 + GELU-tanh, "
                          f"[{M}x{D}]x[{D}x{F}] (block 0 of every forward pass)", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                          "flops_per_launch": fc1_flops, "avg_launch_ms": avg_ms, "launches_timed": n_probe},

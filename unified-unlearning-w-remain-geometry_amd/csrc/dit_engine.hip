@@ -84,8 +84,7 @@ constexpr int SPLIT_K_ADA = 64;
 constexpr int CSUM_PARTS = 64;     // row chunks of the bias column sums (stage 2 reads CSUM_PARTS x N floats with N/256 workgroups)
 
 // Weight gradients dW[N][K] = dY[M][N]^T X[M][K] have few 192x192 output tiles and a long reduction (M = batch*tokens):
-// split the reduction so that one GEMM offers about 150-250 workgroups (the side stream it runs on is otherwise the
-// critical path of the backward pass).  1 = no split.
+// a split of the reduction offers about 150-250 workgroups per GEMM.  Kept as an option (see wgrad_side): 1 = no split.
 inline int wgrad_splits(int N, int K, int Mred) {
   if (N % 192 || K % 192 || Mred % 64) return 1;
   const int tiles = (N / 192) * (K / 192);
@@ -188,7 +187,7 @@ int64_t sfron_dit_workspace_bytes(const sfron_dit_cfg* cfg) {
 }
 
 // SFRON_ABLATE (debug / A-B measurement only): bit 0 = run LN backward and gate backward as separate kernels,
-// bit 1 = no split-K in the block weight gradients, bit 2 = side stream at the lowest priority
+// bit 1 = split-K in the block weight gradients (off by default), bit 2 = side stream at the lowest priority
 static int ablate_mask() {
   static const int m = [] { const char* e = getenv("SFRON_ABLATE"); return e ? atoi(e) : 0; }();
   return m;
@@ -374,7 +373,9 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
   // block weight gradient on the side stream, reduction split per wgrad_splits() into fp32 slabs + fixed-order sum
   auto wgrad_side = [&](const void* dY, const void* X, int N, int K, float* dW) -> int {
     sfron_gemm_desc q = wgrad_desc(dY, X, M, N, K, dW);
-    const int sp = (ablate_mask() & 2) ? 1 : wgrad_splits(N, K, M);
+    // measured: the splits shorten the side stream (proj 175 -> 60 us) but the backward pass is bound by total CU time, and
+    // the slab traffic + reductions make the step 0.5-2 ms SLOWER -> off unless SFRON_ABLATE bit 1 asks for the A-B run
+    const int sp = (ablate_mask() & 2) ? wgrad_splits(N, K, M) : 1;
     if (sp > 1) { q.c_f32 = w.wslab; q.split_k = sp; q.split_stride = (long)N * K; }
     RUN(sfron_gemm_bf16(&q, side));
     if (sp > 1) RUN(sfron_reduce_chunks(w.wslab, 1, sp, N * K, dW, N * K, 0, side));
