@@ -21,4 +21,9 @@ reference file:line it follows.  Pinning status:
 * Adam / clip_grad_norm_ / LayerNorm / GELU -- torch itself is the reference.
 * DDPM loss, adaptive loss, EMAHelper, mask arithmetic -- pinned by golden
   vectors from the imported reference.
+* DDPM Conditional_Model (ddpm_ref.py): state_dict keys, parameter count,
+  seeded forward (train / test), gradients and a 2-iteration SFR-on
+  trajectory -- pinned by golden vectors from the imported reference class.
+* sampling (space_timesteps, respaced tables, p_sample, p_sample_loop,
+  forward_with_cfg) -- pinned by golden vectors from the imported reference.
 """
