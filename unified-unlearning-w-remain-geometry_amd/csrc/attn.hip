@@ -288,31 +288,12 @@ __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv,
   }
 }
 
-// delta[b,h,q] = sum_d dO[q, h, d] * O[q, h, d]
-__global__ __launch_bounds__(NT) void k_attn_delta(const __bf16* __restrict__ o, const __bf16* __restrict__ d_o,
-                                                   float* __restrict__ delta, int B, int T, int H, int hd) {
-  const int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x;
-  if (idx >= (int64_t)B * T * H) return;
-  const int h = (int)(idx % H);
-  const int64_t row = idx / H;
-  const int b = (int)(row / T), q = (int)(row % T);
-  const __bf16* po = o + row * (size_t)(H * hd) + h * hd;
-  const __bf16* pd = d_o + row * (size_t)(H * hd) + h * hd;
-  float s = 0.f;
-  for (int d = 0; d < hd; d += 8) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(po + d);
-    const bf16x8 e = *reinterpret_cast<const bf16x8*>(pd + d);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s += bf2f(a[j]) * bf2f(e[j]);
-  }
-  delta[((size_t)b * H + h) * T + q] = s;
-}
-
 // ------------------------------------------------------------------------------------- dQ
 template <int HDP, int KS, int NDT, int QT>
-__global__ __launch_bounds__(NT) void k_attn_bwd_dq(const __bf16* __restrict__ qkv, const __bf16* __restrict__ d_o,
-                                                    const float* __restrict__ lse, const float* __restrict__ delta,
-                                                    __bf16* __restrict__ dqkv, int T, int H, int hd, float scale) {
+__global__ __launch_bounds__(NT) void k_attn_bwd_dq(const __bf16* __restrict__ qkv, const __bf16* __restrict__ o,
+                                                    const __bf16* __restrict__ d_o, const float* __restrict__ lse,
+                                                    float* __restrict__ delta, __bf16* __restrict__ dqkv, int T, int H, int hd,
+                                                    float scale) {
   extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
   Ring<HDP> ring{smem};
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
@@ -322,6 +303,7 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dq(const __bf16* __restrict__ q
   const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
   const __bf16* base = qkv + (size_t)b * T * ld + h * hd;
   const __bf16* dob = d_o + (size_t)b * T * D + h * hd;
+  const __bf16* ob = o + (size_t)b * T * D + h * hd;
   const float c = scale * LOG2E;
   const int nchunk = T / 64;
 
@@ -340,14 +322,22 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dq(const __bf16* __restrict__ q
   float nl[QT], dl[QT];
 #pragma unroll
   for (int qi = 0; qi < QT; ++qi) {
+    // delta[q] = sum_d dO[q,d] * O[q,d] of this wave's own rows, from the same fragment layout as dO: a lane holds
+    // 8 elements per k-step of row (lane & 15); the 4 lane groups of a row are summed with two shuffles.  Written out
+    // for the dK/dV kernel, which runs after this one on the same stream (the separate delta kernel is gone).
+    float dsum = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       fq[qi][ks] = frag_rows_global(base, ld, q0 + 16 * qi, ks, hd, lane);
       fdo[qi][ks] = frag_rows_global(dob, D, q0 + 16 * qi, ks, hd, lane);
+      const bf16x8 fo = frag_rows_global(ob, D, q0 + 16 * qi, ks, hd, lane);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dsum += bf2f(fdo[qi][ks][j]) * bf2f(fo[j]);
     }
     const int q = q0 + 16 * qi + (lane & 15);
     nl[qi] = -lse[(size_t)bh * T + q] * LOG2E;
-    dl[qi] = delta[(size_t)bh * T + q];
+    dl[qi] = group_sum(dsum);
+    if (lane < 16) delta[(size_t)bh * T + q] = dl[qi];
   }
   zero_pads<HDP>(smem, NSLOT * 2, hd, tid);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -566,8 +556,8 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dkv(const __bf16* __restrict__ 
 #define SFRON_INST_ATTN(HDP, KS, NDT)                                                                              \
   template __global__ void k_attn_fwd<HDP, KS, NDT, 1>(const __bf16*, __bf16*, float*, int, int, int, float);      \
   template __global__ void k_attn_fwd<HDP, KS, NDT, 2>(const __bf16*, __bf16*, float*, int, int, int, float);      \
-  template __global__ void k_attn_bwd_dq<HDP, KS, NDT, 1>(const __bf16*, const __bf16*, const float*, const float*, __bf16*, int, int, int, float); \
-  template __global__ void k_attn_bwd_dq<HDP, KS, NDT, 2>(const __bf16*, const __bf16*, const float*, const float*, __bf16*, int, int, int, float); \
+  template __global__ void k_attn_bwd_dq<HDP, KS, NDT, 1>(const __bf16*, const __bf16*, const __bf16*, const float*, float*, __bf16*, int, int, int, float); \
+  template __global__ void k_attn_bwd_dq<HDP, KS, NDT, 2>(const __bf16*, const __bf16*, const __bf16*, const float*, float*, __bf16*, int, int, int, float); \
   template __global__ void k_attn_bwd_dkv<HDP, KS, NDT, 1>(const __bf16*, const __bf16*, const float*, const float*, __bf16*, int, int, int, float);
 SFRON_INST_ATTN(64, 2, 4)
 SFRON_INST_ATTN(96, 3, 5)
@@ -599,14 +589,13 @@ int launch_fwd(const __bf16* qkv, __bf16* o, float* lse, int B, int T, int H, in
 template <int HDP, int KS, int NDT>
 int launch_bwd(const __bf16* qkv, const __bf16* o, const __bf16* d_o, const float* lse, float* delta, __bf16* dqkv, int B,
                int T, int H, int hd, float scale, hipStream_t s) {
-  hipLaunchKernelGGL(k_attn_delta, dim3(cdiv((long)B * T * H, NT)), dim3(NT), 0, s, o, d_o, delta, B, T, H, hd);
   const size_t lds = lds_bytes<HDP>(0), lds2 = lds_bytes<HDP>(2 * T);
   if (T % 128 == 0) {
     int rc = set_lds(&k_attn_bwd_dq<HDP, KS, NDT, 2>, lds); if (rc) return rc;
-    hipLaunchKernelGGL((k_attn_bwd_dq<HDP, KS, NDT, 2>), dim3(T / 128, B * H), dim3(NT), lds, s, qkv, d_o, lse, delta, dqkv, T, H, hd, scale);
+    hipLaunchKernelGGL((k_attn_bwd_dq<HDP, KS, NDT, 2>), dim3(T / 128, B * H), dim3(NT), lds, s, qkv, o, d_o, lse, delta, dqkv, T, H, hd, scale);
   } else {
     int rc = set_lds(&k_attn_bwd_dq<HDP, KS, NDT, 1>, lds); if (rc) return rc;
-    hipLaunchKernelGGL((k_attn_bwd_dq<HDP, KS, NDT, 1>), dim3(T / 64, B * H), dim3(NT), lds, s, qkv, d_o, lse, delta, dqkv, T, H, hd, scale);
+    hipLaunchKernelGGL((k_attn_bwd_dq<HDP, KS, NDT, 1>), dim3(T / 64, B * H), dim3(NT), lds, s, qkv, o, d_o, lse, delta, dqkv, T, H, hd, scale);
   }
   int rc = set_lds(&k_attn_bwd_dkv<HDP, KS, NDT, 1>, lds2); if (rc) return rc;
   hipLaunchKernelGGL((k_attn_bwd_dkv<HDP, KS, NDT, 1>), dim3(T / 64, B * H), dim3(NT), lds2, s, qkv, d_o, lse, delta, dqkv, T, H, hd, scale);
