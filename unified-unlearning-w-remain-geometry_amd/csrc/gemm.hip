@@ -31,6 +31,8 @@ struct GemmArgs {
   const float* resid;       // EPI_GATE_RES: Cf = resid + gate * result (resid may alias Cf)
   int kchunk;               // split-K: contraction range per split (multiple of BK); K if no split
   long split_stride;        // split-K: fp32 slab stride (elements) between splits
+  int nt_out;               // streaming (nontemporal) stores: bit 0 = the epilogue's saved-for-backward bf16 output (aux),
+                            // bit 1 = fp32 weight-gradient output
   int ntm, ntn;
   int group_m;              // fast path: tile-rows per group of the grouped tile order
 };
@@ -125,6 +127,13 @@ struct Stager {
 
 
 // ---- fused epilogue for 4 consecutive output columns (row, col..col+3) -----------------------------
+// streaming store for tensors that only the backward pass reads again (pre-activations, branch outputs): keeps them from
+// displacing the operands of the next kernels in L2 / Infinity Cache
+__device__ __forceinline__ void nt_store(bf16x4* p, bf16x4 v, int nt) {
+  if (nt) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int row, int col, f32x4 v) {
   v = v * g.alpha;
@@ -139,15 +148,16 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int row, int c
     float4* dst = reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col);
     float4 o = make_float4(v[0], v[1], v[2], v[3]);
     if (g.accumulate) { const float4 c = *dst; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
-    *dst = o;
+    if (g.nt_out & 2) __builtin_nontemporal_store(f32x4{o.x, o.y, o.z, o.w}, reinterpret_cast<f32x4*>(dst));
+    else *dst = o;
   } else if (EPI == EPI_GELU) {
     bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-    *reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col) = h;
+    nt_store(reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col), h, g.nt_out & 1);   // read again only by the backward pass
     bf16x4 o = {f2bf(gelu_tanh(v[0])), f2bf(gelu_tanh(v[1])), f2bf(gelu_tanh(v[2])), f2bf(gelu_tanh(v[3]))};
     *reinterpret_cast<bf16x4*>(g.Cb + (size_t)row * g.ldcb + col) = o;
   } else if (EPI == EPI_GATE_RES) {
     bf16x4 a = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-    *reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col) = a;
+    nt_store(reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col), a, g.nt_out & 1);
     const float4 gt = *reinterpret_cast<const float4*>(g.gate + (size_t)(row / g.T) * g.ldgate + col);
     float4 x = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldcf + col);
     x.x += gt.x * v[0]; x.y += gt.y * v[1]; x.z += gt.z * v[2]; x.w += gt.w * v[3];
@@ -520,7 +530,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_fast(GemmArgs g) {
         f32x4 v = acc[mt][nt] * g.alpha;
         if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
         bf16x4 a = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        *reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col) = a;
+        nt_store(reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col), a, g.nt_out & 1);
         const float4 gg = uniform_sample ? gt[nt] : *reinterpret_cast<const float4*>(g.gate + (size_t)(row / g.T) * g.ldgate + col);
         float4 x = xr[nt];
         x.x += gg.x * v[0]; x.y += gg.y * v[1]; x.z += gg.z * v[2]; x.w += gg.w * v[3];
@@ -758,7 +768,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_ring(GemmArgs g) {
         f32x4 v = acc[mt][nt] * g.alpha;
         if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
         bf16x4 a = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        *reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col) = a;
+        nt_store(reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col), a, g.nt_out & 1);
         float4 x = xr[nt];
         x.x += gt[nt].x * v[0]; x.y += gt[nt].y * v[1]; x.z += gt[nt].z * v[2]; x.w += gt[nt].w * v[3];
         *reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col) = x;
@@ -1140,7 +1150,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
         f32x4 v = acc[mt][nt] * g.alpha;
         if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
         bf16x4 a = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        *reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col) = a;
+        nt_store(reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col), a, g.nt_out & 1);
         float4 x = xr[nt];
         x.x += gt[nt].x * v[0]; x.y += gt[nt].y * v[1]; x.z += gt[nt].z * v[2]; x.w += gt[nt].w * v[3];
         *reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col) = x;
@@ -1323,11 +1333,10 @@ extern "C" int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
   g.alpha = d->alpha; g.accumulate = d->accumulate;
   g.resid = d->resid ? d->resid : d->c_f32;
   g.kchunk = d->K; g.split_stride = 0;
-  if (d->split_k > 1) {
-    SFRON_CHECK_ARG(d->epilogue == SFRON_EPI_F32 && !d->bias && !d->accumulate && d->split_stride >= (long)d->M * d->ldc_f32);
-    g.kchunk = cdiv(cdiv(d->K, d->split_k), BK) * BK;
-    g.split_stride = d->split_stride;
-  }
+  // SFRON_GEMM_NT (A-B knob, default 0): bit 0 = saved-for-backward epilogue outputs (pre-activation, branch output) are
+  // stored nontemporally, bit 1 = weight gradients too.  Same-box A-B runs: bit 0 +-0.3 ms/step (noise), bit 1 +0.3 ms: off.
+  static const int nt_mask = [] { const char* e = getenv("SFRON_GEMM_NT"); return e ? atoi(e) : 0; }();
+  g.nt_out = (nt_mask & 1) | ((nt_mask & 2) && d->a_transposed && d->b_transposed && d->split_k <= 1 && !d->accumulate ? 2 : 0);
   g.ntm = cdiv(d->M, BM); g.ntn = cdiv(d->N, BN);
   hipStream_t s = (hipStream_t)stream;
   const int force = d->tile_hint;   // 0 auto, -1 generic kernel, 1/2/3 force a fast tile (tests, tuning)
