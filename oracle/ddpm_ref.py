@@ -19,7 +19,7 @@ import torch.nn.functional as F
 def timestep_embedding(t, dim):
     half = dim // 2
     e = math.log(10000) / (half - 1)
-    e = torch.exp(torch.arange(half, dtype=torch.float32) * -e)
+    e = torch.exp(torch.arange(half, dtype=torch.float32, device=t.device) * -e)
     e = t.float()[:, None] * e[None, :]
     e = torch.cat([torch.sin(e), torch.cos(e)], dim=1)
     if dim % 2 == 1:
@@ -172,8 +172,9 @@ class ConditionalUNet(nn.Module):
         if p > 0:
             if keep_mask is None:          # prob_mask_like((b,), 1 - p)
                 q = 1 - p
-                keep_mask = (torch.ones(b, dtype=torch.bool) if q == 1 else torch.zeros(b, dtype=torch.bool) if q == 0
-                             else torch.zeros(b).float().uniform_(0, 1) < q)
+                dev = x.device
+                keep_mask = (torch.ones(b, dtype=torch.bool, device=dev) if q == 1 else torch.zeros(b, dtype=torch.bool, device=dev)
+                             if q == 0 else torch.zeros(b, device=dev).float().uniform_(0, 1) < q)
             cemb = torch.where(keep_mask[:, None], cemb, self.null_classes_emb[None, :].expand(b, -1))
         cemb = self.cemb.dense[1](swish(self.cemb.dense[0](cemb)))
         hs = [self.conv_in(x)]

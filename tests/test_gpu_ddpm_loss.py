@@ -85,3 +85,54 @@ def test_ddpm_per_sample_keepdim():
     per = ddpm.noise_estimation_loss_conditional(model, x0.to(DEV), t.to(DEV), None, e.to(DEV), ddpm.get_beta_schedule(device=DEV), keepdim=True)
     want = sfron_ref.ddpm_loss_per_sample(lambda x, tf: 0.5 * x, x0, t, e, sfron_ref.ddpm_get_betas())
     np.testing.assert_allclose(per.cpu().numpy(), want.numpy(), rtol=2e-6)
+
+
+def test_ddpm_sfron_iteration_native_loss_and_sweep_vs_oracle():
+    """DDPM/runners/diffusion.py:1075-1180 at reduced width: the oracle's U-Net (torch ops, stands for the caller's denoiser)
+    driven by the native loss + flat mask/clip/Adam/EMA sweep on the GPU, against DDPMSfronOracle on the CPU."""
+    from sfron import ddpm
+    from oracle import ddpm_ref, sfron_ref
+    cfg = dict(ch=128, out_ch=3, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(4,), dropout=0.0, in_channels=3,
+               resolution=8, resamp_with_conv=True, n_classes=10, cond_drop_prob=0.0)
+    torch.manual_seed(21)
+    ref_net = ddpm_ref.ConditionalUNet(**cfg)
+    gpu_net = ddpm_ref.ConditionalUNet(**cfg)
+    gpu_net.load_state_dict(ref_net.state_dict())
+    gpu_net.to(DEV)
+    gm = torch.Generator().manual_seed(8)
+    mask = {n: (torch.rand(p.shape, generator=gm) < 0.5) for n, p in ref_net.named_parameters()}
+
+    class Wrapped(torch.nn.Module):
+        def __init__(self, net):
+            super().__init__()
+            self.net = net
+
+        def forward(self, x, tf, c, drop=None):
+            return self.net(x, tf, c, mode="train", cond_drop_prob=0.0)
+    orc = sfron_ref.DDPMSfronOracle(Wrapped(ref_net), sfron_ref.ddpm_get_betas(), lr=1e-3, forget_alpha=10.0, remain_alpha=1.0,
+                                    grad_clip=1.0, ema_mu=1e-4, mask={"net." + k: v for k, v in mask.items()},
+                                    unlearn_loss="adaga", lambd=0.5, n_iters=2, decay_forget_alpha=True)
+    run = ddpm.DDPMSFRon(gpu_net, lr=1e-3, forget_alpha=10.0, remain_alpha=1.0, grad_clip=1.0, ema_rate=1e-4, mask=mask,
+                         unlearn_loss="adaga", lambd=0.5, n_iters=2, decay_forget_alpha=True, cond_drop_prob=0.0)
+    g = torch.Generator().manual_seed(3)
+    N = 4
+    for step in range(2):
+        mk = lambda cls: dict(x0=torch.rand(N, 3, 8, 8, generator=g) * 2 - 1, e=torch.randn(N, 3, 8, 8, generator=g),
+                              t=torch.randint(0, 1000, (N,), generator=g), c=cls, drop=None)
+        f, r = mk(torch.zeros(N, dtype=torch.long)), mk(torch.randint(1, 10, (N,), generator=g))
+        want = orc.step(step, f, r)
+        got = run.step(step, {k: v.to(DEV) for k, v in f.items() if v is not None}, {k: v.to(DEV) for k, v in r.items() if v is not None})
+        assert got["alpha"] == pytest.approx(want["alpha"])
+        assert float(got["forget_loss"]) == pytest.approx(want["forget_loss"], rel=2e-4)
+        assert float(got["remain_loss"]) == pytest.approx(want["remain_loss"], rel=2e-4)
+    # parameters and EMA shadow: Adam's first steps move every unmasked weight by ~lr, so a sign flip of a ~0 gradient
+    # (conv rounding differs between MIOpen and the CPU) shows as a 2e-3 outlier: bound the bulk and the outlier rate
+    tot = bad = 0
+    worst = 0.0
+    for n, p in ref_net.named_parameters():
+        d = (dict(gpu_net.named_parameters())[n].detach().cpu() - p.detach()).abs()
+        tot += d.numel(); bad += int((d > 2e-5).sum()); worst = max(worst, float(d.max()))
+    assert bad / tot < 0.02 and worst < 5e-3, (bad / tot, worst)
+    sh = run.ema_state_dict()
+    d = (sh["conv_out.weight"].cpu() - orc.shadow["net.conv_out.weight"]).abs()
+    assert float(d.max()) < 1e-5

@@ -108,3 +108,101 @@ def adaptive_loss(loss_fn, model, x0, t, c, e, b, lambd=0.5, dp_group=None):
 
 def cosine_lr_scheduler(alpha, step, n_steps):
     return alpha * (1 + math.cos(math.pi * step / n_steps)) / 2
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+class FlatParams:
+    """Re-homes the trainable parameters of ANY autograd module in one flat fp32 arena (parameters and their .grad
+    become views), so that the mask -> clip -> Adam -> EMA sweep of csrc/sweep.hip runs over it in two launches per
+    stage instead of the reference's per-tensor loops (DDPM/runners/diffusion.py:1126-1138,1169-1180)."""
+
+    def __init__(self, model):
+        self.names, self.params = [], []
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                self.names.append(n)
+                self.params.append(p)
+        dev = self.params[0].device
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + 7) // 8 * 8                       # 16-byte aligned tensors
+        self.n = off
+        self.p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.g = torch.zeros(off, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            k = p.numel()
+            self.p[o:o + k].copy_(p.data.reshape(-1))
+            p.data = self.p[o:o + k].view(p.shape)
+            p.grad = self.g[o:o + k].view(p.shape)                # autograd accumulates in place into the arena
+
+    def mask_arena(self, mask):
+        """name -> bool tensor / python int (DDPM/generate_fisher_mask.py:39-46; keys with or without 'module.')."""
+        arena = torch.zeros(self.n, dtype=torch.uint8, device=self.p.device)
+        for n, p, o in zip(self.names, self.params, self.offsets):
+            m = mask.get(n, mask.get("module." + n))
+            if m is None:
+                raise KeyError(f"saliency mask has no entry for {n}")
+            if isinstance(m, int):
+                arena[o:o + p.numel()] = 1 if m else 0
+            else:
+                arena[o:o + p.numel()] = m.reshape(-1).to(device=self.p.device, dtype=torch.uint8)
+        return arena
+
+    def named_views(self, flat):
+        return {n: flat[o:o + p.numel()].view(p.shape) for n, p, o in zip(self.names, self.params, self.offsets)}
+
+
+class DDPMSFRon:
+    """The SFR-on iteration of DDPM/runners/diffusion.py:1075-1180 (method "ron"): cosine-decayed alpha, forget loss
+    "ga" / "adaga" -> mask -> clip -> Adam, remain loss -> clip -> Adam, EMAHelper update.  The denoiser is the caller's
+    autograd module (``model(x, t_float, c, mode="train", cond_drop_prob=...)``); loss, gradient hand-off and the whole
+    parameter sweep run in the HIP library.  ``step(forget, remain)`` takes dicts with x0 (already data_transform-ed),
+    c, t, e."""
+
+    def __init__(self, model, betas=None, lr=1e-4, forget_alpha=10.0, remain_alpha=1.0, grad_clip=1.0, ema_rate=None, mask=None,
+                 unlearn_loss="adaga", lambd=0.5, n_iters=50, decay_forget_alpha=True, cond_drop_prob=0.1, process_group=None):
+        from . import dp, sweep
+        if unlearn_loss not in ("ga", "adaga"):
+            raise NotImplementedError("unlearn_loss 'rl' of the DDPM runner is not on the native path yet")
+        self.model, self.flat = model, FlatParams(model)
+        dev = self.flat.p.device
+        self.b = betas if betas is not None else get_beta_schedule(device=dev)
+        self.forget_alpha, self.remain_alpha, self.grad_clip = forget_alpha, remain_alpha, grad_clip
+        self.unlearn_loss, self.lambd, self.n_iters, self.decay = unlearn_loss, lambd, n_iters, decay_forget_alpha
+        self.cond_drop_prob, self.pg, self._dp = cond_drop_prob, process_group, dp
+        self.world = dp.world_size(process_group)
+        marena = self.flat.mask_arena(mask) if mask is not None else None
+        # DDPM/functions/__init__.py:9-18 with cifar10_sfron.yml:48-56: Adam, wd 0, betas (0.9, 0.999), eps 1e-8
+        self.opt = sweep.FlatAdam(self.flat.p, self.flat.g, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adamw=True, mask=marena)
+        self.mu = ema_rate
+        self.shadow = self.flat.p.clone() if ema_rate is not None else None       # EMAHelper.register (models/ema.py:11-15)
+
+    def _loss(self, batch, kind):
+        fn = loss_registry_conditional["simple"]
+        wrapped = lambda x, tf, c, cond_drop_prob=0.1, mode="train": self.model(x, tf, c, cond_drop_prob=self.cond_drop_prob, mode=mode)
+        args = (wrapped, batch["x0"], batch["t"], batch["c"], batch["e"], self.b)
+        pg = self.pg if self.world > 1 else None
+        if kind == "adaga":
+            return adaptive_loss(fn, *args, lambd=self.lambd, dp_group=pg)
+        return fn(*args, dp_group=pg)
+
+    def _backward(self, loss):
+        self.flat.g.zero_()                                       # optimizer.zero_grad()
+        loss.backward()
+        if self.world > 1:
+            self._dp.allreduce_flat_(self.flat.g, 64 << 20, self.pg)
+
+    def step(self, step_idx, forget, remain):
+        alpha = cosine_lr_scheduler(self.forget_alpha, step_idx, self.n_iters) if self.decay else self.forget_alpha
+        self.model.train()
+        ori_forget = -self._loss(forget, "adaga" if self.unlearn_loss == "adaga" else "simple")
+        self._backward(alpha * ori_forget)
+        self.opt.step(max_norm=self.grad_clip, use_mask=True)
+        ori_remain = self._loss(remain, "simple")
+        self._backward(self.remain_alpha * ori_remain)
+        self.opt.step(max_norm=self.grad_clip, use_mask=False, ema=self.shadow, ema_decay=self.mu if self.mu is not None else 0.0, ema_mode=2)
+        return {"forget_loss": ori_forget.detach(), "remain_loss": ori_remain.detach(), "alpha": alpha}
+
+    def ema_state_dict(self):
+        return {n: v.clone() for n, v in self.flat.named_views(self.shadow).items()}
