@@ -121,3 +121,54 @@ def test_sfron_iterations_vs_oracle(case, loss, micro):
         e = eng.view(runner.ema, n).cpu()
         assert torch.allclose(e, orc.ema[n], atol=5e-4), n
     assert runner.opt.step_count == 6
+
+
+@pytest.mark.parametrize("batch", [1, 5])
+def test_dit_odd_batch_sizes_and_label_drop_extremes(batch):
+    """Ragged ends of the batch dimension (1 and 5 samples: M = 64 / 320 token rows) with every label dropped and none."""
+    cfg = CASES["hd64"]
+    ref, model = build_pair(cfg, batch, seed=2)
+    gen = torch.Generator().manual_seed(batch)
+    S = cfg["input_size"]
+    x = torch.randn(batch, 4, S, S, generator=gen)
+    t = torch.tensor([0, 999, 1, 998, 500][:batch])
+    y = torch.randint(0, 10, (batch,), generator=gen)
+    w = torch.randn(batch, 8, S, S, generator=gen) * 0.1
+    for drop in (torch.ones(batch, dtype=torch.long), torch.zeros(batch, dtype=torch.long)):
+        ref.train(); ref.zero_grad()
+        out_ref = ref(x, t, y, force_drop_ids=drop)
+        (out_ref * w).sum().backward()
+        model.train(); model.zero_grad()
+        out = model(x.to(DEV), t.to(DEV), y.to(DEV), force_drop_ids=drop.to(DEV))
+        assert rel_err(out, out_ref) < 1.5e-2
+        (out * w.to(DEV)).sum().backward()
+        gm = torch.cat([p.grad.flatten().cpu() for _, p in model.named_parameters() if p.grad is not None])
+        gr = torch.cat([q.grad.flatten() for _, q in ref.named_parameters() if q.grad is not None])
+        assert torch.dot(gm, gr) / (gm.norm() * gr.norm()) > 0.9995
+        # dropped labels touch only the null-class row of the embedding table (models.py:78-94)
+        tab = dict(model.named_parameters())["y_embedder.embedding_table.weight"].grad
+        rows = tab.abs().sum(1).cpu() > 0
+        assert rows[cfg["num_classes"]] == bool(drop[0]) and int(rows.sum()) <= batch
+
+
+def test_dit_b4_widths_vs_oracle():
+    """BASELINE config 2 widths (DiT-B/4: D 768, 12 heads of 64, patch 4, 64 tokens) at depth 2, batch 8."""
+    cfg = dict(input_size=32, patch_size=4, in_channels=4, hidden_size=768, depth=2, num_heads=12, num_classes=1000)
+    B = 8
+    ref, model = build_pair(cfg, B, seed=6)
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(B, 4, 32, 32, generator=gen)
+    t = torch.randint(0, 1000, (B,), generator=gen)
+    y = torch.randint(0, 1000, (B,), generator=gen)
+    drop = (torch.rand(B, generator=gen) < 0.3).long()
+    w = torch.randn(B, 8, 32, 32, generator=gen) * 0.1
+    ref.train()
+    out_ref = ref(x, t, y, force_drop_ids=drop)
+    (out_ref * w).sum().backward()
+    model.train()
+    out = model(x.to(DEV), t.to(DEV), y.to(DEV), force_drop_ids=drop.to(DEV))
+    assert rel_err(out, out_ref) < 1.5e-2
+    (out * w.to(DEV)).sum().backward()
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        if q.requires_grad:
+            assert rel_err(p.grad, q.grad) < 4e-2, n
