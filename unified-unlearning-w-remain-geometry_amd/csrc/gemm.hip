@@ -299,7 +299,12 @@ typedef __attribute__((address_space(3))) void lptr_t;
 // ds_read_b64_tr_b16 bank rule (64 banks x 4 B, conflicts counted per 32-lane half = rows r..r+3 and r+8..r+11):
 //   COLS 128/256/384 (row stride = 0 mod 256 B): 4-bit XOR ((r&3)<<2)|((r>>2)&3) inside each 16-chunk group
 //   COLS 192 (row stride = 128 mod 256 B): 2-bit XOR on the chunk-pair index inside each 8-chunk group
+//   COLS 144: the image row is padded to 160 columns (320 B: rows r and r+8 start on the same bank, rows r..r+3 are 16
+//             banks apart) and rows with bit 3 set are shifted by two chunks: the 8 rows x 32 B of one half-wave read tile
+//             the 64 banks exactly.  The two pad chunks of a row are never read; the DMA sends their lanes out of range.
+template <int COLS> constexpr int tr_cols() { return COLS == 144 ? 160 : COLS; }   // physical columns of a transposed-read image row
 template <int COLS> __device__ __forceinline__ int swz_chunk(int r, int ch) {
+  if (COLS == 144) return ch + 2 * ((r >> 3) & 1);
   if (COLS == 192) return ch ^ ((((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1);
   return (ch & ~15) | ((ch & 15) ^ swz_tr(r));
 }
@@ -309,7 +314,7 @@ template <int COLS> __device__ __forceinline__ int swz_chunk(int r, int ch) {
 // LDS image is lane-linear (1 KiB per wave-instruction); the swizzle lives in the SOURCE address.
 template <int EXT, bool TR, int NW>
 struct GldsPlan {
-  static constexpr int CPR = TR ? EXT / 8 : 8;              // 16-B chunks per image row
+  static constexpr int CPR = TR ? tr_cols<EXT>() / 8 : 8;   // 16-B chunks per (physical) image row
   static constexpr int NINSTR = (TR ? 64 : EXT) * CPR / 64; // wave-instructions per tile
   static constexpr int PER_WAVE = (NINSTR + NW - 1) / NW;   // uneven splits: the waves without a last share issue a no-op
   static constexpr bool EVEN = NINSTR % NW == 0;
@@ -320,6 +325,10 @@ struct GldsPlan {
       const int e = (wave + i * NW) * 64 + lane;            // linear chunk index inside the image
       const int row = e / CPR, p = e % CPR;
       if (!TR) off[i] = 2 * ((d0 + row) * ld + ((p ^ (row & 7)) << 3));
+      else if (EXT == 144) {                               // physical chunk p holds logical chunk p - shift; pad chunks go out of range
+        const int lc = p - 2 * ((row >> 3) & 1);
+        off[i] = (lc >= 0 && lc < EXT / 8) ? 2 * (row * ld + d0 + (lc << 3)) : 0x7ffffff0;
+      }
       else     off[i] = 2 * (row * ld + d0 + (swz_chunk<EXT>(row, p) << 3));
     }
   }
@@ -891,11 +900,12 @@ __device__ __forceinline__ void lds_reads_done() {
 template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI, int SCHED = 0, int PRO = 2>
 __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
   constexpr int FBM = WM * MT * 16, FBN = WN * NT * 16, NW = WM * WN;
-  constexpr int A_ELEMS = FBM * 64, B_ELEMS = FBN * 64;
+  constexpr int FBM_P = A_TR ? tr_cols<FBM>() : FBM, FBN_P = B_TR ? tr_cols<FBN>() : FBN;   // physical row length of a transposed-read image
+  constexpr int A_ELEMS = FBM_P * 64, B_ELEMS = FBN_P * 64;
   extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
   constexpr int NS = SCHED == 2 ? 3 : 2;                  // LDS slots (64-deep tiles); SCHED 2 = interleaved schedule, 3 slots
   // ds offset field is 16 bits: the third slot of a 256-row direct A image starts at 65,536 -> second base register
-  static_assert(NS == 2 || ((A_TR ? 2 * 2 * A_ELEMS + 64 * FBM < 65536 : 2 * A_ELEMS < 65536) && 2 * 2 * B_ELEMS + 64 * FBN < 65536),
+  static_assert(NS == 2 || ((A_TR ? 2 * 2 * A_ELEMS + 64 * FBM_P < 65536 : 2 * A_ELEMS < 65536) && 2 * 2 * B_ELEMS + 64 * FBN_P < 65536),
                 "ds offset field");
   auto sAp = [&](int b) { return smem + b * A_ELEMS; };
   auto sBp = [&](int b) { return smem + NS * A_ELEMS + b * B_ELEMS; };
@@ -960,8 +970,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
         adA[mt][0] = lds_addr(sAp(0)) + 2 * (row * 64 + ((gq ^ (row & 7)) << 3));
       } else {
         const int ch = ((wm * MT * 16 + mt * 16) >> 3) + (pp >> 1), r0 = 8 * gq + q;
-        adA[mt][0] = lds_addr(sAp(0)) + 2 * (r0 * FBM + (swz_chunk<FBM>(r0, ch) << 3) + 4 * (pp & 1));
-        adA[mt][1] = lds_addr(sAp(0)) + 2 * ((r0 + 4) * FBM + (swz_chunk<FBM>(r0 + 4, ch) << 3) + 4 * (pp & 1));
+        adA[mt][0] = lds_addr(sAp(0)) + 2 * (r0 * FBM_P + (swz_chunk<FBM>(r0, ch) << 3) + 4 * (pp & 1));
+        adA[mt][1] = lds_addr(sAp(0)) + 2 * ((r0 + 4) * FBM_P + (swz_chunk<FBM>(r0 + 4, ch) << 3) + 4 * (pp & 1));
       }
     }
 #pragma unroll
@@ -971,8 +981,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
         adB[nt][0] = lds_addr(sBp(0)) + 2 * (row * 64 + ((gq ^ (row & 7)) << 3));
       } else {
         const int ch = ((wn * NT * 16 + nt * 16) >> 3) + (pp >> 1), r0 = 8 * gq + q;
-        adB[nt][0] = lds_addr(sBp(0)) + 2 * (r0 * FBN + (swz_chunk<FBN>(r0, ch) << 3) + 4 * (pp & 1));
-        adB[nt][1] = lds_addr(sBp(0)) + 2 * ((r0 + 4) * FBN + (swz_chunk<FBN>(r0 + 4, ch) << 3) + 4 * (pp & 1));
+        adB[nt][0] = lds_addr(sBp(0)) + 2 * (r0 * FBN_P + (swz_chunk<FBN>(r0, ch) << 3) + 4 * (pp & 1));
+        adB[nt][1] = lds_addr(sBp(0)) + 2 * ((r0 + 4) * FBN_P + (swz_chunk<FBN>(r0 + 4, ch) << 3) + 4 * (pp & 1));
       }
     }
   }
@@ -984,7 +994,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
       if (!A_TR) {
         f.a[mt] = asm_read_b128((adA[mt][0] ^ (ks ? 64u : 0u)) + buf * (2 * A_ELEMS));
       } else {
-        const unsigned o = buf * (2 * A_ELEMS) + ks * (2 * 32 * FBM);
+        const unsigned o = buf * (2 * A_ELEMS) + ks * (2 * 32 * FBM_P);
         const bf16x4 lo = asm_read_tr(adA[mt][0] + o), hi = asm_read_tr(adA[mt][1] + o);
         f.a[mt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
@@ -994,7 +1004,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
       if (!B_TR) {
         f.b[nt] = asm_read_b128((adB[nt][0] ^ (ks ? 64u : 0u)) + buf * (2 * B_ELEMS));
       } else {
-        const unsigned o = buf * (2 * B_ELEMS) + ks * (2 * 32 * FBN);
+        const unsigned o = buf * (2 * B_ELEMS) + ks * (2 * 32 * FBN_P);
         const bf16x4 lo = asm_read_tr(adB[nt][0] + o), hi = asm_read_tr(adB[nt][1] + o);
         f.b[nt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
@@ -1036,7 +1046,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
           else f.a[r] = asm_read_b128_off<BUF * 2 * A_ELEMS>(KS ? adA1[r] : adA[r][0]);
         } else {
           constexpr int mt = r >> 1, h = r & 1;
-          const bf16x4 t = asm_read_tr_off<BUF * 2 * A_ELEMS + KS * 64 * FBM>(adA[mt][h]);
+          const bf16x4 t = asm_read_tr_off<BUF * 2 * A_ELEMS + KS * 64 * FBM_P>(adA[mt][h]);
           f.a[mt][4 * h] = t[0]; f.a[mt][4 * h + 1] = t[1]; f.a[mt][4 * h + 2] = t[2]; f.a[mt][4 * h + 3] = t[3];
         }
       } else {
@@ -1045,7 +1055,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
           f.b[q] = asm_read_b128_off<BUF * 2 * B_ELEMS>(KS ? adB1[q] : adB[q][0]);
         } else {
           constexpr int nt = q >> 1, h = q & 1;
-          const bf16x4 t = asm_read_tr_off<BUF * 2 * B_ELEMS + KS * 64 * FBN>(adB[nt][h]);
+          const bf16x4 t = asm_read_tr_off<BUF * 2 * B_ELEMS + KS * 64 * FBN_P>(adB[nt][h]);
           f.b[nt][4 * h] = t[0]; f.b[nt][4 * h + 1] = t[1]; f.b[nt][4 * h + 2] = t[2]; f.b[nt][4 * h + 3] = t[3];
         }
       }
@@ -1239,6 +1249,8 @@ template __global__ void k_gemm_pipe<8, 1, 2, 9, false, false, 1, 2, 3>(GemmArgs
 template __global__ void k_gemm_pipe<8, 1, 2, 9, false, false, 2, 2, 3>(GemmArgs);
 template __global__ void k_gemm_pipe<8, 1, 2, 9, false, false, 3, 2, 3>(GemmArgs);
 template __global__ void k_gemm_pipe<8, 1, 2, 9, false, false, 5, 2, 3>(GemmArgs);
+template __global__ void k_gemm_pipe<8, 1, 2, 9, false, true, 0, 2, 3>(GemmArgs);   // dgrad into a 1152-wide input gradient
+template __global__ void k_gemm_pipe<8, 1, 2, 9, false, true, 1, 2, 3>(GemmArgs);
 
 namespace {
 
@@ -1253,7 +1265,8 @@ int launch_pipe(GemmArgs g, hipStream_t s) {
     g.group_m = gm;
   }
   constexpr bool uneven = !GldsPlan<FBM, A_TR, WM * WN>::EVEN || !GldsPlan<FBN, B_TR, WM * WN>::EVEN;
-  const size_t lds = (SCHED == 2 ? 3 : 2) * (FBM + FBN) * 64 * sizeof(__bf16) + (uneven ? 1024 : 0);
+  constexpr int FBM_P = A_TR ? tr_cols<FBM>() : FBM, FBN_P = B_TR ? tr_cols<FBN>() : FBN;
+  const size_t lds = (SCHED == 2 ? 3 : 2) * (FBM_P + FBN_P) * 64 * sizeof(__bf16) + (uneven ? 1024 : 0);
   static bool done = false;
   if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pipe<WM, WN, MT, NT, A_TR, B_TR, EPI, SCHED, PRO>),
@@ -1312,7 +1325,7 @@ inline int pick_fast_tile(const GemmArgs& g, int force, int transposed_operands)
   if (transposed_operands == 2) return tile_fits(g, 5) ? 55 : 0;
   // forward layouts: 256x144 three-slot tile when it fills the CUs better than 256x192 (a [8192 x 1152] output is exactly 256
   // tiles instead of 192; measured cold: proj 35.7 -> 28.1 us, qkv 102.7 -> 78.3, fc2 103.9 -> 83.5; fc1 (both 100 %) stays)
-  if (transposed_operands == 0 && tile_fits(g, 8) && g.K % 192 == 0 && (!tile_fits(g, 2) || eff(8) > eff(2) + 0.05)) return 62;
+  if (transposed_operands <= 1 && tile_fits(g, 8) && g.K % 192 == 0 && (!tile_fits(g, 2) || eff(8) > eff(2) + 0.05)) return 62;
   if (tile_fits(g, 2) && eff(2) >= 0.5) return (transposed_operands == 1 || even_nk) ? 42 : 2;
   return (transposed_operands == 0 && tile_fits(g, 1)) ? 1 : 0;   // with transposed reads the generic kernel beats the 4-wave tile
 }
@@ -1340,8 +1353,9 @@ int launch_any(const GemmArgs& g, hipStream_t s, int force) {
     case 45: return (g.kchunk % 128 == 0 && g.K % g.kchunk == 0) ? launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI, 1>(g, s)
                                                                   : launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI>(g, s);
     case 62:   // 256x144 with three LDS slots, forward layouts: needs nk = 3 + 3j tiles (K a multiple of 192), no split
-      if constexpr (!A_TR && !B_TR && (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_GELU || EPI == EPI_GATE_RES || EPI == EPI_POS)) {
-        if (g.kchunk == g.K && g.K % 192 == 0) return launch_pipe<8, 1, 2, 9, false, false, EPI, 2, 3>(g, s);
+      if constexpr ((!A_TR && !B_TR && (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_GELU || EPI == EPI_GATE_RES || EPI == EPI_POS)) ||
+                    (!A_TR && B_TR && (EPI == EPI_BF16 || EPI == EPI_F32))) {
+        if (g.kchunk == g.K && g.K % 192 == 0) return launch_pipe<8, 1, 2, 9, A_TR, B_TR, EPI, 2, 3>(g, s);
       }
       if (!tile_fits(g, 2)) return launch<A_TR, B_TR, EPI>(g, s);
       return g.K % 128 == 0 && g.kchunk == g.K ? launch_pipe<4, 2, 4, 6, A_TR, B_TR, EPI, 1>(g, s) : launch_pipe<4, 2, 4, 6, A_TR, B_TR, EPI>(g, s);
