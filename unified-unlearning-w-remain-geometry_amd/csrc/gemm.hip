@@ -1251,6 +1251,7 @@ template __global__ void k_gemm_pipe<8, 1, 2, 9, false, false, 3, 2, 3>(GemmArgs
 template __global__ void k_gemm_pipe<8, 1, 2, 9, false, false, 5, 2, 3>(GemmArgs);
 template __global__ void k_gemm_pipe<8, 1, 2, 9, false, true, 0, 2, 3>(GemmArgs);   // dgrad into a 1152-wide input gradient
 template __global__ void k_gemm_pipe<8, 1, 2, 9, false, true, 1, 2, 3>(GemmArgs);
+template __global__ void k_gemm_pipe<8, 1, 2, 9, false, true, 4, 2, 3>(GemmArgs);
 
 namespace {
 
@@ -1325,7 +1326,8 @@ inline int pick_fast_tile(const GemmArgs& g, int force, int transposed_operands)
   if (transposed_operands == 2) return tile_fits(g, 5) ? 55 : 0;
   // forward layouts: 256x144 three-slot tile when it fills the CUs better than 256x192 (a [8192 x 1152] output is exactly 256
   // tiles instead of 192; measured cold: proj 35.7 -> 28.1 us, qkv 102.7 -> 78.3, fc2 103.9 -> 83.5; fc1 (both 100 %) stays)
-  if (transposed_operands <= 1 && tile_fits(g, 8) && g.K % 192 == 0 && (!tile_fits(g, 2) || eff(8) > eff(2) + 0.05)) return 62;
+  static const bool t62_all = getenv("SFRON_GEMM_T62_ALL") != nullptr;      // A-B knob: the 256x144 tile wherever it fits
+  if (transposed_operands <= 1 && tile_fits(g, 8) && g.K % 192 == 0 && (t62_all || !tile_fits(g, 2) || eff(8) > eff(2) + 0.05)) return 62;
   if (tile_fits(g, 2) && eff(2) >= 0.5) return (transposed_operands == 1 || even_nk) ? 42 : 2;
   return (transposed_operands == 0 && tile_fits(g, 1)) ? 1 : 0;   // with transposed reads the generic kernel beats the 4-wave tile
 }
@@ -1354,7 +1356,7 @@ int launch_any(const GemmArgs& g, hipStream_t s, int force) {
                                                                   : launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI>(g, s);
     case 62:   // 256x144 with three LDS slots, forward layouts: needs nk = 3 + 3j tiles (K a multiple of 192), no split
       if constexpr ((!A_TR && !B_TR && (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_GELU || EPI == EPI_GATE_RES || EPI == EPI_POS)) ||
-                    (!A_TR && B_TR && (EPI == EPI_BF16 || EPI == EPI_F32))) {
+                    (!A_TR && B_TR && (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_DGELU))) {
         if (g.kchunk == g.K && g.K % 192 == 0) return launch_pipe<8, 1, 2, 9, A_TR, B_TR, EPI, 2, 3>(g, s);
       }
       if (!tile_fits(g, 2)) return launch<A_TR, B_TR, EPI>(g, s);
