@@ -224,3 +224,62 @@ def test_wgrad_split_k_slabs(M, N, K, splits, hint):
     for j in range(1, used):
         s += slabs[j]
     assert torch.equal(out, s)
+
+
+@pytest.mark.parametrize("layout", ["fwd", "dgrad"])
+@pytest.mark.parametrize("M,N,K", [(256, 144, 192), (512, 288, 384), (512, 1152, 576), (1024, 1152, 3456)])
+def test_tile_256x144_three_slots(layout, M, N, K):
+    """hint 62: 8 x 1 waves of 32 x 144, three LDS slots, uneven DMA plan (no-op shares), third A slot past the 16-bit ds
+    offset, transposed-read B image padded to 160 columns (dgrad).  Same accumulation order as the generic kernel."""
+    from sfron import ops, _lib
+    gen = torch.Generator().manual_seed(M + N + K)
+    if layout == "fwd":
+        A, B, kw = _rand((M, K), gen), _rand((N, K), gen, 0.1), dict()
+        want = A.float() @ B.float().t()
+    else:
+        A, B, kw = _rand((M, K), gen), _rand((K, N), gen, 0.1), dict(b_t=True)
+        want = A.float() @ B.float()
+    Cf = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    Cg = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(A.to(DEV), B.to(DEV), M, N, K, epilogue=_lib.EPI_F32, c_f32=Cf, tile_hint=62, **kw)
+    ops.gemm(A.to(DEV), B.to(DEV), M, N, K, epilogue=_lib.EPI_F32, c_f32=Cg, tile_hint=-1, **kw)
+    np.testing.assert_allclose(Cf.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4 * K ** 0.5)
+    assert torch.equal(Cf, Cg)
+
+
+def test_tile_256x144_epilogues():
+    """GELU (+pre-activation), gated residual, GELU' and pos-embed epilogues through the 256x144 tile vs torch."""
+    from sfron import ops, _lib
+    gen = torch.Generator().manual_seed(62)
+    Bsz, T, D, Hd = 4, 64, 576, 1152
+    M = Bsz * T
+    X, W1, W2 = _rand((M, D), gen), _rand((Hd, D), gen, 0.05), _rand((D, Hd), gen, 0.05)
+    b1, b2 = torch.randn(Hd, generator=gen) * 0.1, torch.randn(D, generator=gen) * 0.1
+    h_pre = X.float() @ W1.float().t() + b1
+    aux = torch.empty(M, Hd, dtype=torch.bfloat16, device=DEV)
+    H = torch.empty(M, Hd, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(X.to(DEV), W1.to(DEV), M, Hd, D, epilogue=_lib.EPI_GELU, bias=b1.to(DEV), c_bf16=H, aux=aux, tile_hint=62)
+    np.testing.assert_allclose(aux.float().cpu().numpy(), h_pre.numpy(), rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(H.float().cpu().numpy(), torch.nn.functional.gelu(h_pre, approximate="tanh").numpy(), rtol=1e-2, atol=1e-2)
+    gate = torch.randn(Bsz, 6 * D, generator=gen)
+    x0 = torch.randn(M, D, generator=gen)
+    branch = H.cpu().float() @ W2.float().t() + b2
+    want_x = x0 + gate[:, 2 * D:3 * D].repeat_interleave(T, dim=0) * branch
+    x1 = torch.empty(M, D, dtype=torch.float32, device=DEV)
+    a2 = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(H, W2.to(DEV), M, D, Hd, epilogue=_lib.EPI_GATE_RES, bias=b2.to(DEV), c_f32=x1, resid=x0.to(DEV), aux=a2,
+             gate=gate.to(DEV)[:, 2 * D:], ldgate=6 * D, tokens=T, tile_hint=62)
+    np.testing.assert_allclose(x1.cpu().numpy(), want_x.numpy(), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(a2.float().cpu().numpy(), branch.numpy(), rtol=1e-2, atol=1e-2)
+    dA = _rand((M, D), gen, 0.1)
+    hp = aux.cpu().float().requires_grad_(True)
+    torch.nn.functional.gelu(hp, approximate="tanh").backward(dA.float() @ W2.float())
+    dH = torch.empty(M, Hd, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(dA.to(DEV), W2.to(DEV), M, Hd, D, b_t=True, epilogue=_lib.EPI_DGELU, c_bf16=dH, aux=aux, tile_hint=62)
+    np.testing.assert_allclose(dH.float().cpu().numpy(), hp.grad.numpy(), rtol=1e-2, atol=2e-3)
+    pos = torch.randn(T, D, generator=gen)
+    P, Wp = _rand((M, 192), gen), _rand((D, 192), gen, 0.1)
+    xo = torch.empty(M, D, dtype=torch.float32, device=DEV)
+    ops.gemm(P.to(DEV), Wp.to(DEV), M, D, 192, epilogue=_lib.EPI_POS, bias=b2.to(DEV), c_f32=xo, pos=pos.to(DEV), tokens=T, tile_hint=62)
+    want = P.float() @ Wp.float().t() + b2 + pos.repeat(Bsz, 1)
+    np.testing.assert_allclose(xo.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-3)
