@@ -133,6 +133,16 @@ def test_ddpm_sfron_iteration_native_loss_and_sweep_vs_oracle():
         d = (dict(gpu_net.named_parameters())[n].detach().cpu() - p.detach()).abs()
         tot += d.numel(); bad += int((d > 2e-5).sum()); worst = max(worst, float(d.max()))
     assert bad / tot < 0.02 and worst < 5e-3, (bad / tot, worst)
+    # checkpoint list format (runners/diffusion.py:160-171): the reference classes accept every entry
+    states = run.checkpoint(2)
+    assert len(states) == 4 and states[2] == 2
+    chk = ddpm_ref.ConditionalUNet(**cfg)
+    chk.load_state_dict({k: v.cpu() for k, v in states[0].items()}, strict=True)
+    o2 = torch.optim.Adam(chk.parameters(), lr=1e-3)
+    o2.load_state_dict({"state": {i: {k: (t.cpu() if torch.is_tensor(t) else t) for k, t in st.items()} for i, st in states[1]["state"].items()},
+                        "param_groups": states[1]["param_groups"]})
+    assert all(float(st["step"]) == 4.0 for st in o2.state_dict()["state"].values())
+    assert set(states[3]) == {n for n, p in chk.named_parameters() if p.requires_grad}
     sh = run.ema_state_dict()
     d = (sh["conv_out.weight"].cpu() - orc.shadow["net.conv_out.weight"]).abs()
     assert float(d.max()) < 1e-5

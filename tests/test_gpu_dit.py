@@ -172,3 +172,40 @@ def test_dit_b4_widths_vs_oracle():
     for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
         if q.requires_grad:
             assert rel_err(p.grad, q.grad) < 4e-2, n
+
+
+def test_checkpoint_format_and_resume(tmp_path):
+    """DiT/forget.py:346-353: {"model","ema","opt","args"}; the reference side (oracle DiT + torch.optim.AdamW) loads it, and a
+    runner resumed from it continues bit for bit."""
+    from oracle import dit_ref
+    from sfron import data, diffusion, step
+    cfg = CASES["hd64"]
+    B = 4
+    ref, model = build_pair(cfg, B, seed=11)
+    hp = dict(lr=2e-4, forget_alpha=0.3, grad_clip=1.0, ema_decay=0.99, mask=None, unlearn_loss="ga", forget_class=3)
+    runner = step.DiTSFRon(model, diffusion.create_diffusion(""), **hp)
+    kw = dict(global_batch=B, num_classes=cfg["num_classes"], forget_class=3, input_size=cfg["input_size"], device=DEV)
+    bat = lambda it: (data.synthetic_batch(2, it, "forget", **kw), data.synthetic_batch(2, it, "remain", **kw))
+    runner.step(*bat(0))
+    path = tmp_path / "0000001.pt"
+    torch.save(runner.checkpoint(args={"lr": 2e-4}), path)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck) == {"model", "ema", "opt", "args"}
+    # reference side: the model class and torch's AdamW accept the dicts as they are
+    ref.load_state_dict(ck["model"], strict=True)
+    ema_ref = dit_ref.DiT(**cfg)
+    ema_ref.load_state_dict(ck["ema"], strict=True)
+    opt = torch.optim.AdamW(ref.parameters(), lr=2e-4, weight_decay=0)
+    opt.load_state_dict(ck["opt"])
+    n_state = sum(1 for p in ref.parameters() if p.requires_grad)
+    assert len(opt.state_dict()["state"]) == n_state and all(float(s["step"]) == 2.0 for s in opt.state_dict()["state"].values())
+    # resume: a fresh runner loaded from the checkpoint takes the same next step
+    runner.step(*bat(1))
+    want = model.engine.params.clone()
+    _, model2 = build_pair(cfg, B, seed=12)                      # different weights, then overwritten by the checkpoint
+    runner2 = step.DiTSFRon(model2, diffusion.create_diffusion(""), **hp)
+    runner2.load_checkpoint(ck)
+    assert runner2.opt.step_count == 2
+    runner2.step(*bat(1))
+    assert torch.equal(model2.engine.params, want)
+    assert torch.equal(runner2.ema, runner.ema)

@@ -206,3 +206,18 @@ class DDPMSFRon:
 
     def ema_state_dict(self):
         return {n: v.clone() for n, v in self.flat.named_views(self.shadow).items()}
+
+    def checkpoint(self, step):
+        """[model.state_dict(), optimizer.state_dict(), step, ema_helper.state_dict()] as DDPM/runners/diffusion.py:160-171 saves
+        it; the optimizer entry is in torch.optim.Adam's layout over ``model.parameters()``."""
+        names = [n for n, _ in self.model.named_parameters()]
+        m, v = self.flat.named_views(self.opt.m), self.flat.named_views(self.opt.v)
+        state = {i: {"step": torch.tensor(float(self.opt.step_count)), "exp_avg": m[n].clone(), "exp_avg_sq": v[n].clone()}
+                 for i, n in enumerate(names) if n in m and self.opt.step_count > 0}
+        group = {"lr": self.opt.lr, "betas": tuple(self.opt.betas), "eps": self.opt.eps, "weight_decay": 0.0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "params": list(range(len(names)))}
+        states = [{k: t.clone() for k, t in self.model.state_dict().items()}, {"state": state, "param_groups": [group]}, step]
+        if self.shadow is not None:
+            states.append(self.ema_state_dict())
+        return states

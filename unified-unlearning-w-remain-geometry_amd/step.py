@@ -146,3 +146,45 @@ class DiTSFRon:
     def ema_state_dict(self):
         eng = self.model.engine
         return {name: eng.view(self.ema, name).clone() for name in eng.index}
+
+    # ------------------------------------------------------------------ checkpoint (DiT/forget.py:346-353 format)
+    def opt_state_dict(self):
+        """The shared AdamW state in torch.optim's state_dict layout over ``model.parameters()`` (forget.py:199): entries
+        only for parameters that received gradients (pos_embed has none), so the reference's
+        ``torch.optim.AdamW(model.parameters(), ...).load_state_dict(ckpt["opt"])`` accepts it."""
+        eng = self.model.engine
+        names = [n for n, _ in self.model.named_parameters()]
+        state = {}
+        for i, n in enumerate(names):
+            off, shape, trainable = eng.index[n]
+            if trainable and self.opt.step_count > 0:
+                state[i] = {"step": torch.tensor(float(self.opt.step_count)),
+                            "exp_avg": eng.view(self.opt.m, n).clone(), "exp_avg_sq": eng.view(self.opt.v, n).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.opt.betas), "eps": self.opt.eps, "weight_decay": self.opt.wd, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": True, "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def checkpoint(self, args=None):
+        """{"model", "ema", "opt", "args"} exactly as DiT/forget.py:346-353 saves it (pass the dict to torch.save)."""
+        return {"model": {k: v.clone() for k, v in self.model.state_dict().items()}, "ema": self.ema_state_dict(),
+                "opt": self.opt_state_dict(), "args": args}
+
+    def load_checkpoint(self, ckpt):
+        """Resume from a checkpoint in that format (ours or the reference's)."""
+        eng = self.model.engine
+        self.model.load_state_dict(ckpt["model"])
+        for name, v in ckpt["ema"].items():
+            eng.view(self.ema, name).copy_(v.to(self.ema.device))
+        names = [n for n, _ in self.model.named_parameters()]
+        self.opt.m.zero_(); self.opt.v.zero_()
+        steps = set()
+        for i, st in ckpt["opt"]["state"].items():
+            n = names[int(i)]
+            eng.view(self.opt.m, n).copy_(st["exp_avg"].to(self.ema.device))
+            eng.view(self.opt.v, n).copy_(st["exp_avg_sq"].to(self.ema.device))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ: not a state this optimizer can hold")
+        self.opt.step_count = steps.pop() if steps else 0
+        eng.sync_bf16()
