@@ -111,6 +111,10 @@ int sfron_ddpm_loss_coef(const float* per_sample, int n, int mode, float lambd, 
                          int use_wsum, float* coef, float* loss, void* stream);
 int sfron_ddpm_loss_bwd(const float* e, const float* model_out, const float* coef, int n, int chw, float* d_model_out,
                         void* stream);
+/* one step of DDPM/functions/denoising.py:72-95 (generalized / DDIM update, same timestep for the whole batch):
+ * x0_pred = (x - eps*s1)/s2, x_next = s3*x0_pred + c1*noise + c2*eps; noise may be NULL when c1 == 0, x0_pred may be NULL */
+int sfron_ddim_step(const float* x, const float* eps, const float* noise, int64_t n, float s1, float s2, float s3, float c1,
+                    float c2, float* x_next, float* x0_pred, void* stream);
 
 /* ------------------------------------------------------------------ bf16 MFMA GEMM (gemm.hip)
  * C[M,N] = alpha * op(A)[M,K] · op(B)[K,N] (+ bias[N]) with a fused epilogue; fp32 accumulation.

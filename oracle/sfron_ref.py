@@ -171,3 +171,32 @@ class DDPMSfronOracle:
                 if p.requires_grad:
                     self.shadow[n] = (1.0 - self.mu) * p.data + self.mu * self.shadow[n]
         return {"forget_loss": ori_forget.item(), "remain_loss": ori_remain.item(), "alpha": alpha}
+
+
+# ----------------------------------------------------------------------------- DDPM sampler (snapshots)
+def ddpm_compute_alpha(beta, t):
+    # DDPM/functions/denoising.py:4-7
+    beta = torch.cat([torch.zeros(1), beta], dim=0)
+    return (1 - beta).cumprod(dim=0).index_select(0, t + 1).view(-1, 1, 1, 1)
+
+
+def ddpm_generalized_steps_conditional(x, c, seq, model, b, cond_scale=3.0, eta=0.0, step_noise=None):
+    """DDPM/functions/denoising.py:72-95 (DDIM-style update with eta); ``step_noise[k]`` replaces the k-th randn_like draw."""
+    with torch.no_grad():
+        n = x.size(0)
+        seq_next = [-1] + list(seq[:-1])
+        xs, x0_preds = [x], []
+        for k, (i, j) in enumerate(zip(reversed(seq), reversed(seq_next))):
+            t = torch.ones(n) * i
+            next_t = torch.ones(n) * j
+            at = ddpm_compute_alpha(b, t.long())
+            at_next = ddpm_compute_alpha(b, next_t.long())
+            xt = xs[-1]
+            et = model(xt, t, c, cond_scale=cond_scale, mode="test")
+            x0_t = (xt - et * (1 - at).sqrt()) / at.sqrt()
+            x0_preds.append(x0_t)
+            c1 = eta * ((1 - at / at_next) * (1 - at_next) / (1 - at)).sqrt()
+            c2 = ((1 - at_next) - c1 ** 2).sqrt()
+            noise = torch.randn_like(x) if step_noise is None else step_noise[k]
+            xs.append(at_next.sqrt() * x0_t + c1 * noise + c2 * et)
+    return xs, x0_preds

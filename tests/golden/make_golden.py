@@ -421,6 +421,26 @@ def gen_sampling(ref_models, ref_diffusion):
     np.savez_compressed(os.path.join(HERE, "dit_sampling.npz"), **out)
 
 
+def gen_ddpm_sampler():
+    """DDPM/functions/denoising.py generalized_steps_conditional on a stub model (eta 0 and 0.5, 10 of 1000 steps)."""
+    den = _load("ref_ddpm_denoising", os.path.join(REF, "DDPM", "functions", "denoising.py"))
+    b = torch.from_numpy(np.linspace(1e-4, 2e-2, 1000, dtype=np.float64)).float()
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(3, 3, 8, 8, generator=g)
+    c = torch.tensor([1, 5, 9])
+    A = torch.randn(3, 3, generator=g) * 0.4
+    model = lambda xt, t, cc, cond_scale=3.0, mode="test": torch.einsum("oc,nchw->nohw", A, xt) * torch.cos(t / 300.0).view(-1, 1, 1, 1) + 0.01 * cc.view(-1, 1, 1, 1) * cond_scale
+    seq = list(range(0, 1000, 100))
+    out = dict(x=x.numpy(), c=c.numpy(), A=A.numpy(), seq=np.array(seq))
+    for eta in (0.0, 0.5):
+        torch.manual_seed(13)
+        xs, x0s = den.generalized_steps_conditional(x, c, seq, model, b, cond_scale=2.0, eta=eta)
+        out[f"last_eta{eta}"] = xs[-1].numpy(); out[f"x0_first_eta{eta}"] = x0s[0].numpy(); out[f"x_mid_eta{eta}"] = xs[5].numpy()
+    out["alpha_t"] = den.compute_alpha(b, torch.tensor([0, 999, 500])).flatten().numpy()
+    out["alpha_m1"] = den.compute_alpha(b, torch.tensor([-1])).flatten().numpy()
+    np.savez_compressed(os.path.join(HERE, "ddpm_sampler.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     ref_diffusion = import_ref_dit_diffusion()
@@ -432,4 +452,5 @@ if __name__ == "__main__":
     gen_mask()
     gen_ddpm_model()
     gen_sampling(ref_models, ref_diffusion)
+    gen_ddpm_sampler()
     print("golden vectors written to", HERE)

@@ -146,3 +146,23 @@ def test_ddpm_sfron_iteration_native_loss_and_sweep_vs_oracle():
     sh = run.ema_state_dict()
     d = (sh["conv_out.weight"].cpu() - orc.shadow["net.conv_out.weight"]).abs()
     assert float(d.max()) < 1e-5
+
+
+@pytest.mark.parametrize("eta", [0.0, 0.5])
+def test_ddpm_generalized_sampler_matches_reference(eta):
+    """DDPM/functions/denoising.py:72-95 against the reference's own outputs (tests/golden/ddpm_sampler.npz)."""
+    import os
+    from sfron import ddpm
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ddpm_sampler.npz"))
+    x, c, A = torch.from_numpy(g["x"]), torch.from_numpy(g["c"]), torch.from_numpy(g["A"]).to(DEV)
+    model = lambda xt, t, cc, cond_scale=3.0, mode="test": (torch.einsum("oc,nchw->nohw", A, xt) * torch.cos(t / 300.0).view(-1, 1, 1, 1)
+                                                            + 0.01 * cc.view(-1, 1, 1, 1) * cond_scale)
+    b = ddpm.get_beta_schedule(device=DEV)
+    np.testing.assert_array_equal(ddpm.compute_alpha(b, torch.tensor([0, 999, 500], device=DEV)).cpu().numpy(), g["alpha_t"])
+    torch.manual_seed(13)
+    noises = [torch.randn_like(x).to(DEV) for _ in range(10)]          # the reference's CPU draws, one per step
+    xs, x0s = ddpm.generalized_steps_conditional(x.to(DEV), c.to(DEV), list(g["seq"]), model, b, cond_scale=2.0, eta=eta, step_noise=noises)
+    assert len(xs) == 11 and len(x0s) == 10
+    np.testing.assert_allclose(xs[-1].cpu().numpy(), g[f"last_eta{eta}"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(xs[5].cpu().numpy(), g[f"x_mid_eta{eta}"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(x0s[0].cpu().numpy(), g[f"x0_first_eta{eta}"], rtol=2e-5, atol=2e-5)

@@ -249,3 +249,18 @@ def test_forward_with_cfg_and_guided_sampling_match_reference(golden_dir):
     smp = dref.p_sample_loop(tab, m.forward_with_cfg, zc.shape, zc, clip_denoised=False, model_kwargs=dict(y=yc, cfg_scale=4.0),
                                       step_noise=torch.from_numpy(g["cfg_step_noise"]))
     np.testing.assert_allclose(smp.numpy(), g["cfg_samples"], rtol=1e-4, atol=1e-4)
+
+
+def test_ddpm_sampler_restatement_matches_reference(golden_dir):
+    g = load(golden_dir, "ddpm_sampler.npz")
+    b = sfron_ref.ddpm_get_betas()
+    np.testing.assert_array_equal(sfron_ref.ddpm_compute_alpha(b, torch.tensor([0, 999, 500])).flatten().numpy(), g["alpha_t"])
+    np.testing.assert_array_equal(sfron_ref.ddpm_compute_alpha(b, torch.tensor([-1])).flatten().numpy(), g["alpha_m1"])
+    x, c, A = torch.from_numpy(g["x"]), torch.from_numpy(g["c"]), torch.from_numpy(g["A"])
+    model = lambda xt, t, cc, cond_scale=3.0, mode="test": torch.einsum("oc,nchw->nohw", A, xt) * torch.cos(t / 300.0).view(-1, 1, 1, 1) + 0.01 * cc.view(-1, 1, 1, 1) * cond_scale
+    for eta in (0.0, 0.5):
+        torch.manual_seed(13)
+        xs, x0s = sfron_ref.ddpm_generalized_steps_conditional(x, c, list(g["seq"]), model, b, cond_scale=2.0, eta=eta)
+        np.testing.assert_allclose(xs[-1].numpy(), g[f"last_eta{eta}"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(xs[5].numpy(), g[f"x_mid_eta{eta}"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(x0s[0].numpy(), g[f"x0_first_eta{eta}"], rtol=1e-6, atol=1e-6)

@@ -32,6 +32,7 @@ _PROTOS = {
     "sfron_dit_loss_fwd_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _S]),
     "sfron_p_sample": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _S]),
     "sfron_cfg_combine": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, _S]),
+    "sfron_ddim_step": (c_int, [_P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, _P, _P, _S]),
     "sfron_ddpm_alphas_cumprod": (c_int, [_P, c_int, _P, _S]),
     "sfron_ddpm_q_sample": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _S]),
     "sfron_ddpm_sample_loss": (c_int, [_P, _P, c_int, c_int, _P, _S]),

@@ -245,6 +245,21 @@ __global__ __launch_bounds__(TPB) void k_ddpm_loss_bwd(const float* __restrict__
   for (int i = blockIdx.x * TPB + threadIdx.x; i < chw; i += gridDim.x * TPB) dout[base + i] = c * (out[base + i] - e[base + i]);
 }
 
+
+// DDIM-style step of DDPM/functions/denoising.py:72-95 (one timestep for the whole batch, scalars from the host):
+//   x0 = (x - eps*s1)/s2;  x_next = s3*x0 + c1*noise + c2*eps      with s1 = sqrt(1-a_t), s2 = sqrt(a_t), s3 = sqrt(a_next)
+__global__ __launch_bounds__(TPB) void k_ddim_step(const float* __restrict__ x, const float* __restrict__ eps,
+                                                   const float* __restrict__ noise, long n, float s1, float s2, float s3, float c1,
+                                                   float c2, float* __restrict__ x_next, float* __restrict__ x0_pred) {
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) {
+    const float e = eps[i];
+    const float x0 = (x[i] - e * s1) / s2;
+    const float nz = noise ? noise[i] : 0.0f;
+    x_next[i] = (s3 * x0 + c1 * nz) + c2 * e;
+    if (x0_pred) x0_pred[i] = x0;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -331,6 +346,17 @@ int sfron_cfg_combine(float* model_out, int n_total, int cout, int hw, int n_gui
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(k_cfg_combine, dim3(gx, n_total / 2), dim3(TPB), 0, (hipStream_t)stream, model_out, n_total / 2, cout, hw,
                      n_guided, cfg_scale);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_ddim_step(const float* x, const float* eps, const float* noise, int64_t n, float s1, float s2, float s3, float c1,
+                    float c2, float* x_next, float* x0_pred, void* stream) {
+  SFRON_CHECK_ARG(x && eps && x_next && n > 0 && s2 != 0.0f);
+  long gx = (n + TPB - 1) / TPB;
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(k_ddim_step, dim3((int)gx), dim3(TPB), 0, (hipStream_t)stream, x, eps, noise, (long)n, s1, s2, s3, c1, c2, x_next,
+                     x0_pred);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

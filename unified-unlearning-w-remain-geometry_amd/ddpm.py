@@ -110,6 +110,43 @@ def cosine_lr_scheduler(alpha, step, n_steps):
     return alpha * (1 + math.cos(math.pi * step / n_steps)) / 2
 
 
+def compute_alpha(beta, t):
+    """DDPM/functions/denoising.py:4-7 (host-side, tiny): alpha_bar of timestep t with alpha_bar(-1) = 1."""
+    beta = torch.cat([torch.zeros(1, device=beta.device), beta], dim=0)
+    return alphas_cumprod(beta).index_select(0, t + 1)
+
+
+def generalized_steps_conditional(x, c, seq, model, b, cond_scale=3.0, step_noise=None, **kwargs):
+    """DDPM/functions/denoising.py:72-95: the classifier-free-guided generalized (DDIM, ``eta``) sampler the runner's snapshot
+    path uses.  Returns (xs, x0_preds) like the reference (tensors stay on the device).  The denoiser is the caller's
+    ``model(x, t, c, cond_scale=..., mode="test")``; the update runs in sfron_ddim_step.  ``step_noise[k]`` optionally fixes
+    the k-th ``randn_like`` draw."""
+    eta = float(kwargs.get("eta", 0))
+    abar = torch.cat([torch.ones(1, device=b.device), alphas_cumprod(b)]).cpu()          # index t+1; alpha_bar(-1) = 1
+    with torch.no_grad():
+        n = x.size(0)
+        seq = list(seq)
+        seq_next = [-1] + seq[:-1]
+        xs, x0_preds = [x], []
+        for k, (i, j) in enumerate(zip(reversed(seq), reversed(seq_next))):
+            t = (torch.ones(n) * i).to(x.device)
+            at, at_next = abar[i + 1], abar[j + 1]                                         # fp32 0-dim tensors: torch's scalar math
+            et = model(xs[-1], t, c, cond_scale=cond_scale, mode="test").contiguous().float()
+            c1 = eta * ((1 - at / at_next) * (1 - at_next) / (1 - at)).sqrt()
+            c2 = ((1 - at_next) - c1 ** 2).sqrt()
+            noise = None
+            if eta != 0.0:
+                noise = (torch.randn_like(x) if step_noise is None else step_noise[k]).contiguous()
+            xt = xs[-1].contiguous().float()
+            x_next, x0 = torch.empty_like(xt), torch.empty_like(xt)
+            check(_lib.lib().sfron_ddim_step(ptr(xt), ptr(et), ptr(noise), xt.numel(), float((1 - at).sqrt()), float(at.sqrt()),
+                                             float(at_next.sqrt()), float(c1), float(c2), ptr(x_next), ptr(x0), stream_ptr()),
+                  "ddim_step")
+            x0_preds.append(x0)
+            xs.append(x_next)
+    return xs, x0_preds
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 class FlatParams:
     """Re-homes the trainable parameters of ANY autograd module in one flat fp32 arena (parameters and their .grad
