@@ -4,7 +4,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsfron.so")
+# SFRON_LIB points the binding at another build of the same library (kernel A-B experiments); never a fallback
+LIB_PATH = os.environ.get("SFRON_LIB") or os.path.join(_HERE, "libsfron.so")
 
 
 class SfronError(RuntimeError):
