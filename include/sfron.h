@@ -278,6 +278,16 @@ int sfron_probe_destroy(void* probe);
  * sums then run concurrently with the dgrad / elementwise chain and join `stream` before the call's work ends. */
 int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* d_out,
                        const int64_t* y, const uint8_t* drop, void* workspace, float* grads, void* aux, void* stream);
+/* Data-parallel form of the backward pass.  block_events: L hipEvent_t handles (entries may be NULL), event l is recorded on the
+ * aux handle's weight-gradient stream once every gradient inside block l's arena range is final except proj.bias and fc2.bias;
+ * late_bias: fp32 [L][2][D] that receives those two instead of the arena.  The host can then all-reduce block ranges while the
+ * backward pass is still running, all-reduce late_bias and the non-block ranges at the end, and call
+ * sfron_dit_scatter_late_bias to put the reduced biases into the arena.  (Reference: nn.DataParallel reduces after
+ * loss.backward(), DiT/forget.py:193,288.) */
+int sfron_dit_backward_dp(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* d_out,
+                          const int64_t* y, const uint8_t* drop, void* workspace, float* grads, void* aux,
+                          void* const* block_events, float* late_bias, void* stream);
+int sfron_dit_scatter_late_bias(const sfron_dit_cfg* cfg, const float* late_bias, float* grads, void* stream);
 int sfron_aux_create(void** aux /* HOST out */);
 int sfron_aux_destroy(void* aux);
 

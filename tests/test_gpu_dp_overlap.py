@@ -1,0 +1,48 @@
+"""GPU: the overlapped gradient exchange of the data-parallel path (per-block events on the weight-gradient stream, late-bias
+staging + scatter, communication stream) at world size 1 over RCCL: it must reproduce the plain path bit for bit.  (More ranks
+cannot be started on the one-GPU test box; the collective sequence is rank-independent by construction, and the CPU gloo tests
+cover the sharding / reduction arithmetic.)"""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_overlapped_allreduce_path_matches_plain_path(monkeypatch):
+    from sfron import data, diffusion, step
+    from test_gpu_dit import CASES, build_pair
+    cfg = CASES["hd72"]
+    B = 4
+    kw = dict(global_batch=B, num_classes=cfg["num_classes"], forget_class=3, input_size=cfg["input_size"], device=DEV)
+    bat = lambda it: (data.synthetic_batch(5, it, "forget", **kw), data.synthetic_batch(5, it, "remain", **kw))
+    hp = dict(lr=2e-4, forget_alpha=0.3, grad_clip=1.0, ema_decay=0.99, mask=None, unlearn_loss="ga", forget_class=3)
+
+    def run(overlap):
+        _, model = build_pair(cfg, B, seed=21)
+        runner = step.DiTSFRon(model, diffusion.create_diffusion(""), **hp)
+        assert runner._overlap_enabled() == overlap
+        for it in range(2):
+            out = runner.step(*bat(it))
+        torch.cuda.synchronize()
+        return model.engine.params.clone(), model.engine.grads.clone(), out["stats"].clone()
+
+    monkeypatch.setenv("SFRON_DP_OVERLAP", "0")
+    p0, g0, s0 = run(False)
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        created = True
+    try:
+        monkeypatch.setenv("SFRON_DP_OVERLAP", "force")
+        p1, g1, s1 = run(True)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert torch.equal(g0, g1), "late-bias staging + scatter must leave the gradient arena as the plain backward does"
+    assert torch.equal(p0, p1) and torch.equal(s0, s1)

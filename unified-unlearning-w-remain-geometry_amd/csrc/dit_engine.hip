@@ -348,8 +348,13 @@ int sfron_dit_forward_probed(const sfron_dit_cfg* cfg, const float* params, cons
   return SFRON_OK;
 }
 
-int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* d_out,
-                       const int64_t* y, const uint8_t* drop, void* workspace, float* grads, void* aux, void* stream) {
+// block_events (optional, L entries, may hold NULLs): hipEvent_t recorded on the weight-gradient stream when every gradient of
+// block l that lives in its arena range is final EXCEPT proj.bias / fc2.bias; late_bias (optional, [L][2][D] fp32): where those
+// two go instead of the arena.  Together they let a data-parallel host all-reduce a block's range while the backward pass is
+// still running, and exchange the late biases (plus everything outside the blocks) once at the end.
+static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* d_out,
+                             const int64_t* y, const uint8_t* drop, void* workspace, float* grads, void* aux, void* const* block_events,
+                             float* late_bias, void* stream) {
   Dims d;
   RUN(make_dims(cfg, d));
   SFRON_CHECK_ARG(params && params_bf16 && d_out && y && workspace && grads);
@@ -462,6 +467,9 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
     RUN(sfron_colsum(w.dqkv[pl], 1, M, 3 * D, 3 * D, ax ? w.csum2 : w.csum, CSUM_PARTS, grads + pb + P.o_qkv_b, side));
     RUN(wgrad_side(w.dqkv[pl], xmod1, 3 * D, D, grads + pb + P.o_qkv_w));
     consumed(3, l);
+    if (block_events && block_events[l]) {                 // block l: the four weight gradients, qkv.bias and fc1.bias are final
+      if (hipEventRecord((hipEvent_t)block_events[l], (hipStream_t)side) != hipSuccess) return (int)hipGetLastError();
+    }
     g = dgrad_desc(w.dqkv[pl], wb + pb + P.o_qkv_w, M, 3 * D, D);
     g.c_bf16 = (uint16_t*)w.d_xmod; g.ldc_bf16 = D;
     RUN(sfron_gemm_bf16(&g, stream));
@@ -488,8 +496,9 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
   }
   if (ax) { (void)hipEventRecord(ax->done, ax->side); (void)hipStreamWaitEvent(hs, ax->done, 0); }   // join
   // proj.bias / fc2.bias gradients of every block: sum_b gate[b] * (sum_t dy[b,t])
-  RUN(sfron_gated_bias_grads(w.dysum, w.mod + 2 * D, NM, 6 * D, 3 * D, d.L, B, D, grads + P.blocks, P.blk_stride, P.o_proj_b,
-                             P.o_fc2_b, stream));
+  if (late_bias) RUN(sfron_gated_bias_grads(w.dysum, w.mod + 2 * D, NM, 6 * D, 3 * D, d.L, B, D, late_bias, 2L * D, 0, D, stream));
+  else RUN(sfron_gated_bias_grads(w.dysum, w.mod + 2 * D, NM, 6 * D, 3 * D, d.L, B, D, grads + P.blocks, P.blk_stride, P.o_proj_b,
+                                  P.o_fc2_b, stream));
   // ---- patch embed (pos_embed is frozen: no gradient)
   RUN(sfron_cast_bf16(w.dx, (uint16_t*)w.dx_bf, (int64_t)M * D, stream));
   RUN(sfron_colsum(w.dx, 0, M, D, D, w.csum, CSUM_PARTS, grads + P.pe_b, stream));
@@ -521,6 +530,31 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
   RUN(sfron_colsum(w.d_sc, 0, B, D, D, w.csum, CSUM_PARTS, grads + P.t0_b, stream));
   g = wgrad_desc(w.d_h1_bf, w.tfreq, B, D, d.fdim, grads + P.t0_w);
   RUN(sfron_gemm_bf16(&g, stream));
+  return SFRON_OK;
+}
+
+int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* d_out,
+                       const int64_t* y, const uint8_t* drop, void* workspace, float* grads, void* aux, void* stream) {
+  return dit_backward_impl(cfg, params, params_bf16, d_out, y, drop, workspace, grads, aux, nullptr, nullptr, stream);
+}
+
+int sfron_dit_backward_dp(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* d_out,
+                          const int64_t* y, const uint8_t* drop, void* workspace, float* grads, void* aux,
+                          void* const* block_events, float* late_bias, void* stream) {
+  SFRON_CHECK_ARG(!block_events || aux);          // the events are recorded on the aux handle's weight-gradient stream
+  return dit_backward_impl(cfg, params, params_bf16, d_out, y, drop, workspace, grads, aux, block_events, late_bias, stream);
+}
+
+int sfron_dit_scatter_late_bias(const sfron_dit_cfg* cfg, const float* late_bias, float* grads, void* stream) {
+  Dims d;
+  RUN(make_dims(cfg, d));
+  SFRON_CHECK_ARG(late_bias && grads);
+  const ParamLayout P = make_layout(d);
+  const size_t w = (size_t)d.D * sizeof(float);
+  if (hipMemcpy2DAsync(grads + P.blocks + P.o_proj_b, (size_t)P.blk_stride * sizeof(float), late_bias, 2 * w, w, d.L,
+                       hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
+  if (hipMemcpy2DAsync(grads + P.blocks + P.o_fc2_b, (size_t)P.blk_stride * sizeof(float), late_bias + d.D, 2 * w, w, d.L,
+                       hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
   return SFRON_OK;
 }
 

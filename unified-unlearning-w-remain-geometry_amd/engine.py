@@ -136,6 +136,32 @@ class DitEngine:
         check(_lib.lib().sfron_probe_read(self.probe, ctypes.byref(n), ctypes.byref(ms)), "probe_read")
         return n.value, ms.value
 
+    # ------------------------------------------------------------------ data-parallel backward (overlapped all-reduce)
+    def dp_setup(self):
+        """One torch event per block (recorded by the library on its weight-gradient stream) + the late-bias staging buffer."""
+        if getattr(self, "_dp_events", None) is None:
+            L, D = self.cfg.depth, self.cfg.hidden
+            self._dp_events = [torch.cuda.Event(enable_timing=False) for _ in range(L)]
+            for e in self._dp_events:
+                e.record()                                   # materialises the handle
+            self._dp_handles = (ctypes.c_void_p * L)(*[e.cuda_event for e in self._dp_events])
+            self.late_bias = torch.zeros(L, 2, D, dtype=torch.float32, device=self.device)
+            lay = self.layout
+            self.block_ranges = [(lay["blocks"] + l * lay["blk_stride"], lay["blocks"] + (l + 1) * lay["blk_stride"]) for l in range(L)]
+        return self._dp_events
+
+    def backward_dp(self, d_out, y, drop=None):
+        """Backward pass that records per-block completion events and parks proj.bias / fc2.bias gradients in ``late_bias``."""
+        self.dp_setup()
+        check(_lib.lib().sfron_dit_backward_dp(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(d_out), ptr(y),
+                                               ptr(drop), ptr(self.workspace), ptr(self.grads), self.aux, self._dp_handles,
+                                               ptr(self.late_bias), stream_ptr()), "dit_backward_dp")
+        return self.grads
+
+    def scatter_late_bias(self):
+        check(_lib.lib().sfron_dit_scatter_late_bias(ctypes.byref(self.cfg), ptr(self.late_bias), ptr(self.grads), stream_ptr()),
+              "dit_scatter_late_bias")
+
     def backward(self, d_out, y, drop=None, grads=None):
         g = self.grads if grads is None else grads
         check(_lib.lib().sfron_dit_backward(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(d_out),

@@ -8,6 +8,8 @@ One call = one iteration of /root/reference/DiT/forget.py:256-322 (method "ron")
 Data-parallel: every rank holds full replicas (weights, Adam state, EMA, mask) and a shard of each
 minibatch; gradients are scaled by 1/global_batch in the loss kernel and SUM-all-reduced over RCCL.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -55,6 +57,7 @@ class DiTSFRon:
             raise ValueError("micro_batches must be 1 or 2")
         self.micro = micro_batches
         self._chains = None
+        self._comm = None
         self._bind(mask)
 
     def _bind(self, mask):
@@ -67,6 +70,41 @@ class DiTSFRon:
 
     def _allreduce_grads(self):
         dp.allreduce_flat_(self.model.engine.grads[:self.model.engine.n_trainable], self.bucket_elems, self.pg)
+
+    # ------------------------------------------------------------------ all-reduce overlapped with the backward pass
+    def _overlap_enabled(self):
+        """On for world > 1 (SFRON_DP_OVERLAP=0 turns it off; =force runs the same code path at world 1, for tests)."""
+        mode = os.environ.get("SFRON_DP_OVERLAP", "1")
+        if mode == "0" or self.micro != 1 or not (dist.is_available() and dist.is_initialized()):
+            return False
+        return self.world > 1 or mode == "force"
+
+    def _backward_allreduce_overlapped(self, d_out, y, drop):
+        """Backward + gradient exchange.  The library records one event per block on its weight-gradient stream when that
+        block's arena range is final (all but proj.bias / fc2.bias, which it parks in ``late_bias``); a communication stream
+        waits for each event and SUM-all-reduces the block's range (64 MB for DiT-XL/2) while the backward pass of the earlier
+        blocks is still running.  What is only known at the end -- adaLN / embedder / final-layer gradients and the late
+        biases -- is exchanged after the pass, then the reduced biases are scattered into the arena.  Every rank issues the
+        same collectives in the same order."""
+        eng = self.model.engine
+        evs = eng.dp_setup()
+        if self._comm is None:
+            self._comm = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        eng.backward_dp(d_out, y, drop)
+        for l in reversed(range(len(evs))):
+            lo, hi = eng.block_ranges[l]
+            self._comm.wait_event(evs[l])
+            with torch.cuda.stream(self._comm):
+                dist.all_reduce(eng.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+        nt = eng.n_trainable
+        b_lo, b_hi = eng.block_ranges[0][0], eng.block_ranges[-1][1]
+        dist.all_reduce(eng.grads[:b_lo], op=dist.ReduceOp.SUM, group=self.pg)
+        if b_hi < nt:
+            dist.all_reduce(eng.grads[b_hi:nt], op=dist.ReduceOp.SUM, group=self.pg)
+        dist.all_reduce(eng.late_bias, op=dist.ReduceOp.SUM, group=self.pg)
+        main.wait_stream(self._comm)             # every block range is reduced: now the reduced late biases may land in it
+        eng.scatter_late_bias()
 
     # ------------------------------------------------------------------ two-chain (micro-batch) pass
     def _setup_chains(self, n_local):
@@ -119,8 +157,11 @@ class DiTSFRon:
         x_t = diff.q_sample(batch["x0"], batch["t"], batch["noise"])
         out = eng.forward(x_t, batch["t"], y, batch.get("drop"))
         mse, vb, d_out = diff.loss_fwd_bwd(out, batch["x0"], batch["t"], batch["noise"], sign_alpha / n_global)
-        eng.backward(d_out, y, batch.get("drop"))
-        self._allreduce_grads()
+        if self._overlap_enabled():
+            self._backward_allreduce_overlapped(d_out, y, batch.get("drop"))
+        else:
+            eng.backward(d_out, y, batch.get("drop"))
+            self._allreduce_grads()
         return mse, vb
 
     def step(self, forget, remain):
