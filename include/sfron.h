@@ -282,11 +282,14 @@ int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint
  * aux handle's weight-gradient stream once every gradient inside block l's arena range is final except proj.bias and fc2.bias;
  * late_bias: fp32 [L][2][D] that receives those two instead of the arena.  The host can then all-reduce block ranges while the
  * backward pass is still running, all-reduce late_bias and the non-block ranges at the end, and call
- * sfron_dit_scatter_late_bias to put the reduced biases into the arena.  (Reference: nn.DataParallel reduces after
+ * sfron_dit_scatter_late_bias to put the reduced biases into the arena.  ada_dmod_out / ada_sc_out (both or neither): the
+ * adaLN_modulation weight gradient (all blocks + final layer, [(6L+2)D][D], a third of the arena) is NOT computed; instead its two
+ * bf16 factors dmod [B][(6L+2)D] and silu(c) [B][D] are copied out, so that the host all-gathers them over the ranks and forms
+ * dmod_all^T silu(c)_all with one sfron_gemm_bf16 over the global batch.  (Reference: nn.DataParallel reduces after
  * loss.backward(), DiT/forget.py:193,288.) */
 int sfron_dit_backward_dp(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* d_out,
                           const int64_t* y, const uint8_t* drop, void* workspace, float* grads, void* aux,
-                          void* const* block_events, float* late_bias, void* stream);
+                          void* const* block_events, float* late_bias, uint16_t* ada_dmod_out, uint16_t* ada_sc_out, void* stream);
 int sfron_dit_scatter_late_bias(const sfron_dit_cfg* cfg, const float* late_bias, float* grads, void* stream);
 int sfron_aux_create(void** aux /* HOST out */);
 int sfron_aux_destroy(void* aux);

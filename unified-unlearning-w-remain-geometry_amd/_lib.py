@@ -94,7 +94,7 @@ _PROTOS.update({
     "sfron_dit_workspace_bytes": (c_int64, [POINTER(DitCfg)]),
     "sfron_dit_forward": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_dit_backward": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _S]),
-    "sfron_dit_backward_dp": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _S]),
+    "sfron_dit_backward_dp": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_dit_scatter_late_bias": (c_int, [POINTER(DitCfg), _P, _P, _S]),
     "sfron_aux_create": (c_int, [POINTER(c_void_p)]),
     "sfron_aux_destroy": (c_int, [c_void_p]),

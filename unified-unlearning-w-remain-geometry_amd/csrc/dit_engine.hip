@@ -354,7 +354,7 @@ int sfron_dit_forward_probed(const sfron_dit_cfg* cfg, const float* params, cons
 // still running, and exchange the late biases (plus everything outside the blocks) once at the end.
 static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* d_out,
                              const int64_t* y, const uint8_t* drop, void* workspace, float* grads, void* aux, void* const* block_events,
-                             float* late_bias, void* stream) {
+                             float* late_bias, uint16_t* ada_dmod_out, uint16_t* ada_sc_out, void* stream) {
   Dims d;
   RUN(make_dims(cfg, d));
   SFRON_CHECK_ARG(params && params_bf16 && d_out && y && workspace && grads);
@@ -507,8 +507,16 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
   // ---- adaLN modulation Linear of every block + final layer, as one problem
   RUN(sfron_cast_bf16(w.dmod, (uint16_t*)w.dmod_bf, (int64_t)B * NM, stream));
   RUN(sfron_colsum(w.dmod, 0, B, NM, NM, w.csum, CSUM_PARTS, grads + P.ada_b, stream));
-  g = wgrad_desc(w.dmod_bf, w.sc, B, NM, D, grads + P.ada_w);
-  RUN(sfron_gemm_bf16(&g, stream));
+  if (ada_dmod_out && ada_sc_out) {
+    // data parallel: dW_ada = sum over the GLOBAL batch of dmod[b]^T (x) silu(c)[b] is a rank-(batch) product.  Handing out the
+    // two factors (12.5 MB + 72 KB of bf16 per rank at DiT-XL/2) lets the host all-GATHER them and form the product once over
+    // the global batch, instead of all-reducing the 892 MB result that only becomes final here, in the tail of the pass
+    if (hipMemcpyAsync(ada_dmod_out, w.dmod_bf, (size_t)B * NM * 2, hipMemcpyDeviceToDevice, hs) != hipSuccess) return (int)hipGetLastError();
+    if (hipMemcpyAsync(ada_sc_out, w.sc, (size_t)B * D * 2, hipMemcpyDeviceToDevice, hs) != hipSuccess) return (int)hipGetLastError();
+  } else {
+    g = wgrad_desc(w.dmod_bf, w.sc, B, NM, D, grads + P.ada_w);
+    RUN(sfron_gemm_bf16(&g, stream));
+  }
   g = dgrad_desc(w.dmod_bf, wb + P.ada_w, B, NM, D);
   g.epilogue = SFRON_EPI_F32; g.c_f32 = w.slabs; g.ldc_f32 = D; g.split_k = SPLIT_K_ADA; g.split_stride = (long)B * D;
   RUN(sfron_gemm_bf16(&g, stream));
@@ -535,14 +543,16 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
 
 int sfron_dit_backward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* d_out,
                        const int64_t* y, const uint8_t* drop, void* workspace, float* grads, void* aux, void* stream) {
-  return dit_backward_impl(cfg, params, params_bf16, d_out, y, drop, workspace, grads, aux, nullptr, nullptr, stream);
+  return dit_backward_impl(cfg, params, params_bf16, d_out, y, drop, workspace, grads, aux, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 int sfron_dit_backward_dp(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* d_out,
                           const int64_t* y, const uint8_t* drop, void* workspace, float* grads, void* aux,
-                          void* const* block_events, float* late_bias, void* stream) {
+                          void* const* block_events, float* late_bias, uint16_t* ada_dmod_out, uint16_t* ada_sc_out, void* stream) {
   SFRON_CHECK_ARG(!block_events || aux);          // the events are recorded on the aux handle's weight-gradient stream
-  return dit_backward_impl(cfg, params, params_bf16, d_out, y, drop, workspace, grads, aux, block_events, late_bias, stream);
+  SFRON_CHECK_ARG((ada_dmod_out == nullptr) == (ada_sc_out == nullptr));
+  return dit_backward_impl(cfg, params, params_bf16, d_out, y, drop, workspace, grads, aux, block_events, late_bias, ada_dmod_out,
+                           ada_sc_out, stream);
 }
 
 int sfron_dit_scatter_late_bias(const sfron_dit_cfg* cfg, const float* late_bias, float* grads, void* stream) {

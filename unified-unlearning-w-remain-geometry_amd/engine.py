@@ -146,6 +146,9 @@ class DitEngine:
                 e.record()                                   # materialises the handle
             self._dp_handles = (ctypes.c_void_p * L)(*[e.cuda_event for e in self._dp_events])
             self.late_bias = torch.zeros(L, 2, D, dtype=torch.float32, device=self.device)
+            NM = (6 * L + 2) * D
+            self.ada_dmod = torch.zeros(self.cfg.batch, NM, dtype=torch.bfloat16, device=self.device)     # factors of the adaLN weight gradient
+            self.ada_sc = torch.zeros(self.cfg.batch, D, dtype=torch.bfloat16, device=self.device)
             lay = self.layout
             self.block_ranges = [(lay["blocks"] + l * lay["blk_stride"], lay["blocks"] + (l + 1) * lay["blk_stride"]) for l in range(L)]
         return self._dp_events
@@ -155,7 +158,7 @@ class DitEngine:
         self.dp_setup()
         check(_lib.lib().sfron_dit_backward_dp(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(d_out), ptr(y),
                                                ptr(drop), ptr(self.workspace), ptr(self.grads), self.aux, self._dp_handles,
-                                               ptr(self.late_bias), stream_ptr()), "dit_backward_dp")
+                                               ptr(self.late_bias), ptr(self.ada_dmod), ptr(self.ada_sc), stream_ptr()), "dit_backward_dp")
         return self.grads
 
     def scatter_late_bias(self):
