@@ -187,7 +187,7 @@ int64_t sfron_dit_workspace_bytes(const sfron_dit_cfg* cfg) {
 }
 
 // SFRON_ABLATE (debug / A-B measurement only): bit 0 = run LN backward and gate backward as separate kernels,
-// bit 1 = split-K in the block weight gradients (off by default), bit 2 = side stream at the lowest priority
+// bit 1 = split-K in the block weight gradients (off by default), bit 2 = side stream at the lowest priority, bit 3 = fc2 weight gradient after the fc2 dgrad
 static int ablate_mask() {
   static const int m = [] { const char* e = getenv("SFRON_ABLATE"); return e ? atoi(e) : 0; }();
   return m;
@@ -435,15 +435,22 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     const __bf16* h = w.h + (size_t)l * M * d.F; const __bf16* a2 = w.a2 + (size_t)l * M * D;
     const bool first = (l == d.L - 1);
     // ---- MLP branch: x2 = x1 + gate_mlp * (fc2(gelu(fc1(xmod2))))
-    produced(0);                                  // d_br was written by the fused LN+gate kernel just before this block
     const int pl = l & 1;
-    RUN(wgrad_side(w.d_br[pl], h, D, d.F, grads + pb + P.o_fc2_w));
-    consumed(0, l);
+    const bool delay_fc2 = ablate_mask() & 8;      // A-B knob: start the fc2 weight gradient only after the fc2 dgrad (768 tiles)
+    if (!delay_fc2) {
+      produced(0);                                // d_br was written by the fused LN+gate kernel just before this block
+      RUN(wgrad_side(w.d_br[pl], h, D, d.F, grads + pb + P.o_fc2_w));
+      consumed(0, l);
+    }
     before_overwrite(1, l);
     g = dgrad_desc(w.d_br[pl], wb + pb + P.o_fc2_w, M, D, d.F);
     g.epilogue = SFRON_EPI_DGELU; g.c_bf16 = (uint16_t*)w.d_hpre[pl]; g.ldc_bf16 = d.F; g.aux = (uint16_t*)hpre; g.ldaux = d.F;
     RUN(sfron_gemm_bf16(&g, stream));
     produced(1);
+    if (delay_fc2) {
+      RUN(wgrad_side(w.d_br[pl], h, D, d.F, grads + pb + P.o_fc2_w));
+      consumed(0, l);
+    }
     RUN(sfron_colsum(w.d_hpre[pl], 1, M, d.F, d.F, ax ? w.csum2 : w.csum, CSUM_PARTS, grads + pb + P.o_fc1_b, side));
     RUN(wgrad_side(w.d_hpre[pl], xmod2, d.F, D, grads + pb + P.o_fc1_w));
     consumed(1, l);
