@@ -400,7 +400,13 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
   // for that before block l - 2 overwrites the copy -- so main stalls only when the side stream is a whole block behind.
   auto produced = [&](int i) { if (ax) { (void)hipEventRecord(ax->produced[i], hs); (void)hipStreamWaitEvent(ax->side, ax->produced[i], 0); } };
   auto consumed = [&](int i, int l) { if (ax) (void)hipEventRecord(ax->consumed[2 * i + (l & 1)], ax->side); };
-  auto before_overwrite = [&](int i, int l) { if (ax && l + 2 <= d.L - 1) (void)hipStreamWaitEvent(hs, ax->consumed[2 * i + (l & 1)], 0); };
+  // The weight-gradient stream is in order, so its LAST event of block l + 2 (buffer 3) covers buffers 0..2 of that block too:
+  // one wait per block on the main stream (buffer 0 of block l is written at the end of block l + 1 and waits there) instead
+  // of four -- each wait is a barrier packet in the main queue (a few microseconds of bubble whether or not it blocks).
+  auto before_overwrite = [&](int i, int l) {
+    if (!ax || l + 2 > d.L - 1) return;
+    if (i == 0) (void)hipStreamWaitEvent(hs, ax->consumed[2 * 3 + (l & 1)], 0);   // buffers 1..3 of block l are written later on this stream
+  };
   if (ax) { (void)hipEventRecord(ax->done, hs); (void)hipStreamWaitEvent(ax->side, ax->done, 0); }   // side starts after everything before us
 
   // ---- final layer
