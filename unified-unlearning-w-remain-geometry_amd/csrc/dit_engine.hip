@@ -187,7 +187,7 @@ int64_t sfron_dit_workspace_bytes(const sfron_dit_cfg* cfg) {
 }
 
 // SFRON_ABLATE (debug / A-B measurement only): bit 0 = run LN backward and gate backward as separate kernels,
-// bit 1 = split-K in the block weight gradients (off by default), bit 2 = side stream at the lowest priority, bit 3 = fc2 weight gradient after the fc2 dgrad
+// bit 1 = split-K in the block weight gradients (off by default), bit 2 = side stream at the lowest priority, bit 3 = fc2 weight gradient after the fc2 dgrad, bit 4 = no split-K for the two small-output weight gradients
 static int ablate_mask() {
   static const int m = [] { const char* e = getenv("SFRON_ABLATE"); return e ? atoi(e) : 0; }();
   return m;
@@ -412,8 +412,21 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
   // ---- final layer
   RUN(sfron_patchify(d_out, B, d.Co, d.S, d.S, d.p, 1, (uint16_t*)w.d_tok, d.Po, stream));
   RUN(sfron_colsum(w.d_tok, 1, M, d.Po, d.Po, w.csum, CSUM_PARTS, grads + P.fin_b, stream));
-  g = wgrad_desc(w.d_tok, w.xmodf, M, d.Po, D, grads + P.fin_w);
-  RUN(sfron_gemm_bf16(&g, stream));
+  // small outputs with an M-long reduction (final layer [Po x D], patch embed [D x Kp]): one or nine output tiles would walk
+  // all 8192 rows serially (~100 us each), so the reduction is split into slabs and summed in a fixed order
+  auto small_wgrad = [&](const void* dY, const void* X, int N, int K, float* dW) -> int {
+    sfron_gemm_desc q = wgrad_desc(dY, X, M, N, K, dW);
+    int sp = M / 256;
+    const long cap = (long)SPLIT_K_ADA * B * D / ((long)N * K);          // what fits in w.slabs
+    if (sp > cap) sp = (int)cap;
+    if (sp > 64) sp = 64;
+    if (sp < 2 || (ablate_mask() & 16)) return sfron_gemm_bf16(&q, stream);
+    q.c_f32 = w.slabs; q.split_k = sp; q.split_stride = (long)N * K;
+    RUN(sfron_gemm_bf16(&q, stream));
+    const int kchunk = cdiv(cdiv(M, sp), 64) * 64;
+    return sfron_reduce_chunks(w.slabs, 1, cdiv(M, kchunk), N * K, dW, N * K, 0, stream);
+  };
+  RUN(small_wgrad(w.d_tok, w.xmodf, d.Po, D, grads + P.fin_w));
   g = dgrad_desc(w.d_tok, wb + P.fin_w, M, d.Po, D);
   g.c_bf16 = (uint16_t*)w.d_xmod; g.ldc_bf16 = D;
   RUN(sfron_gemm_bf16(&g, stream));
@@ -515,8 +528,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
   // ---- patch embed (pos_embed is frozen: no gradient)
   RUN(sfron_cast_bf16(w.dx, (uint16_t*)w.dx_bf, (int64_t)M * D, stream));
   RUN(sfron_colsum(w.dx, 0, M, D, D, w.csum, CSUM_PARTS, grads + P.pe_b, stream));
-  g = wgrad_desc(w.dx_bf, w.patches, M, D, d.Kp, grads + P.pe_w);
-  RUN(sfron_gemm_bf16(&g, stream));
+  RUN(small_wgrad(w.dx_bf, w.patches, D, d.Kp, grads + P.pe_w));
   // ---- adaLN modulation Linear of every block + final layer, as one problem
   RUN(sfron_cast_bf16(w.dmod, (uint16_t*)w.dmod_bf, (int64_t)B * NM, stream));
   RUN(sfron_colsum(w.dmod, 0, B, NM, NM, w.csum, CSUM_PARTS, grads + P.ada_b, stream));
