@@ -80,7 +80,7 @@ struct Workspace {
                                                        // dgrad chain may run one block ahead of the weight gradients
   size_t bytes;
 };
-constexpr int SPLIT_K_ADA = 64;
+constexpr int SPLIT_K_ADA = 256;   // adaLN dgrad reads 451 MB of weights with M = batch rows: 64 splits ran at 2.5 TB/s, 256 at ~4.5
 constexpr int CSUM_PARTS = 64;     // row chunks of the bias column sums (stage 2 reads CSUM_PARTS x N floats with N/256 workgroups)
 
 // Weight gradients dW[N][K] = dY[M][N]^T X[M][K] have few 192x192 output tiles and a long reduction (M = batch*tokens):

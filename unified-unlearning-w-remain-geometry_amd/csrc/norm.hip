@@ -365,14 +365,22 @@ struct SlotArgs { SlotDst dst[8]; };      // [kind 0..3][buf 0..1]
 // out[dst(kind,buf).base + layer*stride + b*ld + c] = sum_j partial[(b*per + j)*D + c]
 __global__ __launch_bounds__(TPB) void k_reduce_slots(const float* __restrict__ parts, long slot_stride, int per, int D, SlotArgs a) {
   const int slot = blockIdx.z, b = blockIdx.y;
-  const int c = blockIdx.x * TPB + threadIdx.x;
+  const int c = (blockIdx.x * TPB + threadIdx.x) * 4;          // four columns per thread (D % 4 == 0), 16-byte loads
   if (c >= D) return;
   const int layer = slot >> 3, kb = slot & 7;
   const float* p = parts + (size_t)slot * slot_stride + (size_t)b * per * D + c;
-  float s = 0.f;
-  for (int j = 0; j < per; ++j) s += p[(size_t)j * D];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int j = 0;
+  for (; j + 4 <= per; j += 4) {                                // four loads in flight, summed in index order
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(j + u) * D);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  for (; j < per; ++j) { const float4 v = *reinterpret_cast<const float4*>(p + (size_t)j * D); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
   const SlotDst d = a.dst[kb];
-  d.base[(size_t)layer * d.layer_stride + (size_t)b * d.ld + c] = s;
+  *reinterpret_cast<float4*>(d.base + (size_t)layer * d.layer_stride + (size_t)b * d.ld + c) = s;
 }
 
 }  // namespace
@@ -460,7 +468,9 @@ int sfron_reduce_slots(const float* parts, long slot_stride, int n_slots, int gr
   SFRON_CHECK_ARG(parts && dst_base && dst_layer_stride && dst_ld && n_slots > 0 && groups > 0 && per_group > 0 && D > 0);
   SlotArgs a;
   for (int i = 0; i < 8; ++i) a.dst[i] = SlotDst{dst_base[i], dst_layer_stride[i], dst_ld[i]};
-  hipLaunchKernelGGL(k_reduce_slots, dim3(cdiv(D, TPB), groups, n_slots), dim3(TPB), 0, (hipStream_t)stream, parts, slot_stride,
+  SFRON_CHECK_ARG(D % 4 == 0);
+  for (int i = 0; i < 8; ++i) SFRON_CHECK_ARG(((uintptr_t)dst_base[i] & 15) == 0 && dst_layer_stride[i] % 4 == 0 && dst_ld[i] % 4 == 0);
+  hipLaunchKernelGGL(k_reduce_slots, dim3(cdiv(D, 4 * TPB), groups, n_slots), dim3(TPB), 0, (hipStream_t)stream, parts, slot_stride,
                      per_group, D, a);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
