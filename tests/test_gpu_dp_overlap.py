@@ -46,3 +46,21 @@ def test_overlapped_allreduce_path_matches_plain_path(monkeypatch):
             dist.destroy_process_group()
     assert torch.equal(g0, g1), "late-bias staging + scatter must leave the gradient arena as the plain backward does"
     assert torch.equal(p0, p1) and torch.equal(s0, s1)
+
+
+def test_two_rank_overlapped_exchange_matches_single_process():
+    """Two ranks (two processes sharing cuda:0, gloo transport -- RCCL refuses two ranks on one device) run the overlapped
+    exchange on their halves of the global batch; gradients norms, parameters and EMA match the single-process run on the whole
+    batch and the replicas stay identical (tools/rehearse_dp2.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SFRON_DP_OVERLAP="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rehearse_dp2.py"), "--single"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29537", os.path.join(root, "tools", "rehearse_dp2.py")], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("PASS=True") == 2
