@@ -165,7 +165,7 @@ def main():
 
     if rank == 0:
         res = {
-            "metric": "SFR-on unlearning steps/sec, DiT-XL/2 256px bs32/GPU",
+            "metric": f"SFR-on unlearning steps/sec, {args.model} {args.image_size}px bs{args.batch}/GPU",   # BASELINE.json's metric at the defaults
             "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
