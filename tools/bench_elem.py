@@ -27,6 +27,7 @@ def rep(name, ms, mbytes): print(f"{name:22s} {ms*1e3:8.1f} us  {mbytes/ms/1e3:6
 rep("ln_modulate_fwd", timeit(lambda: ops.ln_modulate_fwd(x, mod[:, 3 * D:], mod[:, 4 * D:], 6 * D, T)), M * D * 6 / 1e6)
 rep("ln_modulate_bwd", timeit(lambda: ops.ln_modulate_bwd(dxm, x, mean, rstd, mod[:, 4 * D:], 6 * D, T, dx, True)), M * D * 14 / 1e6)
 rep("gate_bwd", timeit(lambda: ops.gate_bwd(dx, br, mod[:, 2 * D:], 6 * D, T)), M * D * 8 / 1e6)
+rep("ln+gate bwd fused", timeit(lambda: ops.ln_gate_bwd(dxm, x, mean, rstd, mod[:, 4 * D:], 6 * D, T, dx, True, br, mod[:, 2 * D:], 6 * D)), M * D * 18 / 1e6)
 rep("colsum bf16 [M,4D]", timeit(lambda: ops.colsum(dh)), M * F * 2 / 1e6)
 n = 675_000_000
 p = torch.randn(n, device=DEV); gr = torch.randn(n, device=DEV) * 1e-3
