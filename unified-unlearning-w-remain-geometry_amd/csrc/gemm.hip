@@ -135,9 +135,11 @@ __device__ __forceinline__ void nt_store(bf16x4* p, bf16x4 v, int nt) {
 }
 
 template <int EPI>
-__device__ __forceinline__ void epilogue_store(const GemmArgs& g, int row, int col, f32x4 v) {
+__device__ __forceinline__ void epilogue_store(const GemmArgs& g, int row, int col, f32x4 v, const float4* pre_bias = nullptr) {
   v = v * g.alpha;
-  if (g.bias) {
+  if (pre_bias) {                                     // bias fetched before the main loop (its latency is not on the epilogue's path)
+    v[0] += pre_bias->x; v[1] += pre_bias->y; v[2] += pre_bias->z; v[3] += pre_bias->w;
+  } else if (g.bias) {
     const float4 b = *reinterpret_cast<const float4*>(g.bias + col);
     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
   }
@@ -939,6 +941,16 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
       for (int j = 0; j < NT; ++j) { f32x4& c = acc[i][j]; asm volatile("" : "+v"(c)); }
   }
 
+  // forward layouts (the only ones that carry a bias): this lane's bias columns, one float4 per n-tile, fetched before the
+  // main loop so that their latency is not on the epilogue's path; the transposed layouts keep the registers
+  constexpr bool PRE_BIAS = !A_TR && !B_TR;
+  float4 bias_v[PRE_BIAS ? NT : 1];
+  if constexpr (PRE_BIAS) {
+    const int cb = n0 + wn * NT * 16 + 4 * (lane >> 4);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      bias_v[nt] = g.bias ? *reinterpret_cast<const float4*>(g.bias + cb + nt * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   GldsPlan<FBM, A_TR, NW> planA;
   GldsPlan<FBN, B_TR, NW> planB;
   planA.init(g.lda, m0, wave, lane);
@@ -1193,7 +1205,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
       for (int nt = 0; nt < NT; ++nt) {
         const int col = col_b + nt * 16;
         f32x4 v = acc[mt][nt] * g.alpha;
-        if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+        if constexpr (PRE_BIAS) { const float4 b = bias_v[nt]; v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+        else if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
         bf16x4 a = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
         nt_store(reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col), a, g.nt_out & 1);
         float4 x = xr[nt];
@@ -1206,7 +1219,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        epilogue_store<EPI>(g, row_b + mt * 16, col_b + nt * 16, acc[mt][nt]);
+        epilogue_store<EPI>(g, row_b + mt * 16, col_b + nt * 16, acc[mt][nt], PRE_BIAS ? &bias_v[PRE_BIAS ? nt : 0] : nullptr);
   }
 }
 
