@@ -8,9 +8,14 @@ A "step" = one full SFR-on iteration (DiT/forget.py:256-322): forget fwd/bwd -> 
 remain fwd/bwd -> AdamW, EMA; synthetic latents / labels / timesteps / noise already resident in HBM.
 Weak scaling: every rank runs batch 32 (global batch 32*N), gradients SUM-all-reduced over RCCL.
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline"     -- live HIP-event timing of the dominant kernel class (the Mlp.fc1 GEMM+GELU of block 0,
-                    [B*T x D] x [D x 4D], one sample per forward pass inside the timed region)
+  "roofline"     -- the kernel with the largest share of GPU time (profiles/r02_kernel_table.md): the weight-gradient GEMM of
+                    attn.qkv / mlp.fc1 with the bias row sums fused in, timed live with HIP event pairs recorded on the
+                    weight-gradient stream it is launched on (every 9th block of every backward pass inside the timed
+                    region); "others" holds the same measurement for the fc1 forward GEMM (main stream) and an "hbm" entry for
+                    the parameter sweep k_masked_clip_adam
   "cpu_baseline" -- the oracle (plain PyTorch fp32, CPU) timed on a bounded sample on this box's host cores.
+With N > 1 the overlapped gradient exchange is switched on only after DiTSFRon.verify_overlap() has reproduced the synchronous
+exchange on the ranks of this very run ("dp_overlap" in the JSON says which path was timed).
 """
 import argparse
 import json
@@ -25,6 +30,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0              # HBM3E spec, same guide
 
 
 def parse():
@@ -38,6 +44,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--micro-batches", type=int, default=1, help="independent half-batch chains per pass (1 or 2)")
     ap.add_argument("--cpu-batch", type=int, default=8, help="batch of the bounded CPU-baseline sample")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: keep the synchronous bucketed all-reduce")
+    ap.add_argument("--check", action="store_true",
+                    help="N-rank == 1-rank parity: after the run every rank also computes the gradient of the WHOLE global batch "
+                         "of step 0 by itself and compares it with the all-reduced gradient of the sharded run")
     return ap.parse_args()
 
 
@@ -129,9 +139,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    dp_overlap = False
+    if world > 1 and not args.no_overlap and args.micro_batches == 1:
+        dp_overlap = runner.verify_overlap(batches[0][0])
+        runner.overlap = dp_overlap
+        if rank == 0:
+            print(f"[bench] overlapped gradient exchange vs synchronous all-reduce on {world} ranks: "
+                  f"{'match -> overlap ON' if dp_overlap else 'MISMATCH -> synchronous path'}", file=sys.stderr, flush=True)
     for i in range(args.warmup):
         runner.step(*batches[i % pool])
+    eng = model.engine
     eng.probe_enable(2 * args.steps + 4)
+    eng.wgrad_probe_enable(16 * args.steps + 16)
+    runner.opt.timed = []                       # (start, end) event pairs around every k_masked_clip_adam launch
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -143,8 +163,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
 
+    runner.guard.poll(block=True)               # NaN / Inf loss or gradient norm, bad labels: raises (non-zero exit)
     loss_ok = bool(torch.isfinite(out["remain_mse"]).all().item() and torch.isfinite(out["forget_mse"]).all().item())
     n_probe, probe_ms = eng.probe_read()
+    n_wp, wp_ms = eng.wgrad_probe_read()
+    sweep_ms = [a.elapsed_time(b) for a, b in runner.opt.timed]
     cfg = eng.cfg
     M = args.batch * eng.tokens
     fc1_flops = 2.0 * M * cfg.mlp_hidden * cfg.hidden
@@ -156,12 +179,46 @@ def main():
     step_flops = 6.0 * fwd_per_sample * args.batch
     ms_per_step = elapsed / args.steps * 1e3
 
-    # HBM traffic of the probed kernel: PMC counters need their own rocprofv3 passes (FETCH_SIZE, WRITE_SIZE), so the
-    # number is measured offline on this same command and committed under profiles/ (see the json's "note")
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_fc1_traffic.json")
-    if args.model == "DiT-XL/2" and args.batch == 32 and os.path.isfile(tpath):
-        traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
+    # dominant kernel by GPU time: the qkv / fc1 weight gradient (+ bias row sums): dW[N][D] = dY[M][N]^T X[M][D], N = 3D and F
+    # alternate, so the mean launch does (3D + F) * D * M * 2 / 2 ... FLOP
+    wg_flops = 0.5 * (2.0 * M * 3 * D * D + 2.0 * M * F * D)
+    wg_ms = wp_ms / max(1, n_wp)
+    wg_ach = wg_flops / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0
+    # parameter sweep: bytes per launch = 31 B/param (forget stage: g, mask, p, m, v in; p, m, v, bf16 out) and 38 B/param
+    # (remain stage: + EMA in/out, no mask), alternating
+    nt = eng.n_trainable
+    sweep_bytes = 34.5 * nt
+    sw_ms = sum(sweep_ms) / max(1, len(sweep_ms))
+    sw_ach = sweep_bytes / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else 0.0
+
+    # HBM traffic of the probed kernels: PMC counters need their own rocprofv3 passes (FETCH_SIZE, WRITE_SIZE), so the
+    # numbers are measured offline on this same command and committed under profiles/ (see the json's "note")
+    def committed_traffic(fname):
+        tpath = os.path.join(ROOT, "profiles", fname)
+        if args.model == "DiT-XL/2" and args.batch == 32 and os.path.isfile(tpath):
+            return json.load(open(tpath)).get("traffic_bytes_per_launch")
+        return None
+    traffic = committed_traffic("r02_wgrad_traffic.json")
+
+    check_res = None
+    if args.check and world > 1:
+        # N-rank == 1-rank parity at equal global batch: the all-reduced gradient of the sharded forget pass of step 0 against
+        # the gradient this rank computes by itself on the WHOLE global batch (same loss scale alpha / global_batch)
+        f0 = batches[0][0]
+        runner._pass(f0, f0["y"], -runner.forget_alpha)
+        g_dp = eng.grads[:nt].clone()
+        full = data.synthetic_batch(0, 0, "forget", gb, 0, 1, input_size=latent, device=dev)
+        model.set_batch_size(gb)
+        e2 = model.engine
+        x_t = diff.q_sample(full["x0"], full["t"], full["noise"])
+        o2 = e2.forward(x_t, full["t"], full["y"], full["drop"])
+        _, _, d_o2 = diff.loss_fwd_bwd(o2, full["x0"], full["t"], full["noise"], -runner.forget_alpha / gb)
+        e2.backward(d_o2, full["y"], full["drop"])
+        rel = ((e2.grads[:nt] - g_dp).norm() / (g_dp.norm() + 1e-30))
+        dist.all_reduce(rel, op=dist.ReduceOp.MAX)
+        check_res = {"what": f"all-reduced gradient of {world} shards of {args.batch} vs one rank on the global batch of {gb}",
+                     "rel_l2": rel.item(), "ok": bool(rel.item() < 5e-3)}
+        model.set_batch_size(args.batch)
 
     if rank == 0:
         res = {
@@ -175,10 +232,23 @@ def main():
             "finite_losses": loss_ok,
             "step_tflops_per_gpu": step_flops / (ms_per_step * 1e-3) / 1e12,
             "step_frac_of_bf16_mfma_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-            "roofline": {"bound": "mfma", "kernel": "k_gemm_pipe<4,2,4,6,false,false,2,1> = 256x192 tile, interleaved MFMA/LDS-DMA schedule, Mlp.fc1 + GELU-tanh, "
-                         f"[{M}x{D}]x[{D}x{F}] (block 0 of every forward pass)", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
-                         "flops_per_launch": fc1_flops, "avg_launch_ms": avg_ms, "launches_timed": n_probe},
+            "dp_overlap": dp_overlap, "check": check_res,
+            "roofline": {"bound": "mfma",
+                         "kernel": "k_gemm_pipe<4,2,3,6,true,true,1,2,2,true> = 192x192 tile, three LDS slots, interleaved MFMA/LDS-DMA schedule: weight "
+                                   f"gradient of attn.qkv / mlp.fc1 (dW[N x {D}] = dY[{M} x N]^T X[{M} x {D}], N = {3 * D} and {F} alternating) + bias row "
+                                   "sums; largest share of GPU time (profiles/r02_kernel_table.md); runs on the weight-gradient stream BESIDE the dgrad "
+                                   "chain, so its duration is shared-CU time",
+                         "achieved": wg_ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": wg_ach / MFMA_BF16_PEAK_TFLOPS,
+                         "traffic": traffic, "flops_per_launch": wg_flops, "avg_launch_ms": wg_ms, "launches_timed": n_wp,
+                         "others": {
+                             "fwd_fc1_gelu": {"bound": "mfma", "kernel": f"k_gemm_pipe<4,2,4,6,false,false,2,1,2>: Mlp.fc1 + GELU-tanh [{M}x{D}]x[{D}x{F}], block 0 of "
+                                              "every forward pass (main stream, nothing beside it)", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
+                                              "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": committed_traffic("r01_fc1_traffic.json"),
+                                              "flops_per_launch": fc1_flops, "avg_launch_ms": avg_ms, "launches_timed": n_probe},
+                             "hbm": {"bound": "hbm", "kernel": "k_masked_clip_adam: mask -> clip -> AdamW (+ EMA, + bf16 shadow) over the flat arenas, "
+                                     "31 B/param (forget stage) and 38 B/param (remain stage) alternating", "achieved": sw_ach, "peak": HBM_PEAK_GBS,
+                                     "unit": "GB/s", "frac": sw_ach / HBM_PEAK_GBS, "traffic": committed_traffic("r02_sweep_traffic.json"),
+                                     "bytes_per_launch": sweep_bytes, "avg_launch_ms": sw_ms, "launches_timed": len(sweep_ms)}}},
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.model, latent, args.batch, args.cpu_batch)
@@ -188,6 +258,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if check_res is not None and not check_res["ok"]:
+        raise SystemExit(f"--check failed: {check_res}")
 
 
 if __name__ == "__main__":

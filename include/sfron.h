@@ -153,8 +153,17 @@ typedef struct sfron_gemm_desc {
                                         c_f32 + s * split_stride; sum the slabs with sfron_reduce_chunks */
   long split_stride;
   int tile_hint;                     /* 0 = auto; -1 = generic kernel; fast tiles 1 = 128x128, 2 = 256x192, 3 = 256x256, 4 = 384x192 */
+  float* a_rowsum;                   /* weight-gradient layout only (a_transposed = b_transposed = 1, EPI_F32, no split): fp32 [M],
+                                        a_rowsum[m] = sum_k op(A)[m][k] -- the bias gradient sum_rows dY of the same nn.Linear
+                                        (DiT/models.py:108-121 backward), taken from the dY tiles the GEMM already holds in LDS
+                                        (extra MFMAs against a ones fragment, shared by the workgroups of a tile row).  Only shapes
+                                        sfron_gemm_rowsum_supported accepts. */
+  float* rowsum_ws;                  /* with a_rowsum: fp32 scratch [(N / 192) * M] for the per-tile-column partial sums, added in a
+                                        fixed order by a small reduction launch on the same stream */
 } sfron_gemm_desc;
 int sfron_gemm_bf16(const sfron_gemm_desc* desc /* HOST pointer */, void* stream);
+/* 1 when a weight-gradient GEMM dW[M][N] = dY[K][M]^T X[K][N] of this shape can also produce a_rowsum (else use sfron_colsum) */
+int sfron_gemm_rowsum_supported(int M, int N, int K);
 
 /* ------------------------------------------------------------------ adaLN-Zero elementwise (norm.hip)
  * mod buffers are fp32 [batch][ldmod]; shift/scale/gate pointers already include the column offset of the
@@ -231,9 +240,15 @@ int sfron_unpatchify(const float* rows, int ld, int n, int C, int H, int W, int 
  * softmax(q k^T * hd^-0.5) v, non-causal (timm Attention as used at DiT/models.py:108,120).
  * Supported: hd in {64, 72}, T % 64 == 0. */
 int sfron_attn_fwd(const uint16_t* qkv, uint16_t* o, float* lse, int B, int T, int H, int hd, void* stream);
-/* dqkv [B*T][3*H*hd] bf16 = gradient wrt qkv; delta_scratch fp32 [B*H*T] */
+/* dqkv [B*T][3*H*hd] bf16 = gradient wrt qkv; delta_scratch fp32 [B*H*T] (used by the two-kernel form only).
+ * T = 128 / 256: ONE kernel, one 8-wave workgroup per (batch, head): S and dP are formed once per (query chunk, key block),
+ * dV and dK accumulate from registers, dS crosses LDS once and dQ is formed from that image -- 5 products, no atomics.
+ * Other T (multiples of 64): dQ kernel + dK/dV kernel (7 products). */
 int sfron_attn_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* delta_scratch,
                    uint16_t* dqkv, int B, int T, int H, int hd, void* stream);
+
+/* test hook: 2 = always the two-kernel backward, 0 = default; returns the previous setting (process-wide, not thread-safe) */
+int sfron_attn_bwd_form(int form);
 
 /* ------------------------------------------------------------------ whole-model DiT pass (dit_engine.hip)
  * Replaces autograd over DiT.forward (DiT/models.py:233-248) inside the SFR-on step (DiT/forget.py:271-288,310-319).
@@ -292,6 +307,10 @@ int sfron_dit_backward_dp(const sfron_dit_cfg* cfg, const float* params, const u
                           void* const* block_events, float* late_bias, uint16_t* ada_dmod_out, uint16_t* ada_sc_out, void* stream);
 int sfron_dit_scatter_late_bias(const sfron_dit_cfg* cfg, const float* late_bias, float* grads, void* stream);
 int sfron_aux_create(void** aux /* HOST out */);
+/* attach a probe (sfron_probe_create; NULL detaches): the backward pass then records an event pair on the weight-gradient
+ * stream around the qkv / fc1 weight-gradient GEMM (+ bias row sums) of every 9th block -- the kernel that holds the largest
+ * share of GPU time -- for bench.py's live roofline figure */
+int sfron_aux_set_probe(void* aux, void* probe);
 int sfron_aux_destroy(void* aux);
 
 #ifdef __cplusplus

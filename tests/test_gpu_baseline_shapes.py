@@ -1,0 +1,277 @@
+"""GPU parity AT THE BASELINE SIZES (DiT-XL/2, 256 px, batch 32 per GPU -> M = 8192 token rows, D = 1152, F = 4608):
+(a) every block GEMM of the engine (DiT/models.py:108-121 forward and backward: SURVEY.md appendix D) at its exact shape,
+    through the tile / grouped-order choice the dispatcher makes for that shape (tile_hint = 0, as dit_engine.hip calls it),
+    with the epilogue the engine fuses, against torch fp32 on the same bf16 inputs;
+(b) one whole DiT-XL/2 forward + backward at batch 32 against the CPU oracle (oracle.dit_ref restates DiT/models.py:145-248;
+    the timm Attention / Mlp / PatchEmbed boundary is "parity unpinned");
+(c) DiT-B/4 (BASELINE config 2) at FULL depth: three SFR-on iterations (DiT/forget.py:256-322) against the oracle, and the
+    north-star acceptance -- eps-pred MSE within 1e-4 of the reference path after 50 steps -- on DiT-B/4.
+Tolerances: fp32 outputs differ from torch by accumulation order only (rel-L2 < 1e-5 on K <= 8192); bf16 outputs by one bf16
+rounding (2^-9 relative per element); whole-model bounds as in tests/test_gpu_dit.py (bf16 GEMM operands)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+M, D, F = 8192, 1152, 4608
+T = 256
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return (torch.randn(shape, generator=g, device=DEV) * scale).to(torch.bfloat16)
+
+
+def _rel(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("name,N,K,epi", [("qkv", 3 * D, D, "bf16"), ("proj", D, D, "gate_res"), ("fc1", F, D, "gelu"),
+                                          ("fc2", D, F, "gate_res")])
+def test_forward_gemms_at_baseline_shapes(name, N, K, epi):
+    from sfron import ops, _lib
+    X, W = _rand((M, K), 1), _rand((N, K), 2, 0.03)
+    bias = torch.randn(N, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)) * 0.1
+    pre = X.float() @ W.float().t() + bias
+    if epi == "bf16":
+        C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        ops.gemm(X, W, M, N, K, bias=bias, c_bf16=C)
+        assert _rel(C, pre) < 4e-3
+        assert torch.allclose(C.float(), pre, rtol=1e-2, atol=2e-2)
+    elif epi == "gelu":
+        C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        aux = torch.empty_like(C)
+        ops.gemm(X, W, M, N, K, epilogue=_lib.EPI_GELU, bias=bias, c_bf16=C, aux=aux)
+        assert _rel(aux, pre) < 4e-3
+        want = torch.nn.functional.gelu(pre, approximate="tanh")
+        assert _rel(C, want) < 5e-3
+        assert torch.allclose(C.float(), want, rtol=1e-2, atol=1e-2)
+    else:
+        B = M // T
+        gate = torch.randn(B, 6 * D, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+        x0 = torch.randn(M, N, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+        x1 = torch.empty_like(x0)
+        aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        ops.gemm(X, W, M, N, K, epilogue=_lib.EPI_GATE_RES, bias=bias, c_f32=x1, resid=x0, aux=aux, gate=gate[:, 2 * D:],
+                 ldgate=6 * D, tokens=T)
+        want = x0 + gate[:, 2 * D:3 * D].repeat_interleave(T, dim=0) * pre
+        assert _rel(aux, pre) < 4e-3
+        assert _rel(x1, want) < 1e-5
+        assert torch.allclose(x1, want, rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("name,N,K,epi", [("qkv", D, 3 * D, "bf16"), ("proj", D, D, "bf16"), ("fc1", D, F, "bf16"),
+                                          ("fc2+gelu'", F, D, "dgelu")])
+def test_dgrad_gemms_at_baseline_shapes(name, N, K, epi):
+    """dX[M, N] = dY[M, K] W[K, N] (W row-major [out = K][in = N]: the forward weight read transposed)."""
+    from sfron import ops, _lib
+    dY, W = _rand((M, K), 6, 0.1), _rand((K, N), 7, 0.03)
+    want = dY.float() @ W.float()
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    if epi == "bf16":
+        ops.gemm(dY, W, M, N, K, b_t=True, c_bf16=C)
+        Cf = torch.empty(M, N, dtype=torch.float32, device=DEV)
+        ops.gemm(dY, W, M, N, K, b_t=True, epilogue=_lib.EPI_F32, c_f32=Cf)
+        assert _rel(Cf, want) < 1e-5
+    else:
+        hpre = _rand((M, N), 8, 1.5)
+        ops.gemm(dY, W, M, N, K, b_t=True, epilogue=_lib.EPI_DGELU, c_bf16=C, aux=hpre)
+        h = hpre.float().requires_grad_(True)
+        torch.nn.functional.gelu(h, approximate="tanh").backward(want)
+        want = h.grad
+    assert _rel(C, want) < 5e-3
+    assert torch.allclose(C.float(), want, rtol=1.5e-2, atol=2e-3 * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("name,N,K,rowsum", [("qkv", 3 * D, D, True), ("proj", D, D, False), ("fc1", F, D, True), ("fc2", D, F, False)])
+def test_wgrad_gemms_at_baseline_shapes(name, N, K, rowsum):
+    """dW[N, K] = dY[M, N]^T X[M, K] with the M = 8192 token rows as the contraction; qkv / fc1 also produce their bias
+    gradient sum_rows dY inside the same launch (a_rowsum)."""
+    from sfron import ops, _lib
+    dY, X = _rand((M, N), 9, 0.1), _rand((M, K), 10)
+    want = dY.float().t() @ X.float()
+    dW = torch.full((N, K), float("nan"), dtype=torch.float32, device=DEV)
+    db = torch.full((N,), float("nan"), dtype=torch.float32, device=DEV) if rowsum else None
+    if rowsum:
+        assert _lib.lib().sfron_gemm_rowsum_supported(N, K, M) == 1
+    ops.gemm(dY, X, N, K, M, a_t=True, b_t=True, epilogue=_lib.EPI_F32, c_f32=dW, a_rowsum=db)
+    assert _rel(dW, want) < 1e-5
+    assert torch.allclose(dW, want, rtol=2e-4, atol=2e-4 * M ** 0.5)
+    if rowsum:
+        want_b = dY.float().sum(0)
+        assert torch.allclose(db, want_b, rtol=1e-5, atol=1e-3)
+        # same launch without the row sums: the weight gradient itself is unchanged, bit for bit
+        dW2 = torch.empty_like(dW)
+        ops.gemm(dY, X, N, K, M, a_t=True, b_t=True, epilogue=_lib.EPI_F32, c_f32=dW2)
+        assert torch.equal(dW, dW2)
+
+
+def test_rowsum_small_shapes_and_rejections():
+    from sfron import ops, _lib
+    L = _lib.lib()
+    assert L.sfron_gemm_rowsum_supported(192, 192, 128) == 1 and L.sfron_gemm_rowsum_supported(192, 192, 192) == 0
+    assert L.sfron_gemm_rowsum_supported(128, 192, 128) == 0
+    for (Mw, Nw, Kw) in [(192, 192, 128), (384, 576, 320), (768, 192, 512)]:
+        dY, X = _rand((Kw, Mw), Mw + Kw, 0.3), _rand((Kw, Nw), Nw)
+        dW = torch.empty(Mw, Nw, dtype=torch.float32, device=DEV)
+        db = torch.empty(Mw, dtype=torch.float32, device=DEV)
+        ops.gemm(dY, X, Mw, Nw, Kw, a_t=True, b_t=True, epilogue=_lib.EPI_F32, c_f32=dW, a_rowsum=db)
+        ref = torch.empty_like(dW)
+        ops.gemm(dY, X, Mw, Nw, Kw, a_t=True, b_t=True, epilogue=_lib.EPI_F32, c_f32=ref, tile_hint=-1)
+        assert torch.equal(dW, ref)
+        assert torch.allclose(db, dY.float().sum(0), rtol=1e-6, atol=1e-4)
+    dY, X = _rand((192, 192), 1), _rand((192, 192), 2)
+    with pytest.raises(_lib.SfronError):          # 3 k-tiles: not a shape of the three-slot kernel
+        ops.gemm(dY, X, 192, 192, 192, a_t=True, b_t=True, epilogue=_lib.EPI_F32,
+                 c_f32=torch.empty(192, 192, dtype=torch.float32, device=DEV), a_rowsum=torch.empty(192, device=DEV))
+
+
+def _pair(name_or_cfg, batch, seed, std=0.02):
+    from oracle import dit_ref
+    from sfron import dit
+    torch.manual_seed(seed)
+    if isinstance(name_or_cfg, str):
+        ref = dit_ref.build(name_or_cfg, input_size=32)
+        model = dit.DiT_models[name_or_cfg](input_size=32, num_classes=1000, batch_size=batch)
+    else:
+        ref = dit_ref.DiT(**name_or_cfg)
+        model = dit.DiT(batch_size=batch, **name_or_cfg)
+    dit_ref.randomize_zero_init(ref, std=std, seed=seed + 1)
+    model.load_state_dict(ref.state_dict())
+    return ref, model
+
+
+def test_xl2_batch32_forward_backward_vs_oracle():
+    """The headline configuration itself: DiT-XL/2 (28 blocks, 16 heads of 72), 256 px latents, batch 32, one forward +
+    backward pass (DiT/models.py:233-248 and its autograd) against the CPU oracle; same bounds as the small cases."""
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    B = 32
+    ref, model = _pair("DiT-XL/2", B, seed=21)
+    gen = torch.Generator().manual_seed(22)
+    x = torch.randn(B, 4, 32, 32, generator=gen)
+    t = torch.randint(0, 1000, (B,), generator=gen)
+    t[0], t[1] = 0, 999
+    y = torch.randint(0, 1000, (B,), generator=gen)
+    drop = (torch.rand(B, generator=gen) < 0.1).long()
+    w = torch.randn(B, 8, 32, 32, generator=gen) * 1e-2
+    ref.train()
+    out_ref = ref(x, t, y, force_drop_ids=drop)
+    (out_ref * w).sum().backward()
+    model.train()
+    out = model(x.to(DEV), t.to(DEV), y.to(DEV), force_drop_ids=drop.to(DEV))
+    e_out = _rel(out.cpu(), out_ref)
+    model.zero_grad()
+    (out * w.to(DEV)).sum().backward()
+    worst, worst_name = 0.0, ""
+    dots = norms_a = norms_b = 0.0
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        if not q.requires_grad:
+            continue
+        ga, gb = p.grad.detach().cpu().flatten(), q.grad.flatten()
+        e = ((ga - gb).norm() / (gb.norm() + 1e-30)).item()
+        if e > worst:
+            worst, worst_name = e, n
+        dots += torch.dot(ga.double(), gb.double()).item()
+        norms_a += ga.double().pow(2).sum().item()
+        norms_b += gb.double().pow(2).sum().item()
+    cos = dots / (norms_a ** 0.5 * norms_b ** 0.5)
+    print(f"DiT-XL/2 B=32: output rel-L2 {e_out:.3e}; worst per-tensor gradient rel-L2 {worst:.3e} ({worst_name}); cosine {cos:.6f}")
+    assert e_out < 1.5e-2, e_out
+    assert worst < 4e-2, (worst_name, worst)
+    assert cos > 0.9995, cos
+
+
+B4 = dict(input_size=32, patch_size=4, in_channels=4, hidden_size=768, depth=12, num_heads=12, num_classes=1000)
+
+
+def _update_agreement(ref, eng, p0):
+    """How the parameter UPDATES (p - p0) of the two paths compare: fraction of coordinates (with a non-negligible oracle
+    update) that moved in the same direction, and the bulk relative error of the update vector."""
+    same = tot = 0
+    num = den = 0.0
+    for n, q in ref.named_parameters():
+        if not q.requires_grad:
+            continue
+        du_ref = (q.detach() - p0[n]).flatten()
+        du = (eng.view(eng.params, n).cpu() - p0[n]).flatten()
+        big = du_ref.abs() > 0.05 * du_ref.abs().max()
+        same += int((torch.sign(du[big]) == torch.sign(du_ref[big])).sum())
+        tot += int(big.sum())
+        num += (du - du_ref).double().pow(2).sum().item()
+        den += du_ref.double().pow(2).sum().item()
+    return same / max(1, tot), (num / den) ** 0.5
+
+
+def test_dit_b4_full_depth_sfron_iterations_vs_oracle():
+    """BASELINE config 2 (DiT-B/4, 12 blocks, 12 heads of 64, 64 tokens) through three SFR-on iterations at batch 8."""
+    from oracle import diffusion_ref as dref
+    from oracle import sfron_ref
+    from sfron import data, diffusion, step
+    B = 8
+    ref, model = _pair(B4, B, seed=31, std=0.02)
+    model.train()
+    gm = torch.Generator().manual_seed(32)
+    mask = {"module." + n: (torch.rand(p.shape, generator=gm) < 0.5) for n, p in ref.named_parameters() if p.requires_grad}
+    mask["module.pos_embed"] = 0
+    hp = dict(lr=1e-4, forget_alpha=1e-3, grad_clip=1.0, ema_decay=0.9999, mask=mask, unlearn_loss="ga", forget_class=207)
+    orc = sfron_ref.DiTSfronOracle(ref, dref.DiffusionTables(1000), **hp)
+    runner = step.DiTSFRon(model, diffusion.create_diffusion(""), **hp)
+    p0 = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    kw = dict(global_batch=B, num_classes=1000, forget_class=207)
+    for it in range(3):
+        f, r = data.synthetic_batch(3, it, "forget", **kw), data.synthetic_batch(3, it, "remain", **kw)
+        want = orc.step({k: v.long() if k == "drop" else v for k, v in f.items()},
+                        {k: v.long() if k == "drop" else v for k, v in r.items()})
+        got = runner.step({k: v.to(DEV) for k, v in f.items()}, {k: v.to(DEV) for k, v in r.items()})
+        assert got["forget_mse"].mean().item() == pytest.approx(want["forget_mse"], rel=3e-2)
+        assert got["remain_mse"].mean().item() == pytest.approx(want["remain_mse"], rel=3e-2)
+        assert got["stats"][0].item() == pytest.approx(want["forget_gnorm"], rel=5e-2)
+    agree, bulk = _update_agreement(ref, model.engine, p0)
+    print(f"DiT-B/4 depth 12, 3 iterations: update sign agreement {agree:.4f}, bulk relative error of the update {bulk:.3f}")
+    assert agree > 0.97, agree
+    assert bulk < 0.35, bulk
+    assert runner.opt.step_count == 6
+
+
+def test_dit_b4_fifty_step_eps_mse_within_1e4_of_oracle():
+    """North-star acceptance on BASELINE config 2: after 50 SFR-on steps of DiT-B/4 (full depth), the eps-pred MSE of the HIP
+    path on a held-out batch is within 1e-4 of the CPU oracle's (same seeds, masks, hyper-parameters)."""
+    from oracle import diffusion_ref as dref
+    from oracle import sfron_ref
+    from sfron import data, diffusion, step
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    B = 8
+    ref, model = _pair(B4, B, seed=41, std=0.02)
+    model.train()
+    gm = torch.Generator().manual_seed(42)
+    mask = {"module." + n: (torch.rand(p.shape, generator=gm) < 0.5) for n, p in ref.named_parameters() if p.requires_grad}
+    mask["module.pos_embed"] = 0
+    hp = dict(lr=1e-4, forget_alpha=1e-3, grad_clip=1.0, ema_decay=0.9999, mask=mask, unlearn_loss="ga", forget_class=207)
+    orc = sfron_ref.DiTSfronOracle(ref, dref.DiffusionTables(1000), **hp)
+    runner = step.DiTSFRon(model, diffusion.create_diffusion(""), **hp)
+    kw = dict(global_batch=B, num_classes=1000, forget_class=207)
+    worst = 0.0
+    for it in range(50):
+        f, r = data.synthetic_batch(13, it, "forget", **kw), data.synthetic_batch(13, it, "remain", **kw)
+        want = orc.step({k: v.long() if k == "drop" else v for k, v in f.items()},
+                        {k: v.long() if k == "drop" else v for k, v in r.items()})
+        got = runner.step({k: v.to(DEV) for k, v in f.items()}, {k: v.to(DEV) for k, v in r.items()})
+        worst = max(worst, abs(got["remain_mse"].mean().item() - want["remain_mse"]),
+                    abs(got["forget_mse"].mean().item() - want["forget_mse"]))
+    ref.eval()
+    hb = data.synthetic_batch(14, 0, "remain", global_batch=32, num_classes=1000, forget_class=207)
+    tab = dref.DiffusionTables(1000)
+    with torch.no_grad():
+        t_ref = dref.training_losses(tab, lambda x, t, y: ref(x, t, y), hb["x0"], hb["t"], dict(y=hb["y"]), hb["noise"])
+    model.eval()
+    d = runner.diffusion
+    hbd = {k: v.to(DEV) for k, v in hb.items()}
+    with torch.no_grad():
+        out = model(d.q_sample(hbd["x0"], hbd["t"], hbd["noise"]), hbd["t"], hbd["y"])
+    mse_hip, _, _ = d.loss_fwd_bwd(out.contiguous(), hbd["x0"], hbd["t"], hbd["noise"], 1.0)
+    final_gap = abs(mse_hip.mean().item() - t_ref["mse"].mean().item())
+    print(f"DiT-B/4: max per-step |mse gap| over 50 steps = {worst:.2e}; held-out eps-MSE gap after 50 steps = {final_gap:.2e} "
+          f"(oracle {t_ref['mse'].mean().item():.5f})")
+    assert final_gap < 1e-4, final_gap
+    assert worst < 2e-3, worst        # per-step training-batch mse (bf16 forward noise on a loss of O(1)); measured bound in DESIGN.md

@@ -158,3 +158,42 @@ def test_attention_fwd_bwd(B, T, H, hd):
     # aggregate error must be far below bf16 rounding noise of the reference itself
     err = (dqkv.float().cpu() - g).norm() / g.norm()
     assert err < 2e-2, err
+
+
+@pytest.mark.parametrize("B,T,H,hd", [(2, 256, 2, 64), (3, 256, 3, 72), (2, 128, 2, 72), (1, 128, 4, 64), (32, 256, 16, 72)])
+def test_attention_backward_fused_vs_two_kernel_and_torch(B, T, H, hd):
+    """The one-workgroup-per-(batch, head) backward (T = 128 / 256: S and dP formed once, dQ from the dS image in LDS) against
+    the two-kernel form (dQ kernel + dK/dV kernel, forced through sfron_attn_bwd_form) and against torch autograd; the last
+    case is the DiT-XL/2 batch-32 launch itself (512 workgroups).  Run twice: bitwise reproducible (no float atomics)."""
+    from sfron import ops, _lib
+    gen = torch.Generator().manual_seed(T * 7 + H + hd)
+    D = H * hd
+    qkv = (torch.randn(B * T, 3 * D, generator=gen) * 1.2).to(torch.bfloat16)
+    qkv[3, :hd] *= 5.0
+    qkv[7, D:D + hd] *= 5.0
+    d_o = (torch.randn(B * T, D, generator=gen) * 0.2).to(torch.bfloat16)
+    qd, dd = qkv.to(DEV), d_o.to(DEV)
+    o, lse = ops.attn_fwd(qd, B, T, H, hd)
+    L = _lib.lib()
+    fused = ops.attn_bwd(qd, o, dd, lse, B, T, H, hd)
+    again = ops.attn_bwd(qd, o, dd, lse, B, T, H, hd)
+    assert torch.equal(fused, again)
+    old = L.sfron_attn_bwd_form(2)
+    try:
+        two = ops.attn_bwd(qd, o, dd, lse, B, T, H, hd)
+    finally:
+        L.sfron_attn_bwd_form(old)
+    # reference: torch autograd in fp32 on the GPU (same bf16 inputs)
+    x = qd.float().requires_grad_(True)
+    q, k, v = x.view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4).unbind(0)
+    att = ((q * hd ** -0.5) @ k.transpose(-2, -1)).softmax(-1)
+    (att @ v).transpose(1, 2).reshape(B * T, D).backward(dd.float())
+    g = x.grad
+    for name, got in (("fused", fused), ("two-kernel", two)):
+        err = ((got.float() - g).norm() / g.norm()).item()
+        assert err < 2e-2, (name, err)
+        for w, nm in ((0, "dQ"), (1, "dK"), (2, "dV")):
+            e = ((got.float()[:, w * D:(w + 1) * D] - g[:, w * D:(w + 1) * D]).norm() / g[:, w * D:(w + 1) * D].norm()).item()
+            assert e < 2e-2, (name, nm, e)
+    # the two forms round P and dS to bf16 at the same points: they agree far inside the bound against fp32
+    assert ((fused.float() - two.float()).norm() / two.float().norm()).item() < 6e-3

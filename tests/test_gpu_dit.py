@@ -107,7 +107,8 @@ def test_sfron_iterations_vs_oracle(case, loss, micro):
         assert got["stats"][0].item() == pytest.approx(want["forget_gnorm"], rel=5e-2)
     # parameter UPDATE (p - p0) agrees in direction and size; EMA follows
     eng = model.engine
-    num = den = 0.0
+    num = den = err = 0.0
+    same = tot = 0
     for n, q in ref.named_parameters():
         if not q.requires_grad:
             continue
@@ -115,8 +116,16 @@ def test_sfron_iterations_vs_oracle(case, loss, micro):
         du = (eng.view(eng.params, n).cpu() - p0[n]).flatten()
         num += torch.dot(du, du_ref).item()
         den += du_ref.norm().item() ** 2
-        assert (du - du_ref).abs().max().item() < 6 * 2e-4     # Adam moves each weight <= lr per step
+        err += (du - du_ref).norm().item() ** 2
+        big = du_ref.abs() > 0.05 * du_ref.abs().max()          # coordinates with a non-negligible oracle update
+        same += int((torch.sign(du[big]) == torch.sign(du_ref[big])).sum())
+        tot += int(big.sum())
     assert num / den > 0.9, num / den
+    # (an absolute |du - du_ref| bound would be vacuous: Adam moves a weight by at most lr per step whatever the gradient.)
+    # What carries information: the share of coordinates that moved the same way and the bulk error of the update vector.
+    print(f"{case}/{loss}/micro{micro}: update sign agreement {same / tot:.4f}, bulk relative error {(err / den) ** 0.5:.3f}")
+    assert same / tot > 0.95, same / tot
+    assert (err / den) ** 0.5 < 0.45, (err / den) ** 0.5
     for n in ("blocks.0.mlp.fc1.weight", "pos_embed", "final_layer.linear.bias"):
         e = eng.view(runner.ema, n).cpu()
         assert torch.allclose(e, orc.ema[n], atol=5e-4), n

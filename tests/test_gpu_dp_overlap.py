@@ -12,7 +12,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def test_overlapped_allreduce_path_matches_plain_path(monkeypatch):
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def test_overlapped_allreduce_path_matches_plain_path():
     from sfron import data, diffusion, step
     from test_gpu_dit import CASES, build_pair
     cfg = CASES["hd72"]
@@ -23,24 +30,28 @@ def test_overlapped_allreduce_path_matches_plain_path(monkeypatch):
 
     def run(overlap):
         _, model = build_pair(cfg, B, seed=21)
-        runner = step.DiTSFRon(model, diffusion.create_diffusion(""), **hp)
+        runner = step.DiTSFRon(model, diffusion.create_diffusion(""), overlap_allreduce=overlap, **hp)
         assert runner._overlap_enabled() == overlap
         for it in range(2):
             out = runner.step(*bat(it))
         torch.cuda.synchronize()
         return model.engine.params.clone(), model.engine.grads.clone(), out["stats"].clone()
 
-    monkeypatch.setenv("SFRON_DP_OVERLAP", "0")
     p0, g0, s0 = run(False)
     created = False
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ["MASTER_PORT"] = str(_free_port())
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
         created = True
     try:
-        monkeypatch.setenv("SFRON_DP_OVERLAP", "force")
         p1, g1, s1 = run(True)
+        # the run-time check bench.py uses before it turns the overlap on: one pass each way from the same state
+        _, model = build_pair(cfg, B, seed=21)
+        runner = step.DiTSFRon(model, diffusion.create_diffusion(""), **hp)
+        before = model.engine.params.clone()
+        assert runner.verify_overlap(bat(0)[0]) is True
+        assert torch.equal(before, model.engine.params) and runner.overlap is False
     finally:
         if created:
             dist.destroy_process_group()
@@ -48,19 +59,19 @@ def test_overlapped_allreduce_path_matches_plain_path(monkeypatch):
     assert torch.equal(p0, p1) and torch.equal(s0, s1)
 
 
-def test_two_rank_overlapped_exchange_matches_single_process():
+def test_two_rank_overlapped_exchange_matches_single_process(tmp_path):
     """Two ranks (two processes sharing cuda:0, gloo transport -- RCCL refuses two ranks on one device) run the overlapped
     exchange on their halves of the global batch; gradients norms, parameters and EMA match the single-process run on the whole
     batch and the replicas stay identical (tools/rehearse_dp2.py)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SFRON_DP_OVERLAP="1")
+    env = dict(os.environ, SFRON_REHEARSE_REF=str(tmp_path / "dp2_ref.pt"))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "rehearse_dp2.py"), "--single"], cwd=root, env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29537", os.path.join(root, "tools", "rehearse_dp2.py")], cwd=root, env=env,
+                        "--master-port", str(_free_port()), os.path.join(root, "tools", "rehearse_dp2.py")], cwd=root, env=env,
                        capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("PASS=True") == 2

@@ -129,7 +129,7 @@ def test_gemm_rejects_bad_args():
         ops.gemm(A, A, 128, 128, 60, c_bf16=torch.zeros(128, 128, dtype=torch.bfloat16, device=DEV))   # K % 8 != 0
 
 
-@pytest.mark.parametrize("hint", [1, 2, 3, 12, 13, 32, 42])
+@pytest.mark.parametrize("hint", [1, 2, 3, 32, 42])
 @pytest.mark.parametrize("layout", ["fwd", "dgrad", "wgrad"])
 def test_fast_tiles_all_layouts(hint, layout):
     """LDS-DMA fast path (tile_hint 1: 128x128, 2: 256x128, 3: 256x256) vs the generic kernel and torch."""
@@ -158,8 +158,9 @@ def test_fast_tiles_all_layouts(hint, layout):
 
 
 @pytest.mark.parametrize("layout", ["fwd", "dgrad", "wgrad"])
-def test_ring_tile_192(layout):
-    """192x192 ring tile (hint 15) on a 384 x 576 output, K = 96 (3 stages < ring depth) and K = 1024."""
+def test_tile_192_variants(layout):
+    """192x192 tile on a 384 x 576 output, K = 96 (generic kernel: K % 64 != 0) and K = 1024: compiler-scheduled (5),
+    hand-pipelined (35), interleaved (45) and three-slot (55) forms all accumulate in the generic kernel's order."""
     from sfron import ops, _lib
     for K in (96, 1024):
         M, N = 384, 576
@@ -175,7 +176,7 @@ def test_ring_tile_192(layout):
             want = A.float().t() @ B.float()
         Cf = torch.zeros(M, N, dtype=torch.float32, device=DEV)
         Cg = torch.zeros(M, N, dtype=torch.float32, device=DEV)
-        ops.gemm(A.to(DEV), B.to(DEV), M, N, K, epilogue=_lib.EPI_F32, c_f32=Cf, tile_hint=15, **kw)
+        ops.gemm(A.to(DEV), B.to(DEV), M, N, K, epilogue=_lib.EPI_F32, c_f32=Cf, tile_hint=5, **kw)
         Cp = torch.zeros(M, N, dtype=torch.float32, device=DEV)
         ops.gemm(A.to(DEV), B.to(DEV), M, N, K, epilogue=_lib.EPI_F32, c_f32=Cp, tile_hint=35, **kw)
         ops.gemm(A.to(DEV), B.to(DEV), M, N, K, epilogue=_lib.EPI_F32, c_f32=Cg, tile_hint=-1, **kw)

@@ -14,7 +14,7 @@ import torch.distributed as dist
 DEV = "cuda:0"
 CFG = dict(input_size=16, patch_size=2, in_channels=4, hidden_size=144, depth=3, num_heads=2, num_classes=10)
 GB, STEPS = 8, 3
-REF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "dp2_ref.pt")
+REF = os.environ.get("SFRON_REHEARSE_REF") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "dp2_ref.pt")
 
 
 def run(world, rank):
@@ -24,7 +24,7 @@ def run(world, rank):
     dit.randomize_zero_init(model, std=0.05, seed=4)
     gm = torch.Generator().manual_seed(5)
     runner = step.DiTSFRon(model, diffusion.create_diffusion("", device=DEV), lr=2e-4, forget_alpha=0.3, grad_clip=1.0, ema_decay=0.99,
-                           mask=None, unlearn_loss="ga", forget_class=3)
+                           mask=None, unlearn_loss="ga", forget_class=3, overlap_allreduce=world > 1)
     runner.mask_arena = (torch.rand(model.engine.n_trainable, generator=gm) < 0.5).to(torch.uint8).to(DEV)
     runner.opt.mask = runner.mask_arena
     kw = dict(num_classes=CFG["num_classes"], forget_class=3, input_size=CFG["input_size"], device=DEV)

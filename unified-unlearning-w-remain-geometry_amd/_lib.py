@@ -4,8 +4,9 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SFRON_LIB points the binding at another build of the same library (kernel A-B experiments); never a fallback
-LIB_PATH = os.environ.get("SFRON_LIB") or os.path.join(_HERE, "libsfron.so")
+# tools/ may point LIB_PATH at another build of the same library (the debug-knob build, `make dbg`) BEFORE the first lib()
+# call; the product reads no environment variable and has no fallback
+LIB_PATH = os.path.join(_HERE, "libsfron.so")
 
 
 class SfronError(RuntimeError):
@@ -50,12 +51,14 @@ class GemmDesc(ctypes.Structure):
                 ("bias", c_void_p), ("c_bf16", c_void_p), ("ldc_bf16", c_int), ("c_f32", c_void_p), ("ldc_f32", c_int),
                 ("aux", c_void_p), ("ldaux", c_int), ("gate", c_void_p), ("ldgate", c_int), ("pos", c_void_p),
                 ("tokens", c_int), ("accumulate", c_int), ("resid", c_void_p), ("split_k", c_int),
-                ("split_stride", ctypes.c_long), ("tile_hint", c_int)]
+                ("split_stride", ctypes.c_long), ("tile_hint", c_int), ("a_rowsum", c_void_p),
+                ("rowsum_ws", c_void_p)]
 
 
 EPI_BF16, EPI_F32, EPI_GELU, EPI_GATE_RES, EPI_DGELU, EPI_POS = range(6)
 
 _PROTOS["sfron_gemm_bf16"] = (c_int, [POINTER(GemmDesc), _S])
+_PROTOS["sfron_gemm_rowsum_supported"] = (c_int, [c_int, c_int, c_int])
 _PROTOS.update({
     "sfron_rows_per_chunk": (c_int, [c_int]),
     "sfron_ln_modulate_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _S]),
@@ -79,6 +82,7 @@ _PROTOS.update({
     "sfron_unpatchify": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _S]),
     "sfron_attn_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _S]),
     "sfron_attn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _S]),
+    "sfron_attn_bwd_form": (c_int, [c_int]),
 })
 
 
@@ -98,6 +102,7 @@ _PROTOS.update({
     "sfron_dit_scatter_late_bias": (c_int, [POINTER(DitCfg), _P, _P, _S]),
     "sfron_aux_create": (c_int, [POINTER(c_void_p)]),
     "sfron_aux_destroy": (c_int, [c_void_p]),
+    "sfron_aux_set_probe": (c_int, [c_void_p, c_void_p]),
     "sfron_dit_forward_probed": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_probe_create": (c_int, [c_int, POINTER(c_void_p)]),
     "sfron_probe_reset": (c_int, [c_void_p]),

@@ -19,6 +19,7 @@
 // head_dim 64 -> 128-B image rows, 2 k-steps, 4 d-tiles; head_dim 72 (DiT-XL) -> 192-B rows (96 columns,
 // zero padded), 3 k-steps, 5 d-tiles.
 #include "common.h"
+#include <utility>
 #include "../../include/sfron.h"
 
 namespace {
@@ -110,6 +111,42 @@ __device__ __forceinline__ bf16x4 asm_read_tr(unsigned addr) {
 __device__ __forceinline__ void lds_reads_done() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
+}
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+template <int OFF> __device__ __forceinline__ bf16x4 asm_read_tr_off(unsigned addr) {
+  bf16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+// Permuted column fragments (frag_cols_perm) as base register + immediate: for a lane, the chunk swizzle of its rows
+// (4g + q and 16 + 4g + q of a 32-row step) is one constant, and XOR by it is affine in the d-tile index within a
+// 4-chunk group (HDP 96: two base registers, even / odd d-tile) -- so the per-(d-tile, k-step, half) addresses that hipcc
+// otherwise hoists out of the chunk loop and spills are immediates.
+template <int HDP> struct ColPerm {
+  static constexpr int NB = HDP == 96 ? 2 : HDP / 16;
+  int b[NB];                                   // byte offsets inside an image
+  __device__ __forceinline__ void init(int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) b[k] = 2 * (aoff<HDP>(4 * g + q, 2 * k + (p >> 1)) + 4 * (p & 1));
+  }
+  static constexpr int sel(int dt) { return HDP == 96 ? (dt & 1) : dt; }
+  static constexpr int imm(int dt, int s2, int hi) { return 2 * ((HDP == 96 ? 32 * (dt >> 1) : 0) + (32 * s2 + 16 * hi) * HDP); }
+};
+template <int HDP, int DT, int S2> __device__ __forceinline__ bf16x8 col_frag(const unsigned (&a)[ColPerm<HDP>::NB]) {
+  const bf16x4 lo = asm_read_tr_off<ColPerm<HDP>::imm(DT, S2, 0)>(a[ColPerm<HDP>::sel(DT)]);
+  const bf16x4 hi = asm_read_tr_off<ColPerm<HDP>::imm(DT, S2, 1)>(a[ColPerm<HDP>::sel(DT)]);
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// (register-constraint asm lives in __device__ helpers: inside a __global__ body the host pass rejects the "v" constraint)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, __bf16* dst, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t*)dst, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void asm_write_b64(unsigned addr, bf16x4 v) {
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 template <int HDP> __device__ __forceinline__ bf16x8 frag_cols_perm_asm(const __bf16* img, int rbase, int col0, int lane) {
   const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
@@ -553,6 +590,310 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dkv(const __bf16* __restrict__ 
   }
 }
 
+
+// ------------------------------------------------------------------------------------- fused backward (dQ, dK, dV)
+// One workgroup = 8 waves = one (batch, head); wave w owns the 16*KT keys [w*16*KT, (w+1)*16*KT) and keeps dK^T / dV^T of them
+// in accumulators while the workgroup sweeps the queries in 64-row chunks (Q / dO chunks through the 3-slot LDS-DMA ring).
+// S and dP are formed ONCE per (query chunk, key block) with the key on the MFMA lane: their accumulators, packed to bf16,
+// are the B operands of dV^T += dO^T P and dK^T += Q^T dS straight from registers; dS crosses LDS once (a [keys][64 queries]
+// bf16 image, 8-byte stores, conflict-free both ways) and dQ of the chunk = dS K is formed from that image and a resident
+// K image by transposed reads -- 5 matrix products instead of the 7 of the two-kernel form, one prologue instead of two,
+// no delta round trip through HBM (delta = rowsum(dO * O) is computed in the prologue into LDS).
+// No float atomics: dQ of a chunk is summed over all keys inside one wave's accumulators (fixed order).
+namespace {
+constexpr int FNW = 8, FNT = FNW * 64;
+
+// dS^T image [keys][64 queries], 128-B rows of 16 slots x 4 queries; slot ^= pi(key & 15), pi = bit permutation
+// (b2 b1 | b3 b0): 16 consecutive keys x one slot -> 16 distinct slots (ds_write_b64, banks mod 32), and the 8 consecutive
+// keys x 4 slots of one half-wave transposed read tile the 64 banks exactly (keys of equal parity share a bank half).
+__device__ __forceinline__ int ds_pi(int key) { return (((key >> 1) & 3) << 2) | (key & 1) | (((key >> 3) & 1) << 1); }
+__device__ __forceinline__ int ds_off(int key, int slot) { return key * 64 + ((slot ^ ds_pi(key)) << 2); }
+
+// LDS-DMA plan for a group of 64-row images (each [64][hd] rows of a row-major tensor): instruction j of the group fills
+// piece (j % CPR) of image (j / CPR); the FNW waves take j = wave + FNW * i.
+template <int HDP, int NIMG>
+struct GroupDma {
+  static constexpr int CPR = HDP / 8;
+  static constexpr int PER_WAVE = NIMG * CPR / FNW;
+  static_assert((NIMG * CPR) % FNW == 0, "pieces must split over the waves");
+  int off[PER_WAVE];
+  bool valid[PER_WAVE];
+  // ld_of(img) / base offset (elements) of image img are wave-uniform
+  template <class LD> __device__ __forceinline__ void init(LD ld_of, int hd, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int j = wave + FNW * i, img = j / CPR, jj = j % CPR;
+      const int e = jj * 64 + lane, row = e / CPR, p = e % CPR;
+      const int c = p ^ aswz<HDP>(row);
+      valid[i] = c * 8 < hd;
+      off[i] = 2 * (row * ld_of(img) + c * 8);
+    }
+  }
+};
+}  // namespace
+
+template <int HDP, int KS, int NDT, int KT>
+__global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict__ qkv, const __bf16* __restrict__ o,
+                                                        const __bf16* __restrict__ d_o, const float* __restrict__ lse,
+                                                        __bf16* __restrict__ dqkv, int H, int hd, float scale) {
+  constexpr int T = FNW * 16 * KT, NCH = T / 64, IMG = 64 * HDP;
+  constexpr int ND0 = (NDT + 1) / 2, ND1 = NDT - ND0;       // d-tiles of the two wave groups in the dQ phase
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+  __bf16* const ringb = smem;                                // [NSLOT][2][64][HDP]: Q / dO chunks
+  __bf16* const imgK = smem + NSLOT * 2 * IMG;               // [T][HDP]
+  __bf16* const imgS = imgK + NCH * IMG;                     // [T keys][64 queries]
+  float* const s_lse = reinterpret_cast<float*>(imgS + T * 64);
+  float* const s_del = s_lse + T;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // neighbouring heads of one sample read neighbouring 144-B column slices of the same rows: keep them on one XCD's L2
+  const int nblk = gridDim.x;
+  const int bh = (nblk & 7) == 0 ? (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int b = bh / H, h = bh % H;
+  const int D = H * hd, ld = 3 * D;
+  const int k0 = wave * (16 * KT);
+  const __bf16* base = qkv + (size_t)b * T * ld + h * hd;
+  const __bf16* dob = d_o + (size_t)b * T * D + h * hd;
+  const __bf16* ob = o + (size_t)b * T * D + h * hd;
+  const float c = scale * LOG2E;
+
+  GroupDma<HDP, 2> dmaC;        // one Q / dO chunk
+  GroupDma<HDP, NCH> dmaK;      // the whole K image
+  dmaC.init([&](int img) { return img ? D : ld; }, hd, wave, lane);
+  dmaK.init([&](int) { return ld; }, hd, wave, lane);
+  const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(base + D), 0, 0x7fffffff, 0x00020000);
+  constexpr int CPR = HDP / 8, PC = GroupDma<HDP, 2>::PER_WAVE;
+  auto issue_chunk = [&](int ch) {
+    __bf16* slot = ringb + (ch % NSLOT) * 2 * IMG;
+#pragma unroll
+    for (int i = 0; i < PC; ++i) {
+      const int j = wave + FNW * i, img = j / CPR, jj = j % CPR;
+      if (dmaC.valid[i])
+        dma16(img ? rsO : rsQ, slot + img * IMG + jj * 512, dmaC.off[i], ch * 64 * (img ? D : ld) * 2);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < GroupDma<HDP, NCH>::PER_WAVE; ++i) {
+    const int j = wave + FNW * i, img = j / CPR, jj = j % CPR;
+    if (dmaK.valid[i])
+      dma16(rsK, imgK + img * IMG + jj * 512, dmaK.off[i], img * 64 * ld * 2);
+  }
+  issue_chunk(0);
+  if (NCH > 1) issue_chunk(1);
+
+  // this wave's keys: the V row fragments stay in registers for the whole kernel; the K row fragments are re-read from the
+  // resident K image (holding both costs 48 registers and spills at head_dim 72)
+  bf16x8 fv[KT][KS];
+#pragma unroll
+  for (int ki = 0; ki < KT; ++ki)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) fv[ki][ks] = frag_rows_global(base + 2 * D, ld, k0 + 16 * ki, ks, hd, lane);
+  // -lse * log2(e) and delta[q] = sum_d dO[q][d] O[q][d] (two threads per query row, 8-byte loads)
+  for (int i = tid; i < T; i += FNT) s_lse[i] = -lse[(size_t)bh * T + i] * LOG2E;
+  {
+    const int half = tid & 1, hw = hd >> 1;
+    for (int q = tid >> 1; q < T; q += FNT / 2) {
+      const __bf16* pd = dob + (size_t)q * D + half * hw;
+      const __bf16* po = ob + (size_t)q * D + half * hw;
+      float dsum = 0.f;
+      for (int d = 0; d < hw; d += 4) {
+        const bf16x4 a = *reinterpret_cast<const bf16x4*>(pd + d), bb = *reinterpret_cast<const bf16x4*>(po + d);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dsum += bf2f(a[j]) * bf2f(bb[j]);
+      }
+      dsum += __shfl_xor(dsum, 1, 64);
+      if (!half) s_del[q] = dsum;
+    }
+  }
+  // pad columns of the ring and of the K image (never written by the DMA)
+  {
+    constexpr int NIMG = NSLOT * 2 + NCH;
+    if (hd < HDP) {
+      const uint4 z = make_uint4(0, 0, 0, 0);
+      for (int e = tid; e < NIMG * 64 * CPR; e += FNT) {
+        const int row = (e / CPR) & 63, pos = e % CPR;
+        if (((pos ^ aswz<HDP>(row)) << 3) >= hd) reinterpret_cast<uint4*>(smem)[e] = z;
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  f32x4 dk[KT][NDT], dv[KT][NDT];
+#pragma unroll
+  for (int ki = 0; ki < KT; ++ki)
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) { dk[ki][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[ki][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const unsigned sbase = lds_addr(imgS);
+  // dS^T stores: tile (ki, qt) -> row key = k0 + 16 ki + (lane & 15), logical slot 4 qt + g
+  unsigned wr_addr[KT];
+#pragma unroll
+  for (int ki = 0; ki < KT; ++ki) wr_addr[ki] = sbase + 2 * ((k0 + 16 * ki + (lane & 15)) * 64);
+  const int wr_pi = ds_pi(lane & 15);        // k0 + 16 ki is a multiple of 16
+  // dQ phase: wave -> query tile qi of the chunk and a group of d-tiles
+  const int qi = wave & 3, dgrp = wave >> 2;
+  const int dt0 = dgrp ? ND0 : 0, nd = dgrp ? ND1 : ND0;
+  ColPerm<HDP> cp;
+  cp.init(lane);
+  // transposed-read addresses of the K column fragments of this wave's d-tiles (key step 0) and of the dS^T fragment
+  // (permuted k-slot map: rows 4g + q4 and 16 + 4g + q4 of a 32-key step)
+  unsigned rdK[ND0], rdS[2];
+  {
+    const int i = lane & 15, q4 = i >> 2, p = i & 3;
+#pragma unroll
+    for (int k = 0; k < ND0; ++k)
+      rdK[k] = lds_addr(imgK) + 2 * (aoff<HDP>(4 * g + q4, 2 * (dt0 + (k < nd ? k : 0)) + (p >> 1)) + 4 * (p & 1));
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int r = 16 * hh + 4 * g + q4;                  // key inside the 32-key step (step base is a multiple of 32)
+      rdS[hh] = sbase + 2 * (r * 64 + (((4 * qi + p) ^ ds_pi(r)) << 2));
+    }
+  }
+
+  for (int qc = 0; qc < NCH; ++qc) {
+    // chunk qc has landed (younger: the next chunk's DMA and the previous chunk's dQ stores, at least ND1 of them)
+    if (qc == 0) wait_vmcnt<PC>();
+    else if (qc + 1 < NCH) wait_vmcnt<PC + ND1>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (qc + 2 < NCH) issue_chunk(qc + 2);
+    const __bf16* iQ = ringb + (qc % NSLOT) * 2 * IMG;
+    const __bf16* iO = iQ + IMG;
+    bf16x8 pp[KT][2], sp[KT][2];          // P and dS of this chunk, bf16, in the k-slot order of the transposed fragments
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      bf16x8 fqr[KS], fdr[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) { fqr[ks] = frag_rows<HDP>(iQ, qt * 16, ks, lane); fdr[ks] = frag_rows<HDP>(iO, qt * 16, ks, lane); }
+      const float4 l4 = *reinterpret_cast<const float4*>(s_lse + qc * 64 + qt * 16 + 4 * g);
+      const float4 d4 = *reinterpret_cast<const float4*>(s_del + qc * 64 + qt * 16 + 4 * g);
+      const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq_[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int ki = 0; ki < KT; ++ki) {
+        bf16x8 fk[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) fk[ks] = frag_rows<HDP>(imgK, k0 + 16 * ki, ks, lane);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, p = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqr[ks], fk[ks], a, 0, 0, 0);        // S[q = 4g+j][key = lane&15]
+          p = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fdr[ks], fv[ki][ks], p, 0, 0, 0);    // dP
+        }
+        bf16x4 sv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float pr = fast_exp2(__builtin_fmaf(a[j], c, lq[j]));
+          const float dsv = pr * (p[j] - dq_[j]) * scale;                                  // dS (incl. softmax scale)
+          pp[ki][qt >> 1][4 * (qt & 1) + j] = f2bf(pr);                                    // = pack_perm(tile 2h, tile 2h+1)
+          sv[j] = f2bf(dsv);
+          sp[ki][qt >> 1][4 * (qt & 1) + j] = sv[j];
+        }
+        // dS^T[key][16 qt + 4g .. +3] -> LDS (asm: invisible to hipcc's LDS-DMA alias bookkeeping)
+        asm_write_b64(wr_addr[ki] + 8 * ((4 * qt + g) ^ wr_pi), sv);
+      }
+    }
+    {
+      // dV^T += dO^T P, dK^T += Q^T dS: dO^T / Q^T column fragments of d-tile dt + 1 are read under the MFMAs of d-tile dt
+      unsigned aQ[ColPerm<HDP>::NB], aO[ColPerm<HDP>::NB];
+#pragma unroll
+      for (int k = 0; k < ColPerm<HDP>::NB; ++k) { aQ[k] = lds_addr(iQ) + cp.b[k]; aO[k] = lds_addr(iO) + cp.b[k]; }
+      bf16x8 cot[2], cqt[2], not_[2], nqt[2];
+      __builtin_amdgcn_sched_barrier(0);
+      cot[0] = col_frag<HDP, 0, 0>(aO); cot[1] = col_frag<HDP, 0, 1>(aO);
+      cqt[0] = col_frag<HDP, 0, 0>(aQ); cqt[1] = col_frag<HDP, 0, 1>(aQ);
+      static_for<NDT>([&](auto dtc) {
+        constexpr int dt = decltype(dtc)::value;
+        lds_reads_done();
+        if constexpr (dt + 1 < NDT) {
+          not_[0] = col_frag<HDP, dt + 1, 0>(aO); not_[1] = col_frag<HDP, dt + 1, 1>(aO);
+          nqt[0] = col_frag<HDP, dt + 1, 0>(aQ); nqt[1] = col_frag<HDP, dt + 1, 1>(aQ);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int ki = 0; ki < KT; ++ki) {
+            dv[ki][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cot[s2], pp[ki][s2], dv[ki][dt], 0, 0, 0);
+            dk[ki][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cqt[s2], sp[ki][s2], dk[ki][dt], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) { cot[s2] = not_[s2]; cqt[s2] = nqt[s2]; }
+      });
+    }
+    // every wave's dS^T tiles of this chunk are in LDS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      // dQ[64 qc + 16 qi + ..][16 (dt0 + i) + ..] = sum over all T keys of dS[q][key] K[key][d]
+      f32x4 dq[ND0];
+#pragma unroll
+      for (int i = 0; i < ND0; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x8 fa[ND0], fa_n[ND0];
+      bf16x8 fb, fb_n;
+      auto read_step = [&](int kk, bf16x8 (&A)[ND0], bf16x8& Bf) {
+        const bf16x4 lo = asm_read_tr(rdS[0] + kk * (32 * 64 * 2)), hi = asm_read_tr(rdS[1] + kk * (32 * 64 * 2));
+        Bf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const unsigned ko = kk * (32 * HDP * 2);
+#pragma unroll
+        for (int i = 0; i < ND0; ++i)
+          if (i < nd) {
+            const bf16x4 l2 = asm_read_tr(rdK[i] + ko), h2 = asm_read_tr_off<16 * HDP * 2>(rdK[i] + ko);
+            A[i] = bf16x8{l2[0], l2[1], l2[2], l2[3], h2[0], h2[1], h2[2], h2[3]};
+          }
+      };
+      read_step(0, fa, fb);
+      for (int kk = 0; kk < T / 32; ++kk) {
+        lds_reads_done();
+        if (kk + 1 < T / 32) read_step(kk + 1, fa_n, fb_n);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < ND0; ++i)
+          if (i < nd) dq[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, dq[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < ND0; ++i) fa[i] = fa_n[i];
+        fb = fb_n;
+      }
+      const int q = qc * 64 + 16 * qi + (lane & 15);
+      __bf16* row = dqkv + ((size_t)b * T + q) * ld + h * hd;
+#pragma unroll
+      for (int i = 0; i < ND0; ++i) {
+        const int d = (dt0 + i) * 16 + 4 * g;
+        if (i < nd && d < hd) {
+          const f32x4 v = dq[i];
+          bf16x4 ov = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+          *reinterpret_cast<bf16x4*>(row + d) = ov;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int ki = 0; ki < KT; ++ki) {
+    const int key = k0 + 16 * ki + (lane & 15);
+    __bf16* row = dqkv + ((size_t)b * T + key) * ld + h * hd;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      const int d = dt * 16 + 4 * g;
+      if (d < hd) {
+        const f32x4 a = dk[ki][dt], v = dv[ki][dt];
+        bf16x4 ka = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3])};
+        bf16x4 va = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *reinterpret_cast<bf16x4*>(row + D + d) = ka;
+        *reinterpret_cast<bf16x4*>(row + 2 * D + d) = va;
+      }
+    }
+  }
+}
+
+template __global__ void k_attn_bwd_fused<64, 2, 4, 2>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float);
+template __global__ void k_attn_bwd_fused<96, 3, 5, 2>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float);
+template __global__ void k_attn_bwd_fused<64, 2, 4, 1>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float);
+template __global__ void k_attn_bwd_fused<96, 3, 5, 1>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float);
+
 #define SFRON_INST_ATTN(HDP, KS, NDT)                                                                              \
   template __global__ void k_attn_fwd<HDP, KS, NDT, 1>(const __bf16*, __bf16*, float*, int, int, int, float);      \
   template __global__ void k_attn_fwd<HDP, KS, NDT, 2>(const __bf16*, __bf16*, float*, int, int, int, float);      \
@@ -564,6 +905,9 @@ SFRON_INST_ATTN(96, 3, 5)
 #undef SFRON_INST_ATTN
 
 namespace {
+
+// 0 / 1 = fused backward where the sequence length allows it; 2 = always the two-kernel form (tests compare the two)
+int g_bwd_form = 0;
 
 template <int HDP> size_t lds_bytes(int extra_floats) { return NSLOT * 2 * 64 * HDP * sizeof(__bf16) + extra_floats * sizeof(float); }
 
@@ -586,9 +930,23 @@ int launch_fwd(const __bf16* qkv, __bf16* o, float* lse, int B, int T, int H, in
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
 }
+template <int HDP, int KS, int NDT, int KT>
+int launch_bwd_fused(const __bf16* qkv, const __bf16* o, const __bf16* d_o, const float* lse, __bf16* dqkv, int B, int H, int hd,
+                     float scale, hipStream_t s) {
+  constexpr int T = FNW * 16 * KT;
+  const size_t lds = (size_t)(NSLOT * 2 * 64 * HDP + T * HDP + T * 64) * sizeof(__bf16) + 2 * T * sizeof(float);
+  int rc = set_lds(&k_attn_bwd_fused<HDP, KS, NDT, KT>, lds); if (rc) return rc;
+  hipLaunchKernelGGL((k_attn_bwd_fused<HDP, KS, NDT, KT>), dim3(B * H), dim3(FNT), lds, s, qkv, o, d_o, lse, dqkv, H, hd, scale);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SFRON_OK : (int)e;
+}
+
 template <int HDP, int KS, int NDT>
 int launch_bwd(const __bf16* qkv, const __bf16* o, const __bf16* d_o, const float* lse, float* delta, __bf16* dqkv, int B,
                int T, int H, int hd, float scale, hipStream_t s) {
+  // one workgroup per (batch, head) with the whole sequence behind it: T = 256 (DiT-XL/2 ... DiT-S/2 at 256 px) and T = 128
+  if (T == 256 && g_bwd_form != 2) return launch_bwd_fused<HDP, KS, NDT, 2>(qkv, o, d_o, lse, dqkv, B, H, hd, scale, s);
+  if (T == 128 && g_bwd_form != 2) return launch_bwd_fused<HDP, KS, NDT, 1>(qkv, o, d_o, lse, dqkv, B, H, hd, scale, s);
   const size_t lds = lds_bytes<HDP>(0), lds2 = lds_bytes<HDP>(2 * T);
   if (T % 128 == 0) {
     int rc = set_lds(&k_attn_bwd_dq<HDP, KS, NDT, 2>, lds); if (rc) return rc;
@@ -616,6 +974,9 @@ int sfron_attn_fwd(const uint16_t* qkv, uint16_t* o, float* lse, int B, int T, i
   if (hd == 72) return launch_fwd<96, 3, 5>((const __bf16*)qkv, (__bf16*)o, lse, B, T, H, hd, scale, s);
   return SFRON_ERR_UNSUPPORTED;
 }
+
+/* test hook: 2 = force the two-kernel backward (dQ, then dK/dV) for every T; 0 = default (fused where T is 128 or 256) */
+int sfron_attn_bwd_form(int form) { const int old = g_bwd_form; g_bwd_form = form; return old; }
 
 int sfron_attn_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* delta_scratch,
                    uint16_t* dqkv, int B, int T, int H, int hd, void* stream) {

@@ -187,15 +187,20 @@ int64_t sfron_dit_workspace_bytes(const sfron_dit_cfg* cfg) {
 }
 
 // SFRON_ABLATE (debug / A-B measurement only): bit 0 = run LN backward and gate backward as separate kernels,
-// bit 1 = split-K in the block weight gradients (off by default), bit 2 = side stream at the lowest priority, bit 3 = fc2 weight gradient after the fc2 dgrad, bit 4 = no split-K for the two small-output weight gradients
+// bit 1 = split-K in the block weight gradients (off by default), bit 2 = side stream at the lowest priority, bit 3 = fc2 weight gradient after the fc2 dgrad, bit 4 = no split-K for the two small-output weight gradients, bit 5 = bias gradients by separate column-sum launches
 static int ablate_mask() {
+#ifdef SFRON_DEBUG_KNOBS
   static const int m = [] { const char* e = getenv("SFRON_ABLATE"); return e ? atoi(e) : 0; }();
   return m;
+#else
+  return 0;          // the product build reads no environment variables
+#endif
 }
 
 // ---- aux: a side stream + events so the weight-gradient GEMMs (which nothing downstream in the backward chain
 // depends on) run concurrently with the dgrad / elementwise chain and fill the CUs its tile counts leave idle
-struct Aux { hipStream_t side; hipEvent_t produced[4], consumed[8], done; };
+struct Probe;
+struct Aux { hipStream_t side; hipEvent_t produced[4], consumed[8], done; Probe* probe; };
 
 int sfron_aux_create(void** aux) {
   SFRON_CHECK_ARG(aux);
@@ -225,8 +230,16 @@ int sfron_aux_destroy(void* aux) {
   return SFRON_OK;
 }
 
-// ---- probe: HIP events around the fc1 GEMM of block 0 (the dominant kernel class), for bench.py's roofline
+// ---- probe: HIP event pairs around chosen launches, recorded on the stream the launch goes to, for bench.py's live roofline
+// measurement: the forward pass brackets the fc1 GEMM of block 0; a probe attached to the aux handle (sfron_aux_set_probe)
+// brackets, on the weight-gradient stream, the qkv / fc1 weight-gradient GEMMs (+ bias row sums) of every 9th block
 struct Probe { hipEvent_t* ev; int cap, used; };
+
+int sfron_aux_set_probe(void* aux, void* probe) {
+  SFRON_CHECK_ARG(aux);
+  ((Aux*)aux)->probe = (Probe*)probe;
+  return SFRON_OK;
+}
 
 int sfron_probe_create(int max_samples, void** probe) {
   SFRON_CHECK_ARG(probe && max_samples > 0);
@@ -376,8 +389,21 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
   Aux* ax = (Aux*)aux;
   void* side = ax ? (void*)ax->side : stream;
   // block weight gradient on the side stream, reduction split per wgrad_splits() into fp32 slabs + fixed-order sum
-  auto wgrad_side = [&](const void* dY, const void* X, int N, int K, float* dW) -> int {
+  // db (optional): the bias gradient sum_rows dY of the same Linear.  Where the three-slot weight-gradient kernel takes the
+  // shape it comes out of that GEMM (row sums of dY^T against a ones fragment); otherwise a column-sum launch precedes it.
+  bool probe_block = false;
+  auto wgrad_side = [&](const void* dY, const void* X, int N, int K, float* dW, float* db = nullptr) -> int {
     sfron_gemm_desc q = wgrad_desc(dY, X, M, N, K, dW);
+    Probe* pr = nullptr;
+    if (db) {
+      if (!(ablate_mask() & 32) && sfron_gemm_rowsum_supported(N, K, M)) {
+        q.a_rowsum = db;
+        q.rowsum_ws = ax ? w.csum2 : w.csum;            // [K / 192][N] partial rows (<= CSUM_PARTS rows of the widest output)
+        if (ax && ax->probe && probe_block && ax->probe->used < ax->probe->cap) pr = ax->probe;
+      } else RUN(sfron_colsum(dY, 1, M, N, N, ax ? w.csum2 : w.csum, CSUM_PARTS, db, side));
+    }
+    if (pr) (void)hipEventRecord(pr->ev[2 * pr->used], (hipStream_t)side);
+    struct Close { Probe* p; void* s; ~Close() { if (p) { (void)hipEventRecord(p->ev[2 * p->used + 1], (hipStream_t)s); p->used++; } } } close{pr, side};
     // measured: the splits shorten the side stream (proj 175 -> 60 us) but the backward pass is bound by total CU time, and
     // the slab traffic + reductions make the step 0.5-2 ms SLOWER -> off unless SFRON_ABLATE bit 1 asks for the A-B run
     const int sp = (ablate_mask() & 2) ? wgrad_splits(N, K, M) : 1;
@@ -453,6 +479,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     const __bf16* xmod2 = w.xmod2 + (size_t)l * M * D; const __bf16* hpre = w.hpre + (size_t)l * M * d.F;
     const __bf16* h = w.h + (size_t)l * M * d.F; const __bf16* a2 = w.a2 + (size_t)l * M * D;
     const bool first = (l == d.L - 1);
+    probe_block = (l % 9 == 0);
     // ---- MLP branch: x2 = x1 + gate_mlp * (fc2(gelu(fc1(xmod2))))
     const int pl = l & 1;
     const bool delay_fc2 = ablate_mask() & 8;      // A-B knob: start the fc2 weight gradient only after the fc2 dgrad (768 tiles)
@@ -470,8 +497,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
       RUN(wgrad_side(w.d_br[pl], h, D, d.F, grads + pb + P.o_fc2_w));
       consumed(0, l);
     }
-    RUN(sfron_colsum(w.d_hpre[pl], 1, M, d.F, d.F, ax ? w.csum2 : w.csum, CSUM_PARTS, grads + pb + P.o_fc1_b, side));
-    RUN(wgrad_side(w.d_hpre[pl], xmod2, d.F, D, grads + pb + P.o_fc1_w));
+    RUN(wgrad_side(w.d_hpre[pl], xmod2, d.F, D, grads + pb + P.o_fc1_w, grads + pb + P.o_fc1_b));
     consumed(1, l);
     g = dgrad_desc(w.d_hpre[pl], wb + pb + P.o_fc1_w, M, d.F, D);
     g.c_bf16 = (uint16_t*)w.d_xmod; g.ldc_bf16 = D;
@@ -490,8 +516,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     RUN(sfron_attn_bwd((const uint16_t*)qkv, (const uint16_t*)o, (const uint16_t*)w.d_o, w.lse + (size_t)l * B * d.H * T,
                        w.delta, (uint16_t*)w.dqkv[pl], B, T, d.H, d.hd, stream));
     produced(3);
-    RUN(sfron_colsum(w.dqkv[pl], 1, M, 3 * D, 3 * D, ax ? w.csum2 : w.csum, CSUM_PARTS, grads + pb + P.o_qkv_b, side));
-    RUN(wgrad_side(w.dqkv[pl], xmod1, 3 * D, D, grads + pb + P.o_qkv_w));
+    RUN(wgrad_side(w.dqkv[pl], xmod1, 3 * D, D, grads + pb + P.o_qkv_w, grads + pb + P.o_qkv_b));
     consumed(3, l);
     if (block_events && block_events[l]) {                 // block l: the four weight gradients, qkv.bias and fc1.bias are final
       if (hipEventRecord((hipEvent_t)block_events[l], (hipStream_t)side) != hipSuccess) return (int)hipGetLastError();

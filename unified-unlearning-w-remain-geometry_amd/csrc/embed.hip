@@ -47,7 +47,10 @@ __global__ __launch_bounds__(TPB) void k_cond_fwd(const float* __restrict__ t_em
   const int b = blockIdx.y;
   const int col = blockIdx.x * TPB + threadIdx.x;
   if (col >= D) return;
-  const int64_t lab = (drop && drop[b]) ? num_classes : y[b];
+  const int64_t yb = y[b];
+  // labels outside [0, num_classes) never index the table (the caller's step guard reports them, as the reference's
+  // nn.Embedding would raise): they read / accumulate the null-class row
+  const int64_t lab = ((drop && drop[b]) || yb < 0 || yb >= num_classes) ? num_classes : yb;
   const float v = t_emb[(size_t)b * D + col] + table[(size_t)lab * D + col];
   c[(size_t)b * D + col] = v;
   silu_c[(size_t)b * D + col] = f2bf(silu(v));
@@ -64,7 +67,10 @@ __global__ __launch_bounds__(TPB) void k_cond_bwd(const float* __restrict__ d_si
   for (int b = 0; b < n; ++b) {
     const float g = d_silu_c[(size_t)b * D + col] * silu_grad(c[(size_t)b * D + col]);
     d_c[(size_t)b * D + col] = g;
-    const int64_t lab = (drop && drop[b]) ? num_classes : y[b];
+    const int64_t yb = y[b];
+    // labels outside [0, num_classes) never index the table (the caller's step guard reports them, as the reference's
+    // nn.Embedding would raise): they read / accumulate the null-class row
+    const int64_t lab = ((drop && drop[b]) || yb < 0 || yb >= num_classes) ? num_classes : yb;
     d_table[(size_t)lab * D + col] += g;
   }
 }

@@ -14,6 +14,15 @@
 // ds_read_b128 row fragments and the transposed reads are bank-conflict free.
 #include "common.h"
 #include "../../include/sfron.h"
+#include <atomic>
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per function AND per device: remember per device whether it was set
+static inline bool need_attr(std::atomic<uint64_t>& mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  return (mask.fetch_or(bit) & bit) == 0;
+}
 
 struct GemmArgs {
   const __bf16* A; const __bf16* B;
@@ -35,6 +44,7 @@ struct GemmArgs {
                             // bit 1 = fp32 weight-gradient output
   int ntm, ntn;
   int group_m;              // fast path: tile-rows per group of the grouped tile order
+  float* bsum;              // weight-gradient layout: bsum[m] = sum_k op(A)[m][k] (bias gradient), or null
 };
 
 namespace {
@@ -613,12 +623,11 @@ int launch_fast(GemmArgs g, hipStream_t s) {
   }
   const size_t lds = 2 * (FBM + FBN) * 64 * sizeof(__bf16);
   if (lds > 65536) {
-    static bool done = false;      // per instantiation
-    if (!done) {
+    static std::atomic<uint64_t> done{0};      // per instantiation, one bit per device
+    if (need_attr(done)) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_fast<WM, WN, MT, NT, A_TR, B_TR, EPI, DBG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return (int)hipGetLastError();
-      done = true;
     }
   }
   hipLaunchKernelGGL((k_gemm_fast<WM, WN, MT, NT, A_TR, B_TR, EPI, DBG>), dim3(g.ntm * g.ntn), dim3(WM * WN * 64), lds, s, g);
@@ -627,230 +636,6 @@ int launch_fast(GemmArgs g, hipStream_t s) {
 }
 
 }  // namespace
-
-// =================================================================================================
-// Ring path: the same 8-wave tiles with BK = 32 stages in an NSTAGE-deep LDS ring and COUNTED vmcnt.
-// The 2-stage kernel above keeps at most one tile (56 KB per CU) of LDS-DMA in flight and is bound by
-// bytes-in-flight / load latency (~41 GB/s per CU measured); here NSTAGE-1 stages are in flight, vmcnt never
-// drains in the steady state and there is one raw s_barrier per stage.
-// =================================================================================================
-// direct image [ROWS][32]: 64-B rows, chunk c of row r stored at c ^ (((r>>3)&1)<<1)   (conflict-free ds_read_b128)
-__device__ __forceinline__ int swz32(int row) { return ((row >> 3) & 1) << 1; }
-
-template <int FBM, int FBN, bool A_TR, bool B_TR, int NW>
-struct RingPlan {
-  static constexpr int NA = A_TR ? 32 * (FBM / 8) / 64 : FBM * 4 / 64;    // wave-instructions of the A image
-  static constexpr int NB = B_TR ? 32 * (FBN / 8) / 64 : FBN * 4 / 64;
-  static constexpr int NI = NA + NB;
-  static constexpr int PER_HI = (NI + NW - 1) / NW, PER_LO = NI / NW;      // instructions of waves < NI % NW, and of the rest
-  static constexpr int A_ELEMS = FBM * 32, B_ELEMS = FBN * 32, STAGE_ELEMS = A_ELEMS + B_ELEMS;
-  int off[PER_HI];
-  template <int EXT, bool TR> static __device__ __forceinline__ int lane_off(int j, int lane, int ld, int d0) {
-    constexpr int CPR = TR ? EXT / 8 : 4;
-    const int e = j * 64 + lane, row = e / CPR, p = e % CPR;
-    if (!TR) return 2 * ((d0 + row) * ld + ((p ^ swz32(row)) << 3));
-    return 2 * (row * ld + d0 + (swz_chunk<EXT>(row, p) << 3));
-  }
-  __device__ __forceinline__ void init(int lda, int ldb, int m0, int n0, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < PER_HI; ++i) {
-      const int j = wave + i * NW;
-      off[i] = j < NA ? lane_off<FBM, A_TR>(j, lane, lda, m0) : lane_off<FBN, B_TR>(j - NA, lane, ldb, n0);
-    }
-  }
-  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, int soffA, int soffB,
-                                        __bf16* stage, int wave) const {
-#pragma unroll
-    for (int i = 0; i < PER_HI; ++i) {
-      const int j = wave + i * NW;
-      if (j < NI) {
-        if (j < NA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t*)(stage + j * 512), 16, off[i], soffA, 0, 0);
-        else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t*)(stage + A_ELEMS + (j - NA) * 512), 16, off[i], soffB, 0, 0);
-      }
-    }
-  }
-};
-
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI, int NSTAGE>
-__global__ __launch_bounds__(WM * WN * 64) void k_gemm_ring(GemmArgs g) {
-  constexpr int FBM = WM * MT * 16, FBN = WN * NT * 16, NW = WM * WN;
-  using Plan = RingPlan<FBM, FBN, A_TR, B_TR, NW>;
-  extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int nblk = gridDim.x;
-  int id;
-  {
-    const int b = blockIdx.x, q = nblk >> 3, r = nblk & 7, x = b & 7, y = b >> 3;
-    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
-  }
-  const int per_group = g.group_m * g.ntn;
-  const int first_m = (id / per_group) * g.group_m;
-  const int gsz = min(g.ntm - first_m, g.group_m);
-  const int tm = first_m + (id % per_group) % gsz, tn = (id % per_group) / gsz;
-  const int m0 = tm * FBM, n0 = tn * FBN;
-
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  Plan plan;
-  plan.init(g.lda, g.ldb, m0, n0, wave, lane);
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, 0x7fffffff, 0x00020000);
-  const int kstepA = 2 * (A_TR ? 32 * g.lda : 32), kstepB = 2 * (B_TR ? 32 * g.ldb : 32);   // bytes per stage
-  auto issue = [&](int st) { plan.issue(rsA, rsB, st * kstepA, st * kstepB, smem + (st % NSTAGE) * Plan::STAGE_ELEMS, wave); };
-
-  auto compute = [&](const __bf16* iA, const __bf16* iB) {
-    auto load_a = [&](int mt) -> bf16x8 {
-      const int row = wm * MT * 16 + mt * 16 + (lane & 15);
-      if (!A_TR) return *reinterpret_cast<const bf16x8*>(iA + row * 32 + (((lane >> 4) ^ swz32(row)) << 3));
-      return frag_tr_w<FBM>(iA, wm * MT * 16 + mt * 16, 0, lane);
-    };
-    auto load_b = [&](int nt) -> bf16x8 {
-      const int row = wn * NT * 16 + nt * 16 + (lane & 15);
-      if (!B_TR) return *reinterpret_cast<const bf16x8*>(iB + row * 32 + (((lane >> 4) ^ swz32(row)) << 3));
-      return frag_tr_w<FBN>(iB, wn * NT * 16 + nt * 16, 0, lane);
-    };
-    if (NT <= MT) {
-      bf16x8 fb[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) fb[nt] = load_b(nt);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const bf16x8 fa = load_a(mt);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa, acc[mt][nt], 0, 0, 0);
-      }
-    } else {
-      bf16x8 fa[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) fa[mt] = load_a(mt);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const bf16x8 fb = load_b(nt);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[mt], acc[mt][nt], 0, 0, 0);
-      }
-    }
-  };
-
-  const int ns = g.K / 32;                       // stages of this tile
-  const bool hi = wave < (Plan::NI % NW);        // this wave issues PER_HI (else PER_LO) DMA instructions per stage
-#pragma unroll
-  for (int st = 0; st < NSTAGE - 1; ++st)
-    if (st < ns) issue(st);
-  for (int st = 0; st < ns; ++st) {
-    // stage `st` must have landed; in the steady state NSTAGE-2 younger stages stay in flight
-    if (st + NSTAGE - 2 < ns) {
-      if (Plan::PER_HI != Plan::PER_LO && !hi) wait_vm<(NSTAGE - 2) * Plan::PER_LO>(); else wait_vm<(NSTAGE - 2) * Plan::PER_HI>();
-    } else {
-      wait_vm<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    if (st + NSTAGE - 1 < ns) issue(st + NSTAGE - 1);
-    const __bf16* sbase = smem + (st % NSTAGE) * Plan::STAGE_ELEMS;
-    compute(sbase, sbase + Plan::A_ELEMS);
-  }
-
-  const int row_b = m0 + wm * MT * 16 + (lane & 15), col_b = n0 + wn * NT * 16 + 4 * (lane >> 4);
-  if constexpr (EPI == EPI_DGELU) {
-    bf16x4 hx[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        hx[mt][nt] = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)(row_b + mt * 16) * g.ldaux + col_b + nt * 16);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const f32x4 v = acc[mt][nt] * g.alpha;
-        const bf16x4 h = hx[mt][nt];
-        bf16x4 o = {f2bf(v[0] * gelu_tanh_grad(bf2f(h[0]))), f2bf(v[1] * gelu_tanh_grad(bf2f(h[1]))),
-                    f2bf(v[2] * gelu_tanh_grad(bf2f(h[2]))), f2bf(v[3] * gelu_tanh_grad(bf2f(h[3])))};
-        *reinterpret_cast<bf16x4*>(g.Cb + (size_t)(row_b + mt * 16) * g.ldcb + col_b + nt * 16) = o;
-      }
-  } else if constexpr (EPI == EPI_GATE_RES) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int row = row_b + mt * 16;
-      float4 xr[NT], gt[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        xr[nt] = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldcf + col_b + nt * 16);
-        gt[nt] = *reinterpret_cast<const float4*>(g.gate + (size_t)(row / g.T) * g.ldgate + col_b + nt * 16);
-      }
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int col = col_b + nt * 16;
-        f32x4 v = acc[mt][nt] * g.alpha;
-        if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-        bf16x4 a = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        nt_store(reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col), a, g.nt_out & 1);
-        float4 x = xr[nt];
-        x.x += gt[nt].x * v[0]; x.y += gt[nt].y * v[1]; x.z += gt[nt].z * v[2]; x.w += gt[nt].w * v[3];
-        *reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col) = x;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        epilogue_store<EPI>(g, row_b + mt * 16, col_b + nt * 16, acc[mt][nt]);
-  }
-}
-
-#define SFRON_INST_RING(WM, WN, MT, NT, NS)                                              \
-  template __global__ void k_gemm_ring<WM, WN, MT, NT, false, false, 0, NS>(GemmArgs);  \
-  template __global__ void k_gemm_ring<WM, WN, MT, NT, false, false, 1, NS>(GemmArgs);  \
-  template __global__ void k_gemm_ring<WM, WN, MT, NT, false, false, 2, NS>(GemmArgs);  \
-  template __global__ void k_gemm_ring<WM, WN, MT, NT, false, false, 3, NS>(GemmArgs);  \
-  template __global__ void k_gemm_ring<WM, WN, MT, NT, false, false, 5, NS>(GemmArgs);  \
-  template __global__ void k_gemm_ring<WM, WN, MT, NT, false, true, 0, NS>(GemmArgs);   \
-  template __global__ void k_gemm_ring<WM, WN, MT, NT, false, true, 1, NS>(GemmArgs);   \
-  template __global__ void k_gemm_ring<WM, WN, MT, NT, false, true, 4, NS>(GemmArgs);   \
-  template __global__ void k_gemm_ring<WM, WN, MT, NT, true, true, 0, NS>(GemmArgs);    \
-  template __global__ void k_gemm_ring<WM, WN, MT, NT, true, true, 1, NS>(GemmArgs);
-SFRON_INST_RING(4, 2, 4, 6, 5)
-SFRON_INST_RING(2, 4, 8, 4, 4)
-SFRON_INST_RING(4, 2, 3, 6, 6)
-#undef SFRON_INST_RING
-
-namespace {
-
-template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI, int NSTAGE>
-int launch_ring(GemmArgs g, hipStream_t s) {
-  constexpr int FBM = WM * MT * 16, FBN = WN * NT * 16;
-  g.ntm = g.M / FBM; g.ntn = g.N / FBN;
-  {
-    const double per_xcd = (double)g.ntm * g.ntn / 8.0;
-    int gm = 1;
-    while (gm * 2 <= g.ntm && (double)(gm * 2) * (gm * 2) * FBM <= per_xcd * FBN * 1.5) gm *= 2;
-    g.group_m = gm;
-  }
-  const size_t lds = (size_t)NSTAGE * (FBM + FBN) * 32 * sizeof(__bf16);
-  static bool done = false;
-  if (!done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<WM, WN, MT, NT, A_TR, B_TR, EPI, NSTAGE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return (int)hipGetLastError();
-    done = true;
-  }
-  hipLaunchKernelGGL((k_gemm_ring<WM, WN, MT, NT, A_TR, B_TR, EPI, NSTAGE>), dim3(g.ntm * g.ntn), dim3(WM * WN * 64), lds, s, g);
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? SFRON_OK : (int)e;
-}
-
-}  // namespace
-
 
 // =================================================================================================
 // Pipelined path ("k_gemm_pipe"): same tiles / LDS images / DMA as k_gemm_fast, but the fragment reads are
@@ -899,8 +684,16 @@ __device__ __forceinline__ void lds_reads_done() {
 // the MFMAs they overlap with (one MFMA, then 1-2 memory instructions, sched_barrier), so their issue slots hide under
 // the 16-cycle MFMA occupancy instead of forming an MFMA-free bubble after every barrier; buffer select and k-step are
 // immediate ds offsets (K loop unrolled by two).
-template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI, int SCHED = 0, int PRO = 2>
+// BSUM (weight-gradient layout, three-slot schedule): the kernel also forms bsum[m] = sum_k op(A)[m][k] -- the bias gradient of
+// the same Linear -- with MT extra MFMAs against a ones fragment (waves wn == 0 only): the dY tile is already in LDS /
+// registers, so the separate column-sum kernel (a second 75 MB read of dY per launch) disappears.  The ntn workgroups of a
+// tile row all stream the same dY tiles; they SHARE the extra work: workgroup (tm, tn) sums the k-tiles kt = tn mod ntn and
+// writes partial sums bsum[tn][m] (the host adds the ntn partial rows in a fixed order).  (Giving all of it to the tn = 0
+// column made those 1/ntn of the workgroups 17 % longer, and with one round of tiles the launch ends with its slowest
+// workgroup: measured +20 us per launch.)  fp32 accumulation of bf16 values in a fixed order: deterministic.
+template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI, int SCHED = 0, int PRO = 2, bool BSUM = false>
 __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
+  static_assert(!BSUM || (A_TR && B_TR && EPI == EPI_F32 && SCHED == 2), "row sums ride on the three-slot weight-gradient kernel");
   constexpr int FBM = WM * MT * 16, FBN = WN * NT * 16, NW = WM * WN;
   constexpr int FBM_P = A_TR ? tr_cols<FBM>() : FBM, FBN_P = B_TR ? tr_cols<FBN>() : FBN;   // physical row length of a transposed-read image
   constexpr int A_ELEMS = FBM_P * 64, B_ELEMS = FBN_P * 64;
@@ -939,6 +732,17 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) { f32x4& c = acc[i][j]; asm volatile("" : "+v"(c)); }
+  }
+  f32x4 bacc[BSUM ? MT : 1];
+  bf16x8 ones;
+  const bool do_bs = BSUM && g.bsum != nullptr && wn == 0 && blockIdx.y == 0;     // wave-uniform
+  int bs_c = g.ntn - 1;                      // (index of the previous k-tile) mod ntn; body() advances it
+  if constexpr (BSUM) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; asm volatile("" : "+v"(bacc[i])); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    asm volatile("" : "+v"(ones));
   }
 
   // forward layouts (the only ones that carry a bias): this lane's bias columns, one float4 per n-tile, fetched before the
@@ -1079,6 +883,19 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
       const bf16x8 fb = f.b[nt], fa = f.a[mt];
       asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(fb), "v"(fa));
     };
+    // D[i][j] = sum_k 1 * A^T[k][j]: every accumulator row holds the row sums of this k-step's A fragment
+    auto bsum_step = [&](const Frags& f, int tile_mod) {
+      if constexpr (BSUM) {
+        if (do_bs && tile_mod == tn) {
+          static_for<MT>([&](auto ic) {
+            constexpr int mt = decltype(ic)::value;
+            f32x4& c = bacc[mt];
+            const bf16x8 fa = f.a[mt], o1 = ones;
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(o1), "v"(fa));
+          });
+        }
+      }
+    };
     // one K tile held by BUF; FIRST = nothing to multiply yet in segment 1.  The next tile is always requested: past the
     // end of the k range the request goes through a descriptor with num_records = 0, which makes every lane out of
     // range (an out-of-range raw buffer load fetches nothing), so every iteration runs the same straight-line code.
@@ -1120,6 +937,9 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
         });
       }
       lds_reads_done();
+      if constexpr (!FIRST) bsum_step(f1, bs_c);               // behind the wait: no asynchronous register write is in flight at the
+                                                               // branch; f1 is not refilled before segment 2's first read
+      bs_c = bs_c + 1 == g.ntn ? 0 : bs_c + 1;                 // now: (this k-tile) mod ntn
       constexpr int NOPS2 = NRA + NRB;
       static_for<NM>([&](auto ic) {
         constexpr int i = decltype(ic)::value, lo = i * NOPS2 / NM, hi = (i + 1) * NOPS2 / NM;
@@ -1130,6 +950,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
       });
       lds_reads_done();
+      bsum_step(f0, bs_c);                                     // f0 is refilled only after the next barrier
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     // nk is even and >= 2 here (the launcher routes other k ranges to the plain schedule): no conditional tail, whose
@@ -1153,6 +974,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
       }
     }
     static_for<NM>([&](auto ic) { mfma1(f1, ic); });
+    bsum_step(f1, bs_c);
     // the asm MFMAs are invisible to hipcc's hazard recogniser: let the last results land before the epilogue reads them
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   } else
@@ -1174,6 +996,12 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
   if constexpr (SCHED == 0) mfmas(f1);
 
   const int row_b = m0 + wm * MT * 16 + (lane & 15), col_b = n0 + wn * NT * 16 + 4 * (lane >> 4);
+  if constexpr (BSUM) {
+    if (do_bs && lane < 16) {                 // all four accumulator rows of a lane hold the same sum
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) g.bsum[(size_t)tn * g.M + row_b + mt * 16] = bacc[mt][0] * g.alpha;
+    }
+  }
   if constexpr (EPI == EPI_DGELU) {
     bf16x4 hx[MT][NT];
 #pragma unroll
@@ -1254,6 +1082,7 @@ SFRON_INST_PIPE1(4, 2, 3, 6)
 #undef SFRON_INST_PIPE1
 template __global__ void k_gemm_pipe<4, 2, 3, 6, true, true, 0, 2>(GemmArgs);    // 192x192, three slots: weight gradients
 template __global__ void k_gemm_pipe<4, 2, 3, 6, true, true, 1, 2>(GemmArgs);
+template __global__ void k_gemm_pipe<4, 2, 3, 6, true, true, 1, 2, 2, true>(GemmArgs);   // ... + bias row sums
 template __global__ void k_gemm_pipe<4, 2, 3, 6, false, false, 0, 2>(GemmArgs);  // (experiment: forward layout)
 // 256x144 tile, 8 x 1 waves of 32x144, three slots, 3-tile prologue: the forward GEMMs.  36,864 outputs per tile = exactly
 // 256 tiles for a [8192 x 1152] output (one per CU, where 256x192 gives 192), 768 for qkv, 1024 for fc1.
@@ -1268,7 +1097,7 @@ template __global__ void k_gemm_pipe<8, 1, 2, 9, false, true, 4, 2, 3>(GemmArgs)
 
 namespace {
 
-template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI, int SCHED = 0, int PRO = 2>
+template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI, int SCHED = 0, int PRO = 2, bool BSUM = false>
 int launch_pipe(GemmArgs g, hipStream_t s) {
   constexpr int FBM = WM * MT * 16, FBN = WN * NT * 16;
   g.ntm = g.M / FBM; g.ntn = g.N / FBN;
@@ -1281,14 +1110,13 @@ int launch_pipe(GemmArgs g, hipStream_t s) {
   constexpr bool uneven = !GldsPlan<FBM, A_TR, WM * WN>::EVEN || !GldsPlan<FBN, B_TR, WM * WN>::EVEN;
   constexpr int FBM_P = A_TR ? tr_cols<FBM>() : FBM, FBN_P = B_TR ? tr_cols<FBN>() : FBN;
   const size_t lds = (SCHED == 2 ? 3 : 2) * (FBM_P + FBN_P) * 64 * sizeof(__bf16) + (uneven ? 1024 : 0);
-  static bool done = false;
-  if (!done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pipe<WM, WN, MT, NT, A_TR, B_TR, EPI, SCHED, PRO>),
+  static std::atomic<uint64_t> done{0};        // per instantiation, one bit per device
+  if (need_attr(done)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pipe<WM, WN, MT, NT, A_TR, B_TR, EPI, SCHED, PRO, BSUM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return (int)hipGetLastError();
-    done = true;
   }
-  hipLaunchKernelGGL((k_gemm_pipe<WM, WN, MT, NT, A_TR, B_TR, EPI, SCHED, PRO>), dim3(g.ntm * g.ntn, cdiv(g.K, g.kchunk)), dim3(WM * WN * 64), lds, s, g);
+  hipLaunchKernelGGL((k_gemm_pipe<WM, WN, MT, NT, A_TR, B_TR, EPI, SCHED, PRO, BSUM>), dim3(g.ntm * g.ntn, cdiv(g.K, g.kchunk)), dim3(WM * WN * 64), lds, s, g);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
 }
@@ -1302,6 +1130,11 @@ namespace {
 constexpr int N_TILES = 9;
 static const int TILE_BM[N_TILES] = {0, 128, 256, 256, 384, 192, 256, 192, 256};
 static const int TILE_BN[N_TILES] = {0, 128, 192, 256, 192, 192, 192, 192, 144};
+// shapes whose weight gradient runs on the three-slot 192x192 tile (nk = 2 + 3j k-tiles of 64): the kernel that can also
+// produce the bias row sums
+inline bool rowsum_ok(int M, int N, int K) {
+  return M % 192 == 0 && N % 192 == 0 && K % 64 == 0 && K / 64 >= 2 && (K / 64 - 2) % 3 == 0;
+}
 inline bool tile_fits(const GemmArgs& g, int t) {
   return t >= 1 && t < N_TILES && g.M % TILE_BM[t] == 0 && g.N % TILE_BN[t] == 0;
 }
@@ -1319,7 +1152,7 @@ inline int pick_fast_tile(const GemmArgs& g, int force, int transposed_operands)
   if (force == 42 || force == 45) return tile_fits(g, force - 40) ? force : 0;                  // ... with the interleaved schedule
   if (force == 55) return tile_fits(g, 5) ? force : 0;                                          // ... and three LDS slots
   if (force == 62) return tile_fits(g, 8) ? force : (tile_fits(g, 2) ? 42 : 0);                 // 256x144, three slots (forward layouts)
-  if (force > 10) return (g.K % 32 == 0 && tile_fits(g, force - 10)) ? force : 0;   // ring variants of tiles 2, 3, 5
+  if (force > 10) return 0;
   if (force > 0) return tile_fits(g, force) ? force : 0;
   // Measured policy (tools/bench_gemm.py, DiT-XL/2 B=32 shapes, random data):
   //   both operands k-contiguous (forward)   -> 256x192 k_gemm_pipe, interleaved schedule (800-980 TF; k_gemm_fast 760-950)
@@ -1339,7 +1172,11 @@ inline int pick_fast_tile(const GemmArgs& g, int force, int transposed_operands)
   if (transposed_operands == 2) return tile_fits(g, 5) ? 55 : 0;
   // forward layouts: 256x144 three-slot tile when it fills the CUs better than 256x192 (a [8192 x 1152] output is exactly 256
   // tiles instead of 192; measured cold: proj 35.7 -> 28.1 us, qkv 102.7 -> 78.3, fc2 103.9 -> 83.5; fc1 (both 100 %) stays)
-  static const bool t62_all = getenv("SFRON_GEMM_T62_ALL") != nullptr;      // A-B knob: the 256x144 tile wherever it fits
+#ifdef SFRON_DEBUG_KNOBS
+  static const bool t62_all = getenv("SFRON_GEMM_T62_ALL") != nullptr;      // A-B knob (debug builds only): the 256x144 tile wherever it fits
+#else
+  constexpr bool t62_all = false;
+#endif
   if (transposed_operands <= 1 && tile_fits(g, 8) && g.K % 192 == 0 && (t62_all || !tile_fits(g, 2) || eff(8) > eff(2) + 0.05)) return 62;
   if (tile_fits(g, 2) && eff(2) >= 0.5) return (transposed_operands == 1 || even_nk) ? 42 : 2;
   return (transposed_operands == 0 && tile_fits(g, 1)) ? 1 : 0;   // with transposed reads the generic kernel beats the 4-wave tile
@@ -1375,14 +1212,14 @@ int launch_any(const GemmArgs& g, hipStream_t s, int force) {
       if (!tile_fits(g, 2)) return launch<A_TR, B_TR, EPI>(g, s);
       return g.K % 128 == 0 && g.kchunk == g.K ? launch_pipe<4, 2, 4, 6, A_TR, B_TR, EPI, 1>(g, s) : launch_pipe<4, 2, 4, 6, A_TR, B_TR, EPI>(g, s);
     case 55:   // 192x192 with three LDS slots (weight-gradient layouts only): needs nk = 2 + 3j tiles per split
+      if constexpr (A_TR && B_TR && EPI == EPI_F32) {
+        if (g.bsum) return rowsum_ok(g.M, g.N, g.K) && g.kchunk == g.K ? launch_pipe<4, 2, 3, 6, true, true, EPI_F32, 2, 2, true>(g, s) : SFRON_ERR_UNSUPPORTED;
+      }
       if constexpr ((A_TR && B_TR && (EPI == EPI_BF16 || EPI == EPI_F32)) || (!A_TR && !B_TR && EPI == EPI_BF16)) {
         if (g.K % g.kchunk == 0 && (g.kchunk / 64) >= 2 && ((g.kchunk / 64) - 2) % 3 == 0) return launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI, 2>(g, s);
       }
       return (g.kchunk % 128 == 0 && g.K % g.kchunk == 0) ? launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI, 1>(g, s)
                                                            : launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI>(g, s);
-    case 12: return launch_ring<4, 2, 4, 6, A_TR, B_TR, EPI, 5>(g, s);
-    case 13: return launch_ring<2, 4, 8, 4, A_TR, B_TR, EPI, 4>(g, s);
-    case 15: return launch_ring<4, 2, 3, 6, A_TR, B_TR, EPI, 6>(g, s);
     default: return launch<A_TR, B_TR, EPI>(g, s);
   }
 }
@@ -1396,6 +1233,8 @@ int dispatch_layout(int a_tr, int b_tr, const GemmArgs& g, hipStream_t s, int fo
 }
 
 }  // namespace
+
+extern "C" int sfron_gemm_rowsum_supported(int M, int N, int K) { return rowsum_ok(M, N, K) ? 1 : 0; }
 
 extern "C" int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
   SFRON_CHECK_ARG(d && d->A && d->B && d->M > 0 && d->N > 0 && d->K > 0);
@@ -1423,9 +1262,23 @@ extern "C" int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
   }
   // SFRON_GEMM_NT (A-B knob, default 0): bit 0 = saved-for-backward epilogue outputs (pre-activation, branch output) are
   // stored nontemporally, bit 1 = weight gradients too.  Same-box A-B runs: bit 0 +-0.3 ms/step (noise), bit 1 +0.3 ms: off.
+#ifdef SFRON_DEBUG_KNOBS
   static const int nt_mask = [] { const char* e = getenv("SFRON_GEMM_NT"); return e ? atoi(e) : 0; }();
+#else
+  constexpr int nt_mask = 0;
+#endif
   g.nt_out = (nt_mask & 1) | ((nt_mask & 2) && d->a_transposed && d->b_transposed && d->split_k <= 1 && !d->accumulate ? 2 : 0);
   g.ntm = cdiv(d->M, BM); g.ntn = cdiv(d->N, BN);
+  g.bsum = nullptr;
+  if (d->a_rowsum) {        // only the auto-dispatched three-slot weight-gradient kernel forms it
+    SFRON_CHECK_ARG(d->rowsum_ws && d->a_transposed && d->b_transposed && d->epilogue == SFRON_EPI_F32 && d->split_k <= 1 &&
+                    d->tile_hint == 0);
+    if (!rowsum_ok(d->M, d->N, d->K)) return SFRON_ERR_UNSUPPORTED;
+    g.bsum = d->rowsum_ws;                                         // [N / 192][M] partial rows
+    const int rc = dispatch_layout<EPI_F32>(1, 1, g, (hipStream_t)stream, 0);
+    if (rc != SFRON_OK) return rc;
+    return sfron_reduce_chunks(d->rowsum_ws, 1, d->N / 192, d->M, d->a_rowsum, d->M, 0, stream);
+  }
   hipStream_t s = (hipStream_t)stream;
   const int force = d->tile_hint;   // 0 auto, -1 generic kernel, 1/2/3 force a fast tile (tests, tuning)
   switch (d->epilogue) {

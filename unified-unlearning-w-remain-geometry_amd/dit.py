@@ -112,6 +112,9 @@ class DiT(nn.Module):
         eng.sync_bf16()
 
     def load_state_dict(self, state_dict, strict=True, **kw):
+        # checkpoints written by the reference come from an nn.DataParallel wrapper (DiT/forget.py:193,347): "module." keys
+        if state_dict and all(k.startswith("module.") for k in state_dict):
+            state_dict = {k[len("module."):]: v for k, v in state_dict.items()}
         r = super().load_state_dict(state_dict, strict=strict, **kw)
         self.engine.sync_bf16()
         return r
@@ -121,9 +124,9 @@ class DiT(nn.Module):
         if batch_size == self.engine.cfg.batch:
             return
         old = self.engine
-        new = DitEngine(batch_size, share=old, **self._engine_args)
-        new.grads, new.probe = old.grads, old.probe
-        _lib.lib().sfron_aux_destroy(old.aux)
+        new = DitEngine(batch_size, share=old, grads=old.grads, **self._engine_args)     # same parameter AND gradient arenas
+        new.probe, old.probe = old.probe, None
+        old.close()
         self.engine = new
 
     # ------------------------------------------------------------------ forward
@@ -176,6 +179,8 @@ def _make(name):
     return ctor
 
 
+# (the */8 configurations need input_size >= 64: the attention kernels take token counts that are multiples of 64, and
+#  sfron_dit_param_layout rejects the 16-token grid a 32 x 32 latent gives them)
 DiT_models = {name: _make(name) for name in _CONFIGS}
 
 

@@ -19,8 +19,9 @@ _LAYOUT_KEYS = ["total", "trainable", "pe_w", "pe_b", "t0_w", "t0_b", "t2_w", "t
 
 class DitEngine:
     def __init__(self, batch, input_size=32, patch_size=2, in_channels=4, hidden_size=1152, depth=28, num_heads=16,
-                 mlp_ratio=4.0, num_classes=1000, learn_sigma=True, device="cuda", share=None):
-        """share: another DitEngine whose parameter arenas (fp32 + bf16) this one uses (own workspace, grads, aux)."""
+                 mlp_ratio=4.0, num_classes=1000, learn_sigma=True, device="cuda", share=None, grads=None):
+        """share: another DitEngine whose parameter arenas (fp32 + bf16) this one uses (own workspace, aux; own gradient
+        arena unless ``grads`` hands one over)."""
         self._ctor = dict(input_size=input_size, patch_size=patch_size, in_channels=in_channels, hidden_size=hidden_size,
                           depth=depth, num_heads=num_heads, mlp_ratio=mlp_ratio, num_classes=num_classes,
                           learn_sigma=learn_sigma, device=device)
@@ -46,16 +47,33 @@ class DitEngine:
         else:
             assert share.n_total == self.n_total
             self.params, self.params_bf16 = share.params, share.params_bf16
-        self.grads = torch.zeros(self.n_total, dtype=torch.float32, device=self.device)
+        self.grads = grads if grads is not None else torch.zeros(self.n_total, dtype=torch.float32, device=self.device)
+        assert self.grads.numel() == self.n_total
         ws = L.sfron_dit_workspace_bytes(ctypes.byref(c))
         if ws < 0:
             raise _lib.SfronError("unsupported DiT config")
         self.workspace = torch.empty(ws, dtype=torch.uint8, device=self.device)
         self.out_shape = (batch, c.out_channels, input_size, input_size)
-        self.probe = None
+        self.probe = self.wprobe = None
         h = ctypes.c_void_p()
         check(L.sfron_aux_create(ctypes.byref(h)), "aux_create")     # side stream + events for concurrent wgrads
         self.aux = h
+
+    def close(self):
+        """Release the library-side handles (side stream + events, probe events).  Idempotent; also run by __del__."""
+        aux, probe, wprobe = getattr(self, "aux", None), getattr(self, "probe", None), getattr(self, "wprobe", None)
+        self.aux = self.probe = self.wprobe = None
+        try:
+            if aux is not None:
+                _lib.lib().sfron_aux_destroy(aux)
+            for h in (probe, wprobe):
+                if h is not None:
+                    _lib.lib().sfron_probe_destroy(h)
+        except Exception:          # interpreter shutdown: the library may already be gone
+            pass
+
+    def __del__(self):
+        self.close()
 
     def sibling(self, batch):
         """A second engine over the SAME parameters (own workspace / gradient arena / side stream) for a micro-batch chain."""
@@ -127,6 +145,18 @@ class DitEngine:
         h = ctypes.c_void_p()
         check(_lib.lib().sfron_probe_create(int(max_samples), ctypes.byref(h)), "probe_create")
         self.probe = h
+
+    def wgrad_probe_enable(self, max_samples):
+        """Event pairs around the qkv / fc1 weight-gradient GEMMs (every 9th block) on the weight-gradient stream."""
+        h = ctypes.c_void_p()
+        check(_lib.lib().sfron_probe_create(int(max_samples), ctypes.byref(h)), "probe_create")
+        check(_lib.lib().sfron_aux_set_probe(self.aux, h), "aux_set_probe")
+        self.wprobe = h
+
+    def wgrad_probe_read(self):
+        n, ms = ctypes.c_int(0), ctypes.c_double(0.0)
+        check(_lib.lib().sfron_probe_read(self.wprobe, ctypes.byref(n), ctypes.byref(ms)), "probe_read")
+        return n.value, ms.value
 
     def probe_reset(self):
         check(_lib.lib().sfron_probe_reset(self.probe), "probe_reset")

@@ -1,0 +1,42 @@
+"""Fail-loud checks of an unlearning step that do not stall the host.
+
+The reference raises where something is off (a bad label is an IndexError inside nn.Embedding, DiT/models.py:89-93; a NaN
+loss shows in its per-step log line, DiT/forget.py:329-336).  The fast path never reads a device value on the host, so the
+checks are device-side counters (a few tiny torch ops per step) whose snapshot travels to a pinned host buffer behind a HIP
+event; ``poll()`` looks at the snapshot of an EARLIER step once its event has completed -- no synchronisation -- and raises
+``SfronError``.  ``poll(block=True)`` (end of a run, bench.py, tests) waits for the newest snapshot.
+"""
+import torch
+
+from ._lib import SfronError
+
+REASONS = ("non-finite loss", "non-finite gradient norm", "label outside [0, num_classes)", "timestep outside [0, num_timesteps)")
+
+
+class StepGuard:
+    def __init__(self, device):
+        self.flags = torch.zeros(len(REASONS), dtype=torch.float32, device=device)
+        self.host = torch.zeros(len(REASONS), dtype=torch.float32).pin_memory()
+        self.event = None
+        self.published_step = -1
+
+    def note(self, idx, bad):
+        """bad: 0-dim bool / number tensor on the device (True = violation).  Accumulates; never reset."""
+        self.flags[idx] += bad.to(torch.float32)
+
+    def publish(self, step_no):
+        self.host.copy_(self.flags, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self.published_step = step_no
+
+    def poll(self, block=False):
+        if self.event is None:
+            return
+        if block:
+            self.event.synchronize()
+        elif not self.event.query():
+            return
+        bad = [REASONS[i] for i in range(len(REASONS)) if float(self.host[i]) != 0.0]
+        if bad:
+            raise SfronError(f"SFR-on step guard (by step {self.published_step}): " + "; ".join(bad))

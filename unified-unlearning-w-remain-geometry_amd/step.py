@@ -8,12 +8,10 @@ One call = one iteration of /root/reference/DiT/forget.py:256-322 (method "ron")
 Data-parallel: every rank holds full replicas (weights, Adam state, EMA, mask) and a shard of each
 minibatch; gradients are scaled by 1/global_batch in the loss kernel and SUM-all-reduced over RCCL.
 """
-import os
-
 import torch
 import torch.distributed as dist
 
-from . import _lib, dp, ops, sweep
+from . import _lib, dp, guard, ops, sweep
 
 
 def build_mask_arena(engine, mask):
@@ -40,12 +38,17 @@ def build_mask_arena(engine, mask):
 
 class DiTSFRon:
     def __init__(self, model, diffusion, lr=1e-4, forget_alpha=1e-3, grad_clip=1.0, ema_decay=0.9999, mask=None,
-                 unlearn_loss="ga", forget_class=0, process_group=None, bucket_bytes=256 << 20, micro_batches=1):
+                 unlearn_loss="ga", forget_class=0, process_group=None, bucket_bytes=256 << 20, micro_batches=1,
+                 overlap_allreduce=False):
         """micro_batches = 2: each forward/backward pass runs as TWO independent half-batch chains on two HIP streams
         (own workspace, own gradient arena, own side stream); the latency-bound kernels of one chain (attention,
         LayerNorm / gate backward) then run under the GEMMs of the other.  The optimizer sweep sums the two arenas."""
         if unlearn_loss not in ("ga", "rl"):
             raise ValueError(f"unsupported unlearn_loss {unlearn_loss!r} (DiT/forget.py defines only 'ga' and 'rl')")
+        if unlearn_loss == "rl" and (forget_class + 100) % 1000 >= model.num_classes:
+            # DiT/forget.py:275-279 hard-codes (forget_class + 100) % 1000; with fewer classes the reference's nn.Embedding
+            # raises an IndexError -- so do we, up front
+            raise ValueError(f"'rl' relabels to class {(forget_class + 100) % 1000}, outside num_classes = {model.num_classes}")
         self.model, self.diffusion = model, diffusion
         self.forget_alpha, self.grad_clip, self.ema_decay = forget_alpha, grad_clip, ema_decay
         self.unlearn_loss, self.forget_class = unlearn_loss, forget_class
@@ -56,9 +59,15 @@ class DiTSFRon:
         if micro_batches not in (1, 2):
             raise ValueError("micro_batches must be 1 or 2")
         self.micro = micro_batches
+        # overlap_allreduce: exchange each block's gradient range while the backward pass of the earlier blocks is still
+        # running.  Off unless asked for: bench.py turns it on at N > 1 only after verify_overlap() has shown, on the ranks
+        # of that very run, that it reproduces the synchronous bucketed exchange.
+        self.overlap = bool(overlap_allreduce)
         self._chains = None
         self._comm = None
         self._ada_all = None
+        self.guard = guard.StepGuard(model.engine.device)
+        self.iteration = 0
         self._bind(mask)
 
     def _bind(self, mask):
@@ -74,11 +83,32 @@ class DiTSFRon:
 
     # ------------------------------------------------------------------ all-reduce overlapped with the backward pass
     def _overlap_enabled(self):
-        """On for world > 1 (SFRON_DP_OVERLAP=0 turns it off; =force runs the same code path at world 1, for tests)."""
-        mode = os.environ.get("SFRON_DP_OVERLAP", "1")
-        if mode == "0" or self.micro != 1 or not (dist.is_available() and dist.is_initialized()):
+        """The overlapped exchange runs when asked for (``overlap_allreduce`` / ``self.overlap``), single-chain passes only;
+        it needs an initialised process group (world size 1 is allowed: the tests run the same code path over RCCL)."""
+        return self.overlap and self.micro == 1 and dist.is_available() and dist.is_initialized()
+
+    def verify_overlap(self, batch, y=None, rtol=2e-3):
+        """Run one forget-stage forward/backward twice from the same state -- synchronous bucketed all-reduce, then the
+        overlapped exchange -- and compare the reduced gradient arenas (they differ by summation order only).  Collective:
+        every rank calls it; returns the same verdict on every rank.  Leaves parameters and optimizer state untouched."""
+        if not (dist.is_available() and dist.is_initialized()) or self.micro != 1:
             return False
-        return self.world > 1 or mode == "force"
+        eng = self.model.engine
+        nt = eng.n_trainable
+        y = batch["y"] if y is None else y
+        keep = self.overlap
+        try:
+            self.overlap = False
+            self._pass(batch, y, -self.forget_alpha)
+            g_sync = eng.grads[:nt].clone()
+            self.overlap = True
+            self._pass(batch, y, -self.forget_alpha)
+            diff = (eng.grads[:nt] - g_sync).norm() / (g_sync.norm() + 1e-30)
+            ok = (torch.isfinite(diff) & (diff < rtol)).to(torch.float32)
+        finally:
+            self.overlap = keep
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.pg)
+        return bool(ok.item())
 
     def _backward_allreduce_overlapped(self, d_out, y, drop):
         """Backward + gradient exchange.  The library records one event per block on its weight-gradient stream when that
@@ -105,10 +135,11 @@ class DiTSFRon:
         # 892 MB, all-gather its two bf16 factors (dmod [B][(6L+2)D], silu(c) [B][D]: 12.5 MB per rank) and form the product
         # over the GLOBAL batch with one GEMM -- the same sum, taken in one place
         B, NM, D = eng.cfg.batch, eng.ada_dmod.shape[1], eng.cfg.hidden
-        if self._ada_all is None:
-            self._ada_all = (torch.empty(self.world * B, NM, dtype=torch.bfloat16, device=eng.device),
+        key = (self.world, B, NM, D)
+        if self._ada_all is None or self._ada_all[0] != key:       # re-made when the per-GPU batch changes (set_batch_size)
+            self._ada_all = (key, torch.empty(self.world * B, NM, dtype=torch.bfloat16, device=eng.device),
                              torch.empty(self.world * B, D, dtype=torch.bfloat16, device=eng.device))
-        dmod_all, sc_all = self._ada_all
+        _, dmod_all, sc_all = self._ada_all
         dist.all_gather_into_tensor(dmod_all, eng.ada_dmod, group=self.pg)
         dist.all_gather_into_tensor(sc_all, eng.ada_sc, group=self.pg)
         ada_w = eng.grads[lay["ada_w"]:lay["ada_w"] + NM * D].view(NM, D)
@@ -165,7 +196,25 @@ class DiTSFRon:
             self.opt.g2 = e1.grads[:e1.n_trainable]
         return torch.cat([outs[0][0], outs[1][0]]), torch.cat([outs[0][1], outs[1][1]])
 
+    def _checked(self, batch, y):
+        """Inputs of one pass with the label-dropout draw filled in and out-of-range indices made harmless + flagged:
+        the reference's nn.Embedding / table gather raise an IndexError on a bad label or timestep (DiT/models.py:89-93,
+        gaussian_diffusion.py:861-873); here the kernels see clamped indices (never an out-of-bounds access) and the guard
+        raises SfronError at its next poll."""
+        b = dict(batch)
+        if b.get("drop") is None:
+            # the reference trains both stages under model.train(): LabelEmbedder.token_drop with p = 0.1 (models.py:78-87)
+            b["drop"] = self.model._draw_drop(b["x0"].shape[0])
+        nc, nT = self.model.num_classes, self.diffusion.num_timesteps
+        t_safe = b["t"].clamp(0, nT - 1)
+        y_safe = y.clamp(0, nc - 1)
+        self.guard.note(2, (y_safe != y).any())
+        self.guard.note(3, (t_safe != b["t"]).any())
+        b["t"] = t_safe
+        return b, y_safe
+
     def _pass(self, batch, y, sign_alpha):
+        batch, y = self._checked(batch, y)
         if self.micro == 2:
             return self._pass2(batch, y, sign_alpha)
         eng, diff = self.model.engine, self.diffusion
@@ -183,6 +232,7 @@ class DiTSFRon:
     def step(self, forget, remain):
         """forget / remain: dicts of GPU tensors x0 [N,4,S,S] fp32, y [N] int64, t [N] int64, noise, drop [N] uint8
         (this rank's shard).  Returns per-sample mse / vb tensors (device; no host sync here)."""
+        self.guard.poll()                      # raises on what an EARLIER step found (no synchronisation)
         if self.micro == 1:
             self.model.set_batch_size(forget["x0"].shape[0])
         eng = self.model.engine
@@ -197,6 +247,13 @@ class DiTSFRon:
         self.opt.step(max_norm=None, use_mask=False, ema=self.ema[:nt], ema_decay=self.ema_decay, ema_mode=1)  # :320,322
         if eng.n_total > nt:
             sweep.ema_update(self.ema[nt:], eng.params[nt:], self.ema_decay, mode=1)         # frozen pos_embed (:60-62)
+        # fail loud: a NaN / Inf loss or gradient norm would otherwise poison every weight through
+        # the clip coefficient; counted on the device here, raised by the next poll()
+        self.guard.note(0, ~(torch.isfinite(mse_f).all() & torch.isfinite(vb_f).all() & torch.isfinite(mse_r).all()
+                             & torch.isfinite(vb_r).all()))
+        self.guard.note(1, ~torch.isfinite(self.opt.stats[0]))
+        self.iteration += 1
+        self.guard.publish(self.iteration)
         return {"forget_mse": mse_f, "forget_vb": vb_f, "remain_mse": mse_r, "remain_vb": vb_r,
                 "forget_sign": sign, "stats": self.opt.stats}
 
@@ -222,16 +279,21 @@ class DiTSFRon:
                  "decoupled_weight_decay": True, "params": list(range(len(names)))}
         return {"state": state, "param_groups": [group]}
 
-    def checkpoint(self, args=None):
-        """{"model", "ema", "opt", "args"} exactly as DiT/forget.py:346-353 saves it (pass the dict to torch.save)."""
-        return {"model": {k: v.clone() for k, v in self.model.state_dict().items()}, "ema": self.ema_state_dict(),
+    def checkpoint(self, args=None, data_parallel_prefix=False):
+        """{"model", "ema", "opt", "args"} as DiT/forget.py:346-353 saves it (pass the dict to torch.save).  The reference
+        saves ``model.state_dict()`` of its nn.DataParallel wrapper (forget.py:193,347), whose keys carry a "module."
+        prefix; ``data_parallel_prefix=True`` writes them that way ("ema" is the unwrapped copy there too: no prefix)."""
+        pre = "module." if data_parallel_prefix else ""
+        return {"model": {pre + k: v.clone() for k, v in self.model.state_dict().items()}, "ema": self.ema_state_dict(),
                 "opt": self.opt_state_dict(), "args": args}
 
     def load_checkpoint(self, ckpt):
-        """Resume from a checkpoint in that format (ours or the reference's)."""
+        """Resume from a checkpoint in that format: ours, or one written by the reference, whose "model" keys carry the
+        nn.DataParallel "module." prefix (DiT.load_state_dict strips it)."""
         eng = self.model.engine
         self.model.load_state_dict(ckpt["model"])
         for name, v in ckpt["ema"].items():
+            name = name[len("module."):] if name.startswith("module.") else name
             eng.view(self.ema, name).copy_(v.to(self.ema.device))
         names = [n for n, _ in self.model.named_parameters()]
         self.opt.m.zero_(); self.opt.v.zero_()

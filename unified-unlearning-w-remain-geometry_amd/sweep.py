@@ -33,6 +33,7 @@ class FlatAdam:
         self.w_bf16 = w_bf16        # bf16 [n] shadow or None
         self.step_count = 0
         self.g2 = None              # optional second gradient arena (micro-batch chains), summed inside the kernels
+        self.timed = None           # bench.py: a list that receives a (start, end) torch event pair per sweep launch
         L = _lib.lib()
         self._partials = torch.empty(L.sfron_sweep_partials_len(), dtype=torch.float64, device=params.device)
         self.stats = torch.zeros(4, dtype=torch.float32, device=params.device)
@@ -61,12 +62,20 @@ class FlatAdam:
         step_size = self.lr / bc1
         bc2_sqrt = math.sqrt(bc2)
         decay_mul = 1.0 - self.lr * self.wd
+        ev = None
+        if self.timed is not None:
+            import torch as _t
+            ev = (_t.cuda.Event(enable_timing=True), _t.cuda.Event(enable_timing=True))
+            ev[0].record()
         check(L.sfron_masked_clip_adam(ptr(self.p), ptr(self.g), ptr(self.g2), ptr(self.m), ptr(self.v),
                                        ptr(self.mask if use_mask else None),
                                        ptr(self.stats if max_norm is not None else None),
                                        self.p.numel(), b1, b2, self.eps, step_size, bc2_sqrt, decay_mul,
                                        ptr(self.w_bf16), ptr(ema), float(ema_decay), int(ema_mode if ema is not None else 0),
                                        stream_ptr()), "masked_clip_adam")
+        if ev is not None:
+            ev[1].record()
+            self.timed.append(ev)
 
 
 def ema_update(ema, p, decay, mode=1):
