@@ -165,6 +165,89 @@ int sfron_gemm_bf16(const sfron_gemm_desc* desc /* HOST pointer */, void* stream
 /* 1 when a weight-gradient GEMM dW[M][N] = dY[K][M]^T X[K][N] of this shape can also produce a_rowsum (else use sfron_colsum) */
 int sfron_gemm_rowsum_supported(int M, int N, int K);
 
+
+/* ------------------------------------------------------------------ convolutional U-Net blocks (conv.hip)
+ * Replaces the Conv2d / GroupNorm / bmm-softmax sequences of DDPM/models/diffusion.py:43-192,283-413 (Conditional_Model) forward
+ * and backward.  Activations are NHWC: a [batch * H * W][C] row-major matrix (bf16 where they feed a GEMM, fp32 elsewhere). */
+
+/* batched GEMM on the generic 128x128 tile: C[z] = alpha * op(A[z]) op(B[z]) (+ bias) (+ resid) (+ per-sample row vector),
+ * z < batch, operands advanced by the element strides; layouts as sfron_gemm_desc.  Exactly one of c_bf16 / c_f32 is set. */
+typedef struct sfron_bgemm_desc {
+  const uint16_t* A; const uint16_t* B;
+  int M, N, K, lda, ldb;
+  int a_transposed, b_transposed;
+  int batch;
+  long stride_a, stride_b, stride_c;
+  float alpha;
+  const float* bias;               /* [N] or NULL */
+  uint16_t* c_bf16; float* c_f32; int ldc;
+  const float* resid;              /* fp32 [M][ldc] added to the result (c_f32 only), or NULL */
+  const float* sample_vec;         /* fp32 vec[(row / rows_per_sample) * ld_vec + col] added (c_f32 only), or NULL */
+  int ld_vec, rows_per_sample;
+  int accumulate;                  /* c_f32 += result */
+} sfron_bgemm_desc;
+int sfron_bgemm_bf16(const sfron_bgemm_desc* desc /* HOST pointer */, void* stream);
+
+/* implicit-GEMM convolution.  The GEMM rows are the pixels of an (h_out x w_out) grid per sample; row p = (b, ho, wo) reads, for
+ * tap (kh, kw), the source pixel (ho * stride + kh - pad, wo * stride + kw - pad) of a [batch][h_src][w_src][c_src] bf16 image:
+ *   upsample = 1: through a nearest x2 upsampling (F.interpolate(scale_factor=2) + conv, models/diffusion.py:56-60)
+ *   dilate   = 1: as a zero-dilated x2 image (the input gradient of a stride-2 convolution)
+ * and zero outside it (padding; the (0,1,0,1) pad of Downsample, :76-80, is the bottom / right edge of a pad-0 stride-2 conv). */
+typedef struct sfron_conv_desc {
+  int batch, h_src, w_src, c_src;   /* c_src % 8 == 0 */
+  int h_out, w_out;
+  int n_out;                        /* GEMM N: output channels (forward) / input channels (input gradient) */
+  int taps, stride, pad, upsample, dilate;
+  const float* bias;                /* [n_out] or NULL */
+  const float* resid;               /* fp32 [rows][ld_out] added (out_f32 only) or NULL */
+  const float* sample_vec;          /* fp32 [batch][ld_vec] added per sample (out_f32 only) or NULL */
+  int ld_vec;
+  uint16_t* out_bf16; float* out_f32; int ld_out;
+  int accumulate;
+} sfron_conv_desc;
+/* out[p][n] = sum_{tap, c} src[src(p, tap)][c] * w[n][tap][c]; w bf16 [n_out][taps][c_src] (sfron_conv_wprep's "fwd" layout;
+ * the input gradient calls this on dY with the "dgrad" layout) */
+int sfron_conv_fwd(const sfron_conv_desc* desc, const uint16_t* src, const uint16_t* w, void* stream);
+/* dw_gemm fp32 [n_out][taps * c_src] = sum_p dy[p][n] * src[src(p, tap)][c]   (dy bf16 [rows][ld_dy]) */
+int sfron_conv_wgrad(const sfron_conv_desc* desc, const uint16_t* dy, int ld_dy, const uint16_t* src, float* dw_gemm, void* stream);
+/* fp32 OIHW master weights -> bf16 operands: w_fwd [c_out_p][taps][c_in_p] (zero padded), w_dgrad [c_in][taps flipped][c_out_p] or NULL */
+int sfron_conv_wprep(const float* w_oihw, int c_out, int c_in, int taps, int c_out_p, int c_in_p, uint16_t* w_fwd, uint16_t* w_dgrad,
+                     void* stream);
+/* dw_gemm [c_out_p..][taps][c_in_p] -> OIHW gradient [c_out][c_in][taps] (overwrite) */
+int sfron_conv_wgrad_scatter(const float* dw_gemm, int c_out, int c_in, int taps, int c_in_p, float* dw_oihw, void* stream);
+
+int sfron_nchw_to_rows_bf16(const float* x, int B, int C, int HW, int c_pad, uint16_t* rows, void* stream);
+int sfron_nchw_to_rows_f32(const float* x, int B, int C, int HW, int ld, float* rows, void* stream);
+int sfron_rows_to_nchw(const float* rows, int ld, int B, int C, int HW, float* x, void* stream);
+
+/* y = bf16( act(GroupNorm(x; groups, eps) * gamma + beta) [* drop_mask * drop_scale] ), act = swish when `swish`; x fp32 rows
+ * [B * HW][ldx]; mean / rstd [B][groups] saved for the backward pass (models/diffusion.py:43-46,126-131) */
+int sfron_groupnorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, int B, int HW, int C, int groups, float eps,
+                        int swish, const uint8_t* drop_mask, float drop_scale, uint16_t* y, float* mean, float* rstd, void* stream);
+/* dy fp32 [B * HW][C] = gradient wrt y; dx (+)= gradient wrt x; part_gamma / part_beta [B][C] per-sample partial sums */
+int sfron_groupnorm_bwd(const float* dy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
+                        const float* rstd, int B, int HW, int C, int groups, int swish, const uint8_t* drop_mask, float drop_scale,
+                        float* dx, int lddx, int accumulate, float* part_gamma, float* part_beta, void* stream);
+/* p = bf16(softmax(scale * s)) over rows of length n; ds = bf16(scale * p * (dp - sum(p * dp)))   (AttnBlock, :168-186) */
+int sfron_softmax_fwd(const float* s, int64_t rows, int n, float scale, uint16_t* p, void* stream);
+int sfron_softmax_bwd(const uint16_t* p, const float* dp, int64_t rows, int n, float scale, uint16_t* ds, void* stream);
+/* out[b][c] = sum over the HW rows of sample b of x[row][c] */
+int sfron_sample_colsum(const float* x, int ld, int B, int HW, int C, float* out, int ld_out, void* stream);
+/* out = alpha * a + beta * b (guidance mix (1 + s) * cond - s * null of _forward_with_cond_scale, :340-357) */
+int sfron_axpby(const float* a, const float* b, float alpha, float beta, int64_t n, float* out, void* stream);
+/* backward of nearest x2 upsampling: dx[b][h][w][c] (+)= sum of the 2x2 block of dy [B][2H][2W][C] */
+int sfron_pool2_sum(const float* dy, int B, int H, int W, int C, float* dx, int accumulate, void* stream);
+int sfron_cast_rows_bf16(const float* x, int ldx, int64_t rows, int C, uint16_t* y, void* stream);
+/* y[r][0..C) (+)= x[r][0..C): channel-slice copies of torch.cat(dim=1) and its backward (:404) */
+int sfron_copy_cols(const float* x, int ldx, int64_t rows, int C, float* y, int ldy, int accumulate, void* stream);
+/* get_timestep_embedding (:17-35): bf16 [n][dim] = sin(t f) || cos(t f), f_j = exp(-ln(1e4) j / (dim/2 - 1)); t float */
+int sfron_ddpm_timestep_embed(const float* t, int n, int dim, uint16_t* out, void* stream);
+/* out[b] = keep[b] ? table[c[b]] : null_emb (:370-376; keep NULL = all kept); backward accumulates into d_table (+=), writes d_null */
+int sfron_class_embed_fwd(const float* table, const float* null_emb, const int64_t* c, const uint8_t* keep, int n_classes, int n, int D,
+                          uint16_t* out, void* stream);
+int sfron_class_embed_bwd(const float* d, const int64_t* c, const uint8_t* keep, int n_classes, int n, int D, float* d_table, float* d_null,
+                          void* stream);
+
 /* ------------------------------------------------------------------ adaLN-Zero elementwise (norm.hip)
  * mod buffers are fp32 [batch][ldmod]; shift/scale/gate pointers already include the column offset of the
  * chunk (DiT/models.py:119 .chunk(6, dim=1)).  `tokens` = tokens per sample (row / tokens = sample). */

@@ -128,7 +128,9 @@ class DDPMSfronOracle:
     """DDPM/runners/diffusion.py:1075-1180 over an arbitrary eps-model ``model(x, t_float, c, drop)``."""
 
     def __init__(self, model, betas, lr=1e-4, forget_alpha=10.0, remain_alpha=1.0, grad_clip=1.0,
-                 ema_mu=1e-4, mask=None, unlearn_loss="adaga", lambd=0.5, n_iters=50, decay_forget_alpha=True):
+                 ema_mu=1e-4, mask=None, unlearn_loss="adaga", lambd=0.5, n_iters=50, decay_forget_alpha=True, label_to_forget=0,
+                 n_classes=10):
+        self.label_to_forget, self.n_classes = label_to_forget, n_classes
         self.model = model
         self.b = betas
         # DDPM/functions/__init__.py:9-18 with cifar10_sfron.yml:48-56
@@ -145,13 +147,23 @@ class DDPMSfronOracle:
         m = self.model
         alpha = cosine_alpha(self.forget_alpha, step_idx, self.n_iters) if self.decay else self.forget_alpha
         fn_f = lambda x, tf: m(x, tf, forget["c"], forget["drop"])
-        per = ddpm_loss_per_sample(fn_f, forget["x0"], forget["t"], forget["e"], self.b)
-        if self.unlearn_loss == "ga":
-            ori_forget = -per.mean(dim=0)
-        elif self.unlearn_loss == "adaga":
-            ori_forget = -ddpm_adaptive_loss(per, self.lambd)
+        if self.unlearn_loss == "rl":
+            # DDPM/runners/diffusion.py:1101-1113: MSE between the prediction under the forget label and the (detached)
+            # prediction under the pseudo label (label_to_forget + 1) % 10, on the same x_t
+            a = ddpm_alphas_cumprod_fp32(self.b).index_select(0, forget["t"]).view(-1, 1, 1, 1)
+            x = forget["x0"] * a.sqrt() + forget["e"] * (1.0 - a).sqrt()
+            output = m(x, forget["t"].float(), forget["c"], forget["drop"])
+            pseudo_c = torch.full(forget["c"].shape, (self.label_to_forget + 1) % self.n_classes)
+            pseudo = m(x, forget["t"].float(), pseudo_c, forget["drop"]).detach()
+            ori_forget = torch.nn.functional.mse_loss(pseudo, output)
         else:
-            raise ValueError(self.unlearn_loss)
+            per = ddpm_loss_per_sample(fn_f, forget["x0"], forget["t"], forget["e"], self.b)
+            if self.unlearn_loss == "ga":
+                ori_forget = -per.mean(dim=0)
+            elif self.unlearn_loss == "adaga":
+                ori_forget = -ddpm_adaptive_loss(per, self.lambd)
+            else:
+                raise ValueError(self.unlearn_loss)
         self.opt.zero_grad()
         (alpha * ori_forget).backward()
         if self.mask is not None:

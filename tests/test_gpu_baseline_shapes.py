@@ -229,8 +229,8 @@ def test_dit_b4_full_depth_sfron_iterations_vs_oracle():
         assert got["stats"][0].item() == pytest.approx(want["forget_gnorm"], rel=5e-2)
     agree, bulk = _update_agreement(ref, model.engine, p0)
     print(f"DiT-B/4 depth 12, 3 iterations: update sign agreement {agree:.4f}, bulk relative error of the update {bulk:.3f}")
-    assert agree > 0.97, agree
-    assert bulk < 0.35, bulk
+    assert agree > 0.995, agree          # measured 0.9998
+    assert bulk < 0.08, bulk             # measured 0.023
     assert runner.opt.step_count == 6
 
 
@@ -274,4 +274,4 @@ def test_dit_b4_fifty_step_eps_mse_within_1e4_of_oracle():
     print(f"DiT-B/4: max per-step |mse gap| over 50 steps = {worst:.2e}; held-out eps-MSE gap after 50 steps = {final_gap:.2e} "
           f"(oracle {t_ref['mse'].mean().item():.5f})")
     assert final_gap < 1e-4, final_gap
-    assert worst < 2e-3, worst        # per-step training-batch mse (bf16 forward noise on a loss of O(1)); measured bound in DESIGN.md
+    assert worst < 1e-3, worst        # per-step training-batch mse (bf16 forward noise on a loss of O(1)); measured bound in DESIGN.md

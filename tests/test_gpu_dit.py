@@ -124,8 +124,8 @@ def test_sfron_iterations_vs_oracle(case, loss, micro):
     # (an absolute |du - du_ref| bound would be vacuous: Adam moves a weight by at most lr per step whatever the gradient.)
     # What carries information: the share of coordinates that moved the same way and the bulk error of the update vector.
     print(f"{case}/{loss}/micro{micro}: update sign agreement {same / tot:.4f}, bulk relative error {(err / den) ** 0.5:.3f}")
-    assert same / tot > 0.95, same / tot
-    assert (err / den) ** 0.5 < 0.45, (err / den) ** 0.5
+    assert same / tot > 0.995, same / tot                # measured 0.9998
+    assert (err / den) ** 0.5 < 0.08, (err / den) ** 0.5   # measured 0.017 .. 0.031
     for n in ("blocks.0.mlp.fc1.weight", "pos_embed", "final_layer.linear.bias"):
         e = eng.view(runner.ema, n).cpu()
         assert torch.allclose(e, orc.ema[n], atol=5e-4), n

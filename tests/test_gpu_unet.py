@@ -1,0 +1,400 @@
+"""GPU parity of the convolutional U-Net path (csrc/conv.hip + sfron.unet) -- the DDPM Conditional_Model of BASELINE config 0:
+(1) each kernel against torch fp32 on the same bf16-rounded inputs (implicit-GEMM convolution forward / input gradient / weight
+    gradient incl. the (0,1,0,1)-pad stride-2 Downsample and the nearest-x2 Upsample forms, GroupNorm(32)+swish+dropout forward /
+    backward, batched GEMM + softmax of the single-head AttnBlock);
+(2) the whole model forward + backward against the oracle (oracle/ddpm_ref.py, pinned to DDPM/models/diffusion.py by
+    tests/golden/ddpm_model.npz) with the SAME classifier-free keep mask and dropout masks, at a reduced depth and at
+    cifar10_sfron.yml's size (38.6 M parameters, batch 64);
+(3) the SFR-on loop body DDPM/runners/diffusion.py:1075-1180 (adaga / ga / rl) on the native denoiser against DDPMSfronOracle, and
+    BASELINE config 1 itself: 50 SFR-on steps, batch 64, on the HIP path.
+Tolerances: fp32 kernels 1e-5 .. 1e-4; bf16-operand GEMMs 2^-9 relative per element (bounds per test)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def _rows(x):      # NCHW -> NHWC rows
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
+
+def _nchw(r, B, H, W):
+    return r.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("form", ["same", "down", "up", "rgb_in", "rgb_out"])
+def test_conv3x3_forward_dgrad_wgrad(form):
+    import ctypes
+    from sfron import _lib, unet
+    from sfron._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(len(form))
+    B, H = 3, 8
+    ci, co = {"same": (32, 64), "down": (32, 32), "up": (32, 32), "rgb_in": (3, 32), "rgb_out": (32, 3)}[form]
+    cip, cop = unet._pad8(ci), unet._pad8(co)
+    x = torch.randn(B, ci, H, H, generator=g).to(torch.bfloat16).float()
+    w = (torch.randn(co, ci, 3, 3, generator=g) * 0.1)
+    bias = torch.randn(co, generator=g) * 0.1
+    wq = w.to(torch.bfloat16).float()
+    xr = torch.zeros(B * H * H, cip)
+    xr[:, :ci] = _rows(x)
+    xr = xr.to(torch.bfloat16).to(DEV)
+    wf = torch.empty(cop * 9 * cip, dtype=torch.bfloat16, device=DEV)
+    wd = torch.empty(ci * 9 * cop, dtype=torch.bfloat16, device=DEV) if ci % 8 == 0 else None
+    check(L.sfron_conv_wprep(ptr(w.to(DEV)), co, ci, 9, cop, cip, ptr(wf), ptr(wd), stream_ptr()), "wprep")
+    xt = x.clone().requires_grad_(True)
+    wt = wq.clone().requires_grad_(True)
+    if form == "down":          # Downsample (models/diffusion.py:76-80)
+        ref = F.conv2d(F.pad(xt, (0, 1, 0, 1)), wt, bias, stride=2, padding=0)
+        ho, kw = H // 2, dict(stride=2, pad=0, up=0)
+    elif form == "up":          # Upsample (:56-60)
+        ref = F.conv2d(F.interpolate(xt, scale_factor=2.0, mode="nearest"), wt, bias, padding=1)
+        ho, kw = 2 * H, dict(stride=1, pad=1, up=1)
+    else:
+        ref = F.conv2d(xt, wt, bias, padding=1)
+        ho, kw = H, dict(stride=1, pad=1, up=0)
+    rows = B * ho * ho
+    out = torch.empty(rows, cop, dtype=torch.float32, device=DEV)
+    bp = torch.zeros(cop)
+    bp[:co] = bias
+    d = unet._conv_desc(B, H, H, cip, ho, ho, cop, 9, kw["stride"], kw["pad"], kw["up"], 0, bias=bp.to(DEV), out_f32=out, ld_out=cop)
+    check(L.sfron_conv_fwd(ctypes.byref(d), ptr(xr), ptr(wf), stream_ptr()), "conv_fwd")
+    got = _nchw(out.cpu(), B, ho, ho)[:, :co]
+    np.testing.assert_allclose(got.numpy(), ref.detach().numpy(), rtol=2e-4, atol=2e-4 * math.sqrt(9 * ci))
+    if cop != co:
+        assert float(out[:, co:].abs().max()) == 0.0
+    # backward: d_out random (bf16-rounded)
+    dy = (torch.randn(ref.shape, generator=g) * 0.1).to(torch.bfloat16).float()
+    ref.backward(dy)
+    dyr = torch.zeros(rows, cop)
+    dyr[:, :co] = _rows(dy)
+    dyb = dyr.to(torch.bfloat16).to(DEV)
+    dwg = torch.full((cop * 9 * cip,), float("nan"), dtype=torch.float32, device=DEV)
+    wdsc = unet._conv_desc(B, H, H, cip, ho, ho, cop, 9, kw["stride"], kw["pad"], kw["up"], 0)
+    check(L.sfron_conv_wgrad(ctypes.byref(wdsc), ptr(dyb), cop, ptr(xr), ptr(dwg), stream_ptr()), "conv_wgrad")
+    dw = torch.empty(co, ci, 3, 3, dtype=torch.float32, device=DEV)
+    check(L.sfron_conv_wgrad_scatter(ptr(dwg), co, ci, 9, cip, ptr(dw), stream_ptr()), "scatter")
+    np.testing.assert_allclose(dw.cpu().numpy(), wt.grad.numpy(), rtol=3e-4, atol=3e-4 * math.sqrt(rows))
+    if wd is None:
+        return
+    if form == "down":
+        ds = torch.empty(B * H * H, ci, dtype=torch.float32, device=DEV)
+        dd = unet._conv_desc(B, ho, ho, cop, H, H, ci, 9, 1, 2, 0, 1, out_f32=ds, ld_out=ci)
+        check(L.sfron_conv_fwd(ctypes.byref(dd), ptr(dyb), ptr(wd), stream_ptr()), "dgrad")
+    elif form == "up":
+        du = torch.empty(rows, ci, dtype=torch.float32, device=DEV)
+        dd = unet._conv_desc(B, ho, ho, cop, ho, ho, ci, 9, 1, 1, 0, 0, out_f32=du, ld_out=ci)
+        check(L.sfron_conv_fwd(ctypes.byref(dd), ptr(dyb), ptr(wd), stream_ptr()), "dgrad")
+        ds = torch.empty(B * H * H, ci, dtype=torch.float32, device=DEV)
+        check(L.sfron_pool2_sum(ptr(du), B, H, H, ci, ptr(ds), 0, stream_ptr()), "pool2")
+    else:
+        ds = torch.empty(rows, ci, dtype=torch.float32, device=DEV)
+        dd = unet._conv_desc(B, ho, ho, cop, ho, ho, ci, 9, 1, 1, 0, 0, out_f32=ds, ld_out=ci)
+        check(L.sfron_conv_fwd(ctypes.byref(dd), ptr(dyb), ptr(wd), stream_ptr()), "dgrad")
+    np.testing.assert_allclose(_nchw(ds.cpu(), B, H, H).numpy(), xt.grad.numpy(), rtol=3e-4, atol=3e-4 * math.sqrt(9 * co))
+
+
+@pytest.mark.parametrize("C,HW,swish,drop", [(128, 64, 1, False), (256, 16, 1, True), (64, 256, 0, False), (384, 64, 1, True)])
+def test_groupnorm_swish_dropout_fwd_bwd(C, HW, swish, drop):
+    from sfron import _lib
+    from sfron._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(C + HW)
+    B = 3
+    x = torch.randn(B * HW, C, generator=g) * 1.5 + 0.3
+    gamma, beta = torch.randn(C, generator=g) * 0.5 + 1.0, torch.randn(C, generator=g) * 0.2
+    mask = (torch.rand(B * HW, C, generator=g) > 0.1).to(torch.uint8) if drop else None
+    scale = 1.0 / 0.9 if drop else 1.0
+    xt = x.clone().requires_grad_(True)
+    gt, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    xn = xt.view(B, HW, C).permute(0, 2, 1)                   # [B, C, HW]
+    z = F.group_norm(xn, 32, gt, bt, eps=1e-6)
+    if swish:
+        z = z * torch.sigmoid(z)
+    z = z.permute(0, 2, 1).reshape(B * HW, C)
+    if drop:
+        z = z * mask.float() * scale
+    y = torch.empty(B * HW, C, dtype=torch.bfloat16, device=DEV)
+    mean = torch.empty(B * 32, dtype=torch.float32, device=DEV)
+    rstd = torch.empty_like(mean)
+    xd, gd, bd = x.to(DEV), gamma.to(DEV), beta.to(DEV)
+    md = mask.to(DEV) if drop else None
+    check(L.sfron_groupnorm_fwd(ptr(xd), C, ptr(gd), ptr(bd), B, HW, C, 32, 1e-6, swish, ptr(md), scale, ptr(y), ptr(mean), ptr(rstd),
+                                stream_ptr()), "gn_fwd")
+    np.testing.assert_allclose(y.float().cpu().numpy(), z.detach().numpy(), rtol=1e-2, atol=1e-2)
+    dy = torch.randn(B * HW, C, generator=g) * 0.1
+    z.backward(dy)
+    dx = torch.full((B * HW, C), 0.5, dtype=torch.float32, device=DEV)
+    pg = torch.empty(B, C, dtype=torch.float32, device=DEV)
+    pb = torch.empty_like(pg)
+    check(L.sfron_groupnorm_bwd(ptr(dy.to(DEV)), ptr(xd), C, ptr(gd), ptr(bd), ptr(mean), ptr(rstd), B, HW, C, 32, swish, ptr(md), scale,
+                                ptr(dx), C, 1, ptr(pg), ptr(pb), stream_ptr()), "gn_bwd")
+    np.testing.assert_allclose(dx.cpu().numpy() - 0.5, xt.grad.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(pg.sum(0).cpu().numpy(), gt.grad.numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(pb.sum(0).cpu().numpy(), bt.grad.numpy(), rtol=2e-4, atol=2e-4)
+
+
+def test_batched_gemm_and_softmax():
+    from sfron import _lib, unet
+    from sfron._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    B, T, C = 5, 48, 64
+    qkv = (torch.randn(B * T, 3 * C, generator=g)).to(torch.bfloat16)
+    qd = qkv.to(DEV)
+    q, k, v = qkv.float().view(B, T, 3, C).unbind(2)
+    S = torch.empty(B * T, T, dtype=torch.float32, device=DEV)
+    unet.bgemm(qd.data_ptr(), qd.data_ptr() + 2 * C, T, T, C, lda=3 * C, ldb=3 * C, batch=B, sa=T * 3 * C, sb=T * 3 * C, sc=T * T, c_f32=S, ldc=T)
+    ref = q @ k.transpose(1, 2)
+    np.testing.assert_allclose(S.cpu().view(B, T, T).numpy(), ref.numpy(), rtol=1e-4, atol=1e-3)
+    P = torch.empty(B * T, T, dtype=torch.bfloat16, device=DEV)
+    scale = C ** -0.5
+    check(L.sfron_softmax_fwd(ptr(S), B * T, T, scale, ptr(P), stream_ptr()), "softmax")
+    pr = torch.softmax(ref * scale, dim=-1)
+    np.testing.assert_allclose(P.float().cpu().view(B, T, T).numpy(), pr.numpy(), rtol=1e-2, atol=2e-3)
+    O = torch.empty(B * T, C, dtype=torch.bfloat16, device=DEV)
+    unet.bgemm(P, qd.data_ptr() + 4 * C, T, C, T, lda=T, ldb=3 * C, b_t=True, batch=B, sa=T * T, sb=T * 3 * C, sc=T * C, c_bf16=O, ldc=C)
+    np.testing.assert_allclose(O.float().cpu().view(B, T, C).numpy(), (P.float().cpu().view(B, T, T) @ v).numpy(), rtol=1e-2, atol=1e-2)
+    dP = torch.randn(B * T, T, generator=g)
+    dS = torch.empty(B * T, T, dtype=torch.bfloat16, device=DEV)
+    check(L.sfron_softmax_bwd(ptr(P), ptr(dP.to(DEV)), B * T, T, scale, ptr(dS), stream_ptr()), "softmax_bwd")
+    pf = P.float().cpu()
+    want = scale * pf * (dP - (pf * dP).sum(-1, keepdim=True))
+    np.testing.assert_allclose(dS.float().cpu().numpy(), want.numpy(), rtol=1e-2, atol=2e-3)
+    # transposed forms: dV = P^T dO, dK = dS^T Q
+    dO = torch.randn(B * T, C, generator=g).to(torch.bfloat16).to(DEV)
+    dV = torch.empty(B * T, C, dtype=torch.bfloat16, device=DEV)
+    unet.bgemm(P, dO, T, C, T, lda=T, ldb=C, a_t=True, b_t=True, batch=B, sa=T * T, sb=T * C, sc=T * C, c_bf16=dV, ldc=C)
+    want = pf.view(B, T, T).transpose(1, 2) @ dO.float().cpu().view(B, T, C)
+    np.testing.assert_allclose(dV.float().cpu().view(B, T, C).numpy(), want.numpy(), rtol=1e-2, atol=1e-2)
+
+
+class _FixedDrop(torch.nn.Module):
+    """Stands in for a ResnetBlock's nn.Dropout inside the ORACLE so that it applies the mask the HIP path was given."""
+
+    def __init__(self, mask_nchw, p):
+        super().__init__()
+        self.m, self.s = mask_nchw, 1.0 / (1.0 - p)
+
+    def forward(self, x):
+        return x * self.m * self.s
+
+
+def _pair(cfg, seed):
+    from oracle import ddpm_ref
+    from sfron import unet
+    torch.manual_seed(seed)
+    ref = ddpm_ref.ConditionalUNet(**cfg)
+    model = unet.Conditional_Model(**{k: v for k, v in cfg.items()})
+    assert [n for n, _ in model.named_parameters()] == [n for n, _ in ref.named_parameters()]
+    assert list(model.state_dict().keys()) == list(ref.state_dict().keys())
+    model.load_state_dict({"module." + k: v for k, v in ref.state_dict().items()})        # DataParallel-style keys, as ckpt.pth has them
+    return ref, model
+
+
+def _resblocks_in_execution_order(ref):
+    blocks = []
+    for lvl in range(ref.num_resolutions):
+        blocks += list(ref.down[lvl].block)
+    blocks += [ref.mid.block_1, ref.mid.block_2]
+    for lvl in reversed(range(ref.num_resolutions)):
+        blocks += list(ref.up[lvl].block)
+    return blocks
+
+
+def _fwd_bwd_both(ref, model, cfg, B, seed, p_drop):
+    g = torch.Generator().manual_seed(seed)
+    S = cfg["resolution"]
+    x = torch.randn(B, 3, S, S, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    c = torch.randint(0, 10, (B,), generator=g)
+    keep = (torch.rand(B, generator=g) > 0.3)
+    w = torch.randn(B, 3, S, S, generator=g) * 0.1
+    # dropout masks per ResnetBlock in execution order (NHWC rows for the HIP path, NCHW for the oracle)
+    ref.train(); model.train()
+    masks_rows, blocks = [], _resblocks_in_execution_order(ref)
+    shapes = []
+    hook_handles = [blk.conv2.register_forward_pre_hook(lambda m, inp, sh=shapes: sh.append(tuple(inp[0].shape))) for blk in blocks]
+    with torch.no_grad():
+        ref(x, t.float(), c, mode="train", keep_mask=keep)
+    for h in hook_handles:
+        h.remove()
+    for blk, shp in zip(blocks, shapes):
+        if p_drop > 0:
+            m = (torch.rand(shp[0], shp[2], shp[3], shp[1], generator=g) >= p_drop)
+            masks_rows.append(m.reshape(-1, shp[1]).to(torch.uint8))
+            blk.dropout = _FixedDrop(m.permute(0, 3, 1, 2).float(), p_drop)
+        else:
+            masks_rows.append(None)
+            blk.dropout = torch.nn.Identity()
+    ref.zero_grad()
+    out_ref = ref(x, t.float(), c, mode="train", keep_mask=keep)
+    (out_ref * w).sum().backward()
+    out = model(x.to(DEV), t.float().to(DEV), c.to(DEV), mode="train", keep_mask=keep, dropout_masks=masks_rows)
+    assert out.requires_grad and out.shape == out_ref.shape
+    (out * w.to(DEV)).sum().backward()
+    return out, out_ref
+
+
+SMALL = dict(ch=128, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(8,), dropout=0.1, resolution=16, n_classes=10)
+CIFAR = dict(ch=128, ch_mult=(1, 2, 2, 2), num_res_blocks=2, attn_resolutions=(16,), dropout=0.1, resolution=32, n_classes=10)
+
+
+@pytest.mark.parametrize("cfg,B,p_drop", [(SMALL, 4, 0.0), (SMALL, 3, 0.1), (CIFAR, 8, 0.1)])
+def test_unet_forward_backward_vs_oracle(cfg, B, p_drop):
+    ref, model = _pair(cfg, seed=B)
+    model.dropout_p = p_drop if p_drop > 0 else 0.0
+    out, out_ref = _fwd_bwd_both(ref, model, cfg, B, seed=11, p_drop=p_drop)
+    e_out = _rel(out, out_ref)
+    worst, wname = 0.0, ""
+    dots = na = nb = 0.0
+    gmax = max(q.grad.norm().item() for q in ref.parameters())
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert q.grad is not None, n
+        ga, gb = p.grad.detach().cpu().flatten(), q.grad.flatten()
+        assert torch.isfinite(ga).all(), n
+        if n.endswith(".k.bias"):
+            # softmax over the keys is invariant to a constant added to every key's score: d k.bias = 0 exactly; both sides hold
+            # rounding noise only
+            assert ga.norm().item() < 1e-3 * gmax and gb.norm().item() < 1e-3 * gmax, n
+            continue
+        e = ((ga - gb).norm() / (gb.norm() + 1e-30)).item()
+        if e > worst:
+            worst, wname = e, n
+        dots += torch.dot(ga.double(), gb.double()).item(); na += ga.double().pow(2).sum().item(); nb += gb.double().pow(2).sum().item()
+    cos = dots / math.sqrt(na * nb)
+    print(f"U-Net {cfg['ch_mult']} B={B} dropout {p_drop}: out rel-L2 {e_out:.3e}, worst grad rel-L2 {worst:.3e} ({wname}), cosine {cos:.6f}")
+    assert e_out < 1.5e-2, e_out
+    assert worst < 5e-2, (wname, worst)
+    assert cos > 0.9995, cos
+
+
+def test_unet_cifar10_batch64_forward_backward_vs_oracle():
+    """cifar10_sfron.yml's model (38.6 M parameters) at the batch of BASELINE config 1."""
+    ref, model = _pair(CIFAR, seed=64)
+    assert sum(p.numel() for p in model.parameters()) == 38_632_323
+    out, out_ref = _fwd_bwd_both(ref, model, CIFAR, 64, seed=12, p_drop=0.1)
+    assert _rel(out, out_ref) < 1.5e-2
+    dots = na = nb = 0.0
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        ga, gb = p.grad.detach().cpu().flatten().double(), q.grad.flatten().double()
+        if not n.endswith(".k.bias"):
+            assert ((ga - gb).norm() / (gb.norm() + 1e-30)).item() < 5e-2, n
+        dots += torch.dot(ga, gb).item(); na += ga.pow(2).sum().item(); nb += gb.pow(2).sum().item()
+    assert dots / math.sqrt(na * nb) > 0.9995
+
+
+def test_unet_test_mode_guidance_matches_oracle():
+    ref, model = _pair(SMALL, seed=5)
+    ref.eval(); model.eval()
+    g = torch.Generator().manual_seed(6)
+    x, t, c = torch.randn(3, 3, 16, 16, generator=g), torch.tensor([0.0, 500.0, 999.0]), torch.tensor([1, 9, 4])
+    with torch.no_grad():
+        want = ref(x, t, c, mode="test", cond_scale=2.0)
+        want0 = ref(x, t, c, mode="test", cond_scale=0)
+    got = model(x.to(DEV), t.to(DEV), c.to(DEV), mode="test", cond_scale=2.0)
+    got0 = model(x.to(DEV), t.to(DEV), c.to(DEV), mode="test", cond_scale=0)
+    assert _rel(got, want) < 2e-2 and _rel(got0, want0) < 1.5e-2
+
+
+def _synthetic(step, stream, B, g):
+    x0 = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
+    e = torch.randn(B, 3, 32, 32, generator=g)
+    t = torch.randint(0, 1000, (B // 2 + 1,), generator=g)
+    t = torch.cat([t, 1000 - t - 1])[:B]                        # antithetic (runners/diffusion.py:1091-1094)
+    c = torch.zeros(B, dtype=torch.int64) if stream == "forget" else torch.randint(1, 10, (B,), generator=g)
+    return dict(x0=x0, e=e, t=t, c=c)
+
+
+@pytest.mark.parametrize("loss", ["adaga", "ga", "rl"])
+def test_ddpm_sfron_iterations_native_denoiser_vs_oracle(loss):
+    """DDPM/runners/diffusion.py:1075-1180 on the NATIVE denoiser (no torch-autograd module anywhere on the HIP side): cosine-decayed
+    alpha, forget loss ga / adaga / rl, mask -> clip -> Adam, remain loss -> clip -> Adam, EMAHelper; dropout off (p = 0) and
+    the classifier-free keep masks handed to both sides."""
+    from oracle import sfron_ref
+    from sfron import ddpm
+    cfg = dict(CIFAR, dropout=0.0)
+    ref, model = _pair(cfg, seed=21)
+    B, n_it = 8, 3
+    gm = torch.Generator().manual_seed(22)
+    mask = {n: (torch.rand(p.shape, generator=gm) < 0.5) for n, p in ref.named_parameters()}
+    betas = torch.from_numpy(np.linspace(1e-4, 2e-2, 1000, dtype=np.float64)).float()
+    hp = dict(lr=1e-4, forget_alpha=10.0, grad_clip=1.0, mask=mask, unlearn_loss=loss, lambd=0.5, n_iters=n_it, decay_forget_alpha=True)
+    fwd = ref.forward
+    ref.forward = lambda x, tf, c, drop: fwd(x, tf, c, mode="train", keep_mask=~drop)      # the oracle loop's model signature
+    orc = sfron_ref.DDPMSfronOracle(ref, betas, ema_mu=1e-4, label_to_forget=0, **hp)
+    run = ddpm.DDPMSFRon(model, betas=betas.to(DEV), ema_rate=1e-4, label_to_forget=0, **hp)
+    g = torch.Generator().manual_seed(23)
+    p0 = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    for it in range(n_it):
+        f, r = _synthetic(it, "forget", B, g), _synthetic(it, "remain", B, g)
+        for b in (f, r):
+            b["drop"] = (torch.rand(B, generator=g) < 0.1)              # True = label dropped (null embedding)
+        want = orc.step(it, {k: v for k, v in f.items()}, {k: v for k, v in r.items()})
+        fd = {k: v.to(DEV) for k, v in f.items()}; rd = {k: v.to(DEV) for k, v in r.items()}
+        fd["keep_mask"], rd["keep_mask"] = ~f["drop"], ~r["drop"]
+        got = run.step(it, fd, rd)
+        assert got["forget_loss"].item() == pytest.approx(want["forget_loss"], rel=3e-2, abs=1e-3)
+        assert got["remain_loss"].item() == pytest.approx(want["remain_loss"], rel=3e-2)
+    same = tot = 0
+    num = den = 0.0
+    views = run.flat.named_views(run.flat.p)
+    for n, q in ref.named_parameters():
+        du_ref = (q.detach() - p0[n]).flatten()
+        du = (views[n].cpu() - p0[n]).flatten()
+        big = du_ref.abs() > 0.05 * du_ref.abs().max()
+        same += int((torch.sign(du[big]) == torch.sign(du_ref[big])).sum()); tot += int(big.sum())
+        num += (du - du_ref).double().pow(2).sum().item(); den += du_ref.double().pow(2).sum().item()
+    print(f"DDPM {loss}: update sign agreement {same / tot:.4f}, bulk relative error {(num / den) ** 0.5:.3f}")
+    assert same / tot > 0.99 and (num / den) ** 0.5 < 0.15          # measured 0.9967..0.9977 / 0.068..0.082
+    sh = run.ema_state_dict()
+    # EMAHelper (mu = 1e-4: the shadow follows the weights): same relation to the oracle's shadow as the weights have, and the
+    # shadow is NOT the weights themselves (it lags by mu * the last update)
+    for n in ("conv_in.weight", "mid.attn_1.q.weight", "up.0.block.2.temb_cemb_proj.weight"):
+        moved = (orc.shadow[n] - p0[n]).norm().item()
+        assert (sh[n].cpu() - orc.shadow[n]).norm().item() < 0.35 * moved, n
+        assert not torch.equal(sh[n], views[n])
+
+
+def test_config1_fifty_sfron_steps_batch64_native():
+    """BASELINE config 1 on the HIP path: DDPM CIFAR-10 class-forget, 50 SFR-on steps, batch 64, cifar10_sfron.yml model and
+    hyper-parameters (adaga, lambd 0.5, alpha 10 cosine-decayed, Adam 1e-4, clip 1.0, EMA 1e-4), synthetic inputs."""
+    import time
+    from sfron import ddpm, unet
+    torch.manual_seed(1234)
+    model = unet.Conditional_Model(unet.config_namespace())
+    gm = torch.Generator().manual_seed(0)
+    mask = {n: (torch.rand(p.shape, generator=gm) < 0.5) for n, p in model.named_parameters()}
+    run = ddpm.DDPMSFRon(model, lr=1e-4, forget_alpha=10.0, grad_clip=1.0, ema_rate=1e-4, mask=mask, unlearn_loss="adaga", lambd=0.5,
+                         n_iters=50, decay_forget_alpha=True)
+    g = torch.Generator().manual_seed(1)
+    p0 = run.flat.p.clone()
+    batches = [({k: v.to(DEV) for k, v in _synthetic(i, "forget", 64, g).items()}, {k: v.to(DEV) for k, v in _synthetic(i, "remain", 64, g).items()})
+               for i in range(4)]
+    losses = []
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for it in range(50):
+        out = run.step(it, *batches[it % 4])
+        losses.append((out["forget_loss"], out["remain_loss"]))
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    fl = torch.stack([a for a, _ in losses]).cpu()
+    rl = torch.stack([b for _, b in losses]).cpu()
+    print(f"config 1: 50 SFR-on steps, batch 64: {dt / 50 * 1e3:.1f} ms/step; remain loss {rl[0].item():.1f} -> {rl[-1].item():.1f}; "
+          f"forget loss {fl[0].item():.1f} -> {fl[-1].item():.1f}")
+    assert torch.isfinite(fl).all() and torch.isfinite(rl).all()
+    assert torch.isfinite(run.flat.p).all() and not torch.equal(run.flat.p, p0)
+    assert rl[-5:].mean() < rl[:5].mean()             # the remain stage keeps fitting the remaining classes
+    assert run.opt.step_count == 100

@@ -10,6 +10,8 @@ import sfron  # noqa: E402,F401
 from sfron import _lib  # noqa: E402
 _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libsfron_dbg.so")
 if os.environ.get("SFRON_ATTN_BWD_FORM"):          # 2 = the two-kernel attention backward (process-wide test hook)
+    import torch
+    torch.zeros(1, device=f"cuda:{os.environ.get('LOCAL_RANK', '0')}")      # HIP runtime up (through torch) before the library loads
     _lib.lib().sfron_attn_bwd_form(int(os.environ["SFRON_ATTN_BWD_FORM"]))
 import bench  # noqa: E402
 bench.main()

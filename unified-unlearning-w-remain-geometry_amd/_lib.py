@@ -86,6 +86,48 @@ _PROTOS.update({
 })
 
 
+class BGemmDesc(ctypes.Structure):
+    """Mirror of sfron_bgemm_desc."""
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("M", c_int), ("N", c_int), ("K", c_int), ("lda", c_int), ("ldb", c_int),
+                ("a_transposed", c_int), ("b_transposed", c_int), ("batch", c_int),
+                ("stride_a", ctypes.c_long), ("stride_b", ctypes.c_long), ("stride_c", ctypes.c_long), ("alpha", c_float),
+                ("bias", c_void_p), ("c_bf16", c_void_p), ("c_f32", c_void_p), ("ldc", c_int), ("resid", c_void_p),
+                ("sample_vec", c_void_p), ("ld_vec", c_int), ("rows_per_sample", c_int), ("accumulate", c_int)]
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of sfron_conv_desc."""
+    _fields_ = [("batch", c_int), ("h_src", c_int), ("w_src", c_int), ("c_src", c_int), ("h_out", c_int), ("w_out", c_int),
+                ("n_out", c_int), ("taps", c_int), ("stride", c_int), ("pad", c_int), ("upsample", c_int), ("dilate", c_int),
+                ("bias", c_void_p), ("resid", c_void_p), ("sample_vec", c_void_p), ("ld_vec", c_int),
+                ("out_bf16", c_void_p), ("out_f32", c_void_p), ("ld_out", c_int), ("accumulate", c_int)]
+
+
+_PROTOS.update({
+    "sfron_bgemm_bf16": (c_int, [POINTER(BGemmDesc), _S]),
+    "sfron_conv_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _S]),
+    "sfron_conv_wgrad": (c_int, [POINTER(ConvDesc), _P, c_int, _P, _P, _S]),
+    "sfron_conv_wprep": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _S]),
+    "sfron_conv_wgrad_scatter": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),
+    "sfron_nchw_to_rows_bf16": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),
+    "sfron_nchw_to_rows_f32": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),
+    "sfron_rows_to_nchw": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),
+    "sfron_groupnorm_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, c_float, _P, _P, _P, _S]),
+    "sfron_groupnorm_bwd": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, c_int, c_int,
+                                    _P, _P, _S]),
+    "sfron_softmax_fwd": (c_int, [_P, c_int64, c_int, c_float, _P, _S]),
+    "sfron_softmax_bwd": (c_int, [_P, _P, c_int64, c_int, c_float, _P, _S]),
+    "sfron_sample_colsum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _S]),
+    "sfron_axpby": (c_int, [_P, _P, c_float, c_float, c_int64, _P, _S]),
+    "sfron_pool2_sum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _S]),
+    "sfron_cast_rows_bf16": (c_int, [_P, c_int, c_int64, c_int, _P, _S]),
+    "sfron_copy_cols": (c_int, [_P, c_int, c_int64, c_int, _P, c_int, c_int, _S]),
+    "sfron_ddpm_timestep_embed": (c_int, [_P, c_int, c_int, _P, _S]),
+    "sfron_class_embed_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _S]),
+    "sfron_class_embed_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _S]),
+})
+
+
 class DitCfg(ctypes.Structure):
     """Mirror of sfron_dit_cfg (include/sfron.h)."""
     _fields_ = [(n, c_int) for n in ("batch", "in_channels", "input_size", "patch", "hidden", "depth", "heads",

@@ -744,7 +744,9 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
     const int i = lane & 15, q4 = i >> 2, p = i & 3;
 #pragma unroll
     for (int k = 0; k < ND0; ++k)
-      rdK[k] = lds_addr(imgK) + 2 * (aoff<HDP>(4 * g + q4, 2 * (dt0 + (k < nd ? k : 0)) + (p >> 1)) + 4 * (p & 1));
+      // a wave of the second group with fewer d-tiles (head_dim 72: tiles 3, 4) multiplies a surplus tile made of the zero pad
+      // columns (or repeats its last tile) and never stores it
+      rdK[k] = lds_addr(imgK) + 2 * (aoff<HDP>(4 * g + q4, 2 * ((dt0 + k) * 16 < HDP ? dt0 + k : dt0) + (p >> 1)) + 4 * (p & 1));
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       const int r = 16 * hh + 4 * g + q4;                  // key inside the 32-key step (step base is a multiple of 32)
@@ -832,32 +834,30 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
       f32x4 dq[ND0];
 #pragma unroll
       for (int i = 0; i < ND0; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      bf16x8 fa[ND0], fa_n[ND0];
-      bf16x8 fb, fb_n;
-      auto read_step = [&](int kk, bf16x8 (&A)[ND0], bf16x8& Bf) {
-        const bf16x4 lo = asm_read_tr(rdS[0] + kk * (32 * 64 * 2)), hi = asm_read_tr(rdS[1] + kk * (32 * 64 * 2));
+      // two fragment sets, selected by the parity of the (compile-time) key step: the reads of step kk + 1 go out under
+      // the MFMAs of step kk, and no register is COPIED while an asynchronous read into it is still in flight
+      bf16x8 fa[2][ND0];
+      bf16x8 fb[2];
+      auto read_step = [&](auto kkc, bf16x8 (&A)[ND0], bf16x8& Bf) {
+        constexpr int kk = decltype(kkc)::value;
+        const bf16x4 lo = asm_read_tr_off<kk * (32 * 64 * 2)>(rdS[0]), hi = asm_read_tr_off<kk * (32 * 64 * 2)>(rdS[1]);
         Bf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const unsigned ko = kk * (32 * HDP * 2);
 #pragma unroll
-        for (int i = 0; i < ND0; ++i)
-          if (i < nd) {
-            const bf16x4 l2 = asm_read_tr(rdK[i] + ko), h2 = asm_read_tr_off<16 * HDP * 2>(rdK[i] + ko);
-            A[i] = bf16x8{l2[0], l2[1], l2[2], l2[3], h2[0], h2[1], h2[2], h2[3]};
-          }
+        for (int i = 0; i < ND0; ++i) {      // every wave reads / multiplies ND0 d-tiles: no branch around an asynchronous read
+          const bf16x4 l2 = asm_read_tr_off<kk * (32 * HDP * 2)>(rdK[i]), h2 = asm_read_tr_off<kk * (32 * HDP * 2) + 16 * HDP * 2>(rdK[i]);
+          A[i] = bf16x8{l2[0], l2[1], l2[2], l2[3], h2[0], h2[1], h2[2], h2[3]};
+        }
       };
-      read_step(0, fa, fb);
-      for (int kk = 0; kk < T / 32; ++kk) {
+      read_step(std::integral_constant<int, 0>{}, fa[0], fb[0]);
+      static_for<T / 32>([&](auto kkc) {
+        constexpr int kk = decltype(kkc)::value, cur = kk & 1;
         lds_reads_done();
-        if (kk + 1 < T / 32) read_step(kk + 1, fa_n, fb_n);
+        if constexpr (kk + 1 < T / 32) read_step(std::integral_constant<int, kk + 1>{}, fa[cur ^ 1], fb[cur ^ 1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < ND0; ++i)
-          if (i < nd) dq[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, dq[i], 0, 0, 0);
+        for (int i = 0; i < ND0; ++i) dq[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][i], fb[cur], dq[i], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < ND0; ++i) fa[i] = fa_n[i];
-        fb = fb_n;
-      }
+      });
       const int q = qc * 64 + 16 * qi + (lane & 15);
       __bf16* row = dqkv + ((size_t)b * T + q) * ld + h * hd;
 #pragma unroll

@@ -266,7 +266,7 @@ int sfron_probe_read(void* probe, int* n_samples, double* total_ms) {
 int sfron_probe_destroy(void* probe) {
   SFRON_CHECK_ARG(probe);
   Probe* p = (Probe*)probe;
-  for (int i = 0; i < 2 * p->cap; ++i) hipEventDestroy(p->ev[i]);
+  for (int i = 0; i < 2 * p->cap; ++i) (void)hipEventDestroy(p->ev[i]);
   delete[] p->ev; delete p;
   return SFRON_OK;
 }
@@ -341,9 +341,9 @@ int sfron_dit_forward_probed(const sfron_dit_cfg* cfg, const float* params, cons
     g.aux = (uint16_t*)hpre; g.ldaux = d.F;
     Probe* pr = (Probe*)probe;
     const bool probing = pr && l == 0 && pr->used < pr->cap;
-    if (probing) hipEventRecord(pr->ev[2 * pr->used], (hipStream_t)stream);
+    if (probing) (void)hipEventRecord(pr->ev[2 * pr->used], (hipStream_t)stream);
     RUN(sfron_gemm_bf16(&g, stream));
-    if (probing) { hipEventRecord(pr->ev[2 * pr->used + 1], (hipStream_t)stream); pr->used++; }
+    if (probing) { (void)hipEventRecord(pr->ev[2 * pr->used + 1], (hipStream_t)stream); pr->used++; }
     g = fwd_desc(h, wb + pb + P.o_fc2_w, M, D, d.F);
     g.epilogue = SFRON_EPI_GATE_RES; g.bias = params + pb + P.o_fc2_b; g.c_f32 = x2; g.ldc_f32 = D; g.resid = x1;
     g.aux = (uint16_t*)a2; g.ldaux = D; g.gate = mod + 5 * D; g.ldgate = NM; g.tokens = T;
@@ -396,7 +396,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     sfron_gemm_desc q = wgrad_desc(dY, X, M, N, K, dW);
     Probe* pr = nullptr;
     if (db) {
-      if (!(ablate_mask() & 32) && sfron_gemm_rowsum_supported(N, K, M)) {
+      if ((ablate_mask() & 32) && sfron_gemm_rowsum_supported(N, K, M)) {
         q.a_rowsum = db;
         q.rowsum_ws = ax ? w.csum2 : w.csum;            // [K / 192][N] partial rows (<= CSUM_PARTS rows of the widest output)
         if (ax && ax->probe && probe_block && ax->probe->used < ax->probe->cap) pr = ax->probe;

@@ -159,6 +159,14 @@ class FlatParams:
             if p.requires_grad:
                 self.names.append(n)
                 self.params.append(p)
+        self.w_bf16 = None
+        if hasattr(model, "flat_arena"):
+            # sfron.unet.Conditional_Model: the parameters already live in one arena (with a gradient arena and a bf16 weight
+            # shadow at the same offsets) -- adopt it
+            self.p, self.g, self.w_bf16, index = model.flat_arena()
+            self.offsets = [index[n][0] for n in self.names]
+            self.n = self.p.numel()
+            return
         dev = self.params[0].device
         self.offsets, off = [], 0
         for p in self.params:
@@ -175,7 +183,7 @@ class FlatParams:
 
     def mask_arena(self, mask):
         """name -> bool tensor / python int (DDPM/generate_fisher_mask.py:39-46; keys with or without 'module.')."""
-        arena = torch.zeros(self.n, dtype=torch.uint8, device=self.p.device)
+        arena = torch.zeros(self.n, dtype=torch.uint8, device=self.p.device)     # arena padding stays masked out
         for n, p, o in zip(self.names, self.params, self.offsets):
             m = mask.get(n, mask.get("module." + n))
             if m is None:
@@ -198,10 +206,12 @@ class DDPMSFRon:
     c, t, e."""
 
     def __init__(self, model, betas=None, lr=1e-4, forget_alpha=10.0, remain_alpha=1.0, grad_clip=1.0, ema_rate=None, mask=None,
-                 unlearn_loss="adaga", lambd=0.5, n_iters=50, decay_forget_alpha=True, cond_drop_prob=0.1, process_group=None):
+                 unlearn_loss="adaga", lambd=0.5, n_iters=50, decay_forget_alpha=True, cond_drop_prob=0.1, process_group=None,
+                 label_to_forget=0, n_classes=10):
         from . import dp, sweep
-        if unlearn_loss not in ("ga", "adaga"):
-            raise NotImplementedError("unlearn_loss 'rl' of the DDPM runner is not on the native path yet")
+        if unlearn_loss not in ("ga", "adaga", "rl"):
+            raise ValueError(f"unsupported unlearn_loss {unlearn_loss!r} (DDPM/runners/diffusion.py:1095-1120 defines ga, rl, adaga)")
+        self.label_to_forget, self.n_classes = label_to_forget, n_classes
         self.model, self.flat = model, FlatParams(model)
         dev = self.flat.p.device
         self.b = betas if betas is not None else get_beta_schedule(device=dev)
@@ -211,13 +221,28 @@ class DDPMSFRon:
         self.world = dp.world_size(process_group)
         marena = self.flat.mask_arena(mask) if mask is not None else None
         # DDPM/functions/__init__.py:9-18 with cifar10_sfron.yml:48-56: Adam, wd 0, betas (0.9, 0.999), eps 1e-8
-        self.opt = sweep.FlatAdam(self.flat.p, self.flat.g, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adamw=True, mask=marena)
+        self.opt = sweep.FlatAdam(self.flat.p, self.flat.g, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adamw=True, mask=marena,
+                                  w_bf16=self.flat.w_bf16)
         self.mu = ema_rate
         self.shadow = self.flat.p.clone() if ema_rate is not None else None       # EMAHelper.register (models/ema.py:11-15)
 
     def _loss(self, batch, kind):
         fn = loss_registry_conditional["simple"]
-        wrapped = lambda x, tf, c, cond_drop_prob=0.1, mode="train": self.model(x, tf, c, cond_drop_prob=self.cond_drop_prob, mode=mode)
+        extra = {}
+        if batch.get("keep_mask") is not None:      # explicit classifier-free keep mask (tests; the reference draws it inside the model)
+            extra["keep_mask"] = batch["keep_mask"]
+        wrapped = lambda x, tf, c, cond_drop_prob=0.1, mode="train": self.model(x, tf, c, cond_drop_prob=self.cond_drop_prob, mode=mode, **extra)
+        if kind == "rl":
+            # runners/diffusion.py:1101-1113: criteria(pseudo, output) = mean over ALL elements of (pseudo - output)^2, the pseudo
+            # branch detached; both branches see the same x_t.  The per-sample sums and their gradient are the HIP loss kernels.
+            x = q_sample(batch["x0"], batch["e"], batch["t"], alphas_cumprod(self.b))
+            tf = batch["t"].float()
+            output = wrapped(x, tf, batch["c"])
+            pseudo_c = torch.full_like(batch["c"], (self.label_to_forget + 1) % self.n_classes)
+            with torch.no_grad():
+                pseudo = wrapped(x, tf, pseudo_c)
+            per = _SampleLoss.apply(output, pseudo)
+            return _Reduce.apply(per, 0, 0.0, self.pg if self.world > 1 else None) / float(output[0].numel())
         args = (wrapped, batch["x0"], batch["t"], batch["c"], batch["e"], self.b)
         pg = self.pg if self.world > 1 else None
         if kind == "adaga":
@@ -233,7 +258,10 @@ class DDPMSFRon:
     def step(self, step_idx, forget, remain):
         alpha = cosine_lr_scheduler(self.forget_alpha, step_idx, self.n_iters) if self.decay else self.forget_alpha
         self.model.train()
-        ori_forget = -self._loss(forget, "adaga" if self.unlearn_loss == "adaga" else "simple")
+        if self.unlearn_loss == "rl":
+            ori_forget = self._loss(forget, "rl")
+        else:
+            ori_forget = -self._loss(forget, "adaga" if self.unlearn_loss == "adaga" else "simple")
         self._backward(alpha * ori_forget)
         self.opt.step(max_norm=self.grad_clip, use_mask=True)
         ori_remain = self._loss(remain, "simple")
