@@ -16,6 +16,9 @@ Outputs (small .npz files, inputs + expected outputs only -- no reference source
   fisher_mask.npz     DiT/generate_mask.py main() run on synthetic Fisher files (0/0, int-0 entries)
   ddpm_model.npz      DDPM/models/diffusion.py Conditional_Model forward/backward (tiny config) + a 2-iteration SFR-on
                       trajectory composed from DDPM/functions/losses.py, models/ema.py in runners/diffusion.py order
+  sd_unet.npz         SD/ldm/modules/diffusionmodules/openaimodel.py UNetModel (+ attention.py, util.py): parameter spec of the
+                      v1-inference.yaml UNet (meta device), forward/backward on a tiny config, the "linear" LDM schedule, and a
+                      2-iteration trajectory of the nsfw_removal.py loop body composed from the reference UNet
 """
 import argparse
 import importlib
@@ -441,6 +444,121 @@ def gen_ddpm_sampler():
     np.savez_compressed(os.path.join(HERE, "ddpm_sampler.npz"), **out)
 
 
+# ---------------------------------------------------------------------------------------------------------------- SD / LDM
+SD_TINY = dict(image_size=8, in_channels=4, out_channels=4, model_channels=32, attention_resolutions=[2, 1], num_res_blocks=1,
+               channel_mult=[1, 2], num_heads=2, use_spatial_transformer=True, transformer_depth=1, context_dim=24,
+               use_checkpoint=False, legacy=False)
+SD_V1 = dict(image_size=32, in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1], num_res_blocks=2,
+             channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True, transformer_depth=1, context_dim=768,
+             use_checkpoint=True, legacy=False)
+
+
+def import_ref_sd():
+    """SD/ldm/modules import with a harness stand-in for the NAME omegaconf.listconfig.ListConfig (a type check at
+    openaimodel.py:497-500; omegaconf itself is absent here).  The stand-in is harness code, not reference code."""
+    oc, lc = types.ModuleType("omegaconf"), types.ModuleType("omegaconf.listconfig")
+
+    class ListConfig(list):
+        pass
+    lc.ListConfig = ListConfig
+    oc.listconfig = lc
+    sys.modules.update({"omegaconf": oc, "omegaconf.listconfig": lc})
+    sys.path.insert(0, os.path.join(REF, "SD"))
+    om = importlib.import_module("ldm.modules.diffusionmodules.openaimodel")
+    ut = importlib.import_module("ldm.modules.diffusionmodules.util")
+    return om, ut
+
+
+def sd_tiny_weights(seed=4321):
+    from oracle import sd_ref
+    torch.manual_seed(seed)
+    m = sd_ref.UNetModel(**{k: v for k, v in SD_TINY.items() if k not in ("image_size", "use_spatial_transformer", "use_checkpoint", "legacy")})
+    sd_ref.randomize_zero_init(m, std=0.05, seed=seed + 1)
+    return m.state_dict()
+
+
+def gen_sd():
+    from oracle import sd_ref
+    om, ut = import_ref_sd()
+    out = {}
+    # (1) key / shape list of the v1-inference.yaml UNet, on the meta device (859,520,964 parameters, 686 tensors)
+    with torch.device("meta"):
+        full = om.UNetModel(**SD_V1)
+    spec = "\n".join(f"{n} {tuple(p.shape)}" for n, p in full.named_parameters())
+    out["v1_param_spec"] = np.frombuffer(spec.encode(), dtype=np.uint8)
+    out["v1_param_count"] = np.array(sum(p.numel() for p in full.parameters()), dtype=np.int64)
+    # (2) tiny config: forward + backward of the reference class on weights generated through the oracle class (same keys)
+    ref = om.UNetModel(**SD_TINY)
+    sd = sd_tiny_weights()
+    assert list(ref.state_dict().keys()) == list(sd.keys())
+    ref.load_state_dict(sd)
+    ref.train()
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(3, 4, 8, 8, generator=g)
+    t = torch.tensor([0, 500, 999])
+    ctx = torch.randn(3, 5, 24, generator=g)
+    w = torch.randn(3, 4, 8, 8, generator=g) * 0.1
+    o = ref(x, timesteps=t, context=ctx)
+    (o * w).sum().backward()
+    out.update(x=x.numpy(), t=t.numpy(), ctx=ctx.numpy(), w=w.numpy(), out=o.detach().numpy())
+    names = [n for n, _ in ref.named_parameters()]
+    out["grad_norms"] = np.array([p.grad.norm().item() for _, p in ref.named_parameters()], dtype=np.float64)
+    for n in ("time_embed.0.weight", "input_blocks.0.0.weight", "input_blocks.1.1.transformer_blocks.0.attn2.to_k.weight",
+              "input_blocks.2.0.op.weight", "middle_block.1.transformer_blocks.0.ff.net.0.proj.weight", "output_blocks.1.2.conv.weight",
+              "output_blocks.3.0.skip_connection.weight", "out.2.weight", "out.0.bias"):
+        assert n in names, n
+        out["grad/" + n] = dict(ref.named_parameters())[n].grad.numpy().copy()
+    out["temb"] = ut.timestep_embedding(t, 32).numpy()
+    # (3) schedule: make_beta_schedule("linear", 1000, 0.00085, 0.012) and the fp32 tables register_schedule derives from it
+    betas = ut.make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
+    ac = np.cumprod(1.0 - betas, axis=0)
+    out.update(betas=betas, sqrt_ac=torch.tensor(np.sqrt(ac), dtype=torch.float32).numpy(),
+               sqrt_1m_ac=torch.tensor(np.sqrt(1.0 - ac), dtype=torch.float32).numpy())
+    xs = torch.randn(3, 4, 8, 8, generator=g)
+    nz = torch.randn(3, 4, 8, 8, generator=g)
+    sa, sb = torch.tensor(np.sqrt(ac), dtype=torch.float32), torch.tensor(np.sqrt(1.0 - ac), dtype=torch.float32)
+    out.update(q_x0=xs.numpy(), q_noise=nz.numpy(),
+               q_xt=(ut.extract_into_tensor(sa, t, xs.shape) * xs + ut.extract_into_tensor(sb, t, xs.shape) * nz).numpy())
+    # (4) two iterations of the loop body of train-scripts/nsfw_removal.py:108-173 composed from the reference UNet and the
+    #     schedule above in that order (the script itself needs pytorch_lightning / diffusers): train_method "xattn", Adam lr 1e-3
+    ref2 = om.UNetModel(**SD_TINY)
+    ref2.load_state_dict(sd)
+    ref2.train()
+    params = [p for n, p in ref2.named_parameters() if "attn2" in n]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    g2 = torch.Generator().manual_seed(23)
+    c_f, c_p = torch.randn(1, 5, 24, generator=g2).expand(2, -1, -1), torch.randn(1, 5, 24, generator=g2).expand(2, -1, -1)
+    traj = []
+    batches = []
+    for it in range(2):
+        xf = torch.randn(2, 4, 8, 8, generator=g2); xr = torch.randn(2, 4, 8, 8, generator=g2)
+        tt = torch.randint(0, 1000, (2,), generator=g2); nf = torch.randn(2, 4, 8, 8, generator=g2)
+        tr = torch.randint(0, 1000, (2,), generator=g2); nr = torch.randn(2, 4, 8, 8, generator=g2)
+        batches.append((xf, xr, tt, nf, tr, nr))
+        q = lambda x0, t_, n_: ut.extract_into_tensor(sa, t_, x0.shape) * x0 + ut.extract_into_tensor(sb, t_, x0.shape) * n_
+        opt.zero_grad()
+        f_out = ref2(q(xf, tt, nf), timesteps=tt, context=c_f)
+        p_out = ref2(q(xf, tt, nf), timesteps=tt, context=c_p).detach()        # pseudo branch: same images, other prompt
+        lf = torch.nn.MSELoss()(f_out, p_out)
+        (1.0 * lf).backward()
+        opt.step()
+        opt.zero_grad()
+        r_out = ref2(q(xr, tr, nr), timesteps=tr, context=c_p)
+        lr_ = torch.nn.functional.mse_loss(nr, r_out, reduction="none").mean([1, 2, 3]).mean()
+        (1.0 * lr_).backward()
+        opt.step()
+        traj.append((lf.item(), lr_.item()))
+    out["traj_losses"] = np.array(traj, dtype=np.float64)
+    out["traj_c_f"], out["traj_c_p"] = c_f[:1].numpy().copy(), c_p[:1].numpy().copy()
+    for k, vals in zip(("xf", "xr", "t_f", "noise_f", "t_r", "noise_r"), zip(*batches)):
+        out["traj_" + k] = np.stack([v.numpy() for v in vals])
+    k = "input_blocks.1.1.transformer_blocks.0.attn2.to_v.weight"
+    out["traj_final/" + k] = dict(ref2.named_parameters())[k].detach().numpy().copy()
+    out["traj_untouched/time_embed.0.weight"] = dict(ref2.named_parameters())["time_embed.0.weight"].detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "sd_unet.npz"), **out)
+    print("sd_unet.npz:", {k: getattr(v, "shape", None) for k, v in list(out.items())[:6]}, "v1 params", int(out["v1_param_count"]))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     ref_diffusion = import_ref_dit_diffusion()
@@ -453,4 +571,5 @@ if __name__ == "__main__":
     gen_ddpm_model()
     gen_sampling(ref_models, ref_diffusion)
     gen_ddpm_sampler()
+    gen_sd()
     print("golden vectors written to", HERE)

@@ -264,3 +264,84 @@ def test_ddpm_sampler_restatement_matches_reference(golden_dir):
         np.testing.assert_allclose(xs[-1].numpy(), g[f"last_eta{eta}"], rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(xs[5].numpy(), g[f"x_mid_eta{eta}"], rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(x0s[0].numpy(), g[f"x0_first_eta{eta}"], rtol=1e-6, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------- SD / LDM
+def _sd_fixture(golden_dir):
+    return np.load(os.path.join(golden_dir, "sd_unet.npz"))
+
+
+SD_TINY = dict(in_channels=4, out_channels=4, model_channels=32, attention_resolutions=[2, 1], num_res_blocks=1, channel_mult=[1, 2],
+               num_heads=2, transformer_depth=1, context_dim=24)
+
+
+def _sd_tiny_model(seed=4321):
+    from oracle import sd_ref
+    torch.manual_seed(seed)
+    m = sd_ref.UNetModel(**SD_TINY)
+    sd_ref.randomize_zero_init(m, std=0.05, seed=seed + 1)
+    return m
+
+
+def test_sd_unet_parameter_spec_matches_reference_v1(golden_dir):
+    """Names, shapes and order of the v1-inference.yaml UNet (859,520,964 parameters in 686 tensors): the oracle class built on
+    the meta device against the list the imported reference class produced (SD/ldm/modules/diffusionmodules/openaimodel.py:428-846)."""
+    from oracle import sd_ref
+    g = _sd_fixture(golden_dir)
+    with torch.device("meta"):
+        m = sd_ref.UNetModel()
+    spec = "\n".join(f"{n} {tuple(p.shape)}" for n, p in m.named_parameters())
+    want = bytes(g["v1_param_spec"]).decode()
+    assert spec == want
+    assert sum(p.numel() for p in m.parameters()) == int(g["v1_param_count"]) == 859_520_964
+    assert len(list(m.named_parameters())) == 686
+    assert sum(p.numel() for n, p in m.named_parameters() if "attn2" in n) == 43_962_560        # train_method "xattn"
+
+
+def test_sd_unet_forward_backward_matches_reference(golden_dir):
+    from oracle import sd_ref
+    g = _sd_fixture(golden_dir)
+    m = _sd_tiny_model()
+    m.train()
+    x, t, ctx, w = (torch.from_numpy(g[k]) for k in ("x", "t", "ctx", "w"))
+    np.testing.assert_allclose(sd_ref.timestep_embedding(t, 32).numpy(), g["temb"], rtol=1e-6, atol=1e-6)
+    out = m(x, timesteps=t, context=ctx)
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], rtol=1e-4, atol=1e-5)
+    (out * w).sum().backward()
+    norms = np.array([p.grad.norm().item() for _, p in m.named_parameters()])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-4, atol=1e-7)
+    params = dict(m.named_parameters())
+    for k in g.files:
+        if k.startswith("grad/"):
+            np.testing.assert_allclose(params[k[5:]].grad.numpy(), g[k], rtol=1e-3, atol=2e-6, err_msg=k)
+
+
+def test_sd_schedule_and_q_sample_match_reference(golden_dir):
+    from oracle import sd_ref
+    g = _sd_fixture(golden_dir)
+    s = sd_ref.LDMSchedule()
+    np.testing.assert_array_equal(s.betas.numpy(), g["betas"].astype(np.float32))
+    np.testing.assert_array_equal(s.sqrt_alphas_cumprod.numpy(), g["sqrt_ac"])
+    np.testing.assert_array_equal(s.sqrt_one_minus_alphas_cumprod.numpy(), g["sqrt_1m_ac"])
+    xt = s.q_sample(torch.from_numpy(g["q_x0"]), torch.from_numpy(g["t"]), torch.from_numpy(g["q_noise"]))
+    np.testing.assert_array_equal(xt.numpy(), g["q_xt"])
+
+
+def test_sd_nsfw_removal_trajectory_matches_reference(golden_dir):
+    """Two iterations of train-scripts/nsfw_removal.py:108-173 (train_method "xattn"): losses per iteration and the trained /
+    untouched weights against the trajectory composed from the imported reference UNet."""
+    from oracle import sd_ref
+    g = _sd_fixture(golden_dir)
+    m = _sd_tiny_model()
+    orc = sd_ref.SDSfronOracle(m, sd_ref.LDMSchedule(), lr=1e-3, forget_alpha=1.0, remain_alpha=1.0, train_method="xattn")
+    c_f, c_p = torch.from_numpy(g["traj_c_f"]).expand(2, -1, -1), torch.from_numpy(g["traj_c_p"]).expand(2, -1, -1)
+    for it in range(2):
+        xf = torch.from_numpy(g["traj_xf"][it])
+        forget = dict(x_f=xf, x_p=xf, c_f=c_f, c_p=c_p, t=torch.from_numpy(g["traj_t_f"][it]), noise=torch.from_numpy(g["traj_noise_f"][it]))
+        remain = dict(x=torch.from_numpy(g["traj_xr"][it]), c=c_p, t=torch.from_numpy(g["traj_t_r"][it]), noise=torch.from_numpy(g["traj_noise_r"][it]))
+        got = orc.step(forget, remain)
+        np.testing.assert_allclose([got["forget_loss"], got["remain_loss"]], g["traj_losses"][it], rtol=2e-4)
+    params = dict(m.named_parameters())
+    k = "input_blocks.1.1.transformer_blocks.0.attn2.to_v.weight"
+    np.testing.assert_allclose(params[k].detach().numpy(), g["traj_final/" + k], rtol=1e-3, atol=2e-5)
+    np.testing.assert_array_equal(params["time_embed.0.weight"].detach().numpy(), g["traj_untouched/time_embed.0.weight"])
