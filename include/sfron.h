@@ -58,6 +58,10 @@ int sfron_ema_update(float* ema, const float* p, int64_t n, double decay, int em
 /* F += g^2 / n_iters (DiT/generate_fisher.py:236-239, on device instead of .cpu()) */
 int sfron_fisher_accum(float* fisher, const float* g, int64_t n, float n_iters, void* stream);
 
+/* F += ((g [+ g2]) * stats[1])^2 / n_iters: the DDPM variant squares the gradient AFTER clip_grad_norm_
+ * (DDPM/runners/diffusion.py:1271-1281); stats from sfron_clip_coef (NULL = no clipping), g2 NULL or a second arena added first */
+int sfron_fisher_accum_clipped(float* fisher, const float* g, const float* g2, const float* stats, int64_t n, float n_iters, void* stream);
+
 /* mask = ((F_f + 1e-15) / (F_r + 1e-15)) >= th, IEEE fp32, bit-exact with torch
  * (DiT/generate_mask.py:34-35, DDPM/generate_fisher_mask.py:39-46) */
 int sfron_mask_from_fisher(const float* forget_fisher, const float* remain_fisher, int64_t n, float th,

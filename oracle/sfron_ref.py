@@ -185,6 +185,27 @@ class DDPMSfronOracle:
         return {"forget_loss": ori_forget.item(), "remain_loss": ori_remain.item(), "alpha": alpha}
 
 
+def ddpm_fisher(model, batches, b, cond_scale=2.0, grad_clip=1.0):
+    """DDPM/runners/diffusion.py:1244-1299 (one of the two identical loops): eval mode, guided mode="test" forward WITH
+    gradients through both branches, Sigma_chw (e - output)^2 averaged over the batch, clip_grad_norm_ BEFORE squaring,
+    F[name] += grad^2 / len(loader).  ``model(x, t_float, c, mode="test", cond_scale=...)`` is oracle.ddpm_ref.ConditionalUNet."""
+    model.eval()
+    F = {n: torch.zeros_like(p) for n, p in model.named_parameters()}
+    for bt in batches:
+        a = ddpm_alphas_cumprod_fp32(b).index_select(0, bt["t"]).view(-1, 1, 1, 1)
+        x = bt["x0"] * a.sqrt() + bt["e"] * (1.0 - a).sqrt()
+        output = model(x, bt["t"].float(), bt["c"], cond_scale=cond_scale, mode="test")
+        loss = (bt["e"] - output).square().sum(dim=(1, 2, 3)).mean(dim=0)
+        model.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if p.grad is not None:
+                    F[n] += p.grad.data ** 2 / len(batches)
+    return F
+
+
 # ----------------------------------------------------------------------------- DDPM sampler (snapshots)
 def ddpm_compute_alpha(beta, t):
     # DDPM/functions/denoising.py:4-7

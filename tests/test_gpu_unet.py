@@ -367,6 +367,41 @@ def test_ddpm_sfron_iterations_native_denoiser_vs_oracle(loss):
         assert not torch.equal(sh[n], views[n])
 
 
+def test_ddpm_fisher_clip_before_square_guided_forward_vs_oracle():
+    """DDPM/runners/diffusion.py:1244-1299: Fisher diagonal from the cond_scale-guided mode="test" forward (gradients through the
+    conditional AND the null branch), gradients clipped to norm 1 before they are squared; then the saliency mask
+    (DDPM/generate_fisher_mask.py:39-46) from a forget / remain pair of such Fisher estimates."""
+    from oracle import sfron_ref, sweep_ref
+    from sfron import fisher
+    ref, model = _pair(dict(SMALL, dropout=0.0), seed=31)
+    betas = torch.from_numpy(np.linspace(1e-4, 2e-2, 1000, dtype=np.float64)).float()
+    g = torch.Generator().manual_seed(32)
+
+    def batch(stream):
+        bt = _synthetic(0, stream, 6, g)
+        return {k: (v[:, :, :16, :16].contiguous() if v.dim() == 4 else v) for k, v in bt.items()}
+    sets = {s: [batch(s) for _ in range(2)] for s in ("forget", "remain")}
+    F_ref = {s: sfron_ref.ddpm_fisher(ref, sets[s], betas, cond_scale=2.0, grad_clip=1.0) for s in sets}
+    F_hip = {}
+    for s in sets:
+        acc = fisher.DDPMFisherAccumulator(model, betas.to(DEV), n_batches=2, cond_scale=2.0, grad_clip=1.0)
+        for bt in sets[s]:
+            acc.accumulate({k: v.to(DEV) for k, v in bt.items()})
+        F_hip[s] = acc.state_dict(prefix="")
+    num = den = 0.0
+    for n, fr in F_ref["forget"].items():
+        fh = F_hip["forget"][n]
+        num += (fh - fr).double().pow(2).sum().item(); den += fr.double().pow(2).sum().item()
+        if not n.endswith(".k.bias"):
+            assert ((fh - fr).norm() / (fr.norm() + 1e-30)).item() < 0.12, n          # g^2 doubles the bf16 gradient error
+    assert (num / den) ** 0.5 < 0.05
+    masks = fisher.masks_from_fisher(F_hip["forget"], F_hip["remain"], 1.0)
+    m_ref = sweep_ref.mask_from_fisher(F_ref["forget"]["mid.block_1.conv1.weight"], F_ref["remain"]["mid.block_1.conv1.weight"], 1.0)
+    agree = (masks["mid.block_1.conv1.weight"] == m_ref).float().mean().item()
+    print(f"DDPM Fisher: bulk relative error {(num / den) ** 0.5:.3f}; saliency mask agreement on mid.block_1.conv1.weight {agree:.4f}")
+    assert agree > 0.9
+
+
 def test_config1_fifty_sfron_steps_batch64_native():
     """BASELINE config 1 on the HIP path: DDPM CIFAR-10 class-forget, 50 SFR-on steps, batch 64, cifar10_sfron.yml model and
     hyper-parameters (adaga, lambd 0.5, alpha 10 cosine-decayed, Adam 1e-4, clip 1.0, EMA 1e-4), synthetic inputs."""

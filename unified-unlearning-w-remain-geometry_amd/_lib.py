@@ -28,6 +28,7 @@ _PROTOS = {
                                        c_double, _P, _P, c_double, c_int, _S]),
     "sfron_ema_update": (c_int, [_P, _P, c_int64, c_double, c_int, _S]),
     "sfron_fisher_accum": (c_int, [_P, _P, c_int64, c_float, _S]),
+    "sfron_fisher_accum_clipped": (c_int, [_P, _P, _P, _P, c_int64, c_float, _S]),
     "sfron_mask_from_fisher": (c_int, [_P, _P, c_int64, c_float, _P, _S]),
     "sfron_cast_bf16": (c_int, [_P, _P, c_int64, _S]),
     "sfron_q_sample": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _S]),

@@ -153,6 +153,21 @@ __global__ __launch_bounds__(TPB) void k_fisher_accum(float* __restrict__ F, con
   }
 }
 
+// the DDPM variant squares the CLIPPED gradient (DDPM/runners/diffusion.py:1271-1281: clip_grad_norm_ runs before grad**2):
+// g * stats[1] with stats from sfron_clip_coef; g2 (optional) is a second gradient arena added first (the two guidance
+// branches of the mode="test" forward, back-propagated one after the other)
+__global__ __launch_bounds__(TPB) void k_fisher_accum_clipped(float* __restrict__ F, const float* __restrict__ g,
+                                                              const float* __restrict__ g2, const float* __restrict__ stats, int64_t n,
+                                                              float n_iters) {
+  const float c = stats ? stats[1] : 1.0f;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    float x = g[i];
+    if (g2) x += g2[i];
+    x *= c;                                       // clip_grad_norm_: grad.mul_(clip_coef), then squared
+    F[i] = F[i] + (x * x) / n_iters;
+  }
+}
+
 __global__ __launch_bounds__(TPB) void k_mask_from_fisher(const float* __restrict__ ff, const float* __restrict__ rf,
                                                           int64_t n, float th, uint8_t* __restrict__ mask) {
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
@@ -234,6 +249,13 @@ int sfron_ema_update(float* ema, const float* p, int64_t n, double decay, int em
 int sfron_fisher_accum(float* fisher, const float* g, int64_t n, float n_iters, void* stream) {
   SFRON_CHECK_ARG(fisher && g && n >= 0 && n_iters > 0);
   hipLaunchKernelGGL(k_fisher_accum, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, fisher, g, n, n_iters);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_fisher_accum_clipped(float* fisher, const float* g, const float* g2, const float* stats, int64_t n, float n_iters, void* stream) {
+  SFRON_CHECK_ARG(fisher && g && n >= 0 && n_iters > 0);
+  hipLaunchKernelGGL(k_fisher_accum_clipped, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, fisher, g, g2, stats, n, n_iters);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

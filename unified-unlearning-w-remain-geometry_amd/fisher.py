@@ -8,9 +8,13 @@ The reference squares gradients on the CPU per tensor per step; here the accumul
 flat gradient arena.  Data parallel: per-rank batches are distinct Fisher samples, so ranks accumulate
 g**2 locally and the caller all-reduce-SUMs F at the end (averaging gradients first would NOT be equivalent).
 """
-import torch
+import ctypes
 
-from . import sweep
+import torch
+import torch.distributed as dist
+
+from . import _lib, sweep
+from ._lib import check, ptr, stream_ptr
 
 
 class FisherAccumulator:
@@ -30,6 +34,14 @@ class FisherAccumulator:
         _, _, d_out = diff.loss_fwd_bwd(out, batch["x0"], batch["t"], batch["noise"], 1.0 / n)
         eng.backward(d_out, batch["y"], batch.get("drop"))
         sweep.fisher_accum(self.fisher, eng.grads[:eng.n_trainable], self.n_iters)
+
+    def all_reduce(self, group=None):
+        """Data parallel: every rank has accumulated g^2 / n_iters of ITS batches with n_iters = the GLOBAL number of batches, so the
+        SUM over ranks is the reference's estimator over all batches (all-reducing gradients before
+        squaring would not be -- per-rank batches are distinct Fisher samples).  Call once, after the last accumulate()."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.fisher, op=dist.ReduceOp.SUM, group=group)
+        return self
 
     def state_dict(self, prefix="module."):
         """name -> fp32 CPU tensor, python int 0 for never-grad params (generate_fisher.py:218-239 format)."""
@@ -53,3 +65,69 @@ def masks_from_fisher(forget_fisher, remain_fisher, th, device="cuda"):
             continue
         out[name] = sweep.mask_from_fisher(ff.to(device), rf.to(device), th).cpu()
     return out
+
+
+class DDPMFisherAccumulator:
+    """Fisher diagonal of the DDPM runner (DDPM/runners/diffusion.py:1210-1364) on the native U-Net (sfron.unet.Conditional_Model):
+    per batch, x_t = q_sample(x0, t, e); output = model(x_t, t, c, cond_scale=s, mode="test") = (1 + s) f(cond) - s f(null) WITH
+    gradients through both branches (:1260-1262); loss = sum_chw (e - output)^2 averaged over the batch (:1265);
+    clip_grad_norm_(grad_clip) (:1271-1276) and only then F += grad^2 / len(loader) (:1278-1282).  The model is in eval mode
+    (:1227: no dropout).  Two backward passes (one per branch, with d_out scaled by (1 + s) and -s) fill two gradient arenas;
+    the clip norm and the squared, clipped sum are sweep kernels over both.  n_batches = len(loader) over ALL ranks; finish a
+    data-parallel run with all_reduce()."""
+
+    def __init__(self, model, betas, n_batches, cond_scale=2.0, grad_clip=1.0):
+        from . import ddpm
+        self._ddpm = ddpm
+        self.model, self.b, self.n, self.s, self.clip = model, betas, n_batches, float(cond_scale), grad_clip
+        p, g, _, _ = model.flat_arena()
+        self.fisher = torch.zeros_like(p)
+        self.g_first = torch.zeros_like(p)
+        self._partials = torch.empty(_lib.lib().sfron_sweep_partials_len(), dtype=torch.float64, device=p.device)
+        self._stats = torch.zeros(4, dtype=torch.float32, device=p.device)
+
+    def accumulate(self, batch):
+        """batch: x0 (data_transform-ed), c, t (int64), e."""
+        L, m, ddpm = _lib.lib(), self.model, self._ddpm
+        was_training = m.training
+        m.eval()
+        dev = m.device_
+        x0, e, t, c = batch["x0"], batch["e"].contiguous(), batch["t"], batch["c"]
+        B = x0.shape[0]
+        x_t = ddpm.q_sample(x0, e, t, ddpm.alphas_cumprod(self.b))
+        tf = t.float()
+        out_c, bwd_c = m._run(x_t, tf, c, torch.ones(B, dtype=torch.uint8, device=dev), None, need_grad=True)
+        out_n, bwd_n = m._run(x_t, tf, c, torch.zeros(B, dtype=torch.uint8, device=dev), None, need_grad=True)
+        out = torch.empty_like(out_c)
+        check(L.sfron_axpby(ptr(out_c), ptr(out_n), 1.0 + self.s, -self.s, out.numel(), ptr(out), stream_ptr()), "axpby")
+        # d loss / d output_i = 2 (output_i - e_i) / B ; the branches receive it scaled by (1 + s) and -s
+        chw = out[0].numel()
+        per = torch.empty(B, dtype=torch.float32, device=dev)
+        check(L.sfron_ddpm_sample_loss(ptr(e), ptr(out), B, chw, ptr(per), stream_ptr()), "ddpm_sample_loss")
+        d_out = torch.empty_like(out)
+        for scale, bwd, keep in (((1.0 + self.s), bwd_c, True), (-self.s, bwd_n, False)):
+            coef = torch.full((B,), 2.0 * scale / B, dtype=torch.float32, device=dev)
+            check(L.sfron_ddpm_loss_bwd(ptr(e), ptr(out), ptr(coef), B, chw, ptr(d_out), stream_ptr()), "ddpm_loss_bwd")
+            bwd(d_out)
+            if keep:
+                self.g_first.copy_(m.grads)
+        n = m.grads.numel()
+        stats = None
+        if self.clip is not None:
+            nblk = ctypes.c_int(0)
+            check(L.sfron_sumsq_masked(ptr(m.grads), ptr(self.g_first), None, n, ptr(self._partials), ctypes.byref(nblk), stream_ptr()), "sumsq")
+            check(L.sfron_clip_coef(ptr(self._partials), nblk.value, float(self.clip), ptr(self._stats), stream_ptr()), "clip_coef")
+            stats = self._stats
+        check(L.sfron_fisher_accum_clipped(ptr(self.fisher), ptr(m.grads), ptr(self.g_first), ptr(stats), n, float(self.n), stream_ptr()),
+              "fisher_accum_clipped")
+        m.train(was_training)
+        return per.mean()
+
+    def all_reduce(self, group=None):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.fisher, op=dist.ReduceOp.SUM, group=group)
+        return self
+
+    def state_dict(self, prefix="module."):
+        """name -> fp32 CPU tensor (the runner saves the DataParallel-prefixed names, :1284)."""
+        return {prefix + n: self.model.view(self.fisher, n).detach().cpu().clone() for n in self.model.index}
