@@ -317,6 +317,10 @@ int sfron_cond_fwd(const float* t_emb, const float* table, const int64_t* y, con
 /* d_c = d_silu_c * silu'(c); d_table[label] += d_c  (d_table must be zeroed by the caller) */
 int sfron_cond_bwd(const float* d_silu_c, const float* c, const int64_t* y, const uint8_t* drop, int num_classes, int n,
                    int D, float* d_c, float* d_table, void* stream);
+/* latent front-end: out [n][c][hw] = (mean + exp(0.5 * clamp(logvar, -30, 20)) * eps) * scale from cached VAE posterior moments
+ * [n][2c][hw] = mean || logvar -- vae.encode(x).latent_dist.sample().mul_(0.18215) of DiT/forget.py:265-267,305-307 with the
+ * encoder's output cached offline (diffusers' DiagonalGaussianDistribution.sample; diffusers is absent here: parity unpinned) */
+int sfron_latent_sample(const float* moments, const float* eps, int n, int c, int hw, float scale, float* out, void* stream);
 /* NCHW fp32 image -> bf16 token rows [n*T][C*p*p]; chan_last 0: k = c*p*p + ph*p + pw (Conv2d weight order,
  * timm PatchEmbed); 1: k = (ph*p + pw)*C + c (unpatchify order, DiT/models.py:218-231) */
 int sfron_patchify(const float* img, int n, int C, int H, int W, int p, int chan_last, uint16_t* rows, int ld, void* stream);

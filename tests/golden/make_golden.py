@@ -16,6 +16,8 @@ Outputs (small .npz files, inputs + expected outputs only -- no reference source
   fisher_mask.npz     DiT/generate_mask.py main() run on synthetic Fisher files (0/0, int-0 entries)
   ddpm_model.npz      DDPM/models/diffusion.py Conditional_Model forward/backward (tiny config) + a 2-iteration SFR-on
                       trajectory composed from DDPM/functions/losses.py, models/ema.py in runners/diffusion.py order
+  compvis_export.npz  SD/train-scripts/convertModels.py create_unet_diffusers_config + convert_ldm_unet_checkpoint: the CompVis ->
+                      diffusers key mapping of the v1 UNet and of a small config (names only; tensors pass through unchanged)
   sd_unet.npz         SD/ldm/modules/diffusionmodules/openaimodel.py UNetModel (+ attention.py, util.py): parameter spec of the
                       v1-inference.yaml UNet (meta device), forward/backward on a tiny config, the "linear" LDM schedule, and a
                       2-iteration trajectory of the nsfw_removal.py loop body composed from the reference UNet
@@ -559,6 +561,57 @@ def gen_sd():
     print("sd_unet.npz:", {k: getattr(v, "shape", None) for k, v in list(out.items())[:6]}, "v1 params", int(out["v1_param_count"]))
 
 
+
+def import_ref_convert():
+    """SD/train-scripts/convertModels.py needs diffusers / transformers / omegaconf only for NAMES imported at module top (the
+    UNet key conversion itself is plain dict manipulation): the harness supplies empty stand-in classes."""
+    def stub(name, names):
+        m = types.ModuleType(name)
+        for n in names:
+            setattr(m, n, type(n, (), {}))
+        sys.modules[name] = m
+    stub("omegaconf", ["OmegaConf"])
+    stub("diffusers", ["AutoencoderKL", "DDIMScheduler", "DPMSolverMultistepScheduler", "EulerAncestralDiscreteScheduler", "EulerDiscreteScheduler",
+                       "HeunDiscreteScheduler", "LDMTextToImagePipeline", "LMSDiscreteScheduler", "PNDMScheduler", "StableDiffusionPipeline",
+                       "UNet2DConditionModel"])
+    for n in ("diffusers.pipelines", "diffusers.pipelines.latent_diffusion", "diffusers.pipelines.paint_by_example", "diffusers.pipelines.stable_diffusion"):
+        stub(n, ["StableDiffusionSafetyChecker", "PaintByExampleImageEncoder", "PaintByExamplePipeline"])
+    stub("diffusers.pipelines.latent_diffusion.pipeline_latent_diffusion", ["LDMBertConfig", "LDMBertModel"])
+    stub("transformers", ["AutoFeatureExtractor", "BertTokenizerFast", "CLIPImageProcessor", "CLIPTextModel", "CLIPTextModelWithProjection",
+                          "CLIPTokenizer", "CLIPVisionConfig"])
+    return _load("ref_convert_models", os.path.join(REF, "SD", "train-scripts", "convertModels.py"))
+
+
+class _Cfg(dict):
+    """attribute + item + `in` access, as the OmegaConf nodes the reference reads"""
+    __getattr__ = dict.__getitem__
+
+
+def gen_compvis_export():
+    from oracle import sd_ref
+    conv = import_ref_convert()
+    out = {}
+    for tag, kw in (("v1", dict()), ("small", dict(model_channels=32, channel_mult=(1, 2, 4), attention_resolutions=(2, 1), num_res_blocks=1,
+                                                   num_heads=2, context_dim=24))):
+        with torch.device("meta"):
+            m = sd_ref.UNetModel(**kw)
+        full = dict(model_channels=320, channel_mult=(1, 2, 4, 4), attention_resolutions=(4, 2, 1), num_res_blocks=2, in_channels=4,
+                    out_channels=4, context_dim=768, num_heads=8)
+        full.update(kw)
+        cfg = _Cfg(model=_Cfg(params=_Cfg(unet_config=_Cfg(params=_Cfg(**{k: (list(v) if isinstance(v, tuple) else v) for k, v in full.items()})),
+                                          first_stage_config=_Cfg(params=_Cfg(ddconfig=_Cfg(ch_mult=[1, 2, 4, 4]))))))
+        ucfg = conv.create_unet_diffusers_config(cfg, image_size=512)
+        ck = {"model.diffusion_model." + n: p for n, p in m.named_parameters()}
+        ck["first_stage_model.encoder.conv_in.weight"] = torch.empty(1, device="meta")      # non-UNet entries are ignored
+        ids = {id(v): k for k, v in ck.items()}
+        new = conv.convert_ldm_unet_checkpoint(dict(ck), ucfg)
+        lines = [f"{nk} {ids[id(v)]}" for nk, v in new.items()]
+        out[tag + "_map"] = np.frombuffer("\n".join(lines).encode(), dtype=np.uint8)
+        out[tag + "_config"] = np.frombuffer(repr(sorted(ucfg.items())).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "compvis_export.npz"), **out)
+    print("compvis_export.npz:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     ref_diffusion = import_ref_dit_diffusion()
@@ -572,4 +625,5 @@ if __name__ == "__main__":
     gen_sampling(ref_models, ref_diffusion)
     gen_ddpm_sampler()
     gen_sd()
+    gen_compvis_export()
     print("golden vectors written to", HERE)

@@ -92,3 +92,29 @@ def test_guided_sampling_real_dit_vs_oracle():
                             model_kwargs=dict(y=yc.to(DEV), cfg_scale=4.0), device=DEV, step_noise=noises.to(DEV))
     assert torch.isfinite(got_s).all()
     assert rel_err(got_s, want_s) < 3e-2
+
+
+def test_latent_front_end_sample_kernel_and_loader(tmp_path):
+    """vae.encode(x).latent_dist.sample().mul_(0.18215) (DiT/forget.py:265-267) from cached posterior moments: the sample kernel
+    against torch (diffusers' DiagonalGaussianDistribution: logvar clamped to [-30, 20]), and the loader's device batches."""
+    import numpy as np
+    from sfron import _lib, latents
+    from sfron._lib import check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(0)
+    mom = torch.randn(5, 8, 32, 32, generator=g)
+    mom[0, 4:] = 25.0; mom[1, 4:] = -40.0                       # clamp branches
+    eps = torch.randn(5, 4, 32, 32, generator=g)
+    out = torch.empty(5, 4, 32, 32, device=DEV)
+    check(_lib.lib().sfron_latent_sample(ptr(mom.to(DEV)), ptr(eps.to(DEV)), 5, 4, 1024, 0.18215, ptr(out), stream_ptr()), "latent_sample")
+    mean, lv = mom.chunk(2, dim=1)
+    want = (mean + torch.exp(0.5 * lv.clamp(-30.0, 20.0)) * eps) * 0.18215
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=2e-6, atol=1e-6)
+    rng = np.random.default_rng(1)
+    for i, c in enumerate(("n0", "n1", "n2")):
+        latents.write_shard(str(tmp_path), c, i, rng.standard_normal((6, 8, 32, 32)).astype(np.float16))
+    ld = latents.UnlearnLatentLoader(latents.LatentCache(str(tmp_path)), forget_class=1, global_batch=4, device=DEV)
+    f, r = ld.next("forget"), ld.next("remain")
+    assert f["x0"].shape == (4, 4, 32, 32) and f["x0"].is_cuda and bool((f["y"] == 1).all()) and bool((r["y"] != 1).all())
+    assert f["t"].dtype == torch.int64 and f["drop"].dtype == torch.uint8 and torch.isfinite(r["x0"]).all()
+    f2 = ld.next("forget")                                       # the batch staged ahead on the copy stream
+    assert not torch.equal(f2["noise"], f["noise"])

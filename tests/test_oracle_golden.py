@@ -345,3 +345,31 @@ def test_sd_nsfw_removal_trajectory_matches_reference(golden_dir):
     k = "input_blocks.1.1.transformer_blocks.0.attn2.to_v.weight"
     np.testing.assert_allclose(params[k].detach().numpy(), g["traj_final/" + k], rtol=1e-3, atol=2e-5)
     np.testing.assert_array_equal(params["time_embed.0.weight"].detach().numpy(), g["traj_untouched/time_embed.0.weight"])
+
+
+def test_compvis_to_diffusers_export_matches_reference_mapping(golden_dir, tmp_path):
+    """SD/train-scripts/convertModels.py:242-301,348-591 as savemodelDiffusers (:1006-1128) calls them: key mapping of the v1 UNet
+    (686 tensors) and of a small config, config dict, and the saved file (host-side code: runs without a GPU)."""
+    from oracle import sd_ref
+    from sfron import export
+    g = np.load(os.path.join(golden_dir, "compvis_export.npz"))
+    for tag, kw in (("v1", dict()), ("small", dict(model_channels=32, channel_mult=(1, 2, 4), attention_resolutions=(2, 1), num_res_blocks=1,
+                                                   num_heads=2, context_dim=24))):
+        with torch.device("meta"):
+            m = sd_ref.UNetModel(**kw)
+        want = dict(line.split(" ") for line in bytes(g[tag + "_map"]).decode().split("\n"))        # new -> old (prefixed)
+        sd = {"model.diffusion_model." + n: p for n, p in m.named_parameters()}
+        sd["cond_stage_model.transformer.dummy"] = torch.empty(1, device="meta")
+        got = export.compvis_unet_to_diffusers({"state_dict": sd}, layers_per_block=kw.get("num_res_blocks", 2))
+        assert len(got) == len(want) == len(list(m.named_parameters()))
+        ids = {id(v): k for k, v in sd.items()}
+        assert {nk: ids[id(v)] for nk, v in got.items()} == want
+        cfg = export.unet_diffusers_config(**kw)
+        assert repr(sorted(cfg.items())) == bytes(g[tag + "_config"]).decode()
+    # the save path: CompVis dict as it is + converted UNet, torch.load-able
+    m = sd_ref.UNetModel(**kw)
+    sd = {"model.diffusion_model." + n: p.detach() for n, p in m.named_parameters()}
+    export.save_model(sd, tmp_path / "compvis-x.pt", tmp_path / "diffusers-x.pt", layers_per_block=1)
+    back = torch.load(tmp_path / "diffusers-x.pt")
+    assert torch.equal(back["conv_in.weight"], sd["model.diffusion_model.input_blocks.0.0.weight"])
+    assert set(torch.load(tmp_path / "compvis-x.pt")) == set(sd)

@@ -75,6 +75,7 @@ _PROTOS.update({
                                        ctypes.c_long, ctypes.c_long, _S]),
     "sfron_colsum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, _S]),
     "sfron_timestep_embed": (c_int, [_P, c_int, c_int, _P, c_int, _S]),
+    "sfron_latent_sample": (c_int, [_P, _P, c_int, c_int, c_int, c_float, _P, _S]),
     "sfron_silu_fwd": (c_int, [_P, c_int64, _P, _S]),
     "sfron_silu_bwd": (c_int, [_P, _P, c_int64, _P, _P, _S]),
     "sfron_cond_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _S]),

@@ -106,6 +106,20 @@ __global__ __launch_bounds__(TPB) void k_unpatchify(const float* __restrict__ ro
   }
 }
 
+// latents = (mean + exp(0.5 * clamp(logvar, -30, 20)) * eps) * scale: DiagonalGaussianDistribution.sample() of the diffusers
+// AutoencoderKL posterior followed by .mul_(0.18215) (DiT/forget.py:265-267,305-307); moments [n][2C][hw] = mean || logvar
+__global__ __launch_bounds__(TPB) void k_latent_sample(const float* __restrict__ moments, const float* __restrict__ eps, int n, int c, int hw,
+                                                       float scale, float* __restrict__ out) {
+  const int64_t total = (int64_t)n * c * hw;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
+    const int64_t b = i / ((int64_t)c * hw), r = i - b * c * hw;
+    const float mean = moments[b * 2 * c * hw + r];
+    float lv = moments[b * 2 * c * hw + (int64_t)c * hw + r];
+    lv = fminf(fmaxf(lv, -30.0f), 20.0f);
+    out[i] = (mean + expf(0.5f * lv) * eps[i]) * scale;
+  }
+}
+
 inline int grid_for(int64_t n) {
   int64_t b = (n + TPB - 1) / TPB;
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -114,6 +128,13 @@ inline int grid_for(int64_t n) {
 }  // namespace
 
 extern "C" {
+
+int sfron_latent_sample(const float* moments, const float* eps, int n, int c, int hw, float scale, float* out, void* stream) {
+  SFRON_CHECK_ARG(moments && eps && out && n > 0 && c > 0 && hw > 0);
+  hipLaunchKernelGGL(k_latent_sample, dim3(grid_for((int64_t)n * c * hw)), dim3(TPB), 0, (hipStream_t)stream, moments, eps, n, c, hw, scale, out);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
 
 int sfron_timestep_embed(const int64_t* t, int n, int dim, uint16_t* out, int ld, void* stream) {
   SFRON_CHECK_ARG(t && out && n > 0 && dim > 0 && dim % 2 == 0 && ld >= dim);
