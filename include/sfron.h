@@ -182,6 +182,8 @@ typedef struct sfron_bgemm_desc {
   int a_transposed, b_transposed;
   int batch;
   long stride_a, stride_b, stride_c;
+  int batch2;                      /* inner batch (0 / 1 = none): attention heads that are column slices of one matrix */
+  long stride_a2, stride_b2, stride_c2;
   float alpha;
   const float* bias;               /* [N] or NULL */
   uint16_t* c_bf16; float* c_f32; int ldc;
@@ -233,7 +235,18 @@ int sfron_groupnorm_bwd(const float* dy, const float* x, int ldx, const float* g
                         const float* rstd, int B, int HW, int C, int groups, int swish, const uint8_t* drop_mask, float drop_scale,
                         float* dx, int lddx, int accumulate, float* part_gamma, float* part_beta, void* stream);
 /* p = bf16(softmax(scale * s)) over rows of length n; ds = bf16(scale * p * (dp - sum(p * dp)))   (AttnBlock, :168-186) */
-int sfron_softmax_fwd(const float* s, int64_t rows, int n, float scale, uint16_t* p, void* stream);
+int sfron_softmax_fwd(const float* s, int64_t rows, int n, int n_valid /* keys; columns beyond get probability 0 */, float scale, uint16_t* p,
+                      void* stream);
+/* y = bf16(LayerNorm(x; eps) * gamma + beta) on fp32 rows [rows][D]; backward: dx (+)=, per-block partial sums of d gamma / d beta
+ * [ceil(rows / sfron_layernorm_rows_per_block())][D] (BasicTransformerBlock.norm1..3, SD/ldm/modules/attention.py:223-225) */
+int sfron_layernorm_fwd(const float* x, const float* gamma, const float* beta, int64_t rows, int D, float eps, uint16_t* y, float* mean,
+                        float* rstd, void* stream);
+int sfron_layernorm_rows_per_block(void);
+int sfron_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, int64_t rows, int D, float* dx,
+                        int accumulate, float* part_gamma, float* part_beta, void* stream);
+/* GEGLU (attention.py:37-45): h fp32 [rows][2F] = value || gate; out = bf16(value * gelu_erf(gate)); backward dh bf16 [rows][2F] */
+int sfron_geglu_fwd(const float* h, int64_t rows, int F, uint16_t* out, void* stream);
+int sfron_geglu_bwd(const float* d_out, const float* h, int64_t rows, int F, uint16_t* dh, void* stream);
 int sfron_softmax_bwd(const uint16_t* p, const float* dp, int64_t rows, int n, float scale, uint16_t* ds, void* stream);
 /* out[b][c] = sum over the HW rows of sample b of x[row][c] */
 int sfron_sample_colsum(const float* x, int ld, int B, int HW, int C, float* out, int ld_out, void* stream);

@@ -160,7 +160,7 @@ def test_batched_gemm_and_softmax():
     np.testing.assert_allclose(S.cpu().view(B, T, T).numpy(), ref.numpy(), rtol=1e-4, atol=1e-3)
     P = torch.empty(B * T, T, dtype=torch.bfloat16, device=DEV)
     scale = C ** -0.5
-    check(L.sfron_softmax_fwd(ptr(S), B * T, T, scale, ptr(P), stream_ptr()), "softmax")
+    check(L.sfron_softmax_fwd(ptr(S), B * T, T, T, scale, ptr(P), stream_ptr()), "softmax")
     pr = torch.softmax(ref * scale, dim=-1)
     np.testing.assert_allclose(P.float().cpu().view(B, T, T).numpy(), pr.numpy(), rtol=1e-2, atol=2e-3)
     O = torch.empty(B * T, C, dtype=torch.bfloat16, device=DEV)

@@ -34,3 +34,23 @@ def test_cache_round_trip_and_rank_shares(tmp_path):
     latents.write_shard(str(bad), "z", 3, np.zeros((1, 8, 4, 4), np.float32))
     with pytest.raises(ValueError):
         latents.LatentCache(str(bad))
+
+
+def test_sd_unet_parameter_plan_matches_oracle():
+    """Names / shapes / order of sfron.sd_unet.UNetModel (built without a device: only the plan) against oracle.sd_ref.UNetModel,
+    which tests/golden/sd_unet.npz pins to the reference class (v1-inference.yaml config and a small one)."""
+    import torch
+    from types import SimpleNamespace
+    from oracle import sd_ref
+    from sfron import sd_unet
+    for kw in (dict(), dict(model_channels=32, channel_mult=(1, 2), attention_resolutions=(2, 1), num_res_blocks=1, num_heads=2, context_dim=24),
+               dict(model_channels=64, channel_mult=(1, 2, 4), attention_resolutions=(4, 1), num_res_blocks=2, num_heads=4, context_dim=40)):
+        full = dict(in_channels=4, model_channels=320, out_channels=4, num_res_blocks=2, attention_resolutions=(4, 2, 1), channel_mult=(1, 2, 4, 4),
+                    num_heads=8, context_dim=768)
+        full.update(kw)
+        ns = SimpleNamespace(mc=full["model_channels"], ted=4 * full["model_channels"], in_channels=4, out_channels=4, ctx_dim=full["context_dim"],
+                             num_res_blocks=full["num_res_blocks"], attn_res=tuple(full["attention_resolutions"]), channel_mult=tuple(full["channel_mult"]))
+        sd_unet.UNetModel._plan(ns)
+        with torch.device("meta"):
+            ref = sd_ref.UNetModel(**full)
+        assert [(n, tuple(p.shape)) for n, p in ref.named_parameters()] == [(n, tuple(s)) for n, s in ns.param_specs]

@@ -92,7 +92,8 @@ class BGemmDesc(ctypes.Structure):
     """Mirror of sfron_bgemm_desc."""
     _fields_ = [("A", c_void_p), ("B", c_void_p), ("M", c_int), ("N", c_int), ("K", c_int), ("lda", c_int), ("ldb", c_int),
                 ("a_transposed", c_int), ("b_transposed", c_int), ("batch", c_int),
-                ("stride_a", ctypes.c_long), ("stride_b", ctypes.c_long), ("stride_c", ctypes.c_long), ("alpha", c_float),
+                ("stride_a", ctypes.c_long), ("stride_b", ctypes.c_long), ("stride_c", ctypes.c_long), ("batch2", c_int),
+                ("stride_a2", ctypes.c_long), ("stride_b2", ctypes.c_long), ("stride_c2", ctypes.c_long), ("alpha", c_float),
                 ("bias", c_void_p), ("c_bf16", c_void_p), ("c_f32", c_void_p), ("ldc", c_int), ("resid", c_void_p),
                 ("sample_vec", c_void_p), ("ld_vec", c_int), ("rows_per_sample", c_int), ("accumulate", c_int)]
 
@@ -117,7 +118,12 @@ _PROTOS.update({
     "sfron_groupnorm_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, c_float, _P, _P, _P, _S]),
     "sfron_groupnorm_bwd": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, c_int, c_int,
                                     _P, _P, _S]),
-    "sfron_softmax_fwd": (c_int, [_P, c_int64, c_int, c_float, _P, _S]),
+    "sfron_softmax_fwd": (c_int, [_P, c_int64, c_int, c_int, c_float, _P, _S]),
+    "sfron_layernorm_fwd": (c_int, [_P, _P, _P, c_int64, c_int, c_float, _P, _P, _P, _S]),
+    "sfron_layernorm_rows_per_block": (c_int, []),
+    "sfron_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P, _P, _S]),
+    "sfron_geglu_fwd": (c_int, [_P, c_int64, c_int, _P, _S]),
+    "sfron_geglu_bwd": (c_int, [_P, _P, c_int64, c_int, _P, _S]),
     "sfron_softmax_bwd": (c_int, [_P, _P, c_int64, c_int, c_float, _P, _S]),
     "sfron_sample_colsum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _S]),
     "sfron_axpby": (c_int, [_P, _P, c_float, c_float, c_int64, _P, _S]),

@@ -37,6 +37,7 @@ struct BGemmArgs {
   const __bf16* A; const __bf16* B;
   int M, N, K, lda, ldb;
   long sA, sB, sC;        // batch strides (elements); grid.y = batch
+  long sA2, sB2, sC2;     // inner batch strides; grid.z = inner batch (attention heads: column offsets inside one matrix)
   __bf16* Cb; int ldcb;
   float* Cf; int ldcf;
   const float* bias;      // [N] or null
@@ -192,11 +193,12 @@ __global__ __launch_bounds__(NT) void k_bgemm(BGemmArgs g) {
   const int ntn = (g.N + BN - 1) / BN;
   const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
   const int m0 = tm * BM, n0 = tn * BN;
-  const long bz = blockIdx.y;
-  g.A += bz * g.sA; g.B += bz * g.sB;
-  if (g.Cb) g.Cb += bz * g.sC;
-  if (g.Cf) g.Cf += bz * g.sC;
-  if (g.resid) g.resid += bz * g.sC;
+  const long bz = blockIdx.y, bi = blockIdx.z;
+  g.A += bz * g.sA + bi * g.sA2; g.B += bz * g.sB + bi * g.sB2;
+  const long co = bz * g.sC + bi * g.sC2;
+  if (g.Cb) g.Cb += co;
+  if (g.Cf) g.Cf += co;
+  if (g.resid) g.resid += co;
 
   Stager<A_TR, CONV == CONV_A> stA;
   Stager<B_TR, CONV == CONV_B> stB;
@@ -444,19 +446,20 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd(const float* __restrict__ dy, co
 }
 
 // ---- softmax over rows of length n (fp32 in, bf16 out), one wave per row; backward dS = scale * P * (dP - sum(P dP))
-__global__ __launch_bounds__(TPB) void k_softmax_fwd(const float* __restrict__ s, int64_t rows, int n, float scale, __bf16* __restrict__ p) {
+// rows of `n` stored elements of which the first `nv` are keys (the rest is padding of the context length: probability 0)
+__global__ __launch_bounds__(TPB) void k_softmax_fwd(const float* __restrict__ s, int64_t rows, int n, int nv, float scale, __bf16* __restrict__ p) {
   const int64_t row = (int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
   const float* sr = s + row * n;
   float mx = -INFINITY;
-  for (int i = lane; i < n; i += 64) mx = fmaxf(mx, sr[i] * scale);
+  for (int i = lane; i < nv; i += 64) mx = fmaxf(mx, sr[i] * scale);
   mx = wave_max(mx);
   float sum = 0.f;
-  for (int i = lane; i < n; i += 64) sum += __expf(sr[i] * scale - mx);
+  for (int i = lane; i < nv; i += 64) sum += __expf(sr[i] * scale - mx);
   sum = wave_sum(sum);
   const float inv = 1.0f / sum;
-  for (int i = lane; i < n; i += 64) p[row * n + i] = f2bf(__expf(sr[i] * scale - mx) * inv);
+  for (int i = lane; i < n; i += 64) p[row * n + i] = i < nv ? f2bf(__expf(sr[i] * scale - mx) * inv) : (__bf16)0.0f;
 }
 __global__ __launch_bounds__(TPB) void k_softmax_bwd(const __bf16* __restrict__ p, const float* __restrict__ dp, int64_t rows, int n,
                                                      float scale, __bf16* __restrict__ ds) {
@@ -467,6 +470,82 @@ __global__ __launch_bounds__(TPB) void k_softmax_bwd(const __bf16* __restrict__ 
   for (int i = lane; i < n; i += 64) dot += bf2f(p[row * n + i]) * dp[row * n + i];
   dot = wave_sum(dot);
   for (int i = lane; i < n; i += 64) ds[row * n + i] = f2bf(scale * bf2f(p[row * n + i]) * (dp[row * n + i] - dot));
+}
+
+// ---- LayerNorm(D, eps, affine) on rows, one wave per row (BasicTransformerBlock.norm1..3, SD/ldm/modules/attention.py:223-225)
+__global__ __launch_bounds__(TPB) void k_layernorm_fwd(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int64_t rows, int D, float eps, __bf16* __restrict__ y, float* __restrict__ mean,
+                                                       float* __restrict__ rstd) {
+  const int64_t row = (int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = x + row * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += xr[i];
+  const float m = wave_sum(s) / D;
+  float q = 0.f;
+  for (int i = lane; i < D; i += 64) { const float d = xr[i] - m; q += d * d; }
+  const float r = rsqrtf(wave_sum(q) / D + eps);
+  for (int i = lane; i < D; i += 64) y[row * D + i] = f2bf((xr[i] - m) * r * gamma[i] + beta[i]);
+  if (lane == 0) { mean[row] = m; rstd[row] = r; }
+}
+// dx (+)= d LayerNorm; pg / pb [nblk][D]: per-workgroup (4 rows) partial sums of dy * xhat and dy, written with plain stores
+__global__ __launch_bounds__(TPB) void k_layernorm_bwd(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd, int64_t rows, int D,
+                                                       float* __restrict__ dx, int accumulate, float* __restrict__ pg, float* __restrict__ pb,
+                                                       int rows_per_block) {
+  extern __shared__ float sh[];                     // [4 waves][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* ag = sh + (size_t)wave * 2 * D;
+  float* ab = ag + D;
+  for (int i = lane; i < D; i += 64) { ag[i] = 0.f; ab[i] = 0.f; }
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  for (int64_t row = r0 + wave; row < r0 + rows_per_block && row < rows; row += TPB / 64) {
+    const float m = mean[row], r = rstd[row];
+    const float* xr = x + row * D;
+    const float* dr = dy + row * D;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = lane; i < D; i += 64) {
+      const float xh = (xr[i] - m) * r, d = dr[i] * gamma[i];
+      s1 += d; s2 += d * xh;
+      ag[i] += dr[i] * xh; ab[i] += dr[i];          // a lane owns its columns: no conflict inside the wave
+    }
+    s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+    for (int i = lane; i < D; i += 64) {
+      const float xh = (xr[i] - m) * r;
+      const float v = r * (dr[i] * gamma[i] - s1 - xh * s2);
+      float* o = dx + row * D + i;
+      *o = accumulate ? *o + v : v;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D; i += TPB) {
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < TPB / 64; ++w) { a += sh[(size_t)w * 2 * D + i]; b += sh[(size_t)w * 2 * D + D + i]; }
+    pg[(size_t)blockIdx.x * D + i] = a; pb[(size_t)blockIdx.x * D + i] = b;
+  }
+}
+// GEGLU (attention.py:37-45): h [rows][2F] = value || gate -> out = bf16(value * gelu(gate)), exact (erf) GELU as F.gelu
+__global__ __launch_bounds__(TPB) void k_geglu_fwd(const float* __restrict__ h, int64_t rows, int F, __bf16* __restrict__ out) {
+  const int64_t n = rows * F;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    const int64_t r = i / F; const int c = (int)(i % F);
+    const float a = h[r * 2 * F + c], gt = h[r * 2 * F + F + c];
+    out[i] = f2bf(a * 0.5f * gt * (1.0f + erff(gt * 0.70710678118654752f)));
+  }
+}
+// dh [rows][2F] bf16: d value = d_out * gelu(gate), d gate = d_out * value * gelu'(gate)
+__global__ __launch_bounds__(TPB) void k_geglu_bwd(const float* __restrict__ d_out, const float* __restrict__ h, int64_t rows, int F,
+                                                   __bf16* __restrict__ dh) {
+  const int64_t n = rows * F;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    const int64_t r = i / F; const int c = (int)(i % F);
+    const float a = h[r * 2 * F + c], gt = h[r * 2 * F + F + c], d = d_out[i];
+    const float cdf = 0.5f * (1.0f + erff(gt * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * expf(-0.5f * gt * gt);
+    dh[r * 2 * F + c] = f2bf(d * gt * cdf);
+    dh[r * 2 * F + F + c] = f2bf(d * a * (cdf + gt * pdf));
+  }
 }
 
 // ---- small pieces
@@ -554,10 +633,10 @@ __global__ __launch_bounds__(TPB) void k_class_embed_bwd(const float* __restrict
 }
 
 template <bool A_TR, bool B_TR, int EPI, int CONV>
-int launch_bgemm(const BGemmArgs& g, int nbatch, hipStream_t s) {
+int launch_bgemm(const BGemmArgs& g, int nbatch, hipStream_t s, int ninner = 1) {
   const size_t lds = 4 * TILE_ELEMS * sizeof(__bf16);
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
-  hipLaunchKernelGGL((k_bgemm<A_TR, B_TR, EPI, CONV>), dim3(ntm * ntn, nbatch), dim3(NT), lds, s, g);
+  hipLaunchKernelGGL((k_bgemm<A_TR, B_TR, EPI, CONV>), dim3(ntm * ntn, nbatch, ninner), dim3(NT), lds, s, g);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
 }
@@ -577,6 +656,9 @@ int sfron_bgemm_bf16(const sfron_bgemm_desc* d, void* stream) {
   g.A = (const __bf16*)d->A; g.B = (const __bf16*)d->B;
   g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb;
   g.sA = d->stride_a; g.sB = d->stride_b; g.sC = d->stride_c;
+  g.sA2 = d->stride_a2; g.sB2 = d->stride_b2; g.sC2 = d->stride_c2;
+  const int ni = d->batch2 > 0 ? d->batch2 : 1;
+  SFRON_CHECK_ARG(d->stride_a2 % 8 == 0 && d->stride_b2 % 8 == 0 && d->stride_c2 % 4 == 0);
   g.Cb = (__bf16*)d->c_bf16; g.ldcb = d->ldc; g.Cf = d->c_f32; g.ldcf = d->ldc;
   g.bias = d->bias; g.resid = d->resid; g.vec = d->sample_vec; g.ldvec = d->ld_vec; g.T = d->rows_per_sample > 0 ? d->rows_per_sample : 1;
   g.alpha = d->alpha; g.accumulate = d->accumulate;
@@ -584,11 +666,11 @@ int sfron_bgemm_bf16(const sfron_bgemm_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const bool bf = g.Cb != nullptr;
   if (!d->a_transposed && !d->b_transposed)
-    return bf ? launch_bgemm<false, false, EPI_BF16, CONV_NONE>(g, d->batch, s) : launch_bgemm<false, false, EPI_RES, CONV_NONE>(g, d->batch, s);
+    return bf ? launch_bgemm<false, false, EPI_BF16, CONV_NONE>(g, d->batch, s, ni) : launch_bgemm<false, false, EPI_RES, CONV_NONE>(g, d->batch, s, ni);
   if (!d->a_transposed && d->b_transposed)
-    return bf ? launch_bgemm<false, true, EPI_BF16, CONV_NONE>(g, d->batch, s) : launch_bgemm<false, true, EPI_RES, CONV_NONE>(g, d->batch, s);
+    return bf ? launch_bgemm<false, true, EPI_BF16, CONV_NONE>(g, d->batch, s, ni) : launch_bgemm<false, true, EPI_RES, CONV_NONE>(g, d->batch, s, ni);
   if (d->a_transposed && d->b_transposed)
-    return bf ? launch_bgemm<true, true, EPI_BF16, CONV_NONE>(g, d->batch, s) : launch_bgemm<true, true, EPI_RES, CONV_NONE>(g, d->batch, s);
+    return bf ? launch_bgemm<true, true, EPI_BF16, CONV_NONE>(g, d->batch, s, ni) : launch_bgemm<true, true, EPI_RES, CONV_NONE>(g, d->batch, s, ni);
   return SFRON_ERR_UNSUPPORTED;
 }
 
@@ -685,12 +767,43 @@ int sfron_groupnorm_bwd(const float* dy, const float* x, int ldx, const float* g
   return SFRON_OK;
 }
 
-int sfron_softmax_fwd(const float* s, int64_t rows, int n, float scale, uint16_t* p, void* stream) {
-  SFRON_CHECK_ARG(s && p && rows > 0 && n > 0);
-  hipLaunchKernelGGL(k_softmax_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(TPB), 0, (hipStream_t)stream, s, rows, n, scale, (__bf16*)p);
+int sfron_softmax_fwd(const float* s, int64_t rows, int n, int n_valid, float scale, uint16_t* p, void* stream) {
+  SFRON_CHECK_ARG(s && p && rows > 0 && n > 0 && n_valid > 0 && n_valid <= n);
+  hipLaunchKernelGGL(k_softmax_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(TPB), 0, (hipStream_t)stream, s, rows, n, n_valid, scale, (__bf16*)p);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }
+int sfron_layernorm_fwd(const float* x, const float* gamma, const float* beta, int64_t rows, int D, float eps, uint16_t* y, float* mean,
+                        float* rstd, void* stream) {
+  SFRON_CHECK_ARG(x && gamma && beta && y && mean && rstd && rows > 0 && D > 0);
+  hipLaunchKernelGGL(k_layernorm_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(TPB), 0, (hipStream_t)stream, x, gamma, beta, rows, D, eps, (__bf16*)y,
+                     mean, rstd);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+int sfron_layernorm_rows_per_block(void) { return 64; }
+int sfron_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, int64_t rows, int D, float* dx,
+                        int accumulate, float* part_gamma, float* part_beta, void* stream) {
+  SFRON_CHECK_ARG(dy && x && gamma && mean && rstd && dx && part_gamma && part_beta && rows > 0 && D > 0 && D <= 4096);
+  const int rpb = 64;
+  hipLaunchKernelGGL(k_layernorm_bwd, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(TPB), (size_t)(TPB / 64) * 2 * D * sizeof(float),
+                     (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+int sfron_geglu_fwd(const float* h, int64_t rows, int F, uint16_t* out, void* stream) {
+  SFRON_CHECK_ARG(h && out && rows > 0 && F > 0);
+  hipLaunchKernelGGL(k_geglu_fwd, dim3(grid_for(rows * F)), dim3(TPB), 0, (hipStream_t)stream, h, rows, F, (__bf16*)out);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+int sfron_geglu_bwd(const float* d_out, const float* h, int64_t rows, int F, uint16_t* dh, void* stream) {
+  SFRON_CHECK_ARG(d_out && h && dh && rows > 0 && F > 0);
+  hipLaunchKernelGGL(k_geglu_bwd, dim3(grid_for(rows * F)), dim3(TPB), 0, (hipStream_t)stream, d_out, h, rows, F, (__bf16*)dh);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
 int sfron_softmax_bwd(const uint16_t* p, const float* dp, int64_t rows, int n, float scale, uint16_t* ds, void* stream) {
   SFRON_CHECK_ARG(p && dp && ds && rows > 0 && n > 0);
   hipLaunchKernelGGL(k_softmax_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(TPB), 0, (hipStream_t)stream, (const __bf16*)p, dp, rows, n, scale, (__bf16*)ds);

@@ -1,0 +1,111 @@
+"""The SFR-on concept-erasure iteration for Stable Diffusion (BASELINE config 4) on the native UNet.
+
+One call of ``SDSFRon.step`` = one iteration of /root/reference/SD/train-scripts/nsfw_removal.py:108-173:
+  forget: x_f / x_p noised with the SAME t and noise (:134-141) -> eps(x_f, c_forget) and stop-gradient eps(x_p, c_pseudo)
+          -> forget_alpha * MSE (:143-147) -> backward -> [mask] -> Adam.step
+  remain: LDM eps loss of shared_step (:164-166; ldm/models/diffusion/ddpm.py:1286-1319 with logvar = 0) -> backward -> Adam.step
+Same Adam state for both steps (:81), no gradient clipping, no EMA.  ``train_method`` "full" / "xattn" (:66-77: parameters whose
+name contains "attn2").  The reference's mask application (:157-160) tests a parameter NAME against a list of Parameters and is
+therefore never true: ``mask_mode="as_written"`` reproduces that (no masking), ``"intended"`` multiplies
+the forget-stage gradients by the saliency mask as the sibling scripts do.
+Latents and prompt embeddings arrive resident on the device (the VAE / CLIP front-end of model.get_input is outside the path).
+"""
+import numpy as np
+import torch
+
+from . import _lib, sweep
+from ._lib import check, ptr, stream_ptr
+
+
+class LDMSchedule:
+    """register_schedule (ldm/models/diffusion/ddpm.py:153-240) for v1-inference.yaml: make_beta_schedule "linear" (a linspace of
+    sqrt(beta), squared; util.py:21-30), fp64 numpy tables rounded to fp32 buffers.  Packed as the [T][8] table of sfron_q_sample."""
+
+    def __init__(self, timesteps=1000, linear_start=0.00085, linear_end=0.012, device="cuda"):
+        betas = (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps, dtype=torch.float64) ** 2).numpy()
+        ac = np.cumprod(1.0 - betas, axis=0)
+        self.num_timesteps = timesteps
+        tab = np.zeros((timesteps, _lib.TAB_COLS if hasattr(_lib, "TAB_COLS") else 8), dtype=np.float32)
+        tab[:, 0] = np.sqrt(ac).astype(np.float32)
+        tab[:, 1] = np.sqrt(1.0 - ac).astype(np.float32)
+        self.tab = torch.from_numpy(tab).to(device).contiguous()
+
+    def q_sample(self, x_start, t, noise):
+        x_start, noise = x_start.contiguous(), noise.contiguous()
+        out = torch.empty_like(x_start)
+        n = x_start.shape[0]
+        check(_lib.lib().sfron_q_sample(ptr(x_start), ptr(noise), ptr(t.contiguous()), ptr(self.tab), n, x_start.numel() // n, ptr(out),
+                                        stream_ptr()), "q_sample")
+        return out
+
+
+class SDSFRon:
+    def __init__(self, unet, schedule=None, lr=1e-5, forget_alpha=1.0, remain_alpha=1.0, train_method="full", mask=None,
+                 mask_mode="as_written", process_group=None):
+        from . import dp
+        if train_method not in ("full", "xattn"):
+            raise ValueError("train_method must be 'full' or 'xattn' (nsfw_removal.py:66-77)")
+        if mask_mode not in ("as_written", "intended"):
+            raise ValueError("mask_mode must be 'as_written' or 'intended'")
+        self.unet, self.s = unet, schedule or LDMSchedule(device=unet.device_)
+        self.fa, self.ra = forget_alpha, remain_alpha
+        self.pg, self._dp, self.world = process_group, dp, dp.world_size(process_group)
+        p, g, w16, index = unet.flat_arena()
+        # which coordinates the optimizer owns: Adam leaves a coordinate whose gradient is always zero where it is
+        train = torch.zeros(p.numel(), dtype=torch.uint8, device=p.device)
+        for name, (off, shape) in index.items():
+            if train_method == "full" or "attn2" in name:
+                n = 1
+                for d in shape:
+                    n *= d
+                train[off:off + n] = 1
+        self.train_mask = train
+        self.forget_mask = train
+        if mask is not None and mask_mode == "intended":
+            fm = train.clone()
+            for name, (off, shape) in index.items():
+                m = mask.get(name, mask.get("model.diffusion_model." + name))
+                if m is None:
+                    raise KeyError(f"saliency mask has no entry for {name}")
+                n = 1
+                for d in shape:
+                    n *= d
+                fm[off:off + n] &= m.reshape(-1).to(device=p.device, dtype=torch.uint8)
+            self.forget_mask = fm
+        self.opt = sweep.FlatAdam(p, g, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adamw=True, mask=self.train_mask, w_bf16=w16)
+
+    def _backward(self, out, target, scale):
+        """d(scale * mean((out - target)^2)) / d out through the HIP loss kernels, then the UNet's backward pass."""
+        n, chw = out.shape[0], out[0].numel()
+        coef = torch.full((n,), 2.0 * scale / (n * chw * self.world), dtype=torch.float32, device=out.device)
+        d = torch.empty_like(out)
+        check(_lib.lib().sfron_ddpm_loss_bwd(ptr(target.contiguous()), ptr(out.contiguous()), ptr(coef), n, chw, ptr(d), stream_ptr()), "loss_bwd")
+        out.backward(d)
+        if self.world > 1:
+            self._dp.allreduce_flat_(self.opt.g, 64 << 20, self.pg)
+
+    def _mse(self, a, b):
+        n, chw = a.shape[0], a[0].numel()
+        per = torch.empty(n, dtype=torch.float32, device=a.device)
+        check(_lib.lib().sfron_ddpm_sample_loss(ptr(b.contiguous()), ptr(a.detach().contiguous()), n, chw, ptr(per), stream_ptr()), "sample_loss")
+        return per.sum() / (n * chw)
+
+    def step(self, forget, remain):
+        """forget: dict(x_f, x_p, c_f, c_p, t, noise); remain: dict(x, c, t, noise) -- device tensors, this rank's shard."""
+        u, s = self.unet, self.s
+        u.train()
+        f_noisy = s.q_sample(forget["x_f"], forget["t"], forget["noise"])
+        p_noisy = s.q_sample(forget["x_p"], forget["t"], forget["noise"])
+        with torch.no_grad():
+            p_out = u(p_noisy, forget["t"], context=forget["c_p"])
+        f_out = u(f_noisy, forget["t"], context=forget["c_f"])
+        ori_forget = self._mse(f_out, p_out)
+        self._backward(f_out, p_out, self.fa)
+        self.opt.mask = self.forget_mask
+        self.opt.step(max_norm=None, use_mask=True)                       # nsfw_removal.py:162 (no clipping)
+        r_out = u(s.q_sample(remain["x"], remain["t"], remain["noise"]), remain["t"], context=remain["c"])
+        ori_remain = self._mse(r_out, remain["noise"])
+        self._backward(r_out, remain["noise"], self.ra)
+        self.opt.mask = self.train_mask
+        self.opt.step(max_norm=None, use_mask=True)                       # :170
+        return {"forget_loss": ori_forget, "remain_loss": ori_remain}

@@ -58,14 +58,15 @@ def _pad8(n):
 
 
 # ------------------------------------------------------------------------------------------------ thin kernel wrappers
-def bgemm(A, B, M, N, K, *, lda, ldb, a_t=False, b_t=False, batch=1, sa=0, sb=0, sc=0, alpha=1.0, bias=None, c_bf16=None,
-          c_f32=None, ldc=None, resid=None, vec=None, ld_vec=0, rows_per_sample=1, accumulate=False):
+def bgemm(A, B, M, N, K, *, lda, ldb, a_t=False, b_t=False, batch=1, sa=0, sb=0, sc=0, batch2=1, sa2=0, sb2=0, sc2=0, alpha=1.0, bias=None,
+          c_bf16=None, c_f32=None, ldc=None, resid=None, vec=None, ld_vec=0, rows_per_sample=1, accumulate=False):
     """A / B / outputs may be tensors or raw device addresses (column-slice views are passed as address + leading dimension)."""
     d = _lib.BGemmDesc()
     d.A, d.B = _addr(A), _addr(B)
     d.M, d.N, d.K, d.lda, d.ldb = M, N, K, lda, ldb
     d.a_transposed, d.b_transposed, d.batch = int(a_t), int(b_t), batch
     d.stride_a, d.stride_b, d.stride_c, d.alpha = sa, sb, sc, alpha
+    d.batch2, d.stride_a2, d.stride_b2, d.stride_c2 = batch2, sa2, sb2, sc2
     d.bias = _addr(bias)
     d.c_bf16, d.c_f32, d.ldc = _addr(c_bf16), _addr(c_f32), ldc
     d.resid, d.sample_vec, d.ld_vec, d.rows_per_sample, d.accumulate = _addr(resid), _addr(vec), ld_vec, rows_per_sample, int(accumulate)
@@ -107,7 +108,242 @@ def cast_rows(x, ldx, rows, C, dev):
 
 
 # ------------------------------------------------------------------------------------------------ the model
-class Conditional_Model(nn.Module):
+class _TapeNet(nn.Module):
+    """Shared machinery of the convolutional U-Nets (DDPM Conditional_Model, LDM UNetModel): parameters as views into one flat fp32
+    arena (+ gradient arena, + bf16 shadow), and the building blocks -- each runs its forward launches and returns the closure
+    that runs its backward launches (the caller keeps those on a tape)."""
+
+    GN_EPS = 1e-6
+
+    def _alloc_arena(self, specs, groups):
+        """specs: OrderedDict name -> shape in named_parameters() order; groups: lists of names laid out contiguously (so that one
+        GEMM can read several of them as one matrix); everything else follows in order.  Tensors start at multiples of 8."""
+        off, index = 0, {}
+        for grp in list(groups) + [[nm] for nm in specs]:
+            fresh = [nm for nm in grp if nm not in index]
+            for nm in fresh:
+                n = 1
+                for d in specs[nm]:
+                    n *= d
+                index[nm] = (off, specs[nm])
+                off += n
+            off = _pad8(off)
+        self.n_total = off
+        self.index = OrderedDict((nm, index[nm]) for nm in specs)
+        dev = self.device_
+        self.params = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.params_bf16 = torch.zeros(off, dtype=torch.bfloat16, device=dev)
+        # bf16 GEMM operands of the 3x3 convolutions (re-laid from the OIHW master by sfron_conv_wprep before each pass)
+        self.conv3 = {}
+        for nm, shp in specs.items():
+            if nm.endswith(".weight") and len(shp) == 4 and shp[2] == 3:
+                co, ci = shp[0], shp[1]
+                cop, cip = _pad8(co), _pad8(ci)
+                self.conv3[nm[:-len(".weight")]] = dict(
+                    co=co, ci=ci, cop=cop, cip=cip, fwd=torch.zeros(cop * 9 * cip, dtype=torch.bfloat16, device=dev),
+                    dgr=torch.zeros(ci * 9 * cop, dtype=torch.bfloat16, device=dev) if ci % 8 == 0 else None)
+        mx = max(v["cop"] * 9 * v["cip"] for v in self.conv3.values())
+        self._dw = torch.empty(mx, dtype=torch.float32, device=dev)
+        self._cs = torch.empty(64 * 16384, dtype=torch.float32, device=dev)      # column-sum partials (64 row chunks x widest output)
+
+    def _register_views(self):
+        for name, (off, shape) in self.index.items():
+            node, parts = self, name.split(".")
+            for part in parts[:-1]:
+                if not hasattr(node, part):
+                    node.add_module(part, _Holder())
+                node = getattr(node, part)
+            n = 1
+            for s in shape:
+                n *= s
+            node.register_parameter(parts[-1], nn.Parameter(self.params[off:off + n].view(shape)))
+
+    def view(self, arena, name):
+        off, shape = self.index[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return arena[off:off + n].view(shape)
+
+    def flat_arena(self):
+        """(params, grads, bf16 shadow, name -> (offset, shape)): what sfron.ddpm.FlatParams adopts instead of re-homing."""
+        return self.params, self.grads, self.params_bf16, self.index
+
+    def sync_bf16(self):
+        check(_L().sfron_cast_bf16(ptr(self.params), ptr(self.params_bf16), self.n_total, stream_ptr()), "cast_bf16")
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        if state_dict and all(k.startswith("module.") for k in state_dict):      # DataParallel checkpoints (runners :1055-1061)
+            state_dict = {k[len("module."):]: v for k, v in state_dict.items()}
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.sync_bf16()
+        return r
+
+    def publish_grads(self):
+        for name, p in self.named_parameters():
+            p.grad = self.view(self.grads, name)
+
+    def _w(self, name):      # bf16 shadow of a 2-D weight ([out][in], also a 1x1 conv's [out][in][1][1])
+        off, _ = self.index[name]
+        return self.params_bf16.data_ptr() + 2 * off
+
+    def _p(self, name):      # fp32 master (bias, GroupNorm affine, embedding tables)
+        off, _ = self.index[name]
+        return self.params.data_ptr() + 4 * off
+
+    def _g(self, name):
+        off, _ = self.index[name]
+        return self.grads.data_ptr() + 4 * off
+
+    def _prep_conv_weights(self):
+        for base, v in self.conv3.items():
+            check(_L().sfron_conv_wprep(self._p(base + ".weight"), v["co"], v["ci"], 9, v["cop"], v["cip"], ptr(v["fwd"]),
+                                        ptr(v["dgr"]) if v["dgr"] is not None else None, stream_ptr()), "conv_wprep")
+
+    def _gn(self, tape, x, name, swish, drop_mask=None, eps=None):
+        """y = bf16(act(GroupNorm32(x)) [* dropout]); the backward step adds to x.grad."""
+        eps = self.GN_EPS if eps is None else eps
+        dev = self.device_
+        y = torch.empty(x.rows, x.C, dtype=torch.bfloat16, device=dev)
+        mean = torch.empty(x.B * 32, dtype=torch.float32, device=dev)
+        rstd = torch.empty_like(mean)
+        scale = 1.0 / (1.0 - self.dropout_p) if drop_mask is not None else 1.0
+        gam, bet = self._p(name + ".weight"), self._p(name + ".bias")
+        check(_L().sfron_groupnorm_fwd(ptr(x.t), x.C, gam, bet, x.B, x.H * x.W, x.C, 32, eps, int(swish), ptr(drop_mask), scale, ptr(y),
+                                       ptr(mean), ptr(rstd), stream_ptr()), "groupnorm_fwd")
+
+        def bwd(dy):           # dy: fp32 [rows][C]
+            gbuf, acc = x.grad_buf()
+            pg = torch.empty(x.B, x.C, dtype=torch.float32, device=dev)
+            pb = torch.empty_like(pg)
+            check(_L().sfron_groupnorm_bwd(ptr(dy), ptr(x.t), x.C, gam, bet, ptr(mean), ptr(rstd), x.B, x.H * x.W, x.C, 32, int(swish),
+                                           ptr(drop_mask), scale, ptr(gbuf), x.C, acc, ptr(pg), ptr(pb), stream_ptr()), "groupnorm_bwd")
+            check(_L().sfron_reduce_chunks(ptr(pg), 1, x.B, x.C, self._g(name + ".weight"), x.C, 0, stream_ptr()), "reduce")
+            check(_L().sfron_reduce_chunks(ptr(pb), 1, x.B, x.C, self._g(name + ".bias"), x.C, 0, stream_ptr()), "reduce")
+        return y, bwd
+
+    def _conv3(self, src, B, hs, ws, name, ho, wo, stride=1, pad=1, up=0, vec=None, ld_vec=0, resid=None):
+        """3x3 convolution of a bf16 NHWC source -> fp32 rows [B*ho*wo][Cout_p]; returns (out, backward(d_out fp32) -> d_src fp32
+        at the source resolution, or None for the input layer)."""
+        v = self.conv3[name]
+        dev = self.device_
+        rows = B * ho * wo
+        out = torch.empty(rows, v["cop"], dtype=torch.float32, device=dev)
+        if v["cop"] == v["co"]:
+            bias = self._p(name + ".bias")
+        else:                                        # conv_out: 3 output channels computed as 8 (zero rows / zero bias beyond Cout)
+            bias = torch.zeros(v["cop"], dtype=torch.float32, device=dev)
+            bias[:v["co"]] = self.view(self.params, name + ".bias")
+        d = _conv_desc(B, hs, ws, v["cip"], ho, wo, v["cop"], 9, stride, pad, up, 0, bias=bias, resid=resid, vec=vec, ld_vec=ld_vec,
+                       out_f32=out, ld_out=v["cop"])
+        check(_L().sfron_conv_fwd(ctypes.byref(d), ptr(src), ptr(v["fwd"]), stream_ptr()), "conv_fwd")
+
+        def bwd(d_out, want_dsrc=True):
+            dyb = cast_rows(d_out, v["cop"], rows, v["cop"], dev)
+            if v["cop"] == v["co"]:
+                colsum_f32(d_out, rows, v["co"], v["cop"], self._g(name + ".bias"), self._cs)
+            else:
+                bg = torch.empty(v["cop"], dtype=torch.float32, device=dev)
+                colsum_f32(d_out, rows, v["cop"], v["cop"], bg, self._cs)
+                self.view(self.grads, name + ".bias").copy_(bg[:v["co"]])
+            wd = _conv_desc(B, hs, ws, v["cip"], ho, wo, v["cop"], 9, stride, pad, up, 0)
+            check(_L().sfron_conv_wgrad(ctypes.byref(wd), ptr(dyb), v["cop"], ptr(src), ptr(self._dw), stream_ptr()), "conv_wgrad")
+            check(_L().sfron_conv_wgrad_scatter(ptr(self._dw), v["co"], v["ci"], 9, v["cip"], self._g(name + ".weight"), stream_ptr()),
+                  "conv_wgrad_scatter")
+            if not want_dsrc or v["dgr"] is None:
+                return None
+            if stride == 2:        # Downsample: gradient = flipped kernel over the zero-dilated dY, padding 2 - pad
+                ds = torch.empty(B * hs * ws, v["ci"], dtype=torch.float32, device=dev)
+                dd = _conv_desc(B, ho, wo, v["cop"], hs, ws, v["ci"], 9, 1, 2 - pad, 0, 1, out_f32=ds, ld_out=v["ci"])
+                check(_L().sfron_conv_fwd(ctypes.byref(dd), ptr(dyb), ptr(v["dgr"]), stream_ptr()), "conv_dgrad")
+                return ds
+            if up:                 # Upsample (:56-60): gradient wrt the upsampled image, summed over each 2x2 block
+                du = torch.empty(rows, v["ci"], dtype=torch.float32, device=dev)
+                dd = _conv_desc(B, ho, wo, v["cop"], ho, wo, v["ci"], 9, 1, 1, 0, 0, out_f32=du, ld_out=v["ci"])
+                check(_L().sfron_conv_fwd(ctypes.byref(dd), ptr(dyb), ptr(v["dgr"]), stream_ptr()), "conv_dgrad")
+                ds = torch.empty(B * hs * ws, v["ci"], dtype=torch.float32, device=dev)
+                check(_L().sfron_pool2_sum(ptr(du), B, hs, ws, v["ci"], ptr(ds), 0, stream_ptr()), "pool2_sum")
+                return ds
+            ds = torch.empty(rows, v["ci"], dtype=torch.float32, device=dev)
+            dd = _conv_desc(B, ho, wo, v["cop"], ho, wo, v["ci"], 9, 1, 1, 0, 0, out_f32=ds, ld_out=v["ci"])
+            check(_L().sfron_conv_fwd(ctypes.byref(dd), ptr(dyb), ptr(v["dgr"]), stream_ptr()), "conv_dgrad")
+            return ds
+        return out, bwd
+
+    def _linear(self, x_bf, rows, name, cin, cout, out=None, ldc=None, resid=None, x_lda=None, w_ptr=None, b_ptr=None, g_w=None, g_b=None,
+                bias=True):
+        """out fp32 [rows][cout] = x_bf [rows][cin] W^T + b (+ resid).  Returns (out, backward(d_out fp32 tensor/addr, ld) ->
+        d_x fp32 [rows][cin])."""
+        dev = self.device_
+        if out is None:
+            out = torch.empty(rows, cout, dtype=torch.float32, device=dev)
+            ldc = cout
+        w = w_ptr if w_ptr is not None else self._w(name + ".weight")
+        b = (b_ptr if b_ptr is not None else self._p(name + ".bias")) if bias else None
+        lda = x_lda if x_lda is not None else cin
+        bgemm(x_bf, w, rows, cout, cin, lda=lda, ldb=cin, bias=b, c_f32=out, ldc=ldc, resid=resid)
+        gw = g_w if g_w is not None else self._g(name + ".weight")
+        gb = (g_b if g_b is not None else self._g(name + ".bias")) if bias else None
+
+        def bwd(d_out, ld_d, want_dx=True, d_bf=None):
+            """d_out fp32 [rows][ld_d] (or None when only the bf16 form d_bf [rows][cout] exists)."""
+            if d_bf is None:
+                d_bf = cast_rows(d_out, ld_d, rows, cout, dev)
+            if bias and d_out is not None:
+                colsum_f32(d_out, rows, cout, ld_d, gb, self._cs)
+            elif bias:
+                colsum_bf16(d_bf, rows, cout, cout, gb, self._cs)
+            bgemm(d_bf, x_bf, cout, cin, rows, lda=cout, ldb=lda, a_t=True, b_t=True, c_f32=gw, ldc=cin)
+            if not want_dx:
+                return None
+            dx = torch.empty(rows, cin, dtype=torch.float32, device=dev)
+            bgemm(d_bf, w, rows, cin, cout, lda=cout, ldb=cin, b_t=True, c_f32=dx, ldc=cin)
+            return dx
+        return out, bwd
+
+    # sub-module names of a residual block: (norm1, conv1, norm2, conv2, 1x1 shortcut); the DDPM model's, overridden by the LDM one
+    RES_NAMES = (".norm1", ".conv1", ".norm2", ".conv2", ".nin_shortcut")
+
+    def _resblock(self, tape, name, x, cin, cout, proj, d_proj, drop_mask):
+        """GroupNorm -> swish -> conv3x3 (+ per-sample embedding projection) -> GroupNorm -> swish [-> dropout] -> conv3x3, plus the
+        (1x1-projected) input (DDPM ResnetBlock, models/diffusion.py:85-145; LDM ResBlock, openaimodel.py:177-288)."""
+        n_norm1, n_conv1, n_norm2, n_conv2, n_short = (name + sfx for sfx in self.RES_NAMES)
+        dev, B, H, W = self.device_, x.B, x.H, x.W
+        a1, gn1_b = self._gn(tape, x, n_norm1, True)
+        c0, _ = self.proj_slices[name]
+        h1_t, conv1_b = self._conv3(a1, B, H, W, n_conv1, H, W, vec=proj.data_ptr() + 4 * c0, ld_vec=self.proj_total)
+        h1 = Act(h1_t, B, H, W, cout)
+        a2, gn2_b = self._gn(tape, h1, n_norm2, True, drop_mask)
+        if cin != cout:
+            xb = cast_rows(x.t, cin, x.rows, cin, dev)
+            sc, sc_b = self._linear(xb, x.rows, n_short, cin, cout)
+        else:
+            sc, sc_b = x.t, None
+        out_t, conv2_b = self._conv3(a2, B, H, W, n_conv2, H, W, resid=sc)
+        out = Act(out_t, B, H, W, cout)
+
+        def bwd():
+            d_out = out.grad
+            d_a2 = conv2_b(d_out)
+            if sc_b is None:
+                g, acc = x.grad_buf()
+                check(_L().sfron_copy_cols(ptr(d_out), cout, x.rows, cout, ptr(g), cout, acc, stream_ptr()), "copy_cols")
+            else:
+                dx = sc_b(d_out, cout)
+                g, acc = x.grad_buf()
+                check(_L().sfron_copy_cols(ptr(dx), cin, x.rows, cin, ptr(g), cin, acc, stream_ptr()), "copy_cols")
+            gn2_b(d_a2)                                   # -> h1.grad
+            dh1 = h1.grad
+            check(_L().sfron_sample_colsum(ptr(dh1), cout, B, H * W, cout, d_proj.data_ptr() + 4 * c0, self.proj_total, stream_ptr()),
+                  "sample_colsum")
+            d_a1 = conv1_b(dh1)
+            gn1_b(d_a1)                                   # -> x.grad (+=)
+        tape.append(bwd)
+        return out
+
+
+class Conditional_Model(_TapeNet):
     def __init__(self, config=None, *, ch=128, out_ch=3, ch_mult=(1, 2, 2, 2), num_res_blocks=2, attn_resolutions=(16,), dropout=0.1,
                  in_channels=3, resolution=32, resamp_with_conv=True, n_classes=10, cond_drop_prob=0.1, device="cuda"):
         super().__init__()
@@ -229,83 +465,20 @@ class Conditional_Model(nn.Module):
         network, the input swish(temb || cemb) being the same for every block), their biases, the q / k / v 1x1 convolutions of
         each AttnBlock as one [3C][C] matrix + [3C] bias, then everything else in named_parameters() order."""
         specs = OrderedDict(self.param_specs)
-        off = 0
-        index = {}
-
-        def take(name):
-            nonlocal off
-            n = 1
-            for s in specs[name]:
-                n *= s
-            index[name] = (off, specs[name])
-            return n
-
-        def seq(names, align_each=False):
-            nonlocal off
-            for nm in names:
-                off += take(nm)
-                if align_each:
-                    off = _pad8(off)
-            off = _pad8(off)
-
         proj_names = [n for n, _, _ in self.res_blocks]
-        self.proj_w_off = off
-        seq([n + ".temb_cemb_proj.weight" for n in proj_names])
-        self.proj_b_off = off
-        seq([n + ".temb_cemb_proj.bias" for n in proj_names])
+        groups = [[n + ".temb_cemb_proj.weight" for n in proj_names], [n + ".temb_cemb_proj.bias" for n in proj_names]]
+        self.attn_names = [n[:-len(".q.weight")] for n in specs if n.endswith(".q.weight")]
+        for a in self.attn_names:
+            groups.append([a + ".q.weight", a + ".k.weight", a + ".v.weight"])
+            groups.append([a + ".q.bias", a + ".k.bias", a + ".v.bias"])
+        self._alloc_arena(specs, groups)
+        self.proj_w_off = self.index[proj_names[0] + ".temb_cemb_proj.weight"][0]
+        self.proj_b_off = self.index[proj_names[0] + ".temb_cemb_proj.bias"][0]
         self.proj_slices, c0 = {}, 0
         for n, _, cout in self.res_blocks:
             self.proj_slices[n] = (c0, cout)
             c0 += cout
         self.proj_total = c0
-        self.attn_names = [n[:-len(".q.weight")] for n in specs if n.endswith(".q.weight")]
-        for a in self.attn_names:
-            seq([a + ".q.weight", a + ".k.weight", a + ".v.weight"])
-            seq([a + ".q.bias", a + ".k.bias", a + ".v.bias"])
-        for nm in specs:
-            if nm not in index:
-                seq([nm])
-        self.n_total = off
-        self.index = OrderedDict((nm, index[nm]) for nm in specs)          # named_parameters() order
-        dev = self.device_
-        self.params = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.grads = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.params_bf16 = torch.zeros(off, dtype=torch.bfloat16, device=dev)
-        # bf16 GEMM operands of the 3x3 convolutions (re-laid from the OIHW master by sfron_conv_wprep before each pass)
-        self.conv3 = {}
-        for nm, shp in specs.items():
-            if nm.endswith(".weight") and len(shp) == 4 and shp[2] == 3:
-                co, ci = shp[0], shp[1]
-                cop, cip = _pad8(co), _pad8(ci)
-                self.conv3[nm[:-len(".weight")]] = dict(
-                    co=co, ci=ci, cop=cop, cip=cip, fwd=torch.zeros(cop * 9 * cip, dtype=torch.bfloat16, device=dev),
-                    dgr=torch.zeros(ci * 9 * cop, dtype=torch.bfloat16, device=dev) if ci % 8 == 0 else None)
-        mx = max(v["cop"] * 9 * v["cip"] for v in self.conv3.values())
-        self._dw = torch.empty(mx, dtype=torch.float32, device=dev)
-        self._cs = torch.empty(64 * 8192, dtype=torch.float32, device=dev)       # column-sum partials (64 row chunks x widest output)
-
-    def _register_views(self):
-        for name, (off, shape) in self.index.items():
-            node, parts = self, name.split(".")
-            for part in parts[:-1]:
-                if not hasattr(node, part):
-                    node.add_module(part, _Holder())
-                node = getattr(node, part)
-            n = 1
-            for s in shape:
-                n *= s
-            node.register_parameter(parts[-1], nn.Parameter(self.params[off:off + n].view(shape)))
-
-    def view(self, arena, name):
-        off, shape = self.index[name]
-        n = 1
-        for s in shape:
-            n *= s
-        return arena[off:off + n].view(shape)
-
-    def flat_arena(self):
-        """(params, grads, bf16 shadow, name -> (offset, shape)): what sfron.ddpm.FlatParams adopts instead of re-homing."""
-        return self.params, self.grads, self.params_bf16, self.index
 
     def reset_parameters(self):
         """torch's default initialisers of the layer types the reference builds (Linear / Conv2d: kaiming_uniform(a=sqrt 5) +
@@ -327,168 +500,8 @@ class Conditional_Model(nn.Module):
                     p.uniform_(-bound, bound)
         self.sync_bf16()
 
-    def sync_bf16(self):
-        check(_L().sfron_cast_bf16(ptr(self.params), ptr(self.params_bf16), self.n_total, stream_ptr()), "cast_bf16")
-
-    def load_state_dict(self, state_dict, strict=True, **kw):
-        if state_dict and all(k.startswith("module.") for k in state_dict):      # DataParallel checkpoints (runners :1055-1061)
-            state_dict = {k[len("module."):]: v for k, v in state_dict.items()}
-        r = super().load_state_dict(state_dict, strict=strict, **kw)
-        self.sync_bf16()
-        return r
-
-    def publish_grads(self):
-        for name, p in self.named_parameters():
-            p.grad = self.view(self.grads, name)
-
     # -------------------------------------------------------------------------------------------- parameter access
-    def _w(self, name):      # bf16 shadow of a 2-D weight ([out][in], also a 1x1 conv's [out][in][1][1])
-        off, _ = self.index[name]
-        return self.params_bf16.data_ptr() + 2 * off
-
-    def _p(self, name):      # fp32 master (bias, GroupNorm affine, embedding tables)
-        off, _ = self.index[name]
-        return self.params.data_ptr() + 4 * off
-
-    def _g(self, name):
-        off, _ = self.index[name]
-        return self.grads.data_ptr() + 4 * off
-
-    def _prep_conv_weights(self):
-        for base, v in self.conv3.items():
-            check(_L().sfron_conv_wprep(self._p(base + ".weight"), v["co"], v["ci"], 9, v["cop"], v["cip"], ptr(v["fwd"]),
-                                        ptr(v["dgr"]) if v["dgr"] is not None else None, stream_ptr()), "conv_wprep")
-
     # -------------------------------------------------------------------------------------------- building blocks
-    def _gn(self, tape, x, name, swish, drop_mask=None):
-        """y = bf16(act(GroupNorm32(x)) [* dropout]); the backward step adds to x.grad."""
-        dev = self.device_
-        y = torch.empty(x.rows, x.C, dtype=torch.bfloat16, device=dev)
-        mean = torch.empty(x.B * 32, dtype=torch.float32, device=dev)
-        rstd = torch.empty_like(mean)
-        scale = 1.0 / (1.0 - self.dropout_p) if drop_mask is not None else 1.0
-        gam, bet = self._p(name + ".weight"), self._p(name + ".bias")
-        check(_L().sfron_groupnorm_fwd(ptr(x.t), x.C, gam, bet, x.B, x.H * x.W, x.C, 32, 1e-6, int(swish), ptr(drop_mask), scale, ptr(y),
-                                       ptr(mean), ptr(rstd), stream_ptr()), "groupnorm_fwd")
-
-        def bwd(dy):           # dy: fp32 [rows][C]
-            gbuf, acc = x.grad_buf()
-            pg = torch.empty(x.B, x.C, dtype=torch.float32, device=dev)
-            pb = torch.empty_like(pg)
-            check(_L().sfron_groupnorm_bwd(ptr(dy), ptr(x.t), x.C, gam, bet, ptr(mean), ptr(rstd), x.B, x.H * x.W, x.C, 32, int(swish),
-                                           ptr(drop_mask), scale, ptr(gbuf), x.C, acc, ptr(pg), ptr(pb), stream_ptr()), "groupnorm_bwd")
-            check(_L().sfron_reduce_chunks(ptr(pg), 1, x.B, x.C, self._g(name + ".weight"), x.C, 0, stream_ptr()), "reduce")
-            check(_L().sfron_reduce_chunks(ptr(pb), 1, x.B, x.C, self._g(name + ".bias"), x.C, 0, stream_ptr()), "reduce")
-        return y, bwd
-
-    def _conv3(self, src, B, hs, ws, name, ho, wo, stride=1, pad=1, up=0, vec=None, ld_vec=0, resid=None):
-        """3x3 convolution of a bf16 NHWC source -> fp32 rows [B*ho*wo][Cout_p]; returns (out, backward(d_out fp32) -> d_src fp32
-        at the source resolution, or None for the input layer)."""
-        v = self.conv3[name]
-        dev = self.device_
-        rows = B * ho * wo
-        out = torch.empty(rows, v["cop"], dtype=torch.float32, device=dev)
-        if v["cop"] == v["co"]:
-            bias = self._p(name + ".bias")
-        else:                                        # conv_out: 3 output channels computed as 8 (zero rows / zero bias beyond Cout)
-            bias = torch.zeros(v["cop"], dtype=torch.float32, device=dev)
-            bias[:v["co"]] = self.view(self.params, name + ".bias")
-        d = _conv_desc(B, hs, ws, v["cip"], ho, wo, v["cop"], 9, stride, pad, up, 0, bias=bias, resid=resid, vec=vec, ld_vec=ld_vec,
-                       out_f32=out, ld_out=v["cop"])
-        check(_L().sfron_conv_fwd(ctypes.byref(d), ptr(src), ptr(v["fwd"]), stream_ptr()), "conv_fwd")
-
-        def bwd(d_out, want_dsrc=True):
-            dyb = cast_rows(d_out, v["cop"], rows, v["cop"], dev)
-            if v["cop"] == v["co"]:
-                colsum_f32(d_out, rows, v["co"], v["cop"], self._g(name + ".bias"), self._cs)
-            else:
-                bg = torch.empty(v["cop"], dtype=torch.float32, device=dev)
-                colsum_f32(d_out, rows, v["cop"], v["cop"], bg, self._cs)
-                self.view(self.grads, name + ".bias").copy_(bg[:v["co"]])
-            wd = _conv_desc(B, hs, ws, v["cip"], ho, wo, v["cop"], 9, stride, pad, up, 0)
-            check(_L().sfron_conv_wgrad(ctypes.byref(wd), ptr(dyb), v["cop"], ptr(src), ptr(self._dw), stream_ptr()), "conv_wgrad")
-            check(_L().sfron_conv_wgrad_scatter(ptr(self._dw), v["co"], v["ci"], 9, v["cip"], self._g(name + ".weight"), stream_ptr()),
-                  "conv_wgrad_scatter")
-            if not want_dsrc or v["dgr"] is None:
-                return None
-            if stride == 2:        # Downsample (:76-80): gradient = flipped kernel over the zero-dilated dY, pad 2
-                ds = torch.empty(B * hs * ws, v["ci"], dtype=torch.float32, device=dev)
-                dd = _conv_desc(B, ho, wo, v["cop"], hs, ws, v["ci"], 9, 1, 2, 0, 1, out_f32=ds, ld_out=v["ci"])
-                check(_L().sfron_conv_fwd(ctypes.byref(dd), ptr(dyb), ptr(v["dgr"]), stream_ptr()), "conv_dgrad")
-                return ds
-            if up:                 # Upsample (:56-60): gradient wrt the upsampled image, summed over each 2x2 block
-                du = torch.empty(rows, v["ci"], dtype=torch.float32, device=dev)
-                dd = _conv_desc(B, ho, wo, v["cop"], ho, wo, v["ci"], 9, 1, 1, 0, 0, out_f32=du, ld_out=v["ci"])
-                check(_L().sfron_conv_fwd(ctypes.byref(dd), ptr(dyb), ptr(v["dgr"]), stream_ptr()), "conv_dgrad")
-                ds = torch.empty(B * hs * ws, v["ci"], dtype=torch.float32, device=dev)
-                check(_L().sfron_pool2_sum(ptr(du), B, hs, ws, v["ci"], ptr(ds), 0, stream_ptr()), "pool2_sum")
-                return ds
-            ds = torch.empty(rows, v["ci"], dtype=torch.float32, device=dev)
-            dd = _conv_desc(B, ho, wo, v["cop"], ho, wo, v["ci"], 9, 1, 1, 0, 0, out_f32=ds, ld_out=v["ci"])
-            check(_L().sfron_conv_fwd(ctypes.byref(dd), ptr(dyb), ptr(v["dgr"]), stream_ptr()), "conv_dgrad")
-            return ds
-        return out, bwd
-
-    def _linear(self, x_bf, rows, name, cin, cout, out=None, ldc=None, resid=None, x_lda=None, w_ptr=None, b_ptr=None, g_w=None, g_b=None):
-        """out fp32 [rows][cout] = x_bf [rows][cin] W^T + b (+ resid).  Returns (out, backward(d_out fp32 tensor/addr, ld) ->
-        d_x fp32 [rows][cin])."""
-        dev = self.device_
-        if out is None:
-            out = torch.empty(rows, cout, dtype=torch.float32, device=dev)
-            ldc = cout
-        w = w_ptr if w_ptr is not None else self._w(name + ".weight")
-        b = b_ptr if b_ptr is not None else self._p(name + ".bias")
-        lda = x_lda if x_lda is not None else cin
-        bgemm(x_bf, w, rows, cout, cin, lda=lda, ldb=cin, bias=b, c_f32=out, ldc=ldc, resid=resid)
-        gw = g_w if g_w is not None else self._g(name + ".weight")
-        gb = g_b if g_b is not None else self._g(name + ".bias")
-
-        def bwd(d_out, ld_d, want_dx=True, d_bf=None):
-            if d_bf is None:
-                d_bf = cast_rows(d_out, ld_d, rows, cout, dev)
-            colsum_f32(d_out, rows, cout, ld_d, gb, self._cs)
-            bgemm(d_bf, x_bf, cout, cin, rows, lda=cout, ldb=lda, a_t=True, b_t=True, c_f32=gw, ldc=cin)
-            if not want_dx:
-                return None
-            dx = torch.empty(rows, cin, dtype=torch.float32, device=dev)
-            bgemm(d_bf, w, rows, cin, cout, lda=cout, ldb=cin, b_t=True, c_f32=dx, ldc=cin)
-            return dx
-        return out, bwd
-
-    def _resblock(self, tape, name, x, cin, cout, proj, d_proj, drop_mask):
-        dev, B, H, W = self.device_, x.B, x.H, x.W
-        a1, gn1_b = self._gn(tape, x, name + ".norm1", True)
-        c0, _ = self.proj_slices[name]
-        h1_t, conv1_b = self._conv3(a1, B, H, W, name + ".conv1", H, W, vec=proj.data_ptr() + 4 * c0, ld_vec=self.proj_total)
-        h1 = Act(h1_t, B, H, W, cout)
-        a2, gn2_b = self._gn(tape, h1, name + ".norm2", True, drop_mask)
-        if cin != cout:
-            xb = cast_rows(x.t, cin, x.rows, cin, dev)
-            sc, sc_b = self._linear(xb, x.rows, name + ".nin_shortcut", cin, cout)
-        else:
-            sc, sc_b = x.t, None
-        out_t, conv2_b = self._conv3(a2, B, H, W, name + ".conv2", H, W, resid=sc)
-        out = Act(out_t, B, H, W, cout)
-
-        def bwd():
-            d_out = out.grad
-            d_a2 = conv2_b(d_out)
-            if sc_b is None:
-                g, acc = x.grad_buf()
-                check(_L().sfron_copy_cols(ptr(d_out), cout, x.rows, cout, ptr(g), cout, acc, stream_ptr()), "copy_cols")
-            else:
-                dx = sc_b(d_out, cout)
-                g, acc = x.grad_buf()
-                check(_L().sfron_copy_cols(ptr(dx), cin, x.rows, cin, ptr(g), cin, acc, stream_ptr()), "copy_cols")
-            gn2_b(d_a2)                                   # -> h1.grad
-            dh1 = h1.grad
-            check(_L().sfron_sample_colsum(ptr(dh1), cout, B, H * W, cout, d_proj.data_ptr() + 4 * c0, self.proj_total, stream_ptr()),
-                  "sample_colsum")
-            d_a1 = conv1_b(dh1)
-            gn1_b(d_a1)                                   # -> x.grad (+=)
-        tape.append(bwd)
-        return out
-
     def _attn(self, tape, name, x):
         dev, B, C, T = self.device_, x.B, x.C, x.H * x.W
         rows = x.rows
@@ -500,7 +513,7 @@ class Conditional_Model(nn.Module):
         bgemm(q, k, T, T, C, lda=3 * C, ldb=3 * C, batch=B, sa=T * 3 * C, sb=T * 3 * C, sc=T * T, c_f32=S, ldc=T)
         Pm = torch.empty(B * T, T, dtype=torch.bfloat16, device=dev)
         scale = float(int(C) ** (-0.5))
-        check(_L().sfron_softmax_fwd(ptr(S), B * T, T, scale, ptr(Pm), stream_ptr()), "softmax_fwd")
+        check(_L().sfron_softmax_fwd(ptr(S), B * T, T, T, scale, ptr(Pm), stream_ptr()), "softmax_fwd")
         O = torch.empty(rows, C, dtype=torch.bfloat16, device=dev)
         bgemm(Pm, v, T, C, T, lda=T, ldb=3 * C, b_t=True, batch=B, sa=T * T, sb=T * 3 * C, sc=T * C, c_bf16=O, ldc=C)
         out_t = torch.empty(rows, C, dtype=torch.float32, device=dev)
