@@ -191,6 +191,9 @@ typedef struct sfron_bgemm_desc {
   const float* sample_vec;         /* fp32 vec[(row / rows_per_sample) * ld_vec + col] added (c_f32 only), or NULL */
   int ld_vec, rows_per_sample;
   int accumulate;                  /* c_f32 += result */
+  float* split_ws; int split_ws_slabs;   /* optional: fp32 scratch [split_ws_slabs][M * N] -- a plain weight gradient (both operands
+                                      transposed, batch 1, ldc == N, no epilogue extras) then splits its contraction over the
+                                      chip and adds the slabs in a fixed order */
 } sfron_bgemm_desc;
 int sfron_bgemm_bf16(const sfron_bgemm_desc* desc /* HOST pointer */, void* stream);
 
@@ -214,13 +217,16 @@ typedef struct sfron_conv_desc {
 /* out[p][n] = sum_{tap, c} src[src(p, tap)][c] * w[n][tap][c]; w bf16 [n_out][taps][c_src] (sfron_conv_wprep's "fwd" layout;
  * the input gradient calls this on dY with the "dgrad" layout) */
 int sfron_conv_fwd(const sfron_conv_desc* desc, const uint16_t* src, const uint16_t* w, void* stream);
-/* dw_gemm fp32 [n_out][taps * c_src] = sum_p dy[p][n] * src[src(p, tap)][c]   (dy bf16 [rows][ld_dy]) */
+/* dw_gemm fp32 [splits][n_out][taps * c_src]: slab s = sum over the s-th range of pixels p of dy[p][n] * src[src(p, tap)][c]
+ * (dy bf16 [rows][ld_dy]); splits = sfron_conv_wgrad_splits(desc) >= 1 (the contraction over all pixels is split over the chip) */
+int sfron_conv_wgrad_splits(const sfron_conv_desc* desc);
 int sfron_conv_wgrad(const sfron_conv_desc* desc, const uint16_t* dy, int ld_dy, const uint16_t* src, float* dw_gemm, void* stream);
 /* fp32 OIHW master weights -> bf16 operands: w_fwd [c_out_p][taps][c_in_p] (zero padded), w_dgrad [c_in][taps flipped][c_out_p] or NULL */
 int sfron_conv_wprep(const float* w_oihw, int c_out, int c_in, int taps, int c_out_p, int c_in_p, uint16_t* w_fwd, uint16_t* w_dgrad,
                      void* stream);
-/* dw_gemm [c_out_p..][taps][c_in_p] -> OIHW gradient [c_out][c_in][taps] (overwrite) */
-int sfron_conv_wgrad_scatter(const float* dw_gemm, int c_out, int c_in, int taps, int c_in_p, float* dw_oihw, void* stream);
+/* dw_gemm [n_slabs][c_out_p..][taps][c_in_p] -> OIHW gradient [c_out][c_in][taps] (overwrite; the slabs are added in order) */
+int sfron_conv_wgrad_scatter(const float* dw_gemm, int c_out, int c_in, int taps, int c_in_p, int n_slabs, int64_t slab_stride,
+                             float* dw_oihw, void* stream);
 
 int sfron_nchw_to_rows_bf16(const float* x, int B, int C, int HW, int c_pad, uint16_t* rows, void* stream);
 int sfron_nchw_to_rows_f32(const float* x, int B, int C, int HW, int ld, float* rows, void* stream);

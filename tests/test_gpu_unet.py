@@ -33,15 +33,15 @@ def _nchw(r, B, H, W):
     return r.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
 
 
-@pytest.mark.parametrize("form", ["same", "down", "up", "rgb_in", "rgb_out"])
+@pytest.mark.parametrize("form", ["same", "down", "up", "rgb_in", "rgb_out", "same_big"])
 def test_conv3x3_forward_dgrad_wgrad(form):
     import ctypes
     from sfron import _lib, unet
     from sfron._lib import check, ptr, stream_ptr
     L = _lib.lib()
     g = torch.Generator().manual_seed(len(form))
-    B, H = 3, 8
-    ci, co = {"same": (32, 64), "down": (32, 32), "up": (32, 32), "rgb_in": (3, 32), "rgb_out": (32, 3)}[form]
+    B, H = (16, 16) if form == "same_big" else (3, 8)          # same_big: 4096 pixels -> the weight gradient's split-K path
+    ci, co = {"same": (32, 64), "down": (32, 32), "up": (32, 32), "rgb_in": (3, 32), "rgb_out": (32, 3), "same_big": (64, 128)}[form]
     cip, cop = unet._pad8(ci), unet._pad8(co)
     x = torch.randn(B, ci, H, H, generator=g).to(torch.bfloat16).float()
     w = (torch.randn(co, ci, 3, 3, generator=g) * 0.1)
@@ -80,11 +80,12 @@ def test_conv3x3_forward_dgrad_wgrad(form):
     dyr = torch.zeros(rows, cop)
     dyr[:, :co] = _rows(dy)
     dyb = dyr.to(torch.bfloat16).to(DEV)
-    dwg = torch.full((cop * 9 * cip,), float("nan"), dtype=torch.float32, device=DEV)
     wdsc = unet._conv_desc(B, H, H, cip, ho, ho, cop, 9, kw["stride"], kw["pad"], kw["up"], 0)
+    nsl = L.sfron_conv_wgrad_splits(ctypes.byref(wdsc))
+    dwg = torch.full((nsl * cop * 9 * cip,), float("nan"), dtype=torch.float32, device=DEV)
     check(L.sfron_conv_wgrad(ctypes.byref(wdsc), ptr(dyb), cop, ptr(xr), ptr(dwg), stream_ptr()), "conv_wgrad")
     dw = torch.empty(co, ci, 3, 3, dtype=torch.float32, device=DEV)
-    check(L.sfron_conv_wgrad_scatter(ptr(dwg), co, ci, 9, cip, ptr(dw), stream_ptr()), "scatter")
+    check(L.sfron_conv_wgrad_scatter(ptr(dwg), co, ci, 9, cip, nsl, cop * 9 * cip, ptr(dw), stream_ptr()), "scatter")
     np.testing.assert_allclose(dw.cpu().numpy(), wt.grad.numpy(), rtol=3e-4, atol=3e-4 * math.sqrt(rows))
     if wd is None:
         return

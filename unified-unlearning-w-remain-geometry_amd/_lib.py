@@ -95,7 +95,8 @@ class BGemmDesc(ctypes.Structure):
                 ("stride_a", ctypes.c_long), ("stride_b", ctypes.c_long), ("stride_c", ctypes.c_long), ("batch2", c_int),
                 ("stride_a2", ctypes.c_long), ("stride_b2", ctypes.c_long), ("stride_c2", ctypes.c_long), ("alpha", c_float),
                 ("bias", c_void_p), ("c_bf16", c_void_p), ("c_f32", c_void_p), ("ldc", c_int), ("resid", c_void_p),
-                ("sample_vec", c_void_p), ("ld_vec", c_int), ("rows_per_sample", c_int), ("accumulate", c_int)]
+                ("sample_vec", c_void_p), ("ld_vec", c_int), ("rows_per_sample", c_int), ("accumulate", c_int),
+                ("split_ws", c_void_p), ("split_ws_slabs", c_int)]
 
 
 class ConvDesc(ctypes.Structure):
@@ -111,7 +112,8 @@ _PROTOS.update({
     "sfron_conv_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _S]),
     "sfron_conv_wgrad": (c_int, [POINTER(ConvDesc), _P, c_int, _P, _P, _S]),
     "sfron_conv_wprep": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _S]),
-    "sfron_conv_wgrad_scatter": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),
+    "sfron_conv_wgrad_splits": (c_int, [POINTER(ConvDesc)]),
+    "sfron_conv_wgrad_scatter": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int64, _P, _S]),
     "sfron_nchw_to_rows_bf16": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),
     "sfron_nchw_to_rows_f32": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),
     "sfron_rows_to_nchw": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),

@@ -46,6 +46,8 @@ struct BGemmArgs {
   int ldvec, T;
   float alpha;
   int accumulate;
+  int kchunk;             // split-K (weight gradients: few output tiles, a contraction over all pixels): grid.y = split, split s
+                          // takes k in [s * kchunk, (s + 1) * kchunk) and writes its own fp32 slab Cf + s * sC (0 = no split)
   ConvGeom cg;
 };
 
@@ -194,7 +196,10 @@ __global__ __launch_bounds__(NT) void k_bgemm(BGemmArgs g) {
   const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
   const int m0 = tm * BM, n0 = tn * BN;
   const long bz = blockIdx.y, bi = blockIdx.z;
-  g.A += bz * g.sA + bi * g.sA2; g.B += bz * g.sB + bi * g.sB2;
+  int kbeg = 0, kend = g.K;
+  if (g.kchunk > 0) { kbeg = (int)bz * g.kchunk; kend = min(g.K, kbeg + g.kchunk); }
+  else { g.A += bz * g.sA; g.B += bz * g.sB; }
+  g.A += bi * g.sA2; g.B += bi * g.sB2;
   const long co = bz * g.sC + bi * g.sC2;
   if (g.Cb) g.Cb += co;
   if (g.Cf) g.Cf += co;
@@ -211,10 +216,10 @@ __global__ __launch_bounds__(NT) void k_bgemm(BGemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (g.K + BK - 1) / BK;
+  const int nk = (kend - kbeg + BK - 1) / BK;
   uint4 ra[4], rb[4];
-  stA.load(ra, 0, g.K, g.cg);
-  stB.load(rb, 0, g.K, g.cg);
+  stA.load(ra, kbeg, kend, g.cg);
+  stB.load(rb, kbeg, kend, g.cg);
   stA.store(sA, ra);
   stB.store(sB, rb);
   __syncthreads();
@@ -222,8 +227,8 @@ __global__ __launch_bounds__(NT) void k_bgemm(BGemmArgs g) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nk;
     if (more) {
-      stA.load(ra, (kt + 1) * BK, g.K, g.cg);
-      stB.load(rb, (kt + 1) * BK, g.K, g.cg);
+      stA.load(ra, kbeg + (kt + 1) * BK, kend, g.cg);
+      stB.load(rb, kbeg + (kt + 1) * BK, kend, g.cg);
     }
     const __bf16* iA = sA + cur * TILE_ELEMS;
     const __bf16* iB = sB + cur * TILE_ELEMS;
@@ -301,13 +306,16 @@ __global__ __launch_bounds__(TPB) void k_conv_wprep(const float* __restrict__ w,
     }
   }
 }
-// weight gradient fp32 [Co_p][taps][Ci_p] (GEMM output) -> OIHW gradient (overwrite)
-__global__ __launch_bounds__(TPB) void k_conv_wgrad_scatter(const float* __restrict__ g, int Co, int Ci, int taps, int Ci_p,
-                                                            float* __restrict__ dw) {
+// weight gradient fp32 [nslab][Co_p][taps][Ci_p] (GEMM output, split-K slabs) -> OIHW gradient (overwrite; slabs added in order)
+__global__ __launch_bounds__(TPB) void k_conv_wgrad_scatter(const float* __restrict__ g, int Co, int Ci, int taps, int Ci_p, int nslab,
+                                                            int64_t slab_stride, float* __restrict__ dw) {
   const int64_t n = (int64_t)Co * Ci * taps;
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
     const int t = (int)(i % taps); const int ci = (int)((i / taps) % Ci); const int co = (int)(i / ((int64_t)taps * Ci));
-    dw[i] = g[((int64_t)co * taps + t) * Ci_p + ci];
+    const float* p = g + ((int64_t)co * taps + t) * Ci_p + ci;
+    float a = 0.f;
+    for (int sl = 0; sl < nslab; ++sl) a += p[sl * slab_stride];
+    dw[i] = a;
   }
 }
 
@@ -632,6 +640,16 @@ __global__ __launch_bounds__(TPB) void k_class_embed_bwd(const float* __restrict
   d_null[j] = nul;
 }
 
+// splits of the contraction for a weight-gradient GEMM: enough workgroups for the chip (about two rounds of 256 CUs), at least
+// 512 contraction rows per split, at most `cap`
+inline int plan_splits(int M, int N, int K, int cap) {
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  int s = 512 / (tiles > 0 ? tiles : 1);
+  if (s > K / 512) s = K / 512;
+  if (s > cap) s = cap;
+  return s < 1 ? 1 : s;
+}
+
 template <bool A_TR, bool B_TR, int EPI, int CONV>
 int launch_bgemm(const BGemmArgs& g, int nbatch, hipStream_t s, int ninner = 1) {
   const size_t lds = 4 * TILE_ELEMS * sizeof(__bf16);
@@ -669,8 +687,21 @@ int sfron_bgemm_bf16(const sfron_bgemm_desc* d, void* stream) {
     return bf ? launch_bgemm<false, false, EPI_BF16, CONV_NONE>(g, d->batch, s, ni) : launch_bgemm<false, false, EPI_RES, CONV_NONE>(g, d->batch, s, ni);
   if (!d->a_transposed && d->b_transposed)
     return bf ? launch_bgemm<false, true, EPI_BF16, CONV_NONE>(g, d->batch, s, ni) : launch_bgemm<false, true, EPI_RES, CONV_NONE>(g, d->batch, s, ni);
-  if (d->a_transposed && d->b_transposed)
+  if (d->a_transposed && d->b_transposed) {
+    // a plain weight gradient (fp32 [M][N] contiguous, contraction over all rows): split-K through the caller's slab scratch
+    if (!bf && d->split_ws && d->batch == 1 && ni == 1 && d->ldc == d->N && !d->bias && !d->resid && !d->sample_vec && !d->accumulate) {
+      const int sp = plan_splits(d->M, d->N, d->K, d->split_ws_slabs);
+      if (sp > 1) {
+        g.kchunk = ((g.K + sp - 1) / sp + BK - 1) / BK * BK;
+        const int used = (g.K + g.kchunk - 1) / g.kchunk;
+        g.Cf = d->split_ws; g.sC = (long)d->M * d->N;
+        const int rc = launch_bgemm<true, true, EPI_RES, CONV_NONE>(g, used, s, 1);
+        if (rc) return rc;
+        return sfron_reduce_chunks(d->split_ws, 1, used, d->M * d->N, d->c_f32, d->M * d->N, 0, stream);
+      }
+    }
     return bf ? launch_bgemm<true, true, EPI_BF16, CONV_NONE>(g, d->batch, s, ni) : launch_bgemm<true, true, EPI_RES, CONV_NONE>(g, d->batch, s, ni);
+  }
   return SFRON_ERR_UNSUPPORTED;
 }
 
@@ -700,6 +731,10 @@ int sfron_conv_fwd(const sfron_conv_desc* d, const uint16_t* src, const uint16_t
 }
 
 /* weight gradient: dw[n][tap][c] = sum_p dy[p][n] src[src(p, tap)][c]  (fp32 [n_out][taps * c_src], then k_conv_wgrad_scatter) */
+int sfron_conv_wgrad_splits(const sfron_conv_desc* d) {
+  if (!d) return 0;
+  return plan_splits(d->n_out, d->taps * d->c_src, d->batch * d->h_out * d->w_out, 64);
+}
 int sfron_conv_wgrad(const sfron_conv_desc* d, const uint16_t* dy, int ld_dy, const uint16_t* src, float* dw_gemm, void* stream) {
   SFRON_CHECK_ARG(d && dy && src && dw_gemm && d->n_out % 8 == 0 && ld_dy % 8 == 0);
   BGemmArgs g{};
@@ -708,7 +743,17 @@ int sfron_conv_wgrad(const sfron_conv_desc* d, const uint16_t* dy, int ld_dy, co
   g.M = d->n_out; g.N = d->taps * d->c_src; g.K = d->batch * d->h_out * d->w_out;
   g.lda = ld_dy; g.ldb = d->c_src;
   g.Cf = dw_gemm; g.ldcf = g.N; g.alpha = 1.0f; g.T = 1;
-  return launch_bgemm<true, true, EPI_RES, CONV_B>(g, 1, (hipStream_t)stream);
+  // the contraction runs over every pixel of the batch and the output has few 128x128 tiles: split it; slab s of dw_gemm
+  // ([splits][n_out][taps * c_src]) receives split s, sfron_conv_wgrad_scatter adds the slabs in order
+  const int sp = sfron_conv_wgrad_splits(d);
+  if (sp > 1) { g.kchunk = ((g.K + sp - 1) / sp + BK - 1) / BK * BK; g.sC = (long)g.M * g.N; }
+  const int used = sp > 1 ? (g.K + g.kchunk - 1) / g.kchunk : 1;
+  rc = launch_bgemm<true, true, EPI_RES, CONV_B>(g, used, (hipStream_t)stream);
+  if (rc) return rc;
+  // slabs the rounding left without rows are zeroed so that the scatter can always add `sfron_conv_wgrad_splits` of them
+  for (int sidx = used; sidx < sp; ++sidx)
+    if (hipMemsetAsync(dw_gemm + (size_t)sidx * g.M * g.N, 0, (size_t)g.M * g.N * sizeof(float), (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
+  return SFRON_OK;
 }
 
 int sfron_conv_wprep(const float* w_oihw, int c_out, int c_in, int taps, int c_out_p, int c_in_p, uint16_t* w_fwd, uint16_t* w_dgrad,
@@ -720,10 +765,11 @@ int sfron_conv_wprep(const float* w_oihw, int c_out, int c_in, int taps, int c_o
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }
-int sfron_conv_wgrad_scatter(const float* dw_gemm, int c_out, int c_in, int taps, int c_in_p, float* dw_oihw, void* stream) {
-  SFRON_CHECK_ARG(dw_gemm && dw_oihw);
+int sfron_conv_wgrad_scatter(const float* dw_gemm, int c_out, int c_in, int taps, int c_in_p, int n_slabs, int64_t slab_stride,
+                             float* dw_oihw, void* stream) {
+  SFRON_CHECK_ARG(dw_gemm && dw_oihw && n_slabs >= 1);
   hipLaunchKernelGGL(k_conv_wgrad_scatter, dim3(grid_for((int64_t)c_out * c_in * taps)), dim3(TPB), 0, (hipStream_t)stream, dw_gemm,
-                     c_out, c_in, taps, c_in_p, dw_oihw);
+                     c_out, c_in, taps, c_in_p, n_slabs, slab_stride, dw_oihw);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

@@ -70,7 +70,27 @@ def bgemm(A, B, M, N, K, *, lda, ldb, a_t=False, b_t=False, batch=1, sa=0, sb=0,
     d.bias = _addr(bias)
     d.c_bf16, d.c_f32, d.ldc = _addr(c_bf16), _addr(c_f32), ldc
     d.resid, d.sample_vec, d.ld_vec, d.rows_per_sample, d.accumulate = _addr(resid), _addr(vec), ld_vec, rows_per_sample, int(accumulate)
+    if a_t and b_t and c_f32 is not None and batch == 1 and batch2 == 1 and ldc == N and K >= 2048:
+        ws = _split_scratch(M * N, A if not isinstance(A, int) else (B if not isinstance(B, int) else None))
+        if ws is not None:
+            d.split_ws, d.split_ws_slabs = ws.data_ptr(), ws.numel() // (M * N)
     check(_L().sfron_bgemm_bf16(ctypes.byref(d), stream_ptr()), "bgemm_bf16")
+
+
+_SPLIT_WS = {}
+
+
+def _split_scratch(mn, like):
+    """fp32 slab scratch for split-K weight gradients (one per device, grown on demand; launches are stream-ordered)."""
+    if like is None:
+        return None
+    dev = like.device
+    want = min(64, max(2, (64 << 20) // (4 * mn))) * mn
+    ws = _SPLIT_WS.get(dev)
+    if ws is None or ws.numel() < want:
+        ws = torch.empty(want, dtype=torch.float32, device=dev)
+        _SPLIT_WS[dev] = ws
+    return ws
 
 
 def _addr(t):
@@ -248,8 +268,12 @@ class _TapeNet(nn.Module):
                 colsum_f32(d_out, rows, v["cop"], v["cop"], bg, self._cs)
                 self.view(self.grads, name + ".bias").copy_(bg[:v["co"]])
             wd = _conv_desc(B, hs, ws, v["cip"], ho, wo, v["cop"], 9, stride, pad, up, 0)
+            nsl = _L().sfron_conv_wgrad_splits(ctypes.byref(wd))
+            slab = v["cop"] * 9 * v["cip"]
+            if self._dw.numel() < nsl * slab:
+                self._dw = torch.empty(nsl * slab, dtype=torch.float32, device=dev)
             check(_L().sfron_conv_wgrad(ctypes.byref(wd), ptr(dyb), v["cop"], ptr(src), ptr(self._dw), stream_ptr()), "conv_wgrad")
-            check(_L().sfron_conv_wgrad_scatter(ptr(self._dw), v["co"], v["ci"], 9, v["cip"], self._g(name + ".weight"), stream_ptr()),
+            check(_L().sfron_conv_wgrad_scatter(ptr(self._dw), v["co"], v["ci"], 9, v["cip"], nsl, slab, self._g(name + ".weight"), stream_ptr()),
                   "conv_wgrad_scatter")
             if not want_dsrc or v["dgr"] is None:
                 return None
