@@ -133,7 +133,8 @@ def test_conditioning_and_layout():
     close(ops.unpatchify(r2.float(), 2, 8, 8, 8, 2), im8.to(torch.bfloat16).float(), 0, 0)
 
 
-@pytest.mark.parametrize("B,T,H,hd", [(2, 64, 2, 64), (1, 128, 3, 72), (2, 256, 2, 72), (1, 256, 4, 64), (1, 192, 1, 64)])
+@pytest.mark.parametrize("B,T,H,hd", [(2, 64, 2, 64), (1, 128, 3, 72), (2, 256, 2, 72), (1, 256, 4, 64), (1, 192, 1, 64),
+                                      (1, 1024, 8, 40), (2, 256, 4, 80), (1, 320, 2, 40), (1, 128, 2, 48)])
 def test_attention_fwd_bwd(B, T, H, hd):
     from sfron import ops
     gen = torch.Generator().manual_seed(T + H + hd)

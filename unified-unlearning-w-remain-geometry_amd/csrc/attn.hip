@@ -970,8 +970,11 @@ int sfron_attn_fwd(const uint16_t* qkv, uint16_t* o, float* lse, int B, int T, i
   SFRON_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)o) & 15) == 0);
   const float scale = 1.0f / sqrtf((float)hd);
   hipStream_t s = (hipStream_t)stream;
-  if (hd == 64) return launch_fwd<64, 2, 4>((const __bf16*)qkv, (__bf16*)o, lse, B, T, H, hd, scale, s);
-  if (hd == 72) return launch_fwd<96, 3, 5>((const __bf16*)qkv, (__bf16*)o, lse, B, T, H, hd, scale, s);
+  // any head_dim that is a multiple of 8 up to 96 runs on the 64- or 96-column images (columns beyond head_dim are zero padding):
+  // DiT 64 / 72, the LDM UNet's 40 and 80
+  if (hd % 8 != 0 || hd < 8) return SFRON_ERR_UNSUPPORTED;
+  if (hd <= 64) return launch_fwd<64, 2, 4>((const __bf16*)qkv, (__bf16*)o, lse, B, T, H, hd, scale, s);
+  if (hd <= 96) return launch_fwd<96, 3, 5>((const __bf16*)qkv, (__bf16*)o, lse, B, T, H, hd, scale, s);
   return SFRON_ERR_UNSUPPORTED;
 }
 
@@ -984,9 +987,10 @@ int sfron_attn_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, 
   SFRON_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dqkv) & 15) == 0);
   const float scale = 1.0f / sqrtf((float)hd);
   hipStream_t s = (hipStream_t)stream;
-  if (hd == 64)
+  if (hd % 8 != 0 || hd < 8) return SFRON_ERR_UNSUPPORTED;
+  if (hd <= 64)
     return launch_bwd<64, 2, 4>((const __bf16*)qkv, (const __bf16*)o, (const __bf16*)d_o, lse, delta_scratch, (__bf16*)dqkv, B, T, H, hd, scale, s);
-  if (hd == 72)
+  if (hd <= 96)
     return launch_bwd<96, 3, 5>((const __bf16*)qkv, (const __bf16*)o, (const __bf16*)d_o, lse, delta_scratch, (__bf16*)dqkv, B, T, H, hd, scale, s);
   return SFRON_ERR_UNSUPPORTED;
 }

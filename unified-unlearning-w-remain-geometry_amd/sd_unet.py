@@ -213,6 +213,21 @@ class UNetModel(_TapeNet):
                       sb2=d, sc2=d, c_bf16=dv, ldc=ldv)
         return O, bwd
 
+    def _flash_self_attention(self, qkv, B, N, C):
+        """Self-attention through the fused flash-style kernels of csrc/attn.hip (qkv [B*N][3C], column = which * C + head * d + i)."""
+        h = self.heads
+        d = C // h
+        dev = self.device_
+        O = torch.empty(B * N, C, dtype=torch.bfloat16, device=dev)
+        lse = torch.empty(B * h * N, dtype=torch.float32, device=dev)
+        check(_L().sfron_attn_fwd(ptr(qkv), ptr(O), ptr(lse), B, N, h, d, stream_ptr()), "attn_fwd")
+
+        def bwd(dO, dq, dk, dv):
+            # the kernel writes the whole dqkv matrix: dq is its base address (dk = dq + C, dv = dq + 2C by construction)
+            delta = torch.empty(B * h * N, dtype=torch.float32, device=dev)
+            check(_L().sfron_attn_bwd(ptr(qkv), ptr(O), ptr(dO), ptr(lse), ptr(delta), dq, B, N, h, d, stream_ptr()), "attn_bwd")
+        return O, bwd
+
     def _transformer(self, tape, name, x, ctx, Lp, Lv):
         """SpatialTransformer with one BasicTransformerBlock; ctx bf16 [B*Lp][ctx_dim] (rows >= Lv are zero)."""
         dev, B, C, N = self.device_, x.B, x.C, x.H * x.W
@@ -225,7 +240,10 @@ class UNetModel(_TapeNet):
         qkv = torch.empty(rows, 3 * C, dtype=torch.bfloat16, device=dev)
         wqkv = self._w(t + ".attn1.to_q.weight")
         bgemm(n1, wqkv, rows, 3 * C, C, lda=C, ldb=C, c_bf16=qkv, ldc=3 * C)
-        O1, att1_b = self._mha(qkv.data_ptr(), 3 * C, qkv.data_ptr() + 2 * C, 3 * C, qkv.data_ptr() + 4 * C, 3 * C, B, N, N, N, C, keep=(qkv,))
+        if (C // self.heads) <= 96 and (C // self.heads) % 8 == 0 and N % 64 == 0:
+            O1, att1_b = self._flash_self_attention(qkv, B, N, C)       # scores never leave the chip (4096 tokens at 64x64)
+        else:
+            O1, att1_b = self._mha(qkv.data_ptr(), 3 * C, qkv.data_ptr() + 2 * C, 3 * C, qkv.data_ptr() + 4 * C, 3 * C, B, N, N, N, C, keep=(qkv,))
         x1_t, o1_b = self._linear(O1, rows, t + ".attn1.to_out.0", C, C, resid=X0.t)
         X1 = Act(x1_t, B, x.H, x.W, C)
         # ---- cross-attention: keys / values from the context
