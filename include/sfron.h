@@ -213,6 +213,8 @@ typedef struct sfron_conv_desc {
   int ld_vec;
   uint16_t* out_bf16; float* out_f32; int ld_out;
   int accumulate;
+  float* split_ws; int split_ws_slabs;   /* optional fp32 scratch [split_ws_slabs][rows * n_out]: a forward / input-gradient conv with few
+                                       output tiles and a deep contraction then splits the contraction over the chip */
 } sfron_conv_desc;
 /* out[p][n] = sum_{tap, c} src[src(p, tap)][c] * w[n][tap][c]; w bf16 [n_out][taps][c_src] (sfron_conv_wprep's "fwd" layout;
  * the input gradient calls this on dY with the "dgrad" layout) */

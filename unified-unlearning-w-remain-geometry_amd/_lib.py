@@ -104,7 +104,8 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [("batch", c_int), ("h_src", c_int), ("w_src", c_int), ("c_src", c_int), ("h_out", c_int), ("w_out", c_int),
                 ("n_out", c_int), ("taps", c_int), ("stride", c_int), ("pad", c_int), ("upsample", c_int), ("dilate", c_int),
                 ("bias", c_void_p), ("resid", c_void_p), ("sample_vec", c_void_p), ("ld_vec", c_int),
-                ("out_bf16", c_void_p), ("out_f32", c_void_p), ("ld_out", c_int), ("accumulate", c_int)]
+                ("out_bf16", c_void_p), ("out_f32", c_void_p), ("ld_out", c_int), ("accumulate", c_int),
+                ("split_ws", c_void_p), ("split_ws_slabs", c_int)]
 
 
 _PROTOS.update({

@@ -556,16 +556,43 @@ __global__ __launch_bounds__(TPB) void k_geglu_bwd(const float* __restrict__ d_o
   }
 }
 
+// split-K finish: out[row][col] = sum_s slab[s][row][col] (+ bias) (+ per-sample vector) (+ resid), bf16 or fp32 -- the epilogue of
+// k_bgemm applied after the slabs of a split contraction are added in order
+__global__ __launch_bounds__(TPB) void k_split_finish(const float* __restrict__ slabs, int nsl, int64_t slab_stride, int M, int N,
+                                                      const float* __restrict__ bias, const float* __restrict__ vec, int ldvec, int T,
+                                                      const float* __restrict__ resid, float* __restrict__ of, __bf16* __restrict__ ob, int ldo) {
+  const int64_t n = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    const int col = (int)(i % N); const int64_t row = i / N;
+    float a = 0.f;
+    for (int sl = 0; sl < nsl; ++sl) a += slabs[sl * slab_stride + i];
+    if (bias) a += bias[col];
+    if (vec) a += vec[(row / T) * ldvec + col];
+    if (resid) a += resid[row * ldo + col];
+    if (of) of[row * ldo + col] = a; else ob[row * ldo + col] = f2bf(a);
+  }
+}
+
 // ---- small pieces
 // out[b][c] = sum_{p < HW} x[(b * HW + p) * ld + c]  (per-sample column sums: gradient of a per-sample broadcast vector)
+// one workgroup per (64-column slice, sample): the 4 waves stride over the rows (coalesced 256-B row reads), partial sums meet in LDS
+// in a fixed order
 __global__ __launch_bounds__(TPB) void k_sample_colsum(const float* __restrict__ x, int ld, int HW, int C, float* __restrict__ out, int ldo) {
-  const int b = blockIdx.y;
-  const int c = blockIdx.x * TPB + threadIdx.x;
-  if (c >= C) return;
-  const float* xb = x + (size_t)b * HW * ld + c;
+  __shared__ float sh[TPB / 64][64];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int p = 0; p < HW; ++p) s += xb[(size_t)p * ld];
-  out[(size_t)b * ldo + c] = s;
+  if (c < C) {
+    const float* xb = x + (size_t)b * HW * ld + c;
+    for (int p = wave; p < HW; p += TPB / 64) s += xb[(size_t)p * ld];
+  }
+  sh[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < C) {
+    float a = 0.f;
+    for (int w = 0; w < TPB / 64; ++w) a += sh[w][lane];
+    out[(size_t)b * ldo + c] = a;
+  }
 }
 // out = alpha * a + beta * b   (classifier-free guidance mix (1 + s) cond - s null, models/diffusion.py:340-357)
 __global__ __launch_bounds__(TPB) void k_axpby(const float* __restrict__ a, const float* __restrict__ b, float alpha, float beta, int64_t n,
@@ -726,6 +753,27 @@ int sfron_conv_fwd(const sfron_conv_desc* d, const uint16_t* src, const uint16_t
   SFRON_CHECK_ARG((g.Cb != nullptr) != (g.Cf != nullptr) && d->ld_out % 4 == 0 && d->ld_out >= d->n_out);
   g.bias = d->bias; g.resid = d->resid; g.vec = d->sample_vec; g.ldvec = d->ld_vec; g.T = d->h_out * d->w_out;
   g.alpha = 1.0f; g.accumulate = d->accumulate;
+  // few output pixels, deep contraction (the 16x16 / 8x8 levels of the LDM UNet: 512 x 1280 outputs over K = 11520..23040): split the
+  // contraction over the chip into fp32 slabs, then one pass adds them and applies the epilogue
+  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  if (d->split_ws && !d->accumulate && tiles < 128 && g.K >= 2048) {
+    int sp = 384 / tiles;
+    if (sp > g.K / 512) sp = g.K / 512;
+    if (sp > d->split_ws_slabs) sp = d->split_ws_slabs;
+    if (sp > 1) {
+      BGemmArgs q = g;
+      q.kchunk = ((g.K + sp - 1) / sp + BK - 1) / BK * BK;
+      const int used = (g.K + q.kchunk - 1) / q.kchunk;
+      q.Cb = nullptr; q.Cf = d->split_ws; q.ldcf = g.N; q.sC = (long)g.M * g.N;
+      q.bias = nullptr; q.resid = nullptr; q.vec = nullptr;
+      rc = launch_bgemm<false, false, EPI_RES, CONV_A>(q, used, (hipStream_t)stream);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_split_finish, dim3(grid_for((int64_t)g.M * g.N)), dim3(TPB), 0, (hipStream_t)stream, d->split_ws, used, (int64_t)g.M * g.N,
+                         g.M, g.N, g.bias, g.vec, g.ldvec, g.T, g.resid, g.Cf, g.Cb, d->ld_out);
+      SFRON_LAUNCH_STATUS();
+      return SFRON_OK;
+    }
+  }
   return g.Cb ? launch_bgemm<false, false, EPI_BF16, CONV_A>(g, 1, (hipStream_t)stream)
               : launch_bgemm<false, false, EPI_RES, CONV_A>(g, 1, (hipStream_t)stream);
 }
@@ -865,7 +913,7 @@ int sfron_axpby(const float* a, const float* b, float alpha, float beta, int64_t
 }
 int sfron_sample_colsum(const float* x, int ld, int B, int HW, int C, float* out, int ld_out, void* stream) {
   SFRON_CHECK_ARG(x && out && ld_out >= C);
-  hipLaunchKernelGGL(k_sample_colsum, dim3((C + TPB - 1) / TPB, B), dim3(TPB), 0, (hipStream_t)stream, x, ld, HW, C, out, ld_out);
+  hipLaunchKernelGGL(k_sample_colsum, dim3((C + 63) / 64, B), dim3(TPB), 0, (hipStream_t)stream, x, ld, HW, C, out, ld_out);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

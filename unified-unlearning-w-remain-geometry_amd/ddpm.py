@@ -249,6 +249,11 @@ class DDPMSFRon:
             return adaptive_loss(fn, *args, lambd=self.lambd, dp_group=pg)
         return fn(*args, dp_group=pg)
 
+    def _weights_updated(self):
+        if hasattr(self.model, "weights_updated"):                # native U-Net: re-lay the bf16 conv operands once per Adam step
+            self.model.auto_prep = False
+            self.model.weights_updated()
+
     def _backward(self, loss):
         self.flat.g.zero_()                                       # optimizer.zero_grad()
         loss.backward()
@@ -264,9 +269,11 @@ class DDPMSFRon:
             ori_forget = -self._loss(forget, "adaga" if self.unlearn_loss == "adaga" else "simple")
         self._backward(alpha * ori_forget)
         self.opt.step(max_norm=self.grad_clip, use_mask=True)
+        self._weights_updated()
         ori_remain = self._loss(remain, "simple")
         self._backward(self.remain_alpha * ori_remain)
         self.opt.step(max_norm=self.grad_clip, use_mask=False, ema=self.shadow, ema_decay=self.mu if self.mu is not None else 0.0, ema_mode=2)
+        self._weights_updated()
         return {"forget_loss": ori_forget.detach(), "remain_loss": ori_remain.detach(), "alpha": alpha}
 
     def ema_state_dict(self):

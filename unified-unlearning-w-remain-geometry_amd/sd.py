@@ -73,6 +73,7 @@ class SDSFRon:
                 fm[off:off + n] &= m.reshape(-1).to(device=p.device, dtype=torch.uint8)
             self.forget_mask = fm
         self.opt = sweep.FlatAdam(p, g, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adamw=True, mask=self.train_mask, w_bf16=w16)
+        unet.auto_prep = False                      # this loop tells the model when its weights changed
 
     def _backward(self, out, target, scale):
         """d(scale * mean((out - target)^2)) / d out through the HIP loss kernels, then the UNet's backward pass."""
@@ -103,9 +104,11 @@ class SDSFRon:
         self._backward(f_out, p_out, self.fa)
         self.opt.mask = self.forget_mask
         self.opt.step(max_norm=None, use_mask=True)                       # nsfw_removal.py:162 (no clipping)
+        u.weights_updated()
         r_out = u(s.q_sample(remain["x"], remain["t"], remain["noise"]), remain["t"], context=remain["c"])
         ori_remain = self._mse(r_out, remain["noise"])
         self._backward(r_out, remain["noise"], self.ra)
         self.opt.mask = self.train_mask
         self.opt.step(max_norm=None, use_mask=True)                       # :170
+        u.weights_updated()
         return {"forget_loss": ori_forget, "remain_loss": ori_remain}

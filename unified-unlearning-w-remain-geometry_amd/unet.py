@@ -110,6 +110,11 @@ def _conv_desc(B, hs, ws, cs, ho, wo, n_out, taps=9, stride=1, pad=1, up=0, dil=
     d.taps, d.stride, d.pad, d.upsample, d.dilate = taps, stride, pad, up, dil
     d.bias, d.resid, d.sample_vec, d.ld_vec = _addr(bias), _addr(resid), _addr(vec), ld_vec
     d.out_bf16, d.out_f32, d.ld_out, d.accumulate = _addr(out_bf16), _addr(out_f32), ld_out or 0, int(accumulate)
+    rows, t = B * ho * wo, out_f32 if out_f32 is not None else out_bf16
+    if t is not None and not isinstance(t, int) and rows * n_out <= (1 << 21) and taps * cs >= 2048 and ld_out == n_out:
+        ws = _split_scratch(rows * n_out, t)                 # few output tiles, deep contraction: split-K slabs
+        d.split_ws, d.split_ws_slabs = ws.data_ptr(), ws.numel() // (rows * n_out)
+        d._keep = ws
     return d
 
 
@@ -192,6 +197,7 @@ class _TapeNet(nn.Module):
 
     def sync_bf16(self):
         check(_L().sfron_cast_bf16(ptr(self.params), ptr(self.params_bf16), self.n_total, stream_ptr()), "cast_bf16")
+        self._conv_dirty = True
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         if state_dict and all(k.startswith("module.") for k in state_dict):      # DataParallel checkpoints (runners :1055-1061)
@@ -216,7 +222,18 @@ class _TapeNet(nn.Module):
         off, _ = self.index[name]
         return self.grads.data_ptr() + 4 * off
 
+    def weights_updated(self):
+        """Tell the model its fp32 arena changed (an optimizer step): the bf16 operands of the 3x3 convolutions are re-laid before
+        the next pass.  With ``auto_prep`` (default) every pass re-lays them anyway; the SFR-on loops turn that off and call this
+        after each Adam step, so the two forward passes of a forget stage share one re-layout."""
+        self._conv_dirty = True
+
+    auto_prep = True
+
     def _prep_conv_weights(self):
+        if not self.auto_prep and not getattr(self, "_conv_dirty", True):
+            return
+        self._conv_dirty = False
         for base, v in self.conv3.items():
             check(_L().sfron_conv_wprep(self._p(base + ".weight"), v["co"], v["ci"], 9, v["cop"], v["cip"], ptr(v["fwd"]),
                                         ptr(v["dgr"]) if v["dgr"] is not None else None, stream_ptr()), "conv_wprep")
