@@ -150,7 +150,7 @@ def main():
         runner.step(*batches[i % pool])
     eng = model.engine
     eng.probe_enable(2 * args.steps + 4)
-    eng.wgrad_probe_enable(16 * args.steps + 16)
+    eng.wgrad_probe_enable(32 * args.steps + 32)
     runner.opt.timed = []                       # (start, end) event pairs around every k_masked_clip_adam launch
     sync()
     t0 = time.perf_counter()
@@ -179,9 +179,10 @@ def main():
     step_flops = 6.0 * fwd_per_sample * args.batch
     ms_per_step = elapsed / args.steps * 1e3
 
-    # dominant kernel by GPU time: the qkv / fc1 weight gradient (+ bias row sums): dW[N][D] = dY[M][N]^T X[M][D], N = 3D and F
-    # alternate, so the mean launch does (3D + F) * D * M * 2 / 2 ... FLOP
-    wg_flops = 0.5 * (2.0 * M * 3 * D * D + 2.0 * M * F * D)
+    # dominant kernel by GPU time (profiles/r02_kernel_table.md): the weight-gradient GEMM k_gemm_pipe<4,2,3,6,true,true,1,2,2>, one
+    # kernel name for the four shapes dW = dY^T X of a block (qkv 65.2, proj 21.7, fc1 87.0, fc2 87.0 GFLOP): the probe brackets all
+    # four, so the mean launch does their mean
+    wg_flops = 0.25 * (2.0 * M * 3 * D * D + 2.0 * M * D * D + 2 * 2.0 * M * F * D)
     wg_ms = wp_ms / max(1, n_wp)
     wg_ach = wg_flops / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0
     # parameter sweep: bytes per launch = 31 B/param (forget stage: g, mask, p, m, v in; p, m, v, bf16 out) and 38 B/param
@@ -234,10 +235,10 @@ def main():
             "step_frac_of_bf16_mfma_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
             "dp_overlap": dp_overlap, "check": check_res,
             "roofline": {"bound": "mfma",
-                         "kernel": "k_gemm_pipe<4,2,3,6,true,true,1,2,2,true> = 192x192 tile, three LDS slots, interleaved MFMA/LDS-DMA schedule: weight "
-                                   f"gradient of attn.qkv / mlp.fc1 (dW[N x {D}] = dY[{M} x N]^T X[{M} x {D}], N = {3 * D} and {F} alternating) + bias row "
-                                   "sums; largest share of GPU time (profiles/r02_kernel_table.md); runs on the weight-gradient stream BESIDE the dgrad "
-                                   "chain, so its duration is shared-CU time",
+                         "kernel": "k_gemm_pipe<4,2,3,6,true,true,1,2,2> = 192x192 tile, three LDS slots, interleaved MFMA/LDS-DMA schedule: the weight "
+                                   f"gradients dW = dY^T X of a block (qkv [{3 * D}x{D}], proj [{D}x{D}], fc1 [{F}x{D}], fc2 [{D}x{F}], contraction over "
+                                   f"{M} token rows; mean {wg_flops / 1e9:.1f} GFLOP per launch); largest share of GPU time (profiles/r02_kernel_table.md); "
+                                   "it runs on the weight-gradient stream BESIDE the dgrad chain, so its duration is shared-CU time",
                          "achieved": wg_ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": wg_ach / MFMA_BF16_PEAK_TFLOPS,
                          "traffic": traffic, "flops_per_launch": wg_flops, "avg_launch_ms": wg_ms, "launches_timed": n_wp,
                          "others": {

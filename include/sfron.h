@@ -420,8 +420,8 @@ int sfron_dit_backward_dp(const sfron_dit_cfg* cfg, const float* params, const u
 int sfron_dit_scatter_late_bias(const sfron_dit_cfg* cfg, const float* late_bias, float* grads, void* stream);
 int sfron_aux_create(void** aux /* HOST out */);
 /* attach a probe (sfron_probe_create; NULL detaches): the backward pass then records an event pair on the weight-gradient
- * stream around the qkv / fc1 weight-gradient GEMM (+ bias row sums) of every 9th block -- the kernel that holds the largest
- * share of GPU time -- for bench.py's live roofline figure */
+ * stream around each of the four weight-gradient GEMMs (qkv, proj, fc1, fc2) of every 9th block -- the kernel that holds the
+ * largest share of GPU time -- for bench.py's live roofline figure */
 int sfron_aux_set_probe(void* aux, void* probe);
 int sfron_aux_destroy(void* aux);
 

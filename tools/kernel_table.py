@@ -23,7 +23,7 @@ MFMA_PEAK, HBM_PEAK = 2.5e15, 8.0e12
 # (regex on the kernel name, class label, bound, work per launch [FLOP or bytes], note)
 RULES = [
     (r"k_gemm_pipe<4, 2, 3, 6, true, true, 1, 2, 2, true>", "wgrad qkv/fc1 + bias row sums (192x192, 3 slots)", "mfma", (QKV + FC1) / 2, "mean of qkv 65.2 / fc1 87.0 GFLOP"),
-    (r"k_gemm_pipe<4, 2, 3, 6, true, true, 1, 2, 2(, false)?>", "wgrad proj/fc2 (192x192, 3 slots)", "mfma", None, "set by --wgrad-mix"),
+    (r"k_gemm_pipe<4, 2, 3, 6, true, true, 1, 2, 2(, false)?>", "wgrad qkv/proj/fc1/fc2 (192x192, 3 slots)", "mfma", None, "mean of 65.2 / 21.7 / 87.0 / 87.0 GFLOP"),
     (r"k_gemm_pipe<8, 1, 2, 9, false, true, 0, 2, 3", "dgrad qkv/proj/fc1 -> 1152 wide (256x144)", "mfma", (QKV + PROJ + FC1) / 3, "mean of 65.2 / 21.7 / 87.0"),
     (r"k_gemm_pipe<4, 2, 4, 6, false, true, 4, 1, 2", "dgrad fc2 + GELU' (256x192)", "mfma", FC2, ""),
     (r"k_gemm_pipe<4, 2, 4, 6, false, false, 2, 1, 2", "fwd fc1 + GELU (256x192)", "mfma", FC1, ""),
@@ -47,7 +47,7 @@ RULES = [
 def classify(name, wgrad_plain_flops):
     for rx, label, bound, work, note in RULES:
         if re.search(rx, name):
-            if label.startswith("wgrad proj/fc2"):
+            if label.startswith("wgrad qkv/proj/fc1/fc2"):
                 work = wgrad_plain_flops
             return label, bound, work, note
     return None, None, None, ""
@@ -58,10 +58,10 @@ def main():
     ap.add_argument("csv")
     ap.add_argument("--md")
     ap.add_argument("--json")
-    ap.add_argument("--all-wgrads-one-kernel", action="store_true",
-                    help="round-1 builds: the four weight gradients share one kernel name (mean 65.2 GFLOP)")
+    ap.add_argument("--bsum-build", action="store_true",
+                    help="debug-knob build with the bias row sums inside the qkv / fc1 weight gradients: the plain kernel then runs proj / fc2 only")
     a = ap.parse_args()
-    plain = (QKV + PROJ + FC1 + FC2) / 4 if a.all_wgrads_one_kernel else (PROJ + FC2) / 2
+    plain = (PROJ + FC2) / 2 if a.bsum_build else (QKV + PROJ + FC1 + FC2) / 4
     rows = []
     with open(a.csv, newline="") as f:
         for r in csv.DictReader(f):

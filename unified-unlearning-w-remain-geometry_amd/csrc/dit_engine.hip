@@ -232,7 +232,7 @@ int sfron_aux_destroy(void* aux) {
 
 // ---- probe: HIP event pairs around chosen launches, recorded on the stream the launch goes to, for bench.py's live roofline
 // measurement: the forward pass brackets the fc1 GEMM of block 0; a probe attached to the aux handle (sfron_aux_set_probe)
-// brackets, on the weight-gradient stream, the qkv / fc1 weight-gradient GEMMs (+ bias row sums) of every 9th block
+// brackets, on the weight-gradient stream, the four weight-gradient GEMMs of every 9th block
 struct Probe { hipEvent_t* ev; int cap, used; };
 
 int sfron_aux_set_probe(void* aux, void* probe) {
@@ -394,14 +394,14 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
   bool probe_block = false;
   auto wgrad_side = [&](const void* dY, const void* X, int N, int K, float* dW, float* db = nullptr) -> int {
     sfron_gemm_desc q = wgrad_desc(dY, X, M, N, K, dW);
-    Probe* pr = nullptr;
     if (db) {
       if ((ablate_mask() & 32) && sfron_gemm_rowsum_supported(N, K, M)) {
         q.a_rowsum = db;
         q.rowsum_ws = ax ? w.csum2 : w.csum;            // [K / 192][N] partial rows (<= CSUM_PARTS rows of the widest output)
-        if (ax && ax->probe && probe_block && ax->probe->used < ax->probe->cap) pr = ax->probe;
       } else RUN(sfron_colsum(dY, 1, M, N, N, ax ? w.csum2 : w.csum, CSUM_PARTS, db, side));
     }
+    // roofline probe: an event pair on the weight-gradient stream around the GEMM itself (all four weight gradients of the probed blocks)
+    Probe* pr = (ax && ax->probe && probe_block && ax->probe->used < ax->probe->cap) ? ax->probe : nullptr;
     if (pr) (void)hipEventRecord(pr->ev[2 * pr->used], (hipStream_t)side);
     struct Close { Probe* p; void* s; ~Close() { if (p) { (void)hipEventRecord(p->ev[2 * p->used + 1], (hipStream_t)s); p->used++; } } } close{pr, side};
     // measured: the splits shorten the side stream (proj 175 -> 60 us) but the backward pass is bound by total CU time, and

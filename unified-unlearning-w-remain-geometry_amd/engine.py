@@ -147,7 +147,7 @@ class DitEngine:
         self.probe = h
 
     def wgrad_probe_enable(self, max_samples):
-        """Event pairs around the qkv / fc1 weight-gradient GEMMs (every 9th block) on the weight-gradient stream."""
+        """Event pairs around the four weight-gradient GEMMs of every 9th block, on the weight-gradient stream."""
         h = ctypes.c_void_p()
         check(_lib.lib().sfron_probe_create(int(max_samples), ctypes.byref(h)), "probe_create")
         check(_lib.lib().sfron_aux_set_probe(self.aux, h), "aux_set_probe")
