@@ -298,3 +298,21 @@ class SDSfronOracle:
         (self.ra * ori_remain).backward()
         self.opt.step()
         return {"forget_loss": ori_forget.item(), "remain_loss": ori_remain.item()}
+
+
+def sd_fisher(unet, schedule, batches, c_guidance):
+    """train-scripts/generate_fisher.py:36-79 (and the remain twin :87-128) over resident latents / prompt embeddings:
+    preds = (1 + c) eps(x_t, c_prompt) - c eps(x_t, c_null), loss = -MSELoss(noise, preds), F[name] += grad^2 / len(batches); eval
+    mode (:25).  batches: list of dict(x, c, c_null, t, noise).  Returns name -> fp32 tensor."""
+    unet.eval()
+    fisher = {n: 0 for n, _ in unet.named_parameters()}
+    for b in batches:
+        unet.zero_grad()
+        x_t = schedule.q_sample(b["x"], b["t"], b["noise"])
+        preds = (1 + c_guidance) * unet(x_t, b["t"], context=b["c"]) - c_guidance * unet(x_t, b["t"], context=b["c_null"])
+        (-F.mse_loss(b["noise"], preds)).backward()
+        with torch.no_grad():
+            for n, p in unet.named_parameters():
+                if p.grad is not None:
+                    fisher[n] = fisher[n] + p.grad.detach() ** 2 / len(batches)
+    return fisher

@@ -105,7 +105,8 @@ def test_latent_front_end_sample_kernel_and_loader(tmp_path):
     mom[0, 4:] = 25.0; mom[1, 4:] = -40.0                       # clamp branches
     eps = torch.randn(5, 4, 32, 32, generator=g)
     out = torch.empty(5, 4, 32, 32, device=DEV)
-    check(_lib.lib().sfron_latent_sample(ptr(mom.to(DEV)), ptr(eps.to(DEV)), 5, 4, 1024, 0.18215, ptr(out), stream_ptr()), "latent_sample")
+    mom_d, eps_d = mom.to(DEV), eps.to(DEV)                      # named: the kernel reads them after this statement returns
+    check(_lib.lib().sfron_latent_sample(ptr(mom_d), ptr(eps_d), 5, 4, 1024, 0.18215, ptr(out), stream_ptr()), "latent_sample")
     mean, lv = mom.chunk(2, dim=1)
     want = (mean + torch.exp(0.5 * lv.clamp(-30.0, 20.0)) * eps) * 0.18215
     np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=2e-6, atol=1e-6)

@@ -162,6 +162,42 @@ def test_sd_nsfw_removal_iterations_vs_oracle(method, mask_mode):
     assert same / tot > 0.97 and (num / den) ** 0.5 < 0.3
 
 
+def test_sd_fisher_and_mask_vs_oracle():
+    """SD/train-scripts/generate_fisher.py:36-79: guided two-branch prediction, -MSE, F += g^2 / n; then the saliency mask."""
+    from oracle import sd_ref
+    from sfron import fisher, sd
+    ref, model = _pair(SMALL, seed=21)
+    g = torch.Generator().manual_seed(22)
+    B, S, Lc, n = 3, 8, 6, 3
+    c, c0 = torch.randn(1, Lc, 24, generator=g).expand(B, -1, -1).contiguous(), torch.randn(1, Lc, 24, generator=g).expand(B, -1, -1).contiguous()
+    batches = [dict(x=torch.randn(B, 4, S, S, generator=g), c=c, c_null=c0, t=torch.randint(0, 1000, (B,), generator=g),
+                    noise=torch.randn(B, 4, S, S, generator=g)) for _ in range(n)]
+    want = sd_ref.sd_fisher(ref, sd_ref.LDMSchedule(), batches, c_guidance=7.5)
+    acc = fisher.SDFisherAccumulator(model, sd.LDMSchedule(device=DEV), n_batches=n, c_guidance=7.5)
+    for b in batches:
+        loss = acc.accumulate({k: v.to(DEV) for k, v in b.items()})
+    assert torch.isfinite(loss) and loss.item() < 0
+    got = acc.state_dict()
+    assert list(got.keys()) == [k for k, _ in ref.named_parameters()]
+    num = den = 0.0
+    tot_ref = sum(float(v.sum()) for v in want.values())
+    for k, w in want.items():
+        a = got[k]
+        assert a.shape == w.shape and torch.isfinite(a).all() and (a >= 0).all(), k
+        num += (a - w).double().pow(2).sum().item(); den += w.double().pow(2).sum().item()
+        if float(w.sum()) > 1e-4 * tot_ref:                     # tensors that carry the Fisher mass: their totals agree
+            assert float(a.sum()) == pytest.approx(float(w.sum()), rel=0.2), k
+    print(f"SD Fisher: bulk relative error {(num / den) ** 0.5:.3f}")
+    assert (num / den) ** 0.5 < 0.15
+    # the mask from two Fisher dicts: the threshold rule is bit-exact on identical inputs (tests/test_gpu_fisher_and_acceptance.py);
+    # here: the reference file format round-trips (UNet-relative names, bool tensors)
+    m = fisher.masks_from_fisher(got, {k: v * 0.5 + 1e-9 for k, v in got.items()}, th=1.5)
+    assert set(m.keys()) == set(got.keys()) and all(v.dtype == torch.bool for v in m.values())
+    k0 = max(got, key=lambda k: got[k].numel())
+    exp = ((got[k0] + 1e-15) / (got[k0] * 0.5 + 1e-9 + 1e-15)) >= 1.5
+    assert torch.equal(m[k0], exp)
+
+
 def test_sd_v1_full_size_nsfw_removal_steps():
     """BASELINE config 4 at its real size: the v1-inference.yaml UNet (859,520,964 parameters), 64x64 latents (512 px), 77-token
     context, batch 2 (SD/README.md:69), train_method full: three iterations of the nsfw_removal loop on the HIP path -- finite

@@ -52,7 +52,8 @@ def test_conv3x3_forward_dgrad_wgrad(form):
     xr = xr.to(torch.bfloat16).to(DEV)
     wf = torch.empty(cop * 9 * cip, dtype=torch.bfloat16, device=DEV)
     wd = torch.empty(ci * 9 * cop, dtype=torch.bfloat16, device=DEV) if ci % 8 == 0 else None
-    check(L.sfron_conv_wprep(ptr(w.to(DEV)), co, ci, 9, cop, cip, ptr(wf), ptr(wd), stream_ptr()), "wprep")
+    w_d = w.to(DEV)
+    check(L.sfron_conv_wprep(ptr(w_d), co, ci, 9, cop, cip, ptr(wf), ptr(wd), stream_ptr()), "wprep")
     xt = x.clone().requires_grad_(True)
     wt = wq.clone().requires_grad_(True)
     if form == "down":          # Downsample (models/diffusion.py:76-80)
@@ -139,7 +140,8 @@ def test_groupnorm_swish_dropout_fwd_bwd(C, HW, swish, drop):
     dx = torch.full((B * HW, C), 0.5, dtype=torch.float32, device=DEV)
     pg = torch.empty(B, C, dtype=torch.float32, device=DEV)
     pb = torch.empty_like(pg)
-    check(L.sfron_groupnorm_bwd(ptr(dy.to(DEV)), ptr(xd), C, ptr(gd), ptr(bd), ptr(mean), ptr(rstd), B, HW, C, 32, swish, ptr(md), scale,
+    dy_d = dy.to(DEV)
+    check(L.sfron_groupnorm_bwd(ptr(dy_d), ptr(xd), C, ptr(gd), ptr(bd), ptr(mean), ptr(rstd), B, HW, C, 32, swish, ptr(md), scale,
                                 ptr(dx), C, 1, ptr(pg), ptr(pb), stream_ptr()), "gn_bwd")
     np.testing.assert_allclose(dx.cpu().numpy() - 0.5, xt.grad.numpy(), rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(pg.sum(0).cpu().numpy(), gt.grad.numpy(), rtol=2e-4, atol=2e-4)
@@ -169,7 +171,8 @@ def test_batched_gemm_and_softmax():
     np.testing.assert_allclose(O.float().cpu().view(B, T, C).numpy(), (P.float().cpu().view(B, T, T) @ v).numpy(), rtol=1e-2, atol=1e-2)
     dP = torch.randn(B * T, T, generator=g)
     dS = torch.empty(B * T, T, dtype=torch.bfloat16, device=DEV)
-    check(L.sfron_softmax_bwd(ptr(P), ptr(dP.to(DEV)), B * T, T, scale, ptr(dS), stream_ptr()), "softmax_bwd")
+    dP_d = dP.to(DEV)
+    check(L.sfron_softmax_bwd(ptr(P), ptr(dP_d), B * T, T, scale, ptr(dS), stream_ptr()), "softmax_bwd")
     pf = P.float().cpu()
     want = scale * pf * (dP - (pf * dP).sum(-1, keepdim=True))
     np.testing.assert_allclose(dS.float().cpu().numpy(), want.numpy(), rtol=1e-2, atol=2e-3)

@@ -150,7 +150,8 @@ class GaussianDiffusion:
         if noise is None:
             noise = torch.randn_like(x)
         sample, pred = torch.empty_like(x), torch.empty_like(x)
-        check(_lib.lib().sfron_p_sample(ptr(x), ptr(model_output.contiguous().float()), ptr(t), ptr(self.tab), ptr(noise.contiguous()),
+        mo, nz = model_output.contiguous().float(), noise.contiguous()       # named: temporaries must outlive the launch
+        check(_lib.lib().sfron_p_sample(ptr(x), ptr(mo), ptr(t), ptr(self.tab), ptr(nz),
                                         n, c, x[0, 0].numel(), int(bool(clip_denoised)), ptr(sample), ptr(pred), stream_ptr()),
               "p_sample")
         return {"sample": sample, "pred_xstart": pred}

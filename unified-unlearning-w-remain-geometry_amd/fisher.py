@@ -131,3 +131,55 @@ class DDPMFisherAccumulator:
     def state_dict(self, prefix="module."):
         """name -> fp32 CPU tensor (the runner saves the DataParallel-prefixed names, :1284)."""
         return {prefix + n: self.model.view(self.fisher, n).detach().cpu().clone() for n in self.model.index}
+
+
+class SDFisherAccumulator:
+    """Fisher diagonal of the concept-erasure script (SD/train-scripts/generate_fisher.py:36-79 forget loop, :87-128 remain loop) on
+    the native UNet (sfron.sd_unet.UNetModel): per batch one shared t and noise, x_t = q_sample(latents, t, noise) (:57-62);
+    preds = (1 + c_guidance) eps(x_t, c_prompt) - c_guidance eps(x_t, c_null) with gradients through BOTH branches (:64-67);
+    loss = -MSELoss(noise, preds) (:70, mean over every element); F[name] += grad^2 / len(loader) (:73-77), no clipping; the model
+    is in eval mode (:25).  Two backward passes (d_preds scaled by (1 + c) and -c) fill two gradient arenas, one sweep squares
+    their sum.  Latents and the two prompt embeddings arrive resident (the VAE / CLIP front-end of get_input is outside the path).
+    n_batches = len(loader) over ALL ranks; finish a data-parallel run with all_reduce()."""
+
+    def __init__(self, unet, schedule, n_batches, c_guidance=7.5):
+        self.unet, self.s, self.n, self.c = unet, schedule, n_batches, float(c_guidance)
+        p, g, _, _ = unet.flat_arena()
+        self.fisher = torch.zeros_like(p)
+        self.g_first = torch.zeros_like(p)
+
+    def accumulate(self, batch):
+        """batch: x (latents [B,4,h,w]), c (prompt embedding [B,L,ctx]), c_null (embedding of ""), t (int64), noise."""
+        L, u = _lib.lib(), self.unet
+        was_training = u.training
+        u.eval()
+        x, noise, t = batch["x"], batch["noise"].contiguous(), batch["t"]
+        B, chw = x.shape[0], x[0].numel()
+        x_t = self.s.q_sample(x, t, noise)
+        out_c, bwd_c = u._run(x_t, t, batch["c"], need_grad=True)
+        out_n, bwd_n = u._run(x_t, t, batch["c_null"], need_grad=True)
+        preds = torch.empty_like(out_c)
+        check(L.sfron_axpby(ptr(out_c), ptr(out_n), 1.0 + self.c, -self.c, preds.numel(), ptr(preds), stream_ptr()), "axpby")
+        per = torch.empty(B, dtype=torch.float32, device=x.device)
+        check(L.sfron_ddpm_sample_loss(ptr(noise), ptr(preds), B, chw, ptr(per), stream_ptr()), "sample_loss")
+        # d(-mean((noise - preds)^2)) / d preds = -2 (preds - noise) / (B chw); the branches receive it scaled by (1 + c) and -c
+        d_out = torch.empty_like(preds)
+        for scale, bwd, keep in (((1.0 + self.c), bwd_c, True), (-self.c, bwd_n, False)):
+            coef = torch.full((B,), -2.0 * scale / (B * chw), dtype=torch.float32, device=x.device)
+            check(L.sfron_ddpm_loss_bwd(ptr(noise), ptr(preds), ptr(coef), B, chw, ptr(d_out), stream_ptr()), "loss_bwd")
+            bwd(d_out)
+            if keep:
+                self.g_first.copy_(u.grads)
+        check(L.sfron_fisher_accum_clipped(ptr(self.fisher), ptr(u.grads), ptr(self.g_first), None, u.grads.numel(), float(self.n),
+                                           stream_ptr()), "fisher_accum")
+        u.train(was_training)
+        return -per.sum() / (B * chw)
+
+    def all_reduce(self, group=None):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.fisher, op=dist.ReduceOp.SUM, group=group)
+        return self
+
+    def state_dict(self):
+        """name -> fp32 CPU tensor keyed by the UNet-relative parameter names (generate_fisher.py:31-32,79: nude_forget.pt / nude_remain.pt)."""
+        return {n: self.unet.view(self.fisher, n).detach().cpu().clone() for n in self.unet.index}

@@ -80,7 +80,8 @@ class SDSFRon:
         n, chw = out.shape[0], out[0].numel()
         coef = torch.full((n,), 2.0 * scale / (n * chw * self.world), dtype=torch.float32, device=out.device)
         d = torch.empty_like(out)
-        check(_lib.lib().sfron_ddpm_loss_bwd(ptr(target.contiguous()), ptr(out.contiguous()), ptr(coef), n, chw, ptr(d), stream_ptr()), "loss_bwd")
+        tg, oc = target.contiguous(), out.contiguous()
+        check(_lib.lib().sfron_ddpm_loss_bwd(ptr(tg), ptr(oc), ptr(coef), n, chw, ptr(d), stream_ptr()), "loss_bwd")
         out.backward(d)
         if self.world > 1:
             self._dp.allreduce_flat_(self.opt.g, 64 << 20, self.pg)
@@ -88,7 +89,8 @@ class SDSFRon:
     def _mse(self, a, b):
         n, chw = a.shape[0], a[0].numel()
         per = torch.empty(n, dtype=torch.float32, device=a.device)
-        check(_lib.lib().sfron_ddpm_sample_loss(ptr(b.contiguous()), ptr(a.detach().contiguous()), n, chw, ptr(per), stream_ptr()), "sample_loss")
+        bc, ac = b.contiguous(), a.detach().contiguous()
+        check(_lib.lib().sfron_ddpm_sample_loss(ptr(bc), ptr(ac), n, chw, ptr(per), stream_ptr()), "sample_loss")
         return per.sum() / (n * chw)
 
     def step(self, forget, remain):
