@@ -33,15 +33,23 @@ def _nchw(r, B, H, W):
     return r.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
 
 
-@pytest.mark.parametrize("form", ["same", "down", "up", "rgb_in", "rgb_out", "same_big"])
+# (batch, image side, c_in, c_out).  The *_big / wide / ragged forms have pixels % 256 == 0 and channels % 64 == 0: forward and input
+# gradient run on the LDS-DMA pipelined tile (k_cgemm: im2col as DMA address arithmetic -- stride 2, nearest-upsampled and
+# zero-dilated sources, flipped taps; 160-column tiles for the 320-wide output, 128-column tiles with a ragged last tile for 192)
+CONV_FORMS = {"same": (3, 8, 32, 64), "down": (3, 8, 32, 32), "up": (3, 8, 32, 32), "rgb_in": (3, 8, 3, 32), "rgb_out": (3, 8, 32, 3),
+              "same_big": (16, 16, 64, 128),                     # 4096 pixels -> also the weight gradient's split-K path
+              "down_big": (4, 16, 64, 64), "up_big": (4, 8, 64, 128), "wide": (4, 16, 128, 320), "ragged": (4, 8, 64, 192)}
+
+
+@pytest.mark.parametrize("form", list(CONV_FORMS))
 def test_conv3x3_forward_dgrad_wgrad(form):
     import ctypes
     from sfron import _lib, unet
     from sfron._lib import check, ptr, stream_ptr
     L = _lib.lib()
     g = torch.Generator().manual_seed(len(form))
-    B, H = (16, 16) if form == "same_big" else (3, 8)          # same_big: 4096 pixels -> the weight gradient's split-K path
-    ci, co = {"same": (32, 64), "down": (32, 32), "up": (32, 32), "rgb_in": (3, 32), "rgb_out": (32, 3), "same_big": (64, 128)}[form]
+    B, H, ci, co = CONV_FORMS[form]
+    form = form.split("_")[0] if form.endswith("_big") else form
     cip, cop = unet._pad8(ci), unet._pad8(co)
     x = torch.randn(B, ci, H, H, generator=g).to(torch.bfloat16).float()
     w = (torch.randn(co, ci, 3, 3, generator=g) * 0.1)
@@ -146,6 +154,34 @@ def test_groupnorm_swish_dropout_fwd_bwd(C, HW, swish, drop):
     np.testing.assert_allclose(dx.cpu().numpy() - 0.5, xt.grad.numpy(), rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(pg.sum(0).cpu().numpy(), gt.grad.numpy(), rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(pb.sum(0).cpu().numpy(), bt.grad.numpy(), rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("M,N,K,out", [(512, 320, 1280, "f32"), (1024, 640, 320, "bf16"), (256, 200, 128, "f32"), (768, 2560, 64, "bf16")])
+def test_pipelined_tile_plain_products(M, N, K, out):
+    """C = A B^T (+ bias, + per-sample vector, + residual | accumulate) on the LDS-DMA pipelined tile (M % 256 == 0, K % 64 == 0):
+    160-column tiles (N % 160 == 0) and 128-column tiles with a ragged last tile, both epilogues, against torch fp32."""
+    from sfron import unet
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)
+    b = (torch.randn(N, K, generator=g) * 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    ref = a.float() @ b.float().t() + bias
+    ad, bd, biasd = a.to(DEV), b.to(DEV), bias.to(DEV)
+    if out == "bf16":
+        c = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        unet.bgemm(ad, bd, M, N, K, lda=K, ldb=K, c_bf16=c, ldc=N, bias=biasd)
+        np.testing.assert_allclose(c.float().cpu().numpy(), ref.numpy(), rtol=1e-2, atol=1e-2 * math.sqrt(K) * 0.25)
+        return
+    T = 64
+    vec = torch.randn(M // T, N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    ref2 = ref + vec.repeat_interleave(T, dim=0) + resid
+    c = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    vd, rd = vec.to(DEV), resid.to(DEV)
+    unet.bgemm(ad, bd, M, N, K, lda=K, ldb=K, c_f32=c, ldc=N, bias=biasd, vec=vd, ld_vec=N, rows_per_sample=T, resid=rd)
+    np.testing.assert_allclose(c.cpu().numpy(), ref2.numpy(), rtol=2e-4, atol=2e-4 * math.sqrt(K))
+    unet.bgemm(ad, bd, M, N, K, lda=K, ldb=K, c_f32=c, ldc=N, accumulate=True)          # c += A B^T
+    np.testing.assert_allclose(c.cpu().numpy(), (ref2 + ref - bias).numpy(), rtol=2e-4, atol=4e-4 * math.sqrt(K))
 
 
 def test_batched_gemm_and_softmax():

@@ -19,6 +19,8 @@
 // images XOR-swizzled as in gemm.hip.  The U-Net is 5 % of the DiT step's FLOPs per sample: this kernel is the generic
 // (register-staged) tile, not the LDS-DMA pipeline of gemm.hip.
 #include "common.h"
+#include <atomic>
+#include <utility>
 #include "../../include/sfron.h"
 
 namespace {
@@ -279,6 +281,402 @@ template __global__ void k_bgemm<true, true, EPI_RES, CONV_NONE>(BGemmArgs);
 template __global__ void k_bgemm<false, false, EPI_BF16, CONV_A>(BGemmArgs);
 template __global__ void k_bgemm<false, false, EPI_RES, CONV_A>(BGemmArgs);
 template __global__ void k_bgemm<true, true, EPI_RES, CONV_B>(BGemmArgs);
+
+// =================================================================================================
+// LDS-DMA pipelined tile for the large direct-operand products (3x3 / 1x1 convolution forward and input gradient, Linear forward):
+// 256 x (NT_ * 16) x 64, 8 waves stacked over the rows (32 x NT_*16 each), THREE LDS slots (two K-tiles in flight per CU, the
+// operands of a U-Net pass are cold in L2), operands staged by `buffer_load_dwordx4 ... lds` with the XOR swizzle applied on the
+// SOURCE address (the LDS image is lane-linear).  The im2col gather is address arithmetic of the A-operand DMA: a lane owns four
+// output pixels (b, ho, wo); per K-tile the tap (kh, kw) and the channel offset are wave-uniform (C % 64 == 0), the lane adds the
+// tap to its pixel, and a source outside the image (zero padding, odd positions of a zero-dilated gradient) becomes an
+// out-of-range buffer offset, for which the DMA writes zeros.  NT_ = 10 (160 columns) tiles the 320 / 640 / 1280-wide outputs of
+// the LDM UNet exactly, NT_ = 8 serves the DDPM widths (128 / 256) and ragged N (rows of B past N read as zeros through the
+// descriptor's size, the epilogue skips their columns).  Needs M % 256 == 0 and K % 64 == 0; everything else stays on k_bgemm.
+typedef __attribute__((address_space(3))) void lptr_t;
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// one wave-instruction of LDS-DMA: 64 lanes x 16 B from rsrc[voff + soff] to the lane-linear KiB at `dst` (a __device__ helper:
+// the builtin inside a kernel template's own lambda breaks hipcc's host pass)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, __bf16* dst, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t*)dst, 16, voff, soff, 0, 0);
+}
+
+template <int NT_>
+struct CTile {
+  static constexpr int FBM = 256, FBN = NT_ * 16, NW = 8, NSLOT = 3;
+  static constexpr int A_ELEMS = FBM * 64, B_ELEMS = FBN * 64, SLOT = A_ELEMS + B_ELEMS;
+  static constexpr int NA = FBM * 8 / 64 / NW;           // A wave-instructions per wave and tile (4)
+  static constexpr int NB_TOT = FBN * 8 / 64;            // B wave-instructions per tile
+  static constexpr int NB = (NB_TOT + NW - 1) / NW;
+  static constexpr bool EVEN = NB_TOT % NW == 0;         // NT_ = 10: 20 instructions on 8 waves -- waves 4..7 send a no-op third
+  static constexpr int NDMA = NA + NB;
+  static constexpr size_t LDS = (size_t)NSLOT * SLOT * sizeof(__bf16) + (EVEN ? 0 : 1024);
+};
+
+template <int NT_, int EPI, bool CONV>
+__global__ __launch_bounds__(512) void k_cgemm(BGemmArgs g, unsigned a_bytes, unsigned b_bytes) {
+  using CT = CTile<NT_>;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = (g.N + CT::FBN - 1) / CT::FBN;
+  // workgroups of one XCD (blockIdx % 8) take consecutive tile ids: the column tiles of one row panel share that XCD's L2
+  int id;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x, q = nblk >> 3, r = nblk & 7, x = b & 7, y = b >> 3;
+    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+  }
+  const int tm = id / ntn, tn = id - tm * ntn;
+  const int m0 = tm * CT::FBM, n0 = tn * CT::FBN;
+  int kbeg = 0, kend = g.K;
+  if (g.kchunk > 0) {
+    kbeg = (int)blockIdx.y * g.kchunk; kend = min(g.K, kbeg + g.kchunk);
+    const long co = (long)blockIdx.y * g.sC;
+    if (g.Cf) g.Cf += co;
+  }
+  const int nk = (kend - kbeg) / BK;
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, (int)b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, 0, 0x00020000);
+  __bf16* dummy = smem + CT::NSLOT * CT::SLOT;
+
+  const int lc8 = ((lane & 7) ^ ((lane >> 3) & 7)) << 3;      // logical 8-element chunk this lane fetches (rows start at multiples of 8)
+  int a_off[CT::NA], a_h0[CT::NA], a_w0[CT::NA], a_pb[CT::NA], b_off[CT::NB];
+#pragma unroll
+  for (int i = 0; i < CT::NA; ++i) {
+    const int gr = m0 + (wave + i * CT::NW) * 8 + (lane >> 3);
+    if (!CONV) a_off[i] = 2 * (gr * g.lda + lc8);
+    else {
+      const int wo = gr % g.cg.Wo, t = gr / g.cg.Wo, ho = t % g.cg.Ho, b = t / g.cg.Ho;
+      a_h0[i] = ho * g.cg.stride - g.cg.pad; a_w0[i] = wo * g.cg.stride - g.cg.pad; a_pb[i] = b * g.cg.Hs * g.cg.Ws;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CT::NB; ++i) b_off[i] = 2 * ((n0 + (wave + i * CT::NW) * 8 + (lane >> 3)) * g.ldb + lc8);
+
+  const int Hv = (g.cg.up | g.cg.dil) ? 2 * g.cg.Hs : g.cg.Hs, Wv = (g.cg.up | g.cg.dil) ? 2 * g.cg.Ws : g.cg.Ws;
+  // tile kt -> slot: the A source of a convolution advances tap by tap, channel block by channel block
+  int tap = 0, c0 = 0;
+  if (CONV) { tap = kbeg / g.cg.C; c0 = kbeg - tap * g.cg.C; }
+  auto issue = [&](int slot, int k0) {
+    __bf16* iA = smem + slot * CT::SLOT;
+    __bf16* iB = iA + CT::A_ELEMS;
+    int kh = 0, kw = 0;
+    if (CONV && g.cg.taps == 9) { const int tt = g.cg.flip ? 8 - tap : tap; kh = (tt * 11) >> 5; kw = tt - 3 * kh; }
+#pragma unroll
+    for (int i = 0; i < CT::NA; ++i) {
+      int voff = 0;
+      if (!CONV) voff = a_off[i];
+      else {
+        int hi = a_h0[i] + kh, wi = a_w0[i] + kw;
+        bool ok = (unsigned)hi < (unsigned)Hv && (unsigned)wi < (unsigned)Wv;
+        if (g.cg.dil) ok = ok && !((hi | wi) & 1);
+        if (g.cg.up | g.cg.dil) { hi >>= 1; wi >>= 1; }
+        voff = ok ? 2 * ((a_pb[i] + hi * g.cg.Ws + wi) * g.lda + lc8) : 0x7ffffff0;
+      }
+      dma16(rsA, iA + (wave + i * CT::NW) * 512, voff, 2 * (CONV ? c0 : k0));
+    }
+#pragma unroll
+    for (int i = 0; i < CT::NB; ++i) {
+      if (CT::EVEN || i + 1 < CT::NB) {
+        dma16(rsB, iB + (wave + i * CT::NW) * 512, b_off[i], 2 * k0);
+      } else {
+        const bool ok = wave + i * CT::NW < CT::NB_TOT;     // wave-uniform
+        dma16(ok ? rsB : rs0, ok ? iB + (wave + i * CT::NW) * 512 : dummy, b_off[i], 2 * k0);
+      }
+    }
+    if (CONV) { c0 += BK; if (c0 >= g.cg.C) { c0 = 0; ++tap; } }
+  };
+
+  f32x4 acc[2][NT_];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT_; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4;
+  auto compute = [&](int slot) {
+    const __bf16* iA = smem + slot * CT::SLOT;
+    const __bf16* iB = iA + CT::A_ELEMS;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 fa0 = frag_direct(iA, wave * 32 + fr, ks * 4 + fg);
+      const bf16x8 fa1 = frag_direct(iA, wave * 32 + 16 + fr, ks * 4 + fg);
+#pragma unroll
+      for (int nt = 0; nt < NT_; ++nt) {
+        const bf16x8 fb = frag_direct(iB, nt * 16 + fr, ks * 4 + fg);
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa0, acc[0][nt], 0, 0, 0);
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa1, acc[1][nt], 0, 0, 0);
+      }
+    }
+  };
+
+  if (nk > 0) issue(0, kbeg);
+  if (nk > 1) issue(1, kbeg + BK);
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) wait_vmcnt<CT::NDMA>();
+    else             wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) issue(slot >= 1 ? slot - 1 : 2, kbeg + (kt + 2) * BK);       // (kt + 2) % 3
+    compute(slot);
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int row = m0 + wave * 32 + mt * 16 + fr;
+#pragma unroll
+    for (int nt = 0; nt < NT_; ++nt) {
+      const int col = n0 + nt * 16 + 4 * fg;
+      if (col < g.N) epi_store<EPI>(g, row, col, acc[mt][nt]);
+    }
+  }
+}
+
+template __global__ void k_cgemm<8, EPI_BF16, false>(BGemmArgs, unsigned, unsigned);
+template __global__ void k_cgemm<8, EPI_RES, false>(BGemmArgs, unsigned, unsigned);
+template __global__ void k_cgemm<8, EPI_BF16, true>(BGemmArgs, unsigned, unsigned);
+template __global__ void k_cgemm<8, EPI_RES, true>(BGemmArgs, unsigned, unsigned);
+template __global__ void k_cgemm<10, EPI_BF16, false>(BGemmArgs, unsigned, unsigned);
+template __global__ void k_cgemm<10, EPI_RES, false>(BGemmArgs, unsigned, unsigned);
+template __global__ void k_cgemm<10, EPI_BF16, true>(BGemmArgs, unsigned, unsigned);
+template __global__ void k_cgemm<10, EPI_RES, true>(BGemmArgs, unsigned, unsigned);
+
+// ---- the same pipeline for the products with a TRANSPOSED-READ operand (contraction index = matrix row):
+//   T[p][q] = sum_k P[.][.] Q[k][q],  tile 256 (p) x 128 (q) x 64 (k), 8 waves as 4 x 2 (64 x 64 each), three slots
+//   P_TR = false: P direct [p][k] (Linear input gradient  dX = dY W : P = dY, Q = W [k = out][q = in])
+//   P_TR = true : P read transposed [k][p] (weight gradients; contraction over pixels / tokens)
+//     CONVP: P is the im2col view of an NHWC image ([k = output pixel][p = (tap, ci)]): a lane's column chunk fixes its tap, per
+//            K-tile it decodes its pixel rows (magic-number division) and shifts them by the tap
+//     SWAP : the result is stored transposed, C[q][p] (convolution weight gradient [Co][taps * Ci] with the 256-wide tile on
+//            the long (tap, ci) axis and the 128-wide one on Co: 320 / 640 / 1280 and 128 / 256 outputs tile without waste)
+// Transposed fragments are ds_read_b64_tr_b16 through inline asm (hipcc would drain vmcnt(0) before the builtin while an
+// LDS-DMA is in flight, gemm.hip); their completion is waited for explicitly.
+__device__ __forceinline__ unsigned lds_addr_of(const __bf16* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(const void*)p;
+}
+template <int OFF>
+__device__ __forceinline__ bf16x4 asm_tr_off(unsigned addr) {
+  bf16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 asm_b128_off(unsigned addr) {
+  bf16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+__device__ __forceinline__ void lds_reads_done() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+struct TTile {
+  static constexpr int FBP = 256, FBQ = 128, NW = 8, NSLOT = 3;
+  static constexpr int P_ELEMS = FBP * 64, Q_ELEMS = FBQ * 64, SLOT = P_ELEMS + Q_ELEMS;
+  static constexpr int NP = 4, NQ = 2, NDMA = NP + NQ;
+  static constexpr size_t LDS = (size_t)NSLOT * SLOT * sizeof(__bf16);
+};
+
+template <bool P_TR, bool CONVP, bool SWAP, int EPI>
+__global__ __launch_bounds__(512) void k_cgemm_t(BGemmArgs g, unsigned p_bytes, unsigned q_bytes, unsigned magic_w, unsigned magic_h) {
+  using TT = TTile;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave >> 1, wq = wave & 1;
+  // P / Q roles: the descriptor's A is P unless SWAP (then its B -- the im2col operand -- is P and the output is stored transposed)
+  const __bf16* Pp = SWAP ? g.B : g.A;
+  const __bf16* Qp = SWAP ? g.A : g.B;
+  const int ldp = SWAP ? g.ldb : g.lda, ldq = SWAP ? g.lda : g.ldb;
+  const int NPd = SWAP ? g.N : g.M, NQd = SWAP ? g.M : g.N;        // extents of the p and q axes
+  const int ntq = (NQd + TT::FBQ - 1) / TT::FBQ;
+  int id;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x, qq = nblk >> 3, r = nblk & 7, x = b & 7, y = b >> 3;
+    id = (x < r ? x * (qq + 1) : r * (qq + 1) + (x - r) * qq) + y;
+  }
+  const int tp = id / ntq, tq = id - tp * ntq;
+  const int p0 = tp * TT::FBP, q0 = tq * TT::FBQ;
+  int kbeg = 0, kend = g.K;
+  if (g.kchunk > 0) {
+    kbeg = (int)blockIdx.y * g.kchunk; kend = min(g.K, kbeg + g.kchunk);
+    if (g.Cf) g.Cf += (long)blockIdx.y * g.sC;
+  }
+  const int nk = (kend - kbeg) / BK;
+
+  const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)Pp, 0, (int)p_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)Qp, 0, (int)q_bytes, 0x00020000);
+
+  // ---- DMA plan.  Direct P image [256 p][64 k] (8 chunks per row, chunk ^= row & 7); transposed-read images [64 k][256 | 128]
+  // (32 | 16 chunks per row, low four chunk bits ^= swz_tr(k row)).  Out-of-range columns of a ragged last tile read the next
+  // row's data or zeros; their outputs are never stored.
+  int p_off[TT::NP], q_off[TT::NQ];
+  int p_kh[TT::NP], p_kw[TT::NP], p_ci[TT::NP];           // CONVP: tap and channel offset of the lane's column chunk (tap < 0: none)
+#pragma unroll
+  for (int i = 0; i < TT::NP; ++i) {
+    const int j = wave + i * TT::NW;
+    if (!P_TR) {
+      const int row = j * 8 + (lane >> 3);
+      p_off[i] = 2 * ((p0 + row) * ldp + (((lane & 7) ^ ((lane >> 3) & 7)) << 3));
+    } else {
+      const int krow = 2 * j + (lane >> 5), pch = lane & 31;
+      const int lc = (pch & ~15) | ((pch & 15) ^ swz_tr(krow));
+      const int col = p0 + (lc << 3);
+      if (!CONVP) p_off[i] = 2 * (krow * ldp + col);
+      else {
+        const int tap = col / g.cg.C;
+        p_ci[i] = col - tap * g.cg.C;
+        const int tt = tap < g.cg.taps ? tap : -64;
+        const int kh = g.cg.taps == 9 ? (tt >= 0 ? (tt * 11) >> 5 : -64) : (tt >= 0 ? 0 : -64);
+        p_kh[i] = kh; p_kw[i] = g.cg.taps == 9 ? tt - 3 * ((tt * 11) >> 5) : 0;
+        p_off[i] = krow;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TT::NQ; ++i) {
+    const int j = wave + i * TT::NW;
+    const int krow = 4 * j + (lane >> 4), pch = lane & 15;
+    q_off[i] = 2 * (krow * ldq + q0 + ((pch ^ swz_tr(krow)) << 3));
+  }
+  const int Hv = (g.cg.up | g.cg.dil) ? 2 * g.cg.Hs : g.cg.Hs, Wv = (g.cg.up | g.cg.dil) ? 2 * g.cg.Ws : g.cg.Ws;
+  auto issue = [&](int slot, int k0) {
+    __bf16* iP = smem + slot * TT::SLOT;
+    __bf16* iQ = iP + TT::P_ELEMS;
+#pragma unroll
+    for (int i = 0; i < TT::NP; ++i) {
+      int voff = p_off[i], soff = 0;
+      if (!P_TR) soff = 2 * k0;
+      else if (!CONVP) soff = 2 * k0 * ldp;
+      else {
+        const unsigned px = (unsigned)(k0 + p_off[i]);                  // output pixel of this lane's k row
+        const unsigned t = __umulhi(px, magic_w), wo = px - t * g.cg.Wo;
+        const unsigned b = __umulhi(t, magic_h), ho = t - b * g.cg.Ho;
+        int hi = (int)ho * g.cg.stride + p_kh[i] - g.cg.pad, wi = (int)wo * g.cg.stride + p_kw[i] - g.cg.pad;
+        bool ok = (unsigned)hi < (unsigned)Hv && (unsigned)wi < (unsigned)Wv;
+        if (g.cg.dil) ok = ok && !((hi | wi) & 1);
+        if (g.cg.up | g.cg.dil) { hi >>= 1; wi >>= 1; }
+        voff = ok ? 2 * (((int)b * g.cg.Hs * g.cg.Ws + hi * g.cg.Ws + wi) * ldp + p_ci[i]) : 0x7ffffff0;
+      }
+      dma16(rsP, iP + (wave + i * TT::NW) * 512, voff, soff);
+    }
+#pragma unroll
+    for (int i = 0; i < TT::NQ; ++i) dma16(rsQ, iQ + (wave + i * TT::NW) * 512, q_off[i], 2 * k0 * ldq);
+  };
+
+  // ---- fragment addresses (bytes, relative to the slot): transposed-read fragments of 16 columns x 32 k
+  const int fg = lane >> 4, fi = lane & 15, fq = fi >> 2, fp = fi & 3;
+  const int r0 = 8 * fg + fq;                               // k row (+4 for the upper half, + 32 for the second k-step)
+  const int sw_lo = swz_tr(r0), sw_hi = swz_tr(r0 + 4);
+  unsigned pa[4][2], qa[4][2];                              // P: [mt][lo/hi] (direct P: [.][k-step]); Q: [nt][lo/hi]
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (P_TR) {
+      const int ch = ((wp * 64 + t * 16) >> 3) + (fp >> 1);
+      pa[t][0] = 2 * (r0 * 256 + (((ch & ~15) | ((ch & 15) ^ sw_lo)) << 3) + 4 * (fp & 1));
+      pa[t][1] = 2 * ((r0 + 4) * 256 + (((ch & ~15) | ((ch & 15) ^ sw_hi)) << 3) + 4 * (fp & 1));
+    } else {
+      const int row = wp * 64 + t * 16 + fi;
+      pa[t][0] = 2 * (row * 64 + (((0 + fg) ^ (row & 7)) << 3));
+      pa[t][1] = 2 * (row * 64 + (((4 + fg) ^ (row & 7)) << 3));
+    }
+    const int chq = ((wq * 64 + t * 16) >> 3) + (fp >> 1);
+    qa[t][0] = 2 * TT::P_ELEMS + 2 * (r0 * 128 + ((chq ^ sw_lo) << 3) + 4 * (fp & 1));
+    qa[t][1] = 2 * TT::P_ELEMS + 2 * ((r0 + 4) * 128 + ((chq ^ sw_hi) << 3) + 4 * (fp & 1));
+  }
+  const unsigned smem_base = lds_addr_of(smem);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int slot) {
+    const unsigned sb = smem_base + (unsigned)slot * (TT::SLOT * 2);
+    bf16x8 fpv[2][4], fqv[2][4];
+    static_for<2>([&](auto KS) {
+      constexpr int ks = decltype(KS)::value;
+      static_for<4>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        if constexpr (P_TR) {
+          const bf16x4 lo = asm_tr_off<ks * 32 * 256 * 2>(sb + pa[t][0]);
+          const bf16x4 hi = asm_tr_off<ks * 32 * 256 * 2>(sb + pa[t][1]);
+          fpv[ks][t] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        } else {
+          fpv[ks][t] = asm_b128_off<0>(sb + pa[t][ks]);
+        }
+        const bf16x4 lo = asm_tr_off<ks * 32 * 128 * 2>(sb + qa[t][0]);
+        const bf16x4 hi = asm_tr_off<ks * 32 * 128 * 2>(sb + qa[t][1]);
+        fqv[ks][t] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      });
+      lds_reads_done();
+      static_for<4>([&](auto MT) {
+        constexpr int mt = decltype(MT)::value;
+        static_for<4>([&](auto NTI) {
+          constexpr int nt = decltype(NTI)::value;
+          if constexpr (SWAP) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fpv[ks][mt], fqv[ks][nt], acc[mt][nt], 0, 0, 0);
+          else                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqv[ks][nt], fpv[ks][mt], acc[mt][nt], 0, 0, 0);
+        });
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  if (nk > 0) issue(0, kbeg);
+  if (nk > 1) issue(1, kbeg + BK);
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) wait_vmcnt<TT::NDMA>();
+    else             wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) issue(slot >= 1 ? slot - 1 : 2, kbeg + (kt + 2) * BK);
+    compute(slot);
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+
+  if constexpr (SWAP) {
+    // lane holds T[p = 4 fg + r][q = fi] of each 16 x 16 block: four consecutive p -> one float4 of row q of the transposed result
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int pc = p0 + wp * 64 + mt * 16 + 4 * fg;
+      if (pc >= NPd) continue;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int qr = q0 + wq * 64 + nt * 16 + fi;
+        if (qr >= NQd) continue;
+        float4* dst = reinterpret_cast<float4*>(g.Cf + (size_t)qr * g.ldcf + pc);
+        const f32x4 v = acc[mt][nt] * g.alpha;
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (g.accumulate) { const float4 c = *dst; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+        *dst = o;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int row = p0 + wp * 64 + mt * 16 + fi;
+      if (row >= NPd) continue;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int col = q0 + wq * 64 + nt * 16 + 4 * fg;
+        if (col < NQd) epi_store<EPI>(g, row, col, acc[mt][nt]);
+      }
+    }
+  }
+}
+
+template __global__ void k_cgemm_t<false, false, false, EPI_BF16>(BGemmArgs, unsigned, unsigned, unsigned, unsigned);
+template __global__ void k_cgemm_t<false, false, false, EPI_RES>(BGemmArgs, unsigned, unsigned, unsigned, unsigned);
+template __global__ void k_cgemm_t<true, false, false, EPI_RES>(BGemmArgs, unsigned, unsigned, unsigned, unsigned);
+template __global__ void k_cgemm_t<true, true, true, EPI_RES>(BGemmArgs, unsigned, unsigned, unsigned, unsigned);
 
 namespace {
 
@@ -686,6 +1084,86 @@ int launch_bgemm(const BGemmArgs& g, int nbatch, hipStream_t s, int ninner = 1) 
   return e == hipSuccess ? SFRON_OK : (int)e;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per function AND per device
+inline bool need_attr(std::atomic<uint64_t>& mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  return (mask.fetch_or(bit) & bit) == 0;
+}
+template <int NT_, int EPI, bool CONV>
+int launch_cgemm_t(const BGemmArgs& g, unsigned a_bytes, unsigned b_bytes, int nsplit, hipStream_t s) {
+  using CT = CTile<NT_>;
+  static std::atomic<uint64_t> done{0};        // per instantiation, one bit per device
+  if (need_attr(done)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cgemm<NT_, EPI, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT::LDS) !=
+        hipSuccess)
+      return (int)hipGetLastError();
+  }
+  const int ntm = g.M / CT::FBM, ntn = (g.N + CT::FBN - 1) / CT::FBN;
+  hipLaunchKernelGGL((k_cgemm<NT_, EPI, CONV>), dim3(ntm * ntn, nsplit), dim3(512), CT::LDS, s, g, a_bytes, b_bytes);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SFRON_OK : (int)e;
+}
+// the pipelined tile when the product qualifies (-1: it does not, the caller launches k_bgemm)
+int try_cgemm(const BGemmArgs& g, bool conv, size_t a_rows, int nsplit, hipStream_t s) {
+  if (g.M % 256 || g.K % BK || g.N % 4 || (g.kchunk > 0 && g.kchunk % BK)) return -1;
+  if (conv && (g.cg.C % BK || (g.cg.taps != 9 && g.cg.taps != 1))) return -1;
+  if ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) || g.lda % 8 || g.ldb % 8) return -1;
+  const size_t a_bytes = conv ? a_rows * g.lda * 2 : ((size_t)(g.M - 1) * g.lda + g.K) * 2;
+  const size_t b_bytes = ((size_t)(g.N - 1) * g.ldb + g.K) * 2;
+  if (a_bytes >= 0x7ffffff0ull || b_bytes >= 0x7ffffff0ull || (size_t)(g.N + 160) * g.ldb * 2 >= 0x7ffffff0ull) return -1;
+  const bool bf = g.Cb != nullptr;
+  const bool wide = g.N % 160 == 0;
+#define SFRON_CG(NTV, CV) (bf ? launch_cgemm_t<NTV, EPI_BF16, CV>(g, (unsigned)a_bytes, (unsigned)b_bytes, nsplit, s) \
+                              : launch_cgemm_t<NTV, EPI_RES, CV>(g, (unsigned)a_bytes, (unsigned)b_bytes, nsplit, s))
+  if (conv) return wide ? SFRON_CG(10, true) : SFRON_CG(8, true);
+  return wide ? SFRON_CG(10, false) : SFRON_CG(8, false);
+#undef SFRON_CG
+}
+
+template <bool P_TR, bool CONVP, bool SWAP, int EPI>
+int launch_cgemm_tt(const BGemmArgs& g, size_t p_bytes, size_t q_bytes, unsigned mw, unsigned mh, int nsplit, hipStream_t s) {
+  static std::atomic<uint64_t> done{0};
+  if (need_attr(done)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cgemm_t<P_TR, CONVP, SWAP, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)TTile::LDS) != hipSuccess)
+      return (int)hipGetLastError();
+  }
+  const int np = SWAP ? g.N : g.M, nq = SWAP ? g.M : g.N;
+  const int tiles = ((np + TTile::FBP - 1) / TTile::FBP) * ((nq + TTile::FBQ - 1) / TTile::FBQ);
+  hipLaunchKernelGGL((k_cgemm_t<P_TR, CONVP, SWAP, EPI>), dim3(tiles, nsplit), dim3(512), TTile::LDS, s, g, (unsigned)p_bytes, (unsigned)q_bytes, mw, mh);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SFRON_OK : (int)e;
+}
+inline bool fits31(size_t b) { return b < 0x7ffffff0ull; }
+// Linear input gradient (A direct [M][K], B read transposed [K][N]) on the pipelined tile; -1 = not eligible
+int try_cgemm_dt(const BGemmArgs& g, hipStream_t s) {
+  if (g.M % 256 || g.K % BK || g.N % 8 || g.lda % 8 || g.ldb % 8 || (((uintptr_t)g.A | (uintptr_t)g.B) & 15)) return -1;
+  const size_t pb = ((size_t)(g.M - 1) * g.lda + g.K) * 2, qb = ((size_t)(g.K - 1) * g.ldb + g.N) * 2;
+  if (!fits31(pb) || !fits31(qb) || !fits31((size_t)g.K * g.ldb * 2 + 4096)) return -1;
+  return g.Cb ? launch_cgemm_tt<false, false, false, EPI_BF16>(g, pb, qb, 0, 0, 1, s) : launch_cgemm_tt<false, false, false, EPI_RES>(g, pb, qb, 0, 0, 1, s);
+}
+// plain weight gradient (both operands read transposed, contraction over the rows), fp32 result; -1 = not eligible
+bool tt_ok(const BGemmArgs& g) {
+  if (g.K % BK || g.M % 8 || g.N % 8 || g.lda % 8 || g.ldb % 8 || (((uintptr_t)g.A | (uintptr_t)g.B) & 15) || !g.Cf) return false;
+  if (g.kchunk > 0 && g.kchunk % BK) return false;
+  return fits31(((size_t)g.K * g.lda + 4096) * 2) && fits31(((size_t)g.K * g.ldb + 4096) * 2);
+}
+int try_cgemm_tt(const BGemmArgs& g, int nsplit, hipStream_t s) {
+  if (!tt_ok(g)) return -1;
+  const size_t pb = ((size_t)(g.K - 1) * g.lda + g.M) * 2, qb = ((size_t)(g.K - 1) * g.ldb + g.N) * 2;
+  return launch_cgemm_tt<true, false, false, EPI_RES>(g, pb, qb, 0, 0, nsplit, s);
+}
+// workgroups of the weight-gradient tile (256 on the long axis, 128 on the other)
+inline int tt_tiles(int np, int nq) { return ((np + TTile::FBP - 1) / TTile::FBP) * ((nq + TTile::FBQ - 1) / TTile::FBQ); }
+inline int tt_splits(int tiles, int K, int cap) {
+  int sp = 512 / (tiles > 0 ? tiles : 1);
+  if (sp > K / 512) sp = K / 512;
+  if (sp > cap) sp = cap;
+  return sp < 1 ? 1 : sp;
+}
+
 }  // namespace
 
 extern "C" {
@@ -710,23 +1188,30 @@ int sfron_bgemm_bf16(const sfron_bgemm_desc* d, void* stream) {
   SFRON_CHECK_ARG((g.Cb != nullptr) != (g.Cf != nullptr) && d->ldc % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
   const bool bf = g.Cb != nullptr;
-  if (!d->a_transposed && !d->b_transposed)
+  if (!d->a_transposed && !d->b_transposed) {
+    if (d->batch == 1 && ni == 1) { const int rc = try_cgemm(g, false, 0, 1, s); if (rc >= 0) return rc; }
     return bf ? launch_bgemm<false, false, EPI_BF16, CONV_NONE>(g, d->batch, s, ni) : launch_bgemm<false, false, EPI_RES, CONV_NONE>(g, d->batch, s, ni);
-  if (!d->a_transposed && d->b_transposed)
+  }
+  if (!d->a_transposed && d->b_transposed) {
+    if (d->batch == 1 && ni == 1) { const int rc = try_cgemm_dt(g, s); if (rc >= 0) return rc; }
     return bf ? launch_bgemm<false, true, EPI_BF16, CONV_NONE>(g, d->batch, s, ni) : launch_bgemm<false, true, EPI_RES, CONV_NONE>(g, d->batch, s, ni);
+  }
   if (d->a_transposed && d->b_transposed) {
+    const bool fast = !bf && d->batch == 1 && ni == 1 && tt_ok(g) && d->M >= 64 && d->N >= 64 && d->K >= 256;
     // a plain weight gradient (fp32 [M][N] contiguous, contraction over all rows): split-K through the caller's slab scratch
     if (!bf && d->split_ws && d->batch == 1 && ni == 1 && d->ldc == d->N && !d->bias && !d->resid && !d->sample_vec && !d->accumulate) {
-      const int sp = plan_splits(d->M, d->N, d->K, d->split_ws_slabs);
+      const int sp = fast ? tt_splits(tt_tiles(d->M, d->N), d->K, d->split_ws_slabs) : plan_splits(d->M, d->N, d->K, d->split_ws_slabs);
       if (sp > 1) {
         g.kchunk = ((g.K + sp - 1) / sp + BK - 1) / BK * BK;
         const int used = (g.K + g.kchunk - 1) / g.kchunk;
         g.Cf = d->split_ws; g.sC = (long)d->M * d->N;
-        const int rc = launch_bgemm<true, true, EPI_RES, CONV_NONE>(g, used, s, 1);
+        int rc = fast ? try_cgemm_tt(g, used, s) : -1;
+        if (rc < 0) rc = launch_bgemm<true, true, EPI_RES, CONV_NONE>(g, used, s, 1);
         if (rc) return rc;
         return sfron_reduce_chunks(d->split_ws, 1, used, d->M * d->N, d->c_f32, d->M * d->N, 0, stream);
       }
     }
+    if (fast) { const int rc = try_cgemm_tt(g, 1, s); if (rc >= 0) return rc; }
     return bf ? launch_bgemm<true, true, EPI_BF16, CONV_NONE>(g, d->batch, s, ni) : launch_bgemm<true, true, EPI_RES, CONV_NONE>(g, d->batch, s, ni);
   }
   return SFRON_ERR_UNSUPPORTED;
@@ -755,10 +1240,14 @@ int sfron_conv_fwd(const sfron_conv_desc* d, const uint16_t* src, const uint16_t
   g.alpha = 1.0f; g.accumulate = d->accumulate;
   // few output pixels, deep contraction (the 16x16 / 8x8 levels of the LDM UNet: 512 x 1280 outputs over K = 11520..23040): split the
   // contraction over the chip into fp32 slabs, then one pass adds them and applies the epilogue
-  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-  if (d->split_ws && !d->accumulate && tiles < 128 && g.K >= 2048) {
-    int sp = 384 / tiles;
-    if (sp > g.K / 512) sp = g.K / 512;
+  const size_t a_rows = (size_t)d->batch * d->h_src * d->w_src;
+  // workgroups the launch would have: 256 x 160 | 128 tiles when the pipelined kernel takes it, 128 x 128 otherwise
+  const bool pipelined = g.M % 256 == 0 && g.K % BK == 0 && d->c_src % BK == 0;
+  const int tiles = pipelined ? (g.M / 256) * ((g.N + (g.N % 160 == 0 ? 160 : 128) - 1) / (g.N % 160 == 0 ? 160 : 128))
+                              : ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  if (d->split_ws && !d->accumulate && tiles < (pipelined ? 160 : 128) && g.K >= 2048) {
+    int sp = (pipelined ? 320 : 384) / tiles;
+    if (sp > g.K / (pipelined ? 1024 : 512)) sp = g.K / (pipelined ? 1024 : 512);
     if (sp > d->split_ws_slabs) sp = d->split_ws_slabs;
     if (sp > 1) {
       BGemmArgs q = g;
@@ -766,7 +1255,8 @@ int sfron_conv_fwd(const sfron_conv_desc* d, const uint16_t* src, const uint16_t
       const int used = (g.K + q.kchunk - 1) / q.kchunk;
       q.Cb = nullptr; q.Cf = d->split_ws; q.ldcf = g.N; q.sC = (long)g.M * g.N;
       q.bias = nullptr; q.resid = nullptr; q.vec = nullptr;
-      rc = launch_bgemm<false, false, EPI_RES, CONV_A>(q, used, (hipStream_t)stream);
+      rc = try_cgemm(q, true, a_rows, used, (hipStream_t)stream);
+      if (rc < 0) rc = launch_bgemm<false, false, EPI_RES, CONV_A>(q, used, (hipStream_t)stream);
       if (rc) return rc;
       hipLaunchKernelGGL(k_split_finish, dim3(grid_for((int64_t)g.M * g.N)), dim3(TPB), 0, (hipStream_t)stream, d->split_ws, used, (int64_t)g.M * g.N,
                          g.M, g.N, g.bias, g.vec, g.ldvec, g.T, g.resid, g.Cf, g.Cb, d->ld_out);
@@ -774,14 +1264,23 @@ int sfron_conv_fwd(const sfron_conv_desc* d, const uint16_t* src, const uint16_t
       return SFRON_OK;
     }
   }
+  rc = try_cgemm(g, true, a_rows, 1, (hipStream_t)stream);
+  if (rc >= 0) return rc;
   return g.Cb ? launch_bgemm<false, false, EPI_BF16, CONV_A>(g, 1, (hipStream_t)stream)
               : launch_bgemm<false, false, EPI_RES, CONV_A>(g, 1, (hipStream_t)stream);
 }
 
 /* weight gradient: dw[n][tap][c] = sum_p dy[p][n] src[src(p, tap)][c]  (fp32 [n_out][taps * c_src], then k_conv_wgrad_scatter) */
+static bool conv_wgrad_pipelined(const sfron_conv_desc* d) {
+  const long K = (long)d->batch * d->h_out * d->w_out;
+  return K % BK == 0 && K >= 256 && d->c_src % 8 == 0 && d->n_out % 8 == 0 && d->h_out >= 2 && d->w_out >= 2 && d->n_out >= 64 &&
+         d->taps * d->c_src >= 64 && K < (1l << 21) && d->w_out <= 2048 && d->h_out <= 2048;
+}
 int sfron_conv_wgrad_splits(const sfron_conv_desc* d) {
   if (!d) return 0;
-  return plan_splits(d->n_out, d->taps * d->c_src, d->batch * d->h_out * d->w_out, 64);
+  const int K = d->batch * d->h_out * d->w_out;
+  if (conv_wgrad_pipelined(d)) return tt_splits(tt_tiles(d->taps * d->c_src, d->n_out), K, 64);
+  return plan_splits(d->n_out, d->taps * d->c_src, K, 64);
 }
 int sfron_conv_wgrad(const sfron_conv_desc* d, const uint16_t* dy, int ld_dy, const uint16_t* src, float* dw_gemm, void* stream) {
   SFRON_CHECK_ARG(d && dy && src && dw_gemm && d->n_out % 8 == 0 && ld_dy % 8 == 0);
@@ -796,7 +1295,15 @@ int sfron_conv_wgrad(const sfron_conv_desc* d, const uint16_t* dy, int ld_dy, co
   const int sp = sfron_conv_wgrad_splits(d);
   if (sp > 1) { g.kchunk = ((g.K + sp - 1) / sp + BK - 1) / BK * BK; g.sC = (long)g.M * g.N; }
   const int used = sp > 1 ? (g.K + g.kchunk - 1) / g.kchunk : 1;
-  rc = launch_bgemm<true, true, EPI_RES, CONV_B>(g, used, (hipStream_t)stream);
+  rc = -1;
+  if (conv_wgrad_pipelined(d) && (ld_dy % 8) == 0 && (((uintptr_t)dy | (uintptr_t)src) & 15) == 0) {
+    const size_t pb = (size_t)d->batch * d->h_src * d->w_src * d->c_src * 2, qb = ((size_t)(g.K - 1) * ld_dy + g.M) * 2;
+    if (fits31(pb) && fits31(qb + (size_t)ld_dy * 2 * 64)) {
+      const unsigned mw = (unsigned)(0x100000000ull / (unsigned)d->w_out) + 1u, mh = (unsigned)(0x100000000ull / (unsigned)d->h_out) + 1u;
+      rc = launch_cgemm_tt<true, true, true, EPI_RES>(g, pb, qb, mw, mh, used, (hipStream_t)stream);
+    }
+  }
+  if (rc < 0) rc = launch_bgemm<true, true, EPI_RES, CONV_B>(g, used, (hipStream_t)stream);
   if (rc) return rc;
   // slabs the rounding left without rows are zeroed so that the scatter can always add `sfron_conv_wgrad_splits` of them
   for (int sidx = used; sidx < sp; ++sidx)
