@@ -237,11 +237,13 @@ int sfron_rows_to_nchw(const float* rows, int ld, int B, int C, int HW, float* x
 /* y = bf16( act(GroupNorm(x; groups, eps) * gamma + beta) [* drop_mask * drop_scale] ), act = swish when `swish`; x fp32 rows
  * [B * HW][ldx]; mean / rstd [B][groups] saved for the backward pass (models/diffusion.py:43-46,126-131) */
 int sfron_groupnorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, int B, int HW, int C, int groups, float eps,
-                        int swish, const uint8_t* drop_mask, float drop_scale, uint16_t* y, float* mean, float* rstd, void* stream);
+                        int swish, const uint8_t* drop_mask, float drop_scale, uint16_t* y, float* mean, float* rstd,
+                        void* scratch /* sfron_groupnorm_scratch_bytes(), 16-B aligned; NULL = per-(sample, group) kernels */, void* stream);
 /* dy fp32 [B * HW][C] = gradient wrt y; dx (+)= gradient wrt x; part_gamma / part_beta [B][C] per-sample partial sums */
 int sfron_groupnorm_bwd(const float* dy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
                         const float* rstd, int B, int HW, int C, int groups, int swish, const uint8_t* drop_mask, float drop_scale,
-                        float* dx, int lddx, int accumulate, float* part_gamma, float* part_beta, void* stream);
+                        float* dx, int lddx, int accumulate, float* part_gamma, float* part_beta, void* scratch, void* stream);
+int64_t sfron_groupnorm_scratch_bytes(int B, int HW, int C, int groups);
 /* p = bf16(softmax(scale * s)) over rows of length n; ds = bf16(scale * p * (dp - sum(p * dp)))   (AttnBlock, :168-186) */
 int sfron_softmax_fwd(const float* s, int64_t rows, int n, int n_valid /* keys; columns beyond get probability 0 */, float scale, uint16_t* p,
                       void* stream);

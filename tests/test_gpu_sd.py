@@ -162,6 +162,31 @@ def test_sd_nsfw_removal_iterations_vs_oracle(method, mask_mode):
     assert same / tot > 0.97 and (num / den) ** 0.5 < 0.3
 
 
+def test_sd_graph_replay_matches_eager():
+    """The two stages of an iteration replayed as HIP graphs (sfron.graphs) give bit-for-bit the parameters of the eager loop."""
+    from sfron import sd
+    hp = dict(lr=1e-4, train_method="full")
+    g = torch.Generator().manual_seed(31)
+    B, S, Lc = 4, 8, 6
+    c_f, c_p = torch.randn(B, Lc, 24, generator=g).to(DEV), torch.randn(B, Lc, 24, generator=g).to(DEV)
+    batches = []
+    for it in range(4):
+        xf = torch.randn(B, 4, S, S, generator=g).to(DEV)
+        batches.append((dict(x_f=xf, x_p=xf, c_f=c_f, c_p=c_p, t=torch.randint(0, 1000, (B,), generator=g).to(DEV), noise=torch.randn(B, 4, S, S, generator=g).to(DEV)),
+                        dict(x=torch.randn(B, 4, S, S, generator=g).to(DEV), c=c_p, t=torch.randint(0, 1000, (B,), generator=g).to(DEV),
+                             noise=torch.randn(B, 4, S, S, generator=g).to(DEV))))
+    res = []
+    for use in (False, True):
+        _, model = _pair(SMALL, seed=30)
+        run = sd.SDSFRon(model, use_graphs=use, **hp)
+        losses = [run.step(*b) for b in batches]
+        if use:
+            assert run._graphs["forget"].graph is not None and run._graphs["remain"].graph is not None      # iterations 2.. were replays
+        res.append((model.params.clone(), [(l["forget_loss"].item(), l["remain_loss"].item()) for l in losses]))
+    assert res[0][1] == res[1][1]
+    assert torch.equal(res[0][0], res[1][0])
+
+
 def test_sd_fisher_and_mask_vs_oracle():
     """SD/train-scripts/generate_fisher.py:36-79: guided two-branch prediction, -MSE, F += g^2 / n; then the saliency mask."""
     from oracle import sd_ref

@@ -115,8 +115,12 @@ def test_conv3x3_forward_dgrad_wgrad(form):
     np.testing.assert_allclose(_nchw(ds.cpu(), B, H, H).numpy(), xt.grad.numpy(), rtol=3e-4, atol=3e-4 * math.sqrt(9 * co))
 
 
-@pytest.mark.parametrize("C,HW,swish,drop", [(128, 64, 1, False), (256, 16, 1, True), (64, 256, 0, False), (384, 64, 1, True)])
-def test_groupnorm_swish_dropout_fwd_bwd(C, HW, swish, drop):
+@pytest.mark.parametrize("form", ["rows", "slabs"])
+@pytest.mark.parametrize("C,HW,swish,drop", [(128, 64, 1, False), (256, 16, 1, True), (64, 256, 0, False), (384, 64, 1, True), (320, 1024, 1, False),
+                                             (1280, 64, 1, True), (2560, 16, 1, False)])
+def test_groupnorm_swish_dropout_fwd_bwd(C, HW, swish, drop, form):
+    """form "rows": the row-coalesced two-phase kernels (scratch given); "slabs": the per-(sample, group) kernels (no scratch).
+    Channels per group 2 .. 80, including the LDM widths (10, 40, 80: not powers of two) and more than 1024 channels."""
     from sfron import _lib
     from sfron._lib import check, ptr, stream_ptr
     L = _lib.lib()
@@ -140,8 +144,9 @@ def test_groupnorm_swish_dropout_fwd_bwd(C, HW, swish, drop):
     rstd = torch.empty_like(mean)
     xd, gd, bd = x.to(DEV), gamma.to(DEV), beta.to(DEV)
     md = mask.to(DEV) if drop else None
+    ws = torch.empty(L.sfron_groupnorm_scratch_bytes(B, HW, C, 32) // 8 + 2, dtype=torch.float64, device=DEV) if form == "rows" else None
     check(L.sfron_groupnorm_fwd(ptr(xd), C, ptr(gd), ptr(bd), B, HW, C, 32, 1e-6, swish, ptr(md), scale, ptr(y), ptr(mean), ptr(rstd),
-                                stream_ptr()), "gn_fwd")
+                                ptr(ws), stream_ptr()), "gn_fwd")
     np.testing.assert_allclose(y.float().cpu().numpy(), z.detach().numpy(), rtol=1e-2, atol=1e-2)
     dy = torch.randn(B * HW, C, generator=g) * 0.1
     z.backward(dy)
@@ -150,7 +155,7 @@ def test_groupnorm_swish_dropout_fwd_bwd(C, HW, swish, drop):
     pb = torch.empty_like(pg)
     dy_d = dy.to(DEV)
     check(L.sfron_groupnorm_bwd(ptr(dy_d), ptr(xd), C, ptr(gd), ptr(bd), ptr(mean), ptr(rstd), B, HW, C, 32, swish, ptr(md), scale,
-                                ptr(dx), C, 1, ptr(pg), ptr(pb), stream_ptr()), "gn_bwd")
+                                ptr(dx), C, 1, ptr(pg), ptr(pb), ptr(ws), stream_ptr()), "gn_bwd")
     np.testing.assert_allclose(dx.cpu().numpy() - 0.5, xt.grad.numpy(), rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(pg.sum(0).cpu().numpy(), gt.grad.numpy(), rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(pb.sum(0).cpu().numpy(), bt.grad.numpy(), rtol=2e-4, atol=2e-4)
@@ -405,6 +410,39 @@ def test_ddpm_sfron_iterations_native_denoiser_vs_oracle(loss):
         moved = (orc.shadow[n] - p0[n]).norm().item()
         assert (sh[n].cpu() - orc.shadow[n]).norm().item() < 0.35 * moved, n
         assert not torch.equal(sh[n], views[n])
+
+
+@pytest.mark.parametrize("loss", ["adaga", "rl"])
+def test_ddpm_graph_replay_matches_eager(loss):
+    """The forget / remain stages replayed as HIP graphs (sfron.graphs; the decayed alpha as a device scalar) against the eager loop:
+    dropout off and explicit keep masks, so both runs see identical inputs -- parameters, EMA and losses agree to fp32 rounding of
+    alpha (a python double in the eager loop, an fp32 device scalar in the graph)."""
+    from sfron import ddpm
+    cfg = dict(SMALL, dropout=0.0)
+    B, n_it = 8, 4
+    g = torch.Generator().manual_seed(41)
+    batches = []
+    for it in range(n_it):
+        pair = []
+        for stream in ("forget", "remain"):
+            b = _synthetic(it, stream, B, g)
+            b["x0"], b["e"] = b["x0"][:, :, :16, :16].contiguous(), b["e"][:, :, :16, :16].contiguous()
+            b["keep_mask"] = (torch.rand(B, generator=g) >= 0.1).to(torch.uint8)
+            pair.append({k: v.to(DEV) for k, v in b.items()})
+        batches.append(pair)
+    res = []
+    for use in (False, True):
+        _, model = _pair(cfg, seed=40)
+        run = ddpm.DDPMSFRon(model, lr=1e-4, forget_alpha=10.0, grad_clip=1.0, ema_rate=1e-4, unlearn_loss=loss, n_iters=n_it, use_graphs=use)
+        losses = [run.step(it, *batches[it]) for it in range(n_it)]
+        if use:
+            assert run._graphs["forget"].graph is not None and run._graphs["remain"].graph is not None
+        res.append((run.flat.p.clone(), run.shadow.clone(), [(l["forget_loss"].item(), l["remain_loss"].item()) for l in losses]))
+    for (fa, ra), (fb, rb) in zip(res[0][2], res[1][2]):
+        assert fa == pytest.approx(fb, rel=1e-5) and ra == pytest.approx(rb, rel=1e-5)
+    dp = (res[0][0] - res[1][0]).abs().max().item()
+    assert dp < 2e-5, dp                                           # Adam steps of lr 1e-4: a flipped update would show as 2e-4
+    assert (res[0][1] - res[1][1]).abs().max().item() < 1e-6
 
 
 def test_ddpm_fisher_clip_before_square_guided_forward_vs_oracle():

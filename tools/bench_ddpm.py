@@ -6,12 +6,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=20); ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--eager", action="store_true", help="no HIP-graph replay of the stages")
 a = ap.parse_args()
 from sfron import ddpm, unet
 import test_gpu_unet as T
 torch.manual_seed(1234)
 model = unet.Conditional_Model(unet.config_namespace())
-run = ddpm.DDPMSFRon(model, lr=1e-4, forget_alpha=10.0, grad_clip=1.0, ema_rate=1e-4, mask=None, unlearn_loss="adaga", lambd=0.5, n_iters=50)
+run = ddpm.DDPMSFRon(model, lr=1e-4, forget_alpha=10.0, grad_clip=1.0, ema_rate=1e-4, mask=None, unlearn_loss="adaga", lambd=0.5, n_iters=50, use_graphs=not a.eager)
 g = torch.Generator().manual_seed(1)
 bt = [({k: v.cuda() for k, v in T._synthetic(i, "forget", a.batch, g).items()}, {k: v.cuda() for k, v in T._synthetic(i, "remain", a.batch, g).items()}) for i in range(2)]
 for i in range(3): run.step(i, *bt[i % 2])
@@ -21,4 +22,4 @@ torch.cuda.synchronize(); dt = (time.time() - t0) / a.steps
 t1 = time.time()
 for i in range(3): run.step(i, *bt[i % 2])
 host = (time.time() - t1) / 3
-print(f"DDPM SFR-on step, batch {a.batch}: {dt * 1e3:.1f} ms/step = {1 / dt:.2f} steps/s (host enqueue time per step {host * 1e3:.1f} ms)")
+print(f"DDPM SFR-on step, batch {a.batch}, {'eager' if a.eager else 'graph replay'}: {dt * 1e3:.1f} ms/step = {1 / dt:.2f} steps/s (host enqueue time per step {host * 1e3:.1f} ms)")

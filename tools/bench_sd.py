@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 import torch
 ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--batch", type=int, default=2)
 ap.add_argument("--method", default="full")
+ap.add_argument("--eager", action="store_true", help="no HIP-graph replay of the stages")
 a = ap.parse_args()
 from sfron import sd, sd_unet
 DEV = "cuda"
@@ -18,7 +19,7 @@ with torch.no_grad():
         if not bool(p.any()):
             p.copy_((torch.randn(p.shape, generator=g) * 0.02).to(p.device))
 model.sync_bf16()
-run = sd.SDSFRon(model, lr=1e-5, train_method=a.method)
+run = sd.SDSFRon(model, lr=1e-5, train_method=a.method, use_graphs=not a.eager)
 B = a.batch
 gd = torch.Generator(device=DEV).manual_seed(2)
 rn = lambda *s: torch.randn(*s, device=DEV, generator=gd)
@@ -35,4 +36,4 @@ torch.cuda.synchronize(); dt = (time.time() - t0) / a.steps
 t1 = time.time()
 for i in range(2): run.step(*bts[i % 2])
 host = (time.time() - t1) / 2
-print(f"SD v1 UNet SFR-on iteration, batch {B}, train_method {a.method}: {dt * 1e3:.0f} ms = {1 / dt:.2f} it/s (host enqueue {host * 1e3:.0f} ms)")
+print(f"SD v1 UNet SFR-on iteration, batch {B}, train_method {a.method}, {'eager' if a.eager else 'graph replay'}: {dt * 1e3:.0f} ms = {1 / dt:.2f} it/s (host enqueue {host * 1e3:.0f} ms)")

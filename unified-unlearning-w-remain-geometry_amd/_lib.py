@@ -118,9 +118,10 @@ _PROTOS.update({
     "sfron_nchw_to_rows_bf16": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),
     "sfron_nchw_to_rows_f32": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),
     "sfron_rows_to_nchw": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),
-    "sfron_groupnorm_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, c_float, _P, _P, _P, _S]),
+    "sfron_groupnorm_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, c_float, _P, _P, _P, _P, _S]),
     "sfron_groupnorm_bwd": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, c_int, c_int,
-                                    _P, _P, _S]),
+                                    _P, _P, _P, _S]),
+    "sfron_groupnorm_scratch_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "sfron_softmax_fwd": (c_int, [_P, c_int64, c_int, c_int, c_float, _P, _S]),
     "sfron_layernorm_fwd": (c_int, [_P, _P, _P, c_int64, c_int, c_float, _P, _P, _P, _S]),
     "sfron_layernorm_rows_per_block": (c_int, []),

@@ -20,6 +20,7 @@
 // (register-staged) tile, not the LDS-DMA pipeline of gemm.hip.
 #include "common.h"
 #include <atomic>
+#include <cstdlib>
 #include <utility>
 #include "../../include/sfron.h"
 
@@ -751,11 +752,14 @@ __global__ __launch_bounds__(TPB) void k_gn_fwd(const float* __restrict__ x, int
   const int b = blockIdx.x / G, gi = blockIdx.x % G, cg = C / G;
   const float* xb = x + (size_t)b * HW * ldx + gi * cg;
   const int n = HW * cg;
+  // thread (slot, c) = (tid / cg, tid % cg) walks the pixels slot, slot + tpc, ... of its channel (no per-element division)
+  const int tpc = TPB / cg, slot = threadIdx.x / cg, c = threadIdx.x - slot * cg;
   double s = 0.0, ss = 0.0;
-  for (int i = threadIdx.x; i < n; i += TPB) {
-    const float v = xb[(size_t)(i / cg) * ldx + (i % cg)];
-    s += v; ss += (double)v * v;
-  }
+  if (slot < tpc)
+    for (int p = slot; p < HW; p += tpc) {
+      const float v = xb[(size_t)p * ldx + c];
+      s += v; ss += (double)v * v;
+    }
   s = wave_sum_d(s); ss = wave_sum_d(ss);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = ss; }
   __syncthreads();
@@ -772,12 +776,14 @@ __global__ __launch_bounds__(TPB) void k_gn_fwd(const float* __restrict__ x, int
   const float m = stat[0], r = stat[1];
   __bf16* yb = y + (size_t)b * HW * C + gi * cg;
   const uint8_t* mb = mask ? mask + (size_t)b * HW * C + gi * cg : nullptr;
-  for (int i = threadIdx.x; i < n; i += TPB) {
-    const int p = i / cg, c = i % cg;
-    float z = (xb[(size_t)p * ldx + c] - m) * r * gamma[gi * cg + c] + beta[gi * cg + c];
-    if (swish) z = silu(z);
-    if (mb) z = mb[(size_t)p * C + c] ? z * drop_scale : 0.f;
-    yb[(size_t)p * C + c] = f2bf(z);
+  if (slot < tpc) {
+    const float ga = gamma[gi * cg + c], be = beta[gi * cg + c];
+    for (int p = slot; p < HW; p += tpc) {
+      float z = (xb[(size_t)p * ldx + c] - m) * r * ga + be;
+      if (swish) z = silu(z);
+      if (mb) z = mb[(size_t)p * C + c] ? z * drop_scale : 0.f;
+      yb[(size_t)p * C + c] = f2bf(z);
+    }
   }
 }
 // backward: dy = gradient wrt the bf16 output (fp32 rows, ld = C); dx (+)= d GroupNorm; per-sample partial parameter
@@ -791,41 +797,37 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd(const float* __restrict__ dy, co
   extern __shared__ float sh[];                 // [TPB/64][2] wave partials + per-channel [2][cg] accumulators
   const int b = blockIdx.x / G, gi = blockIdx.x % G, cg = C / G;
   float* chs = sh + 2 * (TPB / 64);             // [2][cg]: sum dz * xhat, sum dz   per channel
-  for (int i = threadIdx.x; i < 2 * cg; i += TPB) chs[i] = 0.f;
-  __syncthreads();
   const float m = mean[blockIdx.x], r = rstd[blockIdx.x];
   const float* xb = x + (size_t)b * HW * ldx + gi * cg;
   const float* dyb = dy + (size_t)b * HW * C + gi * cg;
   const uint8_t* mb = mask ? mask + (size_t)b * HW * C + gi * cg : nullptr;
   const int n = HW * cg;
-  // pass 1: dz = dy * act'(z) (* dropout); group sums of dz * gamma and dz * gamma * xhat; per-channel sums
-  // A thread visits indices i = tid + k * TPB: its channel (i % cg) is fixed when TPB % cg == 0 (cg is a power of two here)
+  // pass 1: dz = dy * act'(z) (* dropout); group sums of dz * gamma and dz * gamma * xhat; per-channel sums.
+  // Thread (slot, c) = (tid / cg, tid % cg) owns channel c and visits the pixels slot, slot + tpc, ... (tpc = TPB / cg slots; the
+  // TPB - tpc * cg surplus threads idle here): consecutive threads still read consecutive addresses of a pixel's cg-channel run, and
+  // every per-channel sum is formed in a fixed order (no atomics: bitwise reproducible for any channels-per-group <= TPB).
   float s1 = 0.f, s2 = 0.f;
-  const bool fixed_c = (TPB % cg) == 0;
   float ca = 0.f, cb = 0.f;
-  for (int i = threadIdx.x; i < n; i += TPB) {
-    const int p = i / cg, c = i % cg;
-    const float xh = (xb[(size_t)p * ldx + c] - m) * r;
-    const float ga = gamma[gi * cg + c];
-    float d = dyb[(size_t)p * C + c];
-    if (mb) d = mb[(size_t)p * C + c] ? d * drop_scale : 0.f;
-    if (swish) d *= silu_grad(xh * ga + beta[gi * cg + c]);
-    s1 += d * ga; s2 += d * ga * xh;
-    if (fixed_c) { ca += d * xh; cb += d; }
-    else { atomicAdd(&chs[c], d * xh); atomicAdd(&chs[cg + c], d); }      // LDS, small odd shapes only
+  const int tpc = TPB / cg, slot = threadIdx.x / cg, c = threadIdx.x - slot * cg;
+  if (slot < tpc) {
+    const float ga = gamma[gi * cg + c], be = beta[gi * cg + c];
+    for (int p = slot; p < HW; p += tpc) {
+      const float xh = (xb[(size_t)p * ldx + c] - m) * r;
+      float d = dyb[(size_t)p * C + c];
+      if (mb) d = mb[(size_t)p * C + c] ? d * drop_scale : 0.f;
+      if (swish) d *= silu_grad(xh * ga + be);
+      s1 += d * ga; s2 += d * ga * xh;
+      ca += d * xh; cb += d;
+    }
   }
-  if (fixed_c) {
-    // threads l, l + cg, l + 2cg ... of the workgroup share a channel: reduce through LDS in a fixed order
-    float* tmp = sh + 2 * (TPB / 64) + 2 * cg;   // [2][TPB]  (threads beyond the group's element count hold zeros)
-    tmp[threadIdx.x] = ca; tmp[TPB + threadIdx.x] = cb;
-  }
+  float* tmp = sh + 2 * (TPB / 64) + 2 * cg;     // [2][TPB]
+  tmp[threadIdx.x] = ca; tmp[TPB + threadIdx.x] = cb;
   s1 = wave_sum(s1); s2 = wave_sum(s2);
   if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s1; sh[TPB / 64 + (threadIdx.x >> 6)] = s2; }
   __syncthreads();
-  if (fixed_c && threadIdx.x < cg) {
-    const float* tmp = sh + 2 * (TPB / 64) + 2 * cg;
+  if (threadIdx.x < cg) {
     float a = 0.f, q = 0.f;
-    for (int j = threadIdx.x; j < TPB; j += cg) { a += tmp[j]; q += tmp[TPB + j]; }
+    for (int j = threadIdx.x; j < tpc * cg; j += cg) { a += tmp[j]; q += tmp[TPB + j]; }
     chs[threadIdx.x] = a; chs[cg + threadIdx.x] = q;
   }
   float t1 = 0.f, t2 = 0.f;
@@ -838,16 +840,263 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd(const float* __restrict__ dy, co
   const float inv = 1.0f / (float)n;
   const float k1 = t1 * inv, k2 = t2 * inv;
   float* dxb = dx + (size_t)b * HW * lddx + gi * cg;
-  for (int i = threadIdx.x; i < n; i += TPB) {
-    const int p = i / cg, c = i % cg;
-    const float xh = (xb[(size_t)p * ldx + c] - m) * r;
-    const float ga = gamma[gi * cg + c];
-    float d = dyb[(size_t)p * C + c];
-    if (mb) d = mb[(size_t)p * C + c] ? d * drop_scale : 0.f;
-    if (swish) d *= silu_grad(xh * ga + beta[gi * cg + c]);
-    const float v = r * (d * ga - k1 - xh * k2);
-    float* o = dxb + (size_t)p * lddx + c;
-    *o = accumulate ? *o + v : v;
+  if (slot < tpc) {
+    const float ga = gamma[gi * cg + c], be = beta[gi * cg + c];
+    for (int p = slot; p < HW; p += tpc) {
+      const float xh = (xb[(size_t)p * ldx + c] - m) * r;
+      float d = dyb[(size_t)p * C + c];
+      if (mb) d = mb[(size_t)p * C + c] ? d * drop_scale : 0.f;
+      if (swish) d *= silu_grad(xh * ga + be);
+      const float v = r * (d * ga - k1 - xh * k2);
+      float* o = dxb + (size_t)p * lddx + c;
+      *o = accumulate ? *o + v : v;
+    }
+  }
+}
+
+// ---- GroupNorm, row-coalesced two-phase form (the production path; the per-(sample, group) kernels above serve odd shapes).
+// NHWC rows: a (sample, group) slab is HW runs of cg floats, 4 * C bytes apart -- a workgroup per slab touches 16..40 useful bytes of
+// every 128-B line.  Here a workgroup owns a CHUNK OF PIXELS of one sample and all C channels: threads read whole rows as float4
+// (thread = (row replica r, quad lane q); C / 4 quads per row, up to three quads per thread for C > 1024), so every load is a
+// full-line stream.  Phase 1 leaves per-chunk partial sums, phase 2 (same chunking) combines them in a fixed order in its
+// prologue and applies the normalisation; all per-channel / per-group sums are formed in a fixed order (bitwise reproducible).
+constexpr int GN_MAXQ = 3;                      // quads per thread: C <= 3 * 4 * TPB = 3072
+struct GnMap {
+  int qpr, qw, rpp, r, ql, nq;                  // quads per row, quad lanes, rows per pass, this thread's row replica / lane, its quads
+  __device__ __forceinline__ void init(int C) {
+    qpr = C >> 2; qw = qpr < TPB ? qpr : TPB; rpp = TPB / qw;
+    r = threadIdx.x / qw; ql = threadIdx.x - r * qw; nq = (qpr - ql + qw - 1) / qw;
+    if (r >= rpp) nq = 0;
+  }
+};
+__host__ __device__ inline int gn_chunks(int B, int HW) {
+  int n = (512 + B - 1) / B;
+  if (n > 32) n = 32;
+  if (n > HW / 8) n = HW / 8;
+  return n < 1 ? 1 : n;
+}
+
+// phase 1 forward: partial (sum, sum of squares) per (sample, chunk, group), fp64
+__global__ __launch_bounds__(TPB) void k_gn2_stats(const float* __restrict__ x, int ldx, int HW, int C, int G, int nchunk, double* __restrict__ part) {
+  extern __shared__ double shd[];               // [rpp][C][2]
+  const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk, cg = C / G;
+  const int p0 = (int)((long)HW * ch / nchunk), p1 = (int)((long)HW * (ch + 1) / nchunk);
+  GnMap m; m.init(C);
+  double s[GN_MAXQ][4], ss[GN_MAXQ][4];
+#pragma unroll
+  for (int j = 0; j < GN_MAXQ; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s[j][e] = 0.0; ss[j][e] = 0.0; }
+  const float* xb = x + (size_t)b * HW * ldx;
+  for (int p = p0 + m.r; p < p1; p += m.rpp) {
+#pragma unroll
+    for (int j = 0; j < GN_MAXQ; ++j)
+      if (j < m.nq) {
+        const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)p * ldx + 4 * (m.ql + j * m.qw));
+        s[j][0] += v.x; ss[j][0] += (double)v.x * v.x; s[j][1] += v.y; ss[j][1] += (double)v.y * v.y;
+        s[j][2] += v.z; ss[j][2] += (double)v.z * v.z; s[j][3] += v.w; ss[j][3] += (double)v.w * v.w;
+      }
+  }
+  if (m.r < m.rpp) {
+#pragma unroll
+    for (int j = 0; j < GN_MAXQ; ++j)
+      if (j < m.nq)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = 4 * (m.ql + j * m.qw) + e;
+          shd[((size_t)m.r * C + c) * 2] = s[j][e]; shd[((size_t)m.r * C + c) * 2 + 1] = ss[j][e];
+        }
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    double a = 0.0, q = 0.0;
+    for (int c = threadIdx.x * cg; c < (threadIdx.x + 1) * cg; ++c)
+      for (int r = 0; r < m.rpp; ++r) { a += shd[((size_t)r * C + c) * 2]; q += shd[((size_t)r * C + c) * 2 + 1]; }
+    double* o = part + (((size_t)b * nchunk + ch) * G + threadIdx.x) * 2;
+    o[0] = a; o[1] = q;
+  }
+}
+// phase 2 forward: mean / rstd from the partials (every workgroup of a sample forms them the same way; chunk 0 stores them), apply
+__global__ __launch_bounds__(TPB) void k_gn2_apply(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   int HW, int C, int G, float eps, int swish, const uint8_t* __restrict__ mask, float drop_scale,
+                                                   int nchunk, const double* __restrict__ part, __bf16* __restrict__ y, float* __restrict__ mean,
+                                                   float* __restrict__ rstd) {
+  __shared__ float st[2][64];
+  const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk, cg = C / G;
+  if (threadIdx.x < G) {
+    double a = 0.0, q = 0.0;
+    for (int k = 0; k < nchunk; ++k) { const double* o = part + (((size_t)b * nchunk + k) * G + threadIdx.x) * 2; a += o[0]; q += o[1]; }
+    const double n = (double)HW * cg, mu = a / n;
+    double var = q / n - mu * mu;                 // biased variance, as torch.nn.GroupNorm
+    var = var < 0 ? 0 : var;
+    st[0][threadIdx.x] = (float)mu; st[1][threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    if (ch == 0) { mean[b * G + threadIdx.x] = st[0][threadIdx.x]; rstd[b * G + threadIdx.x] = st[1][threadIdx.x]; }
+  }
+  __syncthreads();
+  const int p0 = (int)((long)HW * ch / nchunk), p1 = (int)((long)HW * (ch + 1) / nchunk);
+  GnMap m; m.init(C);
+  float mu[GN_MAXQ][4], rs[GN_MAXQ][4], ga[GN_MAXQ][4], be[GN_MAXQ][4];
+#pragma unroll
+  for (int j = 0; j < GN_MAXQ; ++j)
+    if (j < m.nq)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * (m.ql + j * m.qw) + e, gi = c / cg;
+        mu[j][e] = st[0][gi]; rs[j][e] = st[1][gi]; ga[j][e] = gamma[c]; be[j][e] = beta[c];
+      }
+  const float* xb = x + (size_t)b * HW * ldx;
+  __bf16* yb = y + (size_t)b * HW * C;
+  const uint8_t* mb = mask ? mask + (size_t)b * HW * C : nullptr;
+  for (int p = p0 + m.r; p < p1; p += m.rpp) {
+#pragma unroll
+    for (int j = 0; j < GN_MAXQ; ++j)
+      if (j < m.nq) {
+        const int c0 = 4 * (m.ql + j * m.qw);
+        const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)p * ldx + c0);
+        float z[4] = {v.x, v.y, v.z, v.w};
+        uchar4 mk = make_uchar4(1, 1, 1, 1);
+        if (mb) mk = *reinterpret_cast<const uchar4*>(mb + (size_t)p * C + c0);
+        const uint8_t mke[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = (z[e] - mu[j][e]) * rs[j][e] * ga[j][e] + be[j][e];
+          if (swish) t = silu(t);
+          if (mb) t = mke[e] ? t * drop_scale : 0.f;
+          z[e] = t;
+        }
+        *reinterpret_cast<bf16x4*>(yb + (size_t)p * C + c0) = bf16x4{f2bf(z[0]), f2bf(z[1]), f2bf(z[2]), f2bf(z[3])};
+      }
+  }
+}
+// phase 1 backward: per (sample, chunk, channel) partial sums of dz * xhat and dz, dz = dy * act'(z) (* dropout)
+__global__ __launch_bounds__(TPB) void k_gn2_bwd_stats(const float* __restrict__ dy, const float* __restrict__ x, int ldx,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd, int HW, int C, int G,
+                                                       int swish, const uint8_t* __restrict__ mask, float drop_scale, int nchunk,
+                                                       float* __restrict__ part) {
+  extern __shared__ float shf[];                // [rpp][C][2]
+  const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk, cg = C / G;
+  const int p0 = (int)((long)HW * ch / nchunk), p1 = (int)((long)HW * (ch + 1) / nchunk);
+  GnMap m; m.init(C);
+  float mu[GN_MAXQ][4], rs[GN_MAXQ][4], ga[GN_MAXQ][4], be[GN_MAXQ][4], ca[GN_MAXQ][4], cb[GN_MAXQ][4];
+#pragma unroll
+  for (int j = 0; j < GN_MAXQ; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ca[j][e] = 0.f; cb[j][e] = 0.f;
+      if (j < m.nq) {
+        const int c = 4 * (m.ql + j * m.qw) + e, gi = c / cg;
+        mu[j][e] = mean[b * G + gi]; rs[j][e] = rstd[b * G + gi]; ga[j][e] = gamma[c]; be[j][e] = beta[c];
+      }
+    }
+  const float* xb = x + (size_t)b * HW * ldx;
+  const float* dyb = dy + (size_t)b * HW * C;
+  const uint8_t* mb = mask ? mask + (size_t)b * HW * C : nullptr;
+  for (int p = p0 + m.r; p < p1; p += m.rpp) {
+#pragma unroll
+    for (int j = 0; j < GN_MAXQ; ++j)
+      if (j < m.nq) {
+        const int c0 = 4 * (m.ql + j * m.qw);
+        const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)p * ldx + c0);
+        const float4 dv = *reinterpret_cast<const float4*>(dyb + (size_t)p * C + c0);
+        uchar4 mk = make_uchar4(1, 1, 1, 1);
+        if (mb) mk = *reinterpret_cast<const uchar4*>(mb + (size_t)p * C + c0);
+        const float xv[4] = {v.x, v.y, v.z, v.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+        const uint8_t mke[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (xv[e] - mu[j][e]) * rs[j][e];
+          float d = dd[e];
+          if (mb) d = mke[e] ? d * drop_scale : 0.f;
+          if (swish) d *= silu_grad(xh * ga[j][e] + be[j][e]);
+          ca[j][e] += d * xh; cb[j][e] += d;
+        }
+      }
+  }
+  if (m.r < m.rpp) {
+#pragma unroll
+    for (int j = 0; j < GN_MAXQ; ++j)
+      if (j < m.nq)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = 4 * (m.ql + j * m.qw) + e;
+          shf[((size_t)m.r * C + c) * 2] = ca[j][e]; shf[((size_t)m.r * C + c) * 2 + 1] = cb[j][e];
+        }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += TPB) {
+    float a = 0.f, q = 0.f;
+    for (int r = 0; r < m.rpp; ++r) { a += shf[((size_t)r * C + c) * 2]; q += shf[((size_t)r * C + c) * 2 + 1]; }
+    float* o = part + (((size_t)b * nchunk + ch) * C + c) * 2;
+    o[0] = a; o[1] = q;
+  }
+}
+// phase 2 backward: per-channel sums over the chunks -> (chunk 0) the per-sample parameter-gradient partials, the group means
+// k1 = mean(dz gamma), k2 = mean(dz gamma xhat); dx (+)= rstd (dz gamma - k1 - xhat k2)
+__global__ __launch_bounds__(TPB) void k_gn2_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, int ldx,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd, int HW, int C, int G,
+                                                       int swish, const uint8_t* __restrict__ mask, float drop_scale, int nchunk,
+                                                       const float* __restrict__ part, float* __restrict__ dx, int lddx, int accumulate,
+                                                       float* __restrict__ pg, float* __restrict__ pb) {
+  extern __shared__ float shf[];                // [C][2] channel sums, then [G][2] group means
+  const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk, cg = C / G;
+  float* kk = shf + 2 * C;
+  for (int c = threadIdx.x; c < C; c += TPB) {
+    float a = 0.f, q = 0.f;
+    for (int k = 0; k < nchunk; ++k) { const float* o = part + (((size_t)b * nchunk + k) * C + c) * 2; a += o[0]; q += o[1]; }
+    shf[2 * c] = a; shf[2 * c + 1] = q;
+    if (ch == 0) { pg[(size_t)b * C + c] = a; pb[(size_t)b * C + c] = q; }
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int c = threadIdx.x * cg; c < (threadIdx.x + 1) * cg; ++c) { const float g1 = gamma[c]; t1 += g1 * shf[2 * c + 1]; t2 += g1 * shf[2 * c]; }
+    const float inv = 1.0f / ((float)HW * (float)cg);
+    kk[2 * threadIdx.x] = t1 * inv; kk[2 * threadIdx.x + 1] = t2 * inv;
+  }
+  __syncthreads();
+  const int p0 = (int)((long)HW * ch / nchunk), p1 = (int)((long)HW * (ch + 1) / nchunk);
+  GnMap m; m.init(C);
+  float mu[GN_MAXQ][4], rs[GN_MAXQ][4], ga[GN_MAXQ][4], be[GN_MAXQ][4], k1[GN_MAXQ][4], k2[GN_MAXQ][4];
+#pragma unroll
+  for (int j = 0; j < GN_MAXQ; ++j)
+    if (j < m.nq)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * (m.ql + j * m.qw) + e, gi = c / cg;
+        mu[j][e] = mean[b * G + gi]; rs[j][e] = rstd[b * G + gi]; ga[j][e] = gamma[c]; be[j][e] = beta[c];
+        k1[j][e] = kk[2 * gi]; k2[j][e] = kk[2 * gi + 1];
+      }
+  const float* xb = x + (size_t)b * HW * ldx;
+  const float* dyb = dy + (size_t)b * HW * C;
+  const uint8_t* mb = mask ? mask + (size_t)b * HW * C : nullptr;
+  float* dxb = dx + (size_t)b * HW * lddx;
+  for (int p = p0 + m.r; p < p1; p += m.rpp) {
+#pragma unroll
+    for (int j = 0; j < GN_MAXQ; ++j)
+      if (j < m.nq) {
+        const int c0 = 4 * (m.ql + j * m.qw);
+        const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)p * ldx + c0);
+        const float4 dv = *reinterpret_cast<const float4*>(dyb + (size_t)p * C + c0);
+        uchar4 mk = make_uchar4(1, 1, 1, 1);
+        if (mb) mk = *reinterpret_cast<const uchar4*>(mb + (size_t)p * C + c0);
+        const float xv[4] = {v.x, v.y, v.z, v.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+        const uint8_t mke[4] = {mk.x, mk.y, mk.z, mk.w};
+        float4* op = reinterpret_cast<float4*>(dxb + (size_t)p * lddx + c0);
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (accumulate) { const float4 c = *op; o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (xv[e] - mu[j][e]) * rs[j][e];
+          float d = dd[e];
+          if (mb) d = mke[e] ? d * drop_scale : 0.f;
+          if (swish) d *= silu_grad(xh * ga[j][e] + be[j][e]);
+          const float vv = rs[j][e] * (d * ga[j][e] - k1[j][e] - xh * k2[j][e]);
+          o[e] = accumulate ? o[e] + vv : vv;
+        }
+        *op = make_float4(o[0], o[1], o[2], o[3]);
+      }
   }
 }
 
@@ -1084,6 +1333,16 @@ int launch_bgemm(const BGemmArgs& g, int nbatch, hipStream_t s, int ninner = 1) 
   return e == hipSuccess ? SFRON_OK : (int)e;
 }
 
+// debug build only (tools/ A-B runs): SFRON_NO_CGEMM=1 keeps every product on the generic k_bgemm tile; bit i of SFRON_NO_CGEMM
+// disables: 1 direct tile, 2 Linear input gradient, 4 plain weight gradient, 8 convolution weight gradient
+inline int cgemm_off() {
+#ifdef SFRON_DEBUG_KNOBS
+  static const int v = [] { const char* e = getenv("SFRON_NO_CGEMM"); return e ? atoi(e) : 0; }();
+  return v;
+#else
+  return 0;
+#endif
+}
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per function AND per device
 inline bool need_attr(std::atomic<uint64_t>& mask) {
   int dev = 0;
@@ -1107,6 +1366,7 @@ int launch_cgemm_t(const BGemmArgs& g, unsigned a_bytes, unsigned b_bytes, int n
 }
 // the pipelined tile when the product qualifies (-1: it does not, the caller launches k_bgemm)
 int try_cgemm(const BGemmArgs& g, bool conv, size_t a_rows, int nsplit, hipStream_t s) {
+  if (cgemm_off() & 1) return -1;
   if (g.M % 256 || g.K % BK || g.N % 4 || (g.kchunk > 0 && g.kchunk % BK)) return -1;
   if (conv && (g.cg.C % BK || (g.cg.taps != 9 && g.cg.taps != 1))) return -1;
   if ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) || g.lda % 8 || g.ldb % 8) return -1;
@@ -1139,6 +1399,7 @@ int launch_cgemm_tt(const BGemmArgs& g, size_t p_bytes, size_t q_bytes, unsigned
 inline bool fits31(size_t b) { return b < 0x7ffffff0ull; }
 // Linear input gradient (A direct [M][K], B read transposed [K][N]) on the pipelined tile; -1 = not eligible
 int try_cgemm_dt(const BGemmArgs& g, hipStream_t s) {
+  if (cgemm_off() & 2) return -1;
   if (g.M % 256 || g.K % BK || g.N % 8 || g.lda % 8 || g.ldb % 8 || (((uintptr_t)g.A | (uintptr_t)g.B) & 15)) return -1;
   const size_t pb = ((size_t)(g.M - 1) * g.lda + g.K) * 2, qb = ((size_t)(g.K - 1) * g.ldb + g.N) * 2;
   if (!fits31(pb) || !fits31(qb) || !fits31((size_t)g.K * g.ldb * 2 + 4096)) return -1;
@@ -1146,6 +1407,7 @@ int try_cgemm_dt(const BGemmArgs& g, hipStream_t s) {
 }
 // plain weight gradient (both operands read transposed, contraction over the rows), fp32 result; -1 = not eligible
 bool tt_ok(const BGemmArgs& g) {
+  if (cgemm_off() & 4) return false;
   if (g.K % BK || g.M % 8 || g.N % 8 || g.lda % 8 || g.ldb % 8 || (((uintptr_t)g.A | (uintptr_t)g.B) & 15) || !g.Cf) return false;
   if (g.kchunk > 0 && g.kchunk % BK) return false;
   return fits31(((size_t)g.K * g.lda + 4096) * 2) && fits31(((size_t)g.K * g.ldb + 4096) * 2);
@@ -1272,6 +1534,7 @@ int sfron_conv_fwd(const sfron_conv_desc* d, const uint16_t* src, const uint16_t
 
 /* weight gradient: dw[n][tap][c] = sum_p dy[p][n] src[src(p, tap)][c]  (fp32 [n_out][taps * c_src], then k_conv_wgrad_scatter) */
 static bool conv_wgrad_pipelined(const sfron_conv_desc* d) {
+  if (cgemm_off() & 8) return false;
   const long K = (long)d->batch * d->h_out * d->w_out;
   return K % BK == 0 && K >= 256 && d->c_src % 8 == 0 && d->n_out % 8 == 0 && d->h_out >= 2 && d->w_out >= 2 && d->n_out >= 64 &&
          d->taps * d->c_src >= 64 && K < (1l << 21) && d->w_out <= 2048 && d->h_out <= 2048;
@@ -1348,9 +1611,35 @@ int sfron_rows_to_nchw(const float* rows, int ld, int B, int C, int HW, float* x
   return SFRON_OK;
 }
 
+/* scratch (bytes) the row-coalesced GroupNorm needs for a [B][HW][C] activation: per-chunk partial sums (forward fp64 per group,
+ * backward fp32 per channel) */
+int64_t sfron_groupnorm_scratch_bytes(int B, int HW, int C, int groups) {
+  if (B <= 0 || HW <= 0 || C <= 0 || groups <= 0) return 0;
+  const int64_t n = gn_chunks(B, HW);
+  const int64_t f = (int64_t)B * n * groups * 2 * sizeof(double), bw = (int64_t)B * n * C * 2 * sizeof(float);
+  return f > bw ? f : bw;
+}
+static bool gn2_ok(int ldx, int ld2, int C, int groups, const void* scratch) {
+  return scratch && C % 4 == 0 && ldx % 4 == 0 && ld2 % 4 == 0 && C <= GN_MAXQ * 4 * TPB && groups <= 64 && ((uintptr_t)scratch & 15) == 0;
+}
+static size_t gn2_lds(int C, int elem) {
+  const int qpr = C / 4, qw = qpr < TPB ? qpr : TPB, rpp = TPB / qw;
+  return (size_t)rpp * C * 2 * elem;
+}
 int sfron_groupnorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, int B, int HW, int C, int groups, float eps,
-                        int swish, const uint8_t* drop_mask, float drop_scale, uint16_t* y, float* mean, float* rstd, void* stream) {
-  SFRON_CHECK_ARG(x && gamma && beta && y && mean && rstd && groups > 0 && C % groups == 0 && ldx >= C);
+                        int swish, const uint8_t* drop_mask, float drop_scale, uint16_t* y, float* mean, float* rstd, void* scratch,
+                        void* stream) {
+  SFRON_CHECK_ARG(x && gamma && beta && y && mean && rstd && groups > 0 && C % groups == 0 && ldx >= C && C / groups <= TPB);
+  if (gn2_ok(ldx, C, C, groups, scratch) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 && (!drop_mask || ((uintptr_t)drop_mask & 3) == 0)) {
+    const int nchunk = gn_chunks(B, HW);
+    hipLaunchKernelGGL(k_gn2_stats, dim3(B * nchunk), dim3(TPB), gn2_lds(C, sizeof(double)), (hipStream_t)stream, x, ldx, HW, C, groups, nchunk,
+                       (double*)scratch);
+    SFRON_LAUNCH_STATUS();
+    hipLaunchKernelGGL(k_gn2_apply, dim3(B * nchunk), dim3(TPB), 0, (hipStream_t)stream, x, ldx, gamma, beta, HW, C, groups, eps, swish, drop_mask,
+                       drop_scale, nchunk, (const double*)scratch, (__bf16*)y, mean, rstd);
+    SFRON_LAUNCH_STATUS();
+    return SFRON_OK;
+  }
   hipLaunchKernelGGL(k_gn_fwd, dim3(B * groups), dim3(TPB), 0, (hipStream_t)stream, x, ldx, gamma, beta, HW, C, groups, eps, swish, drop_mask,
                      drop_scale, (__bf16*)y, mean, rstd);
   SFRON_LAUNCH_STATUS();
@@ -1358,9 +1647,22 @@ int sfron_groupnorm_fwd(const float* x, int ldx, const float* gamma, const float
 }
 int sfron_groupnorm_bwd(const float* dy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
                         const float* rstd, int B, int HW, int C, int groups, int swish, const uint8_t* drop_mask, float drop_scale,
-                        float* dx, int lddx, int accumulate, float* part_gamma, float* part_beta, void* stream) {
+                        float* dx, int lddx, int accumulate, float* part_gamma, float* part_beta, void* scratch, void* stream) {
   SFRON_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && part_gamma && part_beta && groups > 0 && C % groups == 0);
   const int cg = C / groups;
+  SFRON_CHECK_ARG(cg <= TPB);
+  if (gn2_ok(ldx, lddx, C, groups, scratch) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0 &&
+      (!drop_mask || ((uintptr_t)drop_mask & 3) == 0)) {
+    const int nchunk = gn_chunks(B, HW);
+    hipLaunchKernelGGL(k_gn2_bwd_stats, dim3(B * nchunk), dim3(TPB), gn2_lds(C, sizeof(float)), (hipStream_t)stream, dy, x, ldx, gamma, beta, mean, rstd,
+                       HW, C, groups, swish, drop_mask, drop_scale, nchunk, (float*)scratch);
+    SFRON_LAUNCH_STATUS();
+    hipLaunchKernelGGL(k_gn2_bwd_apply, dim3(B * nchunk), dim3(TPB), (size_t)(2 * C + 2 * groups) * sizeof(float), (hipStream_t)stream, dy, x, ldx, gamma,
+                       beta, mean, rstd, HW, C, groups, swish, drop_mask, drop_scale, nchunk, (const float*)scratch, dx, lddx, accumulate,
+                       part_gamma, part_beta);
+    SFRON_LAUNCH_STATUS();
+    return SFRON_OK;
+  }
   const size_t lds = (2 * (TPB / 64) + 2 * cg + 2 * TPB) * sizeof(float);
   hipLaunchKernelGGL(k_gn_bwd, dim3(B * groups), dim3(TPB), lds, (hipStream_t)stream, dy, x, ldx, gamma, beta, mean, rstd, HW, C, groups, swish,
                      drop_mask, drop_scale, dx, lddx, accumulate, part_gamma, part_beta);

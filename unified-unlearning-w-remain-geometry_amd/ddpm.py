@@ -207,8 +207,9 @@ class DDPMSFRon:
 
     def __init__(self, model, betas=None, lr=1e-4, forget_alpha=10.0, remain_alpha=1.0, grad_clip=1.0, ema_rate=None, mask=None,
                  unlearn_loss="adaga", lambd=0.5, n_iters=50, decay_forget_alpha=True, cond_drop_prob=0.1, process_group=None,
-                 label_to_forget=0, n_classes=10):
+                 label_to_forget=0, n_classes=10, use_graphs=False):
         from . import dp, sweep
+        self.use_graphs, self._graphs, self._pool = bool(use_graphs), {}, None
         if unlearn_loss not in ("ga", "adaga", "rl"):
             raise ValueError(f"unsupported unlearn_loss {unlearn_loss!r} (DDPM/runners/diffusion.py:1095-1120 defines ga, rl, adaga)")
         self.label_to_forget, self.n_classes = label_to_forget, n_classes
@@ -257,24 +258,49 @@ class DDPMSFRon:
     def _backward(self, loss):
         self.flat.g.zero_()                                       # optimizer.zero_grad()
         loss.backward()
-        if self.world > 1:
-            self._dp.allreduce_flat_(self.flat.g, 64 << 20, self.pg)
+
+    # the two stages (forward pass(es), loss, backward pass): stream-ordered device work only, so each can replay as one HIP graph
+    # (sfron.graphs); the decayed forget alpha arrives as a device scalar
+    def _forget_pass(self, alpha, **batch):
+        if self.unlearn_loss == "rl":
+            ori_forget = self._loss(batch, "rl")
+        else:
+            ori_forget = -self._loss(batch, "adaga" if self.unlearn_loss == "adaga" else "simple")
+        self._backward(alpha * ori_forget)
+        return ori_forget.detach()
+
+    def _remain_pass(self, **batch):
+        ori_remain = self._loss(batch, "simple")
+        self._backward(self.remain_alpha * ori_remain)
+        return ori_remain.detach()
+
+    def _stage(self, name, fn, **inputs):
+        # the adaga normaliser of a data-parallel run is a collective in the middle of the stage: those runs stay eager
+        if not self.use_graphs or (self.world > 1 and self.unlearn_loss == "adaga" and name == "forget"):
+            return fn(**inputs)
+        if name not in self._graphs:
+            from . import graphs
+            if self._pool is None:
+                self._pool = graphs.shared_pool()
+            self._graphs[name] = graphs.StageGraph(fn, warmup=1, pool=self._pool)
+        return self._graphs[name](**inputs)
 
     def step(self, step_idx, forget, remain):
         alpha = cosine_lr_scheduler(self.forget_alpha, step_idx, self.n_iters) if self.decay else self.forget_alpha
         self.model.train()
-        if self.unlearn_loss == "rl":
-            ori_forget = self._loss(forget, "rl")
-        else:
-            ori_forget = -self._loss(forget, "adaga" if self.unlearn_loss == "adaga" else "simple")
-        self._backward(alpha * ori_forget)
+        keys = ("x0", "c", "t", "e", "keep_mask")
+        a_dev = torch.full((), float(alpha), dtype=torch.float32, device=self.flat.p.device) if self.use_graphs else alpha
+        ori_forget = self._stage("forget", self._forget_pass, alpha=a_dev, **{k: forget.get(k) for k in keys})
+        if self.world > 1:
+            self._dp.allreduce_flat_(self.flat.g, 64 << 20, self.pg)
         self.opt.step(max_norm=self.grad_clip, use_mask=True)
         self._weights_updated()
-        ori_remain = self._loss(remain, "simple")
-        self._backward(self.remain_alpha * ori_remain)
+        ori_remain = self._stage("remain", self._remain_pass, **{k: remain.get(k) for k in keys})
+        if self.world > 1:
+            self._dp.allreduce_flat_(self.flat.g, 64 << 20, self.pg)
         self.opt.step(max_norm=self.grad_clip, use_mask=False, ema=self.shadow, ema_decay=self.mu if self.mu is not None else 0.0, ema_mode=2)
         self._weights_updated()
-        return {"forget_loss": ori_forget.detach(), "remain_loss": ori_remain.detach(), "alpha": alpha}
+        return {"forget_loss": ori_forget, "remain_loss": ori_remain, "alpha": alpha}
 
     def ema_state_dict(self):
         return {n: v.clone() for n, v in self.flat.named_views(self.shadow).items()}

@@ -13,7 +13,7 @@ Latents and prompt embeddings arrive resident on the device (the VAE / CLIP fron
 import numpy as np
 import torch
 
-from . import _lib, sweep
+from . import _lib, graphs, sweep
 from ._lib import check, ptr, stream_ptr
 
 
@@ -41,8 +41,9 @@ class LDMSchedule:
 
 class SDSFRon:
     def __init__(self, unet, schedule=None, lr=1e-5, forget_alpha=1.0, remain_alpha=1.0, train_method="full", mask=None,
-                 mask_mode="as_written", process_group=None):
+                 mask_mode="as_written", process_group=None, use_graphs=False):
         from . import dp
+        self.use_graphs, self._graphs, self._pool = bool(use_graphs), {}, (graphs.shared_pool() if use_graphs else None)
         if train_method not in ("full", "xattn"):
             raise ValueError("train_method must be 'full' or 'xattn' (nsfw_removal.py:66-77)")
         if mask_mode not in ("as_written", "intended"):
@@ -75,16 +76,14 @@ class SDSFRon:
         self.opt = sweep.FlatAdam(p, g, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adamw=True, mask=self.train_mask, w_bf16=w16)
         unet.auto_prep = False                      # this loop tells the model when its weights changed
 
-    def _backward(self, out, target, scale):
-        """d(scale * mean((out - target)^2)) / d out through the HIP loss kernels, then the UNet's backward pass."""
+    def _d_loss(self, out, target, scale):
+        """d(scale * mean((out - target)^2)) / d out through the HIP loss kernel (this rank's share of the global batch mean)."""
         n, chw = out.shape[0], out[0].numel()
         coef = torch.full((n,), 2.0 * scale / (n * chw * self.world), dtype=torch.float32, device=out.device)
         d = torch.empty_like(out)
         tg, oc = target.contiguous(), out.contiguous()
         check(_lib.lib().sfron_ddpm_loss_bwd(ptr(tg), ptr(oc), ptr(coef), n, chw, ptr(d), stream_ptr()), "loss_bwd")
-        out.backward(d)
-        if self.world > 1:
-            self._dp.allreduce_flat_(self.opt.g, 64 << 20, self.pg)
+        return d
 
     def _mse(self, a, b):
         n, chw = a.shape[0], a[0].numel()
@@ -93,23 +92,42 @@ class SDSFRon:
         check(_lib.lib().sfron_ddpm_sample_loss(ptr(bc), ptr(ac), n, chw, ptr(per), stream_ptr()), "sample_loss")
         return per.sum() / (n * chw)
 
+    # the two stages: forward pass(es), loss, backward pass -- stream-ordered device work only, so each replays as one HIP graph
+    def _forget_pass(self, x_f, x_p, c_f, c_p, t, noise):
+        u, s = self.unet, self.s
+        f_noisy, p_noisy = s.q_sample(x_f, t, noise), s.q_sample(x_p, t, noise)          # the SAME t and noise (:134-141)
+        p_out, _ = u._run(p_noisy, t, c_p, need_grad=False)                               # stop-gradient branch (:145)
+        f_out, bwd = u._run(f_noisy, t, c_f, need_grad=True)
+        loss = self._mse(f_out, p_out)
+        bwd(self._d_loss(f_out, p_out, self.fa))
+        return loss
+
+    def _remain_pass(self, x, c, t, noise):
+        r_out, bwd = self.unet._run(self.s.q_sample(x, t, noise), t, c, need_grad=True)
+        loss = self._mse(r_out, noise)
+        bwd(self._d_loss(r_out, noise, self.ra))
+        return loss
+
+    def _stage(self, name, fn, **inputs):
+        if not self.use_graphs:
+            return fn(**inputs)
+        if name not in self._graphs:
+            self._graphs[name] = graphs.StageGraph(fn, warmup=1, pool=self._pool)
+        return self._graphs[name](**inputs)
+
     def step(self, forget, remain):
         """forget: dict(x_f, x_p, c_f, c_p, t, noise); remain: dict(x, c, t, noise) -- device tensors, this rank's shard."""
-        u, s = self.unet, self.s
+        u = self.unet
         u.train()
-        f_noisy = s.q_sample(forget["x_f"], forget["t"], forget["noise"])
-        p_noisy = s.q_sample(forget["x_p"], forget["t"], forget["noise"])
-        with torch.no_grad():
-            p_out = u(p_noisy, forget["t"], context=forget["c_p"])
-        f_out = u(f_noisy, forget["t"], context=forget["c_f"])
-        ori_forget = self._mse(f_out, p_out)
-        self._backward(f_out, p_out, self.fa)
+        ori_forget = self._stage("forget", self._forget_pass, **{k: forget[k] for k in ("x_f", "x_p", "c_f", "c_p", "t", "noise")})
+        if self.world > 1:
+            self._dp.allreduce_flat_(self.opt.g, 64 << 20, self.pg)
         self.opt.mask = self.forget_mask
         self.opt.step(max_norm=None, use_mask=True)                       # nsfw_removal.py:162 (no clipping)
         u.weights_updated()
-        r_out = u(s.q_sample(remain["x"], remain["t"], remain["noise"]), remain["t"], context=remain["c"])
-        ori_remain = self._mse(r_out, remain["noise"])
-        self._backward(r_out, remain["noise"], self.ra)
+        ori_remain = self._stage("remain", self._remain_pass, **{k: remain[k] for k in ("x", "c", "t", "noise")})
+        if self.world > 1:
+            self._dp.allreduce_flat_(self.opt.g, 64 << 20, self.pg)
         self.opt.mask = self.train_mask
         self.opt.step(max_norm=None, use_mask=True)                       # :170
         u.weights_updated()

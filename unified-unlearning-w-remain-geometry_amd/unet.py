@@ -247,15 +247,17 @@ class _TapeNet(nn.Module):
         rstd = torch.empty_like(mean)
         scale = 1.0 / (1.0 - self.dropout_p) if drop_mask is not None else 1.0
         gam, bet = self._p(name + ".weight"), self._p(name + ".bias")
+        ws = torch.empty(_L().sfron_groupnorm_scratch_bytes(x.B, x.H * x.W, x.C, 32) // 8 + 2, dtype=torch.float64, device=dev)   # per-chunk partial sums
         check(_L().sfron_groupnorm_fwd(ptr(x.t), x.C, gam, bet, x.B, x.H * x.W, x.C, 32, eps, int(swish), ptr(drop_mask), scale, ptr(y),
-                                       ptr(mean), ptr(rstd), stream_ptr()), "groupnorm_fwd")
+                                       ptr(mean), ptr(rstd), ptr(ws), stream_ptr()), "groupnorm_fwd")
 
         def bwd(dy):           # dy: fp32 [rows][C]
             gbuf, acc = x.grad_buf()
             pg = torch.empty(x.B, x.C, dtype=torch.float32, device=dev)
             pb = torch.empty_like(pg)
+            ws2 = torch.empty(_L().sfron_groupnorm_scratch_bytes(x.B, x.H * x.W, x.C, 32) // 8 + 2, dtype=torch.float64, device=dev)
             check(_L().sfron_groupnorm_bwd(ptr(dy), ptr(x.t), x.C, gam, bet, ptr(mean), ptr(rstd), x.B, x.H * x.W, x.C, 32, int(swish),
-                                           ptr(drop_mask), scale, ptr(gbuf), x.C, acc, ptr(pg), ptr(pb), stream_ptr()), "groupnorm_bwd")
+                                           ptr(drop_mask), scale, ptr(gbuf), x.C, acc, ptr(pg), ptr(pb), ptr(ws2), stream_ptr()), "groupnorm_bwd")
             check(_L().sfron_reduce_chunks(ptr(pg), 1, x.B, x.C, self._g(name + ".weight"), x.C, 0, stream_ptr()), "reduce")
             check(_L().sfron_reduce_chunks(ptr(pb), 1, x.B, x.C, self._g(name + ".bias"), x.C, 0, stream_ptr()), "reduce")
         return y, bwd
