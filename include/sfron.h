@@ -248,10 +248,10 @@ int64_t sfron_groupnorm_scratch_bytes(int B, int HW, int C, int groups);
 int sfron_softmax_fwd(const float* s, int64_t rows, int n, int n_valid /* keys; columns beyond get probability 0 */, float scale, uint16_t* p,
                       void* stream);
 /* y = bf16(LayerNorm(x; eps) * gamma + beta) on fp32 rows [rows][D]; backward: dx (+)=, per-block partial sums of d gamma / d beta
- * [ceil(rows / sfron_layernorm_rows_per_block())][D] (BasicTransformerBlock.norm1..3, SD/ldm/modules/attention.py:223-225) */
+ * [ceil(rows / sfron_layernorm_rows_per_block(rows))][D] (BasicTransformerBlock.norm1..3, SD/ldm/modules/attention.py:223-225) */
 int sfron_layernorm_fwd(const float* x, const float* gamma, const float* beta, int64_t rows, int D, float eps, uint16_t* y, float* mean,
                         float* rstd, void* stream);
-int sfron_layernorm_rows_per_block(void);
+int sfron_layernorm_rows_per_block(int64_t rows);
 int sfron_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, int64_t rows, int D, float* dx,
                         int accumulate, float* part_gamma, float* part_beta, void* stream);
 /* GEGLU (attention.py:37-45): h fp32 [rows][2F] = value || gate; out = bf16(value * gelu_erf(gate)); backward dh bf16 [rows][2F] */

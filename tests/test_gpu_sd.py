@@ -39,7 +39,8 @@ def test_layernorm_affine_fwd_bwd(rows, D):
     xd, gd, bd = x.to(DEV), gam.to(DEV), bet.to(DEV)
     check(L.sfron_layernorm_fwd(ptr(xd), ptr(gd), ptr(bd), rows, D, 1e-5, ptr(y), ptr(mean), ptr(rstd), stream_ptr()), "ln_fwd")
     np.testing.assert_allclose(y.float().cpu().numpy(), ref.detach().numpy(), rtol=1e-2, atol=1e-2)
-    nblk = (rows + L.sfron_layernorm_rows_per_block() - 1) // L.sfron_layernorm_rows_per_block()
+    rpb = L.sfron_layernorm_rows_per_block(rows)
+    nblk = (rows + rpb - 1) // rpb
     dx = torch.full((rows, D), 0.25, device=DEV)
     pg, pb = torch.empty(nblk, D, device=DEV), torch.empty(nblk, D, device=DEV)
     dyd = dy.to(DEV)

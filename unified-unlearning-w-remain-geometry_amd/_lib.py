@@ -124,7 +124,7 @@ _PROTOS.update({
     "sfron_groupnorm_scratch_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "sfron_softmax_fwd": (c_int, [_P, c_int64, c_int, c_int, c_float, _P, _S]),
     "sfron_layernorm_fwd": (c_int, [_P, _P, _P, c_int64, c_int, c_float, _P, _P, _P, _S]),
-    "sfron_layernorm_rows_per_block": (c_int, []),
+    "sfron_layernorm_rows_per_block": (c_int, [c_int64]),
     "sfron_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P, _P, _S]),
     "sfron_geglu_fwd": (c_int, [_P, c_int64, c_int, _P, _S]),
     "sfron_geglu_bwd": (c_int, [_P, _P, c_int64, c_int, _P, _S]),

@@ -705,6 +705,29 @@ __global__ __launch_bounds__(TPB) void k_conv_wprep(const float* __restrict__ w,
     }
   }
 }
+// the same for the large 3x3 kernels of the LDM UNet through an LDS tile of 32 output x 32 input channels (bf16 [32][32][9]): the OIHW
+// master is read in contiguous runs of 32 * 9 floats, the forward operand is written in runs of 32 input channels per (co, tap),
+// the input-gradient operand in runs of 32 output channels per (ci, flipped tap).  grid = (ceil(Ci_p / 32), ceil(Co_p / 32)).
+__global__ __launch_bounds__(TPB) void k_conv_wprep9(const float* __restrict__ w, int Co, int Ci, int Co_p, int Ci_p, __bf16* __restrict__ fwd,
+                                                     __bf16* __restrict__ dgr) {
+  __shared__ __bf16 t[32][32 * 9 + 2];
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  for (int i = threadIdx.x; i < 32 * 288; i += TPB) {
+    const int co = i / 288, k = i - co * 288, ci = k / 9;
+    const bool in = co0 + co < Co && ci0 + ci < Ci;
+    t[co][k] = in ? f2bf(w[((int64_t)(co0 + co) * Ci + ci0) * 9 + k]) : (__bf16)0.0f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * 9 * 32; i += TPB) {          // fwd [Co_p][9][Ci_p]
+    const int ci = i & 31, tp = (i >> 5) % 9, co = i / 288;
+    if (co0 + co < Co_p && ci0 + ci < Ci_p) fwd[((int64_t)(co0 + co) * 9 + tp) * Ci_p + ci0 + ci] = t[co][ci * 9 + tp];
+  }
+  if (dgr)
+    for (int i = threadIdx.x; i < 32 * 9 * 32; i += TPB) {        // dgr [Ci][9 flipped][Co_p]
+      const int co = i & 31, tp = (i >> 5) % 9, ci = i / 288;
+      if (co0 + co < Co_p && ci0 + ci < Ci) dgr[((int64_t)(ci0 + ci) * 9 + tp) * Co_p + co0 + co] = t[co][ci * 9 + (8 - tp)];
+    }
+}
 // weight gradient fp32 [nslab][Co_p][taps][Ci_p] (GEMM output, split-K slabs) -> OIHW gradient (overwrite; slabs added in order)
 __global__ __launch_bounds__(TPB) void k_conv_wgrad_scatter(const float* __restrict__ g, int Co, int Ci, int taps, int Ci_p, int nslab,
                                                             int64_t slab_stride, float* __restrict__ dw) {
@@ -1180,6 +1203,57 @@ __global__ __launch_bounds__(TPB) void k_layernorm_bwd(const float* __restrict__
     pg[(size_t)blockIdx.x * D + i] = a; pb[(size_t)blockIdx.x * D + i] = b;
   }
 }
+// the same with the row and the per-column accumulators in registers (D <= 64 * NC): x and dy are read once, nothing but the final
+// per-wave sums goes through LDS.  Sums are formed in the order of k_layernorm_bwd (bitwise the same results).
+template <int NC>
+__global__ __launch_bounds__(TPB) void k_layernorm_bwd_r(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd, int64_t rows, int D,
+                                                         float* __restrict__ dx, int accumulate, float* __restrict__ pg, float* __restrict__ pb,
+                                                         int rows_per_block) {
+  extern __shared__ float sh[];                     // [4 waves][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ag[NC], ab[NC], gm[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) { ag[j] = 0.f; ab[j] = 0.f; const int i = lane + 64 * j; gm[j] = i < D ? gamma[i] : 0.f; }
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  for (int64_t row = r0 + wave; row < r0 + rows_per_block && row < rows; row += TPB / 64) {
+    const float m = mean[row], r = rstd[row];
+    const float* xr = x + row * D;
+    const float* dr = dy + row * D;
+    float xh[NC], dv[NC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int i = lane + 64 * j;
+      const bool in = i < D;
+      xh[j] = in ? (xr[i] - m) * r : 0.f; dv[j] = in ? dr[i] : 0.f;
+      const float d = dv[j] * gm[j];
+      s1 += d; s2 += d * xh[j];
+      ag[j] += dv[j] * xh[j]; ab[j] += dv[j];
+    }
+    s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int i = lane + 64 * j;
+      if (i < D) {
+        const float v = r * (dv[j] * gm[j] - s1 - xh[j] * s2);
+        float* o = dx + row * D + i;
+        *o = accumulate ? *o + v : v;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int i = lane + 64 * j;
+    if (i < D) { sh[(size_t)wave * 2 * D + i] = ag[j]; sh[(size_t)wave * 2 * D + D + i] = ab[j]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D; i += TPB) {
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < TPB / 64; ++w) { a += sh[(size_t)w * 2 * D + i]; b += sh[(size_t)w * 2 * D + D + i]; }
+    pg[(size_t)blockIdx.x * D + i] = a; pb[(size_t)blockIdx.x * D + i] = b;
+  }
+}
 // GEGLU (attention.py:37-45): h [rows][2F] = value || gate -> out = bf16(value * gelu(gate)), exact (erf) GELU as F.gelu
 __global__ __launch_bounds__(TPB) void k_geglu_fwd(const float* __restrict__ h, int64_t rows, int F, __bf16* __restrict__ out) {
   const int64_t n = rows * F;
@@ -1577,6 +1651,12 @@ int sfron_conv_wgrad(const sfron_conv_desc* d, const uint16_t* dy, int ld_dy, co
 int sfron_conv_wprep(const float* w_oihw, int c_out, int c_in, int taps, int c_out_p, int c_in_p, uint16_t* w_fwd, uint16_t* w_dgrad,
                      void* stream) {
   SFRON_CHECK_ARG(w_oihw && w_fwd && c_out_p >= c_out && c_in_p >= c_in && (taps == 9 || taps == 1));
+  if (taps == 9 && (int64_t)c_in_p * c_out_p >= 256 * 1024) {
+    hipLaunchKernelGGL(k_conv_wprep9, dim3((c_in_p + 31) / 32, (c_out_p + 31) / 32), dim3(TPB), 0, (hipStream_t)stream, w_oihw, c_out, c_in, c_out_p,
+                       c_in_p, (__bf16*)w_fwd, (__bf16*)w_dgrad);
+    SFRON_LAUNCH_STATUS();
+    return SFRON_OK;
+  }
   const int64_t n = (int64_t)c_out_p * taps * c_in_p + (w_dgrad ? (int64_t)c_in * taps * c_out_p : 0);
   hipLaunchKernelGGL(k_conv_wprep, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, w_oihw, c_out, c_in, taps, c_out_p, c_in_p,
                      (__bf16*)w_fwd, (__bf16*)w_dgrad);
@@ -1684,13 +1764,21 @@ int sfron_layernorm_fwd(const float* x, const float* gamma, const float* beta, i
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }
-int sfron_layernorm_rows_per_block(void) { return 64; }
+// rows per workgroup of the backward pass (= rows per partial parameter-gradient row): about 512 workgroups, 16 .. 64 rows each
+int sfron_layernorm_rows_per_block(int64_t rows) {
+  int64_t r = ((rows + 511) / 512 + 3) / 4 * 4;
+  return (int)(r < 16 ? 16 : (r > 64 ? 64 : r));
+}
 int sfron_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, int64_t rows, int D, float* dx,
                         int accumulate, float* part_gamma, float* part_beta, void* stream) {
   SFRON_CHECK_ARG(dy && x && gamma && mean && rstd && dx && part_gamma && part_beta && rows > 0 && D > 0 && D <= 4096);
-  const int rpb = 64;
-  hipLaunchKernelGGL(k_layernorm_bwd, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(TPB), (size_t)(TPB / 64) * 2 * D * sizeof(float),
-                     (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb);
+  const int rpb = sfron_layernorm_rows_per_block(rows);
+  const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
+  const size_t lds = (size_t)(TPB / 64) * 2 * D * sizeof(float);
+  if (D <= 320)       hipLaunchKernelGGL(k_layernorm_bwd_r<5>, grid, dim3(TPB), lds, (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb);
+  else if (D <= 640)  hipLaunchKernelGGL(k_layernorm_bwd_r<10>, grid, dim3(TPB), lds, (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb);
+  else if (D <= 1280) hipLaunchKernelGGL(k_layernorm_bwd_r<20>, grid, dim3(TPB), lds, (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb);
+  else hipLaunchKernelGGL(k_layernorm_bwd, grid, dim3(TPB), lds, (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

@@ -255,7 +255,15 @@ __global__ __launch_bounds__(TPB) void k_reduce2(const float* __restrict__ P0, c
   if (c >= D) return;
   const size_t base = (size_t)g * per_group * D + c;
   float s0 = 0.f, s1 = 0.f;
-  for (int j = 0; j < per_group; ++j) { s0 += P0[base + (size_t)j * D]; s1 += P1[base + (size_t)j * D]; }
+  int j = 0;
+  for (; j + 8 <= per_group; j += 8) {            // 16 loads in flight, summed in index order
+    float v0[8], v1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { v0[u] = P0[base + (size_t)(j + u) * D]; v1[u] = P1[base + (size_t)(j + u) * D]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s0 += v0[u]; s1 += v1[u]; }
+  }
+  for (; j < per_group; ++j) { s0 += P0[base + (size_t)j * D]; s1 += P1[base + (size_t)j * D]; }
   out0[(size_t)g * ld0 + c] = s0;
   out1[(size_t)g * ld1 + c] = s1;
 }

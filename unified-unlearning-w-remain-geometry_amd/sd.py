@@ -49,7 +49,7 @@ class SDSFRon:
         if mask_mode not in ("as_written", "intended"):
             raise ValueError("mask_mode must be 'as_written' or 'intended'")
         self.unet, self.s = unet, schedule or LDMSchedule(device=unet.device_)
-        self.fa, self.ra = forget_alpha, remain_alpha
+        self.fa, self.ra, self.train_method = forget_alpha, remain_alpha, train_method
         self.pg, self._dp, self.world = process_group, dp, dp.world_size(process_group)
         p, g, w16, index = unet.flat_arena()
         # which coordinates the optimizer owns: Adam leaves a coordinate whose gradient is always zero where it is
@@ -124,11 +124,11 @@ class SDSFRon:
             self._dp.allreduce_flat_(self.opt.g, 64 << 20, self.pg)
         self.opt.mask = self.forget_mask
         self.opt.step(max_norm=None, use_mask=True)                       # nsfw_removal.py:162 (no clipping)
-        u.weights_updated()
+        u.weights_updated(convs=self.train_method == "full")
         ori_remain = self._stage("remain", self._remain_pass, **{k: remain[k] for k in ("x", "c", "t", "noise")})
         if self.world > 1:
             self._dp.allreduce_flat_(self.opt.g, 64 << 20, self.pg)
         self.opt.mask = self.train_mask
         self.opt.step(max_norm=None, use_mask=True)                       # :170
-        u.weights_updated()
+        u.weights_updated(convs=self.train_method == "full")
         return {"forget_loss": ori_forget, "remain_loss": ori_remain}

@@ -172,13 +172,13 @@ class UNetModel(_TapeNet):
 
         def bwd(dy):
             g, acc = x.grad_buf()
-            nblk = (rows + 63) // 64
+            rpb = _L().sfron_layernorm_rows_per_block(rows)
+            nblk = (rows + rpb - 1) // rpb
             pg = torch.empty(nblk, D, dtype=torch.float32, device=dev)
             pb = torch.empty_like(pg)
             check(_L().sfron_layernorm_bwd(ptr(dy), ptr(x.t), gam, ptr(mean), ptr(rstd), rows, D, ptr(g), acc, ptr(pg), ptr(pb), stream_ptr()),
                   "layernorm_bwd")
-            check(_L().sfron_reduce_chunks(ptr(pg), 1, nblk, D, self._g(name + ".weight"), D, 0, stream_ptr()), "reduce")
-            check(_L().sfron_reduce_chunks(ptr(pb), 1, nblk, D, self._g(name + ".bias"), D, 0, stream_ptr()), "reduce")
+            check(_L().sfron_reduce2(ptr(pg), ptr(pb), 1, nblk, D, self._g(name + ".weight"), D, self._g(name + ".bias"), D, stream_ptr()), "reduce2")
         return y, bwd
 
     def _mha(self, q, ldq, k, ldk, v, ldv, B, N, Lk, Lv, C, keep):

@@ -222,11 +222,13 @@ class _TapeNet(nn.Module):
         off, _ = self.index[name]
         return self.grads.data_ptr() + 4 * off
 
-    def weights_updated(self):
+    def weights_updated(self, convs=True):
         """Tell the model its fp32 arena changed (an optimizer step): the bf16 operands of the 3x3 convolutions are re-laid before
         the next pass.  With ``auto_prep`` (default) every pass re-lays them anyway; the SFR-on loops turn that off and call this
-        after each Adam step, so the two forward passes of a forget stage share one re-layout."""
-        self._conv_dirty = True
+        after each Adam step, so the two forward passes of a forget stage share one re-layout.  ``convs=False``: the step did not touch the
+        convolution kernels (SD train_method "xattn"), their operands stay valid."""
+        if convs:
+            self._conv_dirty = True
 
     auto_prep = True
 
@@ -258,8 +260,7 @@ class _TapeNet(nn.Module):
             ws2 = torch.empty(_L().sfron_groupnorm_scratch_bytes(x.B, x.H * x.W, x.C, 32) // 8 + 2, dtype=torch.float64, device=dev)
             check(_L().sfron_groupnorm_bwd(ptr(dy), ptr(x.t), x.C, gam, bet, ptr(mean), ptr(rstd), x.B, x.H * x.W, x.C, 32, int(swish),
                                            ptr(drop_mask), scale, ptr(gbuf), x.C, acc, ptr(pg), ptr(pb), ptr(ws2), stream_ptr()), "groupnorm_bwd")
-            check(_L().sfron_reduce_chunks(ptr(pg), 1, x.B, x.C, self._g(name + ".weight"), x.C, 0, stream_ptr()), "reduce")
-            check(_L().sfron_reduce_chunks(ptr(pb), 1, x.B, x.C, self._g(name + ".bias"), x.C, 0, stream_ptr()), "reduce")
+            check(_L().sfron_reduce2(ptr(pg), ptr(pb), 1, x.B, x.C, self._g(name + ".weight"), x.C, self._g(name + ".bias"), x.C, stream_ptr()), "reduce2")
         return y, bwd
 
     def _conv3(self, src, B, hs, ws, name, ho, wo, stride=1, pad=1, up=0, vec=None, ld_vec=0, resid=None):
