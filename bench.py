@@ -141,7 +141,12 @@ def main():
 
     dp_overlap = False
     if world > 1 and not args.no_overlap and args.micro_batches == 1:
-        dp_overlap = runner.verify_overlap(batches[0][0])
+        try:
+            dp_overlap = runner.verify_overlap(batches[0][0])
+        except Exception as e:      # the same code runs on every rank: a host-side failure is symmetric -> every rank falls back
+            print(f"[bench] rank {rank}: overlapped exchange failed its check run ({type(e).__name__}: {e}); synchronous path",
+                  file=sys.stderr, flush=True)
+            dp_overlap = False
         runner.overlap = dp_overlap
         if rank == 0:
             print(f"[bench] overlapped gradient exchange vs synchronous all-reduce on {world} ranks: "

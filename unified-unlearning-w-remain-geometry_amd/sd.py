@@ -75,6 +75,7 @@ class SDSFRon:
             self.forget_mask = fm
         self.opt = sweep.FlatAdam(p, g, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adamw=True, mask=self.train_mask, w_bf16=w16)
         unet.auto_prep = False                      # this loop tells the model when its weights changed
+        unet.wgrad_filter = (lambda n: "attn2" in n) if train_method == "xattn" else None
 
     def _d_loss(self, out, target, scale):
         """d(scale * mean((out - target)^2)) / d out through the HIP loss kernel (this rank's share of the global batch mean)."""

@@ -297,7 +297,8 @@ class UNetModel(_TapeNet):
             dO1b = cast_rows(dO1, C, rows, C, dev)
             dqkv = torch.empty(rows, 3 * C, dtype=torch.bfloat16, device=dev)
             att1_b(dO1b, dqkv.data_ptr(), dqkv.data_ptr() + 2 * C, dqkv.data_ptr() + 4 * C)
-            bgemm(dqkv, n1, 3 * C, C, rows, lda=3 * C, ldb=C, a_t=True, b_t=True, c_f32=self._g(t + ".attn1.to_q.weight"), ldc=C)
+            if self._trains(t + ".attn1.to_q.weight"):
+                bgemm(dqkv, n1, 3 * C, C, rows, lda=3 * C, ldb=C, a_t=True, b_t=True, c_f32=self._g(t + ".attn1.to_q.weight"), ldc=C)
             dn1 = torch.empty(rows, C, dtype=torch.float32, device=dev)
             bgemm(dqkv, wqkv, rows, C, 3 * C, lda=3 * C, ldb=C, b_t=True, c_f32=dn1, ldc=C)
             ln1_b(dn1)                                                 # -> X0.grad

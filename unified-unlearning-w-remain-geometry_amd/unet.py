@@ -231,6 +231,13 @@ class _TapeNet(nn.Module):
             self._conv_dirty = True
 
     auto_prep = True
+    # name -> bool, or None: which weights receive a gradient.  The SD loop with train_method "xattn" hands only the attn2 parameters to
+    # Adam (nsfw_removal.py:66-77); the reference's autograd still forms every gradient, here the products for frozen convolution
+    # kernels and Linear weights (a third of a training pass) are skipped -- their arena entries then hold stale values nobody reads.
+    wgrad_filter = None
+
+    def _trains(self, pname):
+        return self.wgrad_filter is None or bool(self.wgrad_filter(pname))
 
     def _prep_conv_weights(self):
         if not self.auto_prep and not getattr(self, "_conv_dirty", True):
@@ -281,20 +288,23 @@ class _TapeNet(nn.Module):
 
         def bwd(d_out, want_dsrc=True):
             dyb = cast_rows(d_out, v["cop"], rows, v["cop"], dev)
-            if v["cop"] == v["co"]:
+            if not self._trains(name + ".weight"):
+                pass                                     # frozen kernel: only the input gradient below
+            elif v["cop"] == v["co"]:
                 colsum_f32(d_out, rows, v["co"], v["cop"], self._g(name + ".bias"), self._cs)
             else:
                 bg = torch.empty(v["cop"], dtype=torch.float32, device=dev)
                 colsum_f32(d_out, rows, v["cop"], v["cop"], bg, self._cs)
                 self.view(self.grads, name + ".bias").copy_(bg[:v["co"]])
-            wd = _conv_desc(B, hs, ws, v["cip"], ho, wo, v["cop"], 9, stride, pad, up, 0)
-            nsl = _L().sfron_conv_wgrad_splits(ctypes.byref(wd))
-            slab = v["cop"] * 9 * v["cip"]
-            if self._dw.numel() < nsl * slab:
-                self._dw = torch.empty(nsl * slab, dtype=torch.float32, device=dev)
-            check(_L().sfron_conv_wgrad(ctypes.byref(wd), ptr(dyb), v["cop"], ptr(src), ptr(self._dw), stream_ptr()), "conv_wgrad")
-            check(_L().sfron_conv_wgrad_scatter(ptr(self._dw), v["co"], v["ci"], 9, v["cip"], nsl, slab, self._g(name + ".weight"), stream_ptr()),
-                  "conv_wgrad_scatter")
+            if self._trains(name + ".weight"):
+                wd = _conv_desc(B, hs, ws, v["cip"], ho, wo, v["cop"], 9, stride, pad, up, 0)
+                nsl = _L().sfron_conv_wgrad_splits(ctypes.byref(wd))
+                slab = v["cop"] * 9 * v["cip"]
+                if self._dw.numel() < nsl * slab:
+                    self._dw = torch.empty(nsl * slab, dtype=torch.float32, device=dev)
+                check(_L().sfron_conv_wgrad(ctypes.byref(wd), ptr(dyb), v["cop"], ptr(src), ptr(self._dw), stream_ptr()), "conv_wgrad")
+                check(_L().sfron_conv_wgrad_scatter(ptr(self._dw), v["co"], v["ci"], 9, v["cip"], nsl, slab, self._g(name + ".weight"),
+                                                    stream_ptr()), "conv_wgrad_scatter")
             if not want_dsrc or v["dgr"] is None:
                 return None
             if stride == 2:        # Downsample: gradient = flipped kernel over the zero-dilated dY, padding 2 - pad
@@ -334,11 +344,14 @@ class _TapeNet(nn.Module):
             """d_out fp32 [rows][ld_d] (or None when only the bf16 form d_bf [rows][cout] exists)."""
             if d_bf is None:
                 d_bf = cast_rows(d_out, ld_d, rows, cout, dev)
-            if bias and d_out is not None:
-                colsum_f32(d_out, rows, cout, ld_d, gb, self._cs)
-            elif bias:
-                colsum_bf16(d_bf, rows, cout, cout, gb, self._cs)
-            bgemm(d_bf, x_bf, cout, cin, rows, lda=cout, ldb=lda, a_t=True, b_t=True, c_f32=gw, ldc=cin)
+            if name is not None and not self._trains(name + ".weight"):
+                pass                                     # frozen layer: only the input gradient below
+            else:
+                if bias and d_out is not None:
+                    colsum_f32(d_out, rows, cout, ld_d, gb, self._cs)
+                elif bias:
+                    colsum_bf16(d_bf, rows, cout, cout, gb, self._cs)
+                bgemm(d_bf, x_bf, cout, cin, rows, lda=cout, ldb=lda, a_t=True, b_t=True, c_f32=gw, ldc=cin)
             if not want_dx:
                 return None
             dx = torch.empty(rows, cin, dtype=torch.float32, device=dev)
