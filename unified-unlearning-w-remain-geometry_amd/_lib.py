@@ -176,6 +176,11 @@ def lib():
         if not os.path.isfile(LIB_PATH):
             raise SfronError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                              f"(make -C {os.path.join(_HERE, 'csrc')}). There is no fallback path.")
+        # torch's HIP runtime first: the library must bind to the runtime instance torch uses, and torch must be the one that
+        # initialises the device (the other order leaves the library's first stream / event creation without a device: status 100)
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
         h = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(h, name)      # AttributeError if the symbol is missing: loud by design
