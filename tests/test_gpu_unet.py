@@ -189,6 +189,34 @@ def test_pipelined_tile_plain_products(M, N, K, out):
     np.testing.assert_allclose(c.cpu().numpy(), (ref2 + ref - bias).numpy(), rtol=2e-4, atol=4e-4 * math.sqrt(K))
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 320, 1280), (256, 200, 192), (1024, 2560, 320), (256, 768, 64), (4096, 320, 320)])
+def test_pipelined_tile_transposed_read_products(M, N, K):
+    """The transposed-read tile (k_cgemm_t) on plain products: Linear input gradient dX = dY W (A direct, B read transposed) and the
+    weight gradient dW = dY^T X (both read transposed, contraction over the M rows; through the split-K slabs when the caller gives
+    scratch), ragged last tiles in both output dimensions, fp32 and bf16 results, against torch fp32."""
+    from sfron import unet
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    dy = (torch.randn(M, N, generator=g) * 0.5).to(torch.bfloat16)          # [rows][out]
+    w = (torch.randn(N, K, generator=g) * 0.5).to(torch.bfloat16)           # [out][in]
+    x = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)           # [rows][in]
+    dyd, wd, xd = dy.to(DEV), w.to(DEV), x.to(DEV)
+    # input gradient [M][K] = dY [M][N] . W [N][K]: contraction over N, B read transposed
+    ref_dx = dy.float() @ w.float()
+    dx = torch.full((M, K), float("nan"), dtype=torch.float32, device=DEV)
+    unet.bgemm(dyd, wd, M, K, N, lda=N, ldb=K, b_t=True, c_f32=dx, ldc=K)
+    np.testing.assert_allclose(dx.cpu().numpy(), ref_dx.numpy(), rtol=2e-4, atol=2e-4 * math.sqrt(N))
+    dxb = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
+    unet.bgemm(dyd, wd, M, K, N, lda=N, ldb=K, b_t=True, c_bf16=dxb, ldc=K)
+    np.testing.assert_allclose(dxb.float().cpu().numpy(), ref_dx.numpy(), rtol=1e-2, atol=1e-2 * math.sqrt(N) * 0.25)
+    # weight gradient [N][K] = dY^T X: contraction over the M rows, both operands read transposed
+    ref_dw = dy.float().t() @ x.float()
+    dw = torch.full((N, K), float("nan"), dtype=torch.float32, device=DEV)
+    unet.bgemm(dyd, xd, N, K, M, lda=N, ldb=K, a_t=True, b_t=True, c_f32=dw, ldc=K)
+    np.testing.assert_allclose(dw.cpu().numpy(), ref_dw.numpy(), rtol=2e-4, atol=2e-4 * math.sqrt(M))
+    unet.bgemm(dyd, xd, N, K, M, lda=N, ldb=K, a_t=True, b_t=True, c_f32=dw, ldc=K, accumulate=True)
+    np.testing.assert_allclose(dw.cpu().numpy(), 2 * ref_dw.numpy(), rtol=2e-4, atol=4e-4 * math.sqrt(M))
+
+
 def test_batched_gemm_and_softmax():
     from sfron import _lib, unet
     from sfron._lib import check, ptr, stream_ptr
