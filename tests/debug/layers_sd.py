@@ -1,5 +1,5 @@
 import sys, os, math
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # tests/debug/ -> repo root (debugging aid; uses the oracle, hence under tests/)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import test_gpu_sd as T

@@ -2,15 +2,20 @@
    python tools/dbg_determinism.py [--dbg-lib]   (with --dbg-lib the debug-knob library is loaded: SFRON_NO_CGEMM=<mask> applies)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import torch
 from sfron import _lib
 if "--dbg-lib" in sys.argv:
     _lib.LIB_PATH = os.path.join(ROOT, "unified-unlearning-w-remain-geometry_amd", "libsfron_dbg.so")
-import test_gpu_unet as T
+from sfron import unet
 DEV = "cuda:0"
-cfg = dict(T.SMALL, dropout=0.0)
-_, model = T._pair(cfg, seed=40)
+torch.manual_seed(40)
+model = unet.Conditional_Model(ch=128, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(8,), dropout=0.0, resolution=16, n_classes=10)
+with torch.no_grad():                         # zero-initialised tensors would hide whole branches of the backward pass
+    for p in model.parameters():
+        if not bool(p.any()):
+            p.copy_(torch.randn(p.shape, device=p.device) * 0.05)
+model.sync_bf16()
 model.train()
 g = torch.Generator().manual_seed(1)
 B = 8
