@@ -163,6 +163,28 @@ def test_sd_nsfw_removal_iterations_vs_oracle(method, mask_mode):
     assert same / tot > 0.97 and (num / den) ** 0.5 < 0.3
 
 
+def test_sd_unet_forward_backward_bitwise_reproducible():
+    """As for the DDPM U-Net: repeated forward + backward passes of the LDM UNet agree bit for bit (GroupNorm over 1 .. 2 channels per
+    group here, LayerNorm, GEGLU, both attention forms, split-K slabs)."""
+    _, model = _pair(MID, seed=50)
+    model.train()
+    g = torch.Generator().manual_seed(2)
+    B, S, Lc = 2, 32, 77
+    x, t = torch.randn(B, 4, S, S, generator=g).to(DEV), torch.randint(0, 1000, (B,), generator=g).to(DEV)
+    ctx, w = torch.randn(B, Lc, MID["context_dim"], generator=g).to(DEV), torch.randn(B, 4, S, S, generator=g).to(DEV)
+    outs, grads = [], []
+    for rep in range(3):
+        junk = torch.randn(1 << 22, device=DEV) * (rep + 1)
+        del junk
+        out, bwd = model._run(x, t, ctx, need_grad=True)
+        bwd(w.clone())
+        outs.append(out.clone()); grads.append(model.grads.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    for r in (1, 2):
+        bad = [n for n in model.index if not torch.equal(model.view(grads[0], n), model.view(grads[r], n))]
+        assert not bad, bad[:8]
+
+
 def test_sd_graph_replay_matches_eager():
     """The two stages of an iteration replayed as HIP graphs (sfron.graphs) give bit-for-bit the parameters of the eager loop."""
     from sfron import sd

@@ -368,6 +368,30 @@ def test_unet_cifar10_batch64_forward_backward_vs_oracle():
     assert dots / math.sqrt(na * nb) > 0.9995
 
 
+def test_unet_forward_backward_bitwise_reproducible():
+    """Three repetitions of the same forward + backward with different garbage in freed memory in between: every output and every
+    gradient bit agrees (no floating-point atomics, no read of uninitialised scratch; the up-path GroupNorms have 12 channels per
+    group, the case that used to go through an LDS atomic)."""
+    _, model = _pair(dict(SMALL, dropout=0.0), seed=40)
+    model.train()
+    g = torch.Generator().manual_seed(1)
+    B = 8
+    x, t = torch.randn(B, 3, 16, 16, generator=g).to(DEV), torch.randint(0, 1000, (B,), generator=g).float().to(DEV)
+    c, keep = torch.randint(0, 10, (B,), generator=g).to(DEV), torch.ones(B, dtype=torch.uint8, device=DEV)
+    w = torch.randn(B, 3, 16, 16, generator=g).to(DEV)
+    outs, grads = [], []
+    for rep in range(3):
+        junk = torch.randn(1 << 22, device=DEV) * (rep + 1)
+        del junk
+        out, bwd = model._run(x, t, c, keep, None, need_grad=True)
+        bwd(w.clone())
+        outs.append(out.clone()); grads.append(model.grads.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    for r in (1, 2):
+        bad = [n for n in model.index if not torch.equal(model.view(grads[0], n), model.view(grads[r], n))]
+        assert not bad, bad[:8]
+
+
 def test_unet_test_mode_guidance_matches_oracle():
     ref, model = _pair(SMALL, seed=5)
     ref.eval(); model.eval()
