@@ -731,13 +731,14 @@ __global__ __launch_bounds__(TPB) void k_conv_wprep9(const float* __restrict__ w
 // weight gradient fp32 [nslab][Co_p][taps][Ci_p] (GEMM output, split-K slabs) -> OIHW gradient (overwrite; slabs added in order)
 __global__ __launch_bounds__(TPB) void k_conv_wgrad_scatter(const float* __restrict__ g, int Co, int Ci, int taps, int Ci_p, int nslab,
                                                             int64_t slab_stride, float* __restrict__ dw) {
+  // threads run over the GEMM layout (ci fastest): the nslab reads per element are coalesced, the single write is the strided one
   const int64_t n = (int64_t)Co * Ci * taps;
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
-    const int t = (int)(i % taps); const int ci = (int)((i / taps) % Ci); const int co = (int)(i / ((int64_t)taps * Ci));
+    const int ci = (int)(i % Ci); const int t = (int)((i / Ci) % taps); const int co = (int)(i / ((int64_t)taps * Ci));
     const float* p = g + ((int64_t)co * taps + t) * Ci_p + ci;
     float a = 0.f;
     for (int sl = 0; sl < nslab; ++sl) a += p[sl * slab_stride];
-    dw[i] = a;
+    dw[((int64_t)co * Ci + ci) * taps + t] = a;
   }
 }
 

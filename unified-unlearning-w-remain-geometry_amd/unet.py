@@ -111,7 +111,7 @@ def _conv_desc(B, hs, ws, cs, ho, wo, n_out, taps=9, stride=1, pad=1, up=0, dil=
     d.bias, d.resid, d.sample_vec, d.ld_vec = _addr(bias), _addr(resid), _addr(vec), ld_vec
     d.out_bf16, d.out_f32, d.ld_out, d.accumulate = _addr(out_bf16), _addr(out_f32), ld_out or 0, int(accumulate)
     rows, t = B * ho * wo, out_f32 if out_f32 is not None else out_bf16
-    if t is not None and not isinstance(t, int) and rows * n_out <= (1 << 21) and taps * cs >= 2048 and ld_out == n_out:
+    if t is not None and not isinstance(t, int) and rows * n_out <= (1 << 23) and taps * cs >= 2048 and ld_out == n_out:
         ws = _split_scratch(rows * n_out, t)                 # few output tiles, deep contraction: split-K slabs
         d.split_ws, d.split_ws_slabs = ws.data_ptr(), ws.numel() // (rows * n_out)
         d._keep = ws
