@@ -8,11 +8,11 @@ A "step" = one full SFR-on iteration (DiT/forget.py:256-322): forget fwd/bwd -> 
 remain fwd/bwd -> AdamW, EMA; synthetic latents / labels / timesteps / noise already resident in HBM.
 Weak scaling: every rank runs batch 32 (global batch 32*N), gradients SUM-all-reduced over RCCL.
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline"     -- the kernel with the largest share of GPU time (profiles/r02_kernel_table.md): the weight-gradient GEMM of
-                    attn.qkv / mlp.fc1 with the bias row sums fused in, timed live with HIP event pairs recorded on the
-                    weight-gradient stream it is launched on (every 9th block of every backward pass inside the timed
-                    region); "others" holds the same measurement for the fc1 forward GEMM (main stream) and an "hbm" entry for
-                    the parameter sweep k_masked_clip_adam
+  "roofline"     -- the kernel with the largest share of GPU time (profiles/r02_kernel_table.md): the weight-gradient GEMM
+                    (one kernel for the four products dW = dY^T X of a block), timed live with HIP event pairs recorded on the
+                    weight-gradient stream it is launched on (all four GEMMs of every 9th block of every backward pass inside
+                    the timed region); "others" holds the same measurement for the fc1 forward GEMM (main stream) and an "hbm"
+                    entry for the parameter sweep k_masked_clip_adam
   "cpu_baseline" -- the oracle (plain PyTorch fp32, CPU) timed on a bounded sample on this box's host cores.
 With N > 1 the overlapped gradient exchange is switched on only after DiTSFRon.verify_overlap() has reproduced the synchronous
 exchange on the ranks of this very run ("dp_overlap" in the JSON says which path was timed).
