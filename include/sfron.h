@@ -226,6 +226,16 @@ int sfron_conv_wgrad(const sfron_conv_desc* desc, const uint16_t* dy, int ld_dy,
 /* fp32 OIHW master weights -> bf16 operands: w_fwd [c_out_p][taps][c_in_p] (zero padded), w_dgrad [c_in][taps flipped][c_out_p] or NULL */
 int sfron_conv_wprep(const float* w_oihw, int c_out, int c_in, int taps, int c_out_p, int c_in_p, uint16_t* w_fwd, uint16_t* w_dgrad,
                      void* stream);
+/* the same for every 3x3 kernel of a model in one launch: a device-resident table, item i owning the tile ids
+ * [tile0, tile0 + sfron_conv_wprep_tiles(c_out_p, c_in_p)) of the grid (tile0 ascending, n_tiles = their total) */
+typedef struct sfron_wprep_item {
+  const float* w;         /* OIHW fp32 master [c_out][c_in][3][3] */
+  uint16_t* fwd;          /* bf16 [c_out_p][9][c_in_p] */
+  uint16_t* dgr;          /* bf16 [c_in][9 flipped][c_out_p], or NULL */
+  int32_t co, ci, co_p, ci_p, tile0, pad_;
+} sfron_wprep_item;
+int sfron_conv_wprep_tiles(int c_out_p, int c_in_p);
+int sfron_conv_wprep_batch(const sfron_wprep_item* items_dev, int n_items, int n_tiles, void* stream);
 /* dw_gemm [n_slabs][c_out_p..][taps][c_in_p] -> OIHW gradient [c_out][c_in][taps] (overwrite; the slabs are added in order) */
 int sfron_conv_wgrad_scatter(const float* dw_gemm, int c_out, int c_in, int taps, int c_in_p, int n_slabs, int64_t slab_stride,
                              float* dw_oihw, void* stream);
@@ -265,7 +275,14 @@ int sfron_axpby(const float* a, const float* b, float alpha, float beta, int64_t
 /* backward of nearest x2 upsampling: dx[b][h][w][c] (+)= sum of the 2x2 block of dy [B][2H][2W][C] */
 int sfron_pool2_sum(const float* dy, int B, int H, int W, int C, float* dx, int accumulate, void* stream);
 int sfron_cast_rows_bf16(const float* x, int ldx, int64_t rows, int C, uint16_t* y, void* stream);
+/* y = bf16(x) and colsum[c] = sum over rows of x[.][c] in one pass (output gradient -> GEMM operand + bias gradient, `Conv2d` /
+ * `Linear` backward); partials: scratch of max_partials * C floats */
+int sfron_cast_rows_colsum(const float* x, int ldx, int64_t rows, int C, uint16_t* y, float* partials, int max_partials, float* colsum,
+                           void* stream);
 /* y[r][0..C) (+)= x[r][0..C): channel-slice copies of torch.cat(dim=1) and its backward (:404) */
+/* keep mask of nn.Dropout(p) (DDPM/models/diffusion.py:131), 1 = kept with probability 1 - p: a counter-based draw keyed by
+ * (seed, counter[0] on the device, salt, element); the caller advances the device counter once per pass */
+int sfron_dropout_mask(uint64_t seed, const int64_t* counter, int64_t salt, int64_t n, float p, uint8_t* mask, void* stream);
 int sfron_copy_cols(const float* x, int ldx, int64_t rows, int C, float* y, int ldy, int accumulate, void* stream);
 /* get_timestep_embedding (:17-35): bf16 [n][dim] = sin(t f) || cos(t f), f_j = exp(-ln(1e4) j / (dim/2 - 1)); t float */
 int sfron_ddpm_timestep_embed(const float* t, int n, int dim, uint16_t* out, void* stream);

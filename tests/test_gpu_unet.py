@@ -368,6 +368,34 @@ def test_unet_cifar10_batch64_forward_backward_vs_oracle():
     assert dots / math.sqrt(na * nb) > 0.9995
 
 
+def test_dropout_mask_kernel_statistics_and_keys():
+    """nn.Dropout's keep mask in one launch: keep rate 1 - p, identical for identical (seed, counter, salt), different when any of the
+    three changes, no run structure along rows (a counter-based draw, not the torch stream: tests that compare with the oracle hand
+    the masks over)."""
+    from sfron import _lib
+    from sfron._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    n, p = 1 << 20, 0.1
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+
+    def draw(seed, salt, size=n):
+        m = torch.empty(size, dtype=torch.uint8, device=DEV)
+        check(L.sfron_dropout_mask(seed, ptr(cnt), salt, size, p, ptr(m), stream_ptr()), "dropout_mask")
+        return m
+    a, a2, b, c = draw(7, 1), draw(7, 1), draw(7, 2), draw(8, 1)
+    cnt.add_(1)
+    d = draw(7, 1)
+    assert torch.equal(a, a2) and not torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, d)
+    for m in (a, b, c, d):
+        assert set(m.unique().tolist()) <= {0, 1}
+        assert abs(m.float().mean().item() - (1 - p)) < 2e-3                                     # sigma = 2.9e-4
+    assert abs((a ^ b).float().mean().item() - 2 * p * (1 - p)) < 3e-3                             # independent draws
+    x = a.view(1024, 1024).float()
+    assert abs(torch.corrcoef(torch.stack([x[:, :-1].flatten(), x[:, 1:].flatten()]))[0, 1].item()) < 5e-3
+    odd = draw(7, 3, size=1001)                                                                   # tail that is not a multiple of four
+    assert odd.shape[0] == 1001 and set(odd.unique().tolist()) <= {0, 1}
+
+
 def test_unet_forward_backward_bitwise_reproducible():
     """Three repetitions of the same forward + backward with different garbage in freed memory in between: every output and every
     gradient bit agrees (no floating-point atomics, no read of uninitialised scratch; the up-path GroupNorms have 12 channels per

@@ -133,6 +133,10 @@ _PROTOS.update({
     "sfron_axpby": (c_int, [_P, _P, c_float, c_float, c_int64, _P, _S]),
     "sfron_pool2_sum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _S]),
     "sfron_cast_rows_bf16": (c_int, [_P, c_int, c_int64, c_int, _P, _S]),
+    "sfron_cast_rows_colsum": (c_int, [_P, c_int, c_int64, c_int, _P, _P, c_int, _P, _S]),
+    "sfron_dropout_mask": (c_int, [ctypes.c_uint64, _P, c_int64, c_int64, c_float, _P, _S]),
+    "sfron_conv_wprep_tiles": (c_int, [c_int, c_int]),
+    "sfron_conv_wprep_batch": (c_int, [_P, c_int, c_int, _S]),
     "sfron_copy_cols": (c_int, [_P, c_int, c_int64, c_int, _P, c_int, c_int, _S]),
     "sfron_ddpm_timestep_embed": (c_int, [_P, c_int, c_int, _P, _S]),
     "sfron_class_embed_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _S]),
@@ -163,6 +167,11 @@ _PROTOS.update({
     "sfron_probe_read": (c_int, [c_void_p, POINTER(c_int), POINTER(c_double)]),
     "sfron_probe_destroy": (c_int, [c_void_p]),
 })
+
+
+class WprepItem(ctypes.Structure):        # sfron_wprep_item
+    _fields_ = [("w", c_void_p), ("fwd", c_void_p), ("dgr", c_void_p), ("co", ctypes.c_int32), ("ci", ctypes.c_int32), ("co_p", ctypes.c_int32),
+                ("ci_p", ctypes.c_int32), ("tile0", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
 def declared_symbols():

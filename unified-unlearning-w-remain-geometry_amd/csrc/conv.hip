@@ -682,6 +682,14 @@ template __global__ void k_cgemm_t<true, true, true, EPI_RES>(BGemmArgs, unsigne
 namespace {
 
 constexpr int TPB = 256;
+// rows per workgroup of the row-vectorised elementwise kernels: about 2048 workgroups over (column blocks x row chunks), >= 4 rows
+inline int rows_chunk(int64_t rows, int C) {
+  const int64_t cb = (C + 255) / 256;
+  int64_t chunks = 2048 / cb; if (chunks < 1) chunks = 1;
+  int64_t r = (rows + chunks - 1) / chunks;
+  r = (r + 3) / 4 * 4;
+  return (int)(r < 4 ? 4 : r);
+}
 inline int grid_for(int64_t n, int per = TPB) {
   int64_t b = (n + per - 1) / per;
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -708,10 +716,8 @@ __global__ __launch_bounds__(TPB) void k_conv_wprep(const float* __restrict__ w,
 // the same for the large 3x3 kernels of the LDM UNet through an LDS tile of 32 output x 32 input channels (bf16 [32][32][9]): the OIHW
 // master is read in contiguous runs of 32 * 9 floats, the forward operand is written in runs of 32 input channels per (co, tap),
 // the input-gradient operand in runs of 32 output channels per (ci, flipped tap).  grid = (ceil(Ci_p / 32), ceil(Co_p / 32)).
-__global__ __launch_bounds__(TPB) void k_conv_wprep9(const float* __restrict__ w, int Co, int Ci, int Co_p, int Ci_p, __bf16* __restrict__ fwd,
-                                                     __bf16* __restrict__ dgr) {
-  __shared__ __bf16 t[32][32 * 9 + 2];
-  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+__device__ __forceinline__ void wprep9_tile(const float* __restrict__ w, int Co, int Ci, int Co_p, int Ci_p, __bf16* __restrict__ fwd,
+                                            __bf16* __restrict__ dgr, int ci0, int co0, __bf16 (*t)[32 * 9 + 2]) {
   for (int i = threadIdx.x; i < 32 * 288; i += TPB) {
     const int co = i / 288, k = i - co * 288, ci = k / 9;
     const bool in = co0 + co < Co && ci0 + ci < Ci;
@@ -727,6 +733,21 @@ __global__ __launch_bounds__(TPB) void k_conv_wprep9(const float* __restrict__ w
       const int co = i & 31, tp = (i >> 5) % 9, ci = i / 288;
       if (co0 + co < Co_p && ci0 + ci < Ci) dgr[((int64_t)(ci0 + ci) * 9 + tp) * Co_p + co0 + co] = t[co][ci * 9 + (8 - tp)];
     }
+}
+__global__ __launch_bounds__(TPB) void k_conv_wprep9(const float* __restrict__ w, int Co, int Ci, int Co_p, int Ci_p, __bf16* __restrict__ fwd,
+                                                     __bf16* __restrict__ dgr) {
+  __shared__ __bf16 t[32][32 * 9 + 2];
+  wprep9_tile(w, Co, Ci, Co_p, Ci_p, fwd, dgr, blockIdx.x * 32, blockIdx.y * 32, t);
+}
+// every 3x3 kernel of a model in ONE launch: block b serves tile (b - item.tile0) of the item whose tile range holds it
+__global__ __launch_bounds__(TPB) void k_conv_wprep9_batch(const sfron_wprep_item* __restrict__ items, int n_items) {
+  __shared__ __bf16 t[32][32 * 9 + 2];
+  int lo = 0, hi = n_items - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (items[mid].tile0 <= b) lo = mid; else hi = mid - 1; }
+  const sfron_wprep_item it = items[lo];
+  const int local = b - it.tile0, tx = (it.ci_p + 31) / 32;
+  wprep9_tile(it.w, it.co, it.ci, it.co_p, it.ci_p, (__bf16*)it.fwd, (__bf16*)it.dgr, (local % tx) * 32, (local / tx) * 32, t);
 }
 // weight gradient fp32 [nslab][Co_p][taps][Ci_p] (GEMM output, split-K slabs) -> OIHW gradient (overwrite; slabs added in order)
 __global__ __launch_bounds__(TPB) void k_conv_wgrad_scatter(const float* __restrict__ g, int Co, int Ci, int taps, int Ci_p, int nslab,
@@ -1336,6 +1357,68 @@ __global__ __launch_bounds__(TPB) void k_cast_rows(const float* __restrict__ x, 
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB)
     y[i] = f2bf(x[(i / C) * ldx + (i % C)]);
 }
+// the same with a lane per float4 of a row (no per-element division), optionally with the column sums of x (the bias gradient of
+// the layer whose output gradient is being cast): grid = (ceil(C / 256), row chunks); the 4 waves of a workgroup take rows
+// r0 + wave, + 4, ... and meet in LDS in a fixed order; partials[chunk][C] are added by k_reduce_chunks
+template <bool SUM>
+__global__ __launch_bounds__(TPB) void k_cast_rows4(const float* __restrict__ x, int ldx, int64_t rows, int C, int rows_per_block,
+                                                    __bf16* __restrict__ y, float* __restrict__ partials) {
+  __shared__ float sh[3][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = (blockIdx.x * 64 + lane) * 4;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (col < C)
+    for (int64_t r = r0 + wave; r < r1; r += TPB / 64) {
+      const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + col);
+      *reinterpret_cast<bf16x4*>(y + r * C + col) = bf16x4{f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+      if (SUM) { a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w; }
+    }
+  if (!SUM) return;
+  if (wave > 0) { sh[wave - 1][0][lane] = a0; sh[wave - 1][1][lane] = a1; sh[wave - 1][2][lane] = a2; sh[wave - 1][3][lane] = a3; }
+  __syncthreads();
+  if (wave == 0 && col < C) {
+    float* o = partials + (size_t)blockIdx.y * C + col;
+    o[0] = ((a0 + sh[0][0][lane]) + sh[1][0][lane]) + sh[2][0][lane];
+    o[1] = ((a1 + sh[0][1][lane]) + sh[1][1][lane]) + sh[2][1][lane];
+    o[2] = ((a2 + sh[0][2][lane]) + sh[1][2][lane]) + sh[2][2][lane];
+    o[3] = ((a3 + sh[0][3][lane]) + sh[1][3][lane]) + sh[2][3][lane];
+  }
+}
+__global__ __launch_bounds__(TPB) void k_copy_cols4(const float* __restrict__ x, int ldx, int64_t rows, int C, float* __restrict__ y, int ldy,
+                                                    int accumulate, int rows_per_block) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = (blockIdx.x * 64 + lane) * 4;
+  if (col >= C) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  for (int64_t r = r0 + wave; r < r1; r += TPB / 64) {
+    float4 v = *reinterpret_cast<const float4*>(x + r * ldx + col);
+    float4* o = reinterpret_cast<float4*>(y + r * ldy + col);
+    if (accumulate) { const float4 c = *o; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+    *o = v;
+  }
+}
+// Bernoulli keep mask of nn.Dropout(p) in one launch (torch.rand >= p -> uint8 takes three): element i of mask (seed, call, salt) is
+// kept when 16 bits of splitmix64(seed, counter, salt, i / 4) reach p * 65536.  `counter` lives on the device and is advanced by the
+// caller once per pass, so a captured graph draws fresh masks at every replay.
+__global__ __launch_bounds__(TPB) void k_dropout_mask(uint64_t seed, const int64_t* __restrict__ counter, int64_t salt, int64_t n, unsigned thresh16,
+                                                      uint8_t* __restrict__ out) {
+  const uint64_t base = seed ^ ((uint64_t)counter[0] * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)salt * 0xD1B54A32D192ED03ull);
+  const int64_t nq = (n + 3) >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nq; i += (int64_t)gridDim.x * TPB) {
+    uint64_t z = base + (uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    uchar4 m;
+    m.x = (unsigned)(z & 0xffff) >= thresh16; m.y = (unsigned)((z >> 16) & 0xffff) >= thresh16;
+    m.z = (unsigned)((z >> 32) & 0xffff) >= thresh16; m.w = (unsigned)(z >> 48) >= thresh16;
+    if (4 * i + 3 < n) *reinterpret_cast<uchar4*>(out + 4 * i) = m;
+    else { const uint8_t e[4] = {m.x, m.y, m.z, m.w}; for (int k = 0; 4 * i + k < n; ++k) out[4 * i + k] = e[k]; }
+  }
+}
 // y[rows][ld_y] column slice <- x[rows][C] (channel concatenation) and back (+=)
 __global__ __launch_bounds__(TPB) void k_copy_cols(const float* __restrict__ x, int ldx, int64_t rows, int C, float* __restrict__ y, int ldy,
                                                    int accumulate) {
@@ -1664,6 +1747,13 @@ int sfron_conv_wprep(const float* w_oihw, int c_out, int c_in, int taps, int c_o
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }
+int sfron_conv_wprep_tiles(int c_out_p, int c_in_p) { return ((c_out_p + 31) / 32) * ((c_in_p + 31) / 32); }
+int sfron_conv_wprep_batch(const sfron_wprep_item* items_dev, int n_items, int n_tiles, void* stream) {
+  SFRON_CHECK_ARG(items_dev && n_items > 0 && n_tiles > 0);
+  hipLaunchKernelGGL(k_conv_wprep9_batch, dim3(n_tiles), dim3(TPB), 0, (hipStream_t)stream, items_dev, n_items);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
 int sfron_conv_wgrad_scatter(const float* dw_gemm, int c_out, int c_in, int taps, int c_in_p, int n_slabs, int64_t slab_stride,
                              float* dw_oihw, void* stream) {
   SFRON_CHECK_ARG(dw_gemm && dw_oihw && n_slabs >= 1);
@@ -1823,12 +1913,48 @@ int sfron_pool2_sum(const float* dy, int B, int H, int W, int C, float* dx, int 
 }
 int sfron_cast_rows_bf16(const float* x, int ldx, int64_t rows, int C, uint16_t* y, void* stream) {
   SFRON_CHECK_ARG(x && y && ldx >= C);
+  if (C % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 7) == 0) {
+    const int rpb = rows_chunk(rows, C);
+    hipLaunchKernelGGL((k_cast_rows4<false>), dim3((C + 255) / 256, (unsigned)((rows + rpb - 1) / rpb)), dim3(TPB), 0, (hipStream_t)stream, x, ldx, rows, C,
+                       rpb, (__bf16*)y, (float*)nullptr);
+    SFRON_LAUNCH_STATUS();
+    return SFRON_OK;
+  }
   hipLaunchKernelGGL(k_cast_rows, dim3(grid_for(rows * C)), dim3(TPB), 0, (hipStream_t)stream, x, ldx, rows, C, (__bf16*)y);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+/* y = bf16(x) and colsum[c] = sum_r x[r][c] in one pass over x (the output gradient of a layer: its bf16 GEMM operand and its bias
+ * gradient); partials: scratch of at least max_partials * C floats */
+int sfron_cast_rows_colsum(const float* x, int ldx, int64_t rows, int C, uint16_t* y, float* partials, int max_partials, float* colsum,
+                           void* stream) {
+  SFRON_CHECK_ARG(x && y && partials && colsum && rows > 0 && C > 0 && ldx >= C && max_partials > 0);
+  SFRON_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 7) == 0);
+  int64_t chunks = (rows + 31) / 32;
+  if (chunks > max_partials) chunks = max_partials;
+  const int rpb = (int)((rows + chunks - 1) / chunks);
+  chunks = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL((k_cast_rows4<true>), dim3((C + 255) / 256, (unsigned)chunks), dim3(TPB), 0, (hipStream_t)stream, x, ldx, rows, C, rpb, (__bf16*)y,
+                     partials);
+  SFRON_LAUNCH_STATUS();
+  return sfron_reduce_chunks(partials, 1, (int)chunks, C, colsum, C, 0, stream);
+}
+int sfron_dropout_mask(uint64_t seed, const int64_t* counter, int64_t salt, int64_t n, float p, uint8_t* mask, void* stream) {
+  SFRON_CHECK_ARG(counter && mask && n > 0 && p >= 0.f && p < 1.f && (((uintptr_t)mask) & 3) == 0);
+  const unsigned thresh = (unsigned)(p * 65536.0f + 0.5f);
+  hipLaunchKernelGGL(k_dropout_mask, dim3(grid_for((n + 3) / 4)), dim3(TPB), 0, (hipStream_t)stream, seed, counter, salt, n, thresh, mask);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }
 int sfron_copy_cols(const float* x, int ldx, int64_t rows, int C, float* y, int ldy, int accumulate, void* stream) {
   SFRON_CHECK_ARG(x && y && ldx >= C && ldy >= C);
+  if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0) {
+    const int rpb = rows_chunk(rows, C);
+    hipLaunchKernelGGL(k_copy_cols4, dim3((C + 255) / 256, (unsigned)((rows + rpb - 1) / rpb)), dim3(TPB), 0, (hipStream_t)stream, x, ldx, rows, C, y, ldy,
+                       accumulate, rpb);
+    SFRON_LAUNCH_STATUS();
+    return SFRON_OK;
+  }
   hipLaunchKernelGGL(k_copy_cols, dim3(grid_for(rows * C)), dim3(TPB), 0, (hipStream_t)stream, x, ldx, rows, C, y, ldy, accumulate);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;

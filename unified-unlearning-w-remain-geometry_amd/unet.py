@@ -126,6 +126,13 @@ def colsum_bf16(x, rows, n, ld, out, scratch):
     check(_L().sfron_colsum(_addr(x), 1, rows, n, ld, ptr(scratch), 64, _addr(out), stream_ptr()), "colsum")
 
 
+def cast_rows_colsum(x, ldx, rows, C, dev, colsum_out, scratch):
+    """bf16 copy of fp32 rows AND their column sums (-> colsum_out, a tensor or device address) in one pass."""
+    y = torch.empty(rows, C, dtype=torch.bfloat16, device=dev)
+    check(_L().sfron_cast_rows_colsum(_addr(x), ldx, rows, C, ptr(y), ptr(scratch), 64, _addr(colsum_out), stream_ptr()), "cast_rows_colsum")
+    return y
+
+
 def cast_rows(x, ldx, rows, C, dev):
     y = torch.empty(rows, C, dtype=torch.bfloat16, device=dev)
     check(_L().sfron_cast_rows_bf16(_addr(x), ldx, rows, C, ptr(y), stream_ptr()), "cast_rows")
@@ -243,9 +250,17 @@ class _TapeNet(nn.Module):
         if not self.auto_prep and not getattr(self, "_conv_dirty", True):
             return
         self._conv_dirty = False
-        for base, v in self.conv3.items():
-            check(_L().sfron_conv_wprep(self._p(base + ".weight"), v["co"], v["ci"], 9, v["cop"], v["cip"], ptr(v["fwd"]),
-                                        ptr(v["dgr"]) if v["dgr"] is not None else None, stream_ptr()), "conv_wprep")
+        if getattr(self, "_wprep_table", None) is None:
+            # device-resident table of every 3x3 kernel: one launch re-lays them all (pointers are into the fixed arenas)
+            items, tile0 = (_lib.WprepItem * len(self.conv3))(), 0
+            for it, (base, v) in zip(items, self.conv3.items()):
+                it.w, it.fwd, it.dgr = self._p(base + ".weight"), v["fwd"].data_ptr(), (v["dgr"].data_ptr() if v["dgr"] is not None else None)
+                it.co, it.ci, it.co_p, it.ci_p, it.tile0 = v["co"], v["ci"], v["cop"], v["cip"], tile0
+                tile0 += _L().sfron_conv_wprep_tiles(v["cop"], v["cip"])
+            raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.device_)
+            self._wprep_table = (raw, len(self.conv3), tile0)
+        raw, n_items, n_tiles = self._wprep_table
+        check(_L().sfron_conv_wprep_batch(ptr(raw), n_items, n_tiles, stream_ptr()), "conv_wprep_batch")
 
     def _gn(self, tape, x, name, swish, drop_mask=None, eps=None):
         """y = bf16(act(GroupNorm32(x)) [* dropout]); the backward step adds to x.grad."""
@@ -287,9 +302,14 @@ class _TapeNet(nn.Module):
         check(_L().sfron_conv_fwd(ctypes.byref(d), ptr(src), ptr(v["fwd"]), stream_ptr()), "conv_fwd")
 
         def bwd(d_out, want_dsrc=True):
-            dyb = cast_rows(d_out, v["cop"], rows, v["cop"], dev)
+            if self._trains(name + ".weight") and v["cop"] == v["co"] and v["co"] % 4 == 0:
+                dyb = cast_rows_colsum(d_out, v["cop"], rows, v["cop"], dev, self._g(name + ".bias"), self._cs)     # bf16 operand + bias gradient
+            else:
+                dyb = cast_rows(d_out, v["cop"], rows, v["cop"], dev)
             if not self._trains(name + ".weight"):
                 pass                                     # frozen kernel: only the input gradient below
+            elif v["cop"] == v["co"] and v["co"] % 4 == 0:
+                pass
             elif v["cop"] == v["co"]:
                 colsum_f32(d_out, rows, v["co"], v["cop"], self._g(name + ".bias"), self._cs)
             else:
@@ -342,12 +362,18 @@ class _TapeNet(nn.Module):
 
         def bwd(d_out, ld_d, want_dx=True, d_bf=None):
             """d_out fp32 [rows][ld_d] (or None when only the bf16 form d_bf [rows][cout] exists)."""
-            if d_bf is None:
+            frozen = name is not None and not self._trains(name + ".weight")
+            fused = d_bf is None and bias and not frozen and cout % 4 == 0 and ld_d % 4 == 0 and not isinstance(d_out, int)
+            if fused:
+                d_bf = cast_rows_colsum(d_out, ld_d, rows, cout, dev, gb, self._cs)
+            elif d_bf is None:
                 d_bf = cast_rows(d_out, ld_d, rows, cout, dev)
-            if name is not None and not self._trains(name + ".weight"):
+            if frozen:
                 pass                                     # frozen layer: only the input gradient below
             else:
-                if bias and d_out is not None:
+                if fused:
+                    pass
+                elif bias and d_out is not None:
                     colsum_f32(d_out, rows, cout, ld_d, gb, self._cs)
                 elif bias:
                     colsum_bf16(d_bf, rows, cout, cout, gb, self._cs)
@@ -652,8 +678,19 @@ class Conditional_Model(_TapeNet):
                 m = next(masks)
                 return None if m is None else m.to(device=dev, dtype=torch.uint8).contiguous()
             if self.training and self.dropout_p > 0:
-                return (torch.rand(rows, C, device=dev) >= self.dropout_p).to(torch.uint8)
+                m = torch.empty(rows, C, dtype=torch.uint8, device=dev)
+                salt[0] += 1
+                check(L.sfron_dropout_mask(self._drop_seed, ptr(self._drop_counter), salt[0], rows * C, self.dropout_p, ptr(m), stream_ptr()),
+                      "dropout_mask")
+                return m
             return None
+
+        salt = [0]
+        if masks is None and self.training and self.dropout_p > 0:
+            if getattr(self, "_drop_counter", None) is None:
+                self._drop_seed = torch.initial_seed() & ((1 << 63) - 1)           # follows torch.manual_seed
+                self._drop_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+            self._drop_counter.add_(1)                                             # one device-side tick per pass (graph-replay safe)
 
         # ---- input
         S = self.resolution
