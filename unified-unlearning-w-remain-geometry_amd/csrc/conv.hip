@@ -1930,8 +1930,11 @@ int sfron_cast_rows_colsum(const float* x, int ldx, int64_t rows, int C, uint16_
                            void* stream) {
   SFRON_CHECK_ARG(x && y && partials && colsum && rows > 0 && C > 0 && ldx >= C && max_partials > 0);
   SFRON_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 7) == 0);
-  int64_t chunks = (rows + 31) / 32;
+  // about 512 workgroups over (column blocks x row chunks), at least 32 rows per chunk, within the caller's scratch
+  int64_t chunks = 512 / ((C + 255) / 256);
+  if (chunks > (rows + 31) / 32) chunks = (rows + 31) / 32;
   if (chunks > max_partials) chunks = max_partials;
+  if (chunks < 1) chunks = 1;
   const int rpb = (int)((rows + chunks - 1) / chunks);
   chunks = (rows + rpb - 1) / rpb;
   hipLaunchKernelGGL((k_cast_rows4<true>), dim3((C + 255) / 256, (unsigned)chunks), dim3(TPB), 0, (hipStream_t)stream, x, ldx, rows, C, rpb, (__bf16*)y,

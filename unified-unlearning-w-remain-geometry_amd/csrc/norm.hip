@@ -220,12 +220,19 @@ __global__ __launch_bounds__(TPB) void k_reduce_chunks(const float* __restrict__
   const float* p = P + (size_t)g * per_group * D + c;
   float s = 0.f;
   int j = 0;
-  for (; j + 8 <= per_group; j += 8) {            // 8 loads in flight, summed in index order
-    float v[8];
+  for (; j + 16 <= per_group; j += 16) {          // 16 loads in flight, summed in index order
+    float v[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(j + u) * D];
+    for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(j + u) * D];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
+    for (int u = 0; u < 16; ++u) s += v[u];
+  }
+  for (; j + 4 <= per_group; j += 4) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = p[(size_t)(j + u) * D];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += v[u];
   }
   for (; j < per_group; ++j) s += p[(size_t)j * D];
   float* o = out + (size_t)g * ldout + c;

@@ -129,7 +129,8 @@ def colsum_bf16(x, rows, n, ld, out, scratch):
 def cast_rows_colsum(x, ldx, rows, C, dev, colsum_out, scratch):
     """bf16 copy of fp32 rows AND their column sums (-> colsum_out, a tensor or device address) in one pass."""
     y = torch.empty(rows, C, dtype=torch.bfloat16, device=dev)
-    check(_L().sfron_cast_rows_colsum(_addr(x), ldx, rows, C, ptr(y), ptr(scratch), 64, _addr(colsum_out), stream_ptr()), "cast_rows_colsum")
+    check(_L().sfron_cast_rows_colsum(_addr(x), ldx, rows, C, ptr(y), ptr(scratch), min(512, scratch.numel() // C), _addr(colsum_out), stream_ptr()),
+          "cast_rows_colsum")
     return y
 
 
