@@ -890,6 +890,8 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
 }
 
 template __global__ void k_attn_bwd_fused<64, 2, 4, 2>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float);
+template __global__ void k_attn_bwd_fused<64, 2, 3, 2>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float);
+template __global__ void k_attn_bwd_fused<64, 2, 3, 1>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float);
 template __global__ void k_attn_bwd_fused<96, 3, 5, 2>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float);
 template __global__ void k_attn_bwd_fused<64, 2, 4, 1>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float);
 template __global__ void k_attn_bwd_fused<96, 3, 5, 1>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float);
@@ -901,6 +903,7 @@ template __global__ void k_attn_bwd_fused<96, 3, 5, 1>(const __bf16*, const __bf
   template __global__ void k_attn_bwd_dq<HDP, KS, NDT, 2>(const __bf16*, const __bf16*, const __bf16*, const float*, float*, __bf16*, int, int, int, float); \
   template __global__ void k_attn_bwd_dkv<HDP, KS, NDT, 1>(const __bf16*, const __bf16*, const float*, const float*, __bf16*, int, int, int, float);
 SFRON_INST_ATTN(64, 2, 4)
+SFRON_INST_ATTN(64, 2, 3)      // head_dim <= 48 (the LDM UNet's 40): three output d-tiles instead of four
 SFRON_INST_ATTN(96, 3, 5)
 #undef SFRON_INST_ATTN
 
@@ -973,6 +976,7 @@ int sfron_attn_fwd(const uint16_t* qkv, uint16_t* o, float* lse, int B, int T, i
   // any head_dim that is a multiple of 8 up to 96 runs on the 64- or 96-column images (columns beyond head_dim are zero padding):
   // DiT 64 / 72, the LDM UNet's 40 and 80
   if (hd % 8 != 0 || hd < 8) return SFRON_ERR_UNSUPPORTED;
+  if (hd <= 48) return launch_fwd<64, 2, 3>((const __bf16*)qkv, (__bf16*)o, lse, B, T, H, hd, scale, s);
   if (hd <= 64) return launch_fwd<64, 2, 4>((const __bf16*)qkv, (__bf16*)o, lse, B, T, H, hd, scale, s);
   if (hd <= 96) return launch_fwd<96, 3, 5>((const __bf16*)qkv, (__bf16*)o, lse, B, T, H, hd, scale, s);
   return SFRON_ERR_UNSUPPORTED;
@@ -988,6 +992,8 @@ int sfron_attn_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, 
   const float scale = 1.0f / sqrtf((float)hd);
   hipStream_t s = (hipStream_t)stream;
   if (hd % 8 != 0 || hd < 8) return SFRON_ERR_UNSUPPORTED;
+  if (hd <= 48)
+    return launch_bwd<64, 2, 3>((const __bf16*)qkv, (const __bf16*)o, (const __bf16*)d_o, lse, delta_scratch, (__bf16*)dqkv, B, T, H, hd, scale, s);
   if (hd <= 64)
     return launch_bwd<64, 2, 4>((const __bf16*)qkv, (const __bf16*)o, (const __bf16*)d_o, lse, delta_scratch, (__bf16*)dqkv, B, T, H, hd, scale, s);
   if (hd <= 96)
