@@ -156,8 +156,12 @@ class SDFisherAccumulator:
         x, noise, t = batch["x"], batch["noise"].contiguous(), batch["t"]
         B, chw = x.shape[0], x[0].numel()
         x_t = self.s.q_sample(x, t, noise)
-        out_c, bwd_c = u._run(x_t, t, batch["c"], need_grad=True)
-        out_n, bwd_n = u._run(x_t, t, batch["c_null"], need_grad=True)
+        keep, u.wgrad_filter = u.wgrad_filter, None           # every parameter's gradient (an xattn SDSFRon may have narrowed it)
+        try:
+            out_c, bwd_c = u._run(x_t, t, batch["c"], need_grad=True)
+            out_n, bwd_n = u._run(x_t, t, batch["c_null"], need_grad=True)
+        finally:
+            u.wgrad_filter = keep
         preds = torch.empty_like(out_c)
         check(L.sfron_axpby(ptr(out_c), ptr(out_n), 1.0 + self.c, -self.c, preds.numel(), ptr(preds), stream_ptr()), "axpby")
         per = torch.empty(B, dtype=torch.float32, device=x.device)

@@ -265,6 +265,8 @@ class UNetModel(_TapeNet):
         out_t, pout_b = self._linear(x3b, rows, name + ".proj_out", C, C, resid=x.t)
         out = Act(out_t, B, x.H, x.W, C)
 
+        trains_qkv1 = self._trains(t + ".attn1.to_q.weight")
+
         def add(dst, src, cols):
             g, acc = dst.grad_buf()
             check(_L().sfron_copy_cols(ptr(src), cols, rows, cols, ptr(g), cols, acc, stream_ptr()), "copy_cols")
@@ -297,7 +299,7 @@ class UNetModel(_TapeNet):
             dO1b = cast_rows(dO1, C, rows, C, dev)
             dqkv = torch.empty(rows, 3 * C, dtype=torch.bfloat16, device=dev)
             att1_b(dO1b, dqkv.data_ptr(), dqkv.data_ptr() + 2 * C, dqkv.data_ptr() + 4 * C)
-            if self._trains(t + ".attn1.to_q.weight"):
+            if trains_qkv1:
                 bgemm(dqkv, n1, 3 * C, C, rows, lda=3 * C, ldb=C, a_t=True, b_t=True, c_f32=self._g(t + ".attn1.to_q.weight"), ldc=C)
             dn1 = torch.empty(rows, C, dtype=torch.float32, device=dev)
             bgemm(dqkv, wqkv, rows, C, 3 * C, lda=3 * C, ldb=C, b_t=True, c_f32=dn1, ldc=C)
@@ -445,7 +447,11 @@ class UNetModel(_TapeNet):
 class _SDFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, x, t, context):
-        out, bwd = model._run(x, t, context, need_grad=True)
+        keep, model.wgrad_filter = model.wgrad_filter, None        # the autograd surface always forms every gradient
+        try:
+            out, bwd = model._run(x, t, context, need_grad=True)
+        finally:
+            model.wgrad_filter = keep
         ctx.model, ctx.bwd = model, bwd
         return out
 

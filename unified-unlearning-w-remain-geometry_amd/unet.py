@@ -302,12 +302,14 @@ class _TapeNet(nn.Module):
                        out_f32=out, ld_out=v["cop"])
         check(_L().sfron_conv_fwd(ctypes.byref(d), ptr(src), ptr(v["fwd"]), stream_ptr()), "conv_fwd")
 
+        trains = self._trains(name + ".weight")          # decided when the tape is built, not when it runs
+
         def bwd(d_out, want_dsrc=True):
-            if self._trains(name + ".weight") and v["cop"] == v["co"] and v["co"] % 4 == 0:
+            if trains and v["cop"] == v["co"] and v["co"] % 4 == 0:
                 dyb = cast_rows_colsum(d_out, v["cop"], rows, v["cop"], dev, self._g(name + ".bias"), self._cs)     # bf16 operand + bias gradient
             else:
                 dyb = cast_rows(d_out, v["cop"], rows, v["cop"], dev)
-            if not self._trains(name + ".weight"):
+            if not trains:
                 pass                                     # frozen kernel: only the input gradient below
             elif v["cop"] == v["co"] and v["co"] % 4 == 0:
                 pass
@@ -317,7 +319,7 @@ class _TapeNet(nn.Module):
                 bg = torch.empty(v["cop"], dtype=torch.float32, device=dev)
                 colsum_f32(d_out, rows, v["cop"], v["cop"], bg, self._cs)
                 self.view(self.grads, name + ".bias").copy_(bg[:v["co"]])
-            if self._trains(name + ".weight"):
+            if trains:
                 wd = _conv_desc(B, hs, ws, v["cip"], ho, wo, v["cop"], 9, stride, pad, up, 0)
                 nsl = _L().sfron_conv_wgrad_splits(ctypes.byref(wd))
                 slab = v["cop"] * 9 * v["cip"]
@@ -361,9 +363,10 @@ class _TapeNet(nn.Module):
         gw = g_w if g_w is not None else self._g(name + ".weight")
         gb = (g_b if g_b is not None else self._g(name + ".bias")) if bias else None
 
+        frozen = name is not None and not self._trains(name + ".weight")      # decided when the tape is built
+
         def bwd(d_out, ld_d, want_dx=True, d_bf=None):
             """d_out fp32 [rows][ld_d] (or None when only the bf16 form d_bf [rows][cout] exists)."""
-            frozen = name is not None and not self._trains(name + ".weight")
             fused = d_bf is None and bias and not frozen and cout % 4 == 0 and ld_d % 4 == 0 and not isinstance(d_out, int)
             if fused:
                 d_bf = cast_rows_colsum(d_out, ld_d, rows, cout, dev, gb, self._cs)
