@@ -1,0 +1,188 @@
+// Probe: how much of a K = 1152 block GEMM is per-tile fixed cost, and what a PERSISTENT grid recovers.  bf16 C[M][N] = A[M][K] B[N][K]^T
+// on the pipelined 256 x 128 x 64 three-slot tile (as csrc/conv.hip k_cgemm), in two forms:
+//   plain      : one workgroup per output tile (what the library launches)
+//   persistent : one workgroup per CU walks its tiles as ONE stream of K-tiles -- the LDS ring never drains at a tile boundary (the next
+//                tile's first two K-tiles are in flight during the last two of the current one), and the epilogue's stores are issued
+//                without waiting: the counted vmcnt waits of the next two steps allow for them (stores and LDS-DMA loads retire in order)
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-value tools/probes/persist_gemm_probe.hip -o tools/probes/persist_gemm_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+constexpr int FBM = 256, BK = 64, NSLOT = 3;
+// WM x WN waves, each MT x NT tiles of 16 x 16: the wave tile (16 MT x 16 NT) sets the LDS bytes read per FLOP, (MT + NT) / (MT NT)
+template <int WM, int WN, int MT, int NT_> struct Cfg {
+  static_assert(WM * MT * 16 == FBM, "256 rows");
+  static constexpr int NW = WM * WN, FBN = WN * NT_ * 16, A_EL = FBM * BK, B_EL = FBN * BK, SLOT = A_EL + B_EL;
+  static constexpr int NA = FBM * 8 / 64 / NW, NB_TOT = FBN * 8 / 64, NB = (NB_TOT + NW - 1) / NW;
+  static constexpr bool EVEN = NB_TOT % NW == 0;
+  static constexpr int NDMA = NA + NB, NST = MT * NT_;
+  static constexpr size_t LDS = (size_t)NSLOT * SLOT * 2 + (EVEN ? 0 : 1024);
+};
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, __bf16* dst, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t*)dst, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ bf16x8 frag(const __bf16* img, int row, int kchunk) {
+  return *reinterpret_cast<const bf16x8*>(img + row * 64 + ((kchunk ^ (row & 7)) << 3));
+}
+
+template <int WM, int WN, int MT, int NT_, bool PERSIST>
+__global__ __launch_bounds__(WM * WN * 64) void k_gemm(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* __restrict__ C, int M, int N, int K) {
+  using CT = Cfg<WM, WN, MT, NT_>;
+  constexpr int NW = CT::NW;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntn = N / CT::FBN, ntiles = (M / FBM) * ntn, nk = K / BK;
+  int id;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x, q = nblk >> 3, r = nblk & 7, x = b & 7, y = b >> 3;
+    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+  }
+  const int n_my = PERSIST ? (ntiles - id + (int)gridDim.x - 1) / (int)gridDim.x : 1;      // tiles id, id + G, id + 2G, ...
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, M * K * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, N * K * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0, 0x00020000);
+  __bf16* dummy = smem + NSLOT * CT::SLOT;
+  const int lc8 = ((lane & 7) ^ ((lane >> 3) & 7)) << 3;
+  int a_off[CT::NA], b_off[CT::NB];                       // per-lane constants; the tile and the K step travel in the scalar offset
+#pragma unroll
+  for (int i = 0; i < CT::NA; ++i) a_off[i] = 2 * (((wave + i * NW) * 8 + (lane >> 3)) * K + lc8);
+#pragma unroll
+  for (int i = 0; i < CT::NB; ++i) b_off[i] = 2 * (((wave + i * NW) * 8 + (lane >> 3)) * K + lc8);
+  auto tile_of = [&](int ti, int& m0, int& n0) { const int t = id + ti * (int)gridDim.x; const int tm = t / ntn; m0 = tm * FBM; n0 = (t - tm * ntn) * CT::FBN; };
+  auto issue = [&](int slot, int ti, int kt) {
+    int m0, n0; tile_of(ti, m0, n0);
+    __bf16* iA = smem + slot * CT::SLOT;
+    __bf16* iB = iA + CT::A_EL;
+    const int sa = 2 * (m0 * K + kt * BK), sb = 2 * (n0 * K + kt * BK);
+#pragma unroll
+    for (int i = 0; i < CT::NA; ++i) dma16(rsA, iA + (wave + i * NW) * 512, a_off[i], sa);
+#pragma unroll
+    for (int i = 0; i < CT::NB; ++i) {
+      if (CT::EVEN || i + 1 < CT::NB) dma16(rsB, iB + (wave + i * NW) * 512, b_off[i], sb);
+      else { const bool ok = wave + i * NW < CT::NB_TOT; dma16(ok ? rsB : rs0, ok ? iB + (wave + i * NW) * 512 : dummy, b_off[i], sb); }
+    }
+  };
+  f32x4 acc[MT][NT_];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT_; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fg = lane >> 4;
+  auto compute = [&](int slot) {
+    const __bf16* iA = smem + slot * CT::SLOT;
+    const __bf16* iB = iA + CT::A_EL;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) fa[mt] = frag(iA, wm * MT * 16 + mt * 16 + fr, ks * 4 + fg);
+#pragma unroll
+      for (int nt = 0; nt < NT_; ++nt) {
+        const bf16x8 fb = frag(iB, wn * NT_ * 16 + nt * 16 + fr, ks * 4 + fg);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[mt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+  };
+  const int S = n_my * nk;
+  // step s = (tile s / nk, K-tile s % nk); (ti, kt) of the step being issued run two steps ahead
+  int i_ti = 0, i_kt = 0;
+  auto issue_next = [&](int slot) { issue(slot, i_ti, i_kt); if (++i_kt == nk) { i_kt = 0; ++i_ti; } };
+  if (S > 0) issue_next(0);
+  if (S > 1) issue_next(1);
+  int slot = 0, ti = 0, kt = 0;
+  for (int s = 0; s < S; ++s) {
+    // DMA(s) has landed: younger operations are DMA(s + 1) and the stores of a tile that ended one or two steps ago
+    const bool st = PERSIST && ti > 0 && kt < 2;
+    if (s + 1 < S) { if (st) wait_vmcnt<CT::NDMA + CT::NST>(); else wait_vmcnt<CT::NDMA>(); }
+    else           { if (st) wait_vmcnt<CT::NST>(); else wait_vmcnt<0>(); }
+    __builtin_amdgcn_s_barrier();
+    if (s + 2 < S) issue_next(slot >= 1 ? slot - 1 : 2);
+    compute(slot);
+    slot = slot == 2 ? 0 : slot + 1;
+    if (++kt == nk) {
+      int m0, n0; tile_of(ti, m0, n0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = m0 + wm * MT * 16 + mt * 16 + fr;
+#pragma unroll
+        for (int nt = 0; nt < NT_; ++nt) {
+          const f32x4 v = acc[mt][nt];
+          *reinterpret_cast<bf16x4*>(C + (size_t)row * N + n0 + wn * NT_ * 16 + nt * 16 + 4 * fg) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+          acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      kt = 0; ++ti;
+    }
+  }
+}
+
+static uint16_t f2bf(float f) { uint32_t u; std::memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
+static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
+
+template <int WM, int WN, int MT, int NT_>
+void run(const char* name, int M, int N, int K) {
+  using CT = Cfg<WM, WN, MT, NT_>;
+  if (N % CT::FBN || CT::LDS > 160 * 1024) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<WM, WN, MT, NT_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT::LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<WM, WN, MT, NT_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT::LDS);
+  std::vector<uint16_t> hA((size_t)M * K), hB((size_t)N * K);
+  uint32_t st = 777u + N + K;
+  auto rnd = [&]() { st = st * 1664525u + 1013904223u; return st >> 8; };
+  for (auto& v : hA) v = f2bf((float)((int)(rnd() % 5) - 2));             // small integers: exact products and sums
+  for (auto& v : hB) v = f2bf((float)((int)(rnd() % 5) - 2));
+  __bf16 *dA, *dB, *dC;
+  hipMalloc(&dA, hA.size() * 2); hipMalloc(&dB, hB.size() * 2); hipMalloc(&dC, (size_t)M * N * 2);
+  hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
+  const int ntiles = (M / FBM) * (N / CT::FBN);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  std::vector<uint16_t> hC((size_t)M * N);
+  for (int persist = 0; persist < 2; ++persist) {
+    const dim3 grid(persist ? (ntiles < 256 ? ntiles : 256) : ntiles);
+    auto launch = [&]() {
+      if (persist) hipLaunchKernelGGL((k_gemm<WM, WN, MT, NT_, true>), grid, dim3(CT::NW * 64), CT::LDS, 0, dA, dB, dC, M, N, K);
+      else         hipLaunchKernelGGL((k_gemm<WM, WN, MT, NT_, false>), grid, dim3(CT::NW * 64), CT::LDS, 0, dA, dB, dC, M, N, K);
+    };
+    hipMemset(dC, 0xff, (size_t)M * N * 2);
+    launch(); hipDeviceSynchronize();
+    hipMemcpy(hC.data(), dC, hC.size() * 2, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int t = 0; t < 6000; ++t) {
+      const int r = rnd() % M, c = rnd() % N;
+      float ref = 0.f;
+      for (int k = 0; k < K; ++k) ref += bf2f(hA[(size_t)r * K + k]) * bf2f(hB[(size_t)c * K + k]);
+      if (hC[(size_t)r * N + c] != f2bf(ref)) ++bad;
+    }
+    for (int i = 0; i < 5; ++i) launch();
+    hipEventRecord(e0);
+    const int reps = 30;
+    for (int i = 0; i < reps; ++i) launch();
+    hipEventRecord(e1); hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("%-16s tile 256x%-3d waves %dx%d (%3dx%-3d each) %-10s grid %4d: %7.1f us  %7.1f TFLOP/s   exact-integer check: %d / 6000 wrong\n", name, CT::FBN, WM, WN, MT * 16, NT_ * 16,
+           persist ? "persistent" : "plain", (int)grid.x, ms * 1e3, 2.0 * M * N * K / ms / 1e9, bad);
+  }
+  hipFree(dA); hipFree(dB); hipFree(dC);
+}
+
+int main() {
+  const int M = 8192;
+  struct Shape { const char* name; int N, K; } shapes[] = {{"qkv  1152->3456", 3456, 1152}, {"proj 1152->1152", 1152, 1152},
+                                                           {"fc1  1152->4608", 4608, 1152}, {"fc2  4608->1152", 1152, 4608}};
+  for (const Shape& s : shapes) {
+    run<8, 1, 2, 8>(s.name, M, s.N, s.K); run<4, 2, 4, 4>(s.name, M, s.N, s.K); run<4, 1, 4, 8>(s.name, M, s.N, s.K);
+    run<8, 1, 2, 9>(s.name, M, s.N, s.K); run<4, 1, 4, 9>(s.name, M, s.N, s.K); run<2, 2, 8, 4>(s.name, M, s.N, s.K);
+  }
+  return 0;
+}
