@@ -674,6 +674,21 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
         dma16(img ? rsO : rsQ, slot + img * IMG + jj * 512, dmaC.off[i], ch * 64 * (img ? D : ld) * 2);
     }
   };
+  // delta[q] = sum_d dO[q][d] O[q][d]: two threads per query row, each with a 16-byte-aligned run of the head's columns; ALL their
+  // loads go out here, ahead of the LDS-DMA traffic (vector-memory operations retire in order: issued behind the 37 KB K image they
+  // would wait for it, and a load-use loop would pay one memory latency per iteration)
+  constexpr int NDC = HDP / 16;
+  static_assert(T <= FNT / 2 || T == FNT / 2, "one query row per thread pair");
+  bf16x8 d_dd[NDC], d_oo[NDC];
+  const int d_q = tid >> 1, d_split = ((hd + 15) >> 4) << 3;
+  const int d_beg = (tid & 1) ? d_split : 0, d_len = (tid & 1) ? hd - d_split : d_split;
+#pragma unroll
+  for (int j = 0; j < NDC; ++j) {
+    const bool in = d_q < T && j * 8 < d_len;
+    const size_t e = (size_t)(in ? d_q : 0) * D + (in ? d_beg + j * 8 : 0);
+    d_dd[j] = *reinterpret_cast<const bf16x8*>(dob + e);
+    d_oo[j] = *reinterpret_cast<const bf16x8*>(ob + e);
+  }
 #pragma unroll
   for (int i = 0; i < GroupDma<HDP, NCH>::PER_WAVE; ++i) {
     const int j = wave + FNW * i, img = j / CPR, jj = j % CPR;
@@ -690,22 +705,18 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
   for (int ki = 0; ki < KT; ++ki)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) fv[ki][ks] = frag_rows_global(base + 2 * D, ld, k0 + 16 * ki, ks, hd, lane);
-  // -lse * log2(e) and delta[q] = sum_d dO[q][d] O[q][d] (two threads per query row, 8-byte loads)
+  // -lse * log2(e), and delta from the operands fetched at the top
   for (int i = tid; i < T; i += FNT) s_lse[i] = -lse[(size_t)bh * T + i] * LOG2E;
   {
-    const int half = tid & 1, hw = hd >> 1;
-    for (int q = tid >> 1; q < T; q += FNT / 2) {
-      const __bf16* pd = dob + (size_t)q * D + half * hw;
-      const __bf16* po = ob + (size_t)q * D + half * hw;
-      float dsum = 0.f;
-      for (int d = 0; d < hw; d += 4) {
-        const bf16x4 a = *reinterpret_cast<const bf16x4*>(pd + d), bb = *reinterpret_cast<const bf16x4*>(po + d);
+    float dsum = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dsum += bf2f(a[j]) * bf2f(bb[j]);
+    for (int j = 0; j < NDC; ++j)
+      if (d_q < T && j * 8 < d_len) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsum += bf2f(d_dd[j][e]) * bf2f(d_oo[j][e]);
       }
-      dsum += __shfl_xor(dsum, 1, 64);
-      if (!half) s_del[q] = dsum;
-    }
+    dsum += __shfl_xor(dsum, 1, 64);
+    if (!(tid & 1) && d_q < T) s_del[d_q] = dsum;
   }
   // pad columns of the ring and of the K image (never written by the DMA)
   {
