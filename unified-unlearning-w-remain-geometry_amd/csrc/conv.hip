@@ -285,7 +285,7 @@ template __global__ void k_bgemm<true, true, EPI_RES, CONV_B>(BGemmArgs);
 
 // =================================================================================================
 // LDS-DMA pipelined tile for the large direct-operand products (3x3 / 1x1 convolution forward and input gradient, Linear forward):
-// 256 x (NT_ * 16) x 64, 8 waves stacked over the rows (32 x NT_*16 each), THREE LDS slots (two K-tiles in flight per CU, the
+// 256 x (NT_ * 16) x 64, 8 waves as 4 x 2 (64 x NT_*8 each), THREE LDS slots (two K-tiles in flight per CU, the
 // operands of a U-Net pass are cold in L2), operands staged by `buffer_load_dwordx4 ... lds` with the XOR swizzle applied on the
 // SOURCE address (the LDS image is lane-linear).  The im2col gather is address arithmetic of the A-operand DMA: a lane owns four
 // output pixels (b, ho, wo); per K-tile the tap (kh, kw) and the channel offset are wave-uniform (C % 64 == 0), the lane adds the
@@ -389,11 +389,16 @@ __global__ __launch_bounds__(512) void k_cgemm(BGemmArgs g, unsigned a_bytes, un
     if (CONV) { c0 += BK; if (c0 >= g.cg.C) { c0 = 0; ++tap; } }
   };
 
-  f32x4 acc[2][NT_];
+  // 4 x 2 waves of 64 x (NT_ / 2 * 16): per K-step a wave reads (4 + NT_ / 2) fragments for 4 * NT_ / 2 MFMAs -- a quarter less LDS traffic
+  // per FLOP than 8 x 1 waves of 32 x NT_ * 16 (measured 6-7 % on every shape, tools/probes/persist_gemm_probe.hip)
+  constexpr int WNT = NT_ / 2;
+  static_assert(NT_ % 2 == 0, "two wave columns");
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x4 acc[4][WNT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < NT_; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < WNT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fg = lane >> 4;
   auto compute = [&](int slot) {
@@ -401,13 +406,14 @@ __global__ __launch_bounds__(512) void k_cgemm(BGemmArgs g, unsigned a_bytes, un
     const __bf16* iB = iA + CT::A_ELEMS;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 fa0 = frag_direct(iA, wave * 32 + fr, ks * 4 + fg);
-      const bf16x8 fa1 = frag_direct(iA, wave * 32 + 16 + fr, ks * 4 + fg);
+      bf16x8 fa[4];
 #pragma unroll
-      for (int nt = 0; nt < NT_; ++nt) {
-        const bf16x8 fb = frag_direct(iB, nt * 16 + fr, ks * 4 + fg);
-        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa0, acc[0][nt], 0, 0, 0);
-        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa1, acc[1][nt], 0, 0, 0);
+      for (int mt = 0; mt < 4; ++mt) fa[mt] = frag_direct(iA, wm * 64 + mt * 16 + fr, ks * 4 + fg);
+#pragma unroll
+      for (int nt = 0; nt < WNT; ++nt) {
+        const bf16x8 fb = frag_direct(iB, wn * WNT * 16 + nt * 16 + fr, ks * 4 + fg);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[mt], acc[mt][nt], 0, 0, 0);
       }
     }
   };
@@ -425,11 +431,11 @@ __global__ __launch_bounds__(512) void k_cgemm(BGemmArgs g, unsigned a_bytes, un
   }
 
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int row = m0 + wave * 32 + mt * 16 + fr;
+  for (int mt = 0; mt < 4; ++mt) {
+    const int row = m0 + wm * 64 + mt * 16 + fr;
 #pragma unroll
-    for (int nt = 0; nt < NT_; ++nt) {
-      const int col = n0 + nt * 16 + 4 * fg;
+    for (int nt = 0; nt < WNT; ++nt) {
+      const int col = n0 + wn * WNT * 16 + nt * 16 + 4 * fg;
       if (col < g.N) epi_store<EPI>(g, row, col, acc[mt][nt]);
     }
   }
