@@ -911,11 +911,12 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd(const float* __restrict__ dy, co
 // (thread = (row replica r, quad lane q); C / 4 quads per row, up to three quads per thread for C > 1024), so every load is a
 // full-line stream.  Phase 1 leaves per-chunk partial sums, phase 2 (same chunking) combines them in a fixed order in its
 // prologue and applies the normalisation; all per-channel / per-group sums are formed in a fixed order (bitwise reproducible).
-constexpr int GN_MAXQ = 3;                      // quads per thread: C <= 3 * 4 * TPB = 3072
+constexpr int GNB = 1024;                       // 16 waves per workgroup: with one workgroup per (sample, chunk) the chip is only full this way
+constexpr int GN_MAXQ = 1;                      // quads per thread: C <= 4 * GNB = 4096
 struct GnMap {
   int qpr, qw, rpp, r, ql, nq;                  // quads per row, quad lanes, rows per pass, this thread's row replica / lane, its quads
   __device__ __forceinline__ void init(int C) {
-    qpr = C >> 2; qw = qpr < TPB ? qpr : TPB; rpp = TPB / qw;
+    qpr = C >> 2; qw = qpr < GNB ? qpr : GNB; rpp = GNB / qw;
     r = threadIdx.x / qw; ql = threadIdx.x - r * qw; nq = (qpr - ql + qw - 1) / qw;
     if (r >= rpp) nq = 0;
   }
@@ -928,7 +929,7 @@ __host__ __device__ inline int gn_chunks(int B, int HW) {
 }
 
 // phase 1 forward: partial (sum, sum of squares) per (sample, chunk, group), fp64
-__global__ __launch_bounds__(TPB) void k_gn2_stats(const float* __restrict__ x, int ldx, int HW, int C, int G, int nchunk, double* __restrict__ part) {
+__global__ __launch_bounds__(GNB) void k_gn2_stats(const float* __restrict__ x, int ldx, int HW, int C, int G, int nchunk, double* __restrict__ part) {
   extern __shared__ double shd[];               // [rpp][C][2]
   const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk, cg = C / G;
   const int p0 = (int)((long)HW * ch / nchunk), p1 = (int)((long)HW * (ch + 1) / nchunk);
@@ -968,7 +969,7 @@ __global__ __launch_bounds__(TPB) void k_gn2_stats(const float* __restrict__ x, 
   }
 }
 // phase 2 forward: mean / rstd from the partials (every workgroup of a sample forms them the same way; chunk 0 stores them), apply
-__global__ __launch_bounds__(TPB) void k_gn2_apply(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+__global__ __launch_bounds__(GNB) void k_gn2_apply(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    int HW, int C, int G, float eps, int swish, const uint8_t* __restrict__ mask, float drop_scale,
                                                    int nchunk, const double* __restrict__ part, __bf16* __restrict__ y, float* __restrict__ mean,
                                                    float* __restrict__ rstd) {
@@ -1020,7 +1021,7 @@ __global__ __launch_bounds__(TPB) void k_gn2_apply(const float* __restrict__ x, 
   }
 }
 // phase 1 backward: per (sample, chunk, channel) partial sums of dz * xhat and dz, dz = dy * act'(z) (* dropout)
-__global__ __launch_bounds__(TPB) void k_gn2_bwd_stats(const float* __restrict__ dy, const float* __restrict__ x, int ldx,
+__global__ __launch_bounds__(GNB) void k_gn2_bwd_stats(const float* __restrict__ dy, const float* __restrict__ x, int ldx,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd, int HW, int C, int G,
                                                        int swish, const uint8_t* __restrict__ mask, float drop_scale, int nchunk,
@@ -1075,7 +1076,7 @@ __global__ __launch_bounds__(TPB) void k_gn2_bwd_stats(const float* __restrict__
         }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += TPB) {
+  for (int c = threadIdx.x; c < C; c += GNB) {
     float a = 0.f, q = 0.f;
     for (int r = 0; r < m.rpp; ++r) { a += shf[((size_t)r * C + c) * 2]; q += shf[((size_t)r * C + c) * 2 + 1]; }
     float* o = part + (((size_t)b * nchunk + ch) * C + c) * 2;
@@ -1084,7 +1085,7 @@ __global__ __launch_bounds__(TPB) void k_gn2_bwd_stats(const float* __restrict__
 }
 // phase 2 backward: per-channel sums over the chunks -> (chunk 0) the per-sample parameter-gradient partials, the group means
 // k1 = mean(dz gamma), k2 = mean(dz gamma xhat); dx (+)= rstd (dz gamma - k1 - xhat k2)
-__global__ __launch_bounds__(TPB) void k_gn2_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, int ldx,
+__global__ __launch_bounds__(GNB) void k_gn2_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, int ldx,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd, int HW, int C, int G,
                                                        int swish, const uint8_t* __restrict__ mask, float drop_scale, int nchunk,
@@ -1093,7 +1094,7 @@ __global__ __launch_bounds__(TPB) void k_gn2_bwd_apply(const float* __restrict__
   extern __shared__ float shf[];                // [C][2] channel sums, then [G][2] group means
   const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk, cg = C / G;
   float* kk = shf + 2 * C;
-  for (int c = threadIdx.x; c < C; c += TPB) {
+  for (int c = threadIdx.x; c < C; c += GNB) {
     float a = 0.f, q = 0.f;
     for (int k = 0; k < nchunk; ++k) { const float* o = part + (((size_t)b * nchunk + k) * C + c) * 2; a += o[0]; q += o[1]; }
     shf[2 * c] = a; shf[2 * c + 1] = q;
@@ -1797,10 +1798,10 @@ int64_t sfron_groupnorm_scratch_bytes(int B, int HW, int C, int groups) {
   return f > bw ? f : bw;
 }
 static bool gn2_ok(int ldx, int ld2, int C, int groups, const void* scratch) {
-  return scratch && C % 4 == 0 && ldx % 4 == 0 && ld2 % 4 == 0 && C <= GN_MAXQ * 4 * TPB && groups <= 64 && ((uintptr_t)scratch & 15) == 0;
+  return scratch && C % 4 == 0 && ldx % 4 == 0 && ld2 % 4 == 0 && C <= GN_MAXQ * 4 * GNB && groups <= 64 && ((uintptr_t)scratch & 15) == 0;
 }
 static size_t gn2_lds(int C, int elem) {
-  const int qpr = C / 4, qw = qpr < TPB ? qpr : TPB, rpp = TPB / qw;
+  const int qpr = C / 4, qw = qpr < GNB ? qpr : GNB, rpp = GNB / qw;
   return (size_t)rpp * C * 2 * elem;
 }
 int sfron_groupnorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, int B, int HW, int C, int groups, float eps,
@@ -1809,10 +1810,10 @@ int sfron_groupnorm_fwd(const float* x, int ldx, const float* gamma, const float
   SFRON_CHECK_ARG(x && gamma && beta && y && mean && rstd && groups > 0 && C % groups == 0 && ldx >= C && C / groups <= TPB);
   if (gn2_ok(ldx, C, C, groups, scratch) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 && (!drop_mask || ((uintptr_t)drop_mask & 3) == 0)) {
     const int nchunk = gn_chunks(B, HW);
-    hipLaunchKernelGGL(k_gn2_stats, dim3(B * nchunk), dim3(TPB), gn2_lds(C, sizeof(double)), (hipStream_t)stream, x, ldx, HW, C, groups, nchunk,
+    hipLaunchKernelGGL(k_gn2_stats, dim3(B * nchunk), dim3(GNB), gn2_lds(C, sizeof(double)), (hipStream_t)stream, x, ldx, HW, C, groups, nchunk,
                        (double*)scratch);
     SFRON_LAUNCH_STATUS();
-    hipLaunchKernelGGL(k_gn2_apply, dim3(B * nchunk), dim3(TPB), 0, (hipStream_t)stream, x, ldx, gamma, beta, HW, C, groups, eps, swish, drop_mask,
+    hipLaunchKernelGGL(k_gn2_apply, dim3(B * nchunk), dim3(GNB), 0, (hipStream_t)stream, x, ldx, gamma, beta, HW, C, groups, eps, swish, drop_mask,
                        drop_scale, nchunk, (const double*)scratch, (__bf16*)y, mean, rstd);
     SFRON_LAUNCH_STATUS();
     return SFRON_OK;
@@ -1831,10 +1832,10 @@ int sfron_groupnorm_bwd(const float* dy, const float* x, int ldx, const float* g
   if (gn2_ok(ldx, lddx, C, groups, scratch) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0 &&
       (!drop_mask || ((uintptr_t)drop_mask & 3) == 0)) {
     const int nchunk = gn_chunks(B, HW);
-    hipLaunchKernelGGL(k_gn2_bwd_stats, dim3(B * nchunk), dim3(TPB), gn2_lds(C, sizeof(float)), (hipStream_t)stream, dy, x, ldx, gamma, beta, mean, rstd,
+    hipLaunchKernelGGL(k_gn2_bwd_stats, dim3(B * nchunk), dim3(GNB), gn2_lds(C, sizeof(float)), (hipStream_t)stream, dy, x, ldx, gamma, beta, mean, rstd,
                        HW, C, groups, swish, drop_mask, drop_scale, nchunk, (float*)scratch);
     SFRON_LAUNCH_STATUS();
-    hipLaunchKernelGGL(k_gn2_bwd_apply, dim3(B * nchunk), dim3(TPB), (size_t)(2 * C + 2 * groups) * sizeof(float), (hipStream_t)stream, dy, x, ldx, gamma,
+    hipLaunchKernelGGL(k_gn2_bwd_apply, dim3(B * nchunk), dim3(GNB), (size_t)(2 * C + 2 * groups) * sizeof(float), (hipStream_t)stream, dy, x, ldx, gamma,
                        beta, mean, rstd, HW, C, groups, swish, drop_mask, drop_scale, nchunk, (const float*)scratch, dx, lddx, accumulate,
                        part_gamma, part_beta);
     SFRON_LAUNCH_STATUS();
