@@ -758,15 +758,23 @@ __global__ __launch_bounds__(TPB) void k_conv_wprep9_batch(const sfron_wprep_ite
 // weight gradient fp32 [nslab][Co_p][taps][Ci_p] (GEMM output, split-K slabs) -> OIHW gradient (overwrite; slabs added in order)
 __global__ __launch_bounds__(TPB) void k_conv_wgrad_scatter(const float* __restrict__ g, int Co, int Ci, int taps, int Ci_p, int nslab,
                                                             int64_t slab_stride, float* __restrict__ dw) {
-  // threads run over the GEMM layout (ci fastest): the nslab reads per element are coalesced, the single write is the strided one
-  const int64_t n = (int64_t)Co * Ci * taps;
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
-    const int ci = (int)(i % Ci); const int t = (int)((i / Ci) % taps); const int co = (int)(i / ((int64_t)taps * Ci));
-    const float* p = g + ((int64_t)co * taps + t) * Ci_p + ci;
-    float a = 0.f;
-    for (int sl = 0; sl < nslab; ++sl) a += p[sl * slab_stride];
-    dw[((int64_t)co * Ci + ci) * taps + t] = a;
-  }
+  // one workgroup per (64 input channels, output channel): thread (tap group tg, channel c) sums the slabs of taps tg, tg + 4, tg + 8
+  // (reads coalesced along ci), the [ci][tap] block is turned through LDS (row stride = taps, odd: no bank conflicts) and leaves as
+  // one contiguous run of the OIHW gradient
+  constexpr int CB = 64, TG = TPB / CB;
+  __shared__ float sh[CB * 9];
+  const int co = blockIdx.y, ci0 = blockIdx.x * CB, c = threadIdx.x % CB, tg = threadIdx.x / CB;
+  const int nci = min(CB, Ci - ci0);
+  if (c < nci)
+    for (int t = tg; t < taps; t += TG) {
+      const float* p = g + ((int64_t)co * taps + t) * Ci_p + ci0 + c;
+      float a = 0.f;
+      for (int sl = 0; sl < nslab; ++sl) a += p[sl * slab_stride];
+      sh[c * taps + t] = a;
+    }
+  __syncthreads();
+  float* o = dw + ((int64_t)co * Ci + ci0) * taps;
+  for (int k = threadIdx.x; k < nci * taps; k += TPB) o[k] = sh[k];
 }
 
 // ---- layout: NCHW fp32 image <-> NHWC rows
@@ -1764,7 +1772,8 @@ int sfron_conv_wprep_batch(const sfron_wprep_item* items_dev, int n_items, int n
 int sfron_conv_wgrad_scatter(const float* dw_gemm, int c_out, int c_in, int taps, int c_in_p, int n_slabs, int64_t slab_stride,
                              float* dw_oihw, void* stream) {
   SFRON_CHECK_ARG(dw_gemm && dw_oihw && n_slabs >= 1);
-  hipLaunchKernelGGL(k_conv_wgrad_scatter, dim3(grid_for((int64_t)c_out * c_in * taps)), dim3(TPB), 0, (hipStream_t)stream, dw_gemm,
+  SFRON_CHECK_ARG(taps <= 9);
+  hipLaunchKernelGGL(k_conv_wgrad_scatter, dim3((c_in + 63) / 64, c_out), dim3(TPB), 0, (hipStream_t)stream, dw_gemm,
                      c_out, c_in, taps, c_in_p, n_slabs, slab_stride, dw_oihw);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
