@@ -73,7 +73,19 @@ class SDSFRon:
                     n *= d
                 fm[off:off + n] &= m.reshape(-1).to(device=p.device, dtype=torch.uint8)
             self.forget_mask = fm
-        self.opt = sweep.FlatAdam(p, g, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adamw=True, mask=self.train_mask, w_bf16=w16)
+        # contiguous arena ranges that hold the trainable tensors (offsets are multiples of 8): with "xattn" the sweep streams 5 % of the arena
+        ranges = None
+        if train_method != "full":
+            spans = sorted((off, off + (int(np.prod(shape)) + 7) // 8 * 8) for name, (off, shape) in index.items() if "attn2" in name)
+            ranges = []
+            for lo, hi in spans:
+                if ranges and lo <= ranges[-1][1]:
+                    ranges[-1][1] = max(ranges[-1][1], hi)
+                else:
+                    ranges.append([lo, hi])
+            ranges = [(lo, min(hi, p.numel())) for lo, hi in ranges]
+        self.opt = sweep.FlatAdam(p, g, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adamw=True, mask=self.train_mask, w_bf16=w16,
+                                  ranges=ranges)
         unet.auto_prep = False                      # this loop tells the model when its weights changed
         unet.wgrad_filter = (lambda n: "attn2" in n) if train_method == "xattn" else None
 
