@@ -131,7 +131,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(const __bf16* __restrict_
 // ---- four waves, one per SIMD, 64 x (NT_*16) each: half the LDS reads of the 8-wave forms.  A single wave per SIMD has nobody to hide
 // its LDS latency, so the loop is software-pipelined by hand: the fragments of the NEXT K-step are read while the MFMAs of the
 // current one issue, and the tile hand-over (vmcnt wait, barrier, next DMA) sits between the two K-steps of a tile.
-template <int NT_>
+template <int NT_, int NS>
 __global__ __launch_bounds__(256) void k_gemm4(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* __restrict__ C, int M, int N, int K) {
   constexpr int NW = 4, MT = 4, FBN = NT_ * 16, A_EL = FBM * BK, B_EL = FBN * BK, SLOT = A_EL + B_EL;
   constexpr int NA = FBM * 8 / 64 / NW, NB_TOT = FBN * 8 / 64, NB = (NB_TOT + NW - 1) / NW;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_gemm4(const __bf16* __restrict__ A, con
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, M * K * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, N * K * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0, 0x00020000);
-  __bf16* dummy = smem + NSLOT * SLOT;
+  __bf16* dummy = smem + NS * SLOT;
   const int lc8 = ((lane & 7) ^ ((lane >> 3) & 7)) << 3;
   int a_off[NA], b_off[NB];
 #pragma unroll
@@ -205,11 +205,13 @@ __global__ __launch_bounds__(256) void k_gemm4(const __bf16* __restrict__ A, con
     __builtin_amdgcn_sched_barrier(0);
     mfmas(f0);
     __builtin_amdgcn_sched_barrier(0);
-    const int nslot = slot == 2 ? 0 : slot + 1;
+    const int nslot = slot == NS - 1 ? 0 : slot + 1;
     if (kt + 1 < nk) {
       wait_vmcnt<0>();                                    // tile kt + 1 (the only DMA in flight) has landed
+      // two slots: tile kt + 2 goes into THIS tile's slot -- legal once every wave holds both K-steps of tile kt in registers
+      if (NS == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                       // ... for every wave, and every wave is done with tile kt - 1's slot
-      if (kt + 2 < nk) issue(slot >= 1 ? slot - 1 : 2, kt + 2);
+      if (kt + 2 < nk) issue(NS == 2 ? slot : (slot >= 1 ? slot - 1 : 2), kt + 2);
       read(f0, nslot, 0);                                 // K-step 0 of the next tile under the MFMAs of K-step 1
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -276,12 +278,12 @@ void run(const char* name, int M, int N, int K) {
   hipFree(dA); hipFree(dB); hipFree(dC);
 }
 
-template <int NT_>
+template <int NT_, int NS>
 void run4(const char* name, int M, int N, int K) {
   constexpr int FBN = NT_ * 16;
-  const size_t lds = (size_t)NSLOT * (FBM + FBN) * BK * 2 + 1024;
+  const size_t lds = (size_t)NS * (FBM + FBN) * BK * 2 + 1024;
   if (N % FBN || lds > 160 * 1024) return;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm4<NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm4<NT_, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   std::vector<uint16_t> hA((size_t)M * K), hB((size_t)N * K);
   uint32_t st = 4242u + N + K;
   auto rnd = [&]() { st = st * 1664525u + 1013904223u; return st >> 8; };
@@ -291,7 +293,7 @@ void run4(const char* name, int M, int N, int K) {
   hipMalloc(&dA, hA.size() * 2); hipMalloc(&dB, hB.size() * 2); hipMalloc(&dC, (size_t)M * N * 2);
   hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
   const dim3 grid((M / FBM) * (N / FBN));
-  auto launch = [&]() { hipLaunchKernelGGL((k_gemm4<NT_>), grid, dim3(256), lds, 0, dA, dB, dC, M, N, K); };
+  auto launch = [&]() { hipLaunchKernelGGL((k_gemm4<NT_, NS>), grid, dim3(256), lds, 0, dA, dB, dC, M, N, K); };
   hipMemset(dC, 0xff, (size_t)M * N * 2);
   launch(); hipDeviceSynchronize();
   std::vector<uint16_t> hC((size_t)M * N);
@@ -310,8 +312,8 @@ void run4(const char* name, int M, int N, int K) {
   for (int i = 0; i < reps; ++i) launch();
   hipEventRecord(e1); hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
-  printf("%-16s tile 256x%-3d waves 4x1 ( 64x%-3d each) hand-piped grid %4d: %7.1f us  %7.1f TFLOP/s   exact-integer check: %d / 6000 wrong\n", name, FBN,
-         FBN, (int)grid.x, ms * 1e3, 2.0 * M * N * K / ms / 1e9, bad);
+  printf("%-16s tile 256x%-3d waves 4x1 ( 64x%-3d each) hand-piped %d slots grid %4d: %7.1f us  %7.1f TFLOP/s   exact-integer check: %d / 6000 wrong\n", name, FBN,
+         FBN, NS, (int)grid.x, ms * 1e3, 2.0 * M * N * K / ms / 1e9, bad);
   hipFree(dA); hipFree(dB); hipFree(dC);
 }
 
@@ -321,7 +323,7 @@ int main() {
                                                            {"fc1  1152->4608", 4608, 1152}, {"fc2  4608->1152", 1152, 4608}};
   for (const Shape& s : shapes) {
     run<4, 2, 4, 4>(s.name, M, s.N, s.K); run<8, 1, 2, 9>(s.name, M, s.N, s.K);
-    run4<8>(s.name, M, s.N, s.K); run4<9>(s.name, M, s.N, s.K);
+    run4<9, 3>(s.name, M, s.N, s.K); run4<9, 2>(s.name, M, s.N, s.K); run4<12, 2>(s.name, M, s.N, s.K); run4<16, 2>(s.name, M, s.N, s.K);
   }
   return 0;
 }
