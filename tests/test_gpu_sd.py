@@ -163,6 +163,33 @@ def test_sd_nsfw_removal_iterations_vs_oracle(method, mask_mode):
     assert same / tot > 0.97 and (num / den) ** 0.5 < 0.3
 
 
+def test_latent_diffusion_surface_p_losses_vs_oracle():
+    """LatentDiffusion.q_sample / apply_model / p_losses (ddpm.py:424-445,1121-1131,1286-1319) on the native UNet: loss and gradients
+    through torch autograd against the oracle's schedule + UNet."""
+    from oracle import sd_ref
+    from sfron import sd
+    ref, model = _pair(SMALL, seed=61)
+    ref.train()
+    ldm = sd.LatentDiffusion(model).train()
+    assert ldm.model.diffusion_model is model and ldm.num_timesteps == 1000
+    g = torch.Generator().manual_seed(62)
+    B, S, Lc = 4, 8, 6
+    x0, noise = torch.randn(B, 4, S, S, generator=g), torch.randn(B, 4, S, S, generator=g)
+    t, c = torch.randint(0, 1000, (B,), generator=g), torch.randn(B, Lc, 24, generator=g)
+    want = sd_ref.LDMSchedule().p_losses(ref, x0, c, t, noise)
+    want.backward()
+    loss, d = ldm.p_losses(x0.to(DEV), {"c_crossattn": [c.to(DEV)]}, t.to(DEV), noise.to(DEV))
+    loss.backward()
+    assert loss.item() == pytest.approx(want.item(), rel=2e-2) and "train/loss_simple" in d
+    dots = na = nb = 0.0
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        ga, gb = p.grad.detach().cpu().flatten().double(), q.grad.flatten().double()
+        dots += torch.dot(ga, gb).item(); na += ga.pow(2).sum().item(); nb += gb.pow(2).sum().item()
+    assert dots / math.sqrt(na * nb) > 0.9995
+    with pytest.raises(NotImplementedError):
+        ldm.get_input({"jpg": None}, "jpg")
+
+
 def test_sd_unet_forward_backward_bitwise_reproducible():
     """As for the DDPM U-Net: repeated forward + backward passes of the LDM UNet agree bit for bit (GroupNorm over 1 .. 2 channels per
     group here, LayerNorm, GEGLU, both attention forms, split-K slabs)."""

@@ -39,6 +39,54 @@ class LDMSchedule:
         return out
 
 
+class LatentDiffusion:
+    """The part of ldm.models.diffusion.ddpm.LatentDiffusion the unlearning scripts call on the denoiser side, over the native UNet:
+    ``model.diffusion_model`` (nsfw_removal.py:66, generate_fisher.py:30), ``num_timesteps``, ``q_sample`` (ddpm.py:424-445),
+    ``apply_model(x_noisy, t, cond)`` (:1121-1131, crossattn conditioning: cond = the prompt embedding [B, 77, 768] or
+    {"c_crossattn": [embedding]}), ``p_losses(x_start, cond, t, noise)`` -> (loss, loss_dict) (:1286-1319 with the v1-inference.yaml
+    settings: eps-parameterisation, l2, logvar = 0 and not learned, l_simple_weight 1, original_elbo_weight 0).  The outputs take part
+    in torch autograd (gradients land in the UNet's flat arena).  The first stage (VAE) and the text encoder (get_input,
+    encode_first_stage, get_learned_conditioning, shared_step) are outside the path: latents and embeddings arrive resident."""
+
+    parameterization, first_stage_key, cond_stage_key = "eps", "jpg", "txt"
+
+    def __init__(self, unet, schedule=None):
+        import types
+        self.model = types.SimpleNamespace(diffusion_model=unet, conditioning_key="crossattn")
+        self.schedule = schedule or LDMSchedule(device=unet.device_)
+        self.num_timesteps = self.schedule.num_timesteps
+        self.training = True
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        self.model.diffusion_model.train(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def q_sample(self, x_start, t, noise=None):
+        return self.schedule.q_sample(x_start, t, torch.randn_like(x_start) if noise is None else noise)
+
+    def apply_model(self, x_noisy, t, cond):
+        if isinstance(cond, dict):
+            cond = torch.cat(cond["c_crossattn"], 1)
+        return self.model.diffusion_model(x_noisy, t, context=cond)
+
+    def p_losses(self, x_start, cond, t, noise=None):
+        noise = torch.randn_like(x_start) if noise is None else noise
+        out = self.apply_model(self.q_sample(x_start, t, noise), t, cond)
+        loss_simple = ((out - noise) ** 2).mean([1, 2, 3])
+        prefix = "train" if self.training else "val"
+        loss = loss_simple.mean()                       # / exp(logvar) + logvar with logvar = 0; elbo weight 0
+        return loss, {f"{prefix}/loss_simple": loss_simple.mean().detach(), f"{prefix}/loss": loss.detach()}
+
+    def _outside(self, *a, **k):
+        raise NotImplementedError("the VAE / CLIP front-end of LatentDiffusion is outside the unlearning hot path: hand latents and prompt "
+                                  "embeddings in (sfron.latents for cached VAE moments)")
+    get_input = shared_step = encode_first_stage = decode_first_stage = get_learned_conditioning = _outside
+
+
 class SDSFRon:
     def __init__(self, unet, schedule=None, lr=1e-5, forget_alpha=1.0, remain_alpha=1.0, train_method="full", mask=None,
                  mask_mode="as_written", process_group=None, use_graphs=False):
