@@ -45,3 +45,32 @@ def test_ops_refuse_cpu_tensors(built):
     from sfron import sweep
     with pytest.raises(built.SfronError):
         sweep.mask_from_fisher(torch.zeros(4), torch.zeros(4), 1.0)
+
+
+def test_descriptor_structs_match_the_header(built):
+    """ctypes mirrors of the header's structs: compile a one-line C program against include/sfron.h that prints sizeof / offsetof and
+    compare (a silent mismatch would hand the library garbage descriptors)."""
+    import ctypes
+    import tempfile
+    fields = {"sfron_wprep_item": (built.WprepItem, ["w", "fwd", "dgr", "co", "tile0"]),
+              "sfron_conv_desc": (built.ConvDesc, ["batch", "n_out", "out_f32", "split_ws"]),
+              "sfron_bgemm_desc": (built.BGemmDesc, ["A", "M", "c_f32", "alpha", "split_ws"]),
+              "sfron_gemm_desc": (built.GemmDesc, ["A", "M", "a_rowsum", "rowsum_ws"])}
+    lines = []
+    for cname, (_, fs) in fields.items():
+        lines.append(f'printf("{cname} %zu", sizeof({cname}));')
+        for f in fs:
+            lines.append(f'printf(" %zu", offsetof({cname}, {f}));')
+        lines.append('printf("\\n");')
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "sfron.h"\nint main(void) {\n' + "\n".join(lines) + "\nreturn 0; }\n"
+    with tempfile.TemporaryDirectory() as d:
+        c, exe = os.path.join(d, "t.c"), os.path.join(d, "t")
+        open(c, "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    for line in out:
+        name, size, *offs = line.split()
+        cls, fs = fields[name]
+        assert ctypes.sizeof(cls) == int(size), (name, ctypes.sizeof(cls), size)
+        for f, o in zip(fs, offs):
+            assert getattr(cls, f).offset == int(o), (name, f, getattr(cls, f).offset, o)
