@@ -6,7 +6,8 @@
 
 A "step" = one full SFR-on iteration (DiT/forget.py:256-322): forget fwd/bwd -> mask -> clip -> AdamW,
 remain fwd/bwd -> AdamW, EMA; synthetic latents / labels / timesteps / noise already resident in HBM.
-Weak scaling: every rank runs batch 32 (global batch 32*N), gradients SUM-all-reduced over RCCL.
+Weak scaling: every rank runs batch 32 (global batch 32*N), gradients SUM-all-reduced over RCCL; "value" counts the batch-32 steps
+of ALL ranks per second (N x the iteration rate), "ms_per_step" is the wall time of one synchronous iteration.
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   "roofline"     -- the kernel with the largest share of GPU time (profiles/r02_kernel_table.md): the weight-gradient GEMM
                     (one kernel for the four products dW = dY^T X of a block), timed live with HIP event pairs recorded on the
@@ -106,11 +107,19 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # rehearsal on a one-GPU box (tools / tests only): SFRON_BENCH_BACKEND=gloo lets N ranks share the visible devices -- RCCL refuses
+    # two ranks on one device; the driver's runs use nccl (= RCCL) with one device per rank
+    backend = os.environ.get("SFRON_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from sfron import data, diffusion, dit, step
 
@@ -229,7 +238,9 @@ def main():
     if rank == 0:
         res = {
             "metric": f"SFR-on unlearning steps/sec, {args.model} {args.image_size}px bs{args.batch}/GPU",   # BASELINE.json's metric at the defaults
-            "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # whole-job aggregate: every rank runs batch-32 steps (weak scaling), so the job does world * steps of them in `elapsed`
+            # (one synchronous iteration over the global batch of 32 * world samples takes ms_per_step)
+            "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.model} {args.image_size}px SFR-on step (forget+remain fwd/bwd, masked clipped AdamW x2, EMA), "
