@@ -217,6 +217,25 @@ def test_pipelined_tile_transposed_read_products(M, N, K):
     np.testing.assert_allclose(dw.cpu().numpy(), 2 * ref_dw.numpy(), rtol=2e-4, atol=4e-4 * math.sqrt(M))
 
 
+def test_few_rows_deep_contraction_split():
+    """dX = dY W with 8 rows over a contraction of 8192 (the embedding projection's input gradient): split over the chip into fp32
+    slabs added in a fixed order -- against torch fp32, and twice the same bits."""
+    from sfron import unet
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 8, 1280, 8192
+    dy = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(K, N, generator=g) * 0.1).to(torch.bfloat16)
+    ref = dy.float() @ w.float()
+    dyd, wd = dy.to(DEV), w.to(DEV)
+    outs = []
+    for _ in range(2):
+        dx = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+        unet.bgemm(dyd, wd, M, N, K, lda=K, ldb=N, b_t=True, c_f32=dx, ldc=N)
+        outs.append(dx.clone())
+    np.testing.assert_allclose(outs[0].cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-4 * math.sqrt(K))
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_batched_gemm_and_softmax():
     from sfron import _lib, unet
     from sfron._lib import check, ptr, stream_ptr

@@ -1629,6 +1629,22 @@ int sfron_bgemm_bf16(const sfron_bgemm_desc* d, void* stream) {
   }
   if (!d->a_transposed && d->b_transposed) {
     if (d->batch == 1 && ni == 1) { const int rc = try_cgemm_dt(g, s); if (rc >= 0) return rc; }
+    // a few rows against a deep contraction (the embedding projection's input gradient: 8 x 1280 over K = 28 000): split K over the chip
+    if (!bf && d->split_ws && d->batch == 1 && ni == 1 && d->ldc == d->N && !d->bias && !d->resid && !d->sample_vec && !d->accumulate &&
+        d->K >= 4096) {
+      const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+      int sp = 256 / (tiles > 0 ? tiles : 1);
+      if (sp > g.K / 512) sp = g.K / 512;
+      if (sp > d->split_ws_slabs) sp = d->split_ws_slabs;
+      if (sp > 1) {
+        g.kchunk = ((g.K + sp - 1) / sp + BK - 1) / BK * BK;
+        const int used = (g.K + g.kchunk - 1) / g.kchunk;
+        g.Cf = d->split_ws; g.sC = (long)d->M * d->N;
+        const int rc = launch_bgemm<false, true, EPI_RES, CONV_NONE>(g, used, s, 1);
+        if (rc) return rc;
+        return sfron_reduce_chunks(d->split_ws, 1, used, d->M * d->N, d->c_f32, d->M * d->N, 0, stream);
+      }
+    }
     return bf ? launch_bgemm<false, true, EPI_BF16, CONV_NONE>(g, d->batch, s, ni) : launch_bgemm<false, true, EPI_RES, CONV_NONE>(g, d->batch, s, ni);
   }
   if (d->a_transposed && d->b_transposed) {

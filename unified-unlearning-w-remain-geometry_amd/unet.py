@@ -70,7 +70,8 @@ def bgemm(A, B, M, N, K, *, lda, ldb, a_t=False, b_t=False, batch=1, sa=0, sb=0,
     d.bias = _addr(bias)
     d.c_bf16, d.c_f32, d.ldc = _addr(c_bf16), _addr(c_f32), ldc
     d.resid, d.sample_vec, d.ld_vec, d.rows_per_sample, d.accumulate = _addr(resid), _addr(vec), ld_vec, rows_per_sample, int(accumulate)
-    if a_t and b_t and c_f32 is not None and batch == 1 and batch2 == 1 and ldc == N and K >= 2048:
+    small_rows = (not a_t) and b_t and M <= 128 and K >= 4096 and bias is None and resid is None and vec is None and not accumulate
+    if ((a_t and b_t and K >= 2048) or small_rows) and c_f32 is not None and batch == 1 and batch2 == 1 and ldc == N:
         ws = _split_scratch(M * N, A if not isinstance(A, int) else (B if not isinstance(B, int) else None))
         if ws is not None:
             d.split_ws, d.split_ws_slabs = ws.data_ptr(), ws.numel() // (M * N)
