@@ -217,6 +217,27 @@ def test_pipelined_tile_transposed_read_products(M, N, K):
     np.testing.assert_allclose(dw.cpu().numpy(), 2 * ref_dw.numpy(), rtol=2e-4, atol=4e-4 * math.sqrt(M))
 
 
+def test_head_batched_products_split_over_the_contraction():
+    """dK / dV of a cross-attention: per (sample, head) out [Lk][d] = A[tokens][Lk]^T B[tokens][d] with the head's columns taken from a
+    [tokens][heads * d] matrix -- one output tile per (sample, head), contraction over 2048 tokens, split into fp32 slabs and added
+    in a fixed order (bf16 result) -- against torch fp32, twice the same bits."""
+    from sfron import unet
+    g = torch.Generator().manual_seed(91)
+    Bn, H, T, Lk, d = 2, 4, 2048, 80, 40
+    P = (torch.rand(Bn * H * T, Lk, generator=g)).to(torch.bfloat16)                    # [b][h][token][key]
+    dO = (torch.randn(Bn * T, H * d, generator=g) * 0.3).to(torch.bfloat16)             # [b][token][h * d]
+    ref = torch.einsum("bhtk,bthd->bkhd", P.float().view(Bn, H, T, Lk), dO.float().view(Bn, T, H, d)).reshape(Bn * Lk, H * d)
+    Pd, dOd = P.to(DEV), dO.to(DEV)
+    outs = []
+    for _ in range(2):
+        dv = torch.full((Bn * Lk, H * d), float("nan"), dtype=torch.bfloat16, device=DEV)
+        unet.bgemm(Pd, dOd, Lk, d, T, lda=Lk, ldb=H * d, a_t=True, b_t=True, batch=Bn, sa=H * T * Lk, sb=T * H * d, sc=Lk * H * d, batch2=H,
+                   sa2=T * Lk, sb2=d, sc2=d, c_bf16=dv, ldc=H * d)
+        outs.append(dv.clone())
+    np.testing.assert_allclose(outs[0].float().cpu().numpy(), ref.numpy(), rtol=1e-2, atol=1e-2 * math.sqrt(T) * 0.3)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_few_rows_deep_contraction_split():
     """dX = dY W with 8 rows over a contraction of 8192 (the embedding projection's input gradient): split over the chip into fp32
     slabs added in a fixed order -- against torch fp32, and twice the same bits."""

@@ -51,6 +51,8 @@ struct BGemmArgs {
   int accumulate;
   int kchunk;             // split-K (weight gradients: few output tiles, a contraction over all pixels): grid.y = split, split s
                           // takes k in [s * kchunk, (s + 1) * kchunk) and writes its own fp32 slab Cf + s * sC (0 = no split)
+  int ksplit;             // split-K of a BATCHED product (k_bgemm only): grid.x = tiles * ksplit; split s of batch (y, z) writes the
+                          // contiguous fp32 slab Cf[((s * gridDim.y + y) * gridDim.z + z)][M][N]; k_bsplit_finish adds the splits
   ConvGeom cg;
 };
 
@@ -196,17 +198,24 @@ __global__ __launch_bounds__(NT) void k_bgemm(BGemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int ntn = (g.N + BN - 1) / BN;
-  const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
+  int tile = blockIdx.x, split = 0;
+  if (g.ksplit > 1) { const int nt = ((g.M + BM - 1) / BM) * ntn; split = tile / nt; tile -= split * nt; }
+  const int tm = tile / ntn, tn = tile % ntn;
   const int m0 = tm * BM, n0 = tn * BN;
   const long bz = blockIdx.y, bi = blockIdx.z;
   int kbeg = 0, kend = g.K;
-  if (g.kchunk > 0) { kbeg = (int)bz * g.kchunk; kend = min(g.K, kbeg + g.kchunk); }
+  if (g.ksplit > 1) { kbeg = split * g.kchunk; kend = min(g.K, kbeg + g.kchunk); g.A += bz * g.sA; g.B += bz * g.sB; }
+  else if (g.kchunk > 0) { kbeg = (int)bz * g.kchunk; kend = min(g.K, kbeg + g.kchunk); }
   else { g.A += bz * g.sA; g.B += bz * g.sB; }
   g.A += bi * g.sA2; g.B += bi * g.sB2;
-  const long co = bz * g.sC + bi * g.sC2;
-  if (g.Cb) g.Cb += co;
-  if (g.Cf) g.Cf += co;
-  if (g.resid) g.resid += co;
+  if (g.ksplit > 1) {
+    g.Cf += (((long)split * gridDim.y + bz) * gridDim.z + bi) * ((long)g.M * g.N);
+  } else {
+    const long co = bz * g.sC + bi * g.sC2;
+    if (g.Cb) g.Cb += co;
+    if (g.Cf) g.Cf += co;
+    if (g.resid) g.resid += co;
+  }
 
   Stager<A_TR, CONV == CONV_A> stA;
   Stager<B_TR, CONV == CONV_B> stB;
@@ -1314,6 +1323,18 @@ __global__ __launch_bounds__(TPB) void k_geglu_bwd(const float* __restrict__ d_o
   }
 }
 
+// finish of a batched split-K product: out[y][z][m][n] (bf16, strides sC / sC2 / ldc) = sum_s slab[s][y][z][m][n]
+__global__ __launch_bounds__(TPB) void k_bsplit_finish(const float* __restrict__ slabs, int nsplit, int ny, int nz, int M, int N, __bf16* __restrict__ out,
+                                                       long sC, long sC2, int ldc) {
+  const int64_t per = (int64_t)M * N, n = (int64_t)ny * nz * per;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    const int64_t b = i / per, r = i - b * per;
+    const int y = (int)(b / nz), z = (int)(b - (int64_t)y * nz), m = (int)(r / N), c = (int)(r - (int64_t)m * N);
+    float a = 0.f;
+    for (int sl = 0; sl < nsplit; ++sl) a += slabs[sl * n + i];
+    out[y * sC + z * sC2 + (int64_t)m * ldc + c] = f2bf(a);
+  }
+}
 // split-K finish: out[row][col] = sum_s slab[s][row][col] (+ bias) (+ per-sample vector) (+ resid), bf16 or fp32 -- the epilogue of
 // k_bgemm applied after the slabs of a split contraction are added in order
 __global__ __launch_bounds__(TPB) void k_split_finish(const float* __restrict__ slabs, int nsl, int64_t slab_stride, int M, int N,
@@ -1501,7 +1522,7 @@ template <bool A_TR, bool B_TR, int EPI, int CONV>
 int launch_bgemm(const BGemmArgs& g, int nbatch, hipStream_t s, int ninner = 1) {
   const size_t lds = 4 * TILE_ELEMS * sizeof(__bf16);
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
-  hipLaunchKernelGGL((k_bgemm<A_TR, B_TR, EPI, CONV>), dim3(ntm * ntn, nbatch, ninner), dim3(NT), lds, s, g);
+  hipLaunchKernelGGL((k_bgemm<A_TR, B_TR, EPI, CONV>), dim3(ntm * ntn * (g.ksplit > 1 ? g.ksplit : 1), nbatch, ninner), dim3(NT), lds, s, g);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
 }
@@ -1663,6 +1684,28 @@ int sfron_bgemm_bf16(const sfron_bgemm_desc* d, void* stream) {
       }
     }
     if (fast) { const int rc = try_cgemm_tt(g, 1, s); if (rc >= 0) return rc; }
+    // head-batched products with a single output tile each and a contraction over all tokens (dK, dV of the cross-attention): a
+    // workgroup per (sample, head) leaves the chip three quarters empty and walks K = 4096 alone -- split the contraction
+    if (bf && d->split_ws && (d->batch > 1 || ni > 1) && !d->bias && !d->resid && !d->sample_vec && !d->accumulate && d->alpha == 1.0f && g.K >= 1024) {
+      const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * d->batch * ni;
+      int sp = 512 / (tiles > 0 ? tiles : 1);
+      if (sp > g.K / 256) sp = g.K / 256;
+      if (sp > 16) sp = 16;
+      const int64_t per = (int64_t)d->batch * ni * d->M * d->N;
+      if ((int64_t)sp * per > (int64_t)d->split_ws_slabs * d->M * d->N) sp = (int)((int64_t)d->split_ws_slabs * d->M * d->N / per);
+      if (sp > 1) {
+        BGemmArgs q = g;
+        q.kchunk = ((g.K + sp - 1) / sp + BK - 1) / BK * BK;
+        q.ksplit = (g.K + q.kchunk - 1) / q.kchunk;
+        q.Cb = nullptr; q.Cf = d->split_ws; q.ldcf = d->N;
+        int rc = launch_bgemm<true, true, EPI_RES, CONV_NONE>(q, d->batch, s, ni);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_bsplit_finish, dim3(grid_for(per)), dim3(TPB), 0, s, d->split_ws, q.ksplit, d->batch, ni, d->M, d->N, (__bf16*)d->c_bf16,
+                           (long)d->stride_c, (long)d->stride_c2, d->ldc);
+        SFRON_LAUNCH_STATUS();
+        return SFRON_OK;
+      }
+    }
     return bf ? launch_bgemm<true, true, EPI_BF16, CONV_NONE>(g, d->batch, s, ni) : launch_bgemm<true, true, EPI_RES, CONV_NONE>(g, d->batch, s, ni);
   }
   return SFRON_ERR_UNSUPPORTED;

@@ -75,6 +75,9 @@ def bgemm(A, B, M, N, K, *, lda, ldb, a_t=False, b_t=False, batch=1, sa=0, sb=0,
         ws = _split_scratch(M * N, A if not isinstance(A, int) else (B if not isinstance(B, int) else None))
         if ws is not None:
             d.split_ws, d.split_ws_slabs = ws.data_ptr(), ws.numel() // (M * N)
+    elif a_t and b_t and c_bf16 is not None and batch * batch2 > 1 and K >= 1024 and M <= 128 and N <= 256 and not isinstance(A, int):
+        ws = _split_scratch(M * N * batch * batch2, A)               # head-batched single-tile products: split the contraction
+        d.split_ws, d.split_ws_slabs = ws.data_ptr(), ws.numel() // (M * N)
     check(_L().sfron_bgemm_bf16(ctypes.byref(d), stream_ptr()), "bgemm_bf16")
 
 
