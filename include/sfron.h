@@ -269,7 +269,8 @@ int sfron_geglu_fwd(const float* h, int64_t rows, int F, uint16_t* out, void* st
 int sfron_geglu_bwd(const float* d_out, const float* h, int64_t rows, int F, uint16_t* dh, void* stream);
 int sfron_softmax_bwd(const uint16_t* p, const float* dp, int64_t rows, int n, float scale, uint16_t* ds, void* stream);
 /* out[b][c] = sum over the HW rows of sample b of x[row][c] */
-int sfron_sample_colsum(const float* x, int ld, int B, int HW, int C, float* out, int ld_out, void* stream);
+int sfron_sample_colsum(const float* x, int ld, int B, int HW, int C, float* out, int ld_out,
+                        float* scratch /* optional row-chunk partials, >= B * 32 * C floats */, int64_t scratch_floats, void* stream);
 /* out = alpha * a + beta * b (guidance mix (1 + s) * cond - s * null of _forward_with_cond_scale, :340-357) */
 int sfron_axpby(const float* a, const float* b, float alpha, float beta, int64_t n, float* out, void* stream);
 /* backward of nearest x2 upsampling: dx[b][h][w][c] (+)= sum of the 2x2 block of dy [B][2H][2W][C] */

@@ -129,7 +129,7 @@ _PROTOS.update({
     "sfron_geglu_fwd": (c_int, [_P, c_int64, c_int, _P, _S]),
     "sfron_geglu_bwd": (c_int, [_P, _P, c_int64, c_int, _P, _S]),
     "sfron_softmax_bwd": (c_int, [_P, _P, c_int64, c_int, c_float, _P, _S]),
-    "sfron_sample_colsum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _S]),
+    "sfron_sample_colsum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int64, _S]),
     "sfron_axpby": (c_int, [_P, _P, c_float, c_float, c_int64, _P, _S]),
     "sfron_pool2_sum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _S]),
     "sfron_cast_rows_bf16": (c_int, [_P, c_int, c_int64, c_int, _P, _S]),

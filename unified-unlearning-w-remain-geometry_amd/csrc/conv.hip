@@ -1356,21 +1356,25 @@ __global__ __launch_bounds__(TPB) void k_split_finish(const float* __restrict__ 
 // out[b][c] = sum_{p < HW} x[(b * HW + p) * ld + c]  (per-sample column sums: gradient of a per-sample broadcast vector)
 // one workgroup per (64-column slice, sample): the 4 waves stride over the rows (coalesced 256-B row reads), partial sums meet in LDS
 // in a fixed order
+// gridDim.z row chunks per sample (chunk z takes rows [HW z / nz, HW (z + 1) / nz)): with nz > 1 `out` is the partial buffer
+// [B][nz][C] (ldo = C) that k_reduce_chunks adds per sample in a fixed order
 __global__ __launch_bounds__(TPB) void k_sample_colsum(const float* __restrict__ x, int ld, int HW, int C, float* __restrict__ out, int ldo) {
   __shared__ float sh[TPB / 64][64];
   const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
+  const int nz = gridDim.z, z = blockIdx.z;
+  const int p0 = (int)((long)HW * z / nz), p1 = (int)((long)HW * (z + 1) / nz);
   float s = 0.f;
   if (c < C) {
     const float* xb = x + (size_t)b * HW * ld + c;
-    for (int p = wave; p < HW; p += TPB / 64) s += xb[(size_t)p * ld];
+    for (int p = p0 + wave; p < p1; p += TPB / 64) s += xb[(size_t)p * ld];
   }
   sh[wave][lane] = s;
   __syncthreads();
   if (wave == 0 && c < C) {
     float a = 0.f;
     for (int w = 0; w < TPB / 64; ++w) a += sh[w][lane];
-    out[(size_t)b * ldo + c] = a;
+    out[((size_t)b * nz + z) * ldo + c] = a;
   }
 }
 // out = alpha * a + beta * b   (classifier-free guidance mix (1 + s) cond - s null, models/diffusion.py:340-357)
@@ -1974,9 +1978,19 @@ int sfron_axpby(const float* a, const float* b, float alpha, float beta, int64_t
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }
-int sfron_sample_colsum(const float* x, int ld, int B, int HW, int C, float* out, int ld_out, void* stream) {
-  SFRON_CHECK_ARG(x && out && ld_out >= C);
-  hipLaunchKernelGGL(k_sample_colsum, dim3((C + 63) / 64, B), dim3(TPB), 0, (hipStream_t)stream, x, ld, HW, C, out, ld_out);
+int sfron_sample_colsum(const float* x, int ld, int B, int HW, int C, float* out, int ld_out, float* scratch, int64_t scratch_floats,
+                        void* stream) {
+  SFRON_CHECK_ARG(x && out && ld_out >= C && B > 0 && HW > 0 && C > 0);
+  // few (column block, sample) pairs and many rows: chunk the rows, partial sums [B][nz][C] in the caller's scratch, fixed-order add
+  int nz = 512 / (((C + 63) / 64) * B);
+  if (nz > 32) nz = 32;
+  if (nz > HW / 16) nz = HW / 16;
+  if (scratch && nz > 1 && (int64_t)B * nz * C <= scratch_floats) {
+    hipLaunchKernelGGL(k_sample_colsum, dim3((C + 63) / 64, B, nz), dim3(TPB), 0, (hipStream_t)stream, x, ld, HW, C, scratch, C);
+    SFRON_LAUNCH_STATUS();
+    return sfron_reduce_chunks(scratch, B, nz, C, out, ld_out, 0, stream);
+  }
+  hipLaunchKernelGGL(k_sample_colsum, dim3((C + 63) / 64, B, 1), dim3(TPB), 0, (hipStream_t)stream, x, ld, HW, C, out, ld_out);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

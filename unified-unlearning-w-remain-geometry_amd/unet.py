@@ -426,7 +426,8 @@ class _TapeNet(nn.Module):
                 check(_L().sfron_copy_cols(ptr(dx), cin, x.rows, cin, ptr(g), cin, acc, stream_ptr()), "copy_cols")
             gn2_b(d_a2)                                   # -> h1.grad
             dh1 = h1.grad
-            check(_L().sfron_sample_colsum(ptr(dh1), cout, B, H * W, cout, d_proj.data_ptr() + 4 * c0, self.proj_total, stream_ptr()),
+            check(_L().sfron_sample_colsum(ptr(dh1), cout, B, H * W, cout, d_proj.data_ptr() + 4 * c0, self.proj_total, ptr(self._cs), self._cs.numel(),
+                                           stream_ptr()),
                   "sample_colsum")
             d_a1 = conv1_b(dh1)
             gn1_b(d_a1)                                   # -> x.grad (+=)
