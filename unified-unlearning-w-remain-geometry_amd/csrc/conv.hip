@@ -1213,6 +1213,43 @@ __global__ __launch_bounds__(TPB) void k_layernorm_fwd(const float* __restrict__
   for (int i = lane; i < D; i += 64) y[row * D + i] = f2bf((xr[i] - m) * r * gamma[i] + beta[i]);
   if (lane == 0) { mean[row] = m; rstd[row] = r; }
 }
+// the same with the row in registers as float4 chunks (one 16-byte load per chunk, D <= 256 * NC, D % 4 == 0)
+template <int NC>
+__global__ __launch_bounds__(TPB) void k_layernorm_fwd_r(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int64_t rows, int D, float eps, __bf16* __restrict__ y, float* __restrict__ mean,
+                                                         float* __restrict__ rstd) {
+  const int64_t row = (int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63, D4 = D >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + row * D);
+  float4 v[NC];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int c = lane + 64 * j;
+    v[j] = c < D4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  }
+  const float m = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NC; ++j)
+    if (lane + 64 * j < D4) {
+      const float a = v[j].x - m, b = v[j].y - m, c2 = v[j].z - m, d = v[j].w - m;
+      q += (a * a + b * b) + (c2 * c2 + d * d);
+    }
+  const float r = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int c = lane + 64 * j;
+    if (c < D4) {
+      const float4 g4 = reinterpret_cast<const float4*>(gamma)[c], b4 = reinterpret_cast<const float4*>(beta)[c];
+      reinterpret_cast<bf16x4*>(y + row * D)[c] = bf16x4{f2bf((v[j].x - m) * r * g4.x + b4.x), f2bf((v[j].y - m) * r * g4.y + b4.y),
+                                                         f2bf((v[j].z - m) * r * g4.z + b4.z), f2bf((v[j].w - m) * r * g4.w + b4.w)};
+    }
+  }
+  if (lane == 0) { mean[row] = m; rstd[row] = r; }
+}
 // dx (+)= d LayerNorm; pg / pb [nblk][D]: per-workgroup (4 rows) partial sums of dy * xhat and dy, written with plain stores
 __global__ __launch_bounds__(TPB) void k_layernorm_bwd(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd, int64_t rows, int D,
@@ -1249,49 +1286,63 @@ __global__ __launch_bounds__(TPB) void k_layernorm_bwd(const float* __restrict__
     pg[(size_t)blockIdx.x * D + i] = a; pb[(size_t)blockIdx.x * D + i] = b;
   }
 }
-// the same with the row and the per-column accumulators in registers (D <= 64 * NC): x and dy are read once, nothing but the final
-// per-wave sums goes through LDS.  Sums are formed in the order of k_layernorm_bwd (bitwise the same results).
-template <int NC>
+// the same with the row and the per-column accumulators in registers, a lane owning float4 column chunks (16-byte loads): x and dy are
+// read once, nothing but the final per-wave sums goes through LDS.
+template <int NC>      // float4 chunks per lane: D <= 256 * NC, D % 4 == 0
 __global__ __launch_bounds__(TPB) void k_layernorm_bwd_r(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd, int64_t rows, int D,
                                                          float* __restrict__ dx, int accumulate, float* __restrict__ pg, float* __restrict__ pb,
                                                          int rows_per_block) {
   extern __shared__ float sh[];                     // [4 waves][2][D]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float ag[NC], ab[NC], gm[NC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, D4 = D >> 2;
+  float4 ag[NC], ab[NC], gm[NC];
 #pragma unroll
-  for (int j = 0; j < NC; ++j) { ag[j] = 0.f; ab[j] = 0.f; const int i = lane + 64 * j; gm[j] = i < D ? gamma[i] : 0.f; }
+  for (int j = 0; j < NC; ++j) {
+    ag[j] = make_float4(0.f, 0.f, 0.f, 0.f); ab[j] = ag[j];
+    const int c = lane + 64 * j;
+    gm[j] = c < D4 ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   for (int64_t row = r0 + wave; row < r0 + rows_per_block && row < rows; row += TPB / 64) {
     const float m = mean[row], r = rstd[row];
-    const float* xr = x + row * D;
-    const float* dr = dy + row * D;
-    float xh[NC], dv[NC];
+    const float4* xr = reinterpret_cast<const float4*>(x + row * D);
+    const float4* dr = reinterpret_cast<const float4*>(dy + row * D);
+    float4 xh[NC], dv[NC];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-      const int i = lane + 64 * j;
-      const bool in = i < D;
-      xh[j] = in ? (xr[i] - m) * r : 0.f; dv[j] = in ? dr[i] : 0.f;
-      const float d = dv[j] * gm[j];
-      s1 += d; s2 += d * xh[j];
-      ag[j] += dv[j] * xh[j]; ab[j] += dv[j];
+      const int c = lane + 64 * j;
+      const bool in = c < D4;
+      const float4 xv = in ? xr[c] : make_float4(m, m, m, m);
+      dv[j] = in ? dr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      xh[j] = make_float4((xv.x - m) * r, (xv.y - m) * r, (xv.z - m) * r, (xv.w - m) * r);
+      // the order of k_layernorm_bwd within a lane differs (columns grouped by fours): sums are fixed-order, results reproducible
+      const float d0 = dv[j].x * gm[j].x, d1 = dv[j].y * gm[j].y, d2 = dv[j].z * gm[j].z, d3 = dv[j].w * gm[j].w;
+      s1 += (d0 + d1) + (d2 + d3);
+      s2 += (d0 * xh[j].x + d1 * xh[j].y) + (d2 * xh[j].z + d3 * xh[j].w);
+      ag[j].x += dv[j].x * xh[j].x; ag[j].y += dv[j].y * xh[j].y; ag[j].z += dv[j].z * xh[j].z; ag[j].w += dv[j].w * xh[j].w;
+      ab[j].x += dv[j].x; ab[j].y += dv[j].y; ab[j].z += dv[j].z; ab[j].w += dv[j].w;
     }
     s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-      const int i = lane + 64 * j;
-      if (i < D) {
-        const float v = r * (dv[j] * gm[j] - s1 - xh[j] * s2);
-        float* o = dx + row * D + i;
-        *o = accumulate ? *o + v : v;
+      const int c = lane + 64 * j;
+      if (c < D4) {
+        float4 v = make_float4(r * (dv[j].x * gm[j].x - s1 - xh[j].x * s2), r * (dv[j].y * gm[j].y - s1 - xh[j].y * s2),
+                               r * (dv[j].z * gm[j].z - s1 - xh[j].z * s2), r * (dv[j].w * gm[j].w - s1 - xh[j].w * s2));
+        float4* o = reinterpret_cast<float4*>(dx + row * D) + c;
+        if (accumulate) { const float4 p = *o; v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+        *o = v;
       }
     }
   }
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
-    const int i = lane + 64 * j;
-    if (i < D) { sh[(size_t)wave * 2 * D + i] = ag[j]; sh[(size_t)wave * 2 * D + D + i] = ab[j]; }
+    const int c = lane + 64 * j;
+    if (c < D4) {
+      reinterpret_cast<float4*>(sh + (size_t)wave * 2 * D)[c] = ag[j];
+      reinterpret_cast<float4*>(sh + (size_t)wave * 2 * D + D)[c] = ab[j];
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < D; i += TPB) {
@@ -1929,8 +1980,12 @@ int sfron_softmax_fwd(const float* s, int64_t rows, int n, int n_valid, float sc
 int sfron_layernorm_fwd(const float* x, const float* gamma, const float* beta, int64_t rows, int D, float eps, uint16_t* y, float* mean,
                         float* rstd, void* stream) {
   SFRON_CHECK_ARG(x && gamma && beta && y && mean && rstd && rows > 0 && D > 0);
-  hipLaunchKernelGGL(k_layernorm_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(TPB), 0, (hipStream_t)stream, x, gamma, beta, rows, D, eps, (__bf16*)y,
-                     mean, rstd);
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  const bool v4 = D % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0 && (((uintptr_t)y) & 7) == 0;
+  if (v4 && D <= 512)       hipLaunchKernelGGL(k_layernorm_fwd_r<2>, grid, dim3(TPB), 0, (hipStream_t)stream, x, gamma, beta, rows, D, eps, (__bf16*)y, mean, rstd);
+  else if (v4 && D <= 768)  hipLaunchKernelGGL(k_layernorm_fwd_r<3>, grid, dim3(TPB), 0, (hipStream_t)stream, x, gamma, beta, rows, D, eps, (__bf16*)y, mean, rstd);
+  else if (v4 && D <= 1280) hipLaunchKernelGGL(k_layernorm_fwd_r<5>, grid, dim3(TPB), 0, (hipStream_t)stream, x, gamma, beta, rows, D, eps, (__bf16*)y, mean, rstd);
+  else hipLaunchKernelGGL(k_layernorm_fwd, grid, dim3(TPB), 0, (hipStream_t)stream, x, gamma, beta, rows, D, eps, (__bf16*)y, mean, rstd);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }
@@ -1945,9 +2000,10 @@ int sfron_layernorm_bwd(const float* dy, const float* x, const float* gamma, con
   const int rpb = sfron_layernorm_rows_per_block(rows);
   const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
   const size_t lds = (size_t)(TPB / 64) * 2 * D * sizeof(float);
-  if (D <= 320)       hipLaunchKernelGGL(k_layernorm_bwd_r<5>, grid, dim3(TPB), lds, (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb);
-  else if (D <= 640)  hipLaunchKernelGGL(k_layernorm_bwd_r<10>, grid, dim3(TPB), lds, (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb);
-  else if (D <= 1280) hipLaunchKernelGGL(k_layernorm_bwd_r<20>, grid, dim3(TPB), lds, (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb);
+  const bool v4 = D % 4 == 0 && ((((uintptr_t)dy) | ((uintptr_t)x) | ((uintptr_t)dx) | ((uintptr_t)gamma)) & 15) == 0;
+  if (v4 && D <= 512)       hipLaunchKernelGGL(k_layernorm_bwd_r<2>, grid, dim3(TPB), lds, (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb);
+  else if (v4 && D <= 768)  hipLaunchKernelGGL(k_layernorm_bwd_r<3>, grid, dim3(TPB), lds, (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb);
+  else if (v4 && D <= 1280) hipLaunchKernelGGL(k_layernorm_bwd_r<5>, grid, dim3(TPB), lds, (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb);
   else hipLaunchKernelGGL(k_layernorm_bwd, grid, dim3(TPB), lds, (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
