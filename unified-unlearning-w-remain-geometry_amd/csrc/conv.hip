@@ -1373,6 +1373,41 @@ __global__ __launch_bounds__(TPB) void k_geglu_bwd(const float* __restrict__ d_o
     dh[r * 2 * F + F + c] = f2bf(d * a * (cdf + gt * pdf));
   }
 }
+// the same on float4 column quads, rows walked by the workgroup's y index (no per-element 64-bit division): F % 4 == 0
+__global__ __launch_bounds__(TPB) void k_geglu_fwd4(const float* __restrict__ h, int64_t rows, int F, int rows_per_block, __bf16* __restrict__ out) {
+  const int c = (blockIdx.x * TPB + threadIdx.x) * 4;
+  if (c >= F) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  for (int64_t r = r0; r < r1; ++r) {
+    const float4 a = *reinterpret_cast<const float4*>(h + r * 2 * F + c), gt = *reinterpret_cast<const float4*>(h + r * 2 * F + F + c);
+    const float av[4] = {a.x, a.y, a.z, a.w}, gv[4] = {gt.x, gt.y, gt.z, gt.w};
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f2bf(av[e] * 0.5f * gv[e] * (1.0f + erff(gv[e] * 0.70710678118654752f)));
+    *reinterpret_cast<bf16x4*>(out + r * F + c) = o;
+  }
+}
+__global__ __launch_bounds__(TPB) void k_geglu_bwd4(const float* __restrict__ d_out, const float* __restrict__ h, int64_t rows, int F, int rows_per_block,
+                                                    __bf16* __restrict__ dh) {
+  const int c = (blockIdx.x * TPB + threadIdx.x) * 4;
+  if (c >= F) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  for (int64_t r = r0; r < r1; ++r) {
+    const float4 a = *reinterpret_cast<const float4*>(h + r * 2 * F + c), gt = *reinterpret_cast<const float4*>(h + r * 2 * F + F + c);
+    const float4 d4 = *reinterpret_cast<const float4*>(d_out + r * F + c);
+    const float av[4] = {a.x, a.y, a.z, a.w}, gv[4] = {gt.x, gt.y, gt.z, gt.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+    bf16x4 o1, o2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float cdf = 0.5f * (1.0f + erff(gv[e] * 0.70710678118654752f));
+      const float pdf = 0.3989422804014327f * expf(-0.5f * gv[e] * gv[e]);
+      o1[e] = f2bf(dv[e] * gv[e] * cdf);
+      o2[e] = f2bf(dv[e] * av[e] * (cdf + gv[e] * pdf));
+    }
+    *reinterpret_cast<bf16x4*>(dh + r * 2 * F + c) = o1;
+    *reinterpret_cast<bf16x4*>(dh + r * 2 * F + F + c) = o2;
+  }
+}
 
 // finish of a batched split-K product: out[y][z][m][n] (bf16, strides sC / sC2 / ldc) = sum_s slab[s][y][z][m][n]
 __global__ __launch_bounds__(TPB) void k_bsplit_finish(const float* __restrict__ slabs, int nsplit, int ny, int nz, int M, int N, __bf16* __restrict__ out,
@@ -2010,12 +2045,28 @@ int sfron_layernorm_bwd(const float* dy, const float* x, const float* gamma, con
 }
 int sfron_geglu_fwd(const float* h, int64_t rows, int F, uint16_t* out, void* stream) {
   SFRON_CHECK_ARG(h && out && rows > 0 && F > 0);
+  if (F % 4 == 0 && ((((uintptr_t)h)) & 15) == 0 && (((uintptr_t)out) & 7) == 0) {
+    const int cb = (F / 4 + TPB - 1) / TPB;
+    int64_t chunks = 4096 / cb; if (chunks > rows) chunks = rows; if (chunks < 1) chunks = 1;
+    const int rpb = (int)((rows + chunks - 1) / chunks);
+    hipLaunchKernelGGL(k_geglu_fwd4, dim3(cb, (unsigned)((rows + rpb - 1) / rpb)), dim3(TPB), 0, (hipStream_t)stream, h, rows, F, rpb, (__bf16*)out);
+    SFRON_LAUNCH_STATUS();
+    return SFRON_OK;
+  }
   hipLaunchKernelGGL(k_geglu_fwd, dim3(grid_for(rows * F)), dim3(TPB), 0, (hipStream_t)stream, h, rows, F, (__bf16*)out);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }
 int sfron_geglu_bwd(const float* d_out, const float* h, int64_t rows, int F, uint16_t* dh, void* stream) {
   SFRON_CHECK_ARG(d_out && h && dh && rows > 0 && F > 0);
+  if (F % 4 == 0 && ((((uintptr_t)h) | ((uintptr_t)d_out)) & 15) == 0 && (((uintptr_t)dh) & 7) == 0) {
+    const int cb = (F / 4 + TPB - 1) / TPB;
+    int64_t chunks = 4096 / cb; if (chunks > rows) chunks = rows; if (chunks < 1) chunks = 1;
+    const int rpb = (int)((rows + chunks - 1) / chunks);
+    hipLaunchKernelGGL(k_geglu_bwd4, dim3(cb, (unsigned)((rows + rpb - 1) / rpb)), dim3(TPB), 0, (hipStream_t)stream, d_out, h, rows, F, rpb, (__bf16*)dh);
+    SFRON_LAUNCH_STATUS();
+    return SFRON_OK;
+  }
   hipLaunchKernelGGL(k_geglu_bwd, dim3(grid_for(rows * F)), dim3(TPB), 0, (hipStream_t)stream, d_out, h, rows, F, (__bf16*)dh);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
