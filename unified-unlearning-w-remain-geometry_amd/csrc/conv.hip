@@ -1703,11 +1703,18 @@ int try_cgemm_tt(const BGemmArgs& g, int nsplit, hipStream_t s) {
 }
 // workgroups of the weight-gradient tile (256 on the long axis, 128 on the other)
 inline int tt_tiles(int np, int nq) { return ((np + TTile::FBP - 1) / TTile::FBP) * ((nq + TTile::FBQ - 1) / TTile::FBQ); }
-inline int tt_splits(int tiles, int K, int cap) {
-  int sp = 512 / (tiles > 0 ? tiles : 1);
-  if (sp > K / 512) sp = K / 512;
-  if (sp > cap) sp = cap;
-  return sp < 1 ? 1 : sp;
+inline int tt_splits(int tiles, int K, int cap, int64_t out_elems) {
+  // time model (us): rounds of workgroups x K-tiles each walks (1.4 us per 64 contraction rows) + the fp32 slabs every split
+  // writes and the scatter / reduction reads back (8 B per output element at ~4 TB/s)
+  int best = 1;
+  double best_t = 1e30;
+  const int lim = K / 512 < cap ? K / 512 : cap;
+  for (int sp = 1; sp <= (lim < 1 ? 1 : lim); ++sp) {
+    const int rounds = (tiles * sp + 255) / 256;
+    const double t = rounds * ((double)K / sp) * (1.4 / 64.0) + (sp > 1 ? sp : 0) * (double)out_elems * 2e-6;
+    if (t < best_t) { best_t = t; best = sp; }
+  }
+  return best;
 }
 
 }  // namespace
@@ -1762,7 +1769,7 @@ int sfron_bgemm_bf16(const sfron_bgemm_desc* d, void* stream) {
     const bool fast = !bf && d->batch == 1 && ni == 1 && tt_ok(g) && d->M >= 64 && d->N >= 64 && d->K >= 256;
     // a plain weight gradient (fp32 [M][N] contiguous, contraction over all rows): split-K through the caller's slab scratch
     if (!bf && d->split_ws && d->batch == 1 && ni == 1 && d->ldc == d->N && !d->bias && !d->resid && !d->sample_vec && !d->accumulate) {
-      const int sp = fast ? tt_splits(tt_tiles(d->M, d->N), d->K, d->split_ws_slabs) : plan_splits(d->M, d->N, d->K, d->split_ws_slabs);
+      const int sp = fast ? tt_splits(tt_tiles(d->M, d->N), d->K, d->split_ws_slabs, (int64_t)d->M * d->N) : plan_splits(d->M, d->N, d->K, d->split_ws_slabs);
       if (sp > 1) {
         g.kchunk = ((g.K + sp - 1) / sp + BK - 1) / BK * BK;
         const int used = (g.K + g.kchunk - 1) / g.kchunk;
@@ -1864,7 +1871,7 @@ static bool conv_wgrad_pipelined(const sfron_conv_desc* d) {
 int sfron_conv_wgrad_splits(const sfron_conv_desc* d) {
   if (!d) return 0;
   const int K = d->batch * d->h_out * d->w_out;
-  if (conv_wgrad_pipelined(d)) return tt_splits(tt_tiles(d->taps * d->c_src, d->n_out), K, 64);
+  if (conv_wgrad_pipelined(d)) return tt_splits(tt_tiles(d->taps * d->c_src, d->n_out), K, 64, (int64_t)d->taps * d->c_src * d->n_out);
   return plan_splits(d->n_out, d->taps * d->c_src, K, 64);
 }
 int sfron_conv_wgrad(const sfron_conv_desc* d, const uint16_t* dy, int ld_dy, const uint16_t* src, float* dw_gemm, void* stream) {
