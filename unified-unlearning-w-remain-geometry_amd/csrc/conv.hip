@@ -1836,9 +1836,21 @@ int sfron_conv_fwd(const sfron_conv_desc* d, const uint16_t* src, const uint16_t
   const bool pipelined = g.M % 256 == 0 && g.K % BK == 0 && d->c_src % BK == 0;
   const int tiles = pipelined ? (g.M / 256) * ((g.N + (g.N % 160 == 0 ? 160 : 128) - 1) / (g.N % 160 == 0 ? 160 : 128))
                               : ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-  if (d->split_ws && !d->accumulate && tiles < (pipelined ? 160 : 128) && g.K >= 2048) {
-    int sp = (pipelined ? 320 : 384) / tiles;
-    if (sp > g.K / (pipelined ? 1024 : 512)) sp = g.K / (pipelined ? 1024 : 512);
+  if (d->split_ws && !d->accumulate && tiles < (pipelined ? 224 : 128) && g.K >= 2048) {
+    int sp = 384 / tiles;
+    if (sp > g.K / 512) sp = g.K / 512;
+    if (pipelined) {
+      // the time model of tt_splits: rounds of workgroups x K-tiles each walks + the slabs the finish kernel reads back
+      int lim = g.K / 1024;
+      if (lim > d->split_ws_slabs) lim = d->split_ws_slabs;
+      double best_t = 1e30;
+      sp = 1;
+      for (int c = 1; c <= (lim < 1 ? 1 : lim); ++c) {
+        const int rounds = (tiles * c + 255) / 256;
+        const double t = rounds * ((double)g.K / c) * (1.3 / 64.0) + (c > 1 ? c + 1 : 0) * (double)g.M * g.N * 1e-6;
+        if (t < best_t) { best_t = t; sp = c; }
+      }
+    }
     if (sp > d->split_ws_slabs) sp = d->split_ws_slabs;
     if (sp > 1) {
       BGemmArgs q = g;
