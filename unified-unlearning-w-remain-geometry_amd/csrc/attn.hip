@@ -218,13 +218,15 @@ __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv,
     dma.issue(rsK, soff, ring.img(slot, 0), wave);
     dma.issue(rsV, soff, ring.img(slot, 1), wave);
   };
-  issue(0);                              // first two chunks stream in while Q is fetched and the pads are zeroed
-  if (nchunk > 1) issue(1);
+  // the Q fragments go out BEFORE the LDS-DMA of the first two K / V chunks: vector-memory operations retire in order, so loads
+  // issued behind the DMA would keep the first S = Q K^T waiting for chunk 1 as well
   bf16x8 fq[QT][KS];
 #pragma unroll
   for (int qi = 0; qi < QT; ++qi)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) fq[qi][ks] = frag_rows_global(base, ld, q0 + 16 * qi, ks, hd, lane);
+  issue(0);                              // first two chunks stream in while the pads are zeroed
+  if (nchunk > 1) issue(1);
   zero_pads<HDP>(smem, NSLOT * 2, hd, tid);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // pad zeros written before the first barrier of the loop
 
