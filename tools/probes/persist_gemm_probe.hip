@@ -34,7 +34,7 @@ __device__ __forceinline__ bf16x8 frag(const __bf16* img, int row, int kchunk) {
   return *reinterpret_cast<const bf16x8*>(img + row * 64 + ((kchunk ^ (row & 7)) << 3));
 }
 
-template <int WM, int WN, int MT, int NT_, bool PERSIST>
+template <int WM, int WN, int MT, int NT_, bool PERSIST, int GM = 0>
 __global__ __launch_bounds__(WM * WN * 64) void k_gemm(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* __restrict__ C, int M, int N, int K) {
   using CT = Cfg<WM, WN, MT, NT_>;
   constexpr int NW = CT::NW;
@@ -59,7 +59,15 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(const __bf16* __restrict_
   for (int i = 0; i < CT::NA; ++i) a_off[i] = 2 * (((wave + i * NW) * 8 + (lane >> 3)) * K + lc8);
 #pragma unroll
   for (int i = 0; i < CT::NB; ++i) b_off[i] = 2 * (((wave + i * NW) * 8 + (lane >> 3)) * K + lc8);
-  auto tile_of = [&](int ti, int& m0, int& n0) { const int t = id + ti * (int)gridDim.x; const int tm = t / ntn; m0 = tm * FBM; n0 = (t - tm * ntn) * CT::FBN; };
+  auto tile_of = [&](int ti, int& m0, int& n0) {
+    const int t = id + ti * (int)gridDim.x;
+    int tm = t / ntn, tn = t - tm * ntn;
+    if (GM > 0) {            // grouped order: ids sweep GM tile-rows x all columns, so the tiles an XCD runs at once form a 2-D block
+      const int ntm = M / FBM, per = GM * ntn, grp = t / per, rem = t - grp * per, gsz = min(GM, ntm - grp * GM);
+      tm = grp * GM + rem % gsz; tn = rem / gsz;
+    }
+    m0 = tm * FBM; n0 = tn * CT::FBN;
+  };
   auto issue = [&](int slot, int ti, int kt) {
     int m0, n0; tile_of(ti, m0, n0);
     __bf16* iA = smem + slot * CT::SLOT;
@@ -278,6 +286,42 @@ void run(const char* name, int M, int N, int K) {
   hipFree(dA); hipFree(dB); hipFree(dC);
 }
 
+template <int GM>
+void run_grouped(const char* name, int M, int N, int K) {
+  using CT = Cfg<8, 1, 2, 9>;
+  if (N % CT::FBN) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<8, 1, 2, 9, false, GM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT::LDS);
+  std::vector<uint16_t> hA((size_t)M * K), hB((size_t)N * K);
+  uint32_t st = 99u + N + K;
+  auto rnd = [&]() { st = st * 1664525u + 1013904223u; return st >> 8; };
+  for (auto& v : hA) v = f2bf((float)((int)(rnd() % 5) - 2));
+  for (auto& v : hB) v = f2bf((float)((int)(rnd() % 5) - 2));
+  __bf16 *dA, *dB, *dC;
+  hipMalloc(&dA, hA.size() * 2); hipMalloc(&dB, hB.size() * 2); hipMalloc(&dC, (size_t)M * N * 2);
+  hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
+  const dim3 grid((M / FBM) * (N / CT::FBN));
+  auto launch = [&]() { hipLaunchKernelGGL((k_gemm<8, 1, 2, 9, false, GM>), grid, dim3(512), CT::LDS, 0, dA, dB, dC, M, N, K); };
+  launch(); hipDeviceSynchronize();
+  std::vector<uint16_t> hC((size_t)M * N);
+  hipMemcpy(hC.data(), dC, hC.size() * 2, hipMemcpyDeviceToHost);
+  int bad = 0;
+  for (int t = 0; t < 6000; ++t) {
+    const int r = rnd() % M, c = rnd() % N;
+    float ref = 0.f;
+    for (int k = 0; k < K; ++k) ref += bf2f(hA[(size_t)r * K + k]) * bf2f(hB[(size_t)c * K + k]);
+    if (hC[(size_t)r * N + c] != f2bf(ref)) ++bad;
+  }
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 5; ++i) launch();
+  hipEventRecord(e0);
+  for (int i = 0; i < 30; ++i) launch();
+  hipEventRecord(e1); hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 30;
+  printf("%-16s tile 256x144 waves 8x1 grouped order GM=%d grid %4d: %7.1f us  %7.1f TFLOP/s   exact-integer check: %d / 6000 wrong\n", name, GM,
+         (int)grid.x, ms * 1e3, 2.0 * M * N * K / ms / 1e9, bad);
+  hipFree(dA); hipFree(dB); hipFree(dC);
+}
+
 template <int NT_, int NS>
 void run4(const char* name, int M, int N, int K) {
   constexpr int FBN = NT_ * 16;
@@ -322,7 +366,7 @@ int main() {
   struct Shape { const char* name; int N, K; } shapes[] = {{"qkv  1152->3456", 3456, 1152}, {"proj 1152->1152", 1152, 1152},
                                                            {"fc1  1152->4608", 4608, 1152}, {"fc2  4608->1152", 1152, 4608}};
   for (const Shape& s : shapes) {
-    run<4, 2, 4, 4>(s.name, M, s.N, s.K); run<8, 1, 2, 9>(s.name, M, s.N, s.K);
+    run<8, 1, 2, 9>(s.name, M, s.N, s.K); run_grouped<2>(s.name, M, s.N, s.K); run_grouped<4>(s.name, M, s.N, s.K); run_grouped<8>(s.name, M, s.N, s.K);
     run4<9, 3>(s.name, M, s.N, s.K); run4<9, 2>(s.name, M, s.N, s.K); run4<12, 2>(s.name, M, s.N, s.K); run4<16, 2>(s.name, M, s.N, s.K);
   }
   return 0;
