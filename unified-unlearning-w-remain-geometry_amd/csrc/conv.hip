@@ -1438,6 +1438,28 @@ __global__ __launch_bounds__(TPB) void k_split_finish(const float* __restrict__ 
   }
 }
 
+// the same on float4 column quads with the rows walked per workgroup (no per-element 64-bit division): N % 4 == 0, ldo % 4 == 0
+__global__ __launch_bounds__(TPB) void k_split_finish4(const float* __restrict__ slabs, int nsl, int64_t slab_stride, int M, int N,
+                                                       const float* __restrict__ bias, const float* __restrict__ vec, int ldvec, int T,
+                                                       const float* __restrict__ resid, float* __restrict__ of, __bf16* __restrict__ ob, int ldo,
+                                                       int rows_per_block) {
+  const int c = (blockIdx.x * TPB + threadIdx.x) * 4;
+  if (c >= N) return;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) b4 = *reinterpret_cast<const float4*>(bias + c);
+  for (int r = r0; r < r1; ++r) {
+    const float* p = slabs + (int64_t)r * N + c;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sl = 0; sl < nsl; ++sl) { const float4 v = *reinterpret_cast<const float4*>(p + sl * slab_stride); a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    a.x += b4.x; a.y += b4.y; a.z += b4.z; a.w += b4.w;
+    if (vec) { const float4 v = *reinterpret_cast<const float4*>(vec + (int64_t)(r / T) * ldvec + c); a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    if (resid) { const float4 v = *reinterpret_cast<const float4*>(resid + (int64_t)r * ldo + c); a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    if (of) *reinterpret_cast<float4*>(of + (int64_t)r * ldo + c) = a;
+    else *reinterpret_cast<bf16x4*>(ob + (int64_t)r * ldo + c) = bf16x4{f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w)};
+  }
+}
+
 // ---- small pieces
 // out[b][c] = sum_{p < HW} x[(b * HW + p) * ld + c]  (per-sample column sums: gradient of a per-sample broadcast vector)
 // one workgroup per (64-column slice, sample): the 4 waves stride over the rows (coalesced 256-B row reads), partial sums meet in LDS
@@ -1861,6 +1883,15 @@ int sfron_conv_fwd(const sfron_conv_desc* d, const uint16_t* src, const uint16_t
       rc = try_cgemm(q, true, a_rows, used, (hipStream_t)stream);
       if (rc < 0) rc = launch_bgemm<false, false, EPI_RES, CONV_A>(q, used, (hipStream_t)stream);
       if (rc) return rc;
+      const bool al = (((uintptr_t)d->split_ws | (uintptr_t)g.bias | (uintptr_t)g.vec | (uintptr_t)g.resid | (uintptr_t)g.Cf) & 15) == 0 &&
+                      (((uintptr_t)g.Cb) & 7) == 0;
+      if (g.N % 4 == 0 && d->ld_out % 4 == 0 && (!g.vec || g.ldvec % 4 == 0) && al) {
+        const int cb = (g.N / 4 + TPB - 1) / TPB;
+        int chunks = 2048 / cb; if (chunks > g.M) chunks = g.M; if (chunks < 1) chunks = 1;
+        const int rpb = (g.M + chunks - 1) / chunks;
+        hipLaunchKernelGGL(k_split_finish4, dim3(cb, (g.M + rpb - 1) / rpb), dim3(TPB), 0, (hipStream_t)stream, d->split_ws, used, (int64_t)g.M * g.N, g.M,
+                           g.N, g.bias, g.vec, g.ldvec, g.T, g.resid, g.Cf, g.Cb, d->ld_out, rpb);
+      } else
       hipLaunchKernelGGL(k_split_finish, dim3(grid_for((int64_t)g.M * g.N)), dim3(TPB), 0, (hipStream_t)stream, d->split_ws, used, (int64_t)g.M * g.N,
                          g.M, g.N, g.bias, g.vec, g.ldvec, g.T, g.resid, g.Cf, g.Cb, d->ld_out);
       SFRON_LAUNCH_STATUS();
