@@ -99,14 +99,38 @@ def cpu_baseline(model_name, latent, batch_full, cpu_batch):
                       f"model build {build_s:.1f} s not counted"}
 
 
+def launch_ranks(n):
+    """Run this script as n ranks under torch.distributed.run (child process, rendezvous on 127.0.0.1, a free port)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] WORLD_SIZE unset and --gpus {n}: starting {' '.join(cmd[1:8])} ... as a child job", file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this pool
+    return subprocess.run(cmd, env=env).returncode          # stdout / stderr are inherited: rank 0's JSON line passes through
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks as a CHILD job (one process per GPU under torch.distributed.run) and
+        # relay its output and exit code.  Nothing in this process has touched the GPU yet (importing torch does not), and it
+        # never will: a process that initialised HIP must not exec another program on this pool.
+        raise SystemExit(launch_ranks(args.gpus))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+    wd = None
+    if world > 1:
+        from sfron import dp as _dp
+        wd = _dp.Watchdog(rank)
+        wd.phase("rendezvous + model build", float(os.environ.get("SFRON_BENCH_SETUP_BUDGET_S", "600")))
     # rehearsal on a one-GPU box (tools / tests only): SFRON_BENCH_BACKEND=gloo lets N ranks share the visible devices -- RCCL refuses
     # two ranks on one device; the driver's runs use nccl (= RCCL) with one device per rank
     backend = os.environ.get("SFRON_BENCH_BACKEND", "nccl")
@@ -148,18 +172,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step_budget = float(os.environ.get("SFRON_BENCH_STEP_BUDGET_S", "30"))     # generous: a healthy step takes < 0.2 s
     dp_overlap = False
     if world > 1 and not args.no_overlap and args.micro_batches == 1:
-        try:
-            dp_overlap = runner.verify_overlap(batches[0][0])
-        except Exception as e:      # the same code runs on every rank: a host-side failure is symmetric -> every rank falls back
-            print(f"[bench] rank {rank}: overlapped exchange failed its check run ({type(e).__name__}: {e}); synchronous path",
-                  file=sys.stderr, flush=True)
-            dp_overlap = False
+        wd.phase("verify_overlap", 120 + 4 * step_budget)
+        # collective: a host-side failure on ONE rank is folded into the verdict inside verify_overlap (every rank still reaches
+        # the MIN all-reduce), so the ranks agree on the path; an exception that escapes ends the job non-zero
+        dp_overlap = runner.verify_overlap(batches[0][0])
         runner.overlap = dp_overlap
         if rank == 0:
             print(f"[bench] overlapped gradient exchange vs synchronous all-reduce on {world} ranks: "
                   f"{'match -> overlap ON' if dp_overlap else 'MISMATCH -> synchronous path'}", file=sys.stderr, flush=True)
+    if wd:
+        wd.phase("warm-up", 120 + step_budget * args.warmup)
     for i in range(args.warmup):
         runner.step(*batches[i % pool])
     eng = model.engine
@@ -167,6 +192,8 @@ def main():
     eng.wgrad_probe_enable(32 * args.steps + 32)
     runner.opt.timed = []                       # (start, end) event pairs around every k_masked_clip_adam launch
     sync()
+    if wd:
+        wd.phase("timed region", 60 + step_budget * args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = runner.step(*batches[i % pool])
@@ -215,6 +242,8 @@ def main():
         return None
     traffic = committed_traffic("r02_wgrad_traffic.json")
 
+    if wd:
+        wd.phase("check / report", 600)
     check_res = None
     if args.check and world > 1:
         # N-rank == 1-rank parity at equal global batch: the all-reduced gradient of the sharded forget pass of step 0 against
@@ -275,6 +304,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+        wd.stop()
     if check_res is not None and not check_res["ok"]:
         raise SystemExit(f"--check failed: {check_res}")
 

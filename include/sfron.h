@@ -52,6 +52,13 @@ int sfron_masked_clip_adam(float* p, const float* g, const float* g2 /* NULL or 
                            int64_t n, double beta1, double beta2, double eps, double step_size, double bc2_sqrt,
                            double decay_mul, uint16_t* w_bf16, float* ema, double ema_decay, int ema_mode, void* stream);
 
+/* the same sweep on at most max_workgroups workgroups of 256 threads (0 = as many as the range offers, capped at 2048): a
+ * sweep issued on a second stream BESIDE a GEMM chain takes a bounded share of the chip's wave slots and HBM queue */
+int sfron_masked_clip_adam_wg(float* p, const float* g, const float* g2, float* m, float* v, const uint8_t* mask, const float* stats,
+                              int64_t n, double beta1, double beta2, double eps, double step_size, double bc2_sqrt,
+                              double decay_mul, uint16_t* w_bf16, float* ema, double ema_decay, int ema_mode, int max_workgroups,
+                              void* stream);
+
 /* stand-alone EMA (frozen parameters such as pos_embed; DiT/forget.py:60-62) */
 int sfron_ema_update(float* ema, const float* p, int64_t n, double decay, int ema_mode, void* stream);
 
@@ -164,8 +171,14 @@ typedef struct sfron_gemm_desc {
                                         sfron_gemm_rowsum_supported accepts. */
   float* rowsum_ws;                  /* with a_rowsum: fp32 scratch [(N / 192) * M] for the per-tile-column partial sums, added in a
                                         fixed order by a small reduction launch on the same stream */
+  float* col_partials;               /* SFRON_EPI_DGELU only: fp32 [sfron_gemm_dgelu_colpart_rows(M, N, K)][N]; row r = the column
+                                        sums of output rows 256 r .. 256 r + 255 (fp32, before the bf16 rounding): partials of the fc1
+                                        bias gradient sum_rows d_hpre, formed where d_hpre is produced instead of by a second pass
+                                        over it (sum them with sfron_reduce_chunks).  NULL = not wanted. */
 } sfron_gemm_desc;
 int sfron_gemm_bf16(const sfron_gemm_desc* desc /* HOST pointer */, void* stream);
+/* number of partial rows an EPI_DGELU product of this shape writes to col_partials (M / 256), 0 = shape unsupported: use sfron_colsum */
+int sfron_gemm_dgelu_colpart_rows(int M, int N, int K);
 /* 1 when a weight-gradient GEMM dW[M][N] = dY[K][M]^T X[K][N] of this shape can also produce a_rowsum (else use sfron_colsum) */
 int sfron_gemm_rowsum_supported(int M, int N, int K);
 
@@ -358,6 +371,15 @@ int sfron_cond_fwd(const float* t_emb, const float* table, const int64_t* y, con
 /* d_c = d_silu_c * silu'(c); d_table[label] += d_c  (d_table must be zeroed by the caller) */
 int sfron_cond_bwd(const float* d_silu_c, const float* c, const int64_t* y, const uint8_t* drop, int num_classes, int n,
                    int D, float* d_c, float* d_table, void* stream);
+/* step guard (fail-loud checks without host syncs; guard.py polls `flags` behind an event).  flags: fp32 [4] =
+ * {non-finite loss, non-finite gradient norm, label outside [0, num_classes), timestep outside [0, num_timesteps)}, accumulated.
+ * guard_inputs: y_safe / t_safe = the inputs clamped into range (what the kernels then index with), flags[2] / [3] += number of
+ * clamped entries -- where the reference's nn.Embedding / table gather raise IndexError (DiT/models.py:89-93,
+ * gaussian_diffusion.py:861-873).  guard_finite: a (and optional b, c, d) are per-sample loss terms [n]; stats (optional) =
+ * the clip statistics of sfron_clip_coef, stats[0] = gradient norm (the values DiT/forget.py:329-336 logs). */
+int sfron_guard_inputs(const int64_t* y, const int64_t* t, int n, int num_classes, int num_timesteps, int64_t* y_safe, int64_t* t_safe,
+                       float* flags, void* stream);
+int sfron_guard_finite(const float* a, const float* b, const float* c, const float* d, int n, const float* stats, float* flags, void* stream);
 /* latent front-end: out [n][c][hw] = (mean + exp(0.5 * clamp(logvar, -30, 20)) * eps) * scale from cached VAE posterior moments
  * [n][2c][hw] = mean || logvar -- vae.encode(x).latent_dist.sample().mul_(0.18215) of DiT/forget.py:265-267,305-307 with the
  * encoder's output cached offline (diffusers' DiagonalGaussianDistribution.sample; diffusers is absent here: parity unpinned) */

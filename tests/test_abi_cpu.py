@@ -55,7 +55,7 @@ def test_descriptor_structs_match_the_header(built):
     fields = {"sfron_wprep_item": (built.WprepItem, ["w", "fwd", "dgr", "co", "tile0"]),
               "sfron_conv_desc": (built.ConvDesc, ["batch", "n_out", "out_f32", "split_ws"]),
               "sfron_bgemm_desc": (built.BGemmDesc, ["A", "M", "c_f32", "alpha", "split_ws"]),
-              "sfron_gemm_desc": (built.GemmDesc, ["A", "M", "a_rowsum", "rowsum_ws"])}
+              "sfron_gemm_desc": (built.GemmDesc, ["A", "M", "a_rowsum", "rowsum_ws", "col_partials"])}
     lines = []
     for cname, (_, fs) in fields.items():
         lines.append(f'printf("{cname} %zu", sizeof({cname}));')

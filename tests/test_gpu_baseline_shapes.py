@@ -82,6 +82,19 @@ def test_dgrad_gemms_at_baseline_shapes(name, N, K, epi):
         h = hpre.float().requires_grad_(True)
         torch.nn.functional.gelu(h, approximate="tanh").backward(want)
         want = h.grad
+        # the same product with the fc1 bias-gradient partials formed in its epilogue (fp32 column sums of each 256-row tile row,
+        # before the bf16 rounding): d_hpre unchanged bit for bit, the partial rows are the column sums of the fp32 product
+        rows = _lib.lib().sfron_gemm_dgelu_colpart_rows(M, N, K)
+        assert rows == M // 256
+        C2 = torch.empty_like(C)
+        part = torch.full((rows, N), float("nan"), device=DEV)
+        ops.gemm(dY, W, M, N, K, b_t=True, epilogue=_lib.EPI_DGELU, c_bf16=C2, aux=hpre, col_partials=part)
+        assert torch.equal(C2, C)
+        assert torch.allclose(part, want.view(rows, 256, N).sum(1), rtol=2e-3, atol=2e-3 * want.abs().max().item())
+        assert _rel(part.sum(0), want.sum(0)) < 2e-3
+        part2 = torch.empty_like(part)             # fixed summation order, no atomics: bitwise reproducible
+        ops.gemm(dY, W, M, N, K, b_t=True, epilogue=_lib.EPI_DGELU, c_bf16=C2, aux=hpre, col_partials=part2)
+        assert torch.equal(part, part2)
     assert _rel(C, want) < 5e-3
     assert torch.allclose(C.float(), want, rtol=1.5e-2, atol=2e-3 * float(want.abs().max()))
 

@@ -22,3 +22,19 @@ def run(kind, it=6):
 for kind, bpp in (("forget", 36.0), ("remain", 38.0)):
     dt = run(kind)
     print(f"{kind}: {dt * 1e3:.2f} ms  ({bpp * n / dt / 1e12:.2f} TB/s algorithmic incl. the norm pre-pass)")
+
+# workgroup-count sweep of the update kernel alone (sfron_masked_clip_adam_wg): fewer, longer-lived workgroups
+import ctypes
+from sfron._lib import check, ptr, stream_ptr
+m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+L = _lib.lib()
+def one(W, with_ema):
+    check(L.sfron_masked_clip_adam_wg(ptr(p), ptr(g), None, ptr(m), ptr(v), None if with_ema else ptr(mask), None, n, 0.9, 0.999, 1e-8,
+                                      1e-4, 1.0, 1.0, ptr(w16), ptr(ema) if with_ema else None, 0.9999, 1 if with_ema else 0, W, stream_ptr()), "adam_wg")
+for with_ema, bpp in ((False, 31.0), (True, 38.0)):
+    for W in (0, 1536, 1024, 768, 512, 384, 320, 256, 192):
+        for _ in range(2): one(W, with_ema)
+        torch.cuda.synchronize(); t0 = time.time()
+        for _ in range(6): one(W, with_ema)
+        torch.cuda.synchronize(); dt = (time.time() - t0) / 6
+        print(f"  update only, {'remain' if with_ema else 'forget'} form, W={W:5d}: {dt * 1e3:.2f} ms  {bpp * n / dt / 1e12:.2f} TB/s")

@@ -26,6 +26,8 @@ _PROTOS = {
     "sfron_clip_coef": (c_int, [_P, c_int, c_float, _P, _S]),
     "sfron_masked_clip_adam": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_double,
                                        c_double, _P, _P, c_double, c_int, _S]),
+    "sfron_masked_clip_adam_wg": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_double,
+                                          c_double, _P, _P, c_double, c_int, c_int, _S]),
     "sfron_ema_update": (c_int, [_P, _P, c_int64, c_double, c_int, _S]),
     "sfron_fisher_accum": (c_int, [_P, _P, c_int64, c_float, _S]),
     "sfron_fisher_accum_clipped": (c_int, [_P, _P, _P, _P, c_int64, c_float, _S]),
@@ -53,13 +55,14 @@ class GemmDesc(ctypes.Structure):
                 ("aux", c_void_p), ("ldaux", c_int), ("gate", c_void_p), ("ldgate", c_int), ("pos", c_void_p),
                 ("tokens", c_int), ("accumulate", c_int), ("resid", c_void_p), ("split_k", c_int),
                 ("split_stride", ctypes.c_long), ("tile_hint", c_int), ("a_rowsum", c_void_p),
-                ("rowsum_ws", c_void_p)]
+                ("rowsum_ws", c_void_p), ("col_partials", c_void_p)]
 
 
 EPI_BF16, EPI_F32, EPI_GELU, EPI_GATE_RES, EPI_DGELU, EPI_POS = range(6)
 
 _PROTOS["sfron_gemm_bf16"] = (c_int, [POINTER(GemmDesc), _S])
 _PROTOS["sfron_gemm_rowsum_supported"] = (c_int, [c_int, c_int, c_int])
+_PROTOS["sfron_gemm_dgelu_colpart_rows"] = (c_int, [c_int, c_int, c_int])
 _PROTOS.update({
     "sfron_rows_per_chunk": (c_int, [c_int]),
     "sfron_ln_modulate_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _S]),
@@ -76,6 +79,8 @@ _PROTOS.update({
     "sfron_colsum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, _S]),
     "sfron_timestep_embed": (c_int, [_P, c_int, c_int, _P, c_int, _S]),
     "sfron_latent_sample": (c_int, [_P, _P, c_int, c_int, c_int, c_float, _P, _S]),
+    "sfron_guard_inputs": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _S]),
+    "sfron_guard_finite": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _S]),
     "sfron_silu_fwd": (c_int, [_P, c_int64, _P, _S]),
     "sfron_silu_bwd": (c_int, [_P, _P, c_int64, _P, _P, _S]),
     "sfron_cond_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _S]),

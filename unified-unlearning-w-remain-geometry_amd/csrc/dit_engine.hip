@@ -74,7 +74,7 @@ struct Workspace {
   __bf16* xmodf;
   float* tok;
   // backward temporaries
-  float *dx, *dmod, *d_sc, *d_c, *d_h1s, *delta, *part, *csum, *csum2, *slabs, *wslab, *dysum;
+  float *dx, *dmod, *d_sc, *d_c, *d_h1s, *delta, *part, *csum, *csum2, *slabs, *wslab, *dysum, *bpart;
   __bf16 *d_tok, *d_xmod, *d_o, *dmod_bf, *d_c_bf, *d_h1_bf, *dx_bf;
   __bf16 *d_br[2], *d_br2[2], *d_hpre[2], *dqkv[2];   // read by the side stream: double-buffered by block parity so the
                                                        // dgrad chain may run one block ahead of the weight gradients
@@ -131,6 +131,9 @@ inline Workspace make_ws(const Dims& d, char* base) {
     w.wslab = (float*)take(mx * 4);
   }
   w.dysum = (float*)take((L + 1) * 2 * B * D * 4);                       // [L][proj|fc2][B][D] token sums of dy (gated bias grads)
+  // per-tile-row partials of the fc1 / qkv bias gradients, written by the kernels that PRODUCE d_hpre / dqkv (double-buffered
+  // by block parity like those tensors: the side stream reduces them one block behind)
+  w.bpart = (float*)take(2 * (size_t)((M + 255) / 256) * (size_t)(d.F > 3 * d.D ? d.F : 3 * d.D) * 4);
   w.d_tok = (__bf16*)take(M * (size_t)d.Po * 2);
   for (int i = 0; i < 2; ++i) {
     w.d_br[i] = (__bf16*)take(M * D * 2); w.d_br2[i] = (__bf16*)take(M * D * 2);
@@ -187,7 +190,7 @@ int64_t sfron_dit_workspace_bytes(const sfron_dit_cfg* cfg) {
 }
 
 // SFRON_ABLATE (debug / A-B measurement only): bit 0 = run LN backward and gate backward as separate kernels,
-// bit 1 = split-K in the block weight gradients (off by default), bit 2 = side stream at the lowest priority, bit 3 = fc2 weight gradient after the fc2 dgrad, bit 4 = no split-K for the two small-output weight gradients, bit 5 = bias gradients by separate column-sum launches
+// bit 1 = split-K in the block weight gradients (off by default), bit 2 = side stream at the lowest priority, bit 3 = fc2 weight gradient after the fc2 dgrad, bit 4 = no split-K for the two small-output weight gradients, bit 5 = bias row sums inside the weight-gradient GEMM, bit 6 = fc1 bias gradient by a separate column-sum launch
 static int ablate_mask() {
 #ifdef SFRON_DEBUG_KNOBS
   static const int m = [] { const char* e = getenv("SFRON_ABLATE"); return e ? atoi(e) : 0; }();
@@ -434,6 +437,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     if (i == 0) (void)hipStreamWaitEvent(hs, ax->consumed[2 * 3 + (l & 1)], 0);   // buffers 1..3 of block l are written later on this stream
   };
   if (ax) { (void)hipEventRecord(ax->done, hs); (void)hipStreamWaitEvent(ax->side, ax->done, 0); }   // side starts after everything before us
+  const int fc1_rows = (ablate_mask() & 64) ? 0 : sfron_gemm_dgelu_colpart_rows(M, d.F, D);    // 0: shape not on a 256-row pipelined tile -> column-sum launch
 
   // ---- final layer
   RUN(sfron_patchify(d_out, B, d.Co, d.S, d.S, d.p, 1, (uint16_t*)w.d_tok, d.Po, stream));
@@ -491,13 +495,20 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     before_overwrite(1, l);
     g = dgrad_desc(w.d_br[pl], wb + pb + P.o_fc2_w, M, D, d.F);
     g.epilogue = SFRON_EPI_DGELU; g.c_bf16 = (uint16_t*)w.d_hpre[pl]; g.ldc_bf16 = d.F; g.aux = (uint16_t*)hpre; g.ldaux = d.F;
+    // fc1.bias gradient = column sums of d_hpre: the epilogue that produces d_hpre leaves per-tile-row partials (fp32, before the
+    // bf16 rounding); the side stream only adds the M / 256 partial rows (was: a second 75 MB pass over d_hpre per block)
+    float* const bp_fc1 = w.bpart + (size_t)pl * fc1_rows * d.F;
+    if (fc1_rows) g.col_partials = bp_fc1;
     RUN(sfron_gemm_bf16(&g, stream));
     produced(1);
     if (delay_fc2) {
       RUN(wgrad_side(w.d_br[pl], h, D, d.F, grads + pb + P.o_fc2_w));
       consumed(0, l);
     }
-    RUN(wgrad_side(w.d_hpre[pl], xmod2, d.F, D, grads + pb + P.o_fc1_w, grads + pb + P.o_fc1_b));
+    if (fc1_rows) {
+      RUN(sfron_reduce_chunks(bp_fc1, 1, fc1_rows, d.F, grads + pb + P.o_fc1_b, d.F, 0, side));
+      RUN(wgrad_side(w.d_hpre[pl], xmod2, d.F, D, grads + pb + P.o_fc1_w));
+    } else RUN(wgrad_side(w.d_hpre[pl], xmod2, d.F, D, grads + pb + P.o_fc1_w, grads + pb + P.o_fc1_b));
     consumed(1, l);
     g = dgrad_desc(w.d_hpre[pl], wb + pb + P.o_fc1_w, M, d.F, D);
     g.c_bf16 = (uint16_t*)w.d_xmod; g.ldc_bf16 = D;

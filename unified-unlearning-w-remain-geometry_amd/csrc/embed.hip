@@ -125,6 +125,54 @@ inline int grid_for(int64_t n) {
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
+// ---- step guard (host side: guard.py): the fail-loud checks of one SFR-on iteration as two tiny launches instead of ~40 torch ops.
+// Inputs of a pass: labels / timesteps clamped into range (the kernels downstream never index out of bounds) and the number of
+// clamped entries added to flags[2] (labels) / flags[3] (timesteps) -- the reference raises an IndexError there
+// (DiT/models.py:89-93, gaussian_diffusion.py:861-873); the host raises SfronError at its next poll.
+__global__ __launch_bounds__(TPB) void k_guard_inputs(const int64_t* __restrict__ y, const int64_t* __restrict__ t, int n, int num_classes,
+                                                      int num_timesteps, int64_t* __restrict__ y_safe, int64_t* __restrict__ t_safe,
+                                                      float* __restrict__ flags) {
+  __shared__ int bad[2];
+  if (threadIdx.x < 2) bad[threadIdx.x] = 0;
+  __syncthreads();
+  int by = 0, bt = 0;
+  for (int i = threadIdx.x; i < n; i += TPB) {
+    const int64_t yy = y[i], tt = t[i];
+    const int64_t yc = yy < 0 ? 0 : (yy >= num_classes ? num_classes - 1 : yy);
+    const int64_t tc = tt < 0 ? 0 : (tt >= num_timesteps ? num_timesteps - 1 : tt);
+    by += yc != yy; bt += tc != tt;
+    y_safe[i] = yc; t_safe[i] = tc;
+  }
+  if (by) atomicAdd(&bad[0], by);       // integer LDS atomics: order-independent
+  if (bt) atomicAdd(&bad[1], bt);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (bad[0]) flags[2] += (float)bad[0];
+    if (bad[1]) flags[3] += (float)bad[1];
+  }
+}
+// flags[0] += 1 if any of the per-sample loss terms is NaN / Inf, flags[1] += 1 if the gradient norm (stats[0]) is
+__global__ __launch_bounds__(TPB) void k_guard_finite(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                      const float* __restrict__ d, int n, const float* __restrict__ stats,
+                                                      float* __restrict__ flags) {
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  int nb = 0;
+  for (int i = threadIdx.x; i < n; i += TPB) {
+    nb += !isfinite(a[i]);
+    if (b) nb += !isfinite(b[i]);
+    if (c) nb += !isfinite(c[i]);
+    if (d) nb += !isfinite(d[i]);
+  }
+  if (nb) atomicAdd(&bad, nb);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (bad) flags[0] += 1.0f;
+    if (stats && !isfinite(stats[0])) flags[1] += 1.0f;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -188,6 +236,21 @@ int sfron_unpatchify(const float* rows, int ld, int n, int C, int H, int W, int 
   SFRON_CHECK_ARG(img && rows && n > 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0 && ld >= C * p * p);
   hipLaunchKernelGGL(k_unpatchify, dim3(grid_for((int64_t)n * C * H * W)), dim3(TPB), 0, (hipStream_t)stream, rows, ld, n, C, H,
                      W, p, img);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_guard_inputs(const int64_t* y, const int64_t* t, int n, int num_classes, int num_timesteps, int64_t* y_safe, int64_t* t_safe,
+                       float* flags, void* stream) {
+  SFRON_CHECK_ARG(y && t && y_safe && t_safe && flags && n > 0 && num_classes > 0 && num_timesteps > 0);
+  hipLaunchKernelGGL(k_guard_inputs, dim3(1), dim3(TPB), 0, (hipStream_t)stream, y, t, n, num_classes, num_timesteps, y_safe, t_safe, flags);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_guard_finite(const float* a, const float* b, const float* c, const float* d, int n, const float* stats, float* flags, void* stream) {
+  SFRON_CHECK_ARG(a && flags && n > 0);
+  hipLaunchKernelGGL(k_guard_finite, dim3(1), dim3(TPB), 0, (hipStream_t)stream, a, b, c, d, n, stats, flags);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

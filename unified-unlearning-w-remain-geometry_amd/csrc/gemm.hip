@@ -45,6 +45,8 @@ struct GemmArgs {
   int ntm, ntn;
   int group_m;              // fast path: tile-rows per group of the grouped tile order
   float* bsum;              // weight-gradient layout: bsum[m] = sum_k op(A)[m][k] (bias gradient), or null
+  float* colpart;           // EPI_DGELU on the 256-row pipelined tiles: colpart[tm * N + n] = sum over the tile's 256 rows of the
+                            // fp32 output (before bf16 rounding) -- per-tile-row partials of the fc1 bias gradient, or null
 };
 
 namespace {
@@ -1009,16 +1011,47 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         hx[mt][nt] = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)(row_b + mt * 16) * g.ldaux + col_b + nt * 16);
+    f32x4 cs[NT];                                  // this lane's column sums over its MT rows (fc1 bias gradient partials)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) cs[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const f32x4 v = acc[mt][nt] * g.alpha;
         const bf16x4 h = hx[mt][nt];
-        bf16x4 o = {f2bf(v[0] * gelu_tanh_grad(bf2f(h[0]))), f2bf(v[1] * gelu_tanh_grad(bf2f(h[1]))),
-                    f2bf(v[2] * gelu_tanh_grad(bf2f(h[2]))), f2bf(v[3] * gelu_tanh_grad(bf2f(h[3])))};
+        const f32x4 r = {v[0] * gelu_tanh_grad(bf2f(h[0])), v[1] * gelu_tanh_grad(bf2f(h[1])),
+                         v[2] * gelu_tanh_grad(bf2f(h[2])), v[3] * gelu_tanh_grad(bf2f(h[3]))};
+        cs[nt] += r;
+        bf16x4 o = {f2bf(r[0]), f2bf(r[1]), f2bf(r[2]), f2bf(r[3])};
         *reinterpret_cast<bf16x4*>(g.Cb + (size_t)(row_b + mt * 16) * g.ldcb + col_b + nt * 16) = o;
       }
+    if (g.colpart) {                               // kernel-uniform
+      // rows of a wave: the 16 lanes that share lane >> 4 hold the same 4 columns -> butterfly over lane & 15, then the WM
+      // waves stacked over the rows meet in LDS (free now: every wave is past the main loop after the barrier); fixed order
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float x = cs[nt][j];
+          x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+          cs[nt][j] = x;
+        }
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);                         // [WM][FBN]
+      if ((lane & 15) == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          *reinterpret_cast<f32x4*>(red + wm * FBN + wn * NT * 16 + nt * 16 + 4 * (lane >> 4)) = cs[nt];
+      }
+      __syncthreads();
+      for (int cidx = tid; cidx < FBN; cidx += NW * 64) {
+        float x = red[cidx];
+#pragma unroll
+        for (int w2 = 1; w2 < WM; ++w2) x += red[w2 * FBN + cidx];
+        g.colpart[(size_t)tm * g.N + n0 + cidx] = x;
+      }
+    }
   } else if constexpr (EPI == EPI_GATE_RES) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -1236,6 +1269,19 @@ int dispatch_layout(int a_tr, int b_tr, const GemmArgs& g, hipStream_t s, int fo
 
 extern "C" int sfron_gemm_rowsum_supported(int M, int N, int K) { return rowsum_ok(M, N, K) ? 1 : 0; }
 
+// EPI_DGELU products dX[M][N] = dY[M][K] W[K][N] (B read transposed) whose automatic tile is one of the 256-row pipelined tiles can
+// also write the per-tile-row column sums of their output: returns the number of partial rows (M / 256), or 0 when the shape goes
+// to another kernel (the caller then uses sfron_colsum)
+extern "C" int sfron_gemm_dgelu_colpart_rows(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  GemmArgs g{};
+  g.M = M; g.N = N; g.K = K; g.kchunk = K;
+  const int t = pick_fast_tile(g, 0, 1);
+  if (t == 42) return M / 256;
+  if (t == 62) return (K % 192 == 0 || tile_fits(g, 2)) ? M / 256 : 0;
+  return 0;
+}
+
 extern "C" int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
   SFRON_CHECK_ARG(d && d->A && d->B && d->M > 0 && d->N > 0 && d->K > 0);
   SFRON_CHECK_ARG(d->N % 4 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0);
@@ -1270,6 +1316,12 @@ extern "C" int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
   g.nt_out = (nt_mask & 1) | ((nt_mask & 2) && d->a_transposed && d->b_transposed && d->split_k <= 1 && !d->accumulate ? 2 : 0);
   g.ntm = cdiv(d->M, BM); g.ntn = cdiv(d->N, BN);
   g.bsum = nullptr;
+  g.colpart = nullptr;
+  if (d->col_partials) {      // only the auto-dispatched 256-row pipelined tiles form it (sfron_gemm_dgelu_colpart_rows)
+    SFRON_CHECK_ARG(d->epilogue == SFRON_EPI_DGELU && d->split_k <= 1 && d->tile_hint == 0);
+    if (sfron_gemm_dgelu_colpart_rows(d->M, d->N, d->K) == 0) return SFRON_ERR_UNSUPPORTED;
+    g.colpart = d->col_partials;
+  }
   if (d->a_rowsum) {        // only the auto-dispatched three-slot weight-gradient kernel forms it
     SFRON_CHECK_ARG(d->rowsum_ws && d->a_transposed && d->b_transposed && d->epilogue == SFRON_EPI_F32 && d->split_k <= 1 &&
                     d->tile_hint == 0);

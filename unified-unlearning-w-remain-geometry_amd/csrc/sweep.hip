@@ -222,9 +222,10 @@ int sfron_clip_coef(const double* partials, int nblk, float max_norm, float* sta
   return SFRON_OK;
 }
 
-int sfron_masked_clip_adam(float* p, const float* g, const float* g2, float* m, float* v, const uint8_t* mask, const float* stats,
-                           int64_t n, double beta1, double beta2, double eps, double step_size, double bc2_sqrt,
-                           double decay_mul, uint16_t* w_bf16, float* ema, double ema_decay, int ema_mode, void* stream) {
+int sfron_masked_clip_adam_wg(float* p, const float* g, const float* g2, float* m, float* v, const uint8_t* mask, const float* stats,
+                              int64_t n, double beta1, double beta2, double eps, double step_size, double bc2_sqrt,
+                              double decay_mul, uint16_t* w_bf16, float* ema, double ema_decay, int ema_mode, int max_workgroups,
+                              void* stream) {
   SFRON_CHECK_ARG(p && g && m && v && n >= 0);
   SFRON_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)g2 | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
   SFRON_CHECK_ARG(!mask || ((uintptr_t)mask & 3) == 0);
@@ -232,10 +233,23 @@ int sfron_masked_clip_adam(float* p, const float* g, const float* g2, float* m, 
   SFRON_CHECK_ARG(ema_mode == 0 || (ema && ((uintptr_t)ema & 15) == 0 && (ema_mode == 1 || ema_mode == 2)));
   AdamArgs a{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)step_size, (float)bc2_sqrt,
              (float)decay_mul, (float)ema_decay, (float)(1.0 - ema_decay), ema_mode};
-  hipLaunchKernelGGL(k_masked_clip_adam, dim3(grid_for(n >> 2)), dim3(TPB), 0, (hipStream_t)stream,
+  // three resident workgroups per CU (768 on 256 CUs), each striding through the arenas: measured 5.7-6.0 TB/s against 5.4-5.5 for
+  // 2048 short-lived ones (tools/bench_sweep.py, 675 M parameters; fewer than 512 starve the memory system)
+  constexpr int ADAM_GRID = 768;
+  int grid = grid_for(n >> 2);
+  if (grid > ADAM_GRID) grid = ADAM_GRID;
+  if (max_workgroups > 0 && grid > max_workgroups) grid = max_workgroups;      // a sweep that runs BESIDE a GEMM chain: bounded share of the chip
+  hipLaunchKernelGGL(k_masked_clip_adam, dim3(grid), dim3(TPB), 0, (hipStream_t)stream,
                      p, g, g2, m, v, mask, stats, n, a, w_bf16, ema);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
+}
+
+int sfron_masked_clip_adam(float* p, const float* g, const float* g2, float* m, float* v, const uint8_t* mask, const float* stats,
+                           int64_t n, double beta1, double beta2, double eps, double step_size, double bc2_sqrt,
+                           double decay_mul, uint16_t* w_bf16, float* ema, double ema_decay, int ema_mode, void* stream) {
+  return sfron_masked_clip_adam_wg(p, g, g2, m, v, mask, stats, n, beta1, beta2, eps, step_size, bc2_sqrt, decay_mul, w_bf16, ema,
+                                   ema_decay, ema_mode, 0, stream);
 }
 
 int sfron_ema_update(float* ema, const float* p, int64_t n, double decay, int ema_mode, void* stream) {

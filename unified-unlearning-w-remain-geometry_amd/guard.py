@@ -2,13 +2,14 @@
 
 The reference raises where something is off (a bad label is an IndexError inside nn.Embedding, DiT/models.py:89-93; a NaN
 loss shows in its per-step log line, DiT/forget.py:329-336).  The fast path never reads a device value on the host, so the
-checks are device-side counters (a few tiny torch ops per step) whose snapshot travels to a pinned host buffer behind a HIP
+checks are device-side counters (two tiny kernels per step, csrc/embed.hip) whose snapshot travels to a pinned host buffer behind a HIP
 event; ``poll()`` looks at the snapshot of an EARLIER step once its event has completed -- no synchronisation -- and raises
 ``SfronError``.  ``poll(block=True)`` (end of a run, bench.py, tests) waits for the newest snapshot.
 """
 import torch
 
-from ._lib import SfronError
+from . import _lib
+from ._lib import SfronError, check, ptr, stream_ptr
 
 REASONS = ("non-finite loss", "non-finite gradient norm", "label outside [0, num_classes)", "timestep outside [0, num_timesteps)")
 
@@ -23,6 +24,22 @@ class StepGuard:
     def note(self, idx, bad):
         """bad: 0-dim bool / number tensor on the device (True = violation).  Accumulates; never reset."""
         self.flags[idx] += bad.to(torch.float32)
+
+    def check_inputs(self, y, t, num_classes, num_timesteps):
+        """Labels / timesteps clamped into range (new tensors) + the violation counters, in ONE launch (csrc/embed.hip)."""
+        y, t = y.contiguous(), t.contiguous()
+        y_safe, t_safe = torch.empty_like(y), torch.empty_like(t)
+        check(_lib.lib().sfron_guard_inputs(ptr(y), ptr(t), y.numel(), int(num_classes), int(num_timesteps), ptr(y_safe), ptr(t_safe),
+                                            ptr(self.flags), stream_ptr()), "guard_inputs")
+        return y_safe, t_safe
+
+    def check_finite(self, terms, stats=None):
+        """terms: up to four per-sample fp32 loss vectors of equal length; stats: the optimizer's clip statistics (or None)."""
+        terms = [x.contiguous() for x in terms]
+        assert 1 <= len(terms) <= 4 and all(x.numel() == terms[0].numel() and x.dtype == torch.float32 for x in terms)
+        p = [ptr(x) for x in terms] + [None] * (4 - len(terms))
+        check(_lib.lib().sfron_guard_finite(p[0], p[1], p[2], p[3], terms[0].numel(), ptr(stats), ptr(self.flags), stream_ptr()),
+              "guard_finite")
 
     def publish(self, step_no):
         self.host.copy_(self.flags, non_blocking=True)

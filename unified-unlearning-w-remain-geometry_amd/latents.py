@@ -134,7 +134,13 @@ class UnlearnLatentLoader:
         self.step[stream] = step + 1
         dv, sync = staged
         if sync is not None:
-            torch.cuda.current_stream().wait_event(sync[0])
+            cur = torch.cuda.current_stream()
+            cur.wait_event(sync[0])
+            # the staged tensors were allocated on the copy stream: tell the caching allocator that the consumer stream
+            # reads them, so a dropped batch is not handed to a later staging copy while queued step kernels still use it
+            # (the fast path never syncs the host and may run several steps ahead of the GPU)
+            for v in dv.values():
+                v.record_stream(cur)
         mom = dv["moments"].contiguous()
         n, c2, h, w = mom.shape
         x0 = torch.empty(n, c2 // 2, h, w, dtype=torch.float32, device=mom.device)

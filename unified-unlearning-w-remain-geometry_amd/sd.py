@@ -176,19 +176,27 @@ class SDSFRon:
             self._graphs[name] = graphs.StageGraph(fn, warmup=1, pool=self._pool)
         return self._graphs[name](**inputs)
 
+    def _exchange(self):
+        """SUM all-reduce of this stage's gradients: the whole arena ("full"), or only the ranges the optimizer owns ("xattn" --
+        the frozen layers' weight gradients are not even formed, their arena entries are stale)."""
+        if self.opt.ranges is not None:
+            self._dp.allreduce_ranges_(self.opt.g, self.opt.ranges, 64 << 20, self.pg)
+        else:
+            self._dp.allreduce_flat_(self.opt.g, 64 << 20, self.pg)
+
     def step(self, forget, remain):
         """forget: dict(x_f, x_p, c_f, c_p, t, noise); remain: dict(x, c, t, noise) -- device tensors, this rank's shard."""
         u = self.unet
         u.train()
         ori_forget = self._stage("forget", self._forget_pass, **{k: forget[k] for k in ("x_f", "x_p", "c_f", "c_p", "t", "noise")})
         if self.world > 1:
-            self._dp.allreduce_flat_(self.opt.g, 64 << 20, self.pg)
+            self._exchange()
         self.opt.mask = self.forget_mask
         self.opt.step(max_norm=None, use_mask=True)                       # nsfw_removal.py:162 (no clipping)
         u.weights_updated(convs=self.train_method == "full")
         ori_remain = self._stage("remain", self._remain_pass, **{k: remain[k] for k in ("x", "c", "t", "noise")})
         if self.world > 1:
-            self._dp.allreduce_flat_(self.opt.g, 64 << 20, self.pg)
+            self._exchange()
         self.opt.mask = self.train_mask
         self.opt.step(max_norm=None, use_mask=True)                       # :170
         u.weights_updated(convs=self.train_method == "full")

@@ -39,7 +39,7 @@ def build_mask_arena(engine, mask):
 class DiTSFRon:
     def __init__(self, model, diffusion, lr=1e-4, forget_alpha=1e-3, grad_clip=1.0, ema_decay=0.9999, mask=None,
                  unlearn_loss="ga", forget_class=0, process_group=None, bucket_bytes=256 << 20, micro_batches=1,
-                 overlap_allreduce=False):
+                 overlap_allreduce=False, grad_transport="fp32"):
         """micro_batches = 2: each forward/backward pass runs as TWO independent half-batch chains on two HIP streams
         (own workspace, own gradient arena, own side stream); the latency-bound kernels of one chain (attention,
         LayerNorm / gate backward) then run under the GEMMs of the other.  The optimizer sweep sums the two arenas."""
@@ -63,6 +63,11 @@ class DiTSFRon:
         # running.  Off unless asked for: bench.py turns it on at N > 1 only after verify_overlap() has shown, on the ranks
         # of that very run, that it reproduces the synchronous bucketed exchange.
         self.overlap = bool(overlap_allreduce)
+        # grad_transport "bf16": gradient ranges cross the xGMI links as bf16 (half the bytes; dp.allreduce_); "fp32" = exact sum
+        if grad_transport not in ("fp32", "bf16"):
+            raise ValueError("grad_transport must be 'fp32' or 'bf16'")
+        self.grad_transport = grad_transport
+        self._tx_scratch = None
         self._chains = None
         self._comm = None
         self._ada_all = None
@@ -78,8 +83,26 @@ class DiTSFRon:
                                   mask=self.mask_arena, w_bf16=eng.params_bf16[:nt])          # forget.py:199
         self.ema = eng.params.clone()                                                      # forget.py:190,230
 
+    def _scratch(self, n):
+        """bf16 staging buffer of the gradient transport (None for fp32), at least n elements, one per stream (the overlapped
+        exchange stages block ranges on the communication stream while the tail ranges go through the compute stream)."""
+        if self.grad_transport == "fp32" or self.world == 1:
+            return None
+        if self._tx_scratch is None:
+            self._tx_scratch = {}
+        dev = self.model.engine.device
+        key = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        buf = self._tx_scratch.get(key)
+        if buf is None or buf.numel() < n:
+            buf = self._tx_scratch[key] = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        return buf
+
+    def _ar(self, t):
+        dp.allreduce_(t, self.pg, self.grad_transport if self.world > 1 else "fp32", self._scratch(t.numel()))
+
     def _allreduce_grads(self):
-        dp.allreduce_flat_(self.model.engine.grads[:self.model.engine.n_trainable], self.bucket_elems, self.pg)
+        g = self.model.engine.grads[:self.model.engine.n_trainable]
+        dp.allreduce_flat_(g, self.bucket_elems, self.pg, transport=self.grad_transport, scratch=self._scratch(min(g.numel(), self.bucket_elems)))
 
     # ------------------------------------------------------------------ all-reduce overlapped with the backward pass
     def _overlap_enabled(self):
@@ -97,6 +120,7 @@ class DiTSFRon:
         nt = eng.n_trainable
         y = batch["y"] if y is None else y
         keep = self.overlap
+        ok = torch.zeros((), dtype=torch.float32, device=eng.device)
         try:
             self.overlap = False
             self._pass(batch, y, -self.forget_alpha)
@@ -105,6 +129,11 @@ class DiTSFRon:
             self._pass(batch, y, -self.forget_alpha)
             diff = (eng.grads[:nt] - g_sync).norm() / (g_sync.norm() + 1e-30)
             ok = (torch.isfinite(diff) & (diff < rtol)).to(torch.float32)
+        except Exception as e:      # a host-side failure on THIS rank (allocation, library error): vote "no" instead of leaving
+            import sys              # the other ranks alone in the MIN all-reduce below
+            print(f"[sfron] verify_overlap failed on this rank ({type(e).__name__}: {e}); voting for the synchronous path",
+                  file=sys.stderr, flush=True)
+            ok = torch.zeros((), dtype=torch.float32, device=eng.device)
         finally:
             self.overlap = keep
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.pg)
@@ -127,7 +156,7 @@ class DiTSFRon:
             lo, hi = eng.block_ranges[l]
             self._comm.wait_event(evs[l])
             with torch.cuda.stream(self._comm):
-                dist.all_reduce(eng.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+                self._ar(eng.grads[lo:hi])
         nt = eng.n_trainable
         lay = eng.layout
         b_lo, b_hi = eng.block_ranges[0][0], eng.block_ranges[-1][1]
@@ -145,11 +174,11 @@ class DiTSFRon:
         ada_w = eng.grads[lay["ada_w"]:lay["ada_w"] + NM * D].view(NM, D)
         ops.gemm(dmod_all, sc_all, NM, D, self.world * B, a_t=True, b_t=True, epilogue=_lib.EPI_F32, c_f32=ada_w)
         # everything else outside the blocks (embedders, label table, adaLN bias, final layer) and the late biases
-        dist.all_reduce(eng.grads[:lay["ada_w"]], op=dist.ReduceOp.SUM, group=self.pg)
-        dist.all_reduce(eng.grads[lay["ada_b"]:b_lo], op=dist.ReduceOp.SUM, group=self.pg)
+        self._ar(eng.grads[:lay["ada_w"]])
+        self._ar(eng.grads[lay["ada_b"]:b_lo])
         if b_hi < nt:
-            dist.all_reduce(eng.grads[b_hi:nt], op=dist.ReduceOp.SUM, group=self.pg)
-        dist.all_reduce(eng.late_bias, op=dist.ReduceOp.SUM, group=self.pg)
+            self._ar(eng.grads[b_hi:nt])
+        self._ar(eng.late_bias.view(-1))
         main.wait_stream(self._comm)             # every block range is reduced: now the reduced late biases may land in it
         eng.scatter_late_bias()
 
@@ -191,7 +220,8 @@ class DiTSFRon:
             nt = e0.n_trainable
             e0.grads[:nt].add_(e1.grads[:nt])
             self.opt.g2 = None
-            dp.allreduce_flat_(e0.grads[:nt], self.bucket_elems, self.pg)
+            dp.allreduce_flat_(e0.grads[:nt], self.bucket_elems, self.pg, transport=self.grad_transport,
+                               scratch=self._scratch(min(nt, self.bucket_elems)))
         else:
             self.opt.g2 = e1.grads[:e1.n_trainable]
         return torch.cat([outs[0][0], outs[1][0]]), torch.cat([outs[0][1], outs[1][1]])
@@ -205,12 +235,7 @@ class DiTSFRon:
         if b.get("drop") is None:
             # the reference trains both stages under model.train(): LabelEmbedder.token_drop with p = 0.1 (models.py:78-87)
             b["drop"] = self.model._draw_drop(b["x0"].shape[0])
-        nc, nT = self.model.num_classes, self.diffusion.num_timesteps
-        t_safe = b["t"].clamp(0, nT - 1)
-        y_safe = y.clamp(0, nc - 1)
-        self.guard.note(2, (y_safe != y).any())
-        self.guard.note(3, (t_safe != b["t"]).any())
-        b["t"] = t_safe
+        y_safe, b["t"] = self.guard.check_inputs(y, b["t"], self.model.num_classes, self.diffusion.num_timesteps)
         return b, y_safe
 
     def _pass(self, batch, y, sign_alpha):
@@ -249,9 +274,7 @@ class DiTSFRon:
             sweep.ema_update(self.ema[nt:], eng.params[nt:], self.ema_decay, mode=1)         # frozen pos_embed (:60-62)
         # fail loud: a NaN / Inf loss or gradient norm would otherwise poison every weight through
         # the clip coefficient; counted on the device here, raised by the next poll()
-        self.guard.note(0, ~(torch.isfinite(mse_f).all() & torch.isfinite(vb_f).all() & torch.isfinite(mse_r).all()
-                             & torch.isfinite(vb_r).all()))
-        self.guard.note(1, ~torch.isfinite(self.opt.stats[0]))
+        self.guard.check_finite((mse_f, vb_f, mse_r, vb_r), self.opt.stats)
         self.iteration += 1
         self.guard.publish(self.iteration)
         return {"forget_mse": mse_f, "forget_vb": vb_f, "remain_mse": mse_r, "remain_vb": vb_r,

@@ -74,27 +74,35 @@ def bgemm(A, B, M, N, K, *, lda, ldb, a_t=False, b_t=False, batch=1, sa=0, sb=0,
     if ((a_t and b_t and K >= 2048) or small_rows) and c_f32 is not None and batch == 1 and batch2 == 1 and ldc == N:
         ws = _split_scratch(M * N, A if not isinstance(A, int) else (B if not isinstance(B, int) else None))
         if ws is not None:
-            d.split_ws, d.split_ws_slabs = ws.data_ptr(), ws.numel() // (M * N)
+            d.split_ws, d.split_ws_slabs = ws[0].data_ptr(), ws[1]
     elif a_t and b_t and c_bf16 is not None and batch * batch2 > 1 and K >= 1024 and M <= 128 and N <= 256 and not isinstance(A, int):
-        ws = _split_scratch(M * N * batch * batch2, A)               # head-batched single-tile products: split the contraction
-        d.split_ws, d.split_ws_slabs = ws.data_ptr(), ws.numel() // (M * N)
+        ws, nsl = _split_scratch(M * N * batch * batch2, A)          # head-batched single-tile products: split the contraction
+        d.split_ws, d.split_ws_slabs = ws.data_ptr(), nsl * batch * batch2
     check(_L().sfron_bgemm_bf16(ctypes.byref(d), stream_ptr()), "bgemm_bf16")
 
 
 _SPLIT_WS = {}
+_SPLIT_WS_RETIRED = []      # superseded scratch tensors stay alive: a captured HIP graph may hold their addresses
+_SPLIT_WS_FLOOR = 16 << 20  # floats (64 MB): the most any conv / Linear caller asks for (rows * n_out <= 2^23, >= 2 slabs)
 
 
 def _split_scratch(mn, like):
-    """fp32 slab scratch for split-K weight gradients (one per device, grown on demand; launches are stream-ordered)."""
+    """fp32 slab scratch for split-K products, one per (device, stream): allocated at its upper bound on first use, so a later,
+    larger request (another batch size, a Fisher pass, a second model) does not move it under a captured stage graph; if a
+    caller ever needs more, the old tensor is retired, not freed.  Keyed by stream because two streams may run split-K
+    products concurrently (launch order on ONE stream is what makes sharing safe)."""
     if like is None:
         return None
     dev = like.device
     want = min(64, max(2, (64 << 20) // (4 * mn))) * mn
-    ws = _SPLIT_WS.get(dev)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _SPLIT_WS.get(key)
     if ws is None or ws.numel() < want:
-        ws = torch.empty(want, dtype=torch.float32, device=dev)
-        _SPLIT_WS[dev] = ws
-    return ws
+        if ws is not None:
+            _SPLIT_WS_RETIRED.append(ws)
+        ws = torch.empty(max(want, _SPLIT_WS_FLOOR), dtype=torch.float32, device=dev)
+        _SPLIT_WS[key] = ws
+    return ws, want // mn         # slab count as the callers' split models were tuned with (not what the floor would allow)
 
 
 def _addr(t):
@@ -116,8 +124,8 @@ def _conv_desc(B, hs, ws, cs, ho, wo, n_out, taps=9, stride=1, pad=1, up=0, dil=
     d.out_bf16, d.out_f32, d.ld_out, d.accumulate = _addr(out_bf16), _addr(out_f32), ld_out or 0, int(accumulate)
     rows, t = B * ho * wo, out_f32 if out_f32 is not None else out_bf16
     if t is not None and not isinstance(t, int) and rows * n_out <= (1 << 23) and taps * cs >= 2048 and ld_out == n_out:
-        ws = _split_scratch(rows * n_out, t)                 # few output tiles, deep contraction: split-K slabs
-        d.split_ws, d.split_ws_slabs = ws.data_ptr(), ws.numel() // (rows * n_out)
+        ws, nsl = _split_scratch(rows * n_out, t)            # few output tiles, deep contraction: split-K slabs
+        d.split_ws, d.split_ws_slabs = ws.data_ptr(), nsl
         d._keep = ws
     return d
 
@@ -182,6 +190,7 @@ class _TapeNet(nn.Module):
                     dgr=torch.zeros(ci * 9 * cop, dtype=torch.bfloat16, device=dev) if ci % 8 == 0 else None)
         mx = max(v["cop"] * 9 * v["cip"] for v in self.conv3.values())
         self._dw = torch.empty(mx, dtype=torch.float32, device=dev)
+        self._dw_retired = []
         self._cs = torch.empty(64 * 16384, dtype=torch.float32, device=dev)      # column-sum partials (64 row chunks x widest output)
 
     def _register_views(self):
@@ -328,6 +337,7 @@ class _TapeNet(nn.Module):
                 nsl = _L().sfron_conv_wgrad_splits(ctypes.byref(wd))
                 slab = v["cop"] * 9 * v["cip"]
                 if self._dw.numel() < nsl * slab:
+                    self._dw_retired.append(self._dw)   # a captured stage graph may still write through the old address
                     self._dw = torch.empty(nsl * slab, dtype=torch.float32, device=dev)
                 check(_L().sfron_conv_wgrad(ctypes.byref(wd), ptr(dyb), v["cop"], ptr(src), ptr(self._dw), stream_ptr()), "conv_wgrad")
                 check(_L().sfron_conv_wgrad_scatter(ptr(self._dw), v["co"], v["ci"], 9, v["cip"], nsl, slab, self._g(name + ".weight"),
