@@ -400,6 +400,13 @@ int sfron_attn_fwd(const uint16_t* qkv, uint16_t* o, float* lse, int B, int T, i
  * Other T (multiples of 64): dQ kernel + dK/dV kernel (7 products). */
 int sfron_attn_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* delta_scratch,
                    uint16_t* dqkv, int B, int T, int H, int hd, void* stream);
+/* the same backward pass (one-kernel form only: sfron_attn_bwd_bias_supported(T)) that also leaves the qkv.bias gradient partials:
+ * bias_partials fp32 [B][3*H*hd], row b = sum over the T tokens of sample b of dqkv (fp32, before the bf16 rounding; fixed
+ * summation order, no atomics) -- sum the B rows with sfron_reduce_chunks.  Replaces a second pass over dqkv (sfron_colsum):
+ * the bias gradient of timm Attention.qkv (DiT/models.py:108,120 backward). */
+int sfron_attn_bwd_bias_supported(int T);
+int sfron_attn_bwd_bias(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, uint16_t* dqkv, float* bias_partials,
+                        int B, int T, int H, int hd, void* stream);
 
 /* test hook: 2 = always the two-kernel backward, 0 = default; returns the previous setting (process-wide, not thread-safe) */
 int sfron_attn_bwd_form(int form);

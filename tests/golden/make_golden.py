@@ -10,12 +10,16 @@ Outputs (small .npz files, inputs + expected outputs only -- no reference source
                       The three timm classes are NOT in /root/reference (un-vendored, un-pinned):
                       the harness supplies oracle.dit_ref.{PatchEmbed,Attention,Mlp} in their
                       place, so this fixture pins everything in models.py EXCEPT those classes.
+  dit_gpu.npz         the same reference class at a shape the HIP engine accepts (64 tokens, D 128): forward / backward (a number per
+                      gradient tensor: norm + a seeded random projection; ten tensors in full) and a 3-iteration SFR-on
+                      trajectory -- consumed by tests/test_gpu_reference_fixtures.py with no oracle in between
   dit_sfron_traj.npz  3 SFR-on iterations composed from reference functions in the order of
                       DiT/forget.py:256-322 (forget.py itself needs torchvision/diffusers/CUDA)
   ddpm_loss.npz       DDPM/functions/losses.py (simple, adaptive), cosine schedule, EMAHelper
   fisher_mask.npz     DiT/generate_mask.py main() run on synthetic Fisher files (0/0, int-0 entries)
   ddpm_model.npz      DDPM/models/diffusion.py Conditional_Model forward/backward (tiny config) + a 2-iteration SFR-on
                       trajectory composed from DDPM/functions/losses.py, models/ema.py in runners/diffusion.py order
+  ddpm_gpu.npz        the same class at ch 128 / 16 x 16 / attention over 64 tokens / dropout 0 with explicit keep masks, for the GPU tests
   compvis_export.npz  SD/train-scripts/convertModels.py create_unet_diffusers_config + convert_ldm_unet_checkpoint: the CompVis ->
                       diffusers key mapping of the v1 UNet and of a small config (names only; tensors pass through unchanged)
   sd_unet.npz         SD/ldm/modules/diffusionmodules/openaimodel.py UNetModel (+ attention.py, util.py): parameter spec of the
@@ -209,6 +213,123 @@ def gen_traj(ref_models, ref_diffusion):
                         **{k: np.array(v) for k, v in rec.items()}, **inputs)
 
 
+GPU_DIT = dict(input_size=16, patch_size=2, in_channels=4, hidden_size=128, depth=2, num_heads=2, num_classes=10)
+
+
+def gpu_dit_weights(seed=4242):
+    torch.manual_seed(seed)
+    m = dit_ref.DiT(**GPU_DIT)
+    dit_ref.randomize_zero_init(m, std=0.05, seed=seed + 1)
+    return m.state_dict()
+
+
+def _proj(t, name):
+    """<t, r> with r ~ N(0,1) seeded by the tensor's name: one number that pins a whole tensor (the test regenerates r)"""
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    return float((t.double().flatten() * torch.randn(t.numel(), generator=g, dtype=torch.float64)).sum())
+
+
+def gen_dit_gpu(ref_models, ref_diffusion):
+    """The reference DiT class at a shape the HIP engine takes (16 x 16 latents, patch 2 -> 64 tokens, D 128, 2 heads of 64, depth 2):
+    forward (eval / train with explicit drop ids), backward, and 3 SFR-on iterations in DiT/forget.py:256-322 order -- so that the
+    GPU tests compare the HIP path with numbers the REFERENCE produced, with no oracle in between (timm stand-ins as above)."""
+    from collections import OrderedDict
+    from copy import deepcopy
+    sd = gpu_dit_weights()
+    m = ref_models.DiT(**GPU_DIT)
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(311)
+    N = 4
+    x = torch.randn(N, 4, 16, 16, generator=g)
+    t = torch.tensor([3, 999, 421, 0])
+    y = torch.tensor([1, 9, 4, 3])
+    drop = torch.tensor([0, 1, 0, 0])
+    w = torch.randn(N, 8, 16, 16, generator=g) * 0.1
+
+    def fwd(model, x_, t_, y_, fd):
+        xx = model.x_embedder(x_) + model.pos_embed
+        c = model.t_embedder(t_) + model.y_embedder(y_, True, force_drop_ids=fd)
+        for blk in model.blocks:
+            xx = blk(xx, c)
+        return model.unpatchify(model.final_layer(xx, c))
+    m.eval()
+    out_eval = m(x, t, y)
+    out_drop = fwd(m, x, t, y, drop)
+    m.zero_grad()
+    (fwd(m, x, t, y, drop) * w).sum().backward()
+    names = [n for n, p in m.named_parameters() if p.grad is not None]
+    grads = {n: dict(m.named_parameters())[n].grad.clone() for n in names}
+    pick = ["x_embedder.proj.bias", "t_embedder.mlp.2.bias", "y_embedder.embedding_table.weight", "blocks.0.attn.qkv.bias",
+            "blocks.0.attn.proj.bias", "blocks.1.mlp.fc1.bias", "blocks.1.mlp.fc2.bias", "blocks.1.adaLN_modulation.1.bias",
+            "final_layer.linear.weight", "final_layer.adaLN_modulation.1.bias"]
+    out = dict(x=x.numpy(), t=t.numpy(), y=y.numpy(), drop=drop.numpy(), w=w.numpy(), out_eval=out_eval.detach().numpy(),
+               out_drop=out_drop.detach().numpy(), param_names=np.array(list(sd.keys())),
+               param_sums=np.array([float(v.double().sum()) for v in sd.values()]),
+               grad_names=np.array(names), grad_norms=np.array([float(grads[n].double().norm()) for n in names]),
+               grad_proj=np.array([_proj(grads[n], n) for n in names]))
+    out.update({"grad::" + n: grads[n].numpy() for n in pick})
+    # ---- 3 SFR-on iterations (ga, mask, clip, AdamW x2, EMA 0.9) at batch 4
+    model = ref_models.DiT(**GPU_DIT)
+    model.load_state_dict(sd)
+    ema = deepcopy(model)
+    diffusion = ref_diffusion.create_diffusion(timestep_respacing="")
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0)
+    gm = torch.Generator().manual_seed(5)
+    mask = {"module." + n: (torch.rand(p.shape, generator=gm) < 0.5) for n, p in model.named_parameters() if p.requires_grad}
+    model.train()
+    forget_alpha, grad_clip = 0.5, 1.0
+    g2 = torch.Generator().manual_seed(2025)
+    rec = {"forget_loss": [], "remain_loss": [], "forget_mse": [], "remain_mse": [], "gnorm": []}
+    p0 = {n: p.detach().clone() for n, p in model.named_parameters()}
+    for step in range(3):
+        batch = {}
+        for stream in ("forget", "remain"):
+            batch[stream] = dict(x0=torch.randn(N, 4, 16, 16, generator=g2) * 0.8, t=torch.randint(0, 1000, (N,), generator=g2),
+                                 noise=torch.randn(N, 4, 16, 16, generator=g2),
+                                 y=(torch.full((N,), 3) if stream == "forget" else torch.randint(0, 10, (N,), generator=g2)),
+                                 drop=(torch.rand(N, generator=g2) < 0.25).long())
+            for k, v in batch[stream].items():
+                out[f"s{step}_{stream}_{k}"] = v.numpy()
+
+        def run(b):
+            return diffusion.training_losses(lambda xx, ts, y: fwd(model, xx, ts, y, b["drop"]), b["x0"], b["t"], dict(y=b["y"]),
+                                             noise=b["noise"])
+        tf = run(batch["forget"])
+        ori_forget = -tf["loss"].mean()
+        opt.zero_grad()
+        (forget_alpha * ori_forget).backward()
+        for name, p in model.named_parameters():
+            if p.grad is not None:
+                p.grad *= mask["module." + name]
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip)
+        opt.step()
+        tr = run(batch["remain"])
+        ori_remain = tr["loss"].mean()
+        opt.zero_grad()
+        ori_remain.backward()
+        opt.step()
+        with torch.no_grad():
+            ep, mp = OrderedDict(ema.named_parameters()), OrderedDict(model.named_parameters())
+            for name, p in mp.items():
+                ep[name].mul_(0.9).add_(p.data, alpha=1 - 0.9)
+        rec["forget_loss"].append(ori_forget.item()); rec["remain_loss"].append(ori_remain.item())
+        rec["forget_mse"].append(float(tf["mse"].mean())); rec["remain_mse"].append(float(tr["mse"].mean()))
+        rec["gnorm"].append(float(gn))
+    tn = [n for n, p in model.named_parameters() if p.requires_grad]
+    fin = dict(model.named_parameters())
+    out.update(traj_names=np.array(tn), traj_lr=np.array(1e-3), traj_forget_alpha=np.array(forget_alpha), traj_ema_decay=np.array(0.9),
+               traj_mask_seed=np.array(5),
+               traj_update_norms=np.array([float((fin[n].detach() - p0[n]).double().norm()) for n in tn]),
+               traj_update_proj=np.array([_proj(fin[n].detach() - p0[n], n) for n in tn]),
+               traj_final_qkv1_bias=fin["blocks.1.attn.qkv.bias"].detach().numpy(),
+               traj_final_fc1_0_bias=fin["blocks.0.mlp.fc1.bias"].detach().numpy(),
+               traj_final_ema_proj1_bias=dict(ema.named_parameters())["blocks.1.attn.proj.bias"].detach().numpy(),
+               **{"traj_" + k: np.array(v) for k, v in rec.items()})
+    np.savez_compressed(os.path.join(HERE, "dit_gpu.npz"), **out)
+    print("dit_gpu.npz:", len(out), "entries;", "traj", rec)
+
+
 def gen_ddpm():
     losses = _load("ref_ddpm_losses", os.path.join(REF, "DDPM", "functions", "losses.py"))
     ema_mod = _load("ref_ddpm_ema", os.path.join(REF, "DDPM", "models", "ema.py"))
@@ -375,6 +496,102 @@ def gen_ddpm_model():
                         **{"grad::" + n: grads[n].numpy() for n in pick}, **inputs)
 
 
+DDPM_GPU = dict(ch=128, out_ch=3, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(8,), dropout=0.0, in_channels=3,
+                resolution=16, resamp_with_conv=True, n_classes=10, cond_drop_prob=0.1)
+
+
+def gen_ddpm_gpu():
+    """Conditional_Model at a size the HIP convolution tiles take (ch 128, 16 x 16 images, attention at 8 x 8 = 64 tokens, dropout 0
+    so that the only random draw is the classifier-free keep mask, stored explicitly): test-mode forward, gradients of every tensor
+    (norm + seeded projection; seven in full) and 2 SFR-on iterations in DDPM/runners/diffusion.py:1075-1180 order -- for
+    tests/test_gpu_reference_fixtures.py (HIP vs these numbers, no oracle in between)."""
+    from oracle import ddpm_ref
+    ref_mod = _load("ref_ddpm_model_g", os.path.join(REF, "DDPM", "models", "diffusion.py"))
+    losses = _load("ref_ddpm_losses_g", os.path.join(REF, "DDPM", "functions", "losses.py"))
+    ema_mod = _load("ref_ddpm_ema_g", os.path.join(REF, "DDPM", "models", "ema.py"))
+    torch.manual_seed(78)
+    sd = ddpm_ref.ConditionalUNet(**DDPM_GPU).state_dict()
+    model = ref_mod.Conditional_Model(ddpm_ref_config(DDPM_GPU))
+    model.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(22)
+    N, S = 4, 16
+    x = torch.rand(N, 3, S, S, generator=g) * 2 - 1
+    t = torch.tensor([0, 999, 17, 500])
+    c = torch.tensor([3, 3, 1, 9])
+    w = torch.randn(N, 3, S, S, generator=g) * 0.1
+    model.eval()
+    out_test = model(x, t.float(), c, mode="test", cond_scale=2.0)
+    model.train()
+    model.zero_grad()
+    out_train = model(x, t.float(), c, mode="train", cond_drop_prob=0.0)
+    (out_train * w).sum().backward()
+    names = [n for n, p in model.named_parameters() if p.grad is not None]
+    grads = {n: dict(model.named_parameters())[n].grad.clone() for n in names}
+    pick = ["conv_in.weight", "down.0.block.0.temb_cemb_proj.bias", "down.1.attn.0.q.bias", "mid.attn_1.proj_out.bias",
+            "up.0.block.1.nin_shortcut.bias", "classes_emb.weight", "norm_out.weight"]
+    out = dict(x=x.numpy(), t=t.numpy(), c=c.numpy(), w=w.numpy(), keys=np.array(list(sd.keys())),
+               param_sums=np.array([float(v.double().sum()) for v in sd.values()]),
+               out_test_scale2=out_test.detach().numpy(), out_train_nodrop=out_train.detach().numpy(),
+               grad_names=np.array(names), grad_norms=np.array([float(grads[n].double().norm()) for n in names]),
+               grad_proj=np.array([_proj(grads[n], n) for n in names]))
+    out.update({"grad::" + n: grads[n].numpy() for n in pick})
+    # ---- 2 SFR-on iterations: adaga (lambd 0.5), cosine alpha from 10, mask, clip 1.0 in both stages, Adam 1e-3, EMAHelper(1e-4)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), amsgrad=False, eps=1e-8)
+    helper = ema_mod.EMAHelper(mu=1e-4)
+    helper.register(model)
+    b = torch.from_numpy(np.linspace(1e-4, 2e-2, 1000, dtype=np.float64)).float()
+    gm = torch.Generator().manual_seed(8)
+    mask = {n: (torch.rand(p.shape, generator=gm) < 0.5) for n, p in model.named_parameters()}
+    p0 = {n: p.detach().clone() for n, p in model.named_parameters()}
+    rec = {"forget": [], "remain": [], "alpha": []}
+    n_iters, forget_alpha = 2, 10.0
+    for step in range(n_iters):
+        alpha = losses.cosine_lr_scheduler(forget_alpha, step, n_iters)
+        fx = torch.rand(N, 3, S, S, generator=g) * 2 - 1
+        fe = torch.randn(N, 3, S, S, generator=g)
+        ft = torch.randint(0, 1000, (N // 2 + 1,), generator=g)
+        ft = torch.cat([ft, 1000 - ft - 1], dim=0)[:N]
+        fc = torch.zeros(N, dtype=torch.long)
+        rx = torch.rand(N, 3, S, S, generator=g) * 2 - 1
+        re_ = torch.randn(N, 3, S, S, generator=g)
+        rt = torch.randint(0, 1000, (N // 2 + 1,), generator=g)
+        rt = torch.cat([rt, 1000 - rt - 1], dim=0)[:N]
+        rc = torch.randint(1, 10, (N,), generator=g)
+        # the keep masks the reference's prob_mask_like((b,), 0.9) will draw from these seeds (the only RNG use with dropout 0)
+        torch.manual_seed(200 + step)
+        fkeep = torch.zeros((N,)).float().uniform_(0, 1) < 0.9
+        torch.manual_seed(300 + step)
+        rkeep = torch.zeros((N,)).float().uniform_(0, 1) < 0.9
+        for k, v in dict(fx=fx, fe=fe, ft=ft, fc=fc, rx=rx, re=re_, rt=rt, rc=rc, fkeep=fkeep, rkeep=rkeep).items():
+            out[f"s{step}_{k}"] = v.numpy()
+        torch.manual_seed(200 + step)
+        ori_forget = -losses.adaptive_loss(losses.loss_registry_conditional["simple"], model, fx, ft, fc, fe, b, lambd=0.5)
+        opt.zero_grad()
+        (alpha * ori_forget).backward()
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                p.grad *= mask[n]
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        torch.manual_seed(300 + step)
+        ori_remain = losses.loss_registry_conditional["simple"](model, rx, rt, rc, re_, b)
+        opt.zero_grad()
+        (1.0 * ori_remain).backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        helper.update(model)
+        rec["forget"].append(ori_forget.item()); rec["remain"].append(ori_remain.item()); rec["alpha"].append(alpha)
+    fin = dict(model.named_parameters())
+    tn = list(fin)
+    out.update(traj_forget=np.array(rec["forget"]), traj_remain=np.array(rec["remain"]), traj_alpha=np.array(rec["alpha"]),
+               traj_names=np.array(tn), traj_update_norms=np.array([float((fin[n].detach() - p0[n]).double().norm()) for n in tn]),
+               traj_update_proj=np.array([_proj(fin[n].detach() - p0[n], n) for n in tn]),
+               traj_final_conv_out_bias=model.conv_out.bias.detach().numpy(),
+               traj_final_shadow_norm_out=helper.shadow["norm_out.weight"].numpy())
+    np.savez_compressed(os.path.join(HERE, "ddpm_gpu.npz"), **out)
+    print("ddpm_gpu.npz:", len(out), "entries; traj", rec)
+
+
 def gen_sampling(ref_models, ref_diffusion):
     """Sampling path: space_timesteps / respaced tables, p_sample_loop on a stub model (clip on and off), and
     the DiT's forward_with_cfg driven through p_sample_loop as DiT/forget.py:114-145 does (clip_denoised=False, cfg 4.0)."""
@@ -398,6 +615,20 @@ def gen_sampling(ref_models, ref_diffusion):
     for clip in (True, False):
         torch.manual_seed(77)
         out[f"stub_clip{int(clip)}"] = d.p_sample_loop(stub, z.shape, z, clip_denoised=clip, model_kwargs={}, device="cpu").numpy()
+    # a CONTRACTIVE stub for the un-clamped loop (the linear stub above grows to ~1e36 without the clamp -- NaN == NaN pins nothing):
+    # eps-hat = 0.9 x / sqrt(1 - abar_t) + a small channel mix, i.e. close to the exact eps of data concentrated near 0, so that
+    # pred_xstart = sqrt(1/abar) x - sqrt(1/abar - 1) eps-hat stays O(|x|) at every step; the variance half as before
+    abar1000 = np.cumprod(1.0 - np.linspace(1e-4, 2e-2, 1000, dtype=np.float64))
+    s1m = torch.tensor(np.sqrt(1.0 - abar1000), dtype=torch.float32)
+    out["abar1000"] = abar1000
+
+    def stub2(x, ts, **kw):
+        lin = torch.einsum("oc,nchw->nohw", A, x)
+        eps = 0.9 * x / s1m[ts].view(-1, 1, 1, 1) + 0.02 * lin[:, :C]
+        return torch.cat([eps, lin[:, C:] * torch.cos(ts.float() / 300.0).view(-1, 1, 1, 1) + 0.05], dim=1)
+    torch.manual_seed(77)
+    out["stub2_clip0"] = d.p_sample_loop(stub2, z.shape, z, clip_denoised=False, model_kwargs={}, device="cpu").numpy()
+    assert np.isfinite(out["stub2_clip0"]).all() and np.abs(out["stub2_clip0"]).max() < 1e3, np.abs(out["stub2_clip0"]).max()
     one = d.p_sample(stub, z, torch.tensor([0, 9, 3, 0]), clip_denoised=False, model_kwargs={})
     torch.manual_seed(5)
     one = d.p_sample(stub, z, torch.tensor([0, 9, 3, 0]), clip_denoised=False, model_kwargs={})
@@ -613,17 +844,35 @@ def gen_compvis_export():
 
 
 if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None, help="regenerate just these fixtures (e.g. dit_gpu sampling); default: all")
+    only = ap.parse_args().only
+    want = lambda k: only is None or k in only
     torch.set_num_threads(4)
     ref_diffusion = import_ref_dit_diffusion()
-    gen_diffusion(ref_diffusion)
     ref_models = import_ref_dit_models()
-    gen_model(ref_models)
-    gen_traj(ref_models, ref_diffusion)
-    gen_ddpm()
-    gen_mask()
-    gen_ddpm_model()
-    gen_sampling(ref_models, ref_diffusion)
-    gen_ddpm_sampler()
-    gen_sd()
-    gen_compvis_export()
+    if want("diffusion"):
+        gen_diffusion(ref_diffusion)
+    if want("model"):
+        gen_model(ref_models)
+    if want("traj"):
+        gen_traj(ref_models, ref_diffusion)
+    if want("dit_gpu"):
+        gen_dit_gpu(ref_models, ref_diffusion)
+    if want("ddpm"):
+        gen_ddpm()
+    if want("mask"):
+        gen_mask()
+    if want("ddpm_model"):
+        gen_ddpm_model()
+    if want("ddpm_gpu"):
+        gen_ddpm_gpu()
+    if want("sampling"):
+        gen_sampling(ref_models, ref_diffusion)
+    if want("ddpm_sampler"):
+        gen_ddpm_sampler()
+    if want("sd"):
+        gen_sd()
+    if want("compvis_export"):
+        gen_compvis_export()
     print("golden vectors written to", HERE)

@@ -198,3 +198,35 @@ def test_attention_backward_fused_vs_two_kernel_and_torch(B, T, H, hd):
             assert e < 2e-2, (name, nm, e)
     # the two forms round P and dS to bf16 at the same points: they agree far inside the bound against fp32
     assert ((fused.float() - two.float()).norm() / two.float().norm()).item() < 6e-3
+
+
+@pytest.mark.parametrize("B,T,H,hd", [(2, 256, 2, 64), (3, 256, 3, 72), (2, 128, 2, 72), (2, 256, 4, 40), (32, 256, 16, 72)])
+def test_attention_backward_with_qkv_bias_partials(B, T, H, hd):
+    """sfron_attn_bwd_bias: the fused backward also leaves one partial row per sample of the qkv.bias gradient (token sums of
+    dQ | dK | dV in fp32 before the bf16 rounding).  dqkv is bit-identical to the plain call; the rows match the column sums of
+    the fp32 autograd gradient; two runs agree bit for bit (fixed order, no atomics)."""
+    from sfron import ops, _lib
+    assert _lib.lib().sfron_attn_bwd_bias_supported(T) == 1 and _lib.lib().sfron_attn_bwd_bias_supported(192) == 0
+    gen = torch.Generator().manual_seed(T * 11 + H + hd)
+    D = H * hd
+    qd = (torch.randn(B * T, 3 * D, generator=gen) * 1.2).to(torch.bfloat16).to(DEV)
+    dd = (torch.randn(B * T, D, generator=gen) * 0.2 + 0.05).to(torch.bfloat16).to(DEV)      # non-zero mean: sums do not cancel
+    o, lse = ops.attn_fwd(qd, B, T, H, hd)
+    plain = ops.attn_bwd(qd, o, dd, lse, B, T, H, hd)
+    dqkv, part = ops.attn_bwd_bias(qd, o, dd, lse, B, T, H, hd)
+    dqkv2, part2 = ops.attn_bwd_bias(qd, o, dd, lse, B, T, H, hd)
+    assert torch.equal(dqkv, plain) and torch.equal(dqkv, dqkv2) and torch.equal(part, part2)
+    x = qd.float().requires_grad_(True)
+    q, k, v = x.view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4).unbind(0)
+    att = ((q * hd ** -0.5) @ k.transpose(-2, -1)).softmax(-1)
+    (att @ v).transpose(1, 2).reshape(B * T, D).backward(dd.float())
+    want = x.grad.view(B, T, 3 * D).sum(1)
+    assert torch.isfinite(part).all()
+    for w, nm in ((0, "dQ"), (1, "dK"), (2, "dV")):
+        a, b = part[:, w * D:(w + 1) * D], want[:, w * D:(w + 1) * D]
+        # dV sums do not cancel (tight); dQ / dK rows sum to ~0 over the softmax, so they are compared on the scale of the column norms
+        scale = x.grad.view(B, T, 3 * D)[:, :, w * D:(w + 1) * D].abs().sum(1)
+        assert ((a - b).abs() <= 2e-2 * scale + 1e-6).all(), (nm, ((a - b).abs() / (scale + 1e-9)).max().item())
+    # against the column sums of the bf16 output itself (what the old column-sum launch formed): same numbers up to the rounding
+    old = plain.float().view(B, T, 3 * D).sum(1)
+    assert ((part - old).abs() <= 2.0 ** -8 * plain.float().abs().view(B, T, 3 * D).sum(1) + 1e-6).all()

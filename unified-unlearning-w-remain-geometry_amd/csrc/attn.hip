@@ -637,7 +637,8 @@ struct GroupDma {
 template <int HDP, int KS, int NDT, int KT>
 __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict__ qkv, const __bf16* __restrict__ o,
                                                         const __bf16* __restrict__ d_o, const float* __restrict__ lse,
-                                                        __bf16* __restrict__ dqkv, int H, int hd, float scale) {
+                                                        __bf16* __restrict__ dqkv, int H, int hd, float scale,
+                                                        float* __restrict__ bias_part) {
   constexpr int T = FNW * 16 * KT, NCH = T / 64, IMG = 64 * HDP;
   constexpr int ND0 = (NDT + 1) / 2, ND1 = NDT - ND0;       // d-tiles of the two wave groups in the dQ phase
   extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
@@ -646,6 +647,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
   __bf16* const imgS = imgK + NCH * IMG;                     // [T keys][64 queries]
   float* const s_lse = reinterpret_cast<float*>(imgS + T * 64);
   float* const s_del = s_lse + T;
+  float* const s_dq = s_del + T;                             // [FNW][ND0 * 16]: token sums of this wave's dQ columns (qkv.bias partials)
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // neighbouring heads of one sample read neighbouring 144-B column slices of the same rows: keep them on one XCD's L2
@@ -709,6 +711,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
     for (int ks = 0; ks < KS; ++ks) fv[ki][ks] = frag_rows_global(base + 2 * D, ld, k0 + 16 * ki, ks, hd, lane);
   // -lse * log2(e), and delta from the operands fetched at the top
   for (int i = tid; i < T; i += FNT) s_lse[i] = -lse[(size_t)bh * T + i] * LOG2E;
+  if (bias_part) for (int i = tid; i < FNW * ND0 * 16; i += FNT) s_dq[i] = 0.f;
   {
     float dsum = 0.f;
 #pragma unroll
@@ -882,6 +885,24 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
           *reinterpret_cast<bf16x4*>(row + d) = ov;
         }
       }
+      if (bias_part) {
+        // qkv.bias gradient, Q part: sum of this chunk's 16 query rows (butterfly over lane & 15, all lanes active), added by
+        // lane 16 g of the wave to its own LDS row -- no other lane or wave touches those words: no atomics, fixed order
+#pragma unroll
+        for (int i = 0; i < ND0; ++i) {
+          f32x4 v = dq[i];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float x = v[j];
+            x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+            v[j] = x;
+          }
+          if ((lane & 15) == 0) {
+            f32x4* acc = reinterpret_cast<f32x4*>(s_dq + wave * (ND0 * 16) + i * 16 + 4 * g);
+            *acc = *acc + v;
+          }
+        }
+      }
     }
   }
 #pragma unroll
@@ -900,14 +921,53 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
       }
     }
   }
+  if (bias_part) {
+    // K / V parts: this wave's 16 KT keys summed per column, then the eight waves meet in LDS.  The Q / dO ring is free: its last
+    // reads were before the loop's mid-iteration barrier, which every wave has passed.
+    float* const s_kv = reinterpret_cast<float*>(ringb);           // [FNW][2][NDT * 16]
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      f32x4 sk = dk[0][dt], sv = dv[0][dt];
+#pragma unroll
+      for (int ki = 1; ki < KT; ++ki) { sk += dk[ki][dt]; sv += dv[ki][dt]; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = sk[j], y = sv[j];
+        x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+        y += __shfl_xor(y, 1, 64); y += __shfl_xor(y, 2, 64); y += __shfl_xor(y, 4, 64); y += __shfl_xor(y, 8, 64);
+        sk[j] = x; sv[j] = y;
+      }
+      if ((lane & 15) == 0) {
+        *reinterpret_cast<f32x4*>(s_kv + (wave * 2 + 0) * (NDT * 16) + dt * 16 + 4 * g) = sk;
+        *reinterpret_cast<f32x4*>(s_kv + (wave * 2 + 1) * (NDT * 16) + dt * 16 + 4 * g) = sv;
+      }
+    }
+    __syncthreads();
+    float* const out = bias_part + (size_t)b * ld + h * hd;          // row b of [B][3 D]
+    for (int e = tid; e < 3 * hd; e += FNT) {
+      const int which = e / hd, d = e % hd;
+      float x;
+      if (which == 0) {                                              // waves 4 dgrp + qi hold d-tiles dt0(dgrp) .. of query tile qi
+        const int dt = d >> 4, grp = dt >= ND0 ? 1 : 0, i = dt - (grp ? ND0 : 0);
+        const float* p = s_dq + (grp * 4) * (ND0 * 16) + i * 16 + (d & 15);
+        x = ((p[0] + p[ND0 * 16]) + p[2 * ND0 * 16]) + p[3 * ND0 * 16];
+      } else {
+        const float* p = s_kv + (which - 1) * (NDT * 16) + d;
+        x = p[0];
+#pragma unroll
+        for (int w2 = 1; w2 < FNW; ++w2) x += p[w2 * 2 * (NDT * 16)];
+      }
+      out[which * D + d] = x;
+    }
+  }
 }
 
-template __global__ void k_attn_bwd_fused<64, 2, 4, 2>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float);
-template __global__ void k_attn_bwd_fused<64, 2, 3, 2>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float);
-template __global__ void k_attn_bwd_fused<64, 2, 3, 1>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float);
-template __global__ void k_attn_bwd_fused<96, 3, 5, 2>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float);
-template __global__ void k_attn_bwd_fused<64, 2, 4, 1>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float);
-template __global__ void k_attn_bwd_fused<96, 3, 5, 1>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float);
+template __global__ void k_attn_bwd_fused<64, 2, 4, 2>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float, float*);
+template __global__ void k_attn_bwd_fused<64, 2, 3, 2>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float, float*);
+template __global__ void k_attn_bwd_fused<64, 2, 3, 1>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float, float*);
+template __global__ void k_attn_bwd_fused<96, 3, 5, 2>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float, float*);
+template __global__ void k_attn_bwd_fused<64, 2, 4, 1>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float, float*);
+template __global__ void k_attn_bwd_fused<96, 3, 5, 1>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float, float*);
 
 #define SFRON_INST_ATTN(HDP, KS, NDT)                                                                              \
   template __global__ void k_attn_fwd<HDP, KS, NDT, 1>(const __bf16*, __bf16*, float*, int, int, int, float);      \
@@ -948,21 +1008,23 @@ int launch_fwd(const __bf16* qkv, __bf16* o, float* lse, int B, int T, int H, in
 }
 template <int HDP, int KS, int NDT, int KT>
 int launch_bwd_fused(const __bf16* qkv, const __bf16* o, const __bf16* d_o, const float* lse, __bf16* dqkv, int B, int H, int hd,
-                     float scale, hipStream_t s) {
+                     float scale, float* bias_part, hipStream_t s) {
   constexpr int T = FNW * 16 * KT;
-  const size_t lds = (size_t)(NSLOT * 2 * 64 * HDP + T * HDP + T * 64) * sizeof(__bf16) + 2 * T * sizeof(float);
+  const size_t lds = (size_t)(NSLOT * 2 * 64 * HDP + T * HDP + T * 64) * sizeof(__bf16) + 2 * T * sizeof(float) +
+                     FNW * ((NDT + 1) / 2) * 16 * sizeof(float);
   int rc = set_lds(&k_attn_bwd_fused<HDP, KS, NDT, KT>, lds); if (rc) return rc;
-  hipLaunchKernelGGL((k_attn_bwd_fused<HDP, KS, NDT, KT>), dim3(B * H), dim3(FNT), lds, s, qkv, o, d_o, lse, dqkv, H, hd, scale);
+  hipLaunchKernelGGL((k_attn_bwd_fused<HDP, KS, NDT, KT>), dim3(B * H), dim3(FNT), lds, s, qkv, o, d_o, lse, dqkv, H, hd, scale, bias_part);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
 }
 
 template <int HDP, int KS, int NDT>
 int launch_bwd(const __bf16* qkv, const __bf16* o, const __bf16* d_o, const float* lse, float* delta, __bf16* dqkv, int B,
-               int T, int H, int hd, float scale, hipStream_t s) {
+               int T, int H, int hd, float scale, hipStream_t s, float* bias_part = nullptr) {
   // one workgroup per (batch, head) with the whole sequence behind it: T = 256 (DiT-XL/2 ... DiT-S/2 at 256 px) and T = 128
-  if (T == 256 && g_bwd_form != 2) return launch_bwd_fused<HDP, KS, NDT, 2>(qkv, o, d_o, lse, dqkv, B, H, hd, scale, s);
-  if (T == 128 && g_bwd_form != 2) return launch_bwd_fused<HDP, KS, NDT, 1>(qkv, o, d_o, lse, dqkv, B, H, hd, scale, s);
+  if (T == 256 && g_bwd_form != 2) return launch_bwd_fused<HDP, KS, NDT, 2>(qkv, o, d_o, lse, dqkv, B, H, hd, scale, bias_part, s);
+  if (T == 128 && g_bwd_form != 2) return launch_bwd_fused<HDP, KS, NDT, 1>(qkv, o, d_o, lse, dqkv, B, H, hd, scale, bias_part, s);
+  if (bias_part) return SFRON_ERR_UNSUPPORTED;
   const size_t lds = lds_bytes<HDP>(0), lds2 = lds_bytes<HDP>(2 * T);
   if (T % 128 == 0) {
     int rc = set_lds(&k_attn_bwd_dq<HDP, KS, NDT, 2>, lds); if (rc) return rc;
@@ -1011,6 +1073,25 @@ int sfron_attn_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, 
     return launch_bwd<64, 2, 4>((const __bf16*)qkv, (const __bf16*)o, (const __bf16*)d_o, lse, delta_scratch, (__bf16*)dqkv, B, T, H, hd, scale, s);
   if (hd <= 96)
     return launch_bwd<96, 3, 5>((const __bf16*)qkv, (const __bf16*)o, (const __bf16*)d_o, lse, delta_scratch, (__bf16*)dqkv, B, T, H, hd, scale, s);
+  return SFRON_ERR_UNSUPPORTED;
+}
+
+/* 1 when sfron_attn_bwd_bias accepts this sequence length (the one-kernel backward: T = 128 / 256) */
+int sfron_attn_bwd_bias_supported(int T) { return (T == 256 || T == 128) && g_bwd_form != 2 ? 1 : 0; }
+
+int sfron_attn_bwd_bias(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, uint16_t* dqkv, float* bias_partials,
+                        int B, int T, int H, int hd, void* stream) {
+  SFRON_CHECK_ARG(qkv && o && d_o && lse && dqkv && bias_partials && B > 0 && H > 0 && T > 0);
+  SFRON_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dqkv) & 15) == 0);
+  if (!sfron_attn_bwd_bias_supported(T) || hd % 8 != 0 || hd < 8) return SFRON_ERR_UNSUPPORTED;
+  const float scale = 1.0f / sqrtf((float)hd);
+  hipStream_t s = (hipStream_t)stream;
+  if (hd <= 48)
+    return launch_bwd<64, 2, 3>((const __bf16*)qkv, (const __bf16*)o, (const __bf16*)d_o, lse, nullptr, (__bf16*)dqkv, B, T, H, hd, scale, s, bias_partials);
+  if (hd <= 64)
+    return launch_bwd<64, 2, 4>((const __bf16*)qkv, (const __bf16*)o, (const __bf16*)d_o, lse, nullptr, (__bf16*)dqkv, B, T, H, hd, scale, s, bias_partials);
+  if (hd <= 96)
+    return launch_bwd<96, 3, 5>((const __bf16*)qkv, (const __bf16*)o, (const __bf16*)d_o, lse, nullptr, (__bf16*)dqkv, B, T, H, hd, scale, s, bias_partials);
   return SFRON_ERR_UNSUPPORTED;
 }
 

@@ -74,7 +74,7 @@ struct Workspace {
   __bf16* xmodf;
   float* tok;
   // backward temporaries
-  float *dx, *dmod, *d_sc, *d_c, *d_h1s, *delta, *part, *csum, *csum2, *slabs, *wslab, *dysum, *bpart;
+  float *dx, *dmod, *d_sc, *d_c, *d_h1s, *delta, *part, *csum, *csum2, *slabs, *wslab, *dysum, *bpart, *bpart_qkv;
   __bf16 *d_tok, *d_xmod, *d_o, *dmod_bf, *d_c_bf, *d_h1_bf, *dx_bf;
   __bf16 *d_br[2], *d_br2[2], *d_hpre[2], *dqkv[2];   // read by the side stream: double-buffered by block parity so the
                                                        // dgrad chain may run one block ahead of the weight gradients
@@ -133,7 +133,8 @@ inline Workspace make_ws(const Dims& d, char* base) {
   w.dysum = (float*)take((L + 1) * 2 * B * D * 4);                       // [L][proj|fc2][B][D] token sums of dy (gated bias grads)
   // per-tile-row partials of the fc1 / qkv bias gradients, written by the kernels that PRODUCE d_hpre / dqkv (double-buffered
   // by block parity like those tensors: the side stream reduces them one block behind)
-  w.bpart = (float*)take(2 * (size_t)((M + 255) / 256) * (size_t)(d.F > 3 * d.D ? d.F : 3 * d.D) * 4);
+  w.bpart = (float*)take(2 * (size_t)((M + 255) / 256) * (size_t)d.F * 4);        // [parity][M / 256][F]
+  w.bpart_qkv = (float*)take(2 * B * 3 * D * 4);                                  // [parity][B][3 D]
   w.d_tok = (__bf16*)take(M * (size_t)d.Po * 2);
   for (int i = 0; i < 2; ++i) {
     w.d_br[i] = (__bf16*)take(M * D * 2); w.d_br2[i] = (__bf16*)take(M * D * 2);
@@ -190,7 +191,7 @@ int64_t sfron_dit_workspace_bytes(const sfron_dit_cfg* cfg) {
 }
 
 // SFRON_ABLATE (debug / A-B measurement only): bit 0 = run LN backward and gate backward as separate kernels,
-// bit 1 = split-K in the block weight gradients (off by default), bit 2 = side stream at the lowest priority, bit 3 = fc2 weight gradient after the fc2 dgrad, bit 4 = no split-K for the two small-output weight gradients, bit 5 = bias row sums inside the weight-gradient GEMM, bit 6 = fc1 bias gradient by a separate column-sum launch
+// bit 1 = split-K in the block weight gradients (off by default), bit 2 = side stream at the lowest priority, bit 3 = fc2 weight gradient after the fc2 dgrad, bit 4 = no split-K for the two small-output weight gradients, bit 5 = bias row sums inside the weight-gradient GEMM, bit 6 = fc1 bias gradient by a separate column-sum launch, bit 7 = qkv bias gradient likewise
 static int ablate_mask() {
 #ifdef SFRON_DEBUG_KNOBS
   static const int m = [] { const char* e = getenv("SFRON_ABLATE"); return e ? atoi(e) : 0; }();
@@ -438,6 +439,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
   };
   if (ax) { (void)hipEventRecord(ax->done, hs); (void)hipStreamWaitEvent(ax->side, ax->done, 0); }   // side starts after everything before us
   const int fc1_rows = (ablate_mask() & 64) ? 0 : sfron_gemm_dgelu_colpart_rows(M, d.F, D);    // 0: shape not on a 256-row pipelined tile -> column-sum launch
+  const bool qkv_fused = !(ablate_mask() & 128) && sfron_attn_bwd_bias_supported(T);           // one-kernel attention backward (T = 128 / 256)
 
   // ---- final layer
   RUN(sfron_patchify(d_out, B, d.Co, d.S, d.S, d.p, 1, (uint16_t*)w.d_tok, d.Po, stream));
@@ -524,10 +526,21 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     g.c_bf16 = (uint16_t*)w.d_o; g.ldc_bf16 = D;
     RUN(sfron_gemm_bf16(&g, stream));
     before_overwrite(3, l);
-    RUN(sfron_attn_bwd((const uint16_t*)qkv, (const uint16_t*)o, (const uint16_t*)w.d_o, w.lse + (size_t)l * B * d.H * T,
-                       w.delta, (uint16_t*)w.dqkv[pl], B, T, d.H, d.hd, stream));
-    produced(3);
-    RUN(wgrad_side(w.dqkv[pl], xmod1, 3 * D, D, grads + pb + P.o_qkv_w, grads + pb + P.o_qkv_b));
+    if (qkv_fused) {
+      // qkv.bias gradient = token sums of dqkv: the attention backward kernel leaves one partial row per sample (it holds dQ / dK / dV
+      // of a whole (sample, head) in registers); the side stream adds the B rows (was: a second 57 MB pass over dqkv per block)
+      float* const bp = w.bpart_qkv + (size_t)pl * B * 3 * D;
+      RUN(sfron_attn_bwd_bias((const uint16_t*)qkv, (const uint16_t*)o, (const uint16_t*)w.d_o, w.lse + (size_t)l * B * d.H * T,
+                              (uint16_t*)w.dqkv[pl], bp, B, T, d.H, d.hd, stream));
+      produced(3);
+      RUN(sfron_reduce_chunks(bp, 1, B, 3 * D, grads + pb + P.o_qkv_b, 3 * D, 0, side));
+      RUN(wgrad_side(w.dqkv[pl], xmod1, 3 * D, D, grads + pb + P.o_qkv_w));
+    } else {
+      RUN(sfron_attn_bwd((const uint16_t*)qkv, (const uint16_t*)o, (const uint16_t*)w.d_o, w.lse + (size_t)l * B * d.H * T,
+                         w.delta, (uint16_t*)w.dqkv[pl], B, T, d.H, d.hd, stream));
+      produced(3);
+      RUN(wgrad_side(w.dqkv[pl], xmod1, 3 * D, D, grads + pb + P.o_qkv_w, grads + pb + P.o_qkv_b));
+    }
     consumed(3, l);
     if (block_events && block_events[l]) {                 // block l: the four weight gradients, qkv.bias and fc1.bias are final
       if (hipEventRecord((hipEvent_t)block_events[l], (hipStream_t)side) != hipSuccess) return (int)hipGetLastError();

@@ -184,3 +184,11 @@ def attn_bwd(qkv, o, d_o, lse, B, T, H, hd):
     delta = torch.empty(B * H * T, dtype=torch.float32, device=qkv.device)
     check(_L().sfron_attn_bwd(ptr(qkv), ptr(o), ptr(d_o), ptr(lse), ptr(delta), ptr(dqkv), B, T, H, hd, stream_ptr()), "attn_bwd")
     return dqkv
+
+
+def attn_bwd_bias(qkv, o, d_o, lse, B, T, H, hd):
+    """Attention backward that also returns the qkv.bias gradient partials [B][3*H*hd] (token sums per sample, fp32)."""
+    dqkv = torch.empty_like(qkv)
+    part = torch.empty(B, 3 * H * hd, dtype=torch.float32, device=qkv.device)
+    check(_L().sfron_attn_bwd_bias(ptr(qkv), ptr(o), ptr(d_o), ptr(lse), ptr(dqkv), ptr(part), B, T, H, hd, stream_ptr()), "attn_bwd_bias")
+    return dqkv, part
