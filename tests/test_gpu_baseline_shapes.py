@@ -290,3 +290,56 @@ def test_dit_b4_fifty_step_eps_mse_within_1e4_of_oracle():
           f"(oracle {t_ref['mse'].mean().item():.5f})")
     assert final_gap < 1e-4, final_gap
     assert worst < 1e-3, worst        # per-step training-batch mse (bf16 forward noise on a loss of O(1)); measured bound in DESIGN.md
+
+
+def test_xl2_ten_sfron_iterations_vs_oracle():
+    """Multi-step acceptance AT THE HEADLINE GEOMETRY (DiT-XL/2: 28 blocks, 16 heads of 72, 256 tokens), batch 4: ten iterations of
+    DiT/forget.py:256-322 on the fused HIP runner against DiTSfronOracle (same seeds, mask, hyper-parameters; about a minute of CPU):
+    per-step losses and gradient norms, the direction of the parameter updates, and the eps-pred MSE on a held-out batch after the
+    ten steps (north-star: within 1e-4 of the reference path)."""
+    from oracle import diffusion_ref as dref
+    from oracle import sfron_ref
+    from sfron import data, diffusion, step
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    B = 4
+    ref, model = _pair("DiT-XL/2", B, seed=51, std=0.02)
+    model.train()
+    gm = torch.Generator().manual_seed(52)
+    mask = {"module." + n: (torch.rand(p.shape, generator=gm) < 0.5) for n, p in ref.named_parameters() if p.requires_grad}
+    mask["module.pos_embed"] = 0
+    hp = dict(lr=1e-4, forget_alpha=1e-3, grad_clip=1.0, ema_decay=0.9999, mask=mask, unlearn_loss="ga", forget_class=207)
+    orc = sfron_ref.DiTSfronOracle(ref, dref.DiffusionTables(1000), **hp)
+    runner = step.DiTSFRon(model, diffusion.create_diffusion(""), **hp)
+    p0 = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    kw = dict(global_batch=B, num_classes=1000, forget_class=207)
+    worst = 0.0
+    for it in range(10):
+        f, r = data.synthetic_batch(23, it, "forget", **kw), data.synthetic_batch(23, it, "remain", **kw)
+        want = orc.step({k: v.long() if k == "drop" else v for k, v in f.items()},
+                        {k: v.long() if k == "drop" else v for k, v in r.items()})
+        got = runner.step({k: v.to(DEV) for k, v in f.items()}, {k: v.to(DEV) for k, v in r.items()})
+        fm, rm = got["forget_mse"].mean().item(), got["remain_mse"].mean().item()
+        assert fm == pytest.approx(want["forget_mse"], rel=3e-2), it
+        assert rm == pytest.approx(want["remain_mse"], rel=3e-2), it
+        assert got["stats"][0].item() == pytest.approx(want["forget_gnorm"], rel=5e-2), it
+        worst = max(worst, abs(fm - want["forget_mse"]), abs(rm - want["remain_mse"]))
+    runner.guard.poll(block=True)
+    agree, bulk = _update_agreement(ref, model.engine, p0)
+    ref.eval()
+    hb = data.synthetic_batch(24, 0, "remain", global_batch=8, num_classes=1000, forget_class=207)
+    with torch.no_grad():
+        t_ref = dref.training_losses(dref.DiffusionTables(1000), lambda x, t, y: ref(x, t, y), hb["x0"], hb["t"], dict(y=hb["y"]), hb["noise"])
+    model.eval()
+    d = runner.diffusion
+    hbd = {k: v.to(DEV) for k, v in hb.items()}
+    with torch.no_grad():
+        out = model(d.q_sample(hbd["x0"], hbd["t"], hbd["noise"]), hbd["t"], hbd["y"])
+    mse_hip, _, _ = d.loss_fwd_bwd(out.contiguous(), hbd["x0"], hbd["t"], hbd["noise"], 1.0)
+    gap = abs(mse_hip.mean().item() - t_ref["mse"].mean().item())
+    print(f"DiT-XL/2 batch 4, 10 iterations: update sign agreement {agree:.4f}, bulk relative error of the update {bulk:.3f}, "
+          f"max per-step |mse gap| {worst:.2e}, held-out eps-MSE gap {gap:.2e} (oracle {t_ref['mse'].mean().item():.5f})")
+    assert agree > 0.995, agree
+    assert bulk < 0.1, bulk
+    assert gap < 1e-4, gap
+    assert worst < 1e-3, worst
+    assert runner.opt.step_count == 20

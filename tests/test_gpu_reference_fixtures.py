@@ -129,12 +129,22 @@ def test_dit_sfron_trajectory_vs_reference_fixture():
     # its norm and its seeded projection against the reference's (sign flips of near-zero gradients show up here)
     un, up = G["traj_update_norms"], G["traj_update_proj"]
     bad = 0
+    D = GPU_DIT["hidden_size"]
     for n, want_n, want_p in zip(names, un, up):
+        if n.endswith("attn.qkv.bias"):
+            # the K third of qkv.bias has an EXACTLY zero gradient (softmax is invariant to a shift of all keys): the reference holds
+            # fp32 cancellation noise far below Adam's eps there and barely moves it, bf16 operands leave noise above eps that Adam
+            # normalises to +-lr steps.  Neither is "right"; the Q and V thirds are compared below on the tensor stored in full.
+            continue
         du = eng.view(eng.params, n).detach().cpu() - p0[n]
         assert abs(du.double().norm().item() - want_n) < 0.1 * want_n + 1e-9, (n, du.norm().item(), want_n)
         bad += abs(_proj(du, n) - want_p) > 0.35 * want_n
     assert bad <= len(names) // 10, bad
-    assert _rel(eng.view(eng.params, "blocks.1.attn.qkv.bias"), G["traj_final_qkv1_bias"]) < 2e-2
+    got_b, want_b = eng.view(eng.params, "blocks.1.attn.qkv.bias").detach().cpu(), torch.from_numpy(G["traj_final_qkv1_bias"])
+    p0_b = p0["blocks.1.attn.qkv.bias"]
+    for lo in (0, 2 * D):                          # Q and V thirds: the UPDATE, not the value (the value is dominated by the init)
+        assert _rel(got_b[lo:lo + D] - p0_b[lo:lo + D], want_b[lo:lo + D] - p0_b[lo:lo + D]) < 0.25
+    assert (got_b[D:2 * D] - p0_b[D:2 * D]).abs().max().item() <= 6.5 * float(G["traj_lr"])       # K third: at most lr per Adam step
     assert _rel(eng.view(eng.params, "blocks.0.mlp.fc1.bias"), G["traj_final_fc1_0_bias"]) < 2e-2
     assert _rel(eng.view(runner.ema, "blocks.1.attn.proj.bias"), G["traj_final_ema_proj1_bias"]) < 2e-2
 
@@ -164,7 +174,9 @@ def test_ddpm_unet_forward_backward_vs_reference_fixture():
     model.eval()
     with torch.no_grad():
         got = model(x, t, c, mode="test", cond_scale=2.0)
-    assert _rel(got, G["out_test_scale2"]) < 1.5e-2, _rel(got, G["out_test_scale2"])
+    # (1 + s) cond - s null with s = 2: the two branches' bf16 errors (each < 1.5e-2 of its own norm) add with weights 3 and 2 while
+    # the difference is no larger than one branch -> bound 3e-2 for the guided output, 1.5e-2 for the single branch below
+    assert _rel(got, G["out_test_scale2"]) < 3e-2, _rel(got, G["out_test_scale2"])
     model.train()
     model.zero_grad()
     out = model(x, t, c, mode="train", cond_drop_prob=0.0)
@@ -179,7 +191,7 @@ def test_ddpm_sfron_trajectory_vs_reference_fixture():
     model, sd = _ddpm_from_fixture(G)
     gm = torch.Generator().manual_seed(8)
     mask = {n: (torch.rand(v.shape, generator=gm) < 0.5) for n, v in sd.items()}
-    runner = ddpm.DDPMSFRon(model, lr=1e-3, forget_alpha=10.0, remain_alpha=1.0, grad_clip=1.0, ema_mu=1e-4, mask=mask, unlearn_loss="adaga",
+    runner = ddpm.DDPMSFRon(model, lr=1e-3, forget_alpha=10.0, remain_alpha=1.0, grad_clip=1.0, ema_rate=1e-4, mask=mask, unlearn_loss="adaga",
                             lambd=0.5, n_iters=2, decay_forget_alpha=True, use_graphs=False)
     for s in range(2):
         f = dict(x0=G[f"s{s}_fx"], e=G[f"s{s}_fe"], t=G[f"s{s}_ft"], c=G[f"s{s}_fc"], keep_mask=G[f"s{s}_fkeep"])
@@ -195,6 +207,11 @@ def test_ddpm_sfron_trajectory_vs_reference_fixture():
     bad = 0
     for n, want_n, want_p in zip(names, G["traj_update_norms"], G["traj_update_proj"]):
         du = views[n].detach().cpu() - sd[n]
+        if n.endswith(".k.bias"):
+            # exactly-zero gradient (a shift of every key leaves the softmax unchanged): fp32 cancellation noise below Adam's eps in
+            # the reference, bf16 noise above it here -> Adam turns it into +-lr steps along a direction the function ignores
+            assert du.abs().max().item() <= 4.5 * 1e-3
+            continue
         assert abs(du.double().norm().item() - want_n) < 0.12 * want_n + 1e-9, (n, du.norm().item(), want_n)
         bad += abs(_proj(du, n) - want_p) > 0.4 * want_n
     assert bad <= len(names) // 8, bad

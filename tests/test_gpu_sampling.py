@@ -35,8 +35,7 @@ def _stub():
 
 
 def test_p_sample_loop_stub_model_matches_reference():
-    """clip_denoised=True trajectory of the fixture.  (The fixture's un-clamped trajectory grows to ~1e33 -- an ill-conditioned
-    comparison; the un-clamped step is pinned by the single-step test and by the guided DiT trajectory below.)"""
+    """clip_denoised=True trajectory of the fixture (the un-clamped loop: next test, on a contractive stub)."""
     from sfron import diffusion
     d = diffusion.create_diffusion("10", device=DEV)
     z = torch.from_numpy(G["z"])
@@ -46,6 +45,27 @@ def test_p_sample_loop_stub_model_matches_reference():
     got = d.p_sample_loop(stub, z.shape, z.to(DEV), clip_denoised=True, model_kwargs={}, device=DEV, step_noise=step_noise)
     np.testing.assert_allclose(got.cpu().numpy(), G["stub_clip1"], rtol=2e-5, atol=2e-5)
     assert [int(s[0]) for s in seen] == list(G["map10"])[::-1]          # the model sees ORIGINAL timesteps, last first
+
+
+def test_p_sample_loop_unclamped_contractive_stub_matches_reference():
+    """clip_denoised=False (what DiT/forget.py:114-145 samples with) over all 10 respaced steps, against the REFERENCE's output for a stub
+    whose eps-hat keeps pred_xstart bounded (fixture stub2_clip0: finite, O(0.1))."""
+    from sfron import diffusion
+    d = diffusion.create_diffusion("10", device=DEV)
+    z = torch.from_numpy(G["z"])
+    A = torch.from_numpy(G["A"]).to(DEV)
+    s1m = torch.tensor(np.sqrt(1.0 - G["abar1000"]), dtype=torch.float32, device=DEV)
+    C = z.shape[1]
+
+    def stub2(x, ts, **kw):
+        lin = torch.einsum("oc,nchw->nohw", A, x)
+        eps = 0.9 * x / s1m[ts].view(-1, 1, 1, 1) + 0.02 * lin[:, :C]
+        return torch.cat([eps, lin[:, C:] * torch.cos(ts.float() / 300.0).view(-1, 1, 1, 1) + 0.05], dim=1)
+    torch.manual_seed(77)
+    step_noise = [torch.randn_like(z).to(DEV) for _ in range(10)]
+    got = d.p_sample_loop(stub2, z.shape, z.to(DEV), clip_denoised=False, model_kwargs={}, device=DEV, step_noise=step_noise)
+    assert torch.isfinite(got).all()
+    np.testing.assert_allclose(got.cpu().numpy(), G["stub2_clip0"], rtol=2e-4, atol=2e-5)
 
 
 def test_p_sample_single_step_matches_reference():

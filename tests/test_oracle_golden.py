@@ -222,6 +222,19 @@ def test_sampling_restatement_matches_reference(golden_dir):
         torch.manual_seed(77)
         got = dref.p_sample_loop(tab, stub, z.shape, z, clip_denoised=clip, model_kwargs={})
         np.testing.assert_allclose(got.numpy(), g[f"stub_clip{int(clip)}"], rtol=1e-6, atol=1e-6)
+    # the un-clamped loop on a CONTRACTIVE stub (the linear stub's un-clamped trajectory overflows: its fixture entry is NaN / 1e36 and
+    # pins nothing beyond "the same overflow"): finite numbers of O(0.1), compared tightly
+    assert np.isfinite(g["stub2_clip0"]).all() and np.abs(g["stub2_clip0"]).max() < 10
+    s1m = torch.tensor(np.sqrt(1.0 - g["abar1000"]), dtype=torch.float32)
+    C = z.shape[1]
+
+    def stub2(x, ts, **kw):
+        lin = torch.einsum("oc,nchw->nohw", A, x)
+        eps = 0.9 * x / s1m[ts].view(-1, 1, 1, 1) + 0.02 * lin[:, :C]
+        return torch.cat([eps, lin[:, C:] * torch.cos(ts.float() / 300.0).view(-1, 1, 1, 1) + 0.05], dim=1)
+    torch.manual_seed(77)
+    got = dref.p_sample_loop(tab, stub2, z.shape, z, clip_denoised=False, model_kwargs={})
+    np.testing.assert_allclose(got.numpy(), g["stub2_clip0"], rtol=1e-5, atol=1e-6)
     torch.manual_seed(5)
     one = dref.p_sample(tab, stub, z, torch.tensor([0, 9, 3, 0]), clip_denoised=False, model_kwargs={})
     np.testing.assert_allclose(one["sample"].numpy(), g["one_sample_seed5"], rtol=1e-6, atol=1e-6)
