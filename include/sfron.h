@@ -392,7 +392,8 @@ int sfron_unpatchify(const float* rows, int ld, int n, int C, int H, int W, int 
 /* ------------------------------------------------------------------ attention (attn.hip)
  * qkv [B*T][3*H*hd] bf16 (column = which*D + head*hd + d), o / d_o [B*T][H*hd] bf16, lse [B][H][T] fp32.
  * softmax(q k^T * hd^-0.5) v, non-causal (timm Attention as used at DiT/models.py:108,120).
- * Supported: head_dim a multiple of 8 up to 96 (DiT 64 / 72; the LDM UNet's 40 / 80), T % 64 == 0. */
+ * Supported: T % 64 == 0 with head_dim a multiple of 8 up to 96 (DiT 64 / 72; the LDM UNet's 40 / 80) on the tiled kernels; T < 64
+ * (any T, head_dim <= 128: the patch-8 DiT models at 256 px have 16 tokens) on plain-FMA kernels, one workgroup per (batch, head). */
 int sfron_attn_fwd(const uint16_t* qkv, uint16_t* o, float* lse, int B, int T, int H, int hd, void* stream);
 /* dqkv [B*T][3*H*hd] bf16 = gradient wrt qkv; delta_scratch fp32 [B*H*T] (used by the two-kernel form only).
  * T = 128 / 256: ONE kernel, one 8-wave workgroup per (batch, head): S and dP are formed once per (query chunk, key block),

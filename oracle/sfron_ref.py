@@ -31,7 +31,10 @@ class DiTSfronOracle:
     """State = (model, AdamW on model.parameters(), ema list over all named params)."""
 
     def __init__(self, model, tables, lr=1e-4, forget_alpha=1e-3, grad_clip=1.0, ema_decay=0.9999,
-                 mask=None, unlearn_loss="ga", forget_class=0, num_classes=1000):
+                 mask=None, unlearn_loss="ga", forget_class=0, num_classes=1000, method="ron"):
+        if method not in ("ron", "joint"):
+            raise ValueError(method)
+        self.method = method        # "joint": forget.py:314-316 -- one step on remain + alpha * forget, no mask, no clip
         self.model = model
         self.tab = tables
         self.opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=0)   # forget.py:199
@@ -71,22 +74,25 @@ class DiTSfronOracle:
             ori_forget = terms_f["loss"].mean()
         else:
             raise ValueError(f"unsupported unlearn_loss {self.unlearn_loss!r} (SURVEY.md section 9 Q4)")
-        forget_loss = self.forget_alpha * ori_forget
-        self.opt.zero_grad()
-        forget_loss.backward()
-        if self.mask is not None:
-            for name, p in m.named_parameters():
-                if p.grad is not None:
-                    mk = self._mask_for(name)
-                    if mk is not None:
-                        p.grad *= mk
-        gnorm = torch.nn.utils.clip_grad_norm_(m.parameters(), self.grad_clip)
-        self.opt.step()
+        gnorm = float("nan")
+        if self.method == "ron":                                   # forget.py:283-299
+            forget_loss = self.forget_alpha * ori_forget
+            self.opt.zero_grad()
+            forget_loss.backward()
+            if self.mask is not None:
+                for name, p in m.named_parameters():
+                    if p.grad is not None:
+                        mk = self._mask_for(name)
+                        if mk is not None:
+                            p.grad *= mk
+            gnorm = torch.nn.utils.clip_grad_norm_(m.parameters(), self.grad_clip)
+            self.opt.step()
         # ---- remain stage (forget.py:301-320)
         terms_r = self._losses(remain["x0"], remain["y"], remain["t"], remain["noise"], remain["drop"])
         ori_remain = terms_r["loss"].mean()
         self.opt.zero_grad()
-        ori_remain.backward()
+        loss = ori_remain + self.forget_alpha * ori_forget if self.method == "joint" else ori_remain       # forget.py:314-318
+        loss.backward()
         self.opt.step()
         # ---- EMA (forget.py:322)
         with torch.no_grad():

@@ -72,14 +72,142 @@ def test_dit_forward_backward_vs_oracle(case):
     assert cos > 0.9995, cos
 
 
+TINY = dict(input_size=8, patch_size=2, in_channels=4, hidden_size=64, depth=2, num_heads=2, num_classes=10)     # the fixtures' config: 16 tokens
+
+
+def _tiny_from_fixture(g, batch):
+    from oracle import dit_ref            # weight generator only (tests/golden/make_golden.py:tiny_weights)
+    from sfron import dit
+    torch.manual_seed(1234)
+    src = dit_ref.DiT(**TINY)
+    dit_ref.randomize_zero_init(src, std=0.05, seed=1235)
+    sd = src.state_dict()
+    np.testing.assert_allclose([float(v.double().sum()) for v in sd.values()], g["param_sums"], rtol=1e-9, atol=1e-9)
+    model = dit.DiT(batch_size=batch, **TINY)
+    model.load_state_dict(sd)
+    return model, sd
+
+
 def test_dit_matches_golden_reference_output(golden_dir):
-    """The tiny reference-class fixture has T = 16 (< 64 tokens, unsupported by the attention kernel), so the
-    model-level golden check runs through the oracle (tests/test_oracle_golden.py); here we pin the engine's
-    frozen pos_embed table against the reference fixture on the same grid."""
+    """tests/golden/dit_model.npz -- the reference DiT class (DiT/models.py:145-248) at 16 tokens (a patch-8-style short sequence,
+    heads of 32): pos_embed table bit for bit, eval forward, and the ten gradient tensors + every gradient norm the reference's
+    autograd produced, against the HIP engine DIRECTLY (short-sequence attention kernels, generic GEMM tiles)."""
     from sfron import dit
     g = np.load(os.path.join(golden_dir, "dit_model.npz"))
     pe = dit.get_2d_sincos_pos_embed(64, 4)
     np.testing.assert_array_equal(pe.astype(np.float32)[None], g["pos_embed"])
+    model, _ = _tiny_from_fixture(g, 3)
+    x, t, y, w = (torch.from_numpy(g[k]).to(DEV) for k in ("x", "t", "y", "w"))
+    model.eval()
+    out = model(x, t, y)
+    assert rel_err(out, torch.from_numpy(g["out_eval"])) < 1.5e-2
+    model.zero_grad()
+    (out * w).sum().backward()
+    norms = g["grad_norms"]
+    gmax = norms.max()
+    for (n, p), gn in zip(model.named_parameters(), norms):
+        if gn < 0:                                   # the reference had no gradient there (frozen pos_embed)
+            assert p.grad is None, n
+        elif gn < 1e-3 * gmax:
+            assert p.grad.norm().item() < 3e-2 * gmax
+        else:
+            assert abs(p.grad.norm().item() - gn) < 4e-2 * gn, (n, p.grad.norm().item(), gn)
+    grads = {n: p.grad for n, p in model.named_parameters()}
+    for k in g.files:
+        if k.startswith("grad::"):
+            n = k[len("grad::"):]
+            if n == "blocks.0.attn.qkv.bias":         # K third: exactly zero gradient, cancellation noise on both sides
+                D = TINY["hidden_size"]
+                for lo in (0, 2 * D):
+                    assert rel_err(grads[n][lo:lo + D], torch.from_numpy(g[k])[lo:lo + D]) < 4e-2, n
+                continue
+            assert rel_err(grads[n], torch.from_numpy(g[k])) < 4e-2, (n, rel_err(grads[n], torch.from_numpy(g[k])))
+
+
+def test_sfron_trajectory_vs_golden_reference(golden_dir):
+    """tests/golden/dit_sfron_traj.npz: 3 iterations of DiT/forget.py:256-322 composed from the reference's own functions (16 tokens),
+    against the fused HIP runner directly: per-step losses and gradient norms, final parameter sums, two tensors in full."""
+    from sfron import diffusion, step
+    g = np.load(os.path.join(golden_dir, "dit_sfron_traj.npz"))
+    gm_ = np.load(os.path.join(golden_dir, "dit_model.npz"))
+    model, sd = _tiny_from_fixture(gm_, 4)
+    model.train()
+    gen = torch.Generator().manual_seed(int(g["mask_seed"]))
+    names = [str(n) for n in g["names"]]
+    mask = {"module." + n: (torch.rand(sd[n].shape, generator=gen) < 0.5) for n in names if n != "pos_embed"}
+    mask["module.pos_embed"] = 0
+    runner = step.DiTSFRon(model, diffusion.create_diffusion(""), lr=float(g["lr"]), forget_alpha=float(g["forget_alpha"]), grad_clip=1.0,
+                           ema_decay=float(g["ema_decay"]), mask=mask, unlearn_loss="ga", forget_class=3)
+    for s_ in range(3):
+        b = {st: {k: torch.from_numpy(g[f"s{s_}_{st}_{k}"]).to(DEV) for k in ("x0", "t", "noise", "y", "drop")} for st in ("forget", "remain")}
+        for st in b:
+            b[st]["drop"] = b[st]["drop"].to(torch.uint8)
+        out = runner.step(b["forget"], b["remain"])
+        torch.cuda.synchronize()
+        assert out["forget_mse"].mean().item() == pytest.approx(float(g["forget_mse"][s_]), rel=2e-2)
+        assert out["remain_mse"].mean().item() == pytest.approx(float(g["remain_mse"][s_]), rel=2e-2)
+        assert -(out["forget_mse"] + out["forget_vb"]).mean().item() == pytest.approx(float(g["forget_loss"][s_]), rel=3e-2)
+        assert (out["remain_mse"] + out["remain_vb"]).mean().item() == pytest.approx(float(g["remain_loss"][s_]), rel=3e-2)
+        assert out["stats"][0].item() == pytest.approx(float(g["gnorm"][s_]), rel=5e-2)
+    runner.guard.poll(block=True)
+    eng = model.engine
+    # Adam moves a coordinate by <= lr per step whatever its gradient: |sum| of a tensor may differ by (#coords whose tiny gradient
+    # changes sign) * lr; compare on the scale of the reference's absolute sums
+    for n, want, wabs in zip(names, g["final_param_sums"], g["final_param_abs"]):
+        if n.endswith("attn.qkv.bias"):
+            continue        # K third: exactly-zero gradient; bf16 cancellation noise above Adam's eps becomes +-lr steps (harmless direction)
+        got = eng.view(eng.params, n).double().sum().item()
+        assert abs(got - want) < 2e-3 * wabs + 1e-6, (n, got, want)
+    assert rel_err(eng.view(eng.params, "blocks.0.attn.qkv.weight"), torch.from_numpy(g["final_qkv0"])) < 2e-2
+    assert rel_err(eng.view(runner.ema, "blocks.1.mlp.fc1.bias"), torch.from_numpy(g["final_ema_fc1"])) < 2e-2
+
+
+@pytest.mark.parametrize("B,T,H,hd", [(2, 16, 2, 32), (3, 16, 6, 64), (1, 16, 16, 72), (2, 36, 3, 40), (2, 4, 1, 8)])
+def test_short_sequence_attention_vs_torch(B, T, H, hd):
+    """T < 64 (the registry's patch-8 models at 256 px: 16 tokens) on the plain-FMA kernels, forward and backward against torch
+    autograd in fp32 on the same bf16 inputs."""
+    from sfron import ops
+    gen = torch.Generator().manual_seed(T + H + hd)
+    D = H * hd
+    qkv = (torch.randn(B * T, 3 * D, generator=gen) * 1.2).to(torch.bfloat16).to(DEV)
+    d_o = (torch.randn(B * T, D, generator=gen) * 0.2).to(torch.bfloat16).to(DEV)
+    o, lse = ops.attn_fwd(qkv, B, T, H, hd)
+    dqkv = ops.attn_bwd(qkv, o, d_o, lse, B, T, H, hd)
+    x = qkv.float().requires_grad_(True)
+    q, k, v = x.view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4).unbind(0)
+    s_ = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    ref = (s_.softmax(-1) @ v).transpose(1, 2).reshape(B * T, D)
+    ref.backward(d_o.float())
+    assert rel_err(o, ref) < 6e-3
+    np.testing.assert_allclose(lse.view(B, H, T).cpu().numpy(), torch.logsumexp(s_, -1).detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    assert rel_err(dqkv, x.grad) < 1e-2
+    assert torch.equal(dqkv, ops.attn_bwd(qkv, o, d_o, lse, B, T, H, hd))
+
+
+@pytest.mark.parametrize("name", ["DiT-S/8", "DiT-B/8"])
+def test_registry_patch8_models_run(name):
+    """DiT/models.py:328-370 registers */8 models; at 256 px they see 16 tokens.  Forward + backward against the oracle."""
+    from oracle import dit_ref
+    from sfron import dit
+    B = 2
+    torch.manual_seed(3)
+    ref = dit_ref.build(name, input_size=32)
+    dit_ref.randomize_zero_init(ref, std=0.02, seed=4)
+    model = dit.DiT_models[name](input_size=32, num_classes=1000, batch_size=B)
+    model.load_state_dict(ref.state_dict())
+    assert model.engine.tokens == 16
+    gen = torch.Generator().manual_seed(8)
+    x, t, y = torch.randn(B, 4, 32, 32, generator=gen), torch.tensor([5, 990]), torch.tensor([207, 3])
+    w = torch.randn(B, 8, 32, 32, generator=gen) * 0.05
+    ref.eval(); model.eval()
+    out_ref = ref(x, t, y)
+    (out_ref * w).sum().backward()
+    out = model(x.to(DEV), t.to(DEV), y.to(DEV))
+    assert rel_err(out, out_ref) < 1.5e-2
+    (out * w.to(DEV)).sum().backward()
+    gm = torch.cat([p.grad.flatten().cpu() for _, p in model.named_parameters() if p.grad is not None])
+    gr = torch.cat([q.grad.flatten() for _, q in ref.named_parameters() if q.grad is not None])
+    assert (torch.dot(gm, gr) / (gm.norm() * gr.norm())).item() > 0.9995
 
 
 @pytest.mark.parametrize("case,loss,micro", [("hd64", "ga", 1), ("hd72", "ga", 1), ("hd64_nc200", "rl", 1), ("hd72", "ga", 2)])
@@ -220,3 +348,41 @@ def test_checkpoint_format_and_resume(tmp_path):
     runner2.step(*bat(1))
     assert torch.equal(model2.engine.params, want)
     assert torch.equal(runner2.ema, runner.ema)
+
+
+def test_joint_method_vs_oracle():
+    """method "joint" (DiT/forget.py:314-316): loss = remain + forget_alpha * forget, ONE AdamW step per iteration, no mask, no
+    clip; three iterations against the oracle restating the same lines."""
+    from oracle import diffusion_ref as dref
+    from oracle import sfron_ref
+    from sfron import data, diffusion, step
+    cfg = CASES["hd64"]
+    B = 4
+    ref, model = build_pair(cfg, B, seed=6)
+    model.train()
+    hp = dict(lr=1e-3, forget_alpha=0.5, grad_clip=1.0, ema_decay=0.99, mask=None, unlearn_loss="ga", forget_class=3, method="joint")
+    orc = sfron_ref.DiTSfronOracle(ref, dref.DiffusionTables(1000), **hp)
+    runner = step.DiTSFRon(model, diffusion.create_diffusion(""), **hp)
+    p0 = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    kw = dict(global_batch=B, num_classes=cfg["num_classes"], forget_class=3, input_size=cfg["input_size"])
+    for it in range(3):
+        f, r = data.synthetic_batch(5, it, "forget", **kw), data.synthetic_batch(5, it, "remain", **kw)
+        want = orc.step({k: v.long() if k == "drop" else v for k, v in f.items()}, {k: v.long() if k == "drop" else v for k, v in r.items()})
+        got = runner.step({k: v.to(DEV) for k, v in f.items()}, {k: v.to(DEV) for k, v in r.items()})
+        assert got["forget_mse"].mean().item() == pytest.approx(want["forget_mse"], rel=3e-2)
+        assert got["remain_mse"].mean().item() == pytest.approx(want["remain_mse"], rel=3e-2)
+    runner.guard.poll(block=True)
+    assert runner.opt.step_count == 3                       # one optimizer step per iteration
+    eng = model.engine
+    same = tot = 0
+    for n, q in ref.named_parameters():
+        if not q.requires_grad or n.endswith("attn.qkv.bias"):
+            continue
+        du_ref, du = (q.detach() - p0[n]).flatten(), (eng.view(eng.params, n).cpu() - p0[n]).flatten()
+        big = du_ref.abs() > 0.05 * du_ref.abs().max()
+        same += int((torch.sign(du[big]) == torch.sign(du_ref[big])).sum()); tot += int(big.sum())
+    assert same / tot > 0.97, same / tot
+    for n in ("blocks.1.mlp.fc2.bias", "final_layer.linear.weight"):
+        assert rel_err(eng.view(runner.ema, n), orc.ema[n]) < 2e-2, n
+    with pytest.raises(ValueError):
+        step.DiTSFRon(model, diffusion.create_diffusion(""), method="sa")

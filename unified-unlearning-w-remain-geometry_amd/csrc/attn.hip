@@ -980,6 +980,116 @@ SFRON_INST_ATTN(64, 2, 3)      // head_dim <= 48 (the LDM UNet's 40): three outp
 SFRON_INST_ATTN(96, 3, 5)
 #undef SFRON_INST_ATTN
 
+
+// =================================================================================================
+// Short sequences (T < 64, any T): the patch-8 entries of the reference's model registry at 256 px give 16 tokens
+// (DiT/models.py:328-370).  One workgroup per (batch, head), everything in LDS as fp32, plain FMA loops -- the work is a few
+// thousand multiply-adds per head; no MFMA tile would be filled.  Same math as the tiled kernels (softmax(q k^T hd^-0.5) v and
+// its autograd), P and dS kept in fp32.  Fixed summation order, no atomics.
+// =================================================================================================
+namespace {
+constexpr int SNT = 256;
+__device__ __forceinline__ void small_load(const __bf16* base, int ld, int T, int hd, int HDS, float* dst, int tid) {
+  for (int e = tid; e < T * hd; e += SNT) { const int i = e / hd, d = e % hd; dst[i * HDS + d] = bf2f(base[(size_t)i * ld + d]); }
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_attn_small_fwd(const __bf16* __restrict__ qkv, __bf16* __restrict__ o, float* __restrict__ lse,
+                                                         int T, int H, int hd, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int HDS = hd + 1;                                    // odd row stride: rows of K / V walk the banks
+  float* q = sm; float* k = q + T * HDS; float* v = k + T * HDS; float* S = v + T * HDS;      // S [T][T + 1]
+  const int TS = T + 1;
+  const int tid = threadIdx.x, bh = blockIdx.x, b = bh / H, h = bh % H, D = H * hd, ld = 3 * D;
+  const __bf16* base = qkv + (size_t)b * T * ld + h * hd;
+  small_load(base, ld, T, hd, HDS, q, tid); small_load(base + D, ld, T, hd, HDS, k, tid); small_load(base + 2 * D, ld, T, hd, HDS, v, tid);
+  __syncthreads();
+  for (int e = tid; e < T * T; e += SNT) {
+    const int i = e / T, j = e % T;
+    float a = 0.f;
+    for (int d = 0; d < hd; ++d) a += q[i * HDS + d] * k[j * HDS + d];
+    S[i * TS + j] = a * scale;
+  }
+  __syncthreads();
+  for (int i = tid; i < T; i += SNT) {
+    float m = -INFINITY;
+    for (int j = 0; j < T; ++j) m = fmaxf(m, S[i * TS + j]);
+    float sum = 0.f;
+    for (int j = 0; j < T; ++j) { const float e = __expf(S[i * TS + j] - m); S[i * TS + j] = e; sum += e; }
+    const float inv = 1.0f / sum;
+    for (int j = 0; j < T; ++j) S[i * TS + j] *= inv;
+    lse[(size_t)bh * T + i] = m + __logf(sum);
+  }
+  __syncthreads();
+  for (int e = tid; e < T * hd; e += SNT) {
+    const int i = e / hd, d = e % hd;
+    float a = 0.f;
+    for (int j = 0; j < T; ++j) a += S[i * TS + j] * v[j * HDS + d];
+    o[((size_t)b * T + i) * D + h * hd + d] = f2bf(a);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_attn_small_bwd(const __bf16* __restrict__ qkv, const __bf16* __restrict__ o,
+                                                         const __bf16* __restrict__ d_o, const float* __restrict__ lse,
+                                                         __bf16* __restrict__ dqkv, int T, int H, int hd, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int HDS = hd + 1, TS = T + 1;
+  float* q = sm; float* k = q + T * HDS; float* v = k + T * HDS; float* dO = v + T * HDS;
+  float* P = dO + T * HDS; float* dS = P + T * TS; float* delta = dS + T * TS;
+  const int tid = threadIdx.x, bh = blockIdx.x, b = bh / H, h = bh % H, D = H * hd, ld = 3 * D;
+  const __bf16* base = qkv + (size_t)b * T * ld + h * hd;
+  const __bf16* dob = d_o + (size_t)b * T * D + h * hd;
+  const __bf16* ob = o + (size_t)b * T * D + h * hd;
+  small_load(base, ld, T, hd, HDS, q, tid); small_load(base + D, ld, T, hd, HDS, k, tid); small_load(base + 2 * D, ld, T, hd, HDS, v, tid);
+  small_load(dob, D, T, hd, HDS, dO, tid);
+  for (int i = tid; i < T; i += SNT) {
+    float a = 0.f;
+    for (int d = 0; d < hd; ++d) a += bf2f(dob[(size_t)i * D + d]) * bf2f(ob[(size_t)i * D + d]);
+    delta[i] = a;
+  }
+  __syncthreads();
+  for (int e = tid; e < T * T; e += SNT) {
+    const int i = e / T, j = e % T;
+    float a = 0.f, dp = 0.f;
+    for (int d = 0; d < hd; ++d) { a += q[i * HDS + d] * k[j * HDS + d]; dp += dO[i * HDS + d] * v[j * HDS + d]; }
+    const float p = __expf(a * scale - lse[(size_t)bh * T + i]);
+    P[i * TS + j] = p;
+    dS[i * TS + j] = p * (dp - delta[i]) * scale;
+  }
+  __syncthreads();
+  __bf16* outb = dqkv + (size_t)b * T * ld + h * hd;
+  for (int e = tid; e < T * hd; e += SNT) {
+    const int i = e / hd, d = e % hd;
+    float dq = 0.f, dk = 0.f, dv = 0.f;
+    for (int j = 0; j < T; ++j) {
+      dq += dS[i * TS + j] * k[j * HDS + d];
+      dk += dS[j * TS + i] * q[j * HDS + d];
+      dv += P[j * TS + i] * dO[j * HDS + d];
+    }
+    outb[(size_t)i * ld + d] = f2bf(dq);
+    outb[(size_t)i * ld + D + d] = f2bf(dk);
+    outb[(size_t)i * ld + 2 * D + d] = f2bf(dv);
+  }
+}
+
+static int launch_small_fwd(const __bf16* qkv, __bf16* o, float* lse, int B, int T, int H, int hd, float scale, hipStream_t s) {
+  const size_t lds = (size_t)(3 * T * (hd + 1) + T * (T + 1)) * sizeof(float);
+  if (lds > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_small_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return (int)hipGetLastError();
+  hipLaunchKernelGGL(k_attn_small_fwd, dim3(B * H), dim3(256), lds, s, qkv, o, lse, T, H, hd, scale);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SFRON_OK : (int)e;
+}
+static int launch_small_bwd(const __bf16* qkv, const __bf16* o, const __bf16* d_o, const float* lse, __bf16* dqkv, int B, int T, int H, int hd,
+                            float scale, hipStream_t s) {
+  const size_t lds = (size_t)(4 * T * (hd + 1) + 2 * T * (T + 1) + T) * sizeof(float);
+  if (lds > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_small_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return (int)hipGetLastError();
+  hipLaunchKernelGGL(k_attn_small_bwd, dim3(B * H), dim3(256), lds, s, qkv, o, d_o, lse, dqkv, T, H, hd, scale);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SFRON_OK : (int)e;
+}
+
 namespace {
 
 // 0 / 1 = fused backward where the sequence length allows it; 2 = always the two-kernel form (tests compare the two)
@@ -1044,10 +1154,12 @@ int launch_bwd(const __bf16* qkv, const __bf16* o, const __bf16* d_o, const floa
 extern "C" {
 
 int sfron_attn_fwd(const uint16_t* qkv, uint16_t* o, float* lse, int B, int T, int H, int hd, void* stream) {
-  SFRON_CHECK_ARG(qkv && o && lse && B > 0 && H > 0 && T > 0 && T % 64 == 0);
-  SFRON_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)o) & 15) == 0);
+  SFRON_CHECK_ARG(qkv && o && lse && B > 0 && H > 0 && T > 0 && hd > 0);
   const float scale = 1.0f / sqrtf((float)hd);
   hipStream_t s = (hipStream_t)stream;
+  if (T < 64) return hd <= 128 ? launch_small_fwd((const __bf16*)qkv, (__bf16*)o, lse, B, T, H, hd, scale, s) : SFRON_ERR_UNSUPPORTED;
+  if (T % 64 != 0) return SFRON_ERR_UNSUPPORTED;          // longer sequences run on 64-row tiles
+  SFRON_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)o) & 15) == 0);
   // any head_dim that is a multiple of 8 up to 96 runs on the 64- or 96-column images (columns beyond head_dim are zero padding):
   // DiT 64 / 72, the LDM UNet's 40 and 80
   if (hd % 8 != 0 || hd < 8) return SFRON_ERR_UNSUPPORTED;
@@ -1062,10 +1174,14 @@ int sfron_attn_bwd_form(int form) { const int old = g_bwd_form; g_bwd_form = for
 
 int sfron_attn_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* delta_scratch,
                    uint16_t* dqkv, int B, int T, int H, int hd, void* stream) {
-  SFRON_CHECK_ARG(qkv && o && d_o && lse && delta_scratch && dqkv && B > 0 && H > 0 && T > 0 && T % 64 == 0);
-  SFRON_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dqkv) & 15) == 0);
+  SFRON_CHECK_ARG(qkv && o && d_o && lse && delta_scratch && dqkv && B > 0 && H > 0 && T > 0 && hd > 0);
   const float scale = 1.0f / sqrtf((float)hd);
   hipStream_t s = (hipStream_t)stream;
+  if (T < 64)
+    return hd <= 128 ? launch_small_bwd((const __bf16*)qkv, (const __bf16*)o, (const __bf16*)d_o, lse, (__bf16*)dqkv, B, T, H, hd, scale, s)
+                     : SFRON_ERR_UNSUPPORTED;
+  if (T % 64 != 0) return SFRON_ERR_UNSUPPORTED;
+  SFRON_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dqkv) & 15) == 0);
   if (hd % 8 != 0 || hd < 8) return SFRON_ERR_UNSUPPORTED;
   if (hd <= 48)
     return launch_bwd<64, 2, 3>((const __bf16*)qkv, (const __bf16*)o, (const __bf16*)d_o, lse, delta_scratch, (__bf16*)dqkv, B, T, H, hd, scale, s);

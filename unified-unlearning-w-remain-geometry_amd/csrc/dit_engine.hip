@@ -28,8 +28,12 @@ inline int make_dims(const sfron_dit_cfg* c, Dims& d) {
   if (d.S % d.p || d.D % d.H || d.D % 8 || d.F % 8 || d.fdim % 8) return SFRON_ERR_ARG;
   d.hd = d.D / d.H; d.g = d.S / d.p; d.T = d.g * d.g; d.M = d.B * d.T; d.Kp = d.C * d.p * d.p; d.Po = d.p * d.p * d.Co;
   d.NM = (6 * d.L + 2) * d.D;
-  if (d.Kp % 8 || d.Po % 8 || d.T % 64) return SFRON_ERR_UNSUPPORTED;
-  if (d.hd != 64 && d.hd != 72) return SFRON_ERR_UNSUPPORTED;
+  // token counts: multiples of 64 (tiled attention) or fewer than 64 (the registry's patch-8 models at 256 px: 16 tokens -- plain-FMA
+  // attention kernels, generic GEMM tiles); T must be even for the row-kernel chunking
+  if (d.Kp % 8 || d.Po % 8 || (d.T % 64 && d.T > 64) || (d.T & 1)) return SFRON_ERR_UNSUPPORTED;
+  // head widths the attention kernels take: multiples of 8 up to 96 on the tiled kernels (DiT 64 / 72), anything up to 128 on the
+  // short-sequence kernels
+  if (d.T >= 64 ? (d.hd % 8 || d.hd > 96) : d.hd > 128) return SFRON_ERR_UNSUPPORTED;
   return SFRON_OK;
 }
 

@@ -39,12 +39,20 @@ def build_mask_arena(engine, mask):
 class DiTSFRon:
     def __init__(self, model, diffusion, lr=1e-4, forget_alpha=1e-3, grad_clip=1.0, ema_decay=0.9999, mask=None,
                  unlearn_loss="ga", forget_class=0, process_group=None, bucket_bytes=256 << 20, micro_batches=1,
-                 overlap_allreduce=False, grad_transport="fp32"):
+                 overlap_allreduce=False, grad_transport="fp32", method="ron"):
         """micro_batches = 2: each forward/backward pass runs as TWO independent half-batch chains on two HIP streams
         (own workspace, own gradient arena, own side stream); the latency-bound kernels of one chain (attention,
         LayerNorm / gate backward) then run under the GEMMs of the other.  The optimizer sweep sums the two arenas."""
         if unlearn_loss not in ("ga", "rl"):
             raise ValueError(f"unsupported unlearn_loss {unlearn_loss!r} (DiT/forget.py defines only 'ga' and 'rl')")
+        # method "ron" = the SFR-on iteration (two optimizer steps); "joint" = DiT/forget.py:314-316: ONE step on
+        # remain_loss + forget_alpha * forget_loss, no mask, no clip (SURVEY.md section 9 Q5)
+        if method not in ("ron", "joint"):
+            raise ValueError(f"unsupported method {method!r} (DiT/forget.py:283-320 defines 'ron' and 'joint')")
+        if method == "joint" and micro_batches != 1:
+            raise ValueError("method 'joint' runs single-chain passes (micro_batches = 1)")
+        self.method = method
+        self._joint = None
         if unlearn_loss == "rl" and (forget_class + 100) % 1000 >= model.num_classes:
             # DiT/forget.py:275-279 hard-codes (forget_class + 100) % 1000; with fewer classes the reference's nn.Embedding
             # raises an IndexError -- so do we, up front
@@ -254,6 +262,45 @@ class DiTSFRon:
             self._allreduce_grads()
         return mse, vb
 
+    def _step_joint(self, forget, remain, y_f, sign):
+        """DiT/forget.py:314-320 with method "joint": loss = remain_loss + forget_alpha * forget_loss, one backward through BOTH
+        graphs, one AdamW step (no mask, no clip), EMA.  Both forward passes see the same weights; their activations live in two
+        workspaces (a sibling engine over the same parameters) and their gradients in two arenas that the sweep adds."""
+        n = forget["x0"].shape[0]
+        if remain["x0"].shape[0] != n:
+            raise ValueError("method 'joint' needs equal forget / remain batch sizes per rank")
+        self.model.set_batch_size(n)
+        e0 = self.model.engine
+        if self._joint is None or self._joint[0] is not e0:
+            self._joint = (e0, e0.sibling(n))
+        e1 = self._joint[1]
+        diff = self.diffusion
+        n_global = n * self.world
+        res = []
+        for eng, b, y, scale in ((e0, forget, y_f, sign * self.forget_alpha), (e1, remain, remain["y"], 1.0)):
+            b, y = self._checked(b, y)
+            x_t = diff.q_sample(b["x0"], b["t"], b["noise"])
+            out = eng.forward(x_t, b["t"], y, b.get("drop"))
+            mse, vb, d_out = diff.loss_fwd_bwd(out, b["x0"], b["t"], b["noise"], scale / n_global)
+            eng.backward(d_out, y, b.get("drop"))
+            res.append((mse, vb))
+        nt = e0.n_trainable
+        if self.world > 1:
+            e0.grads[:nt].add_(e1.grads[:nt])
+            self.opt.g, self.opt.g2 = e0.grads[:nt], None
+            self._allreduce_grads()
+        else:
+            self.opt.g, self.opt.g2 = e0.grads[:nt], e1.grads[:nt]
+        self.opt.step(max_norm=None, use_mask=False, ema=self.ema[:nt], ema_decay=self.ema_decay, ema_mode=1)      # forget.py:320,322
+        self.opt.g2 = None
+        if e0.n_total > nt:
+            sweep.ema_update(self.ema[nt:], e0.params[nt:], self.ema_decay, mode=1)
+        (mse_f, vb_f), (mse_r, vb_r) = res
+        self.guard.check_finite((mse_f, vb_f, mse_r, vb_r), None)
+        self.iteration += 1
+        self.guard.publish(self.iteration)
+        return {"forget_mse": mse_f, "forget_vb": vb_f, "remain_mse": mse_r, "remain_vb": vb_r, "forget_sign": sign, "stats": self.opt.stats}
+
     def step(self, forget, remain):
         """forget / remain: dicts of GPU tensors x0 [N,4,S,S] fp32, y [N] int64, t [N] int64, noise, drop [N] uint8
         (this rank's shard).  Returns per-sample mse / vb tensors (device; no host sync here)."""
@@ -265,6 +312,8 @@ class DiTSFRon:
             y_f, sign = forget["y"], -1.0                                                   # forget.py:269-272
         else:
             y_f, sign = torch.full_like(forget["y"], (self.forget_class + 100) % 1000), 1.0  # forget.py:274-282
+        if self.method == "joint":
+            return self._step_joint(forget, remain, y_f, sign)
         mse_f, vb_f = self._pass(forget, y_f, sign * self.forget_alpha)
         self.opt.step(max_norm=self.grad_clip, use_mask=True)                               # forget.py:289-299
         mse_r, vb_r = self._pass(remain, remain["y"], 1.0)
