@@ -46,6 +46,10 @@ def parse():
     ap.add_argument("--micro-batches", type=int, default=1, help="independent half-batch chains per pass (1 or 2)")
     ap.add_argument("--cpu-batch", type=int, default=8, help="batch of the bounded CPU-baseline sample")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: keep the synchronous bucketed all-reduce")
+    ap.add_argument("--fp8", action="store_true",
+                    help="BASELINE config 5: the four block GEMMs of every FORWARD pass on the fp8 (e4m3) matrix core, e4m3 weight shadow "
+                         "re-quantised after each optimizer step; backward GEMMs stay bf16")
+    ap.add_argument("--grad-transport", default="fp32", choices=("fp32", "bf16"), help="N > 1: precision of the gradient exchange")
     ap.add_argument("--check", action="store_true",
                     help="N-rank == 1-rank parity: after the run every rank also computes the gradient of the WHOLE global batch "
                          "of step 0 by itself and compares it with the all-reduced gradient of the sharded run")
@@ -158,7 +162,8 @@ def main():
     mask_arena = (torch.rand(eng.n_trainable, generator=gm) < 0.5).to(torch.uint8).to(dev)     # 50 % synthetic saliency mask
     diff = diffusion.create_diffusion("", device=dev)
     runner = step.DiTSFRon(model, diff, lr=1e-4, forget_alpha=1e-3, grad_clip=1.0, ema_decay=0.9999, mask=None,
-                           unlearn_loss="ga", forget_class=207, micro_batches=args.micro_batches)
+                           unlearn_loss="ga", forget_class=207, micro_batches=args.micro_batches, fp8=args.fp8,
+                           grad_transport=args.grad_transport)
     runner.mask_arena = mask_arena
     runner.opt.mask = mask_arena
 
@@ -271,9 +276,11 @@ def main():
             # (one synchronous iteration over the global batch of 32 * world samples takes ms_per_step)
             "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "fp8_e4m3 forward GEMMs (weights + activations), bf16 backward GEMMs, fp32 accumulate" if args.fp8 else "bf16",
+            "data": "synthetic",
             "config": {"workload": f"{args.model} {args.image_size}px SFR-on step (forget+remain fwd/bwd, masked clipped AdamW x2, EMA), "
-                                   f"batch {args.batch}/GPU, random-init weights (zero-init tensors re-drawn N(0,0.02)), 50% synthetic mask",
+                                   f"batch {args.batch}/GPU, random-init weights (zero-init tensors re-drawn N(0,0.02)), 50% synthetic mask"
+                                   + (" -- BASELINE config 5 (fp8 forward)" if args.fp8 else ""),
                        "global_batch": gb, "tokens": T, "parallelism": f"dp{world}"},
             "finite_losses": loss_ok,
             "step_tflops_per_gpu": step_flops / (ms_per_step * 1e-3) / 1e12,

@@ -183,6 +183,50 @@ int sfron_gemm_dgelu_colpart_rows(int M, int N, int K);
 int sfron_gemm_rowsum_supported(int M, int N, int K);
 
 
+/* ------------------------------------------------------------------ fp8 (e4m3) forward GEMMs (fp8.hip) -- BASELINE config 5
+ * "DiT-XL/2 fp8 weights + bf16 activations on the CDNA4 fp8 MFMA": the four token GEMMs of a DiT block forward
+ * (DiT/models.py:108-121) on v_mfma_scale_f32_16x16x128_f8f6f4.  The reference has no fp8 path; tolerance is stated against the bf16
+ * path (config 3) in tests/test_gpu_fp8.py.  e4m3 = OCP e4m3fn, round to nearest even, saturating at +-448.
+ * Weights: fp32 masters + e4m3 shadow arena (same offsets, 1 byte / element) + ONE power-of-two scale per tensor;
+ * activations: quantised by their producers with static power-of-two scales. */
+
+/* table [n_tensors][2] int64 (DEVICE): element offset and length (multiples of 8) of each quantised tensor inside the arena.
+ * mode 0: amax_bits[t] = max(amax_bits[t], bits(max |p|)) only.  mode 1: dst[off + i] = e4m3(p[off + i] * scales[t]) and the same amax
+ * (delayed scaling: quantise with the scale derived from the PREVIOUS pass's amax while collecting the next one). */
+int sfron_fp8_quant_tensors(const float* params, const int64_t* table, int n_tensors, const float* scales, uint32_t* amax_bits,
+                            uint8_t* dst, int mode, void* stream);
+/* scales[t] = 2^floor(log2(224 / amax_t)) (2x headroom under 448; 1 for an all-zero tensor); clears amax_bits */
+int sfron_fp8_update_scales(uint32_t* amax_bits, int n_tensors, float* scales, void* stream);
+/* dst[i] = e4m3(src[i] * scale); src bf16 (src_is_bf16 = 1) or fp32; n % 8 == 0 */
+int sfron_cast_e4m3(const void* src, int src_is_bf16, int64_t n, float scale, uint8_t* dst, void* stream);
+/* sfron_ln_modulate_fwd that also writes out_e4m3 = e4m3(value * e4m3_scale) from the fp32 value (the A operand of the next GEMM) */
+int sfron_ln_modulate_fwd_q(const float* x, const float* shift, const float* scale, int ldmod, int tokens, int M, int D, uint16_t* out,
+                            uint8_t* out_e4m3, float e4m3_scale, float* mean, float* rstd, void* stream);
+
+/* C[M][N] = (A8[M][K] . B8[N][K]^T) / (a_scale * *w_scale) + bias with one of the block's epilogues:
+ *   SFRON_EPI_BF16      c_bf16 = result                                                   (qkv)
+ *   SFRON_EPI_GELU      aux = result (pre-activation, bf16), c_bf16 = gelu_tanh(result),
+ *                       c_e4m3 = e4m3(gelu_tanh(result) * c_e4m3_scale) [M][N]            (fc1: h for the backward pass AND for fc2)
+ *   SFRON_EPI_GATE_RES  aux = result (bf16), c_f32 = resid + gate[row / tokens] * result  (proj, fc2)
+ * Shapes: M % 256 == 0, N % 128 == 0, K % 128 == 0 (sfron_fp8_gemm_supported). */
+typedef struct sfron_fp8_gemm_desc {
+  const uint8_t* A; const uint8_t* B;
+  int M, N, K;
+  const float* w_scale;              /* DEVICE scalar: the scale B was quantised with (sfron_fp8_update_scales output) */
+  float a_scale;                     /* the scale A was quantised with */
+  int epilogue;
+  const float* bias;
+  uint16_t* c_bf16; int ldc_bf16;
+  uint16_t* aux; int ldaux;
+  uint8_t* c_e4m3; float c_e4m3_scale;
+  float* c_f32; int ldc_f32;
+  const float* resid;                /* NULL = in place */
+  const float* gate; int ldgate;
+  int tokens;
+} sfron_fp8_gemm_desc;
+int sfron_fp8_gemm_supported(int M, int N, int K);
+int sfron_fp8_gemm(const sfron_fp8_gemm_desc* desc /* HOST pointer */, void* stream);
+
 /* ------------------------------------------------------------------ convolutional U-Net blocks (conv.hip)
  * Replaces the Conv2d / GroupNorm / bmm-softmax sequences of DDPM/models/diffusion.py:43-192,283-413 (Conditional_Model) forward
  * and backward.  Activations are NHWC: a [batch * H * W][C] row-major matrix (bf16 where they feed a GEMM, fp32 elsewhere). */
@@ -441,6 +485,15 @@ int64_t sfron_dit_workspace_bytes(const sfron_dit_cfg* cfg);   /* < 0 on unsuppo
  * Saves activations in `workspace` for sfron_dit_backward. */
 int sfron_dit_forward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
                       const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out, void* stream);
+/* Config 5: the same forward pass with the four block GEMMs on the fp8 matrix core.  params_e4m3: e4m3 shadow arena (same offsets as
+ * params); w_scales: DEVICE fp32 [depth][4] = quantisation scales of {qkv, proj, fc1, fc2}.weight of each block; act_scales: HOST
+ * fp32 [3] = static scales of {LayerNorm+modulate output, attention output, gelu(fc1)}; workspace_e4m3: sfron_dit_fp8_workspace_bytes.
+ * Saves the same bf16 activations as sfron_dit_forward, so sfron_dit_backward follows unchanged (straight-through estimator).
+ * Returns SFRON_ERR_UNSUPPORTED when a block GEMM shape is not a multiple of the fp8 tile (sfron_fp8_gemm_supported). */
+int64_t sfron_dit_fp8_workspace_bytes(const sfron_dit_cfg* cfg);
+int sfron_dit_forward_fp8(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const uint8_t* params_e4m3,
+                          const float* w_scales, const float* act_scales, const float* x_t, const int64_t* t, const int64_t* y,
+                          const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out, void* stream);
 /* Same as sfron_dit_forward, with HIP events recorded (on `stream`) around the fc1 GEMM of block 0 -- the
  * dominant kernel class -- into `probe` (may be NULL).  Used by bench.py for the live roofline measurement. */
 int sfron_dit_forward_probed(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,

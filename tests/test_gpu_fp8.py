@@ -1,0 +1,269 @@
+"""GPU parity of BASELINE config 5 -- DiT block GEMMs forward on the CDNA4 fp8 (e4m3) matrix core (csrc/fp8.hip).
+
+The reference has no fp8 path, so there is no reference number to match; what is checked:
+(1) the quantisers against torch.float8_e4m3fn BIT FOR BIT (OCP e4m3fn, RNE, saturating), the per-tensor power-of-two scales
+    against oracle/fp8_ref.py;
+(2) the fp8 GEMM with each epilogue against torch fp32 on the de-quantised operands (products of e4m3 values are exact in fp32:
+    rel-L2 1e-5 on fp32 outputs, one bf16 rounding on bf16 outputs, one e4m3 rounding on the e4m3 output);
+(3) the whole forward pass and three SFR-on iterations against the fake-quantised oracle (oracle/fp8_ref.py: same rounding points,
+    straight-through backward) at the bounds of the bf16 path;
+(4) the TOLERANCE STATEMENT of config 5 against config 3 (the bf16 path): output of DiT-XL/2 within 6e-2 rel-L2, gradient
+    direction cosine > 0.99 -- e4m3 carries 3 mantissa bits (2^-4 relative per operand element)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def test_e4m3_quantisers_bit_exact_vs_torch():
+    from oracle import fp8_ref
+    from sfron import _lib
+    from sfron._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1 << 16, generator=g) * torch.logspace(-4, 3, 1 << 16)             # subnormals ... beyond the 448 maximum
+    x[:8] = torch.tensor([0.0, -0.0, 448.0, -448.0, 449.0, 1e6, 2.0 ** -9, 2.0 ** -10])
+    for scale in (1.0, 8.0, 0.25):
+        out = torch.empty(x.numel(), dtype=torch.uint8, device=DEV)
+        check(L.sfron_cast_e4m3(ptr(x.to(DEV)), 0, x.numel(), scale, ptr(out), stream_ptr()), "cast_e4m3")
+        want = fp8_ref.e4m3_bytes(x, scale)
+        got = out.cpu()
+        # +0 / -0 are the same value; everything else bit for bit
+        assert ((got == want) | (((got & 0x7F) == 0) & ((want & 0x7F) == 0))).all(), (got != want).sum()
+        xb = x.to(torch.bfloat16)
+        check(L.sfron_cast_e4m3(ptr(xb.to(DEV)), 1, x.numel(), scale, ptr(out), stream_ptr()), "cast_e4m3")
+        want = fp8_ref.e4m3_bytes(xb.float(), scale)
+        got = out.cpu()
+        assert ((got == want) | (((got & 0x7F) == 0) & ((want & 0x7F) == 0))).all()
+
+
+def test_weight_quantisation_scales_and_delayed_scaling():
+    from oracle import fp8_ref
+    from sfron import _lib
+    from sfron._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(2)
+    sizes = [4096, 128 * 136, 8, 1024]
+    stds = [0.02, 3.0, 1e-5, 0.0]
+    offs, arena = [], []
+    o = 16
+    for n, sd in zip(sizes, stds):
+        offs.append((o, n)); o += n + 24
+    p = torch.zeros(o)
+    for (off, n), sd in zip(offs, stds):
+        p[off:off + n] = torch.randn(n, generator=g) * sd
+    pd = p.to(DEV)
+    table = torch.tensor(offs, dtype=torch.int64, device=DEV)
+    scales = torch.ones(len(offs), device=DEV)
+    amax = torch.zeros(len(offs), dtype=torch.int32, device=DEV)
+    w8 = torch.full((o,), 0xAA, dtype=torch.uint8, device=DEV)
+    check(L.sfron_fp8_quant_tensors(ptr(pd), ptr(table), len(offs), None, ptr(amax), None, 0, stream_ptr()), "amax")
+    got_amax = amax.view(torch.float32).cpu()
+    for (off, n), a in zip(offs, got_amax):
+        assert a.item() == p[off:off + n].abs().max().item()
+    check(L.sfron_fp8_update_scales(ptr(amax), len(offs), ptr(scales), stream_ptr()), "scales")
+    assert (amax == 0).all()
+    for (off, n), s in zip(offs, scales.cpu()):
+        assert s.item() == fp8_ref.weight_scale(p[off:off + n])
+        assert s.item() == 2.0 ** round(np.log2(s.item()))                      # a power of two
+        if p[off:off + n].abs().max() > 0:
+            assert 112.0 < p[off:off + n].abs().max().item() * s.item() <= 224.0     # 2x headroom under 448
+    check(L.sfron_fp8_quant_tensors(ptr(pd), ptr(table), len(offs), ptr(scales), ptr(amax), ptr(w8), 1, stream_ptr()), "quant")
+    for (off, n), s in zip(offs, scales.cpu()):
+        want = fp8_ref.e4m3_bytes(p[off:off + n], s.item())
+        got = w8[off:off + n].cpu()
+        assert ((got == want) | (((got & 0x7F) == 0) & ((want & 0x7F) == 0))).all()
+    assert (w8[:16] == 0xAA).all() and (w8[offs[0][0] + sizes[0]:offs[1][0]] == 0xAA).all()      # padding between tensors untouched
+    assert torch.equal(amax.view(torch.float32).cpu(), got_amax)                  # the quantising pass collected the amax again
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (512, 384, 256), (8192, 1152, 1152)])
+def test_fp8_gemm_epilogues_vs_torch(M, N, K):
+    import ctypes
+    from oracle import fp8_ref
+    from sfron import _lib
+    from sfron._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    assert L.sfron_fp8_gemm_supported(M, N, K) == 1 and L.sfron_fp8_gemm_supported(M, N + 64, K) == 0
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    sa, sw, sh = 8.0, 1024.0, 16.0
+    X = torch.randn(M, K, device=DEV, generator=g) * 1.5
+    W = torch.randn(N, K, device=DEV, generator=g) * 0.03
+    bias = torch.randn(N, device=DEV, generator=g) * 0.1
+    A8, B8 = torch.empty(M, K, dtype=torch.uint8, device=DEV), torch.empty(N, K, dtype=torch.uint8, device=DEV)
+    check(L.sfron_cast_e4m3(ptr(X), 0, X.numel(), sa, ptr(A8), stream_ptr()), "cast")
+    check(L.sfron_cast_e4m3(ptr(W), 0, W.numel(), sw, ptr(B8), stream_ptr()), "cast")
+    Xq = A8.view(torch.float8_e4m3fn).float() / sa
+    Wq = B8.view(torch.float8_e4m3fn).float() / sw
+    want = Xq @ Wq.t() + bias
+    wsc = torch.tensor([sw], device=DEV)
+
+    def desc(epi):
+        d = _lib.Fp8GemmDesc()
+        d.A, d.B, d.M, d.N, d.K = A8.data_ptr(), B8.data_ptr(), M, N, K
+        d.w_scale, d.a_scale, d.epilogue, d.bias, d.tokens = wsc.data_ptr(), sa, epi, bias.data_ptr(), 64
+        return d
+    # plain bf16 output
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    d = desc(_lib.EPI_BF16); d.c_bf16, d.ldc_bf16 = C.data_ptr(), N
+    check(L.sfron_fp8_gemm(ctypes.byref(d), stream_ptr()), "fp8_gemm")
+    assert _rel(C, want) < 3e-3 and torch.allclose(C.float(), want, rtol=1e-2, atol=1e-2 * want.abs().max().item())
+    # GELU: pre-activation, bf16 h, e4m3 h
+    H, HP = torch.empty(M, N, dtype=torch.bfloat16, device=DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    H8 = torch.empty(M, N, dtype=torch.uint8, device=DEV)
+    d = desc(_lib.EPI_GELU); d.c_bf16, d.ldc_bf16, d.aux, d.ldaux, d.c_e4m3, d.c_e4m3_scale = H.data_ptr(), N, HP.data_ptr(), N, H8.data_ptr(), sh
+    check(L.sfron_fp8_gemm(ctypes.byref(d), stream_ptr()), "fp8_gemm")
+    hw = torch.nn.functional.gelu(want, approximate="tanh")
+    assert _rel(HP, want) < 3e-3 and _rel(H, hw) < 4e-3
+    assert _rel(H8.view(torch.float8_e4m3fn).float() / sh, hw) < 4e-2                 # one e4m3 rounding (2^-4 per element)
+    # gated residual
+    Tk = 64
+    gate = torch.randn(M // Tk, N, device=DEV, generator=g)
+    resid = torch.randn(M, N, device=DEV, generator=g)
+    x1, a1 = torch.empty(M, N, device=DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    d = desc(_lib.EPI_GATE_RES); d.c_f32, d.ldc_f32, d.resid, d.aux, d.ldaux, d.gate, d.ldgate = x1.data_ptr(), N, resid.data_ptr(), a1.data_ptr(), N, gate.data_ptr(), N
+    check(L.sfron_fp8_gemm(ctypes.byref(d), stream_ptr()), "fp8_gemm")
+    assert _rel(a1, want) < 3e-3
+    assert _rel(x1, resid + gate.repeat_interleave(Tk, 0) * want) < 2e-5
+
+
+CFG = dict(input_size=16, patch_size=2, in_channels=4, hidden_size=128, depth=2, num_heads=2, num_classes=10)     # 64 tokens; batch 4 -> M = 256
+
+
+def _pair(cfg, batch, seed, std=0.05):
+    from oracle import dit_ref, fp8_ref
+    from sfron import dit
+    torch.manual_seed(seed)
+    ref = dit_ref.DiT(**cfg)
+    dit_ref.randomize_zero_init(ref, std=std, seed=seed + 1)
+    model = dit.DiT(batch_size=batch, **cfg)
+    model.load_state_dict(ref.state_dict())
+    model.engine.enable_fp8()
+    fq = fp8_ref.apply_fake_quant(copy.deepcopy(ref))
+    return ref, fq, model
+
+
+def _pin_scales(fq, eng):
+    """hand the oracle the weight scales the HIP path is using (delayed scaling may lag a power of two behind the fresh amax)"""
+    sc = eng.fp8["scales"].cpu().view(-1, 4)
+    for l, blk in enumerate(fq.blocks):
+        for i, lin in enumerate((blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2)):
+            lin.w_scale_override = float(sc[l, i])
+
+
+def test_fp8_forward_backward_vs_fake_quant_oracle():
+    from oracle import fp8_ref
+    B = 4
+    ref, fq, model = _pair(CFG, B, seed=3)
+    eng = model.engine
+    sc = eng.fp8["scales"].cpu().view(-1, 4)
+    for l, blk in enumerate(ref.blocks):            # fresh scales = the oracle's rule
+        for i, lin in enumerate((blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2)):
+            assert float(sc[l, i]) == fp8_ref.weight_scale(lin.weight)
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(B, 4, 16, 16, generator=gen)
+    t, y, drop = torch.tensor([0, 999, 17, 500]), torch.tensor([1, 9, 4, 4]), torch.tensor([0, 1, 0, 0])
+    w = torch.randn(B, 8, 16, 16, generator=gen) * 0.1
+    fq.train(); ref.train(); model.train()
+    out_q = fq(x, t, y, force_drop_ids=drop)
+    (out_q * w).sum().backward()
+    out_fp32 = ref(x, t, y, force_drop_ids=drop)
+    out = model(x.to(DEV), t.to(DEV), y.to(DEV), force_drop_ids=drop.to(DEV))
+    e_q, e_32 = _rel(out, out_q), _rel(out, out_fp32)
+    print(f"fp8 forward: vs fake-quant oracle {e_q:.3e}, vs fp32 oracle {e_32:.3e} (fake-quant vs fp32 {_rel(out_q, out_fp32):.3e})")
+    assert e_q < 1.5e-2, e_q                         # same rounding points: what is left is the bf16 rounding of everything else
+    model.zero_grad()
+    (out * w.to(DEV)).sum().backward()
+    gm = torch.cat([p.grad.flatten().cpu() for _, p in model.named_parameters() if p.grad is not None])
+    gr = torch.cat([q.grad.flatten() for _, q in fq.named_parameters() if q.grad is not None])
+    cos = (torch.dot(gm, gr) / (gm.norm() * gr.norm())).item()
+    assert cos > 0.999, cos
+    for (n, p), (_, q) in zip(model.named_parameters(), fq.named_parameters()):
+        if q.grad is not None and not n.endswith("attn.qkv.bias"):
+            assert _rel(p.grad, q.grad) < 6e-2, (n, _rel(p.grad, q.grad))
+
+
+def test_fp8_sfron_iterations_vs_fake_quant_oracle():
+    from oracle import diffusion_ref as dref
+    from oracle import sfron_ref
+    from sfron import data, diffusion, step
+    B = 4
+    ref, fq, model = _pair(CFG, B, seed=7)
+    model.train()
+    gm = torch.Generator().manual_seed(5)
+    mask = {"module." + n: (torch.rand(p.shape, generator=gm) < 0.5) for n, p in fq.named_parameters() if p.requires_grad}
+    mask["module.pos_embed"] = 0
+    hp = dict(lr=2e-4, forget_alpha=0.3, grad_clip=1.0, ema_decay=0.99, mask=mask, unlearn_loss="ga", forget_class=3)
+    orc = sfron_ref.DiTSfronOracle(fq, dref.DiffusionTables(1000), **hp)
+    runner = step.DiTSFRon(model, diffusion.create_diffusion(""), fp8=True, **hp)
+    p0 = {n: p.detach().clone() for n, p in fq.named_parameters()}
+    kw = dict(global_batch=B, num_classes=10, forget_class=3, input_size=16)
+    w8_before = model.engine.fp8["w8"].clone()
+    for it in range(3):
+        f, r = data.synthetic_batch(9, it, "forget", **kw), data.synthetic_batch(9, it, "remain", **kw)
+        _pin_scales(fq, model.engine)
+        want = orc.step({k: v.long() if k == "drop" else v for k, v in f.items()}, {k: v.long() if k == "drop" else v for k, v in r.items()})
+        got = runner.step({k: v.to(DEV) for k, v in f.items()}, {k: v.to(DEV) for k, v in r.items()})
+        assert got["forget_mse"].mean().item() == pytest.approx(want["forget_mse"], rel=3e-2)
+        assert got["remain_mse"].mean().item() == pytest.approx(want["remain_mse"], rel=3e-2)
+        assert got["stats"][0].item() == pytest.approx(want["forget_gnorm"], rel=6e-2)
+    runner.guard.poll(block=True)
+    eng = model.engine
+    assert not torch.equal(eng.fp8["w8"], w8_before)              # the e4m3 shadow follows the optimizer
+    same = tot = 0
+    for n, q in fq.named_parameters():
+        if not q.requires_grad or n.endswith("attn.qkv.bias"):
+            continue
+        du_ref, du = (q.detach() - p0[n]).flatten(), (eng.view(eng.params, n).cpu() - p0[n]).flatten()
+        big = du_ref.abs() > 0.05 * du_ref.abs().max()
+        same += int((torch.sign(du[big]) == torch.sign(du_ref[big])).sum()); tot += int(big.sum())
+    assert same / tot > 0.97, same / tot
+    # the shadow is the e4m3 image of the CURRENT masters under the scales in use
+    from oracle import fp8_ref
+    lay = eng.layout
+    off = lay["blocks"] + lay["fc1_w"]
+    n = eng.cfg.mlp_hidden * eng.cfg.hidden
+    want8 = fp8_ref.e4m3_bytes(eng.params[off:off + n].cpu(), float(eng.fp8["scales"][2]))
+    got8 = eng.fp8["w8"][off:off + n].cpu()
+    assert ((got8 == want8) | (((got8 & 0x7F) == 0) & ((want8 & 0x7F) == 0))).all()
+
+
+def test_config5_tolerance_against_config3_dit_xl2():
+    """The tolerance statement: DiT-XL/2 (28 blocks, 256 tokens), batch 4, same weights and inputs through the fp8 forward (config 5)
+    and the bf16 forward (config 3)."""
+    from sfron import dit
+    B = 4
+    model = dit.DiT_models["DiT-XL/2"](input_size=32, num_classes=1000, batch_size=B)
+    torch.manual_seed(11)
+    model.initialize_weights()
+    dit.randomize_zero_init(model, std=0.02, seed=12)
+    model.train()
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn(B, 4, 32, 32, generator=gen).to(DEV)
+    t, y = torch.tensor([0, 999, 17, 500], device=DEV), torch.tensor([1, 900, 207, 4], device=DEV)
+    drop = torch.zeros(B, dtype=torch.uint8, device=DEV)
+    w = (torch.randn(B, 8, 32, 32, generator=gen) * 0.01).to(DEV)
+
+    def run():
+        out = model(x, t, y, force_drop_ids=drop)
+        model.zero_grad()
+        (out * w).sum().backward()
+        return out.detach().clone(), torch.cat([p.grad.flatten() for _, p in model.named_parameters() if p.grad is not None]).clone()
+    out3, g3 = run()
+    model.engine.enable_fp8()
+    out5, g5 = run()
+    e = _rel(out5, out3)
+    cos = (torch.dot(g5, g3) / (g5.norm() * g3.norm())).item()
+    print(f"config 5 vs config 3, DiT-XL/2 batch {B}: output rel-L2 {e:.3e}, gradient cosine {cos:.5f}, gradient rel-L2 {_rel(g5, g3):.3e}")
+    assert torch.isfinite(out5).all() and torch.isfinite(g5).all()
+    assert e < 6e-2, e
+    assert cos > 0.99, cos

@@ -279,18 +279,58 @@ int sfron_probe_destroy(void* probe) {
   return SFRON_OK;
 }
 
-int sfron_dit_forward_probed(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
-                             const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
-                             void* probe, void* stream);
+// config 5: e4m3 weight shadow + scales + the e4m3 activation scratch of ONE block (only the forward GEMMs read them)
+struct Fp8Ctx {
+  const uint8_t* w8; const float* w_scales; float s_x, s_o, s_h;
+  uint8_t *xmod8, *o8, *h8;
+};
+static size_t fp8_ws(const Dims& d, char* base, Fp8Ctx* f) {
+  size_t o = 0;
+  auto take = [&](size_t bytes) { char* r = base ? base + o : nullptr; o += (bytes + 255) / 256 * 256; return r; };
+  uint8_t* a = (uint8_t*)take((size_t)d.M * d.D); uint8_t* b = (uint8_t*)take((size_t)d.M * d.D); uint8_t* c = (uint8_t*)take((size_t)d.M * d.F);
+  if (f) { f->xmod8 = a; f->o8 = b; f->h8 = c; }
+  return o;
+}
+
+static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
+                            const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
+                            void* probe, const Fp8Ctx* f8, void* stream);
 
 int sfron_dit_forward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
                       const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out, void* stream) {
-  return sfron_dit_forward_probed(cfg, params, params_bf16, x_t, t, y, drop, workspace, out, nullptr, stream);
+  return dit_forward_impl(cfg, params, params_bf16, x_t, t, y, drop, workspace, out, nullptr, nullptr, stream);
 }
 
 int sfron_dit_forward_probed(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
                              const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
                              void* probe, void* stream) {
+  return dit_forward_impl(cfg, params, params_bf16, x_t, t, y, drop, workspace, out, probe, nullptr, stream);
+}
+
+int64_t sfron_dit_fp8_workspace_bytes(const sfron_dit_cfg* cfg) {
+  Dims d;
+  if (make_dims(cfg, d) != SFRON_OK) return -1;
+  return (int64_t)fp8_ws(d, nullptr, nullptr);
+}
+
+int sfron_dit_forward_fp8(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const uint8_t* params_e4m3,
+                          const float* w_scales, const float* act_scales, const float* x_t, const int64_t* t, const int64_t* y,
+                          const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out, void* stream) {
+  Dims d;
+  RUN(make_dims(cfg, d));
+  SFRON_CHECK_ARG(params_e4m3 && w_scales && act_scales && workspace_e4m3);
+  SFRON_CHECK_ARG(act_scales[0] > 0.f && act_scales[1] > 0.f && act_scales[2] > 0.f);
+  if (!sfron_fp8_gemm_supported(d.M, 3 * d.D, d.D) || !sfron_fp8_gemm_supported(d.M, d.D, d.D) || !sfron_fp8_gemm_supported(d.M, d.F, d.D) ||
+      !sfron_fp8_gemm_supported(d.M, d.D, d.F))
+    return SFRON_ERR_UNSUPPORTED;
+  Fp8Ctx f{params_e4m3, w_scales, act_scales[0], act_scales[1], act_scales[2], nullptr, nullptr, nullptr};
+  (void)fp8_ws(d, (char*)workspace_e4m3, &f);
+  return dit_forward_impl(cfg, params, params_bf16, x_t, t, y, drop, workspace, out, nullptr, &f, stream);
+}
+
+static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
+                            const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
+                            void* probe, const Fp8Ctx* f8, void* stream) {
   Dims d;
   RUN(make_dims(cfg, d));
   SFRON_CHECK_ARG(params && params_bf16 && x_t && t && y && workspace && out);
@@ -330,6 +370,38 @@ int sfron_dit_forward_probed(const sfron_dit_cfg* cfg, const float* params, cons
     __bf16* o = w.o + (size_t)l * M * D; __bf16* a1 = w.a1 + (size_t)l * M * D;
     __bf16* xmod2 = w.xmod2 + (size_t)l * M * D; __bf16* hpre = w.hpre + (size_t)l * M * d.F;
     __bf16* h = w.h + (size_t)l * M * d.F; __bf16* a2 = w.a2 + (size_t)l * M * D;
+    if (f8) {
+      // config 5: the same block with its four products on the fp8 matrix core.  Every bf16 tensor the backward pass reads is
+      // written exactly as in the bf16 path; the e4m3 copies (xmod8, o8, h8) live only until the next block overwrites them.
+      const float* ws = f8->w_scales + (size_t)l * 4;
+      auto g8 = [&](const uint8_t* A, int64_t w_off, int N, int K, const float* wsc, float asc, int epi) {
+        sfron_fp8_gemm_desc q{};
+        q.A = A; q.B = f8->w8 + w_off; q.M = M; q.N = N; q.K = K; q.w_scale = wsc; q.a_scale = asc; q.epilogue = epi; q.tokens = T;
+        return q;
+      };
+      RUN(sfron_ln_modulate_fwd_q(x0, mod, mod + D, NM, T, M, D, (uint16_t*)xmod1, f8->xmod8, f8->s_x, w.mean + (size_t)(2 * l) * M,
+                                  w.rstd + (size_t)(2 * l) * M, stream));
+      sfron_fp8_gemm_desc q = g8(f8->xmod8, pb + P.o_qkv_w, 3 * D, D, ws + 0, f8->s_x, SFRON_EPI_BF16);
+      q.bias = params + pb + P.o_qkv_b; q.c_bf16 = (uint16_t*)qkv; q.ldc_bf16 = 3 * D;
+      RUN(sfron_fp8_gemm(&q, stream));
+      RUN(sfron_attn_fwd((const uint16_t*)qkv, (uint16_t*)o, w.lse + (size_t)l * d.B * d.H * T, d.B, T, d.H, d.hd, stream));
+      RUN(sfron_cast_e4m3(o, 1, (int64_t)M * D, f8->s_o, f8->o8, stream));
+      q = g8(f8->o8, pb + P.o_proj_w, D, D, ws + 1, f8->s_o, SFRON_EPI_GATE_RES);
+      q.bias = params + pb + P.o_proj_b; q.c_f32 = x1; q.ldc_f32 = D; q.resid = x0; q.aux = (uint16_t*)a1; q.ldaux = D;
+      q.gate = mod + 2 * D; q.ldgate = NM;
+      RUN(sfron_fp8_gemm(&q, stream));
+      RUN(sfron_ln_modulate_fwd_q(x1, mod + 3 * D, mod + 4 * D, NM, T, M, D, (uint16_t*)xmod2, f8->xmod8, f8->s_x,
+                                  w.mean + (size_t)(2 * l + 1) * M, w.rstd + (size_t)(2 * l + 1) * M, stream));
+      q = g8(f8->xmod8, pb + P.o_fc1_w, d.F, D, ws + 2, f8->s_x, SFRON_EPI_GELU);
+      q.bias = params + pb + P.o_fc1_b; q.c_bf16 = (uint16_t*)h; q.ldc_bf16 = d.F; q.aux = (uint16_t*)hpre; q.ldaux = d.F;
+      q.c_e4m3 = f8->h8; q.c_e4m3_scale = f8->s_h;
+      RUN(sfron_fp8_gemm(&q, stream));
+      q = g8(f8->h8, pb + P.o_fc2_w, D, d.F, ws + 3, f8->s_h, SFRON_EPI_GATE_RES);
+      q.bias = params + pb + P.o_fc2_b; q.c_f32 = x2; q.ldc_f32 = D; q.resid = x1; q.aux = (uint16_t*)a2; q.ldaux = D;
+      q.gate = mod + 5 * D; q.ldgate = NM;
+      RUN(sfron_fp8_gemm(&q, stream));
+      continue;
+    }
     // x = x + gate_msa * attn(modulate(norm1(x), shift_msa, scale_msa))   (models.py:120)
     RUN(sfron_ln_modulate_fwd(x0, mod, mod + D, NM, T, M, D, (uint16_t*)xmod1, w.mean + (size_t)(2 * l) * M,
                               w.rstd + (size_t)(2 * l) * M, stream));

@@ -1,0 +1,357 @@
+// BASELINE config 5: the four token GEMMs of a DiT block (DiT/models.py:108-121 forward) on the CDNA4 fp8 matrix core.
+//
+// Both MFMA operands must be fp8 (v_mfma_scale_f32_16x16x128_f8f6f4 has no bf16 x fp8 form, and a bf16 A tile of a 128-deep step
+// would not fit a ring in LDS), so
+//   weights      live as fp32 masters (the optimizer's arena) + an e4m3 shadow, one power-of-two scale per tensor
+//                (scale = 2^floor(log2(224 / amax)): exact to apply and to undo, 2x headroom under the 448 maximum), re-quantised
+//                after every optimizer step in ONE pass with the scale of the previous step's amax (delayed scaling: a weight moves
+//                by at most lr per step) while the pass collects the new amax (integer atomicMax on the float bits: order-free);
+//   activations  are quantised where they are PRODUCED, with static power-of-two scales per kind: LayerNorm+modulate writes its
+//                bf16 output (the backward pass's operand) and the e4m3 copy, the fc1 epilogue writes h in bf16 and e4m3, the
+//                attention output gets one cast kernel.
+// The backward pass is unchanged (bf16 operands, bf16 weight shadow): the quantisation is a straight-through estimator, as in
+// oracle/fp8_ref.py.  e4m3 = OCP e4m3fn (gfx950's v_cvt_pk_fp8_f32), round to nearest even, saturating at +-448.
+//
+// GEMM kernel: C[M][N] = deq * (A8[M][K] . B8[N][K]^T) with the 256 x 128 x 128-byte tile of tools/probes/fp8_gemm_probe.hip
+// (three LDS slots, both operands staged by buffer_load ... lds with the XOR swizzle on the source address, 8 waves of 32 x 128;
+// exact-integer verified there), plus the epilogues the block needs: bias -> bf16 (qkv); bias, GELU-tanh, pre-activation + bf16 + e4m3
+// outputs (fc1); bias, gate, residual -> fp32 stream + bf16 branch output (proj, fc2).
+#include "common.h"
+#include "../../include/sfron.h"
+#include <atomic>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((address_space(3))) void lptr8_t;
+
+constexpr float E4M3_MAX = 448.0f;
+constexpr int TPB = 256;
+
+__device__ __forceinline__ float sat8(float x) { return fminf(fmaxf(x, -E4M3_MAX), E4M3_MAX); }
+// four fp32 -> four e4m3 bytes (little endian: a in bits 0..7)
+__device__ __forceinline__ uint32_t pack_e4m3(float a, float b, float c, float d) {
+  int v = 0;
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(sat8(a), sat8(b), v, false);
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(sat8(c), sat8(d), v, true);
+  return (uint32_t)v;
+}
+
+// ---------------------------------------------------------------- weights: per-tensor amax / quantisation
+struct TensorRange { long long off, n; };   // element range of one tensor inside the arena (off, n multiples of 8)
+
+// mode 0: amax only.  mode 1: dst = e4m3(p * scale[t]) AND amax.  grid (chunks, tensors)
+__global__ __launch_bounds__(TPB) void k_fp8_quant_tensors(const float* __restrict__ p, const TensorRange* __restrict__ tab,
+                                                           const float* __restrict__ scales, unsigned* __restrict__ amax_bits,
+                                                           uint8_t* __restrict__ dst, int mode) {
+  const int t = blockIdx.y;
+  const TensorRange r = tab[t];
+  const float s = mode ? scales[t] : 1.0f;
+  const float4* src = reinterpret_cast<const float4*>(p + r.off);
+  uint32_t* out = reinterpret_cast<uint32_t*>(dst + r.off);
+  const long long n4 = r.n >> 2;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long long)gridDim.x * TPB) {
+    const float4 v = src[i];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    if (mode) out[i] = pack_e4m3(v.x * s, v.y * s, v.z * s, v.w * s);
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits + t, __float_as_uint(m));   // non-negative floats order like their bits
+}
+
+// scale = 2^floor(log2(224 / amax)) (1 for an all-zero tensor); amax is cleared for the next pass
+__global__ void k_fp8_update_scales(unsigned* __restrict__ amax_bits, int n, float* __restrict__ scales) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const float a = __uint_as_float(amax_bits[t]);
+  float s = 1.0f;
+  if (a > 0.f && isfinite(a)) {
+    int e;
+    (void)frexpf(224.0f / a, &e);            // 224 / a = f * 2^e, f in [0.5, 1)  ->  floor(log2) = e - 1
+    e -= 1;
+    e = e < -60 ? -60 : (e > 60 ? 60 : e);
+    s = ldexpf(1.0f, e);
+  }
+  scales[t] = s;
+  amax_bits[t] = 0u;
+}
+
+__global__ __launch_bounds__(TPB) void k_cast_e4m3_bf16(const __bf16* __restrict__ src, int64_t n, float scale, uint8_t* __restrict__ dst) {
+  const int64_t n8 = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (int64_t)gridDim.x * TPB) {
+    const bf16x8 v = reinterpret_cast<const bf16x8*>(src)[i];
+    uint2 o;
+    o.x = pack_e4m3(bf2f(v[0]) * scale, bf2f(v[1]) * scale, bf2f(v[2]) * scale, bf2f(v[3]) * scale);
+    o.y = pack_e4m3(bf2f(v[4]) * scale, bf2f(v[5]) * scale, bf2f(v[6]) * scale, bf2f(v[7]) * scale);
+    reinterpret_cast<uint2*>(dst)[i] = o;
+  }
+}
+__global__ __launch_bounds__(TPB) void k_cast_e4m3_f32(const float* __restrict__ src, int64_t n, float scale, uint8_t* __restrict__ dst) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    reinterpret_cast<uint32_t*>(dst)[i] = pack_e4m3(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+  }
+}
+
+// ---------------------------------------------------------------- LayerNorm + modulate with the e4m3 copy (norm.hip's k_ln_mod_fwd + one store)
+constexpr int NCHQ = 5;            // row chunks of 256 floats: D <= 1280
+__global__ __launch_bounds__(TPB) void k_ln_mod_fwd_q(const float* __restrict__ x, const float* __restrict__ shift,
+                                                      const float* __restrict__ scale, int ldmod, int T, int M, int D,
+                                                      __bf16* __restrict__ out, uint8_t* __restrict__ out8, float s8,
+                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  const int D4 = D >> 2;
+  float4 v[NCHQ];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCHQ; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < D4 ? reinterpret_cast<const float4*>(x + (size_t)row * D)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += v[i].x + v[i].y + v[i].z + v[i].w;
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCHQ; ++i) {
+    if (lane + 64 * i < D4) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += a * a + b * b + c * c + d * d;
+    }
+  }
+  const float var = wave_sum(q) / (float)D;
+  const float rstd = 1.0f / sqrtf(var + 1e-6f);
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+  const int b = row / T;
+  const float* sh = shift + (size_t)b * ldmod;
+  const float* sc = scale + (size_t)b * ldmod;
+#pragma unroll
+  for (int i = 0; i < NCHQ; ++i) {
+    const int c = lane + 64 * i;
+    if (c < D4) {
+      const float4 h = reinterpret_cast<const float4*>(sh)[c];
+      const float4 g = reinterpret_cast<const float4*>(sc)[c];
+      const float o0 = (v[i].x - mean) * rstd * (1.0f + g.x) + h.x, o1 = (v[i].y - mean) * rstd * (1.0f + g.y) + h.y;
+      const float o2 = (v[i].z - mean) * rstd * (1.0f + g.z) + h.z, o3 = (v[i].w - mean) * rstd * (1.0f + g.w) + h.w;
+      bf16x4 o = {f2bf(o0), f2bf(o1), f2bf(o2), f2bf(o3)};
+      reinterpret_cast<bf16x4*>(out + (size_t)row * D)[c] = o;
+      reinterpret_cast<uint32_t*>(out8 + (size_t)row * D)[c] = pack_e4m3(o0 * s8, o1 * s8, o2 * s8, o3 * s8);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- fp8 x fp8 GEMM
+struct Gemm8Args {
+  const uint8_t* A; const uint8_t* B;     // [M][K], [N][K] e4m3
+  int M, N, K;
+  const float* w_scale;                   // device scalar: the weight tensor's quantisation scale
+  float a_scale;                          // the activation's (static)
+  const float* bias;                      // [N] fp32 or null
+  __bf16* Cb; int ldcb;                   // bf16 output (EPI_BF16: result; EPI_GELU: gelu(result))
+  __bf16* aux; int ldaux;                 // EPI_GELU: pre-activation; EPI_GATE_RES: branch output
+  uint8_t* C8; float c8_scale;            // EPI_GELU: e4m3(gelu(result) * c8_scale) -- the A operand of fc2
+  float* Cf; int ldcf; const float* resid;      // EPI_GATE_RES: Cf = resid + gate * result
+  const float* gate; int ldgate; int T;
+};
+enum { E8_BF16 = 0, E8_GELU = 2, E8_GATE_RES = 3 };
+
+constexpr int FBM = 256, FBN = 128, BKB = 128, NW = 8, NSLOT8 = 3, NT8 = FBN / 16;
+constexpr int A_BYTES = FBM * BKB, B_BYTES = FBN * BKB, SLOT = A_BYTES + B_BYTES;
+constexpr int NA = FBM * 8 / 64 / NW, NB = FBN * 8 / 64 / NW, NDMA8 = NA + NB;
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void dma16b(__amdgpu_buffer_rsrc_t rsrc, uint8_t* dst, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr8_t*)dst, 16, voff, soff, 0, 0);
+}
+// 32 consecutive k-bytes of row `row`, k group g: chunks 2g and 2g + 1 of the 128-byte row, chunk ^= row & 7
+__device__ __forceinline__ i32x8 frag32(const uint8_t* img, int row, int g) {
+  const i32x4 lo = *reinterpret_cast<const i32x4*>(img + row * 128 + (((2 * g) ^ (row & 7)) << 4));
+  const i32x4 hi = *reinterpret_cast<const i32x4*>(img + row * 128 + (((2 * g + 1) ^ (row & 7)) << 4));
+  return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+}  // namespace
+
+template <int EPI>
+__global__ __launch_bounds__(512) void k_gemm8(Gemm8Args g) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = g.N / FBN;
+  int id;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x, q = nblk >> 3, r = nblk & 7, x = b & 7, y = b >> 3;
+    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+  }
+  const int tm = id / ntn, tn = id - tm * ntn, m0 = tm * FBM, n0 = tn * FBN;
+  const int K = g.K, nk = K / BKB;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, g.M * K, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, g.N * K, 0x00020000);
+  const int lc16 = ((lane & 7) ^ ((lane >> 3) & 7)) << 4;
+  int a_off[NA], b_off[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) a_off[i] = (m0 + (wave + i * NW) * 8 + (lane >> 3)) * K + lc16;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) b_off[i] = (n0 + (wave + i * NW) * 8 + (lane >> 3)) * K + lc16;
+  auto issue = [&](int slot, int k0) {
+    uint8_t* iA = smem8 + slot * SLOT;
+    uint8_t* iB = iA + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) dma16b(rsA, iA + (wave + i * NW) * 1024, a_off[i], k0);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) dma16b(rsB, iB + (wave + i * NW) * 1024, b_off[i], k0);
+  };
+  f32x4 acc[2][NT8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fg = lane >> 4;
+  // this lane's output columns: bias fetched ahead of the main loop
+  float4 bias_v[NT8];
+#pragma unroll
+  for (int nt = 0; nt < NT8; ++nt)
+    bias_v[nt] = g.bias ? *reinterpret_cast<const float4*>(g.bias + n0 + nt * 16 + 4 * fg) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float deq = 1.0f / (g.a_scale * *g.w_scale);
+  if (nk > 0) issue(0, 0);
+  if (nk > 1) issue(1, BKB);
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) wait_vm<NDMA8>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) issue(slot >= 1 ? slot - 1 : 2, (kt + 2) * BKB);
+    const uint8_t* iA = smem8 + slot * SLOT;
+    const uint8_t* iB = iA + A_BYTES;
+    const i32x8 fa0 = frag32(iA, wave * 32 + fr, fg), fa1 = frag32(iA, wave * 32 + 16 + fr, fg);
+#pragma unroll
+    for (int nt = 0; nt < NT8; ++nt) {
+      const i32x8 fb = frag32(iB, nt * 16 + fr, fg);
+      // cbsz = blgp = 0: both operands e4m3; block scales 2^(127 - 127) = 1 (the tensor scales are undone in the epilogue)
+      acc[0][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb, fa0, acc[0][nt], 0, 0, 0, 127, 0, 127);
+      acc[1][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb, fa1, acc[1][nt], 0, 0, 0, 127, 0, 127);
+    }
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  // lane holds C[m0 + 32 wave + 16 mt + fr][n0 + 16 nt + 4 fg .. +3]
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int row = m0 + wave * 32 + mt * 16 + fr;
+#pragma unroll
+    for (int nt = 0; nt < NT8; ++nt) {
+      const int col = n0 + nt * 16 + 4 * fg;
+      f32x4 v = acc[mt][nt] * deq;
+      v[0] += bias_v[nt].x; v[1] += bias_v[nt].y; v[2] += bias_v[nt].z; v[3] += bias_v[nt].w;
+      if constexpr (EPI == E8_BF16) {
+        *reinterpret_cast<bf16x4*>(g.Cb + (size_t)row * g.ldcb + col) = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+      } else if constexpr (EPI == E8_GELU) {
+        *reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col) = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        const float h0 = gelu_tanh(v[0]), h1 = gelu_tanh(v[1]), h2 = gelu_tanh(v[2]), h3 = gelu_tanh(v[3]);
+        *reinterpret_cast<bf16x4*>(g.Cb + (size_t)row * g.ldcb + col) = bf16x4{f2bf(h0), f2bf(h1), f2bf(h2), f2bf(h3)};
+        *reinterpret_cast<uint32_t*>(g.C8 + (size_t)row * g.N + col) = pack_e4m3(h0 * g.c8_scale, h1 * g.c8_scale, h2 * g.c8_scale, h3 * g.c8_scale);
+      } else {
+        *reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col) = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        const float4 gt = *reinterpret_cast<const float4*>(g.gate + (size_t)(row / g.T) * g.ldgate + col);
+        float4 x = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldcf + col);
+        x.x += gt.x * v[0]; x.y += gt.y * v[1]; x.z += gt.z * v[2]; x.w += gt.w * v[3];
+        *reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col) = x;
+      }
+    }
+  }
+}
+template __global__ void k_gemm8<E8_BF16>(Gemm8Args);
+template __global__ void k_gemm8<E8_GELU>(Gemm8Args);
+template __global__ void k_gemm8<E8_GATE_RES>(Gemm8Args);
+
+namespace {
+template <int EPI>
+int launch8(const Gemm8Args& g, hipStream_t s) {
+  const size_t lds = (size_t)NSLOT8 * SLOT;
+  static std::atomic<uint64_t> done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if ((done.fetch_or(bit) & bit) == 0) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return (int)hipGetLastError();
+  }
+  hipLaunchKernelGGL((k_gemm8<EPI>), dim3((g.M / FBM) * (g.N / FBN)), dim3(512), lds, s, g);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SFRON_OK : (int)e;
+}
+inline int grid_for(int64_t items) { int64_t b = (items + TPB - 1) / TPB; return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
+}  // namespace
+
+extern "C" {
+
+int sfron_fp8_gemm_supported(int M, int N, int K) { return (M > 0 && N > 0 && K > 0 && M % FBM == 0 && N % FBN == 0 && K % BKB == 0) ? 1 : 0; }
+
+int sfron_fp8_gemm(const sfron_fp8_gemm_desc* d, void* stream) {
+  SFRON_CHECK_ARG(d && d->A && d->B && d->w_scale && d->a_scale > 0.f);
+  if (!sfron_fp8_gemm_supported(d->M, d->N, d->K)) return SFRON_ERR_UNSUPPORTED;
+  SFRON_CHECK_ARG((long)d->M * d->K < (1L << 31) && (long)d->N * d->K < (1L << 31));        // 32-bit buffer offsets
+  SFRON_CHECK_ARG((((uintptr_t)d->A | (uintptr_t)d->B) & 15) == 0);
+  Gemm8Args g{};
+  g.A = d->A; g.B = d->B; g.M = d->M; g.N = d->N; g.K = d->K; g.w_scale = d->w_scale; g.a_scale = d->a_scale; g.bias = d->bias;
+  g.Cb = (__bf16*)d->c_bf16; g.ldcb = d->ldc_bf16; g.aux = (__bf16*)d->aux; g.ldaux = d->ldaux; g.C8 = d->c_e4m3; g.c8_scale = d->c_e4m3_scale;
+  g.Cf = d->c_f32; g.ldcf = d->ldc_f32; g.resid = d->resid ? d->resid : d->c_f32; g.gate = d->gate; g.ldgate = d->ldgate;
+  g.T = d->tokens > 0 ? d->tokens : 1;
+  hipStream_t s = (hipStream_t)stream;
+  switch (d->epilogue) {
+    case SFRON_EPI_BF16:
+      SFRON_CHECK_ARG(g.Cb && g.ldcb % 4 == 0);
+      return launch8<E8_BF16>(g, s);
+    case SFRON_EPI_GELU:
+      SFRON_CHECK_ARG(g.Cb && g.aux && g.C8 && g.c8_scale > 0.f && g.ldcb % 4 == 0 && g.ldaux % 4 == 0);
+      return launch8<E8_GELU>(g, s);
+    case SFRON_EPI_GATE_RES:
+      SFRON_CHECK_ARG(g.Cf && g.aux && g.gate && g.ldcf % 4 == 0 && g.ldaux % 4 == 0 && g.ldgate % 4 == 0);
+      return launch8<E8_GATE_RES>(g, s);
+    default:
+      return SFRON_ERR_UNSUPPORTED;
+  }
+}
+
+int sfron_fp8_quant_tensors(const float* params, const int64_t* table, int n_tensors, const float* scales, uint32_t* amax_bits,
+                            uint8_t* dst, int mode, void* stream) {
+  SFRON_CHECK_ARG(params && table && amax_bits && n_tensors > 0 && (mode == 0 || (mode == 1 && scales && dst)));
+  SFRON_CHECK_ARG((((uintptr_t)params) & 15) == 0 && (!dst || ((uintptr_t)dst & 3) == 0));
+  static_assert(sizeof(TensorRange) == 2 * sizeof(int64_t), "table layout");
+  hipLaunchKernelGGL(k_fp8_quant_tensors, dim3(64, n_tensors), dim3(TPB), 0, (hipStream_t)stream, params, (const TensorRange*)table, scales,
+                     amax_bits, dst, mode);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_fp8_update_scales(uint32_t* amax_bits, int n_tensors, float* scales, void* stream) {
+  SFRON_CHECK_ARG(amax_bits && scales && n_tensors > 0);
+  hipLaunchKernelGGL(k_fp8_update_scales, dim3(cdiv(n_tensors, 64)), dim3(64), 0, (hipStream_t)stream, amax_bits, n_tensors, scales);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_cast_e4m3(const void* src, int src_is_bf16, int64_t n, float scale, uint8_t* dst, void* stream) {
+  SFRON_CHECK_ARG(src && dst && n >= 0 && n % 8 == 0 && scale > 0.f && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0);
+  if (src_is_bf16)
+    hipLaunchKernelGGL(k_cast_e4m3_bf16, dim3(grid_for(n >> 3)), dim3(TPB), 0, (hipStream_t)stream, (const __bf16*)src, n, scale, dst);
+  else
+    hipLaunchKernelGGL(k_cast_e4m3_f32, dim3(grid_for(n >> 2)), dim3(TPB), 0, (hipStream_t)stream, (const float*)src, n, scale, dst);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_ln_modulate_fwd_q(const float* x, const float* shift, const float* scale, int ldmod, int tokens, int M, int D, uint16_t* out,
+                            uint8_t* out_e4m3, float e4m3_scale, float* mean, float* rstd, void* stream) {
+  SFRON_CHECK_ARG(x && shift && scale && out && out_e4m3 && mean && rstd && M > 0 && tokens > 0 && e4m3_scale > 0.f);
+  SFRON_CHECK_ARG(D % 4 == 0 && D <= 64 * 4 * NCHQ && ldmod % 4 == 0);
+  SFRON_CHECK_ARG((((uintptr_t)x | (uintptr_t)shift | (uintptr_t)scale) & 15) == 0 && ((uintptr_t)out & 7) == 0 && ((uintptr_t)out_e4m3 & 3) == 0);
+  hipLaunchKernelGGL(k_ln_mod_fwd_q, dim3(cdiv(M, 4)), dim3(TPB), 0, (hipStream_t)stream, x, shift, scale, ldmod, tokens, M, D, (__bf16*)out,
+                     out_e4m3, e4m3_scale, mean, rstd);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+}  // extern "C"

@@ -126,6 +126,7 @@ class DiT(nn.Module):
         old = self.engine
         new = DitEngine(batch_size, share=old, grads=old.grads, **self._engine_args)     # same parameter AND gradient arenas
         new.probe, old.probe = old.probe, None
+        new._share_fp8(old)
         old.close()
         self.engine = new
 

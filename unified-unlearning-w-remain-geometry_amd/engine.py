@@ -55,6 +55,7 @@ class DitEngine:
         self.workspace = torch.empty(ws, dtype=torch.uint8, device=self.device)
         self.out_shape = (batch, c.out_channels, input_size, input_size)
         self.probe = self.wprobe = None
+        self.fp8 = None
         h = ctypes.c_void_p()
         check(L.sfron_aux_create(ctypes.byref(h)), "aux_create")     # side stream + events for concurrent wgrads
         self.aux = h
@@ -77,7 +78,9 @@ class DitEngine:
 
     def sibling(self, batch):
         """A second engine over the SAME parameters (own workspace / gradient arena / side stream) for a micro-batch chain."""
-        return DitEngine(batch, share=self, **self._ctor)
+        e = DitEngine(batch, share=self, **self._ctor)
+        e._share_fp8(self)
+        return e
 
     # ------------------------------------------------------------------ names
     def _build_index(self):
@@ -128,6 +131,57 @@ class DitEngine:
 
     def sync_bf16(self):
         check(_lib.lib().sfron_cast_bf16(ptr(self.params), ptr(self.params_bf16), self.n_total, stream_ptr()), "cast_bf16")
+        if getattr(self, "fp8", None) is not None:
+            self.fp8_requantize(fresh=True)
+
+    # ------------------------------------------------------------------ config 5: fp8 (e4m3) forward GEMMs
+    FP8_ACT_SCALES = (8.0, 32.0, 16.0)     # LayerNorm+modulate output, attention output, gelu(fc1): static powers of two
+
+    def enable_fp8(self, act_scales=None):
+        """Run the four token GEMMs of every block's FORWARD pass on the fp8 matrix core (BASELINE config 5): an e4m3 shadow of
+        the block weights with one power-of-two scale per tensor (re-quantised after every optimizer step: fp8_requantize), e4m3
+        activations written by their producers.  The backward pass keeps bf16 operands (straight-through estimator)."""
+        L = _lib.lib()
+        c, lay = self.cfg, self.layout
+        M = c.batch * self.tokens
+        D, F = c.hidden, c.mlp_hidden
+        for N, K in ((3 * D, D), (D, D), (F, D), (D, F)):
+            if not L.sfron_fp8_gemm_supported(M, N, K):
+                raise _lib.SfronError(f"fp8 path: GEMM {M}x{N}x{K} is not a multiple of the 256x128x128 fp8 tile")
+        act = tuple(float(a) for a in (act_scales or self.FP8_ACT_SCALES))
+        rows = []
+        for l in range(c.depth):
+            b = lay["blocks"] + l * lay["blk_stride"]
+            rows += [(b + lay["qkv_w"], 3 * D * D), (b + lay["proj_w"], D * D), (b + lay["fc1_w"], F * D), (b + lay["fc2_w"], D * F)]
+        ws = L.sfron_dit_fp8_workspace_bytes(ctypes.byref(c))
+        self.fp8 = dict(
+            act=(ctypes.c_float * 3)(*act), act_scales=act,
+            table=torch.tensor(rows, dtype=torch.int64, device=self.device), n=len(rows),
+            w8=torch.zeros(self.n_total, dtype=torch.uint8, device=self.device),
+            scales=torch.ones(len(rows), dtype=torch.float32, device=self.device),
+            amax=torch.zeros(len(rows), dtype=torch.int32, device=self.device),
+            ws=torch.empty(ws, dtype=torch.uint8, device=self.device))
+        self.fp8_requantize(fresh=True)
+        return self
+
+    def fp8_requantize(self, fresh=False):
+        """e4m3 shadow <- fp32 masters, after every optimizer step.  One pass: the scales come from the amax the PREVIOUS call
+        collected (delayed scaling: a weight moves by at most lr per step and the scale keeps 2x headroom under 448), and this
+        pass collects the amax for the next call.  fresh=True (after loading / initialising weights): an extra amax-only pass
+        first, so the scales fit the current weights exactly."""
+        f, L, s = self.fp8, _lib.lib(), stream_ptr()
+        if fresh:
+            f["amax"].zero_()
+            check(L.sfron_fp8_quant_tensors(ptr(self.params), ptr(f["table"]), f["n"], None, ptr(f["amax"]), None, 0, s), "fp8_amax")
+        check(L.sfron_fp8_update_scales(ptr(f["amax"]), f["n"], ptr(f["scales"]), s), "fp8_update_scales")
+        check(L.sfron_fp8_quant_tensors(ptr(self.params), ptr(f["table"]), f["n"], ptr(f["scales"]), ptr(f["amax"]), ptr(f["w8"]), 1, s),
+              "fp8_quant")
+
+    def _share_fp8(self, other):
+        """Another engine over the same parameters (another batch size / a micro-batch chain) uses the same e4m3 shadow and scales."""
+        if getattr(other, "fp8", None) is not None:
+            ws = _lib.lib().sfron_dit_fp8_workspace_bytes(ctypes.byref(self.cfg))
+            self.fp8 = dict(other.fp8, ws=torch.empty(ws, dtype=torch.uint8, device=self.device))
 
     # ------------------------------------------------------------------ passes
     def forward(self, x_t, t, y, drop=None, out=None):
@@ -135,6 +189,12 @@ class DitEngine:
             out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
         if x_t.shape[0] != self.cfg.batch:
             raise _lib.SfronError(f"engine was built for batch {self.cfg.batch}, got {x_t.shape[0]}")
+        if getattr(self, "fp8", None) is not None:
+            f = self.fp8
+            check(_lib.lib().sfron_dit_forward_fp8(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(f["w8"]),
+                                                   ptr(f["scales"]), f["act"], ptr(x_t), ptr(t), ptr(y), ptr(drop), ptr(self.workspace),
+                                                   ptr(f["ws"]), ptr(out), stream_ptr()), "dit_forward_fp8")
+            return out
         check(_lib.lib().sfron_dit_forward_probed(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(x_t),
                                                   ptr(t), ptr(y), ptr(drop), ptr(self.workspace), ptr(out), self.probe,
                                                   stream_ptr()), "dit_forward")

@@ -39,7 +39,7 @@ def build_mask_arena(engine, mask):
 class DiTSFRon:
     def __init__(self, model, diffusion, lr=1e-4, forget_alpha=1e-3, grad_clip=1.0, ema_decay=0.9999, mask=None,
                  unlearn_loss="ga", forget_class=0, process_group=None, bucket_bytes=256 << 20, micro_batches=1,
-                 overlap_allreduce=False, grad_transport="fp32", method="ron"):
+                 overlap_allreduce=False, grad_transport="fp32", method="ron", fp8=False):
         """micro_batches = 2: each forward/backward pass runs as TWO independent half-batch chains on two HIP streams
         (own workspace, own gradient arena, own side stream); the latency-bound kernels of one chain (attention,
         LayerNorm / gate backward) then run under the GEMMs of the other.  The optimizer sweep sums the two arenas."""
@@ -53,6 +53,11 @@ class DiTSFRon:
             raise ValueError("method 'joint' runs single-chain passes (micro_batches = 1)")
         self.method = method
         self._joint = None
+        # fp8 (BASELINE config 5): forward GEMMs of the blocks on the fp8 matrix core (engine.enable_fp8); the e4m3 weight shadow
+        # is refreshed after every optimizer step
+        self.fp8 = bool(fp8)
+        if self.fp8 and model.engine.fp8 is None:
+            model.engine.enable_fp8()
         if unlearn_loss == "rl" and (forget_class + 100) % 1000 >= model.num_classes:
             # DiT/forget.py:275-279 hard-codes (forget_class + 100) % 1000; with fewer classes the reference's nn.Embedding
             # raises an IndexError -- so do we, up front
@@ -293,6 +298,8 @@ class DiTSFRon:
             self.opt.g, self.opt.g2 = e0.grads[:nt], e1.grads[:nt]
         self.opt.step(max_norm=None, use_mask=False, ema=self.ema[:nt], ema_decay=self.ema_decay, ema_mode=1)      # forget.py:320,322
         self.opt.g2 = None
+        if self.fp8:
+            e0.fp8_requantize()
         if e0.n_total > nt:
             sweep.ema_update(self.ema[nt:], e0.params[nt:], self.ema_decay, mode=1)
         (mse_f, vb_f), (mse_r, vb_r) = res
@@ -316,9 +323,13 @@ class DiTSFRon:
             return self._step_joint(forget, remain, y_f, sign)
         mse_f, vb_f = self._pass(forget, y_f, sign * self.forget_alpha)
         self.opt.step(max_norm=self.grad_clip, use_mask=True)                               # forget.py:289-299
+        if self.fp8:
+            self.model.engine.fp8_requantize()
         mse_r, vb_r = self._pass(remain, remain["y"], 1.0)
         nt = eng.n_trainable
         self.opt.step(max_norm=None, use_mask=False, ema=self.ema[:nt], ema_decay=self.ema_decay, ema_mode=1)  # :320,322
+        if self.fp8:
+            self.model.engine.fp8_requantize()
         if eng.n_total > nt:
             sweep.ema_update(self.ema[nt:], eng.params[nt:], self.ema_decay, mode=1)         # frozen pos_embed (:60-62)
         # fail loud: a NaN / Inf loss or gradient norm would otherwise poison every weight through
