@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--micro-batches", type=int, default=1, help="independent half-batch chains per pass (1 or 2)")
     ap.add_argument("--cpu-batch", type=int, default=8, help="batch of the bounded CPU-baseline sample")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: keep the synchronous bucketed all-reduce")
+    ap.add_argument("--no-factored-ada", action="store_true", help="A-B knob: form the adaLN weight gradient by a GEMM + flat sweep")
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE config 5: the four block GEMMs of every FORWARD pass on the fp8 (e4m3) matrix core, e4m3 weight shadow "
                          "re-quantised after each optimizer step; backward GEMMs stay bf16")
@@ -166,6 +167,8 @@ def main():
                            grad_transport=args.grad_transport)
     runner.mask_arena = mask_arena
     runner.opt.mask = mask_arena
+    if args.no_factored_ada:
+        runner.factored_ada = False
 
     pool = 4
     gb = args.batch * world

@@ -59,6 +59,17 @@ int sfron_masked_clip_adam_wg(float* p, const float* g, const float* g2, float* 
                               double decay_mul, uint16_t* w_bf16, float* ema, double ema_decay, int ema_mode, int max_workgroups,
                               void* stream);
 
+/* The same two sweeps over a weight matrix W [NM][D] (p / m / v / mask / w_bf16 / ema point at ITS first element) whose gradient is
+ * a rank-R product dW[n][k] = sum_{b < R} dmod[b][n] * sc[b][k] (bf16 factors, fp32 accumulation in index order), formed inside
+ * the sweep instead of by a weight-gradient GEMM that writes NM*D floats for the sweep to read back: the adaLN_modulation Linears
+ * of all DiT blocks (DiT/models.py:113-116,131-134: input silu(c) [batch][D], a third of DiT-XL/2's parameters; R = batch).
+ * NM % 8 == 0, D % 4 == 0.  sumsq: *nblk_out partials (NM / 8), to be combined with the other ranges' by sfron_clip_coef. */
+int sfron_sumsq_lowrank(const uint16_t* dmod, const uint16_t* sc, int R, int NM, int D, const uint8_t* mask, double* partials,
+                        int* nblk_out, void* stream);
+int sfron_adam_lowrank(float* p, float* m, float* v, const uint8_t* mask, const float* stats, const uint16_t* dmod, const uint16_t* sc, int R,
+                       int NM, int D, double beta1, double beta2, double eps, double step_size, double bc2_sqrt, double decay_mul,
+                       uint16_t* w_bf16, float* ema, double ema_decay, int ema_mode, void* stream);
+
 /* stand-alone EMA (frozen parameters such as pos_embed; DiT/forget.py:60-62) */
 int sfron_ema_update(float* ema, const float* p, int64_t n, double decay, int ema_mode, void* stream);
 

@@ -142,3 +142,46 @@ def test_ddpm_ema_and_fisher(dev):
         sweep_ref.fisher_accumulate_(F, g, 3)
         sweep.fisher_accum(Fd, g.to(dev), 3)
     np.testing.assert_allclose(Fd.cpu().numpy(), F.numpy(), rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,NM,D", [(4, 64, 128), (32, 8 * 13, 1152), (3, 24, 36)])
+def test_lowrank_gradient_sweeps_vs_flat_kernels(R, NM, D):
+    """sfron_sumsq_lowrank / sfron_adam_lowrank form dW = dmod^T sc (bf16 factors, fp32 accumulation) inside the sweep; against the
+    flat kernels fed with the same product computed by torch in fp32 (mask, clip coefficient, AdamW, bf16 shadow, EMA)."""
+    import ctypes
+    from sfron import _lib
+    from sfron._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(R + NM + D)
+    dmod = (torch.randn(R, NM, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    sc = torch.randn(R, D, generator=g).to(torch.bfloat16).to(dev)
+    grad = (dmod.float().t() @ sc.float()).contiguous().view(-1)
+    n = NM * D
+    p0 = (torch.randn(n, generator=g) * 0.05).to(dev)
+    mask = (torch.rand(n, generator=g) < 0.5).to(torch.uint8).to(dev)
+    part = torch.empty(max(NM // 8, L.sfron_sweep_partials_len()), dtype=torch.float64, device=dev)
+    stats_a, stats_b = torch.zeros(4, device=dev), torch.zeros(4, device=dev)
+    nb = ctypes.c_int(0)
+    check(L.sfron_sumsq_lowrank(ptr(dmod), ptr(sc), R, NM, D, ptr(mask), ptr(part), ctypes.byref(nb), stream_ptr()), "sumsq_lowrank")
+    assert nb.value == NM // 8
+    check(L.sfron_clip_coef(ptr(part), nb.value, 0.01, ptr(stats_a), stream_ptr()), "clip")
+    check(L.sfron_sumsq_masked(ptr(grad), None, ptr(mask), n, ptr(part), ctypes.byref(nb), stream_ptr()), "sumsq")
+    check(L.sfron_clip_coef(ptr(part), nb.value, 0.01, ptr(stats_b), stream_ptr()), "clip")
+    assert torch.allclose(stats_a[:3], stats_b[:3], rtol=2e-6)
+    outs = []
+    for low in (True, False):
+        p, m, v, ema = p0.clone(), torch.full((n,), 1e-3, device=dev), torch.full((n,), 1e-5, device=dev), p0.clone()
+        w16 = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+        args = (0.9, 0.999, 1e-8, 1e-3 / (1 - 0.9), (1 - 0.999) ** 0.5, 1.0)
+        if low:
+            check(L.sfron_adam_lowrank(ptr(p), ptr(m), ptr(v), ptr(mask), ptr(stats_b), ptr(dmod), ptr(sc), R, NM, D, *args, ptr(w16), ptr(ema),
+                                       0.99, 1, stream_ptr()), "adam_lowrank")
+        else:
+            check(L.sfron_masked_clip_adam(ptr(p), ptr(grad), None, ptr(m), ptr(v), ptr(mask), ptr(stats_b), n, *args, ptr(w16), ptr(ema), 0.99, 1,
+                                           stream_ptr()), "adam")
+        outs.append((p, m, v, ema, w16.float()))
+    for a, b, nm in zip(outs[0], outs[1], ("p", "m", "v", "ema", "bf16")):
+        assert torch.allclose(a, b, rtol=3e-5, atol=1e-7), (nm, (a - b).abs().max().item())
+    assert not torch.equal(outs[0][0], p0)

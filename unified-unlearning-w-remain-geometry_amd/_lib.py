@@ -28,6 +28,9 @@ _PROTOS = {
                                        c_double, _P, _P, c_double, c_int, _S]),
     "sfron_masked_clip_adam_wg": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_double,
                                           c_double, _P, _P, c_double, c_int, c_int, _S]),
+    "sfron_sumsq_lowrank": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, POINTER(c_int), _S]),
+    "sfron_adam_lowrank": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_double,
+                                   c_double, _P, _P, c_double, c_int, _S]),
     "sfron_ema_update": (c_int, [_P, _P, c_int64, c_double, c_int, _S]),
     "sfron_fisher_accum": (c_int, [_P, _P, c_int64, c_float, _S]),
     "sfron_fisher_accum_clipped": (c_int, [_P, _P, _P, _P, c_int64, c_float, _S]),

@@ -141,6 +141,84 @@ __global__ __launch_bounds__(TPB) void k_masked_clip_adam(float* __restrict__ p,
   }
 }
 
+// ---- rank-R gradient: the adaLN_modulation weight of ALL blocks, W [NM][D] (a third of DiT-XL/2's parameters), has the gradient
+// dW[n][k] = sum_{b < R} dmod[b][n] * sc[b][k] (R = batch rows; bf16 factors, fp32 accumulation -- the same numbers the
+// weight-gradient GEMM would form from the same factors).  Forming it HERE, inside the sweep, removes the 892 MB fp32 write of that
+// GEMM and the sweep's read of it (and, in the forget stage, the norm pre-pass's).  One thread owns 4 consecutive k of LR_ROWS rows:
+// per b one 8-byte load of sc and one 16-byte wave-uniform load of dmod feed LR_ROWS x 4 FMAs; b runs in index order (deterministic).
+constexpr int LR_ROWS = 8;
+__device__ __forceinline__ void lowrank_grad(const __bf16* __restrict__ dmod, const __bf16* __restrict__ sc, int R, int NM, int D, int n0,
+                                             int c, f32x4 (&acc)[LR_ROWS]) {
+#pragma unroll
+  for (int r = 0; r < LR_ROWS; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < R; ++b) {
+    const bf16x4 s4 = *reinterpret_cast<const bf16x4*>(sc + (size_t)b * D + 4 * c);
+    const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(dmod + (size_t)b * NM + n0);       // wave-uniform address
+    const f32x4 sv = {bf2f(s4[0]), bf2f(s4[1]), bf2f(s4[2]), bf2f(s4[3])};
+#pragma unroll
+    for (int r = 0; r < LR_ROWS; ++r) acc[r] += sv * bf2f(d8[r]);
+  }
+}
+
+// partials[blockIdx.x] = sum over this workgroup's LR_ROWS rows of (mask ? g : 0)^2
+__global__ void k_sumsq_lowrank(const __bf16* __restrict__ dmod, const __bf16* __restrict__ sc, int R, int NM, int D,
+                                const uint8_t* __restrict__ mask, double* __restrict__ partials) {
+  __shared__ double sh[16];
+  const int c = threadIdx.x, n0 = blockIdx.x * LR_ROWS;
+  float a = 0.f;
+  if (c < (D >> 2)) {
+    f32x4 g[LR_ROWS];
+    lowrank_grad(dmod, sc, R, NM, D, n0, c, g);
+#pragma unroll
+    for (int r = 0; r < LR_ROWS; ++r) {
+      f32x4 x = g[r];
+      if (mask) {
+        const uchar4 mk = reinterpret_cast<const uchar4*>(mask + (size_t)(n0 + r) * D)[c];
+        x[0] = mk.x ? x[0] : 0.f; x[1] = mk.y ? x[1] : 0.f; x[2] = mk.z ? x[2] : 0.f; x[3] = mk.w ? x[3] : 0.f;
+      }
+      a += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+    }
+  }
+  double d = wave_sum_d((double)a);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    partials[blockIdx.x] = t;
+  }
+}
+
+__global__ void k_adam_lowrank(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const uint8_t* __restrict__ mask,
+                               const float* __restrict__ stats, const __bf16* __restrict__ dmod, const __bf16* __restrict__ sc, int R,
+                               int NM, int D, AdamArgs a, uint16_t* __restrict__ wbf, float* __restrict__ ema) {
+  const int c = threadIdx.x, n0 = blockIdx.x * LR_ROWS;
+  if (c >= (D >> 2)) return;
+  const float coef = stats ? stats[1] : 1.0f;
+  f32x4 g[LR_ROWS];
+  lowrank_grad(dmod, sc, R, NM, D, n0, c, g);
+#pragma unroll
+  for (int r = 0; r < LR_ROWS; ++r) {
+    const size_t i = (size_t)(n0 + r) * (D >> 2) + c;               // float4 index inside W
+    float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    f32x4 gg = g[r];
+    if (mask) {
+      const uchar4 mk = reinterpret_cast<const uchar4*>(mask)[i];
+      gg[0] = mk.x ? gg[0] : 0.f; gg[1] = mk.y ? gg[1] : 0.f; gg[2] = mk.z ? gg[2] : 0.f; gg[3] = mk.w ? gg[3] : 0.f;
+    }
+    gg = gg * coef;
+    pp.x = adam_one(pp.x, gg[0], mm.x, vv.x, a); pp.y = adam_one(pp.y, gg[1], mm.y, vv.y, a);
+    pp.z = adam_one(pp.z, gg[2], mm.z, vv.z, a); pp.w = adam_one(pp.w, gg[3], mm.w, vv.w, a);
+    reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+    if (wbf) reinterpret_cast<bf16x4*>(wbf)[i] = bf16x4{f2bf(pp.x), f2bf(pp.y), f2bf(pp.z), f2bf(pp.w)};
+    if (a.ema_mode) {
+      float4 ee = reinterpret_cast<float4*>(ema)[i];
+      ee.x = ema_one(ee.x, pp.x, a); ee.y = ema_one(ee.y, pp.y, a); ee.z = ema_one(ee.z, pp.z, a); ee.w = ema_one(ee.w, pp.w, a);
+      reinterpret_cast<float4*>(ema)[i] = ee;
+    }
+  }
+}
+
 __global__ __launch_bounds__(TPB) void k_ema(float* __restrict__ ema, const float* __restrict__ p, int64_t n, AdamArgs a) {
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB)
     ema[i] = ema_one(ema[i], p[i], a);
@@ -250,6 +328,35 @@ int sfron_masked_clip_adam(float* p, const float* g, const float* g2, float* m, 
                            double decay_mul, uint16_t* w_bf16, float* ema, double ema_decay, int ema_mode, void* stream) {
   return sfron_masked_clip_adam_wg(p, g, g2, m, v, mask, stats, n, beta1, beta2, eps, step_size, bc2_sqrt, decay_mul, w_bf16, ema,
                                    ema_decay, ema_mode, 0, stream);
+}
+
+// rank-R gradient sweeps (see k_adam_lowrank): W = p[0 .. NM*D), dW = dmod^T sc with dmod bf16 [R][NM], sc bf16 [R][D]
+int sfron_sumsq_lowrank(const uint16_t* dmod, const uint16_t* sc, int R, int NM, int D, const uint8_t* mask, double* partials,
+                        int* nblk_out, void* stream) {
+  SFRON_CHECK_ARG(dmod && sc && partials && nblk_out && R > 0 && NM > 0 && D > 0 && NM % LR_ROWS == 0 && D % 4 == 0 && D <= 4096);
+  SFRON_CHECK_ARG((((uintptr_t)dmod) & 15) == 0 && (((uintptr_t)sc) & 7) == 0 && (!mask || ((uintptr_t)mask & 3) == 0));
+  const int threads = (D / 4 + 63) / 64 * 64;
+  *nblk_out = NM / LR_ROWS;
+  hipLaunchKernelGGL(k_sumsq_lowrank, dim3(NM / LR_ROWS), dim3(threads), 0, (hipStream_t)stream, (const __bf16*)dmod, (const __bf16*)sc, R, NM, D,
+                     mask, partials);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_adam_lowrank(float* p, float* m, float* v, const uint8_t* mask, const float* stats, const uint16_t* dmod, const uint16_t* sc, int R,
+                       int NM, int D, double beta1, double beta2, double eps, double step_size, double bc2_sqrt, double decay_mul,
+                       uint16_t* w_bf16, float* ema, double ema_decay, int ema_mode, void* stream) {
+  SFRON_CHECK_ARG(p && m && v && dmod && sc && R > 0 && NM > 0 && D > 0 && NM % LR_ROWS == 0 && D % 4 == 0 && D <= 4096);
+  SFRON_CHECK_ARG((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)dmod) & 15) == 0 && (((uintptr_t)sc) & 7) == 0);
+  SFRON_CHECK_ARG((!mask || ((uintptr_t)mask & 3) == 0) && (!w_bf16 || ((uintptr_t)w_bf16 & 7) == 0));
+  SFRON_CHECK_ARG(ema_mode == 0 || (ema && ((uintptr_t)ema & 15) == 0 && (ema_mode == 1 || ema_mode == 2)));
+  AdamArgs a{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)step_size, (float)bc2_sqrt,
+             (float)decay_mul, (float)ema_decay, (float)(1.0 - ema_decay), ema_mode};
+  const int threads = (D / 4 + 63) / 64 * 64;
+  hipLaunchKernelGGL(k_adam_lowrank, dim3(NM / LR_ROWS), dim3(threads), 0, (hipStream_t)stream, p, m, v, mask, stats, (const __bf16*)dmod,
+                     (const __bf16*)sc, R, NM, D, a, w_bf16, ema);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
 }
 
 int sfron_ema_update(float* ema, const float* p, int64_t n, double decay, int ema_mode, void* stream) {

@@ -251,6 +251,20 @@ class DitEngine:
                                                ptr(self.late_bias), ptr(self.ada_dmod), ptr(self.ada_sc), stream_ptr()), "dit_backward_dp")
         return self.grads
 
+    def backward_factored_ada(self, d_out, y, drop=None):
+        """Backward pass that does NOT form the adaLN_modulation weight gradient (a [(6L+2)D][D] fp32 matrix, a third of the arena):
+        it hands out its two bf16 factors instead -- dmod [batch][(6L+2)D] and silu(c) [batch][D] -- for a sweep that forms the
+        rank-(batch) product itself (sweep.FlatAdam.lowrank).  The arena's ada_w range is left untouched (stale)."""
+        if getattr(self, "_ada_f", None) is None or self._ada_f[0].shape[0] != self.cfg.batch:
+            NM = (6 * self.cfg.depth + 2) * self.cfg.hidden
+            self._ada_f = (torch.empty(self.cfg.batch, NM, dtype=torch.bfloat16, device=self.device),
+                           torch.empty(self.cfg.batch, self.cfg.hidden, dtype=torch.bfloat16, device=self.device))
+        dmod, sc = self._ada_f
+        check(_lib.lib().sfron_dit_backward_dp(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(d_out), ptr(y),
+                                               ptr(drop), ptr(self.workspace), ptr(self.grads), self.aux, None, None, ptr(dmod), ptr(sc),
+                                               stream_ptr()), "dit_backward (factored adaLN gradient)")
+        return dict(lo=self.layout["ada_w"], NM=dmod.shape[1], D=self.cfg.hidden, dmod=dmod, sc=sc, R=self.cfg.batch)
+
     def scatter_late_bias(self):
         check(_lib.lib().sfron_dit_scatter_late_bias(ctypes.byref(self.cfg), ptr(self.late_bias), ptr(self.grads), stream_ptr()),
               "dit_scatter_late_bias")

@@ -55,6 +55,8 @@ class DiTSFRon:
         self._joint = None
         # fp8 (BASELINE config 5): forward GEMMs of the blocks on the fp8 matrix core (engine.enable_fp8); the e4m3 weight shadow
         # is refreshed after every optimizer step
+        # the adaLN weight gradient as two factors + a rank-(batch) sweep (see _pass); the engine's (6L+2)D must be a multiple of 8
+        self.factored_ada = ((6 * model.engine.cfg.depth + 2) * model.engine.cfg.hidden) % 8 == 0
         self.fp8 = bool(fp8)
         if self.fp8 and model.engine.fp8 is None:
             model.engine.enable_fp8()
@@ -251,7 +253,11 @@ class DiTSFRon:
         y_safe, b["t"] = self.guard.check_inputs(y, b["t"], self.model.num_classes, self.diffusion.num_timesteps)
         return b, y_safe
 
-    def _pass(self, batch, y, sign_alpha):
+    def _pass(self, batch, y, sign_alpha, factored_ada=False):
+        """factored_ada (single process, single chain -- what step() uses): the backward pass leaves the adaLN_modulation weight
+        gradient as its two bf16 factors and the next optimizer sweep forms the rank-(batch) product itself (engine.
+        backward_factored_ada, csrc/sweep.hip k_adam_lowrank): 892 MB less to write and 892 MB (forget stage: twice) less to read
+        per pass at DiT-XL/2.  Everything else (tests, verify_overlap, bench --check, data-parallel runs) gets the full arena."""
         batch, y = self._checked(batch, y)
         if self.micro == 2:
             return self._pass2(batch, y, sign_alpha)
@@ -262,6 +268,8 @@ class DiTSFRon:
         mse, vb, d_out = diff.loss_fwd_bwd(out, batch["x0"], batch["t"], batch["noise"], sign_alpha / n_global)
         if self._overlap_enabled():
             self._backward_allreduce_overlapped(d_out, y, batch.get("drop"))
+        elif factored_ada and self.world == 1 and self.factored_ada:
+            self.opt.lowrank = eng.backward_factored_ada(d_out, y, batch.get("drop"))
         else:
             eng.backward(d_out, y, batch.get("drop"))
             self._allreduce_grads()
@@ -321,11 +329,11 @@ class DiTSFRon:
             y_f, sign = torch.full_like(forget["y"], (self.forget_class + 100) % 1000), 1.0  # forget.py:274-282
         if self.method == "joint":
             return self._step_joint(forget, remain, y_f, sign)
-        mse_f, vb_f = self._pass(forget, y_f, sign * self.forget_alpha)
+        mse_f, vb_f = self._pass(forget, y_f, sign * self.forget_alpha, factored_ada=True)
         self.opt.step(max_norm=self.grad_clip, use_mask=True)                               # forget.py:289-299
         if self.fp8:
             self.model.engine.fp8_requantize()
-        mse_r, vb_r = self._pass(remain, remain["y"], 1.0)
+        mse_r, vb_r = self._pass(remain, remain["y"], 1.0, factored_ada=True)
         nt = eng.n_trainable
         self.opt.step(max_norm=None, use_mask=False, ema=self.ema[:nt], ema_decay=self.ema_decay, ema_mode=1)  # :320,322
         if self.fp8:

@@ -36,20 +36,47 @@ class FlatAdam:
         # only those (SD train_method "xattn": 44 M of 860 M parameters); unclipped steps only
         self.ranges = ranges
         self.g2 = None              # optional second gradient arena (micro-batch chains), summed inside the kernels
+        # optional rank-R gradient of one weight matrix inside the arena (set per step by the caller, cleared by step()):
+        # dict(lo=element offset of W [NM][D], NM=, D=, dmod=bf16 [R][NM], sc=bf16 [R][D], R=) -- the gradient arena is NOT read
+        # over [lo, lo + NM * D): the sweep forms dmod^T sc itself (csrc/sweep.hip k_adam_lowrank)
+        self.lowrank = None
         self.timed = None           # bench.py: a list that receives a (start, end) torch event pair per sweep launch
         L = _lib.lib()
         self._partials = torch.empty(L.sfron_sweep_partials_len(), dtype=torch.float64, device=params.device)
         self.stats = torch.zeros(4, dtype=torch.float32, device=params.device)
 
+    def _segments(self):
+        """[(lo, hi, lowrank?)] covering the arena: one flat segment, or flat / rank-R / flat around the low-rank matrix."""
+        n = self.p.numel()
+        lr = self.lowrank
+        if lr is None:
+            return [(0, n, False)]
+        lo, hi = lr["lo"], lr["lo"] + lr["NM"] * lr["D"]
+        assert 0 <= lo < hi <= n and lo % 8 == 0 and hi % 8 == 0 and self.g2 is None
+        return [sg for sg in ((0, lo, False), (lo, hi, True), (hi, n, False)) if sg[1] > sg[0]]
+
     def grad_norm_clip_coef(self, max_norm, use_mask):
         """Launch the norm pre-pass; leaves (norm, coef, sumsq) in self.stats on device (no host sync)."""
         L = _lib.lib()
-        n = self.p.numel()
-        nblk = ctypes.c_int(0)
         mask = self.mask if use_mask else None
         s = stream_ptr()
-        check(L.sfron_sumsq_masked(ptr(self.g), ptr(self.g2), ptr(mask), n, ptr(self._partials), ctypes.byref(nblk), s), "sumsq_masked")
-        check(L.sfron_clip_coef(ptr(self._partials), nblk.value, float(max_norm), ptr(self.stats), s), "clip_coef")
+        segs = self._segments()
+        need = sum((self.lowrank["NM"] // 8) if lr else L.sfron_sweep_partials_len() for _, _, lr in segs)
+        if self._partials.numel() < need:
+            self._partials = torch.empty(need, dtype=torch.float64, device=self.p.device)
+        used = 0
+        sl = lambda t, lo, hi: None if t is None else t[lo:hi]
+        for lo, hi, lr in segs:
+            nblk = ctypes.c_int(0)
+            if lr:
+                q = self.lowrank
+                check(L.sfron_sumsq_lowrank(ptr(q["dmod"]), ptr(q["sc"]), q["R"], q["NM"], q["D"], ptr(sl(mask, lo, hi)),
+                                            ptr(self._partials[used:]), ctypes.byref(nblk), s), "sumsq_lowrank")
+            else:
+                check(L.sfron_sumsq_masked(ptr(self.g[lo:hi]), ptr(sl(self.g2, lo, hi)), ptr(sl(mask, lo, hi)), hi - lo,
+                                           ptr(self._partials[used:]), ctypes.byref(nblk), s), "sumsq_masked")
+            used += nblk.value
+        check(L.sfron_clip_coef(ptr(self._partials), used, float(max_norm), ptr(self.stats), s), "clip_coef")
 
     def step(self, max_norm=None, use_mask=False, ema=None, ema_decay=0.0, ema_mode=0):
         """One optimizer step on the current grads.  max_norm=None -> no clipping (DiT remain stage)."""
@@ -78,12 +105,23 @@ class FlatAdam:
                                                bc2_sqrt, decay_mul, ptr(sl(self.w_bf16, lo, hi)), ptr(sl(ema, lo, hi)), float(ema_decay),
                                                int(ema_mode if ema is not None else 0), stream_ptr()), "masked_clip_adam")
         else:
-            check(L.sfron_masked_clip_adam(ptr(self.p), ptr(self.g), ptr(self.g2), ptr(self.m), ptr(self.v),
-                                           ptr(self.mask if use_mask else None),
-                                           ptr(self.stats if max_norm is not None else None),
-                                           self.p.numel(), b1, b2, self.eps, step_size, bc2_sqrt, decay_mul,
-                                           ptr(self.w_bf16), ptr(ema), float(ema_decay), int(ema_mode if ema is not None else 0),
-                                           stream_ptr()), "masked_clip_adam")
+            sl = lambda t, lo, hi: None if t is None else t[lo:hi]
+            mask = self.mask if use_mask else None
+            stats = self.stats if max_norm is not None else None
+            emode = int(ema_mode if ema is not None else 0)
+            for lo, hi, lr in self._segments():
+                if lr:
+                    q = self.lowrank
+                    check(L.sfron_adam_lowrank(ptr(self.p[lo:hi]), ptr(self.m[lo:hi]), ptr(self.v[lo:hi]), ptr(sl(mask, lo, hi)), ptr(stats),
+                                               ptr(q["dmod"]), ptr(q["sc"]), q["R"], q["NM"], q["D"], b1, b2, self.eps, step_size, bc2_sqrt,
+                                               decay_mul, ptr(sl(self.w_bf16, lo, hi)), ptr(sl(ema, lo, hi)), float(ema_decay), emode,
+                                               stream_ptr()), "adam_lowrank")
+                else:
+                    check(L.sfron_masked_clip_adam(ptr(self.p[lo:hi]), ptr(self.g[lo:hi]), ptr(sl(self.g2, lo, hi)), ptr(self.m[lo:hi]),
+                                                   ptr(self.v[lo:hi]), ptr(sl(mask, lo, hi)), ptr(stats), hi - lo, b1, b2, self.eps,
+                                                   step_size, bc2_sqrt, decay_mul, ptr(sl(self.w_bf16, lo, hi)), ptr(sl(ema, lo, hi)),
+                                                   float(ema_decay), emode, stream_ptr()), "masked_clip_adam")
+            self.lowrank = None
         if ev is not None:
             ev[1].record()
             self.timed.append(ev)
