@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--micro-batches", type=int, default=1, help="independent half-batch chains per pass (1 or 2)")
     ap.add_argument("--cpu-batch", type=int, default=8, help="batch of the bounded CPU-baseline sample")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: keep the synchronous bucketed all-reduce")
+    ap.add_argument("--no-sweep-beside", action="store_true", help="A-B knob: forget-stage AdamW of the blocks on the main stream")
     ap.add_argument("--no-factored-ada", action="store_true", help="A-B knob: form the adaLN weight gradient by a GEMM + flat sweep")
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE config 5: the four block GEMMs of every FORWARD pass on the fp8 (e4m3) matrix core, e4m3 weight shadow "
@@ -169,6 +170,10 @@ def main():
     runner.opt.mask = mask_arena
     if args.no_factored_ada:
         runner.factored_ada = False
+    if args.no_sweep_beside:
+        runner.sweep_beside_forward = False
+    if os.environ.get("SFRON_BENCH_SWEEP_BESIDE"):          # tuning knob (tools only): "workgroups,head"
+        runner.sweep_beside_wg, runner.sweep_beside_head = (int(v) for v in os.environ["SFRON_BENCH_SWEEP_BESIDE"].split(","))
 
     pool = 4
     gb = args.batch * world

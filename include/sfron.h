@@ -496,6 +496,12 @@ int64_t sfron_dit_workspace_bytes(const sfron_dit_cfg* cfg);   /* < 0 on unsuppo
  * Saves activations in `workspace` for sfron_dit_backward. */
 int sfron_dit_forward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
                       const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out, void* stream);
+/* sfron_dit_forward_probed whose block l first waits (hipStreamWaitEvent on `stream`) for block_ready[l] (hipEvent_t, [depth], NULL
+ * entries skipped): the optimizer sweep of the previous stage may still be rewriting the LATER blocks' weights on another stream
+ * while the first blocks already run (DiT/forget.py:299 -> :310: the remain forward needs block l's new weights only at block l). */
+int sfron_dit_forward_after(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
+                            const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
+                            void* const* block_ready, void* probe, void* stream);
 /* Config 5: the same forward pass with the four block GEMMs on the fp8 matrix core.  params_e4m3: e4m3 shadow arena (same offsets as
  * params); w_scales: DEVICE fp32 [depth][4] = quantisation scales of {qkv, proj, fc1, fc2}.weight of each block; act_scales: HOST
  * fp32 [3] = static scales of {LayerNorm+modulate output, attention output, gelu(fc1)}; workspace_e4m3: sfron_dit_fp8_workspace_bytes.

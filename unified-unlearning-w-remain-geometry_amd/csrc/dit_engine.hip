@@ -294,7 +294,7 @@ static size_t fp8_ws(const Dims& d, char* base, Fp8Ctx* f) {
 
 static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
                             const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
-                            void* probe, const Fp8Ctx* f8, void* stream);
+                            void* probe, const Fp8Ctx* f8, void* stream, void* const* block_wait = nullptr);
 
 int sfron_dit_forward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
                       const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out, void* stream) {
@@ -305,6 +305,13 @@ int sfron_dit_forward_probed(const sfron_dit_cfg* cfg, const float* params, cons
                              const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
                              void* probe, void* stream) {
   return dit_forward_impl(cfg, params, params_bf16, x_t, t, y, drop, workspace, out, probe, nullptr, stream);
+}
+
+int sfron_dit_forward_after(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
+                            const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
+                            void* const* block_ready, void* probe, void* stream) {
+  SFRON_CHECK_ARG(block_ready);
+  return dit_forward_impl(cfg, params, params_bf16, x_t, t, y, drop, workspace, out, probe, nullptr, stream, block_ready);
 }
 
 int64_t sfron_dit_fp8_workspace_bytes(const sfron_dit_cfg* cfg) {
@@ -330,7 +337,7 @@ int sfron_dit_forward_fp8(const sfron_dit_cfg* cfg, const float* params, const u
 
 static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
                             const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
-                            void* probe, const Fp8Ctx* f8, void* stream) {
+                            void* probe, const Fp8Ctx* f8, void* stream, void* const* block_wait) {
   Dims d;
   RUN(make_dims(cfg, d));
   SFRON_CHECK_ARG(params && params_bf16 && x_t && t && y && workspace && out);
@@ -362,6 +369,9 @@ static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const
 
   for (int l = 0; l < d.L; ++l) {
     const int64_t pb = P.blocks + (int64_t)l * P.blk_stride;
+    // block l's weights may still be under an optimizer sweep that runs on another stream (sfron_dit_forward_after): wait for ITS event
+    if (block_wait && block_wait[l] && hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)block_wait[l], 0) != hipSuccess)
+      return (int)hipGetLastError();
     const float* mod = w.mod + (size_t)l * 6 * D;          // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     float* x0 = w.xs + (size_t)(2 * l) * M * D;
     float* x1 = x0 + (size_t)M * D;

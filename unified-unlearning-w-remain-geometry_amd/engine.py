@@ -184,11 +184,29 @@ class DitEngine:
             self.fp8 = dict(other.fp8, ws=torch.empty(ws, dtype=torch.uint8, device=self.device))
 
     # ------------------------------------------------------------------ passes
-    def forward(self, x_t, t, y, drop=None, out=None):
+    def block_sweep_setup(self):
+        """Per-block events + a stream for an optimizer sweep that runs beside the next forward pass (FlatAdam.step(split=...))."""
+        if getattr(self, "_bs", None) is None:
+            L, lay = self.cfg.depth, self.layout
+            evs = [torch.cuda.Event(enable_timing=False) for _ in range(L)]
+            st = torch.cuda.Stream(device=self.device)
+            for e in evs:
+                e.record(st)
+            self._bs = dict(ranges=[(lay["blocks"] + l * lay["blk_stride"], lay["blocks"] + (l + 1) * lay["blk_stride"]) for l in range(L)],
+                            stream=st, events=evs, handles=(ctypes.c_void_p * L)(*[e.cuda_event for e in evs]))
+        return self._bs
+
+    def forward(self, x_t, t, y, drop=None, out=None, block_ready=None):
+        """block_ready: ctypes array of depth hipEvent_t handles -- block l waits for entry l before it touches its weights."""
         if out is None:
             out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
         if x_t.shape[0] != self.cfg.batch:
             raise _lib.SfronError(f"engine was built for batch {self.cfg.batch}, got {x_t.shape[0]}")
+        if block_ready is not None and self.fp8 is None:
+            check(_lib.lib().sfron_dit_forward_after(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(x_t), ptr(t), ptr(y),
+                                                     ptr(drop), ptr(self.workspace), ptr(out), block_ready, self.probe, stream_ptr()),
+                  "dit_forward_after")
+            return out
         if getattr(self, "fp8", None) is not None:
             f = self.fp8
             check(_lib.lib().sfron_dit_forward_fp8(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(f["w8"]),

@@ -57,6 +57,8 @@ class DiTSFRon:
         # is refreshed after every optimizer step
         # the adaLN weight gradient as two factors + a rank-(batch) sweep (see _pass); the engine's (6L+2)D must be a multiple of 8
         self.factored_ada = ((6 * model.engine.cfg.depth + 2) * model.engine.cfg.hidden) % 8 == 0
+        self.sweep_beside_forward = True
+        self.sweep_beside_wg, self.sweep_beside_head = 256, 2
         self.fp8 = bool(fp8)
         if self.fp8 and model.engine.fp8 is None:
             model.engine.enable_fp8()
@@ -253,7 +255,7 @@ class DiTSFRon:
         y_safe, b["t"] = self.guard.check_inputs(y, b["t"], self.model.num_classes, self.diffusion.num_timesteps)
         return b, y_safe
 
-    def _pass(self, batch, y, sign_alpha, factored_ada=False):
+    def _pass(self, batch, y, sign_alpha, factored_ada=False, block_ready=None):
         """factored_ada (single process, single chain -- what step() uses): the backward pass leaves the adaLN_modulation weight
         gradient as its two bf16 factors and the next optimizer sweep forms the rank-(batch) product itself (engine.
         backward_factored_ada, csrc/sweep.hip k_adam_lowrank): 892 MB less to write and 892 MB (forget stage: twice) less to read
@@ -264,7 +266,7 @@ class DiTSFRon:
         eng, diff = self.model.engine, self.diffusion
         n_global = batch["x0"].shape[0] * self.world
         x_t = diff.q_sample(batch["x0"], batch["t"], batch["noise"])
-        out = eng.forward(x_t, batch["t"], y, batch.get("drop"))
+        out = eng.forward(x_t, batch["t"], y, batch.get("drop"), block_ready=block_ready)
         mse, vb, d_out = diff.loss_fwd_bwd(out, batch["x0"], batch["t"], batch["noise"], sign_alpha / n_global)
         if self._overlap_enabled():
             self._backward_allreduce_overlapped(d_out, y, batch.get("drop"))
@@ -330,10 +332,19 @@ class DiTSFRon:
         if self.method == "joint":
             return self._step_joint(forget, remain, y_f, sign)
         mse_f, vb_f = self._pass(forget, y_f, sign * self.forget_alpha, factored_ada=True)
-        self.opt.step(max_norm=self.grad_clip, use_mask=True)                               # forget.py:289-299
+        # The forget-stage AdamW of the 28 block ranges runs on a second stream, on a bounded grid, BESIDE the remain forward pass,
+        # which waits for block l's event when it reaches block l; embedders / adaLN / final layer (needed at once) stay on this
+        # stream.  Measured (tools/bench_sweep_beside.py): a full-grid sweep beside the GEMM chain gains nothing, one capped at
+        # 256 workgroups hides ~0.8 ms of its 2.6 ms.  Single-chain, single-process, bf16 passes only.
+        split = None
+        if self.sweep_beside_forward and self.micro == 1 and self.world == 1 and not self.fp8:
+            bs = self.model.engine.block_sweep_setup()
+            split = dict(ranges=bs["ranges"], stream=bs["stream"], events=bs["events"], max_workgroups=self.sweep_beside_wg,
+                         head=self.sweep_beside_head)
+        self.opt.step(max_norm=self.grad_clip, use_mask=True, split=split)                  # forget.py:289-299
         if self.fp8:
             self.model.engine.fp8_requantize()
-        mse_r, vb_r = self._pass(remain, remain["y"], 1.0, factored_ada=True)
+        mse_r, vb_r = self._pass(remain, remain["y"], 1.0, factored_ada=True, block_ready=bs["handles"] if split else None)
         nt = eng.n_trainable
         self.opt.step(max_norm=None, use_mask=False, ema=self.ema[:nt], ema_decay=self.ema_decay, ema_mode=1)  # :320,322
         if self.fp8:

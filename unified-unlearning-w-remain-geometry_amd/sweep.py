@@ -45,15 +45,24 @@ class FlatAdam:
         self._partials = torch.empty(L.sfron_sweep_partials_len(), dtype=torch.float64, device=params.device)
         self.stats = torch.zeros(4, dtype=torch.float32, device=params.device)
 
-    def _segments(self):
-        """[(lo, hi, lowrank?)] covering the arena: one flat segment, or flat / rank-R / flat around the low-rank matrix."""
+    def _segments(self, exclude=None):
+        """[(lo, hi, lowrank?)] covering the arena (minus ``exclude`` = (lo, hi), which must not cut the low-rank matrix): one flat
+        segment, or flat / rank-R / flat around the low-rank matrix."""
         n = self.p.numel()
+        cuts = [(0, n)]
+        if exclude is not None:
+            cuts = [(0, exclude[0]), (exclude[1], n)]
         lr = self.lowrank
-        if lr is None:
-            return [(0, n, False)]
-        lo, hi = lr["lo"], lr["lo"] + lr["NM"] * lr["D"]
-        assert 0 <= lo < hi <= n and lo % 8 == 0 and hi % 8 == 0 and self.g2 is None
-        return [sg for sg in ((0, lo, False), (lo, hi, True), (hi, n, False)) if sg[1] > sg[0]]
+        out = []
+        for a, b in cuts:
+            if lr is not None and a <= lr["lo"] and lr["lo"] + lr["NM"] * lr["D"] <= b:
+                lo, hi = lr["lo"], lr["lo"] + lr["NM"] * lr["D"]
+                assert lo % 8 == 0 and hi % 8 == 0 and self.g2 is None
+                out += [(a, lo, False), (lo, hi, True), (hi, b, False)]
+            else:
+                assert lr is None or b <= lr["lo"] or a >= lr["lo"] + lr["NM"] * lr["D"]
+                out.append((a, b, False))
+        return [sg for sg in out if sg[1] > sg[0]]
 
     def grad_norm_clip_coef(self, max_norm, use_mask):
         """Launch the norm pre-pass; leaves (norm, coef, sumsq) in self.stats on device (no host sync)."""
@@ -78,8 +87,12 @@ class FlatAdam:
             used += nblk.value
         check(L.sfron_clip_coef(ptr(self._partials), used, float(max_norm), ptr(self.stats), s), "clip_coef")
 
-    def step(self, max_norm=None, use_mask=False, ema=None, ema_decay=0.0, ema_mode=0):
-        """One optimizer step on the current grads.  max_norm=None -> no clipping (DiT remain stage)."""
+    def step(self, max_norm=None, use_mask=False, ema=None, ema_decay=0.0, ema_mode=0, split=None):
+        """One optimizer step on the current grads.  max_norm=None -> no clipping (DiT remain stage).
+        split (optional): dict(ranges=[(lo, hi)] consecutive element ranges (the DiT blocks, in forward order), stream=, events=[one
+        torch event per range], max_workgroups=): those ranges are swept on ``stream`` (bounded grid), one event each, while the
+        rest of the arena is swept on the current stream -- the next forward pass waits for block l's event only when it
+        reaches block l (engine.forward(block_ready=...))."""
         L = _lib.lib()
         if use_mask and self.mask is None:
             use_mask = False
@@ -109,7 +122,13 @@ class FlatAdam:
             mask = self.mask if use_mask else None
             stats = self.stats if max_norm is not None else None
             emode = int(ema_mode if ema is not None else 0)
-            for lo, hi, lr in self._segments():
+            excl = None
+            if split is not None:
+                import torch as _t
+                head = int(split.get("head", 0))              # the first `head` ranges stay on the current stream (needed first)
+                rngs = split["ranges"]
+                excl = (rngs[head][0], rngs[-1][1]) if head < len(rngs) else None
+            for lo, hi, lr in self._segments(excl):
                 if lr:
                     q = self.lowrank
                     check(L.sfron_adam_lowrank(ptr(self.p[lo:hi]), ptr(self.m[lo:hi]), ptr(self.v[lo:hi]), ptr(sl(mask, lo, hi)), ptr(stats),
@@ -121,6 +140,23 @@ class FlatAdam:
                                                    ptr(self.v[lo:hi]), ptr(sl(mask, lo, hi)), ptr(stats), hi - lo, b1, b2, self.eps,
                                                    step_size, bc2_sqrt, decay_mul, ptr(sl(self.w_bf16, lo, hi)), ptr(sl(ema, lo, hi)),
                                                    float(ema_decay), emode, stream_ptr()), "masked_clip_adam")
+            if split is not None and excl is not None:
+                # the remaining block ranges: on the second stream, behind everything above (what this stream swept at full rate
+                # is what the forward pass needs first), bounded grid, one event per range
+                cur = _t.cuda.current_stream()
+                ready = _t.cuda.Event()
+                ready.record(cur)
+                split["stream"].wait_event(ready)
+                sp = ctypes.c_void_p(split["stream"].cuda_stream)
+                for i, ((lo, hi), blk_ev) in enumerate(zip(rngs, split["events"])):
+                    if i < head:
+                        blk_ev.record(cur)
+                        continue
+                    check(L.sfron_masked_clip_adam_wg(ptr(self.p[lo:hi]), ptr(self.g[lo:hi]), None, ptr(self.m[lo:hi]), ptr(self.v[lo:hi]),
+                                                      ptr(sl(mask, lo, hi)), ptr(stats), hi - lo, b1, b2, self.eps, step_size, bc2_sqrt,
+                                                      decay_mul, ptr(sl(self.w_bf16, lo, hi)), ptr(sl(ema, lo, hi)), float(ema_decay), emode,
+                                                      int(split.get("max_workgroups", 0)), sp), "masked_clip_adam_wg")
+                    blk_ev.record(split["stream"])
             self.lowrank = None
         if ev is not None:
             ev[1].record()
