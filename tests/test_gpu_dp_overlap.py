@@ -28,16 +28,23 @@ def test_overlapped_allreduce_path_matches_plain_path():
     bat = lambda it: (data.synthetic_batch(5, it, "forget", **kw), data.synthetic_batch(5, it, "remain", **kw))
     hp = dict(lr=2e-4, forget_alpha=0.3, grad_clip=1.0, ema_decay=0.99, mask=None, unlearn_loss="ga", forget_class=3)
 
-    def run(overlap):
+    def run(overlap, single_process_shortcuts=False):
         _, model = build_pair(cfg, B, seed=21)
         runner = step.DiTSFRon(model, diffusion.create_diffusion(""), overlap_allreduce=overlap, **hp)
         assert runner._overlap_enabled() == overlap
+        if not single_process_shortcuts:
+            # the data-parallel machinery is compared with the plain GEMM + flat-sweep pass: the single-process shortcuts (adaLN
+            # gradient as a rank-(batch) sweep -- another summation order --, block sweeps beside the forward pass) are checked below
+            runner.factored_ada = runner.sweep_beside_forward = False
         for it in range(2):
             out = runner.step(*bat(it))
         torch.cuda.synchronize()
         return model.engine.params.clone(), model.engine.grads.clone(), out["stats"].clone()
 
     p0, g0, s0 = run(False)
+    p2, _, s2 = run(False, single_process_shortcuts=True)
+    # the shortcuts change summation orders only: the same parameters to fp32 rounding after two iterations (4 optimizer steps)
+    assert torch.allclose(s2, s0, rtol=1e-5) and (p2 - p0).abs().max().item() <= 2e-4 * 4 * 1e-3 + 1e-7, (p2 - p0).abs().max().item()
     created = False
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
