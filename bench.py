@@ -9,7 +9,7 @@ remain fwd/bwd -> AdamW, EMA; synthetic latents / labels / timesteps / noise alr
 Weak scaling: every rank runs batch 32 (global batch 32*N), gradients SUM-all-reduced over RCCL; "value" counts the batch-32 steps
 of ALL ranks per second (N x the iteration rate), "ms_per_step" is the wall time of one synchronous iteration.
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline"     -- the kernel with the largest share of GPU time (profiles/r02_kernel_table.md): the weight-gradient GEMM
+  "roofline"     -- the kernel with the largest share of GPU time (profiles/r03_kernel_table.md): the weight-gradient GEMM
                     (one kernel for the four products dW = dY^T X of a block), timed live with HIP event pairs recorded on the
                     weight-gradient stream it is launched on (all four GEMMs of every 9th block of every backward pass inside
                     the timed region); "others" holds the same measurement for the fc1 forward GEMM (main stream) and an "hbm"
@@ -221,7 +221,8 @@ def main():
     loss_ok = bool(torch.isfinite(out["remain_mse"]).all().item() and torch.isfinite(out["forget_mse"]).all().item())
     n_probe, probe_ms = eng.probe_read()
     n_wp, wp_ms = eng.wgrad_probe_read()
-    sweep_ms = [a.elapsed_time(b) for a, b in runner.opt.timed]
+    sweep_ms = [a.elapsed_time(b) for a, b, whole in runner.opt.timed if whole]      # the remain-stage sweeps (the forget stage's block
+                                                                                        # ranges run beside the next forward pass)
     cfg = eng.cfg
     M = args.batch * eng.tokens
     fc1_flops = 2.0 * M * cfg.mlp_hidden * cfg.hidden
@@ -233,30 +234,36 @@ def main():
     step_flops = 6.0 * fwd_per_sample * args.batch
     ms_per_step = elapsed / args.steps * 1e3
 
-    # dominant kernel by GPU time (profiles/r02_kernel_table.md): the weight-gradient GEMM k_gemm_pipe<4,2,3,6,true,true,1,2,2>, one
+    # dominant kernel by GPU time (profiles/r03_kernel_table.md): the weight-gradient GEMM k_gemm_pipe<4,2,3,6,true,true,1,2,2>, one
     # kernel name for the four shapes dW = dY^T X of a block (qkv 65.2, proj 21.7, fc1 87.0, fc2 87.0 GFLOP): the probe brackets all
     # four, so the mean launch does their mean
     wg_flops = 0.25 * (2.0 * M * 3 * D * D + 2.0 * M * D * D + 2 * 2.0 * M * F * D)
     wg_ms = wp_ms / max(1, n_wp)
     wg_ach = wg_flops / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0
-    # parameter sweep: bytes per launch = 31 B/param (forget stage: g, mask, p, m, v in; p, m, v, bf16 out) and 38 B/param
-    # (remain stage: + EMA in/out, no mask), alternating
+    # parameter sweep, remain stage: 38 B/param (g, p, m, v, EMA in; p, m, v, EMA, bf16 out) over the arena, minus the 4 B/param
+    # gradient read of the adaLN matrix, whose gradient the sweep forms from its two factors (k_adam_lowrank)
     nt = eng.n_trainable
-    sweep_bytes = 34.5 * nt
+    n_ada = (6 * L + 2) * D * D if runner.factored_ada and world == 1 else 0
+    sweep_bytes = 38.0 * nt - 4.0 * n_ada
     sw_ms = sum(sweep_ms) / max(1, len(sweep_ms))
     sw_ach = sweep_bytes / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else 0.0
 
-    # HBM traffic of the probed kernels: PMC counters need their own rocprofv3 passes (FETCH_SIZE, WRITE_SIZE), so the
-    # numbers are measured offline on this same command and committed under profiles/ (see the json's "note")
-    def committed_traffic(fname):
-        tpath = os.path.join(ROOT, "profiles", fname)
-        if args.model == "DiT-XL/2" and args.batch == 32 and os.path.isfile(tpath):
-            return json.load(open(tpath)).get("traffic_bytes_per_launch")
-        return None
-    traffic = committed_traffic("r02_wgrad_traffic.json")
+    # HBM traffic of the probed kernels: PMC counters need their own rocprofv3 passes (FETCH_SIZE, WRITE_SIZE), so the numbers are
+    # measured offline on this same command (tools/pmc_traffic.py) and committed under profiles/ TOGETHER WITH the hash of the HIP
+    # sources they were measured on: a figure whose hash differs from the tree's is not reported (traffic: null)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from csrc_sha import csrc_sha
+    tree_sha = csrc_sha()
 
-    if wd:
-        wd.phase("check / report", 600)
+    def committed_traffic(fname, key="traffic_bytes_per_launch"):
+        tpath = os.path.join(ROOT, "profiles", fname)
+        if args.model == "DiT-XL/2" and args.batch == 32 and not args.fp8 and os.path.isfile(tpath):
+            j = json.load(open(tpath))
+            if j.get("csrc_sha") == tree_sha:
+                return j.get(key)
+        return None
+    traffic = committed_traffic("r03_wgrad_traffic.json")
+
     check_res = None
     if args.check and world > 1:
         # N-rank == 1-rank parity at equal global batch: the all-reduced gradient of the sharded forget pass of step 0 against
@@ -297,18 +304,20 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": "k_gemm_pipe<4,2,3,6,true,true,1,2,2> = 192x192 tile, three LDS slots, interleaved MFMA/LDS-DMA schedule: the weight "
                                    f"gradients dW = dY^T X of a block (qkv [{3 * D}x{D}], proj [{D}x{D}], fc1 [{F}x{D}], fc2 [{D}x{F}], contraction over "
-                                   f"{M} token rows; mean {wg_flops / 1e9:.1f} GFLOP per launch); largest share of GPU time (profiles/r02_kernel_table.md); "
+                                   f"{M} token rows; mean {wg_flops / 1e9:.1f} GFLOP per launch); largest share of GPU time (profiles/r03_kernel_table.md); "
                                    "it runs on the weight-gradient stream BESIDE the dgrad chain, so its duration is shared-CU time",
                          "achieved": wg_ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": wg_ach / MFMA_BF16_PEAK_TFLOPS,
                          "traffic": traffic, "flops_per_launch": wg_flops, "avg_launch_ms": wg_ms, "launches_timed": n_wp,
                          "others": {
                              "fwd_fc1_gelu": {"bound": "mfma", "kernel": f"k_gemm_pipe<4,2,4,6,false,false,2,1,2>: Mlp.fc1 + GELU-tanh [{M}x{D}]x[{D}x{F}], block 0 of "
                                               "every forward pass (main stream, nothing beside it)", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
-                                              "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": committed_traffic("r01_fc1_traffic.json"),
+                                              "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": committed_traffic("r03_fc1_traffic.json"),
                                               "flops_per_launch": fc1_flops, "avg_launch_ms": avg_ms, "launches_timed": n_probe},
-                             "hbm": {"bound": "hbm", "kernel": "k_masked_clip_adam: mask -> clip -> AdamW (+ EMA, + bf16 shadow) over the flat arenas, "
-                                     "31 B/param (forget stage) and 38 B/param (remain stage) alternating", "achieved": sw_ach, "peak": HBM_PEAK_GBS,
-                                     "unit": "GB/s", "frac": sw_ach / HBM_PEAK_GBS, "traffic": committed_traffic("r02_sweep_traffic.json"),
+                             "hbm": {"bound": "hbm", "kernel": "remain-stage parameter sweep: k_masked_clip_adam (AdamW + EMA + bf16 shadow, 38 B/param) over the flat arenas "
+                                     "+ k_adam_lowrank over the adaLN matrix (gradient formed from its two factors: 34 B/param)", "achieved": sw_ach, "peak": HBM_PEAK_GBS,
+                                     "unit": "GB/s", "frac": sw_ach / HBM_PEAK_GBS, "traffic": None,
+                                     "traffic_all_sweeps_per_step": committed_traffic("r03_sweep_traffic.json", "traffic_bytes_per_step"),
+                                     "algorithmic_all_sweeps_per_step": committed_traffic("r03_sweep_traffic.json", "algorithmic_bytes_per_step"),
                                      "bytes_per_launch": sweep_bytes, "avg_launch_ms": sw_ms, "launches_timed": len(sweep_ms)}}},
         }
         if not args.no_cpu_baseline and world == 1:

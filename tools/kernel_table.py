@@ -15,6 +15,7 @@ import re
 
 M, D, F, T, H, HD, B, L = 8192, 1152, 4608, 256, 16, 72, 32, 28
 NPAR = 674_834_720 + 0          # trainable parameters of DiT-XL/2 (arena padding ignored)
+NADA = (6 * L + 2) * D * D      # the adaLN_modulation weights of all blocks + final layer, one [NM][D] matrix
 G = lambda m, n, k: 2.0 * m * n * k
 QKV, PROJ, FC1, FC2 = G(M, 3 * D, D), G(M, D, D), G(M, F, D), G(M, D, F)
 ATT_F = 4.0 * T * T * HD * H * B            # QK^T + PV
@@ -33,8 +34,12 @@ RULES = [
     (r"k_attn_bwd_fused", "attention backward (fused dQ, dK, dV)", "mfma", 2.5 * ATT_F, "5 products"),
     (r"k_attn_bwd_dq", "attention backward dQ (recomputes S, dP)", "mfma", 1.5 * ATT_F, "3 products of the 5 algorithmic ones"),
     (r"k_attn_bwd_dkv", "attention backward dK, dV (recomputes S, dP)", "mfma", 1.0 * ATT_F, "remaining 2 of the 5 algorithmic products"),
-    (r"k_masked_clip_adam", "mask -> clip -> AdamW (+EMA, +bf16 shadow)", "hbm", 34.5 * NPAR, "31 B/param forget stage, 38 B/param remain stage"),
-    (r"k_sumsq_masked", "masked sum of squares (clip norm)", "hbm", 5.0 * NPAR, "g fp32 + mask byte"),
+    (r"k_masked_clip_adam", "mask -> clip -> AdamW (+EMA, +bf16 shadow), flat ranges (round 3: many launches of different length)", "hbm", None,
+     "31 B/param forget stage, 38 B/param remain stage; bytes per launch vary: see bench.py's others.hbm for the timed remain-stage sweep"),
+    (r"k_adam_lowrank", "AdamW of the adaLN matrix, gradient formed from its two factors", "hbm", 30.5 * NADA, "27 B/param forget stage, 34 remain stage"),
+    (r"k_sumsq_lowrank", "masked sum of squares of the rank-(batch) adaLN gradient", "hbm", 1.0 * NADA, "mask byte only; 32 FMA per element"),
+    (r"k_sumsq_masked", "masked sum of squares (clip norm), flat ranges", "hbm", None, "g fp32 + mask byte"),
+    (r"k_gemm8", "fp8 (e4m3) forward GEMM (config 5)", "mfma", None, ""),
     (r"k_row_bwd<true, true>", "LN backward + gate backward (fused)", "hbm", 170e6, "DESIGN.md section 4"),
     (r"k_row_bwd<true, false>", "LN backward", "hbm", 113e6, ""),
     (r"k_row_bwd<false, true>", "gate backward", "hbm", 94e6, ""),

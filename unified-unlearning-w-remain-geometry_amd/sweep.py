@@ -160,7 +160,8 @@ class FlatAdam:
             self.lowrank = None
         if ev is not None:
             ev[1].record()
-            self.timed.append(ev)
+            # (start, end, whole): whole = every byte of this step went through the current stream inside the bracket
+            self.timed.append((ev[0], ev[1], split is None))
 
 
 def ema_update(ema, p, decay, mode=1):
