@@ -631,3 +631,18 @@ def test_config1_fifty_sfron_steps_batch64_native():
     assert torch.isfinite(run.flat.p).all() and not torch.equal(run.flat.p, p0)
     assert rl[-5:].mean() < rl[:5].mean()             # the remain stage keeps fitting the remaining classes
     assert run.opt.step_count == 100
+
+
+def test_unet_test_mode_backward_raises_clear_error():
+    """mode="test" is inference-only here (the reference's is differentiable: models/diffusion.py:340-357): a backward() through it
+    must fail with a message that points to DDPMFisherAccumulator, not with a missing-gradient surprise later."""
+    from sfron import _lib
+    _, model = _pair(SMALL, seed=6)
+    model.eval()
+    x, t, c = torch.randn(2, 3, 16, 16, device=DEV), torch.tensor([3.0, 700.0], device=DEV), torch.tensor([1, 2], device=DEV)
+    out = model(x, t, c, mode="test", cond_scale=2.0)
+    assert out.requires_grad
+    with pytest.raises(_lib.SfronError, match="DDPMFisherAccumulator"):
+        out.sum().backward()
+    with torch.no_grad():
+        assert not model(x, t, c, mode="test", cond_scale=2.0).requires_grad

@@ -151,12 +151,23 @@ __device__ __forceinline__ void lowrank_grad(const __bf16* __restrict__ dmod, co
                                              int c, f32x4 (&acc)[LR_ROWS]) {
 #pragma unroll
   for (int r = 0; r < LR_ROWS; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int b = 0; b < R; ++b) {
-    const bf16x4 s4 = *reinterpret_cast<const bf16x4*>(sc + (size_t)b * D + 4 * c);
-    const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(dmod + (size_t)b * NM + n0);       // wave-uniform address
-    const f32x4 sv = {bf2f(s4[0]), bf2f(s4[1]), bf2f(s4[2]), bf2f(s4[3])};
+  // eight batch rows per trip: all sixteen loads of a trip are issued before its 256 FMAs (a load-use loop pays one L2 latency per row)
+  for (int b0 = 0; b0 < R; b0 += 8) {
+    bf16x4 s4[8];
+    bf16x8 d8[8];
 #pragma unroll
-    for (int r = 0; r < LR_ROWS; ++r) acc[r] += sv * bf2f(d8[r]);
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + u < R ? b0 + u : R - 1;                       // clamped: the tail's surplus rows get weight 0 below
+      s4[u] = *reinterpret_cast<const bf16x4*>(sc + (size_t)b * D + 4 * c);
+      d8[u] = *reinterpret_cast<const bf16x8*>(dmod + (size_t)b * NM + n0);    // wave-uniform address
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float on = b0 + u < R ? 1.0f : 0.0f;
+      const f32x4 sv = {bf2f(s4[u][0]) * on, bf2f(s4[u][1]) * on, bf2f(s4[u][2]) * on, bf2f(s4[u][3]) * on};
+#pragma unroll
+      for (int r = 0; r < LR_ROWS; ++r) acc[r] += sv * bf2f(d8[u][r]);
+    }
   }
 }
 

@@ -445,6 +445,18 @@ class _TapeNet(nn.Module):
         return out
 
 
+class _GuidedNoBackward(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, anchor):
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        raise _lib.SfronError("Conditional_Model(mode='test') is inference-only here: its backward pass is not implemented.  For the Fisher "
+                              "pass of DDPM/runners/diffusion.py:1244-1299 use sfron.fisher.DDPMFisherAccumulator (both guidance branches, "
+                              "gradients summed in the arena); for sampling wrap the call in torch.no_grad().")
+
+
 class Conditional_Model(_TapeNet):
     def __init__(self, config=None, *, ch=128, out_ch=3, ch_mult=(1, 2, 2, 2), num_res_blocks=2, attn_resolutions=(16,), dropout=0.1,
                  in_channels=3, resolution=32, resamp_with_conv=True, n_classes=10, cond_drop_prob=0.1, device="cuda"):
@@ -850,6 +862,11 @@ class Conditional_Model(_TapeNet):
             null = self._forward(x, t, c, keep_mask=torch.zeros(B, dtype=torch.uint8, device=self.device_))
             out = torch.empty_like(logits)
             check(_L().sfron_axpby(ptr(logits), ptr(null), 1.0 + cond_scale, -float(cond_scale), logits.numel(), ptr(out), stream_ptr()), "axpby")
+        if torch.is_grad_enabled():
+            # the reference's mode="test" (_forward_with_cond_scale, models/diffusion.py:340-357) is differentiable and its Fisher loop
+            # back-propagates through it (runners/diffusion.py:1260-1276); here the guided forward is inference-only.  The result
+            # carries an autograd edge whose backward says so, instead of a tensor that silently has no gradient.
+            return _GuidedNoBackward.apply(out, self._anchor())
         return out
 
 
