@@ -219,7 +219,8 @@ int sfron_ln_modulate_fwd_q(const float* x, const float* shift, const float* sca
  *   SFRON_EPI_GELU      aux = result (pre-activation, bf16), c_bf16 = gelu_tanh(result),
  *                       c_e4m3 = e4m3(gelu_tanh(result) * c_e4m3_scale) [M][N]            (fc1: h for the backward pass AND for fc2)
  *   SFRON_EPI_GATE_RES  aux = result (bf16), c_f32 = resid + gate[row / tokens] * result  (proj, fc2)
- * Shapes: M % 256 == 0, N % 128 == 0, K % 128 == 0 (sfron_fp8_gemm_supported). */
+ * Shapes: M % 256 == 0, N % 128 == 0 or N % 144 == 0 (256 x 128 / 256 x 144 tiles, the one that fills the CUs better), K % 128 == 0
+ * (sfron_fp8_gemm_supported). */
 typedef struct sfron_fp8_gemm_desc {
   const uint8_t* A; const uint8_t* B;
   int M, N, K;

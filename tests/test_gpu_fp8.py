@@ -86,7 +86,7 @@ def test_weight_quantisation_scales_and_delayed_scaling():
     assert torch.equal(amax.view(torch.float32).cpu(), got_amax)                  # the quantising pass collected the amax again
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (512, 384, 256), (8192, 1152, 1152)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (512, 384, 256), (256, 288, 256), (8192, 1152, 1152), (8192, 4608, 1152)])
 def test_fp8_gemm_epilogues_vs_torch(M, N, K):
     import ctypes
     from oracle import fp8_ref

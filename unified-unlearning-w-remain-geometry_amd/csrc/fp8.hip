@@ -159,9 +159,17 @@ struct Gemm8Args {
 };
 enum { E8_BF16 = 0, E8_GELU = 2, E8_GATE_RES = 3 };
 
-constexpr int FBM = 256, FBN = 128, BKB = 128, NW = 8, NSLOT8 = 3, NT8 = FBN / 16;
-constexpr int A_BYTES = FBM * BKB, B_BYTES = FBN * BKB, SLOT = A_BYTES + B_BYTES;
-constexpr int NA = FBM * 8 / 64 / NW, NB = FBN * 8 / 64 / NW, NDMA8 = NA + NB;
+constexpr int FBM = 256, BKB = 128, NW = 8, NSLOT8 = 3;
+constexpr int A_BYTES = FBM * BKB, NA = FBM * 8 / 64 / NW;
+// NTL = 16-column n-tiles per workgroup tile: 8 (256 x 128) or 9 (256 x 144 -- a [8192 x 1152] output is then exactly 256 tiles, as
+// for the bf16 kernels; its 18 B-tile DMA instructions do not divide by the 8 waves: the waves without a third share send theirs
+// through a zero-length descriptor to a dummy LDS kilobyte, so every wave issues the same number and the counted vmcnt waits hold)
+template <int NTL> struct Tile8 {
+  static constexpr int FBN = NTL * 16, B_BYTES = FBN * BKB, SLOT = A_BYTES + B_BYTES;
+  static constexpr int NB_TOTAL = FBN * 8 / 64, NB = (NB_TOTAL + NW - 1) / NW, NDMA = NA + NB;
+  static constexpr bool EVEN = NB_TOTAL % NW == 0;
+  static constexpr size_t LDS = (size_t)NSLOT8 * SLOT + (EVEN ? 0 : 1024);
+};
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void dma16b(__amdgpu_buffer_rsrc_t rsrc, uint8_t* dst, int voff, int soff) {
@@ -176,8 +184,10 @@ __device__ __forceinline__ i32x8 frag32(const uint8_t* img, int row, int g) {
 
 }  // namespace
 
-template <int EPI>
+template <int EPI, int NTL>
 __global__ __launch_bounds__(512) void k_gemm8(Gemm8Args g) {
+  using TL = Tile8<NTL>;
+  constexpr int FBN = TL::FBN, SLOT = TL::SLOT, NB = TL::NB, NT8 = NTL, NDMA8 = TL::NDMA;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -191,6 +201,8 @@ __global__ __launch_bounds__(512) void k_gemm8(Gemm8Args g) {
   const int K = g.K, nk = K / BKB;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, g.M * K, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, g.N * K, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsNull = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, 0, 0x00020000);
+  uint8_t* const dummy = smem8 + NSLOT8 * SLOT;
   const int lc16 = ((lane & 7) ^ ((lane >> 3) & 7)) << 4;
   int a_off[NA], b_off[NB];
 #pragma unroll
@@ -203,7 +215,13 @@ __global__ __launch_bounds__(512) void k_gemm8(Gemm8Args g) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) dma16b(rsA, iA + (wave + i * NW) * 1024, a_off[i], k0);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) dma16b(rsB, iB + (wave + i * NW) * 1024, b_off[i], k0);
+    for (int i = 0; i < NB; ++i) {
+      if constexpr (TL::EVEN) dma16b(rsB, iB + (wave + i * NW) * 1024, b_off[i], k0);
+      else {
+        const bool ok = wave + i * NW < TL::NB_TOTAL;               // wave-uniform
+        dma16b(ok ? rsB : rsNull, ok ? iB + (wave + i * NW) * 1024 : dummy, b_off[i], k0);
+      }
+    }
   };
   f32x4 acc[2][NT8];
 #pragma unroll
@@ -262,32 +280,51 @@ __global__ __launch_bounds__(512) void k_gemm8(Gemm8Args g) {
     }
   }
 }
-template __global__ void k_gemm8<E8_BF16>(Gemm8Args);
-template __global__ void k_gemm8<E8_GELU>(Gemm8Args);
-template __global__ void k_gemm8<E8_GATE_RES>(Gemm8Args);
+template __global__ void k_gemm8<E8_BF16, 8>(Gemm8Args);
+template __global__ void k_gemm8<E8_GELU, 8>(Gemm8Args);
+template __global__ void k_gemm8<E8_GATE_RES, 8>(Gemm8Args);
+template __global__ void k_gemm8<E8_BF16, 9>(Gemm8Args);
+template __global__ void k_gemm8<E8_GELU, 9>(Gemm8Args);
+template __global__ void k_gemm8<E8_GATE_RES, 9>(Gemm8Args);
 
 namespace {
-template <int EPI>
-int launch8(const Gemm8Args& g, hipStream_t s) {
-  const size_t lds = (size_t)NSLOT8 * SLOT;
+template <int EPI, int NTL>
+int launch8t(const Gemm8Args& g, hipStream_t s) {
+  const size_t lds = Tile8<NTL>::LDS;
   static std::atomic<uint64_t> done{0};
   int dev = 0;
   (void)hipGetDevice(&dev);
   const uint64_t bit = 1ull << (dev & 63);
   if ((done.fetch_or(bit) & bit) == 0) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, NTL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return (int)hipGetLastError();
   }
-  hipLaunchKernelGGL((k_gemm8<EPI>), dim3((g.M / FBM) * (g.N / FBN)), dim3(512), lds, s, g);
+  hipLaunchKernelGGL((k_gemm8<EPI, NTL>), dim3((g.M / FBM) * (g.N / (NTL * 16))), dim3(512), lds, s, g);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
+}
+// tile width: the one that fills the last round of 256 CUs better (ties: the wider tile, fewer operand bytes per FLOP)
+inline int pick_ntl(int M, int N) {
+  auto eff = [&](int w) {
+    if (N % w) return 0.0;
+    const long tiles = (long)(M / FBM) * (N / w);
+    return (double)tiles / (double)(((tiles + 255) / 256) * 256);
+  };
+  const double e8 = eff(128), e9 = eff(144);
+  return e9 >= e8 && e9 > 0.0 ? 9 : 8;
+}
+template <int EPI>
+int launch8(const Gemm8Args& g, hipStream_t s) {
+  return pick_ntl(g.M, g.N) == 9 ? launch8t<EPI, 9>(g, s) : launch8t<EPI, 8>(g, s);
 }
 inline int grid_for(int64_t items) { int64_t b = (items + TPB - 1) / TPB; return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
 }  // namespace
 
 extern "C" {
 
-int sfron_fp8_gemm_supported(int M, int N, int K) { return (M > 0 && N > 0 && K > 0 && M % FBM == 0 && N % FBN == 0 && K % BKB == 0) ? 1 : 0; }
+int sfron_fp8_gemm_supported(int M, int N, int K) {
+  return (M > 0 && N > 0 && K > 0 && M % FBM == 0 && (N % 128 == 0 || N % 144 == 0) && K % BKB == 0) ? 1 : 0;
+}
 
 int sfron_fp8_gemm(const sfron_fp8_gemm_desc* d, void* stream) {
   SFRON_CHECK_ARG(d && d->A && d->B && d->w_scale && d->a_scale > 0.f);
