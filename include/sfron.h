@@ -59,6 +59,13 @@ int sfron_masked_clip_adam_wg(float* p, const float* g, const float* g2, float* 
                               double decay_mul, uint16_t* w_bf16, float* ema, double ema_decay, int ema_mode, int max_workgroups,
                               void* stream);
 
+/* config 5: the sweep over ONE weight tensor (+ its bias) that also writes the e4m3 shadow of the new values, w_e4m3[i] =
+ * e4m3(p_new[i] * *w_e4m3_scale) (device scalar from sfron_fp8_update_scales): the optimizer step re-quantises what it touches, no
+ * second pass over the masters.  n % 4 == 0; max_workgroups as sfron_masked_clip_adam_wg. */
+int sfron_masked_clip_adam_q(float* p, const float* g, float* m, float* v, const uint8_t* mask, const float* stats, int64_t n, double beta1,
+                             double beta2, double eps, double step_size, double bc2_sqrt, double decay_mul, uint16_t* w_bf16, float* ema,
+                             double ema_decay, int ema_mode, uint8_t* w_e4m3, const float* w_e4m3_scale, int max_workgroups, void* stream);
+
 /* The same two sweeps over a weight matrix W [NM][D] (p / m / v / mask / w_bf16 / ema point at ITS first element) whose gradient is
  * a rank-R product dW[n][k] = sum_{b < R} dmod[b][n] * sc[b][k] (bf16 factors, fp32 accumulation in index order), formed inside
  * the sweep instead of by a weight-gradient GEMM that writes NM*D floats for the sweep to read back: the adaLN_modulation Linears
@@ -511,7 +518,8 @@ int sfron_dit_forward_after(const sfron_dit_cfg* cfg, const float* params, const
 int64_t sfron_dit_fp8_workspace_bytes(const sfron_dit_cfg* cfg);
 int sfron_dit_forward_fp8(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const uint8_t* params_e4m3,
                           const float* w_scales, const float* act_scales, const float* x_t, const int64_t* t, const int64_t* y,
-                          const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out, void* stream);
+                          const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out,
+                          void* const* block_ready /* as sfron_dit_forward_after, or NULL */, void* stream);
 /* Same as sfron_dit_forward, with HIP events recorded (on `stream`) around the fc1 GEMM of block 0 -- the
  * dominant kernel class -- into `probe` (may be NULL).  Used by bench.py for the live roofline measurement. */
 int sfron_dit_forward_probed(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,

@@ -28,6 +28,8 @@ _PROTOS = {
                                        c_double, _P, _P, c_double, c_int, _S]),
     "sfron_masked_clip_adam_wg": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_double,
                                           c_double, _P, _P, c_double, c_int, c_int, _S]),
+    "sfron_masked_clip_adam_q": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_double, c_double, _P, _P,
+                                         c_double, c_int, _P, _P, c_int, _S]),
     "sfron_sumsq_lowrank": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, POINTER(c_int), _S]),
     "sfron_adam_lowrank": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_double,
                                    c_double, _P, _P, c_double, c_int, _S]),
@@ -192,7 +194,7 @@ _PROTOS.update({
     "sfron_dit_forward_probed": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_dit_forward_after": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_dit_fp8_workspace_bytes": (c_int64, [POINTER(DitCfg)]),
-    "sfron_dit_forward_fp8": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, POINTER(c_float), _P, _P, _P, _P, _P, _P, _P, _S]),
+    "sfron_dit_forward_fp8": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, POINTER(c_float), _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_probe_create": (c_int, [c_int, POINTER(c_void_p)]),
     "sfron_probe_reset": (c_int, [c_void_p]),
     "sfron_probe_read": (c_int, [c_void_p, POINTER(c_int), POINTER(c_double)]),

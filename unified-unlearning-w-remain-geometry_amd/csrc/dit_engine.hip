@@ -322,7 +322,7 @@ int64_t sfron_dit_fp8_workspace_bytes(const sfron_dit_cfg* cfg) {
 
 int sfron_dit_forward_fp8(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const uint8_t* params_e4m3,
                           const float* w_scales, const float* act_scales, const float* x_t, const int64_t* t, const int64_t* y,
-                          const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out, void* stream) {
+                          const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out, void* const* block_ready, void* stream) {
   Dims d;
   RUN(make_dims(cfg, d));
   SFRON_CHECK_ARG(params_e4m3 && w_scales && act_scales && workspace_e4m3);
@@ -332,7 +332,7 @@ int sfron_dit_forward_fp8(const sfron_dit_cfg* cfg, const float* params, const u
     return SFRON_ERR_UNSUPPORTED;
   Fp8Ctx f{params_e4m3, w_scales, act_scales[0], act_scales[1], act_scales[2], nullptr, nullptr, nullptr};
   (void)fp8_ws(d, (char*)workspace_e4m3, &f);
-  return dit_forward_impl(cfg, params, params_bf16, x_t, t, y, drop, workspace, out, nullptr, &f, stream);
+  return dit_forward_impl(cfg, params, params_bf16, x_t, t, y, drop, workspace, out, nullptr, &f, stream, block_ready);
 }
 
 static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,

@@ -91,12 +91,24 @@ __device__ __forceinline__ float ema_one(float e, float p, const AdamArgs& a) {
   return a.ema_w * p + a.ema_decay * e;
 }
 
+__device__ __forceinline__ uint32_t pack4_e4m3(float a, float b, float c, float d) {      // OCP e4m3fn, RNE, saturating (as csrc/fp8.hip)
+  const float mx = 448.0f;
+  int r = 0;
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(a, -mx), mx), fminf(fmaxf(b, -mx), mx), r, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(c, -mx), mx), fminf(fmaxf(d, -mx), mx), r, true);
+  return (uint32_t)r;
+}
+
+// w8 / w8_scale (optional, config 5): the e4m3 shadow of the NEW p, quantised with the device scalar *w8_scale -- the range is one
+// weight tensor (+ its bias, whose e4m3 bytes nobody reads), so the re-quantisation pass over the masters disappears
 __global__ __launch_bounds__(TPB) void k_masked_clip_adam(float* __restrict__ p, const float* __restrict__ g,
                                                           const float* __restrict__ g2, float* __restrict__ m, float* __restrict__ v,
                                                           const uint8_t* __restrict__ mask, const float* __restrict__ stats,
                                                           int64_t n, AdamArgs a, uint16_t* __restrict__ wbf,
-                                                          float* __restrict__ ema) {
+                                                          float* __restrict__ ema, uint8_t* __restrict__ w8 = nullptr,
+                                                          const float* __restrict__ w8_scale = nullptr) {
   const float coef = stats ? stats[1] : 1.0f;
+  const float s8 = w8 ? *w8_scale : 1.0f;
   const int64_t n4 = n >> 2;
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -120,6 +132,7 @@ __global__ __launch_bounds__(TPB) void k_masked_clip_adam(float* __restrict__ p,
       bf16x4 b = {f2bf(pp.x), f2bf(pp.y), f2bf(pp.z), f2bf(pp.w)};
       reinterpret_cast<bf16x4*>(wbf)[i] = b;
     }
+    if (w8) reinterpret_cast<uint32_t*>(w8)[i] = pack4_e4m3(pp.x * s8, pp.y * s8, pp.z * s8, pp.w * s8);
     if (a.ema_mode) {
       float4 ee = reinterpret_cast<float4*>(ema)[i];
       ee.x = ema_one(ee.x, pp.x, a); ee.y = ema_one(ee.y, pp.y, a);
@@ -330,6 +343,25 @@ int sfron_masked_clip_adam_wg(float* p, const float* g, const float* g2, float* 
   if (max_workgroups > 0 && grid > max_workgroups) grid = max_workgroups;      // a sweep that runs BESIDE a GEMM chain: bounded share of the chip
   hipLaunchKernelGGL(k_masked_clip_adam, dim3(grid), dim3(TPB), 0, (hipStream_t)stream,
                      p, g, g2, m, v, mask, stats, n, a, w_bf16, ema);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_masked_clip_adam_q(float* p, const float* g, float* m, float* v, const uint8_t* mask, const float* stats, int64_t n, double beta1,
+                             double beta2, double eps, double step_size, double bc2_sqrt, double decay_mul, uint16_t* w_bf16, float* ema,
+                             double ema_decay, int ema_mode, uint8_t* w_e4m3, const float* w_e4m3_scale, int max_workgroups, void* stream) {
+  SFRON_CHECK_ARG(p && g && m && v && n >= 0 && n % 4 == 0 && w_e4m3 && w_e4m3_scale);
+  SFRON_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && ((uintptr_t)w_e4m3 & 3) == 0);
+  SFRON_CHECK_ARG(!mask || ((uintptr_t)mask & 3) == 0);
+  SFRON_CHECK_ARG(!w_bf16 || ((uintptr_t)w_bf16 & 7) == 0);
+  SFRON_CHECK_ARG(ema_mode == 0 || (ema && ((uintptr_t)ema & 15) == 0 && (ema_mode == 1 || ema_mode == 2)));
+  AdamArgs a{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)step_size, (float)bc2_sqrt,
+             (float)decay_mul, (float)ema_decay, (float)(1.0 - ema_decay), ema_mode};
+  int grid = grid_for(n >> 2);
+  if (grid > 768) grid = 768;
+  if (max_workgroups > 0 && grid > max_workgroups) grid = max_workgroups;
+  hipLaunchKernelGGL(k_masked_clip_adam, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, p, g, (const float*)nullptr, m, v, mask, stats, n, a, w_bf16,
+                     ema, w_e4m3, w_e4m3_scale);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

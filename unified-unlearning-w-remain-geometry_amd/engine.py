@@ -153,8 +153,16 @@ class DitEngine:
         for l in range(c.depth):
             b = lay["blocks"] + l * lay["blk_stride"]
             rows += [(b + lay["qkv_w"], 3 * D * D), (b + lay["proj_w"], D * D), (b + lay["fc1_w"], F * D), (b + lay["fc2_w"], D * F)]
+        # per block: the (weight + bias) element ranges with the index of their scale -- what a re-quantising sweep launches over
+        tens = []
+        for l in range(c.depth):
+            b = lay["blocks"] + l * lay["blk_stride"]
+            ends = [b + lay["proj_w"], b + lay["fc1_w"], b + lay["fc2_w"], b + lay["blk_stride"]]
+            starts = [b + lay["qkv_w"], b + lay["proj_w"], b + lay["fc1_w"], b + lay["fc2_w"]]
+            tens.append([(starts[i], ends[i], 4 * l + i) for i in range(4)])
         ws = L.sfron_dit_fp8_workspace_bytes(ctypes.byref(c))
         self.fp8 = dict(
+            tensors=tens, refresh_every=16, sweeps=0,
             act=(ctypes.c_float * 3)(*act), act_scales=act,
             table=torch.tensor(rows, dtype=torch.int64, device=self.device), n=len(rows),
             w8=torch.zeros(self.n_total, dtype=torch.uint8, device=self.device),
@@ -176,6 +184,15 @@ class DitEngine:
         check(L.sfron_fp8_update_scales(ptr(f["amax"]), f["n"], ptr(f["scales"]), s), "fp8_update_scales")
         check(L.sfron_fp8_quant_tensors(ptr(self.params), ptr(f["table"]), f["n"], ptr(f["scales"]), ptr(f["amax"]), ptr(f["w8"]), 1, s),
               "fp8_quant")
+
+    def fp8_refresh_scales(self):
+        """amax pass over the fp32 masters + new power-of-two scales (no quantisation): what a run whose optimizer sweep writes the e4m3
+        shadow itself (FlatAdam.step(split=dict(quant=...))) calls every ``refresh_every`` sweeps, BEFORE the sweep -- the sweep then
+        rewrites every e4m3 weight with the new scale."""
+        f, L, s = self.fp8, _lib.lib(), stream_ptr()
+        f["amax"].zero_()
+        check(L.sfron_fp8_quant_tensors(ptr(self.params), ptr(f["table"]), f["n"], None, ptr(f["amax"]), None, 0, s), "fp8_amax")
+        check(L.sfron_fp8_update_scales(ptr(f["amax"]), f["n"], ptr(f["scales"]), s), "fp8_update_scales")
 
     def _share_fp8(self, other):
         """Another engine over the same parameters (another batch size / a micro-batch chain) uses the same e4m3 shadow and scales."""
@@ -211,7 +228,7 @@ class DitEngine:
             f = self.fp8
             check(_lib.lib().sfron_dit_forward_fp8(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(f["w8"]),
                                                    ptr(f["scales"]), f["act"], ptr(x_t), ptr(t), ptr(y), ptr(drop), ptr(self.workspace),
-                                                   ptr(f["ws"]), ptr(out), stream_ptr()), "dit_forward_fp8")
+                                                   ptr(f["ws"]), ptr(out), block_ready, stream_ptr()), "dit_forward_fp8")
             return out
         check(_lib.lib().sfron_dit_forward_probed(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(x_t),
                                                   ptr(t), ptr(y), ptr(drop), ptr(self.workspace), ptr(out), self.probe,

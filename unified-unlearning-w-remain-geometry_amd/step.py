@@ -277,6 +277,16 @@ class DiTSFRon:
             self._allreduce_grads()
         return mse, vb
 
+    def _fp8_before_sweep(self, fused_q):
+        """config 5 with re-quantising sweeps: every `refresh_every` sweeps the per-tensor scales are re-derived from the current
+        masters' amax (weights move by at most lr per sweep; the scale keeps 2x headroom and the conversion saturates)"""
+        if not fused_q:
+            return
+        f8 = self.model.engine.fp8
+        if f8["sweeps"] % f8["refresh_every"] == 0 and f8["sweeps"] > 0:
+            self.model.engine.fp8_refresh_scales()
+        f8["sweeps"] += 1
+
     def _step_joint(self, forget, remain, y_f, sign):
         """DiT/forget.py:314-320 with method "joint": loss = remain_loss + forget_alpha * forget_loss, one backward through BOTH
         graphs, one AdamW step (no mask, no clip), EMA.  Both forward passes see the same weights; their activations live in two
@@ -337,17 +347,26 @@ class DiTSFRon:
         # stream.  Measured (tools/bench_sweep_beside.py): a full-grid sweep beside the GEMM chain gains nothing, one capped at
         # 256 workgroups hides ~0.8 ms of its 2.6 ms.  Single-chain, single-process, bf16 passes only.
         split = None
-        if self.sweep_beside_forward and self.micro == 1 and self.world == 1 and not self.fp8:
+        fused_q = self.fp8 and self.micro == 1 and self.world == 1      # config 5: the sweeps write the e4m3 shadow themselves
+        quant = None
+        if fused_q:
+            f8 = self.model.engine.fp8
+            quant = dict(tensors=f8["tensors"], w8=f8["w8"], scales=f8["scales"])
+        if self.micro == 1 and self.world == 1 and (self.sweep_beside_forward or fused_q):
             bs = self.model.engine.block_sweep_setup()
-            split = dict(ranges=bs["ranges"], stream=bs["stream"], events=bs["events"], max_workgroups=self.sweep_beside_wg,
-                         head=self.sweep_beside_head)
+            split = dict(ranges=bs["ranges"], stream=bs["stream"] if self.sweep_beside_forward else None, events=bs["events"],
+                         max_workgroups=self.sweep_beside_wg, head=self.sweep_beside_head, quant=quant)
+        self._fp8_before_sweep(fused_q)
         self.opt.step(max_norm=self.grad_clip, use_mask=True, split=split)                  # forget.py:289-299
-        if self.fp8:
+        if self.fp8 and not fused_q:
             self.model.engine.fp8_requantize()
-        mse_r, vb_r = self._pass(remain, remain["y"], 1.0, factored_ada=True, block_ready=bs["handles"] if split else None)
+        beside = split is not None and split["stream"] is not None
+        mse_r, vb_r = self._pass(remain, remain["y"], 1.0, factored_ada=True, block_ready=bs["handles"] if beside else None)
         nt = eng.n_trainable
-        self.opt.step(max_norm=None, use_mask=False, ema=self.ema[:nt], ema_decay=self.ema_decay, ema_mode=1)  # :320,322
-        if self.fp8:
+        self._fp8_before_sweep(fused_q)
+        self.opt.step(max_norm=None, use_mask=False, ema=self.ema[:nt], ema_decay=self.ema_decay, ema_mode=1,   # :320,322
+                      split=dict(ranges=bs["ranges"], stream=None, quant=quant) if fused_q else None)
+        if self.fp8 and not fused_q:
             self.model.engine.fp8_requantize()
         if eng.n_total > nt:
             sweep.ema_update(self.ema[nt:], eng.params[nt:], self.ema_decay, mode=1)         # frozen pos_embed (:60-62)

@@ -123,11 +123,16 @@ class FlatAdam:
             stats = self.stats if max_norm is not None else None
             emode = int(ema_mode if ema is not None else 0)
             excl = None
+            quant = None
             if split is not None:
                 import torch as _t
-                head = int(split.get("head", 0))              # the first `head` ranges stay on the current stream (needed first)
-                rngs = split["ranges"]
-                excl = (rngs[head][0], rngs[-1][1]) if head < len(rngs) else None
+                rngs, quant = split["ranges"], split.get("quant")
+                side = split.get("stream")
+                # the first `head` ranges stay on the current stream (the next forward pass needs them first); with `quant` (config 5)
+                # every range goes through the per-tensor launches below, without a second stream all of them on this one
+                head = int(split.get("head", 0)) if side is not None else len(rngs)
+                first_own = 0 if quant is not None else head
+                excl = (rngs[first_own][0], rngs[-1][1]) if first_own < len(rngs) else None
             for lo, hi, lr in self._segments(excl):
                 if lr:
                     q = self.lowrank
@@ -141,22 +146,39 @@ class FlatAdam:
                                                    step_size, bc2_sqrt, decay_mul, ptr(sl(self.w_bf16, lo, hi)), ptr(sl(ema, lo, hi)),
                                                    float(ema_decay), emode, stream_ptr()), "masked_clip_adam")
             if split is not None and excl is not None:
-                # the remaining block ranges: on the second stream, behind everything above (what this stream swept at full rate
-                # is what the forward pass needs first), bounded grid, one event per range
+                # the block ranges: the first `head` on this stream, the rest on the second stream behind everything above (what this
+                # stream swept at full rate is what the forward pass needs first), bounded grid, one event per range
                 cur = _t.cuda.current_stream()
-                ready = _t.cuda.Event()
-                ready.record(cur)
-                split["stream"].wait_event(ready)
-                sp = ctypes.c_void_p(split["stream"].cuda_stream)
-                for i, ((lo, hi), blk_ev) in enumerate(zip(rngs, split["events"])):
+                cap = int(split.get("max_workgroups", 0))
+
+                def sweep_range(i, sp, wg):
+                    lo, hi = rngs[i]
+                    if quant is None:
+                        check(L.sfron_masked_clip_adam_wg(ptr(self.p[lo:hi]), ptr(self.g[lo:hi]), None, ptr(self.m[lo:hi]), ptr(self.v[lo:hi]),
+                                                          ptr(sl(mask, lo, hi)), ptr(stats), hi - lo, b1, b2, self.eps, step_size, bc2_sqrt,
+                                                          decay_mul, ptr(sl(self.w_bf16, lo, hi)), ptr(sl(ema, lo, hi)), float(ema_decay), emode,
+                                                          wg, sp), "masked_clip_adam_wg")
+                        return
+                    for tlo, thi, si in quant["tensors"][i]:          # one weight tensor (+ bias) per launch: ONE e4m3 scale each
+                        check(L.sfron_masked_clip_adam_q(ptr(self.p[tlo:thi]), ptr(self.g[tlo:thi]), ptr(self.m[tlo:thi]), ptr(self.v[tlo:thi]),
+                                                         ptr(sl(mask, tlo, thi)), ptr(stats), thi - tlo, b1, b2, self.eps, step_size, bc2_sqrt,
+                                                         decay_mul, ptr(sl(self.w_bf16, tlo, thi)), ptr(sl(ema, tlo, thi)), float(ema_decay), emode,
+                                                         ptr(quant["w8"][tlo:thi]), ptr(quant["scales"][si:si + 1]), wg, sp), "masked_clip_adam_q")
+                if side is not None:
+                    ready = _t.cuda.Event()
+                    ready.record(cur)
+                    side.wait_event(ready)
+                cur_p = ctypes.c_void_p(cur.cuda_stream)
+                side_p = ctypes.c_void_p(side.cuda_stream) if side is not None else None
+                for i in range(len(rngs)):
                     if i < head:
-                        blk_ev.record(cur)
-                        continue
-                    check(L.sfron_masked_clip_adam_wg(ptr(self.p[lo:hi]), ptr(self.g[lo:hi]), None, ptr(self.m[lo:hi]), ptr(self.v[lo:hi]),
-                                                      ptr(sl(mask, lo, hi)), ptr(stats), hi - lo, b1, b2, self.eps, step_size, bc2_sqrt,
-                                                      decay_mul, ptr(sl(self.w_bf16, lo, hi)), ptr(sl(ema, lo, hi)), float(ema_decay), emode,
-                                                      int(split.get("max_workgroups", 0)), sp), "masked_clip_adam_wg")
-                    blk_ev.record(split["stream"])
+                        if i >= first_own:
+                            sweep_range(i, cur_p, 0)
+                        if side is not None:
+                            split["events"][i].record(cur)
+                    else:
+                        sweep_range(i, side_p, cap)
+                        split["events"][i].record(side)
             self.lowrank = None
         if ev is not None:
             ev[1].record()
