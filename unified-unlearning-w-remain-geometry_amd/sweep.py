@@ -182,8 +182,8 @@ class FlatAdam:
             self.lowrank = None
         if ev is not None:
             ev[1].record()
-            # (start, end, whole): whole = every byte of this step went through the current stream inside the bracket
-            self.timed.append((ev[0], ev[1], split is None))
+            # (start, end, whole): whole = a remain-stage step (EMA fused) whose every byte went through the current stream in ONE pass
+            self.timed.append((ev[0], ev[1], (split is None or split.get("stream") is None and split.get("quant") is None) and ema is not None))
 
 
 def ema_update(ema, p, decay, mode=1):
