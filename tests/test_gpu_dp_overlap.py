@@ -82,3 +82,46 @@ def test_two_rank_overlapped_exchange_matches_single_process(tmp_path):
                        capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("PASS=True") == 2
+
+
+def test_pipelined_synchronous_exchange_matches_plain_path():
+    """The synchronous fallback exchange of a data-parallel run (what runs when verify_overlap votes no): buckets all-reduced on a
+    communication stream, the norm pre-pass / the remain-stage AdamW + EMA of bucket i on the compute stream as soon as bucket i is
+    reduced.  At world size 1 over RCCL (force_dp: the collectives are identities) it must reproduce the plain pass: identical
+    gradients, parameters to fp32 rounding (the clip norm is summed per bucket instead of per arena chunk)."""
+    from sfron import data, diffusion, step
+    from test_gpu_dit import CASES, build_pair
+    cfg = CASES["hd72"]
+    B = 4
+    kw = dict(global_batch=B, num_classes=cfg["num_classes"], forget_class=3, input_size=cfg["input_size"], device=DEV)
+    bat = lambda it: (data.synthetic_batch(6, it, "forget", **kw), data.synthetic_batch(6, it, "remain", **kw))
+    hp = dict(lr=2e-4, forget_alpha=0.3, grad_clip=1.0, ema_decay=0.99, mask=None, unlearn_loss="ga", forget_class=3)
+
+    def run(force, transport="fp32"):
+        _, model = build_pair(cfg, B, seed=23)
+        runner = step.DiTSFRon(model, diffusion.create_diffusion(""), grad_transport=transport, **hp)
+        runner.factored_ada = runner.sweep_beside_forward = False
+        runner.force_dp = force
+        runner.bucket_elems = 50_000                      # several buckets in front of the blocks
+        for it in range(2):
+            out = runner.step(*bat(it))
+        torch.cuda.synchronize()
+        runner.guard.poll(block=True)
+        return model.engine.params.clone(), model.engine.grads.clone(), out["stats"].clone(), runner.ema.clone()
+
+    p0, g0, s0, e0 = run(False)
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = str(_free_port())
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        created = True
+    try:
+        p1, g1, s1, e1 = run(True)
+        assert len(step.DiTSFRon._dp_buckets.__doc__) > 0
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert torch.allclose(s1, s0, rtol=1e-5)
+    assert (p1 - p0).abs().max().item() <= 1e-6 and (e1 - e0).abs().max().item() <= 1e-6
+    assert (g1 - g0).abs().max().item() <= 1e-6 * g0.abs().max().item()

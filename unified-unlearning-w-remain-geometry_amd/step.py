@@ -57,6 +57,8 @@ class DiTSFRon:
         # is refreshed after every optimizer step
         # the adaLN weight gradient as two factors + a rank-(batch) sweep (see _pass); the engine's (6L+2)D must be a multiple of 8
         self.factored_ada = ((6 * model.engine.cfg.depth + 2) * model.engine.cfg.hidden) % 8 == 0
+        self.force_dp = False           # tests: run the world > 1 exchange code at world size 1 (the collectives are identities)
+        self._pipeline = None
         self.sweep_beside_forward = True
         self.sweep_beside_wg, self.sweep_beside_head = 256, 2
         self.fp8 = bool(fp8)
@@ -100,6 +102,10 @@ class DiTSFRon:
                                   mask=self.mask_arena, w_bf16=eng.params_bf16[:nt])          # forget.py:199
         self.ema = eng.params.clone()                                                      # forget.py:190,230
 
+    def _dp_active(self):
+        """gradients must be exchanged: more than one rank, or a test forcing the data-parallel code path at world size 1"""
+        return (self.world > 1 or self.force_dp) and dist.is_available() and dist.is_initialized()
+
     def _scratch(self, n):
         """bf16 staging buffer of the gradient transport (None for fp32), at least n elements, one per stream (the overlapped
         exchange stages block ranges on the communication stream while the tail ranges go through the compute stream)."""
@@ -116,6 +122,38 @@ class DiTSFRon:
 
     def _ar(self, t):
         dp.allreduce_(t, self.pg, self.grad_transport if self.world > 1 else "fp32", self._scratch(t.numel()))
+
+    def _dp_buckets(self):
+        """Exchange buckets of the synchronous path in arena order: everything in front of the blocks in pieces of at most
+        bucket_elems (the adaLN matrix alone is 892 MB at DiT-XL/2), one bucket per block (64 MB), the tail."""
+        eng = self.model.engine
+        lay, nt = eng.layout, eng.n_trainable
+        b_lo, stride, L = lay["blocks"], lay["blk_stride"], eng.cfg.depth
+        out = [(s, min(s + self.bucket_elems, b_lo)) for s in range(0, b_lo, self.bucket_elems)]
+        out += [(b_lo + l * stride, b_lo + (l + 1) * stride) for l in range(L)]
+        if b_lo + L * stride < nt:
+            out.append((b_lo + L * stride, nt))
+        return out
+
+    def _exchange_async(self):
+        """The synchronous exchange (no per-block events from the backward pass) moved OFF the compute stream: the buckets are
+        all-reduced one after another on the communication stream, each followed by an event; the optimizer sweep consumes
+        range i when event i has fired (FlatAdam.step(pipeline=...)), so the sweep of the early buckets and -- in the remain
+        stage -- their AdamW + EMA run while the later buckets are still on the links.  Same collectives in the same order on
+        every rank."""
+        if self._comm is None:
+            self._comm = torch.cuda.Stream()
+        g = self.model.engine.grads
+        cur = torch.cuda.current_stream()
+        self._comm.wait_stream(cur)
+        out = []
+        with torch.cuda.stream(self._comm):
+            for lo, hi in self._dp_buckets():
+                self._ar(g[lo:hi])
+                ev = torch.cuda.Event()
+                ev.record(self._comm)
+                out.append((lo, hi, ev))
+        return out
 
     def _allreduce_grads(self):
         g = self.model.engine.grads[:self.model.engine.n_trainable]
@@ -255,7 +293,7 @@ class DiTSFRon:
         y_safe, b["t"] = self.guard.check_inputs(y, b["t"], self.model.num_classes, self.diffusion.num_timesteps)
         return b, y_safe
 
-    def _pass(self, batch, y, sign_alpha, factored_ada=False, block_ready=None):
+    def _pass(self, batch, y, sign_alpha, factored_ada=False, block_ready=None, async_exchange=False):
         """factored_ada (single process, single chain -- what step() uses): the backward pass leaves the adaLN_modulation weight
         gradient as its two bf16 factors and the next optimizer sweep forms the rank-(batch) product itself (engine.
         backward_factored_ada, csrc/sweep.hip k_adam_lowrank): 892 MB less to write and 892 MB (forget stage: twice) less to read
@@ -270,11 +308,14 @@ class DiTSFRon:
         mse, vb, d_out = diff.loss_fwd_bwd(out, batch["x0"], batch["t"], batch["noise"], sign_alpha / n_global)
         if self._overlap_enabled():
             self._backward_allreduce_overlapped(d_out, y, batch.get("drop"))
-        elif factored_ada and self.world == 1 and self.factored_ada:
+        elif factored_ada and not self._dp_active() and self.factored_ada:
             self.opt.lowrank = eng.backward_factored_ada(d_out, y, batch.get("drop"))
         else:
             eng.backward(d_out, y, batch.get("drop"))
-            self._allreduce_grads()
+            if async_exchange and self._dp_active():
+                self._pipeline = self._exchange_async()          # consumed by the optimizer step that follows in step()
+            else:
+                self._allreduce_grads()
         return mse, vb
 
     def _fp8_before_sweep(self, fused_q):
@@ -341,31 +382,35 @@ class DiTSFRon:
             y_f, sign = torch.full_like(forget["y"], (self.forget_class + 100) % 1000), 1.0  # forget.py:274-282
         if self.method == "joint":
             return self._step_joint(forget, remain, y_f, sign)
-        mse_f, vb_f = self._pass(forget, y_f, sign * self.forget_alpha, factored_ada=True)
+        dp_sync = self._dp_active() and not self._overlap_enabled() and self.micro == 1
+        mse_f, vb_f = self._pass(forget, y_f, sign * self.forget_alpha, factored_ada=True, async_exchange=dp_sync)
         # The forget-stage AdamW of the 28 block ranges runs on a second stream, on a bounded grid, BESIDE the remain forward pass,
         # which waits for block l's event when it reaches block l; embedders / adaLN / final layer (needed at once) stay on this
         # stream.  Measured (tools/bench_sweep_beside.py): a full-grid sweep beside the GEMM chain gains nothing, one capped at
         # 256 workgroups hides ~0.8 ms of its 2.6 ms.  Single-chain, single-process, bf16 passes only.
         split = None
-        fused_q = self.fp8 and self.micro == 1 and self.world == 1      # config 5: the sweeps write the e4m3 shadow themselves
+        fused_q = self.fp8 and self.micro == 1 and not self._dp_active()      # config 5: the sweeps write the e4m3 shadow themselves
         quant = None
         if fused_q:
             f8 = self.model.engine.fp8
             quant = dict(tensors=f8["tensors"], w8=f8["w8"], scales=f8["scales"])
-        if self.micro == 1 and self.world == 1 and (self.sweep_beside_forward or fused_q):
+        if self.micro == 1 and not self._dp_active() and (self.sweep_beside_forward or fused_q):
             bs = self.model.engine.block_sweep_setup()
             split = dict(ranges=bs["ranges"], stream=bs["stream"] if self.sweep_beside_forward else None, events=bs["events"],
                          max_workgroups=self.sweep_beside_wg, head=self.sweep_beside_head, quant=quant)
         self._fp8_before_sweep(fused_q)
-        self.opt.step(max_norm=self.grad_clip, use_mask=True, split=split)                  # forget.py:289-299
+        pipe, self._pipeline = self._pipeline, None
+        self.opt.step(max_norm=self.grad_clip, use_mask=True, split=split, pipeline=pipe)   # forget.py:289-299
         if self.fp8 and not fused_q:
             self.model.engine.fp8_requantize()
         beside = split is not None and split["stream"] is not None
-        mse_r, vb_r = self._pass(remain, remain["y"], 1.0, factored_ada=True, block_ready=bs["handles"] if beside else None)
+        mse_r, vb_r = self._pass(remain, remain["y"], 1.0, factored_ada=True, block_ready=bs["handles"] if beside else None,
+                                 async_exchange=dp_sync)
+        pipe, self._pipeline = self._pipeline, None
         nt = eng.n_trainable
         self._fp8_before_sweep(fused_q)
         self.opt.step(max_norm=None, use_mask=False, ema=self.ema[:nt], ema_decay=self.ema_decay, ema_mode=1,   # :320,322
-                      split=dict(ranges=bs["ranges"], stream=None, quant=quant) if fused_q else None)
+                      split=dict(ranges=bs["ranges"], stream=None, quant=quant) if fused_q else None, pipeline=pipe)
         if self.fp8 and not fused_q:
             self.model.engine.fp8_requantize()
         if eng.n_total > nt:

@@ -87,15 +87,21 @@ class FlatAdam:
             used += nblk.value
         check(L.sfron_clip_coef(ptr(self._partials), used, float(max_norm), ptr(self.stats), s), "clip_coef")
 
-    def step(self, max_norm=None, use_mask=False, ema=None, ema_decay=0.0, ema_mode=0, split=None):
+    def step(self, max_norm=None, use_mask=False, ema=None, ema_decay=0.0, ema_mode=0, split=None, pipeline=None):
         """One optimizer step on the current grads.  max_norm=None -> no clipping (DiT remain stage).
         split (optional): dict(ranges=[(lo, hi)] consecutive element ranges (the DiT blocks, in forward order), stream=, events=[one
         torch event per range], max_workgroups=): those ranges are swept on ``stream`` (bounded grid), one event each, while the
         rest of the arena is swept on the current stream -- the next forward pass waits for block l's event only when it
-        reaches block l (engine.forward(block_ready=...))."""
+        reaches block l (engine.forward(block_ready=...)).
+        pipeline (optional, data-parallel runs): [(lo, hi, event)] consecutive ranges covering the arena whose gradients become final
+        (all-reduced on a communication stream) when their event fires: the norm pre-pass / the unclipped update of range i runs
+        on the current stream as soon as event i has fired, while the later ranges are still being exchanged."""
         L = _lib.lib()
         if use_mask and self.mask is None:
             use_mask = False
+        if pipeline is not None:
+            assert split is None and self.lowrank is None and self.g2 is None and self.ranges is None
+            return self._step_pipelined(pipeline, max_norm, use_mask, ema, ema_decay, ema_mode)
         if max_norm is not None:
             self.grad_norm_clip_coef(max_norm, use_mask)
         self.step_count += 1
@@ -184,6 +190,42 @@ class FlatAdam:
             ev[1].record()
             # (start, end, whole): whole = a remain-stage step (EMA fused) whose every byte went through the current stream in ONE pass
             self.timed.append((ev[0], ev[1], (split is None or split.get("stream") is None and split.get("quant") is None) and ema is not None))
+
+
+    def _step_pipelined(self, pipeline, max_norm, use_mask, ema, ema_decay, ema_mode):
+        import torch as _t
+        L = _lib.lib()
+        cur = _t.cuda.current_stream()
+        s = stream_ptr()
+        mask = self.mask if use_mask else None
+        sl = lambda t, lo, hi: None if t is None else t[lo:hi]
+        stats = None
+        if max_norm is not None:
+            # clip_grad_norm_ needs every range: partial sums per range as each arrives, then one coefficient, then the update
+            per = L.sfron_sweep_partials_len()
+            if self._partials.numel() < per * len(pipeline):
+                self._partials = _t.empty(per * len(pipeline), dtype=_t.float64, device=self.p.device)
+            used = 0
+            for lo, hi, ev in pipeline:
+                cur.wait_event(ev)
+                nblk = ctypes.c_int(0)
+                check(L.sfron_sumsq_masked(ptr(self.g[lo:hi]), None, ptr(sl(mask, lo, hi)), hi - lo, ptr(self._partials[used:]),
+                                           ctypes.byref(nblk), s), "sumsq_masked")
+                used += nblk.value
+            check(L.sfron_clip_coef(ptr(self._partials), used, float(max_norm), ptr(self.stats), s), "clip_coef")
+            stats = self.stats
+        self.step_count += 1
+        b1, b2 = self.betas
+        step_size = self.lr / (1 - b1 ** self.step_count)
+        bc2_sqrt = math.sqrt(1 - b2 ** self.step_count)
+        decay_mul = 1.0 - self.lr * self.wd
+        emode = int(ema_mode if ema is not None else 0)
+        for lo, hi, ev in pipeline:
+            if max_norm is None:
+                cur.wait_event(ev)
+            check(L.sfron_masked_clip_adam(ptr(self.p[lo:hi]), ptr(self.g[lo:hi]), None, ptr(self.m[lo:hi]), ptr(self.v[lo:hi]),
+                                           ptr(sl(mask, lo, hi)), ptr(stats), hi - lo, b1, b2, self.eps, step_size, bc2_sqrt, decay_mul,
+                                           ptr(sl(self.w_bf16, lo, hi)), ptr(sl(ema, lo, hi)), float(ema_decay), emode, s), "masked_clip_adam")
 
 
 def ema_update(ema, p, decay, mode=1):
