@@ -157,7 +157,7 @@ __global__ __launch_bounds__(TPB) void k_masked_clip_adam(float* __restrict__ p,
 // ---- rank-R gradient: the adaLN_modulation weight of ALL blocks, W [NM][D] (a third of DiT-XL/2's parameters), has the gradient
 // dW[n][k] = sum_{b < R} dmod[b][n] * sc[b][k] (R = batch rows; bf16 factors, fp32 accumulation -- the same numbers the
 // weight-gradient GEMM would form from the same factors).  Forming it HERE, inside the sweep, removes the 892 MB fp32 write of that
-// GEMM and the sweep's read of it (and, in the forget stage, the norm pre-pass's).  One thread owns 4 consecutive k of LR_ROWS rows:
+// GEMM and the sweep's read of it (and, in the forget stage, the norm pre-pass's).  One thread owns 4 consecutive k of LR_ROWS (8; 16 measured slower) rows:
 // per b one 8-byte load of sc and one 16-byte wave-uniform load of dmod feed LR_ROWS x 4 FMAs; b runs in index order (deterministic).
 constexpr int LR_ROWS = 8;
 __device__ __forceinline__ void lowrank_grad(const __bf16* __restrict__ dmod, const __bf16* __restrict__ sc, int R, int NM, int D, int n0,
@@ -167,19 +167,24 @@ __device__ __forceinline__ void lowrank_grad(const __bf16* __restrict__ dmod, co
   // eight batch rows per trip: all sixteen loads of a trip are issued before its 256 FMAs (a load-use loop pays one L2 latency per row)
   for (int b0 = 0; b0 < R; b0 += 8) {
     bf16x4 s4[8];
-    bf16x8 d8[8];
+    bf16x8 d8[8][LR_ROWS / 8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int b = b0 + u < R ? b0 + u : R - 1;                       // clamped: the tail's surplus rows get weight 0 below
       s4[u] = *reinterpret_cast<const bf16x4*>(sc + (size_t)b * D + 4 * c);
-      d8[u] = *reinterpret_cast<const bf16x8*>(dmod + (size_t)b * NM + n0);    // wave-uniform address
+#pragma unroll
+      for (int h = 0; h < LR_ROWS / 8; ++h)
+        d8[u][h] = *reinterpret_cast<const bf16x8*>(dmod + (size_t)b * NM + n0 + 8 * h);    // wave-uniform address: scalar loads
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const float on = b0 + u < R ? 1.0f : 0.0f;
       const f32x4 sv = {bf2f(s4[u][0]) * on, bf2f(s4[u][1]) * on, bf2f(s4[u][2]) * on, bf2f(s4[u][3]) * on};
 #pragma unroll
-      for (int r = 0; r < LR_ROWS; ++r) acc[r] += sv * bf2f(d8[u][r]);
+      for (int r = 0; r < LR_ROWS; ++r) {           // explicit FMAs: the library is built with -ffp-contract=off (a * b + c would be two instructions)
+        const float dr = bf2f(d8[u][r >> 3][r & 7]);
+        acc[r] = __builtin_elementwise_fma(sv, f32x4{dr, dr, dr, dr}, acc[r]);
+      }
     }
   }
 }
