@@ -296,7 +296,8 @@ typedef struct sfron_conv_desc {
  * the input gradient calls this on dY with the "dgrad" layout) */
 int sfron_conv_fwd(const sfron_conv_desc* desc, const uint16_t* src, const uint16_t* w, void* stream);
 /* dw_gemm fp32 [splits][n_out][taps * c_src]: slab s = sum over the s-th range of pixels p of dy[p][n] * src[src(p, tap)][c]
- * (dy bf16 [rows][ld_dy]); splits = sfron_conv_wgrad_splits(desc) >= 1 (the contraction over all pixels is split over the chip) */
+ * (dy bf16 [rows][ld_dy]); splits = sfron_conv_wgrad_splits(desc) >= 1 = the number of slabs WRITTEN (the contraction over all pixels is split
+ * over the chip; size dw_gemm for it and pass it to sfron_conv_wgrad_scatter) */
 int sfron_conv_wgrad_splits(const sfron_conv_desc* desc);
 int sfron_conv_wgrad(const sfron_conv_desc* desc, const uint16_t* dy, int ld_dy, const uint16_t* src, float* dw_gemm, void* stream);
 /* fp32 OIHW master weights -> bf16 operands: w_fwd [c_out_p][taps][c_in_p] (zero padded), w_dgrad [c_in][taps flipped][c_out_p] or NULL */

@@ -778,7 +778,15 @@ __global__ __launch_bounds__(TPB) void k_conv_wgrad_scatter(const float* __restr
     for (int t = tg; t < taps; t += TG) {
       const float* p = g + ((int64_t)co * taps + t) * Ci_p + ci0 + c;
       float a = 0.f;
-      for (int sl = 0; sl < nslab; ++sl) a += p[sl * slab_stride];
+      int sl = 0;
+      for (; sl + 8 <= nslab; sl += 8) {          // eight strided loads in flight, added in slab order (a load-use loop pays one
+        float v8[8];                              // memory latency per slab: 38 us for 64 slabs of a 128 x 128 kernel)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = p[(int64_t)(sl + u) * slab_stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v8[u];
+      }
+      for (; sl < nslab; ++sl) a += p[(int64_t)sl * slab_stride];
       sh[c * taps + t] = a;
     }
   __syncthreads();
@@ -1911,11 +1919,20 @@ static bool conv_wgrad_pipelined(const sfron_conv_desc* d) {
   return K % BK == 0 && K >= 256 && d->c_src % 8 == 0 && d->n_out % 8 == 0 && d->h_out >= 2 && d->w_out >= 2 && d->n_out >= 64 &&
          d->taps * d->c_src >= 64 && K < (1l << 21) && d->w_out <= 2048 && d->h_out <= 2048;
 }
-int sfron_conv_wgrad_splits(const sfron_conv_desc* d) {
-  if (!d) return 0;
+static int conv_wgrad_plan(const sfron_conv_desc* d) {
   const int K = d->batch * d->h_out * d->w_out;
   if (conv_wgrad_pipelined(d)) return tt_splits(tt_tiles(d->taps * d->c_src, d->n_out), K, 64, (int64_t)d->taps * d->c_src * d->n_out);
   return plan_splits(d->n_out, d->taps * d->c_src, K, 64);
+}
+// the number of slabs sfron_conv_wgrad WRITES (the planned split count, less the ones the rounding of the k range leaves without rows):
+// the caller sizes dw_gemm for it and hands the same number to sfron_conv_wgrad_scatter -- nothing has to be zeroed
+int sfron_conv_wgrad_splits(const sfron_conv_desc* d) {
+  if (!d) return 0;
+  const int sp = conv_wgrad_plan(d);
+  if (sp <= 1) return sp;
+  const int K = d->batch * d->h_out * d->w_out;
+  const int kchunk = ((K + sp - 1) / sp + BK - 1) / BK * BK;
+  return (K + kchunk - 1) / kchunk;
 }
 int sfron_conv_wgrad(const sfron_conv_desc* d, const uint16_t* dy, int ld_dy, const uint16_t* src, float* dw_gemm, void* stream) {
   SFRON_CHECK_ARG(d && dy && src && dw_gemm && d->n_out % 8 == 0 && ld_dy % 8 == 0);
@@ -1927,9 +1944,9 @@ int sfron_conv_wgrad(const sfron_conv_desc* d, const uint16_t* dy, int ld_dy, co
   g.Cf = dw_gemm; g.ldcf = g.N; g.alpha = 1.0f; g.T = 1;
   // the contraction runs over every pixel of the batch and the output has few 128x128 tiles: split it; slab s of dw_gemm
   // ([splits][n_out][taps * c_src]) receives split s, sfron_conv_wgrad_scatter adds the slabs in order
-  const int sp = sfron_conv_wgrad_splits(d);
+  const int sp = conv_wgrad_plan(d);
   if (sp > 1) { g.kchunk = ((g.K + sp - 1) / sp + BK - 1) / BK * BK; g.sC = (long)g.M * g.N; }
-  const int used = sp > 1 ? (g.K + g.kchunk - 1) / g.kchunk : 1;
+  const int used = sp > 1 ? (g.K + g.kchunk - 1) / g.kchunk : 1;       // == sfron_conv_wgrad_splits(d)
   rc = -1;
   if (conv_wgrad_pipelined(d) && (ld_dy % 8) == 0 && (((uintptr_t)dy | (uintptr_t)src) & 15) == 0) {
     const size_t pb = (size_t)d->batch * d->h_src * d->w_src * d->c_src * 2, qb = ((size_t)(g.K - 1) * ld_dy + g.M) * 2;
@@ -1939,11 +1956,7 @@ int sfron_conv_wgrad(const sfron_conv_desc* d, const uint16_t* dy, int ld_dy, co
     }
   }
   if (rc < 0) rc = launch_bgemm<true, true, EPI_RES, CONV_B>(g, used, (hipStream_t)stream);
-  if (rc) return rc;
-  // slabs the rounding left without rows are zeroed so that the scatter can always add `sfron_conv_wgrad_splits` of them
-  for (int sidx = used; sidx < sp; ++sidx)
-    if (hipMemsetAsync(dw_gemm + (size_t)sidx * g.M * g.N, 0, (size_t)g.M * g.N * sizeof(float), (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
-  return SFRON_OK;
+  return rc;
 }
 
 int sfron_conv_wprep(const float* w_oihw, int c_out, int c_in, int taps, int c_out_p, int c_in_p, uint16_t* w_fwd, uint16_t* w_dgrad,
