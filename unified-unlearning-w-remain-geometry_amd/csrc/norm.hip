@@ -40,43 +40,55 @@ __device__ __forceinline__ void load_row_bf16(const __bf16* __restrict__ p, int 
 }
 
 // ---------------------------------------------------------------- LN + modulate forward
+// RPW rows per wave: both rows' loads are issued before the first reduction (a wave that lives for one 4.6 KB row spends most of its life
+// in launch + one exposed memory latency)
+template <int RPW>
 __global__ __launch_bounds__(TPB) void k_ln_mod_fwd(const float* __restrict__ x, const float* __restrict__ shift,
                                                     const float* __restrict__ scale, int ldmod, int T, int M, int D,
                                                     __bf16* __restrict__ out, float* __restrict__ mean_out,
                                                     float* __restrict__ rstd_out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= M) return;
+  const int row0 = (blockIdx.x * 4 + wave) * RPW;
+  if (row0 >= M) return;
   const int D4 = D >> 2;
-  RowRegs r;
-  load_row_f32(x + (size_t)row * D, D4, lane, r);
-  float s = 0.f;
+  RowRegs r[RPW];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) s += r.v[i].x + r.v[i].y + r.v[i].z + r.v[i].w;
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    if (lane + 64 * i < D4) {
-      const float a = r.v[i].x - mean, b = r.v[i].y - mean, c = r.v[i].z - mean, d = r.v[i].w - mean;
-      q += a * a + b * b + c * c + d * d;
-    }
+  for (int k = 0; k < RPW; ++k) {
+    const int row = row0 + k < M ? row0 + k : M - 1;
+    load_row_f32(x + (size_t)row * D, D4, lane, r[k]);
   }
-  const float var = wave_sum(q) / (float)D;
-  const float rstd = 1.0f / sqrtf(var + LN_EPS);
-  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
-  const int b = row / T;
-  const float* sh = shift + (size_t)b * ldmod;
-  const float* sc = scale + (size_t)b * ldmod;
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i;
-    if (c < D4) {
-      const float4 h = reinterpret_cast<const float4*>(sh)[c];
-      const float4 g = reinterpret_cast<const float4*>(sc)[c];
-      bf16x4 o = {f2bf((r.v[i].x - mean) * rstd * (1.0f + g.x) + h.x), f2bf((r.v[i].y - mean) * rstd * (1.0f + g.y) + h.y),
-                  f2bf((r.v[i].z - mean) * rstd * (1.0f + g.z) + h.z), f2bf((r.v[i].w - mean) * rstd * (1.0f + g.w) + h.w)};
-      reinterpret_cast<bf16x4*>(out + (size_t)row * D)[c] = o;
+  for (int k = 0; k < RPW; ++k) {
+    const int row = row0 + k;
+    if (row >= M) break;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) s += r[k].v[i].x + r[k].v[i].y + r[k].v[i].z + r[k].v[i].w;
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      if (lane + 64 * i < D4) {
+        const float a = r[k].v[i].x - mean, b = r[k].v[i].y - mean, c = r[k].v[i].z - mean, d = r[k].v[i].w - mean;
+        q += a * a + b * b + c * c + d * d;
+      }
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + LN_EPS);
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    const int b = row / T;
+    const float* sh = shift + (size_t)b * ldmod;
+    const float* sc = scale + (size_t)b * ldmod;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D4) {
+        const float4 h = reinterpret_cast<const float4*>(sh)[c];
+        const float4 g = reinterpret_cast<const float4*>(sc)[c];
+        bf16x4 o = {f2bf((r[k].v[i].x - mean) * rstd * (1.0f + g.x) + h.x), f2bf((r[k].v[i].y - mean) * rstd * (1.0f + g.y) + h.y),
+                    f2bf((r[k].v[i].z - mean) * rstd * (1.0f + g.z) + h.z), f2bf((r[k].v[i].w - mean) * rstd * (1.0f + g.w) + h.w)};
+        reinterpret_cast<bf16x4*>(out + (size_t)row * D)[c] = o;
+      }
     }
   }
 }
@@ -409,8 +421,12 @@ int sfron_ln_modulate_fwd(const float* x, const float* shift, const float* scale
   SFRON_CHECK_ARG(x && shift && scale && out && mean && rstd && M > 0 && tokens > 0);
   SFRON_CHECK_ARG(D % 4 == 0 && D <= 64 * 4 * NCH && ldmod % 4 == 0);
   SFRON_CHECK_ARG((((uintptr_t)x | (uintptr_t)shift | (uintptr_t)scale) & 15) == 0 && ((uintptr_t)out & 7) == 0);
-  hipLaunchKernelGGL(k_ln_mod_fwd, dim3(cdiv(M, 4)), dim3(TPB), 0, (hipStream_t)stream, x, shift, scale, ldmod, tokens, M, D,
-                     (__bf16*)out, mean, rstd);
+  if (M >= 4096)       // enough rows to fill the chip with two-row waves
+    hipLaunchKernelGGL(k_ln_mod_fwd<2>, dim3(cdiv(M, 8)), dim3(TPB), 0, (hipStream_t)stream, x, shift, scale, ldmod, tokens, M, D,
+                       (__bf16*)out, mean, rstd);
+  else
+    hipLaunchKernelGGL(k_ln_mod_fwd<1>, dim3(cdiv(M, 4)), dim3(TPB), 0, (hipStream_t)stream, x, shift, scale, ldmod, tokens, M, D,
+                       (__bf16*)out, mean, rstd);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }
