@@ -202,9 +202,14 @@ __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv,
   Ring<HDP> ring{smem};
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  // 1-D grid.  Workgroup ids go round-robin over the 8 XCDs: id -> (id & 7) * (n / 8) + (id >> 3) gives each XCD one contiguous run of
+  // (batch, head, query block) triples, so the query blocks of a head (same K / V) and the neighbouring heads of a sample (neighbouring
+  // 144-B column slices of the same rows: shared 128-B lines) meet in ONE L2
+  const int nblk = gridDim.x, nqb = T / (64 * QT);
+  const int wid = (nblk & 7) == 0 ? (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int bh = wid / nqb, b = bh / H, h = bh % H;
   const int D = H * hd, ld = 3 * D;
-  const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+  const int q0 = (wid % nqb) * (64 * QT) + wave * (16 * QT);
   const __bf16* base = qkv + (size_t)b * T * ld + h * hd;
   const float c = scale * LOG2E;
   const int nchunk = T / 64;
@@ -337,9 +342,11 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dq(const __bf16* __restrict__ q
   Ring<HDP> ring{smem};
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  const int nblk = gridDim.x, nqb = T / (64 * QT);        // XCD-contiguous (batch, head, query block) order: see k_attn_fwd
+  const int wid = (nblk & 7) == 0 ? (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int bh = wid / nqb, b = bh / H, h = bh % H;
   const int D = H * hd, ld = 3 * D;
-  const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+  const int q0 = (wid % nqb) * (64 * QT) + wave * (16 * QT);
   const __bf16* base = qkv + (size_t)b * T * ld + h * hd;
   const __bf16* dob = d_o + (size_t)b * T * D + h * hd;
   const __bf16* ob = o + (size_t)b * T * D + h * hd;
@@ -468,9 +475,11 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dkv(const __bf16* __restrict__ 
   float* s_del = s_lse + T;
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  const int nblk = gridDim.x, nkb = T / (64 * KT);        // XCD-contiguous (batch, head, key block) order: see k_attn_fwd
+  const int wid = (nblk & 7) == 0 ? (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int bh = wid / nkb, b = bh / H, h = bh % H;
   const int D = H * hd, ld = 3 * D;
-  const int k0 = blockIdx.x * (64 * KT) + wave * (16 * KT);
+  const int k0 = (wid % nkb) * (64 * KT) + wave * (16 * KT);
   const __bf16* base = qkv + (size_t)b * T * ld + h * hd;
   const __bf16* dob = d_o + (size_t)b * T * D + h * hd;
   const float c = scale * LOG2E;
@@ -1108,10 +1117,10 @@ int launch_fwd(const __bf16* qkv, __bf16* o, float* lse, int B, int T, int H, in
   const size_t lds = lds_bytes<HDP>(0);
   if (T % 128 == 0) {
     int rc = set_lds(&k_attn_fwd<HDP, KS, NDT, 2>, lds); if (rc) return rc;
-    hipLaunchKernelGGL((k_attn_fwd<HDP, KS, NDT, 2>), dim3(T / 128, B * H), dim3(NT), lds, s, qkv, o, lse, T, H, hd, scale);
+    hipLaunchKernelGGL((k_attn_fwd<HDP, KS, NDT, 2>), dim3(T / 128 * B * H), dim3(NT), lds, s, qkv, o, lse, T, H, hd, scale);
   } else {
     int rc = set_lds(&k_attn_fwd<HDP, KS, NDT, 1>, lds); if (rc) return rc;
-    hipLaunchKernelGGL((k_attn_fwd<HDP, KS, NDT, 1>), dim3(T / 64, B * H), dim3(NT), lds, s, qkv, o, lse, T, H, hd, scale);
+    hipLaunchKernelGGL((k_attn_fwd<HDP, KS, NDT, 1>), dim3(T / 64 * B * H), dim3(NT), lds, s, qkv, o, lse, T, H, hd, scale);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
@@ -1138,13 +1147,13 @@ int launch_bwd(const __bf16* qkv, const __bf16* o, const __bf16* d_o, const floa
   const size_t lds = lds_bytes<HDP>(0), lds2 = lds_bytes<HDP>(2 * T);
   if (T % 128 == 0) {
     int rc = set_lds(&k_attn_bwd_dq<HDP, KS, NDT, 2>, lds); if (rc) return rc;
-    hipLaunchKernelGGL((k_attn_bwd_dq<HDP, KS, NDT, 2>), dim3(T / 128, B * H), dim3(NT), lds, s, qkv, o, d_o, lse, delta, dqkv, T, H, hd, scale);
+    hipLaunchKernelGGL((k_attn_bwd_dq<HDP, KS, NDT, 2>), dim3(T / 128 * B * H), dim3(NT), lds, s, qkv, o, d_o, lse, delta, dqkv, T, H, hd, scale);
   } else {
     int rc = set_lds(&k_attn_bwd_dq<HDP, KS, NDT, 1>, lds); if (rc) return rc;
-    hipLaunchKernelGGL((k_attn_bwd_dq<HDP, KS, NDT, 1>), dim3(T / 64, B * H), dim3(NT), lds, s, qkv, o, d_o, lse, delta, dqkv, T, H, hd, scale);
+    hipLaunchKernelGGL((k_attn_bwd_dq<HDP, KS, NDT, 1>), dim3(T / 64 * B * H), dim3(NT), lds, s, qkv, o, d_o, lse, delta, dqkv, T, H, hd, scale);
   }
   int rc = set_lds(&k_attn_bwd_dkv<HDP, KS, NDT, 1>, lds2); if (rc) return rc;
-  hipLaunchKernelGGL((k_attn_bwd_dkv<HDP, KS, NDT, 1>), dim3(T / 64, B * H), dim3(NT), lds2, s, qkv, d_o, lse, delta, dqkv, T, H, hd, scale);
+  hipLaunchKernelGGL((k_attn_bwd_dkv<HDP, KS, NDT, 1>), dim3(T / 64 * B * H), dim3(NT), lds2, s, qkv, d_o, lse, delta, dqkv, T, H, hd, scale);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
 }

@@ -195,7 +195,7 @@ int64_t sfron_dit_workspace_bytes(const sfron_dit_cfg* cfg) {
 }
 
 // SFRON_ABLATE (debug / A-B measurement only): bit 0 = run LN backward and gate backward as separate kernels,
-// bit 1 = split-K in the block weight gradients (off by default), bit 2 = side stream at the lowest priority, bit 3 = fc2 weight gradient after the fc2 dgrad, bit 4 = no split-K for the two small-output weight gradients, bit 5 = bias row sums inside the weight-gradient GEMM, bit 6 = fc1 bias gradient by a separate column-sum launch, bit 7 = qkv bias gradient likewise
+// bit 1 = split-K in the block weight gradients (off by default), bit 2 = side stream at the lowest priority, bit 3 = fc2 weight gradient after the fc2 dgrad, bit 4 = no split-K for the two small-output weight gradients, bit 5 = bias row sums inside the weight-gradient GEMM, bit 6 = fc1 bias gradient by a separate column-sum launch, bit 7 = qkv bias gradient likewise, bit 8 = proj weight gradient before (not beside) the attention backward
 static int ablate_mask() {
 #ifdef SFRON_DEBUG_KNOBS
   static const int m = [] { const char* e = getenv("SFRON_ABLATE"); return e ? atoi(e) : 0; }();
@@ -208,7 +208,7 @@ static int ablate_mask() {
 // ---- aux: a side stream + events so the weight-gradient GEMMs (which nothing downstream in the backward chain
 // depends on) run concurrently with the dgrad / elementwise chain and fill the CUs its tile counts leave idle
 struct Probe;
-struct Aux { hipStream_t side; hipEvent_t produced[4], consumed[8], done; Probe* probe; };
+struct Aux { hipStream_t side, side2; hipEvent_t produced[4], consumed[8], done, join2; Probe* probe; };
 
 int sfron_aux_create(void** aux) {
   SFRON_CHECK_ARG(aux);
@@ -224,6 +224,9 @@ int sfron_aux_create(void** aux) {
   for (int i = 0; i < 8; ++i)
     if (hipEventCreateWithFlags(&a->consumed[i], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
   if (hipEventCreateWithFlags(&a->done, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+  // second weight-gradient stream: the 36-tile proj weight gradient runs BESIDE the 108-tile qkv one (see dit_backward_impl)
+  if (hipStreamCreateWithFlags(&a->side2, hipStreamNonBlocking) != hipSuccess) return (int)hipGetLastError();
+  if (hipEventCreateWithFlags(&a->join2, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
   *aux = a;
   return SFRON_OK;
 }
@@ -233,7 +236,9 @@ int sfron_aux_destroy(void* aux) {
   for (int i = 0; i < 4; ++i) (void)hipEventDestroy(a->produced[i]);
   for (int i = 0; i < 8; ++i) (void)hipEventDestroy(a->consumed[i]);
   (void)hipEventDestroy(a->done);
+  (void)hipEventDestroy(a->join2);
   (void)hipStreamDestroy(a->side);
+  (void)hipStreamDestroy(a->side2);
   delete a;
   return SFRON_OK;
 }
@@ -482,7 +487,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
   // db (optional): the bias gradient sum_rows dY of the same Linear.  Where the three-slot weight-gradient kernel takes the
   // shape it comes out of that GEMM (row sums of dY^T against a ones fragment); otherwise a column-sum launch precedes it.
   bool probe_block = false;
-  auto wgrad_side = [&](const void* dY, const void* X, int N, int K, float* dW, float* db = nullptr) -> int {
+  auto wgrad_on = [&](void* side, const void* dY, const void* X, int N, int K, float* dW, float* db) -> int {
     sfron_gemm_desc q = wgrad_desc(dY, X, M, N, K, dW);
     if (db) {
       if ((ablate_mask() & 32) && sfron_gemm_rowsum_supported(N, K, M)) {
@@ -502,6 +507,14 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     if (sp > 1) RUN(sfron_reduce_chunks(w.wslab, 1, sp, N * K, dW, N * K, 0, side));
     return SFRON_OK;
   };
+  auto wgrad_side = [&](const void* dY, const void* X, int N, int K, float* dW, float* db = nullptr) -> int {
+    return wgrad_on(side, dY, X, N, K, dW, db);
+  };
+  // The attention backward needs a whole CU's LDS per workgroup (157 KB), and so does a weight-gradient workgroup (144 KB): beside the
+  // 36-tile proj weight gradient it gets 220 CUs = 2.3 rounds of its 512 workgroups.  So proj waits for the attention backward and
+  // then runs on a SECOND stream beside the 108-tile qkv weight gradient (36 + 108 = 144 tiles, the size of the fc1 / fc2 launches);
+  // the attention backward meets an idle weight-gradient stream.  SFRON_ABLATE bit 8 = the old order.
+  const bool pair_proj = ax && !(ablate_mask() & 256);
   // LN backward of one branch + gate backward of the branch before it, on the same dx rows
   auto ln_gate = [&](const float* x, const float* mean, const float* rstd, const float* scale, int acc, float* ps, float* pc,
                      const __bf16* branch, const float* gate, __bf16* d_branch, float* pg, float* pd) -> int {
@@ -606,12 +619,21 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     RUN(ln_gate(x1, w.mean + (size_t)(2 * l + 1) * M, w.rstd + (size_t)(2 * l + 1) * M, mod + 4 * D, 1, slot(l, 1, 0),
                 slot(l, 1, 1), a1, mod + 2 * D, w.d_br2[pl], slot(l, 2, 0), slot(l, 2, 1)));
     produced(2);
-    RUN(wgrad_side(w.d_br2[pl], o, D, D, grads + pb + P.o_proj_w));
-    consumed(2, l);
+    if (!pair_proj) {
+      RUN(wgrad_side(w.d_br2[pl], o, D, D, grads + pb + P.o_proj_w));
+      consumed(2, l);
+    }
     g = dgrad_desc(w.d_br2[pl], wb + pb + P.o_proj_w, M, D, D);
     g.c_bf16 = (uint16_t*)w.d_o; g.ldc_bf16 = D;
     RUN(sfron_gemm_bf16(&g, stream));
     before_overwrite(3, l);
+    int proj_rc = SFRON_OK;
+    auto proj_beside = [&]() {
+      if (!pair_proj) return;
+      (void)hipStreamWaitEvent(ax->side2, ax->produced[3], 0);       // recorded after produced[2] on the same stream: covers d_br2
+      proj_rc = wgrad_on((void*)ax->side2, w.d_br2[pl], o, D, D, grads + pb + P.o_proj_w, nullptr);
+      (void)hipEventRecord(ax->join2, ax->side2);
+    };
     if (qkv_fused) {
       // qkv.bias gradient = token sums of dqkv: the attention backward kernel leaves one partial row per sample (it holds dQ / dK / dV
       // of a whole (sample, head) in registers); the side stream adds the B rows (was: a second 57 MB pass over dqkv per block)
@@ -619,15 +641,19 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
       RUN(sfron_attn_bwd_bias((const uint16_t*)qkv, (const uint16_t*)o, (const uint16_t*)w.d_o, w.lse + (size_t)l * B * d.H * T,
                               (uint16_t*)w.dqkv[pl], bp, B, T, d.H, d.hd, stream));
       produced(3);
+      proj_beside();
       RUN(sfron_reduce_chunks(bp, 1, B, 3 * D, grads + pb + P.o_qkv_b, 3 * D, 0, side));
       RUN(wgrad_side(w.dqkv[pl], xmod1, 3 * D, D, grads + pb + P.o_qkv_w));
     } else {
       RUN(sfron_attn_bwd((const uint16_t*)qkv, (const uint16_t*)o, (const uint16_t*)w.d_o, w.lse + (size_t)l * B * d.H * T,
                          w.delta, (uint16_t*)w.dqkv[pl], B, T, d.H, d.hd, stream));
       produced(3);
+      proj_beside();
       RUN(wgrad_side(w.dqkv[pl], xmod1, 3 * D, D, grads + pb + P.o_qkv_w, grads + pb + P.o_qkv_b));
     }
+    if (pair_proj) { (void)hipStreamWaitEvent(ax->side, ax->join2, 0); consumed(2, l); }   // the in-order stream's later events cover proj too
     consumed(3, l);
+    if (proj_rc != SFRON_OK) return proj_rc;
     if (block_events && block_events[l]) {                 // block l: the four weight gradients, qkv.bias and fc1.bias are final
       if (hipEventRecord((hipEvent_t)block_events[l], (hipStream_t)side) != hipSuccess) return (int)hipGetLastError();
     }

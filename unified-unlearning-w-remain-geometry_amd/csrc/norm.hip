@@ -9,6 +9,7 @@
 // Column reductions are written as per-row-chunk partials and summed by a second tiny kernel in a
 // fixed order, so results are bitwise reproducible (no float atomics).
 #include "common.h"
+#include <cstdlib>
 #include "../../include/sfron.h"
 
 namespace {
@@ -19,24 +20,41 @@ constexpr float LN_EPS = 1e-6f;
 
 struct RowRegs { float4 v[NCH]; };
 
+// Row loads are UNCONDITIONAL (column clamped to the last chunk; lanes past the row end are zeroed by a select): a load inside an
+// `if (c < D4)` body is followed by its first use in the same basic block, and hipcc then waits for EACH load before it issues the next
+// (measured on the row-backward kernel: one exposed memory latency per 16-byte chunk, ~12 per row).
 __device__ __forceinline__ void load_row_f32(const float* __restrict__ p, int D4, int lane, RowRegs& r) {
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
-    r.v[i] = c < D4 ? reinterpret_cast<const float4*>(p)[c] : make_float4(0, 0, 0, 0);
+    r.v[i] = reinterpret_cast<const float4*>(p)[c < D4 ? c : D4 - 1];
   }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if (lane + 64 * i >= D4) r.v[i] = make_float4(0, 0, 0, 0);
 }
-__device__ __forceinline__ void load_row_bf16(const __bf16* __restrict__ p, int D4, int lane, RowRegs& r) {
+// Buffer forms: the descriptor covers exactly ONE row, so a lane past the row end (the fifth 16-byte chunk of a 1152-wide row has 32
+// live lanes) loads zeros and its stores are dropped by the hardware bounds check -- no exec masks, no branches, addresses = one
+// scalar descriptor + one lane offset + immediates.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const void* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+struct RowRaw { bf16x4 v[NCH]; };     // a bf16 row as loaded (converted where it is used: half the registers while in flight)
+__device__ __forceinline__ void load_raw_bf16(const __bf16* __restrict__ p, int D4, int lane, RowRaw& r) {
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
-    if (c < D4) {
-      const bf16x4 b = reinterpret_cast<const bf16x4*>(p)[c];
-      r.v[i] = make_float4(bf2f(b[0]), bf2f(b[1]), bf2f(b[2]), bf2f(b[3]));
-    } else {
-      r.v[i] = make_float4(0, 0, 0, 0);
-    }
+    r.v[i] = reinterpret_cast<const bf16x4*>(p)[c < D4 ? c : D4 - 1];
   }
+}
+__device__ __forceinline__ float4 raw4(const RowRaw& r, int i) { return make_float4(bf2f(r.v[i][0]), bf2f(r.v[i][1]), bf2f(r.v[i][2]), bf2f(r.v[i][3])); }
+__device__ __forceinline__ void load_row_bf16(const __bf16* __restrict__ p, int D4, int lane, RowRegs& r) {
+  RowRaw raw;
+  load_raw_bf16(p, D4, lane, raw);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) r.v[i] = lane + 64 * i < D4 ? raw4(raw, i) : make_float4(0, 0, 0, 0);
 }
 
 // ---------------------------------------------------------------- LN + modulate forward
@@ -109,18 +127,43 @@ struct RowBwdArgs {
   int ldmod_ln, ldmod_gate, T, M, D, rpw, combine;
 };
 
-template <bool LN, bool GATE>
-__global__ __launch_bounds__(TPB) void k_row_bwd(const RowBwdArgs a) {
+// At most 192 registers (amdgpu_num_vgpr counts half of the unified file on gfx90a+): one workgroup (one wave per SIMD) still fits beside a
+// weight-gradient workgroup (2 x 160 registers per SIMD) on the same CU -- left alone hipcc takes 256 and the kernel then runs only on
+// CUs without one
+template <bool LN, bool GATE, bool COMBINE>
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_num_vgpr(96))) void k_row_bwd(const RowBwdArgs a) {
   constexpr int NACC = (LN ? 2 : 0) + (GATE ? 2 : 0);
   // 12 KB of LDS, so that a workgroup still fits on a CU next to a weight-gradient GEMM workgroup (3 x 48 KB slots):
   // these kernels run beside the side stream's GEMMs and are memory-bound, extra resident waves are what they need
   constexpr int HALF = 3;                          // chunks 0..2 (192 float4 per wave) then chunks 3..4
   __shared__ float4 sh[4][64 * HALF];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int D = a.D, D4 = D >> 2;
   const int wchunk = blockIdx.x * 4 + wave;      // the rpw consecutive rows of this wave
   const int row0 = wchunk * a.rpw;
-  if (!a.combine && row0 >= a.M) return;         // combine: M % (4*rpw) == 0, every wave has rows
+  // combine: the 16 rows of the workgroup belong to ONE sample -- its scale / gate rows (4.6 KB each, read by every row) live in LDS
+  // for the row loop (the buffer is free until the final reduction); otherwise (token counts not a multiple of 4) each wave reads
+  // its own sample's rows from global memory
+  float4* const s_sc = &sh[0][0];
+  float4* const s_gt = s_sc + 64 * NCH;
+  static_assert(2 * 64 * NCH <= 4 * 64 * HALF, "scale + gate rows fit the reduction buffer");
+  if constexpr (COMBINE) {
+    const int bw = (blockIdx.x * 4 * a.rpw) / a.T;
+    for (int c = threadIdx.x; c < 64 * NCH; c += TPB) {        // zero past the row end: lanes there multiply it with zeros
+      const int cl = c < D4 ? c : D4 - 1;
+      const float keep = c < D4 ? 1.0f : 0.0f;
+      if constexpr (LN) {
+        const float4 v = reinterpret_cast<const float4*>(a.scale + (size_t)bw * a.ldmod_ln)[cl];
+        s_sc[c] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+      }
+      if constexpr (GATE) {
+        const float4 v = reinterpret_cast<const float4*>(a.gate + (size_t)bw * a.ldmod_gate)[cl];
+        s_gt[c] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+      }
+    }
+    __syncthreads();
+  }
+  if (!COMBINE && row0 >= a.M) return;         // combine: M % (4*rpw) == 0, every wave has rows
   const int b = row0 / a.T;                      // all rows of a chunk belong to one sample
   float4 acc[NACC][NCH];
 #pragma unroll
@@ -129,70 +172,86 @@ __global__ __launch_bounds__(TPB) void k_row_bwd(const RowBwdArgs a) {
     for (int i = 0; i < NCH; ++i) acc[k][i] = make_float4(0, 0, 0, 0);
   const float* sc = LN ? a.scale + (size_t)b * a.ldmod_ln : nullptr;
   const float* gp = GATE ? a.gate + (size_t)b * a.ldmod_gate : nullptr;
+  // The row loop is BRANCH-FREE (buffer loads / stores, see row_rsrc).  With `if (c < D4)` bodies every chunk was its own basic block
+  // and hipcc's wait-count pass drained vmcnt(0) in front of each use: every store of a row waited for the store before it, every
+  // bf16 load for the load before it (~12 exposed memory latencies per row; now one).
+  auto ldf = [&](const float* p, RowRegs& r) {
+    const __amdgpu_buffer_rsrc_t rs = row_rsrc(p, D * 4);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) r.v[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + 1024 * i, 0, 0));
+  };
+  auto ldb = [&](const __bf16* p, RowRaw& r) {
+    const __amdgpu_buffer_rsrc_t rs = row_rsrc(p, D * 2);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) r.v[i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rs, lane * 8 + 512 * i, 0, 0));
+  };
+  // scale / gate element of chunk i (a lane past the row end reads a defined word: the LDS buffer is 64 * NCH chunks long; global: clamped)
+  auto mod4 = [&](const float4* lds_row, const float* grow, int i) {
+    const int c = lane + 64 * i;
+    if constexpr (COMBINE) return lds_row[c]; else return reinterpret_cast<const float4*>(grow)[c < D4 ? c : D4 - 1];
+  };
   for (int rr = 0; rr < a.rpw; ++rr) {
     const int row = row0 + rr;
-    RowRegs cur;                                 // the dx row the gate part sees
+    // every load of the row goes out before the first use: ONE exposed memory latency per row
+    RowRaw braw, draw;
+    RowRegs xr, prev;                            // LN: x, then xhat | the dx row before this kernel (LN: if accumulate)
+    float mean = 0.f, rstd = 0.f, m1 = 0.f, m2 = 0.f;
+    if constexpr (LN) { mean = a.mean[row]; rstd = a.rstd[row]; }     // first: loads return in order, and these are needed first
+    if constexpr (GATE) ldb(a.branch + (size_t)row * D, braw);
+    const __amdgpu_buffer_rsrc_t rs_dx = row_rsrc(a.dx + (size_t)row * D, D * 4);
     if constexpr (LN) {
-      RowRegs xr;
-      load_row_f32(a.x + (size_t)row * D, D4, lane, xr);
-      load_row_bf16(a.dxmod + (size_t)row * D, D4, lane, cur);
-      RowRegs prev;
-      if (a.dx_accumulate) load_row_f32(a.dx + (size_t)row * D, D4, lane, prev);
-      const float mean = a.mean[row], rstd = a.rstd[row];
+      ldf(a.x + (size_t)row * D, xr);
+      ldb(a.dxmod + (size_t)row * D, draw);
+      if (a.dx_accumulate) ldf(a.dx + (size_t)row * D, prev);
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
-        const int c = lane + 64 * i;
-        if (c < D4) {
-          float4& xv = xr.v[i];
-          xv.x = (xv.x - mean) * rstd; xv.y = (xv.y - mean) * rstd; xv.z = (xv.z - mean) * rstd; xv.w = (xv.w - mean) * rstd;
-          float4& g = cur.v[i];
-          acc[0][i].x += g.x; acc[0][i].y += g.y; acc[0][i].z += g.z; acc[0][i].w += g.w;
-          acc[1][i].x += g.x * xv.x; acc[1][i].y += g.y * xv.y; acc[1][i].z += g.z * xv.z; acc[1][i].w += g.w * xv.w;
-          const float4 s4 = reinterpret_cast<const float4*>(sc)[c];      // g = dxmod * (1 + scale); L1/L2-resident
-          g.x *= 1.0f + s4.x; g.y *= 1.0f + s4.y; g.z *= 1.0f + s4.z; g.w *= 1.0f + s4.w;
-          s1 += g.x + g.y + g.z + g.w;
-          s2 += g.x * xv.x + g.y * xv.y + g.z * xv.z + g.w * xv.w;
-        }
+        float4& xv = xr.v[i];
+        xv.x = (xv.x - mean) * rstd; xv.y = (xv.y - mean) * rstd; xv.z = (xv.z - mean) * rstd; xv.w = (xv.w - mean) * rstd;
+        float4 g = raw4(draw, i);                 // zero past the row end: no share in the sums
+        acc[0][i].x += g.x; acc[0][i].y += g.y; acc[0][i].z += g.z; acc[0][i].w += g.w;
+        acc[1][i].x += g.x * xv.x; acc[1][i].y += g.y * xv.y; acc[1][i].z += g.z * xv.z; acc[1][i].w += g.w * xv.w;
+        const float4 s4 = mod4(s_sc, sc, i);      // g = dxmod * (1 + scale)
+        g.x *= 1.0f + s4.x; g.y *= 1.0f + s4.y; g.z *= 1.0f + s4.z; g.w *= 1.0f + s4.w;
+        s1 += g.x + g.y + g.z + g.w;
+        s2 += g.x * xv.x + g.y * xv.y + g.z * xv.z + g.w * xv.w;
+        __builtin_amdgcn_sched_barrier(0);        // chunk by chunk: hoisting all the LDS reads of the row costs 40 registers (spills)
       }
-      const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        const int c = lane + 64 * i;
-        if (c < D4) {
-          const float4 g = cur.v[i], xh = xr.v[i];
-          float4 o = make_float4(rstd * (g.x - m1 - xh.x * m2), rstd * (g.y - m1 - xh.y * m2),
-                                 rstd * (g.z - m1 - xh.z * m2), rstd * (g.w - m1 - xh.w * m2));
-          if (a.dx_accumulate) { const float4 p = prev.v[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
-          reinterpret_cast<float4*>(a.dx + (size_t)row * D)[c] = o;
-          cur.v[i] = o;
-        }
-      }
+      m1 = wave_sum(s1) / (float)D; m2 = wave_sum(s2) / (float)D;
     } else {
-      load_row_f32(a.dx + (size_t)row * D, D4, lane, cur);
+      ldf(a.dx + (size_t)row * D, prev);
     }
-    if constexpr (GATE) {
-      constexpr int G0 = LN ? 2 : 0;
-      RowRegs br;
-      load_row_bf16(a.branch + (size_t)row * D, D4, lane, br);
+    const __amdgpu_buffer_rsrc_t rs_db = row_rsrc(GATE ? a.d_branch + (size_t)row * D : nullptr, D * 2);
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        const int c = lane + 64 * i;
-        if (c < D4) {
-          const float4 d = cur.v[i], h = br.v[i];
-          acc[G0][i].x += d.x * h.x; acc[G0][i].y += d.y * h.y; acc[G0][i].z += d.z * h.z; acc[G0][i].w += d.w * h.w;
-          acc[G0 + 1][i].x += d.x; acc[G0 + 1][i].y += d.y; acc[G0 + 1][i].z += d.z; acc[G0 + 1][i].w += d.w;
-          const float4 gt = reinterpret_cast<const float4*>(gp)[c];
-          bf16x4 o = {f2bf(d.x * gt.x), f2bf(d.y * gt.y), f2bf(d.z * gt.z), f2bf(d.w * gt.w)};
-          reinterpret_cast<bf16x4*>(a.d_branch + (size_t)row * D)[c] = o;
-        }
+    for (int i = 0; i < NCH; ++i) {
+      float4 d;                                  // the dx element the gate part sees
+      if constexpr (LN) {
+        float4 g = raw4(draw, i);                // (recomputed, not kept across the row sums: 20 registers)
+        const float4 s4 = mod4(s_sc, sc, i), xh = xr.v[i];
+        g.x *= 1.0f + s4.x; g.y *= 1.0f + s4.y; g.z *= 1.0f + s4.z; g.w *= 1.0f + s4.w;
+        d = make_float4(rstd * (g.x - m1 - xh.x * m2), rstd * (g.y - m1 - xh.y * m2),
+                        rstd * (g.z - m1 - xh.z * m2), rstd * (g.w - m1 - xh.w * m2));
+        if (a.dx_accumulate) { const float4 p = prev.v[i]; d.x += p.x; d.y += p.y; d.z += p.z; d.w += p.w; }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d), rs_dx, lane * 16 + 1024 * i, 0, 0);
+      } else {
+        d = prev.v[i];
       }
+      if constexpr (GATE) {
+        constexpr int G0 = LN ? 2 : 0;
+        const float4 h = raw4(braw, i);
+        acc[G0][i].x += d.x * h.x; acc[G0][i].y += d.y * h.y; acc[G0][i].z += d.z * h.z; acc[G0][i].w += d.w * h.w;
+        acc[G0 + 1][i].x += d.x; acc[G0 + 1][i].y += d.y; acc[G0 + 1][i].z += d.z; acc[G0 + 1][i].w += d.w;
+        const float4 gt = mod4(s_gt, gp, i);
+        const bf16x4 o = {f2bf(d.x * gt.x), f2bf(d.y * gt.y), f2bf(d.z * gt.z), f2bf(d.w * gt.w)};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_db, lane * 8 + 512 * i, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   float* dst[4];
   if constexpr (LN) { dst[0] = a.p_shift; dst[1] = a.p_scale; }
   if constexpr (GATE) { dst[LN ? 2 : 0] = a.p_gate; dst[LN ? 3 : 1] = a.p_dy; }
-  if (!a.combine) {
+  if constexpr (!COMBINE) {
 #pragma unroll
     for (int k = 0; k < NACC; ++k)
 #pragma unroll
@@ -207,7 +266,7 @@ __global__ __launch_bounds__(TPB) void k_row_bwd(const RowBwdArgs a) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                  // two passes through the 12 KB buffer
       constexpr int I0[2] = {0, HALF}, I1[2] = {HALF, NCH};
-      if (k || h) __syncthreads();
+      __syncthreads();                             // (first pass: every wave is done with the scale / gate rows)
 #pragma unroll
       for (int i = I0[h]; i < I1[h]; ++i) sh[wave][lane + 64 * (i - I0[h])] = acc[k][i];
       __syncthreads();
@@ -369,6 +428,10 @@ __global__ __launch_bounds__(TPB) void k_colsum_partial(const T* __restrict__ X,
 // rows per wave and whether the 4 waves of a workgroup combine their partials (needs 4*rpw | T)
 struct ChunkPlan { int rpw, combine, rows; };
 inline ChunkPlan pick_chunk(int T) {
+#ifdef SFRON_DEBUG_KNOBS
+  static const int knob = getenv("SFRON_ROW_RPW") ? atoi(getenv("SFRON_ROW_RPW")) : 0;      // A-B of the rows per wave (tools/bench_dbg.py)
+  if (knob > 0 && T % (4 * knob) == 0) return {knob, 1, 4 * knob};
+#endif
   if (T % 16 == 0) return {4, 1, 16};
   if (T % 8 == 0) return {2, 1, 8};
   if (T % 4 == 0) return {1, 1, 4};
@@ -380,7 +443,8 @@ template <bool LN, bool GATE>
 int launch_row_bwd(RowBwdArgs a, void* stream) {
   const ChunkPlan cp = pick_chunk(a.T);
   a.rpw = cp.rpw; a.combine = cp.combine;
-  hipLaunchKernelGGL((k_row_bwd<LN, GATE>), dim3(cdiv(a.M / cp.rpw, 4)), dim3(TPB), 0, (hipStream_t)stream, a);
+  if (cp.combine) hipLaunchKernelGGL((k_row_bwd<LN, GATE, true>), dim3(cdiv(a.M / cp.rpw, 4)), dim3(TPB), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((k_row_bwd<LN, GATE, false>), dim3(cdiv(a.M / cp.rpw, 4)), dim3(TPB), 0, (hipStream_t)stream, a);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }
