@@ -225,7 +225,11 @@ int sfron_aux_create(void** aux) {
     if (hipEventCreateWithFlags(&a->consumed[i], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
   if (hipEventCreateWithFlags(&a->done, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
   // second weight-gradient stream: the 36-tile proj weight gradient runs BESIDE the 108-tile qkv one (see dit_backward_impl)
-  if (hipStreamCreateWithFlags(&a->side2, hipStreamNonBlocking) != hipSuccess) return (int)hipGetLastError();
+  if (ablate_mask() & 4) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&a->side2, hipStreamNonBlocking, lo) != hipSuccess) return (int)hipGetLastError();
+  } else if (hipStreamCreateWithFlags(&a->side2, hipStreamNonBlocking) != hipSuccess) return (int)hipGetLastError();
   if (hipEventCreateWithFlags(&a->join2, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
   *aux = a;
   return SFRON_OK;

@@ -65,48 +65,50 @@ __global__ __launch_bounds__(TPB) void k_ln_mod_fwd(const float* __restrict__ x,
                                                     const float* __restrict__ scale, int ldmod, int T, int M, int D,
                                                     __bf16* __restrict__ out, float* __restrict__ mean_out,
                                                     float* __restrict__ rstd_out) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int row0 = (blockIdx.x * 4 + wave) * RPW;
   if (row0 >= M) return;
-  const int D4 = D >> 2;
-  RowRegs r[RPW];
+  // branch-free: one-row buffer descriptors (see row_rsrc), every load of the wave's rows -- x, shift, scale -- before the first use
+  RowRegs r[RPW], sh[RPW], sc[RPW];
 #pragma unroll
   for (int k = 0; k < RPW; ++k) {
     const int row = row0 + k < M ? row0 + k : M - 1;
-    load_row_f32(x + (size_t)row * D, D4, lane, r[k]);
+    const int b = row / T;
+    const __amdgpu_buffer_rsrc_t rx = row_rsrc(x + (size_t)row * D, D * 4);
+    const __amdgpu_buffer_rsrc_t rh = row_rsrc(shift + (size_t)b * ldmod, D * 4), rc = row_rsrc(scale + (size_t)b * ldmod, D * 4);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) r[k].v[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, lane * 16 + 1024 * i, 0, 0));
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      sh[k].v[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rh, lane * 16 + 1024 * i, 0, 0));
+      sc[k].v[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rc, lane * 16 + 1024 * i, 0, 0));
+    }
   }
 #pragma unroll
   for (int k = 0; k < RPW; ++k) {
     const int row = row0 + k;
-    if (row >= M) break;
+    if (row >= M) break;                          // wave-uniform
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) s += r[k].v[i].x + r[k].v[i].y + r[k].v[i].z + r[k].v[i].w;
+    for (int i = 0; i < NCH; ++i) s += r[k].v[i].x + r[k].v[i].y + r[k].v[i].z + r[k].v[i].w;     // zeros past the row end
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      if (lane + 64 * i < D4) {
-        const float a = r[k].v[i].x - mean, b = r[k].v[i].y - mean, c = r[k].v[i].z - mean, d = r[k].v[i].w - mean;
-        q += a * a + b * b + c * c + d * d;
-      }
+      const float live = lane + 64 * i < (D >> 2) ? 1.0f : 0.0f;
+      const float a = r[k].v[i].x - mean, b = r[k].v[i].y - mean, c = r[k].v[i].z - mean, d = r[k].v[i].w - mean;
+      q += live * (a * a + b * b + c * c + d * d);
     }
     const float var = wave_sum(q) / (float)D;
     const float rstd = 1.0f / sqrtf(var + LN_EPS);
     if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
-    const int b = row / T;
-    const float* sh = shift + (size_t)b * ldmod;
-    const float* sc = scale + (size_t)b * ldmod;
+    const __amdgpu_buffer_rsrc_t ro = row_rsrc(out + (size_t)row * D, D * 2);
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
-      if (c < D4) {
-        const float4 h = reinterpret_cast<const float4*>(sh)[c];
-        const float4 g = reinterpret_cast<const float4*>(sc)[c];
-        bf16x4 o = {f2bf((r[k].v[i].x - mean) * rstd * (1.0f + g.x) + h.x), f2bf((r[k].v[i].y - mean) * rstd * (1.0f + g.y) + h.y),
-                    f2bf((r[k].v[i].z - mean) * rstd * (1.0f + g.z) + h.z), f2bf((r[k].v[i].w - mean) * rstd * (1.0f + g.w) + h.w)};
-        reinterpret_cast<bf16x4*>(out + (size_t)row * D)[c] = o;
-      }
+      const float4 h = sh[k].v[i], g = sc[k].v[i];
+      const bf16x4 o = {f2bf((r[k].v[i].x - mean) * rstd * (1.0f + g.x) + h.x), f2bf((r[k].v[i].y - mean) * rstd * (1.0f + g.y) + h.y),
+                        f2bf((r[k].v[i].z - mean) * rstd * (1.0f + g.z) + h.z), f2bf((r[k].v[i].w - mean) * rstd * (1.0f + g.w) + h.w)};
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ro, lane * 8 + 512 * i, 0, 0);
     }
   }
 }
