@@ -985,12 +985,18 @@ __global__ __launch_bounds__(GNB) void k_gn2_stats(const float* __restrict__ x, 
         }
   }
   __syncthreads();
-  if (threadIdx.x < G) {
+  // one wave per group at a time: lane l adds the words l, l + 64, ... of the group's [rpp][cg] block in index order, then a butterfly
+  // over the lanes -- a fixed order (bitwise reproducible).  (Was: G threads walking rpp * cg words each, 256 dependent LDS reads
+  // = most of the kernel at the small levels.)
+  const int lane = threadIdx.x & 63, nw = GNB / 64, per = m.rpp * cg;
+  for (int g = threadIdx.x >> 6; g < G; g += nw) {
     double a = 0.0, q = 0.0;
-    for (int c = threadIdx.x * cg; c < (threadIdx.x + 1) * cg; ++c)
-      for (int r = 0; r < m.rpp; ++r) { a += shd[((size_t)r * C + c) * 2]; q += shd[((size_t)r * C + c) * 2 + 1]; }
-    double* o = part + (((size_t)b * nchunk + ch) * G + threadIdx.x) * 2;
-    o[0] = a; o[1] = q;
+    for (int i = lane; i < per; i += 64) {
+      const int r = i / cg, c = g * cg + (i - r * cg);
+      a += shd[((size_t)r * C + c) * 2]; q += shd[((size_t)r * C + c) * 2 + 1];
+    }
+    a = wave_sum_d(a); q = wave_sum_d(q);
+    if (lane == 0) { double* o = part + (((size_t)b * nchunk + ch) * G + g) * 2; o[0] = a; o[1] = q; }
   }
 }
 // phase 2 forward: mean / rstd from the partials (every workgroup of a sample forms them the same way; chunk 0 stores them), apply
@@ -999,10 +1005,13 @@ __global__ __launch_bounds__(GNB) void k_gn2_apply(const float* __restrict__ x, 
                                                    int nchunk, const double* __restrict__ part, __bf16* __restrict__ y, float* __restrict__ mean,
                                                    float* __restrict__ rstd) {
   __shared__ float st[2][64];
+  __shared__ double sp[32 * 64 * 2];            // [chunk][group][2]: every partial of the sample, fetched by nchunk * G threads at once
   const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk, cg = C / G;
+  for (int i = threadIdx.x; i < nchunk * G * 2; i += GNB) sp[i] = part[(size_t)b * nchunk * G * 2 + i];
+  __syncthreads();
   if (threadIdx.x < G) {
     double a = 0.0, q = 0.0;
-    for (int k = 0; k < nchunk; ++k) { const double* o = part + (((size_t)b * nchunk + k) * G + threadIdx.x) * 2; a += o[0]; q += o[1]; }
+    for (int k = 0; k < nchunk; ++k) { const double* o = sp + ((size_t)k * G + threadIdx.x) * 2; a += o[0]; q += o[1]; }
     const double n = (double)HW * cg, mu = a / n;
     double var = q / n - mu * mu;                 // biased variance, as torch.nn.GroupNorm
     var = var < 0 ? 0 : var;
@@ -1119,16 +1128,28 @@ __global__ __launch_bounds__(GNB) void k_gn2_bwd_apply(const float* __restrict__
   extern __shared__ float shf[];                // [C][2] channel sums, then [G][2] group means
   const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk, cg = C / G;
   float* kk = shf + 2 * C;
+  float* sg = kk + 2 * G;                       // gamma, staged for the group sums below
   for (int c = threadIdx.x; c < C; c += GNB) {
     float a = 0.f, q = 0.f;
-    for (int k = 0; k < nchunk; ++k) { const float* o = part + (((size_t)b * nchunk + k) * C + c) * 2; a += o[0]; q += o[1]; }
+    sg[c] = gamma[c];
+    for (int k0 = 0; k0 < nchunk; k0 += 8) {    // eight partial pairs in flight (a load-use loop pays one L2 latency per chunk)
+      float2 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + u < nchunk ? k0 + u : nchunk - 1;
+        t[u] = *reinterpret_cast<const float2*>(part + (((size_t)b * nchunk + k) * C + c) * 2);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + u < nchunk) { a += t[u].x; q += t[u].y; }
+    }
     shf[2 * c] = a; shf[2 * c + 1] = q;
     if (ch == 0) { pg[(size_t)b * C + c] = a; pb[(size_t)b * C + c] = q; }
   }
   __syncthreads();
   if (threadIdx.x < G) {
     float t1 = 0.f, t2 = 0.f;
-    for (int c = threadIdx.x * cg; c < (threadIdx.x + 1) * cg; ++c) { const float g1 = gamma[c]; t1 += g1 * shf[2 * c + 1]; t2 += g1 * shf[2 * c]; }
+    for (int c = threadIdx.x * cg; c < (threadIdx.x + 1) * cg; ++c) { const float g1 = sg[c]; t1 += g1 * shf[2 * c + 1]; t2 += g1 * shf[2 * c]; }
     const float inv = 1.0f / ((float)HW * (float)cg);
     kk[2 * threadIdx.x] = t1 * inv; kk[2 * threadIdx.x + 1] = t2 * inv;
   }
@@ -2056,7 +2077,7 @@ int sfron_groupnorm_bwd(const float* dy, const float* x, int ldx, const float* g
     hipLaunchKernelGGL(k_gn2_bwd_stats, dim3(B * nchunk), dim3(GNB), gn2_lds(C, sizeof(float)), (hipStream_t)stream, dy, x, ldx, gamma, beta, mean, rstd,
                        HW, C, groups, swish, drop_mask, drop_scale, nchunk, (float*)scratch);
     SFRON_LAUNCH_STATUS();
-    hipLaunchKernelGGL(k_gn2_bwd_apply, dim3(B * nchunk), dim3(GNB), (size_t)(2 * C + 2 * groups) * sizeof(float), (hipStream_t)stream, dy, x, ldx, gamma,
+    hipLaunchKernelGGL(k_gn2_bwd_apply, dim3(B * nchunk), dim3(GNB), (size_t)(3 * C + 2 * groups) * sizeof(float), (hipStream_t)stream, dy, x, ldx, gamma,
                        beta, mean, rstd, HW, C, groups, swish, drop_mask, drop_scale, nchunk, (const float*)scratch, dx, lddx, accumulate,
                        part_gamma, part_beta);
     SFRON_LAUNCH_STATUS();
