@@ -172,6 +172,9 @@ def main():
         runner.factored_ada = False
     if args.no_sweep_beside:
         runner.sweep_beside_forward = False
+    if os.environ.get("SFRON_BENCH_LOADER_WAVES"):          # A-B knob (tools only): form of the three-slot GEMM tiles, 0 or 4
+        from sfron import _lib
+        _lib.lib().sfron_gemm_loader_waves(int(os.environ["SFRON_BENCH_LOADER_WAVES"]))
     if os.environ.get("SFRON_BENCH_SWEEP_BESIDE"):          # tuning knob (tools only): "workgroups,head"
         runner.sweep_beside_wg, runner.sweep_beside_head = (int(v) for v in os.environ["SFRON_BENCH_SWEEP_BESIDE"].split(","))
 

@@ -475,6 +475,11 @@ int sfron_attn_bwd_bias(const uint16_t* qkv, const uint16_t* o, const uint16_t* 
 
 /* test hook: 2 = always the two-kernel backward, 0 = default; returns the previous setting (process-wide, not thread-safe) */
 int sfron_attn_bwd_form(int form);
+/* Process-wide form of the three-slot GEMM tiles (256 x 144 forward / dgrad, 192 x 192 weight gradient): 4 = four extra LOADER waves per
+ * workgroup issue every LDS-DMA piece and the eight multiplying waves none (csrc/gemm.hip k_gemm_pipe NL; taken by the dgrad and
+ * weight-gradient layouts, where it measured faster) -- the default; 0 = every wave issues its share (5 / 6: weight gradients / dgrad
+ * only, for A-B runs).  Same results bit for bit (same products, same summation order).  Returns the previous value. */
+int sfron_gemm_loader_waves(int n);
 
 /* ------------------------------------------------------------------ whole-model DiT pass (dit_engine.hip)
  * Replaces autograd over DiT.forward (DiT/models.py:233-248) inside the SFR-on step (DiT/forget.py:271-288,310-319).

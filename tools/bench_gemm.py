@@ -3,7 +3,11 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from sfron import ops, _lib
+from sfron import _lib
+if os.environ.get("SFRON_DBG_LIB"):       # the debug-knob build (SFRON_GEMM_SAME_TILE ...): `make -C .../csrc dbg`
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libsfron_dbg.so")
+from sfron import ops
+if os.environ.get("SFRON_LOADER_WAVES"): _lib.lib().sfron_gemm_loader_waves(int(os.environ["SFRON_LOADER_WAVES"]))
 
 DEV = "cuda:0"
 HINT = int(sys.argv[1]) if len(sys.argv) > 1 else 0

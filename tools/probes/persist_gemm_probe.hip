@@ -238,6 +238,207 @@ __global__ __launch_bounds__(256) void k_gemm4(const __bf16* __restrict__ A, con
   }
 }
 
+
+// ---- four CONSUMER waves (one per SIMD, 64 x (NT_*16) each, as k_gemm4) + four LOADER waves that issue every LDS-DMA piece of the ring:
+// MI355X_MICROARCH.md prices one 1-KiB LDS-DMA piece at 60-185 cycles of the ISSUING wave (6-7 pieces per wave and K-step in the
+// kernels above, against 576 cycles of MFMA per wave and K-step) -- here the waves that multiply never issue one.  One s_barrier per
+// K-tile for all eight waves: a loader arrives once its share of tile j has landed (counted vmcnt), a consumer once tile j - 1's
+// fragments are in its registers; after it the loaders refill tile j - 1's slot with tile j + 2.
+template <int NT_, int MODE = 0>
+__global__ __launch_bounds__(512) void k_gemm4l(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* __restrict__ C, int M, int N, int K) {
+  constexpr int NW = 4, MT = 4, NS = 3, FBN = NT_ * 16, A_EL = FBM * BK, B_EL = FBN * BK, SLOT = A_EL + B_EL;
+  constexpr int NA = FBM * 8 / 64 / NW, NB_TOT = FBN * 8 / 64, NB = (NB_TOT + NW - 1) / NW;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave8 >= 4;
+  const int wave = wave8 & 3;
+  const int ntn = N / FBN, nk = K / BK;
+  int id;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x, q = nblk >> 3, r = nblk & 7, x = b & 7, y = b >> 3;
+    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+  }
+  const int tm = id / ntn, m0 = tm * FBM, n0 = (id - tm * ntn) * FBN;
+  if (loader) {
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, M * K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, N * K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0, 0x00020000);
+    __bf16* dummy = smem + NS * SLOT;
+    const int lc8 = ((lane & 7) ^ ((lane >> 3) & 7)) << 3;
+    int a_off[NA], b_off[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a_off[i] = 2 * ((m0 + (wave + i * NW) * 8 + (lane >> 3)) * K + lc8);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b_off[i] = 2 * ((n0 + (wave + i * NW) * 8 + (lane >> 3)) * K + lc8);
+    auto issue = [&](int slot, int kt) {
+      __bf16* iA = smem + slot * SLOT;
+      __bf16* iB = iA + A_EL;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) dma16(rsA, iA + (wave + i * NW) * 512, a_off[i], 2 * kt * BK);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const bool ok = wave + i * NW < NB_TOT;
+        dma16(ok ? rsB : rs0, ok ? iB + (wave + i * NW) * 512 : dummy, b_off[i], 2 * kt * BK);
+      }
+    };
+    if (MODE != 2) { issue(0, 0); if (nk > 1) issue(1, 1); }
+    int slot2 = 2;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) wait_vmcnt<NA + NB>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (MODE != 2 && kt + 2 < nk) issue(slot2, kt + 2);
+      slot2 = slot2 == 2 ? 0 : slot2 + 1;
+    }
+    return;
+  }
+  f32x4 acc[MT][NT_];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT_; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fg = lane >> 4;
+  struct Frags { bf16x8 a[MT], b[NT_]; };
+  auto read = [&](Frags& f, int slot, int ks) {
+    const __bf16* iA = smem + slot * SLOT;
+    const __bf16* iB = iA + A_EL;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) f.a[mt] = frag(iA, wave * 64 + mt * 16 + fr, ks * 4 + fg);
+#pragma unroll
+    for (int nt = 0; nt < NT_; ++nt) f.b[nt] = frag(iB, nt * 16 + fr, ks * 4 + fg);
+  };
+  auto mfmas = [&](const Frags& f) {
+#pragma unroll
+    for (int nt = 0; nt < NT_; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        f32x4& c = acc[mt][nt];
+        const bf16x8 fb = f.b[nt], fa = f.a[mt];
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(fb), "v"(fa));
+      }
+  };
+  __builtin_amdgcn_s_barrier();                            // tile 0 is in LDS
+  Frags f0, f1;
+  if (MODE == 1) {                                         // DMA only: the consumers just keep the barrier count
+    for (int kt = 1; kt < nk; ++kt) __builtin_amdgcn_s_barrier();
+  } else {
+  read(f0, 0, 0);
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    read(f1, slot, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int nslot = slot == NS - 1 ? 0 : slot + 1;
+    if (kt + 1 < nk) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // both K-steps of tile kt are in registers: its slot may be refilled
+      __builtin_amdgcn_s_barrier();                            // tile kt + 1 is in LDS
+      read(f0, nslot, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(f1);
+    __builtin_amdgcn_sched_barrier(0);
+    slot = nslot;
+  }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = m0 + wave * 64 + mt * 16 + fr;
+#pragma unroll
+    for (int nt = 0; nt < NT_; ++nt) {
+      const f32x4 v = acc[mt][nt];
+      *reinterpret_cast<bf16x4*>(C + (size_t)row * N + n0 + nt * 16 + 4 * fg) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    }
+  }
+}
+
+// ---- eight CONSUMER waves (32 x (NT_*16) each, compiler-scheduled as the plain k_gemm<8,1,2,NT_>) + four LOADER waves: three waves per SIMD
+// (<= 168 registers), the two consumers of a SIMD hide each other's LDS latency, the loader of the SIMD issues a quarter of the DMA pieces
+template <int NT_, int MODE = 0, int NWL = 4>
+__global__ __launch_bounds__(512 + 64 * NWL) void k_gemm8l(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* __restrict__ C, int M, int N, int K) {
+  constexpr int MT = 2, NS = 3, FBN = NT_ * 16, A_EL = FBM * BK, B_EL = FBN * BK, SLOT = A_EL + B_EL;
+  constexpr int NA = FBM * 8 / 64 / NWL, NB_TOT = FBN * 8 / 64, NB = (NB_TOT + NWL - 1) / NWL;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = N / FBN, nk = K / BK;
+  int id;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x, q = nblk >> 3, r = nblk & 7, x = b & 7, y = b >> 3;
+    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+  }
+  const int tm = id / ntn, m0 = tm * FBM, n0 = (id - tm * ntn) * FBN;
+  if (wave12 >= 8) {
+    const int wave = wave12 - 8;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, M * K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, N * K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0, 0x00020000);
+    __bf16* dummy = smem + NS * SLOT;
+    const int lc8 = ((lane & 7) ^ ((lane >> 3) & 7)) << 3;
+    int a_off[NA], b_off[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a_off[i] = 2 * ((m0 + (wave + i * NWL) * 8 + (lane >> 3)) * K + lc8);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b_off[i] = 2 * ((n0 + (wave + i * NWL) * 8 + (lane >> 3)) * K + lc8);
+    auto issue = [&](int slot, int kt) {
+      __bf16* iA = smem + slot * SLOT;
+      __bf16* iB = iA + A_EL;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) dma16(rsA, iA + (wave + i * NWL) * 512, a_off[i], 2 * kt * BK);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const bool ok = wave + i * NWL < NB_TOT;
+        dma16(ok ? rsB : rs0, ok ? iB + (wave + i * NWL) * 512 : dummy, b_off[i], 2 * kt * BK);
+      }
+    };
+    if (MODE != 2) { issue(0, 0); if (nk > 1) issue(1, 1); }
+    int slot2 = 2;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) wait_vmcnt<NA + NB>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (MODE != 2 && kt + 2 < nk) issue(slot2, kt + 2);
+      slot2 = slot2 == 2 ? 0 : slot2 + 1;
+    }
+    return;
+  }
+  const int wm = wave12;
+  f32x4 acc[MT][NT_];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT_; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fg = lane >> 4;
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_barrier();                          // tile kt is in LDS (and this wave's reads of tile kt - 1 were waited for by its MFMAs)
+    const __bf16* iA = smem + slot * SLOT;
+    const __bf16* iB = iA + A_EL;
+    if (MODE != 1)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) fa[mt] = frag(iA, wm * MT * 16 + mt * 16 + fr, ks * 4 + fg);
+#pragma unroll
+      for (int nt = 0; nt < NT_; ++nt) {
+        const bf16x8 fb = frag(iB, nt * 16 + fr, ks * 4 + fg);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[mt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+    slot = slot == NS - 1 ? 0 : slot + 1;
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = m0 + wm * MT * 16 + mt * 16 + fr;
+#pragma unroll
+    for (int nt = 0; nt < NT_; ++nt) {
+      const f32x4 v = acc[mt][nt];
+      *reinterpret_cast<bf16x4*>(C + (size_t)row * N + n0 + nt * 16 + 4 * fg) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    }
+  }
+}
+
 static uint16_t f2bf(float f) { uint32_t u; std::memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
 static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
 
@@ -361,13 +562,56 @@ void run4(const char* name, int M, int N, int K) {
   hipFree(dA); hipFree(dB); hipFree(dC);
 }
 
+template <int NT_, int FORM, int MODE = 0, int NWL = 4>
+void run4l(const char* name, int M, int N, int K) {
+  constexpr int FBN = NT_ * 16;
+  const size_t lds = (size_t)3 * (FBM + FBN) * BK * 2 + 1024;
+  if (N % FBN || lds > 160 * 1024) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm4l<NT_, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8l<NT_, MODE, NWL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  std::vector<uint16_t> hA((size_t)M * K), hB((size_t)N * K);
+  uint32_t st = 31337u + N + K;
+  auto rnd = [&]() { st = st * 1664525u + 1013904223u; return st >> 8; };
+  for (auto& v : hA) v = f2bf((float)((int)(rnd() % 5) - 2));
+  for (auto& v : hB) v = f2bf((float)((int)(rnd() % 5) - 2));
+  __bf16 *dA, *dB, *dC;
+  hipMalloc(&dA, hA.size() * 2); hipMalloc(&dB, hB.size() * 2); hipMalloc(&dC, (size_t)M * N * 2);
+  hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
+  const dim3 grid((M / FBM) * (N / FBN));
+  auto launch = [&]() {
+    if (FORM == 4) hipLaunchKernelGGL((k_gemm4l<NT_, MODE>), grid, dim3(512), lds, 0, dA, dB, dC, M, N, K);
+    else hipLaunchKernelGGL((k_gemm8l<NT_, MODE, NWL>), grid, dim3(512 + 64 * NWL), lds, 0, dA, dB, dC, M, N, K);
+  };
+  hipMemset(dC, 0xff, (size_t)M * N * 2);
+  launch(); hipDeviceSynchronize();
+  std::vector<uint16_t> hC((size_t)M * N);
+  hipMemcpy(hC.data(), dC, hC.size() * 2, hipMemcpyDeviceToHost);
+  int bad = 0;
+  for (int t = 0; t < 6000; ++t) {
+    const int r = rnd() % M, c = rnd() % N;
+    float ref = 0.f;
+    for (int k = 0; k < K; ++k) ref += bf2f(hA[(size_t)r * K + k]) * bf2f(hB[(size_t)c * K + k]);
+    if (hC[(size_t)r * N + c] != f2bf(ref)) ++bad;
+  }
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 5; ++i) launch();
+  hipEventRecord(e0);
+  const int reps = 30;
+  for (int i = 0; i < reps; ++i) launch();
+  hipEventRecord(e1); hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+  printf("%-16s tile 256x%-3d %d consumer waves + %d loader waves (mode %d: 1 = DMA only, 2 = compute only), 3 slots grid %4d: %7.1f us  %7.1f TFLOP/s   exact-integer check: %d / 6000 wrong\n", name, FBN,
+         FORM, NWL, MODE, (int)grid.x, ms * 1e3, 2.0 * M * N * K / ms / 1e9, bad);
+  hipFree(dA); hipFree(dB); hipFree(dC);
+}
+
 int main() {
   const int M = 8192;
   struct Shape { const char* name; int N, K; } shapes[] = {{"qkv  1152->3456", 3456, 1152}, {"proj 1152->1152", 1152, 1152},
                                                            {"fc1  1152->4608", 4608, 1152}, {"fc2  4608->1152", 1152, 4608}};
   for (const Shape& s : shapes) {
-    run<8, 1, 2, 9>(s.name, M, s.N, s.K); run_grouped<2>(s.name, M, s.N, s.K); run_grouped<4>(s.name, M, s.N, s.K); run_grouped<8>(s.name, M, s.N, s.K);
-    run4<9, 3>(s.name, M, s.N, s.K); run4<9, 2>(s.name, M, s.N, s.K); run4<12, 2>(s.name, M, s.N, s.K); run4<16, 2>(s.name, M, s.N, s.K);
+    run<8, 1, 2, 9>(s.name, M, s.N, s.K);
+    run4l<8, 8>(s.name, M, s.N, s.K); run4l<8, 8, 1>(s.name, M, s.N, s.K); run4l<8, 8, 2>(s.name, M, s.N, s.K); run4l<8, 4>(s.name, M, s.N, s.K); run4l<8, 4, 1>(s.name, M, s.N, s.K); run4l<8, 4, 2>(s.name, M, s.N, s.K);
   }
   return 0;
 }

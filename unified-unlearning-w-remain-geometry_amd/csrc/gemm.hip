@@ -45,6 +45,9 @@ struct GemmArgs {
   int ntm, ntn;
   int group_m;              // fast path: tile-rows per group of the grouped tile order
   float* bsum;              // weight-gradient layout: bsum[m] = sum_k op(A)[m][k] (bias gradient), or null
+#ifdef SFRON_DEBUG_KNOBS
+  int dbg_same;             // timing experiments only (see k_gemm_pipe)
+#endif
   float* colpart;           // EPI_DGELU on the 256-row pipelined tiles: colpart[tm * N + n] = sum over the tile's 256 rows of the
                             // fp32 output (before bf16 rounding) -- per-tile-row partials of the fc1 bias gradient, or null
 };
@@ -693,9 +696,19 @@ __device__ __forceinline__ void lds_reads_done() {
 // writes partial sums bsum[tn][m] (the host adds the ntn partial rows in a fixed order).  (Giving all of it to the tn = 0
 // column made those 1/ntn of the workgroups 17 % longer, and with one round of tiles the launch ends with its slowest
 // workgroup: measured +20 us per launch.)  fp32 accumulation of bf16 values in a fixed order: deterministic.
-template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI, int SCHED = 0, int PRO = 2, bool BSUM = false>
-__global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
+// NL > 0 (three-slot schedule only): NL extra LOADER waves issue every LDS-DMA piece of the ring and nothing else; the WM * WN waves
+// that multiply never issue one.  MI355X_MICROARCH.md prices a 1-KiB piece at 60-185 cycles of the issuing wave, 6-7 pieces per wave
+// and K-step in the shared form, against 576 cycles of MFMA per wave and K-step; tools/probes/persist_gemm_probe.hip measured the
+// split 13-22 % faster on the plain loop.  One s_barrier per K-tile for all waves: a loader arrives once its share of tile kt has
+// landed (counted vmcnt), a consumer once the fragments of tile kt - 1 are in its registers; behind it the loaders refill the slot of
+// tile kt - 1 with tile kt + 2.
+template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI, int SCHED = 0, int PRO = 2, bool BSUM = false, int NL = 0>
+__global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
   static_assert(!BSUM || (A_TR && B_TR && EPI == EPI_F32 && SCHED == 2), "row sums ride on the three-slot weight-gradient kernel");
+  static_assert(NL == 0 || SCHED == 2, "loader waves feed the three-slot ring");
+  static_assert(NL == 0 || !BSUM, "no row sums in the loader form");
+  constexpr bool NL_SIMPLE = false;     // consumers of the loader form: false = the hand-interleaved body minus its DMA operations; true = a compiler-
+                                        // scheduled loop (measured 5-10 % SLOWER than the default form on every shape: hipcc keeps two B fragments in flight)
   constexpr int FBM = WM * MT * 16, FBN = WN * NT * 16, NW = WM * WN;
   constexpr int FBM_P = A_TR ? tr_cols<FBM>() : FBM, FBN_P = B_TR ? tr_cols<FBN>() : FBN;   // physical row length of a transposed-read image
   constexpr int A_ELEMS = FBM_P * 64, B_ELEMS = FBN_P * 64;
@@ -719,7 +732,13 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
   const int per_group = g.group_m * g.ntn;
   const int first_m = (id / per_group) * g.group_m;
   const int gsz = min(g.ntm - first_m, g.group_m);
-  const int tm = first_m + (id % per_group) % gsz, tn = (id % per_group) / gsz;
+  int tm = first_m + (id % per_group) % gsz, tn = (id % per_group) / gsz;
+#ifdef SFRON_DEBUG_KNOBS
+  // timing experiment (results are wrong): g.group_m < 0 sends every workgroup to tile (0, 0) / every tile-row to column 0 / every
+  // tile-column to row 0 -- all operand lines are L2 hits after the first touch: is a K-step bound by the L2-miss latency?
+  if (g.dbg_same & 1) tm = 0;
+  if (g.dbg_same & 2) tn = 0;
+#endif
   const int m0 = tm * FBM, n0 = tn * FBN;
 
   f32x4 acc[MT][NT];
@@ -749,7 +768,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
 
   // forward layouts (the only ones that carry a bias): this lane's bias columns, one float4 per n-tile, fetched before the
   // main loop so that their latency is not on the epilogue's path; the transposed layouts keep the registers
-  constexpr bool PRE_BIAS = !A_TR && !B_TR;
+  constexpr bool PRE_BIAS = !A_TR && !B_TR && NL == 0;      // (the loader form has 168 registers per wave: its epilogue fetches the bias)
   float4 bias_v[PRE_BIAS ? NT : 1];
   if constexpr (PRE_BIAS) {
     const int cb = n0 + wn * NT * 16 + 4 * (lane >> 4);
@@ -757,10 +776,12 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
     for (int nt = 0; nt < NT; ++nt)
       bias_v[nt] = g.bias ? *reinterpret_cast<const float4*>(g.bias + cb + nt * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  GldsPlan<FBM, A_TR, NW> planA;
-  GldsPlan<FBN, B_TR, NW> planB;
-  planA.init(g.lda, m0, wave, lane);
-  planB.init(g.ldb, n0, wave, lane);
+  constexpr int NWD = NL > 0 ? NL : NW;                        // waves that issue LDS-DMA
+  const int dwave = NL > 0 ? wave - NW : wave;                 // (consumers of the NL form never use their plan)
+  GldsPlan<FBM, A_TR, NWD> planA;
+  GldsPlan<FBN, B_TR, NWD> planB;
+  planA.init(g.lda, m0, dwave, lane);
+  planB.init(g.ldb, n0, dwave, lane);
   // num_records = the operand's exact extent: loads past it (the "next tile" request of the last iteration) fetch nothing
   const int bytesA = 2 * (((A_TR ? g.K : g.M) - 1) * g.lda + (A_TR ? g.M : g.K));
   const int bytesB = 2 * (((B_TR ? g.K : g.N) - 1) * g.ldb + (B_TR ? g.N : g.K));
@@ -770,12 +791,33 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
   __bf16* const dma_dummy = smem + NS * (A_ELEMS + B_ELEMS);     // 1 KB behind the slots (allocated for uneven plans only)
   auto stage = [&](int buf, int k0) {
 #pragma unroll
-    for (int i = 0; i < GldsPlan<FBM, A_TR, NW>::PER_WAVE; ++i)
-      planA.issue_one_g(rsA, rsNull, 2 * (A_TR ? k0 * g.lda : k0), sAp(buf), dma_dummy, wave, i);
+    for (int i = 0; i < GldsPlan<FBM, A_TR, NWD>::PER_WAVE; ++i)
+      planA.issue_one_g(rsA, rsNull, 2 * (A_TR ? k0 * g.lda : k0), sAp(buf), dma_dummy, dwave, i);
 #pragma unroll
-    for (int i = 0; i < GldsPlan<FBN, B_TR, NW>::PER_WAVE; ++i)
-      planB.issue_one_g(rsB, rsNull, 2 * (B_TR ? k0 * g.ldb : k0), sBp(buf), dma_dummy, wave, i);
+    for (int i = 0; i < GldsPlan<FBN, B_TR, NWD>::PER_WAVE; ++i)
+      planB.issue_one_g(rsB, rsNull, 2 * (B_TR ? k0 * g.ldb : k0), sBp(buf), dma_dummy, dwave, i);
   };
+  if constexpr (NL > 0) {
+    if (wave >= NW) {                                          // ---- loader wave
+      const int kb = blockIdx.y * g.kchunk;
+      const int nkl = (min(g.K, kb + g.kchunk) - kb) / BK;     // >= 2 (launcher)
+      constexpr int NPT = GldsPlan<FBM, A_TR, NWD>::PER_WAVE + GldsPlan<FBN, B_TR, NWD>::PER_WAVE;   // requests per tile and wave, no-ops included
+      stage(0, kb);
+      stage(1, kb + BK);
+      int slot = 2;
+      for (int kt = 0; kt < nkl; ++kt) {
+        if (kt + 1 < nkl) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nkl) stage(slot, kb + (kt + 2) * BK);
+        slot = slot == 2 ? 0 : slot + 1;
+      }
+      if constexpr (EPI == EPI_DGELU) {                        // the consumers' column-partial reduction meets at two more barriers
+        if (g.colpart) { __syncthreads(); __syncthreads(); }
+      }
+      return;
+    }
+  }
 
   // per-lane LDS byte addresses of the fragments of buffer 0, k-step 0 (other buffer / k-step: + constant)
   unsigned adA[MT][A_TR ? 2 : 1], adB[NT][B_TR ? 2 : 1];
@@ -841,11 +883,54 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
   const int nk = (min(g.K, kbeg + g.kchunk) - kbeg) / BK;
   if constexpr (EPI == EPI_F32) g.Cf += (size_t)blockIdx.y * g.split_stride;
   Frags f0, f1;
-  stage(0, kbeg);
-  if constexpr (NS == 3) stage(1, kbeg + BK);              // three slots: two tiles in flight (nk >= 2 guaranteed by the launcher)
-  if constexpr (SCHED >= 1) {
+  if constexpr (NL == 0) {
+    stage(0, kbeg);
+    if constexpr (NS == 3) stage(1, kbeg + BK);            // three slots: two tiles in flight (nk >= 2 guaranteed by the launcher)
+  }
+  if constexpr (NL > 0 && NL_SIMPLE) {
+    // ---- consumer of the loader form, compiler-scheduled: a consumer has no vector-memory operation in flight, so plain LDS loads
+    // carry no vmcnt drain (the reason the other schedules read through inline asm) and hipcc places the waits; the two consumers
+    // of a SIMD hide each other's LDS latency.  Same products in the same order as every other schedule.
+    const int gq = lane >> 4, li = lane & 15, q4 = li >> 2, pp = li & 3;
+    auto ld_frag = [&](const __bf16* img, auto trc, auto extc, int blk0, int ks) -> bf16x8 {
+      constexpr bool TR = decltype(trc)::value;
+      constexpr int EXT = decltype(extc)::value;
+      if constexpr (!TR) {
+        const int row = blk0 + li;
+        return *reinterpret_cast<const bf16x8*>(img + off_direct(row, ks * 4 + gq));
+      } else {
+        constexpr int P = tr_cols<EXT>();
+        const int ch = (blk0 >> 3) + (pp >> 1), r0 = 8 * gq + q4;
+        const int o0 = r0 * P + (swz_chunk<EXT>(r0, ch) << 3) + 4 * (pp & 1) + ks * 32 * P;
+        const int o1 = (r0 + 4) * P + (swz_chunk<EXT>(r0 + 4, ch) << 3) + 4 * (pp & 1) + ks * 32 * P;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + o0));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + o1));
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    };
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      __builtin_amdgcn_s_barrier();                          // tile kt is in LDS; this wave's reads of tile kt - 1 fed MFMAs already issued
+      const __bf16* iA = sAp(buf);
+      const __bf16* iB = sBp(buf);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 fa[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          fa[mt] = ld_frag(iA, std::integral_constant<bool, A_TR>{}, std::integral_constant<int, FBM>{}, wm * MT * 16 + mt * 16, ks);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const bf16x8 fb = ld_frag(iB, std::integral_constant<bool, B_TR>{}, std::integral_constant<int, FBN>{}, wn * NT * 16 + nt * 16, ks);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[mt], acc[mt][nt], 0, 0, 0);
+        }
+      }
+      buf = buf == 2 ? 0 : buf + 1;
+    }
+  } else if constexpr (SCHED >= 1) {
     constexpr int NM = MT * NT;
-    constexpr int NDA = GldsPlan<FBM, A_TR, NW>::PER_WAVE, NDB = GldsPlan<FBN, B_TR, NW>::PER_WAVE;
+    constexpr int NDA = NL > 0 ? 0 : GldsPlan<FBM, A_TR, NW>::PER_WAVE, NDB = NL > 0 ? 0 : GldsPlan<FBN, B_TR, NW>::PER_WAVE;
     constexpr int NRA = MT * (A_TR ? 2 : 1), NRB = NT * (B_TR ? 2 : 1);
     unsigned adA1[A_TR ? 1 : MT], adB1[B_TR ? 1 : NT];         // direct images: k-step 1 flips chunk bit 2
     if constexpr (!A_TR) static_for<MT>([&](auto i) { adA1[i] = adA[i][0] ^ 64u; });
@@ -860,8 +945,10 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
       constexpr int BUF = decltype(bufc)::value, KS = decltype(ksc)::value, r = decltype(rc)::value;
       if constexpr (r < NRA) {
         if constexpr (!A_TR) {
-          if constexpr (BUF * 2 * A_ELEMS > 65535) f.a[r] = asm_read_b128_off<BUF * 2 * A_ELEMS - 65536>(KS ? adA1h[r] : adAh[r]);
-          else f.a[r] = asm_read_b128_off<BUF * 2 * A_ELEMS>(KS ? adA1[r] : adA[r][0]);
+          // direct image: the 16-row blocks of a wave are 2,048 B apart and share the swizzle term ((row & 7) = (lane & 7)): ONE base
+          // register per k-step + immediates (was: one per block -- 2 (MT + NT) registers the loader form does not have)
+          if constexpr (BUF * 2 * A_ELEMS > 65535) f.a[r] = asm_read_b128_off<BUF * 2 * A_ELEMS - 65536 + r * 2048>(KS ? adA1h[0] : adAh[0]);
+          else f.a[r] = asm_read_b128_off<BUF * 2 * A_ELEMS + r * 2048>(KS ? adA1[0] : adA[0][0]);
         } else {
           constexpr int mt = r >> 1, h = r & 1;
           const bf16x4 t = asm_read_tr_off<BUF * 2 * A_ELEMS + KS * 64 * FBM_P>(adA[mt][h]);
@@ -870,10 +957,12 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
       } else {
         constexpr int q = r - NRA;
         if constexpr (!B_TR) {
-          f.b[q] = asm_read_b128_off<BUF * 2 * B_ELEMS>(KS ? adB1[q] : adB[q][0]);
+          f.b[q] = asm_read_b128_off<BUF * 2 * B_ELEMS + q * 2048>(KS ? adB1[0] : adB[0][0]);
         } else {
           constexpr int nt = q >> 1, h = q & 1;
-          const bf16x4 t = asm_read_tr_off<BUF * 2 * B_ELEMS + KS * 64 * FBN_P>(adB[nt][h]);
+          // 144-column image: the chunk shift is additive (swz_chunk), so n-tile nt is 32 B behind n-tile 0 -- two base registers, not 2 NT
+          constexpr bool AFF = FBN == 144 && WN == 1;
+          const bf16x4 t = asm_read_tr_off<BUF * 2 * B_ELEMS + KS * 64 * FBN_P + (AFF ? nt * 32 : 0)>(adB[AFF ? 0 : nt][h]);
           f.b[nt][4 * h] = t[0]; f.b[nt][4 * h + 1] = t[1]; f.b[nt][4 * h + 2] = t[2]; f.b[nt][4 * h + 3] = t[3];
         }
       }
@@ -906,7 +995,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
       constexpr int BUF = decltype(bufc)::value;
       constexpr bool FIRST = decltype(firstc)::value;
       // this wave's share of tile kt has landed
-      if constexpr (NS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (NL > 0) {}                                                 // (a consumer of the loader form has no vector-memory operation in flight)
+      else if constexpr (NS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDA + NDB) : "memory");   // the younger tile may still be in flight
                                                                                // (every wave issues NDA + NDB requests, no-ops included)
       __builtin_amdgcn_s_barrier();                           // everybody's has; the slot of tile kt-1 is free
@@ -998,6 +1088,15 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
   if constexpr (SCHED == 0) mfmas(f1);
 
   const int row_b = m0 + wm * MT * 16 + (lane & 15), col_b = n0 + wn * NT * 16 + 4 * (lane >> 4);
+  // loader form, forward layouts: the bias columns of this lane, all NT loads issued together now that the fragment registers are free
+  // (a load inside each store's `if (bias)` would be waited for one by one: NT x MT exposed L2 latencies per tile)
+  constexpr bool LATE_BIAS = !A_TR && !B_TR && NL > 0;
+  float4 bias_l[LATE_BIAS ? NT : 1];
+  if constexpr (LATE_BIAS) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      bias_l[nt] = g.bias ? *reinterpret_cast<const float4*>(g.bias + col_b + nt * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   if constexpr (BSUM) {
     if (do_bs && lane < 16) {                 // all four accumulator rows of a lane hold the same sum
 #pragma unroll
@@ -1067,6 +1166,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
         const int col = col_b + nt * 16;
         f32x4 v = acc[mt][nt] * g.alpha;
         if constexpr (PRE_BIAS) { const float4 b = bias_v[nt]; v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+        else if constexpr (LATE_BIAS) { const float4 b = bias_l[nt]; v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
         else if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
         bf16x4 a = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
         nt_store(reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col), a, g.nt_out & 1);
@@ -1080,7 +1180,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_pipe(GemmArgs g) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        epilogue_store<EPI>(g, row_b + mt * 16, col_b + nt * 16, acc[mt][nt], PRE_BIAS ? &bias_v[PRE_BIAS ? nt : 0] : nullptr);
+        epilogue_store<EPI>(g, row_b + mt * 16, col_b + nt * 16, acc[mt][nt],
+                            PRE_BIAS ? &bias_v[PRE_BIAS ? nt : 0] : LATE_BIAS ? &bias_l[LATE_BIAS ? nt : 0] : nullptr);
   }
 }
 
@@ -1127,29 +1228,44 @@ template __global__ void k_gemm_pipe<8, 1, 2, 9, false, false, 5, 2, 3>(GemmArgs
 template __global__ void k_gemm_pipe<8, 1, 2, 9, false, true, 0, 2, 3>(GemmArgs);   // dgrad into a 1152-wide input gradient
 template __global__ void k_gemm_pipe<8, 1, 2, 9, false, true, 1, 2, 3>(GemmArgs);
 template __global__ void k_gemm_pipe<8, 1, 2, 9, false, true, 4, 2, 3>(GemmArgs);
+// ... and with four loader waves
+template __global__ void k_gemm_pipe<8, 1, 2, 9, false, false, 0, 2, 3, false, 4>(GemmArgs);
+template __global__ void k_gemm_pipe<8, 1, 2, 9, false, false, 1, 2, 3, false, 4>(GemmArgs);
+template __global__ void k_gemm_pipe<8, 1, 2, 9, false, false, 2, 2, 3, false, 4>(GemmArgs);
+template __global__ void k_gemm_pipe<8, 1, 2, 9, false, false, 3, 2, 3, false, 4>(GemmArgs);
+template __global__ void k_gemm_pipe<8, 1, 2, 9, false, false, 5, 2, 3, false, 4>(GemmArgs);
+template __global__ void k_gemm_pipe<8, 1, 2, 9, false, true, 0, 2, 3, false, 4>(GemmArgs);
+template __global__ void k_gemm_pipe<8, 1, 2, 9, false, true, 1, 2, 3, false, 4>(GemmArgs);
+template __global__ void k_gemm_pipe<8, 1, 2, 9, false, true, 4, 2, 3, false, 4>(GemmArgs);
+template __global__ void k_gemm_pipe<4, 2, 3, 6, true, true, 0, 2, 2, false, 4>(GemmArgs);
+template __global__ void k_gemm_pipe<4, 2, 3, 6, true, true, 1, 2, 2, false, 4>(GemmArgs);
 
 namespace {
 
-template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI, int SCHED = 0, int PRO = 2, bool BSUM = false>
+template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI, int SCHED = 0, int PRO = 2, bool BSUM = false, int NL = 0>
 int launch_pipe(GemmArgs g, hipStream_t s) {
   constexpr int FBM = WM * MT * 16, FBN = WN * NT * 16;
   g.ntm = g.M / FBM; g.ntn = g.N / FBN;
+#ifdef SFRON_DEBUG_KNOBS
+  { static const int same = getenv("SFRON_GEMM_SAME_TILE") ? atoi(getenv("SFRON_GEMM_SAME_TILE")) : 0; g.dbg_same = same; }
+#endif
   {
     const double per_xcd = (double)g.ntm * g.ntn / 8.0;
     int gm = 1;
     while (gm * 2 <= g.ntm && (double)(gm * 2) * (gm * 2) * FBM <= per_xcd * FBN * 1.5) gm *= 2;
     g.group_m = gm;
   }
-  constexpr bool uneven = !GldsPlan<FBM, A_TR, WM * WN>::EVEN || !GldsPlan<FBN, B_TR, WM * WN>::EVEN;
+  constexpr int NWD = NL > 0 ? NL : WM * WN;
+  constexpr bool uneven = !GldsPlan<FBM, A_TR, NWD>::EVEN || !GldsPlan<FBN, B_TR, NWD>::EVEN;
   constexpr int FBM_P = A_TR ? tr_cols<FBM>() : FBM, FBN_P = B_TR ? tr_cols<FBN>() : FBN;
   const size_t lds = (SCHED == 2 ? 3 : 2) * (FBM_P + FBN_P) * 64 * sizeof(__bf16) + (uneven ? 1024 : 0);
   static std::atomic<uint64_t> done{0};        // per instantiation, one bit per device
   if (need_attr(done)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pipe<WM, WN, MT, NT, A_TR, B_TR, EPI, SCHED, PRO, BSUM>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pipe<WM, WN, MT, NT, A_TR, B_TR, EPI, SCHED, PRO, BSUM, NL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return (int)hipGetLastError();
   }
-  hipLaunchKernelGGL((k_gemm_pipe<WM, WN, MT, NT, A_TR, B_TR, EPI, SCHED, PRO, BSUM>), dim3(g.ntm * g.ntn, cdiv(g.K, g.kchunk)), dim3(WM * WN * 64), lds, s, g);
+  hipLaunchKernelGGL((k_gemm_pipe<WM, WN, MT, NT, A_TR, B_TR, EPI, SCHED, PRO, BSUM, NL>), dim3(g.ntm * g.ntn, cdiv(g.K, g.kchunk)), dim3((WM * WN + NL) * 64), lds, s, g);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
 }
@@ -1215,6 +1331,8 @@ inline int pick_fast_tile(const GemmArgs& g, int force, int transposed_operands)
   return (transposed_operands == 0 && tile_fits(g, 1)) ? 1 : 0;   // with transposed reads the generic kernel beats the 4-wave tile
 }
 
+int g_loader_waves = 4;      // process-wide: 4 = the three-slot tiles with a transposed operand run with four loader waves (k_gemm_pipe NL); sfron_gemm_loader_waves()
+
 template <bool A_TR, bool B_TR, int EPI>
 int launch_any(const GemmArgs& g, hipStream_t s, int force) {
   switch (pick_fast_tile(g, force, (A_TR ? 1 : 0) + (B_TR ? 1 : 0))) {
@@ -1240,7 +1358,10 @@ int launch_any(const GemmArgs& g, hipStream_t s, int force) {
     case 62:   // 256x144 with three LDS slots, forward layouts: needs nk = 3 + 3j tiles (K a multiple of 192), no split
       if constexpr ((!A_TR && !B_TR && (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_GELU || EPI == EPI_GATE_RES || EPI == EPI_POS)) ||
                     (!A_TR && B_TR && (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_DGELU))) {
-        if (g.kchunk == g.K && g.K % 192 == 0) return launch_pipe<8, 1, 2, 9, A_TR, B_TR, EPI, 2, 3>(g, s);
+        if (g.kchunk == g.K && g.K % 192 == 0)
+          // loader waves: measured faster where an operand is read transposed (dgrad: qkv 68 -> 57 us, proj 28.4 -> 26.1, fc1 76.9 -> 72.6), slower
+          // or equal on the forward layouts (qkv 76 -> 83)
+          return ((g_loader_waves == 4 || g_loader_waves == 6) && B_TR) ? launch_pipe<8, 1, 2, 9, A_TR, B_TR, EPI, 2, 3, false, 4>(g, s) : launch_pipe<8, 1, 2, 9, A_TR, B_TR, EPI, 2, 3>(g, s);
       }
       if (!tile_fits(g, 2)) return launch<A_TR, B_TR, EPI>(g, s);
       return g.K % 128 == 0 && g.kchunk == g.K ? launch_pipe<4, 2, 4, 6, A_TR, B_TR, EPI, 1>(g, s) : launch_pipe<4, 2, 4, 6, A_TR, B_TR, EPI>(g, s);
@@ -1249,7 +1370,10 @@ int launch_any(const GemmArgs& g, hipStream_t s, int force) {
         if (g.bsum) return rowsum_ok(g.M, g.N, g.K) && g.kchunk == g.K ? launch_pipe<4, 2, 3, 6, true, true, EPI_F32, 2, 2, true>(g, s) : SFRON_ERR_UNSUPPORTED;
       }
       if constexpr ((A_TR && B_TR && (EPI == EPI_BF16 || EPI == EPI_F32)) || (!A_TR && !B_TR && EPI == EPI_BF16)) {
-        if (g.K % g.kchunk == 0 && (g.kchunk / 64) >= 2 && ((g.kchunk / 64) - 2) % 3 == 0) return launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI, 2>(g, s);
+        if (g.K % g.kchunk == 0 && (g.kchunk / 64) >= 2 && ((g.kchunk / 64) - 2) % 3 == 0) {
+          if constexpr (A_TR && B_TR) { if (g_loader_waves == 4 || g_loader_waves == 5) return launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI, 2, 2, false, 4>(g, s); }
+          return launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI, 2>(g, s);
+        }
       }
       return (g.kchunk % 128 == 0 && g.K % g.kchunk == 0) ? launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI, 1>(g, s)
                                                            : launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI>(g, s);
@@ -1282,7 +1406,10 @@ extern "C" int sfron_gemm_dgelu_colpart_rows(int M, int N, int K) {
   return 0;
 }
 
-extern "C" int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
+extern "C" // test / A-B hook: 4 = loader-wave form of the three-slot tiles (0 = every wave issues its share of the LDS-DMA); returns the old value
+int sfron_gemm_loader_waves(int n) { const int old = g_loader_waves; g_loader_waves = (n >= 4 && n <= 6) ? n : 0; return old; }   // (5 / 6: weight gradients / dgrad only, A-B runs)
+
+int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
   SFRON_CHECK_ARG(d && d->A && d->B && d->M > 0 && d->N > 0 && d->K > 0);
   SFRON_CHECK_ARG(d->N % 4 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0);
   if (!d->a_transposed || !d->b_transposed) SFRON_CHECK_ARG(d->K % 8 == 0);   // k-contiguous operands are staged in 8-element chunks
