@@ -305,7 +305,8 @@ def main():
             "step_frac_of_bf16_mfma_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
             "dp_overlap": dp_overlap, "check": check_res,
             "roofline": {"bound": "mfma",
-                         "kernel": "k_gemm_pipe<4,2,3,6,true,true,1,2,2> = 192x192 tile, three LDS slots, interleaved MFMA/LDS-DMA schedule: the weight "
+                         "kernel": "k_gemm_pipe<4,2,3,6,true,true,1,2,2,false,4> = 192x192 tile, three LDS slots, eight multiplying waves + four loader waves "
+                                   "that issue the LDS-DMA: the weight "
                                    f"gradients dW = dY^T X of a block (qkv [{3 * D}x{D}], proj [{D}x{D}], fc1 [{F}x{D}], fc2 [{D}x{F}], contraction over "
                                    f"{M} token rows; mean {wg_flops / 1e9:.1f} GFLOP per launch); largest share of GPU time (profiles/r03_kernel_table.md); "
                                    "it runs on the weight-gradient stream BESIDE the dgrad chain, so its duration is shared-CU time",

@@ -24,7 +24,7 @@ MFMA_PEAK, HBM_PEAK = 2.5e15, 8.0e12
 # (regex on the kernel name, class label, bound, work per launch [FLOP or bytes], note)
 RULES = [
     (r"k_gemm_pipe<4, 2, 3, 6, true, true, 1, 2, 2, true>", "wgrad qkv/fc1 + bias row sums (192x192, 3 slots)", "mfma", (QKV + FC1) / 2, "mean of qkv 65.2 / fc1 87.0 GFLOP"),
-    (r"k_gemm_pipe<4, 2, 3, 6, true, true, 1, 2, 2(, false)?>", "wgrad qkv/proj/fc1/fc2 (192x192, 3 slots)", "mfma", None, "mean of 65.2 / 21.7 / 87.0 / 87.0 GFLOP"),
+    (r"k_gemm_pipe<4, 2, 3, 6, true, true, 1, 2, 2(, false)?(, \d)?>", "wgrad qkv/proj/fc1/fc2 (192x192, 3 slots, loader waves)", "mfma", None, "mean of 65.2 / 21.7 / 87.0 / 87.0 GFLOP"),
     (r"k_gemm_pipe<8, 1, 2, 9, false, true, 0, 2, 3", "dgrad qkv/proj/fc1 -> 1152 wide (256x144)", "mfma", (QKV + PROJ + FC1) / 3, "mean of 65.2 / 21.7 / 87.0"),
     (r"k_gemm_pipe<4, 2, 4, 6, false, true, 4, 1, 2", "dgrad fc2 + GELU' (256x192)", "mfma", FC2, ""),
     (r"k_gemm_pipe<4, 2, 4, 6, false, false, 2, 1, 2", "fwd fc1 + GELU (256x192)", "mfma", FC1, ""),
@@ -40,9 +40,9 @@ RULES = [
     (r"k_sumsq_lowrank", "masked sum of squares of the rank-(batch) adaLN gradient", "hbm", 1.0 * NADA, "mask byte only; 32 FMA per element"),
     (r"k_sumsq_masked", "masked sum of squares (clip norm), flat ranges", "hbm", None, "g fp32 + mask byte"),
     (r"k_gemm8", "fp8 (e4m3) forward GEMM (config 5)", "mfma", None, ""),
-    (r"k_row_bwd<true, true>", "LN backward + gate backward (fused)", "hbm", 170e6, "DESIGN.md section 4"),
-    (r"k_row_bwd<true, false>", "LN backward", "hbm", 113e6, ""),
-    (r"k_row_bwd<false, true>", "gate backward", "hbm", 94e6, ""),
+    (r"k_row_bwd<true, true(, \w+)?>", "LN backward + gate backward (fused)", "hbm", 170e6, "DESIGN.md section 4"),
+    (r"k_row_bwd<true, false(, \w+)?>", "LN backward", "hbm", 113e6, ""),
+    (r"k_row_bwd<false, true(, \w+)?>", "gate backward", "hbm", 94e6, ""),
     (r"k_ln_mod_fwd", "LayerNorm + modulate forward", "hbm", 56.6e6, "x fp32 in, bf16 out"),
     (r"k_colsum_partial", "column sums (bias gradients)", "hbm", None, "round 1: 75 MB (fc1) / 57 MB (qkv) per launch"),
     (r"k_ema", "EMA of frozen parameters", "hbm", None, ""),
