@@ -354,9 +354,9 @@ __global__ __launch_bounds__(512) void k_gemm4l(const __bf16* __restrict__ A, co
 
 // ---- eight CONSUMER waves (32 x (NT_*16) each, compiler-scheduled as the plain k_gemm<8,1,2,NT_>) + four LOADER waves: three waves per SIMD
 // (<= 168 registers), the two consumers of a SIMD hide each other's LDS latency, the loader of the SIMD issues a quarter of the DMA pieces
-template <int NT_, int MODE = 0, int NWL = 4>
+template <int NT_, int MODE = 0, int NWL = 4, int WN = 1>
 __global__ __launch_bounds__(512 + 64 * NWL) void k_gemm8l(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* __restrict__ C, int M, int N, int K) {
-  constexpr int MT = 2, NS = 3, FBN = NT_ * 16, A_EL = FBM * BK, B_EL = FBN * BK, SLOT = A_EL + B_EL;
+  constexpr int WM = 8 / WN, MT = FBM / 16 / WM, NS = 3, FBN = WN * NT_ * 16, A_EL = FBM * BK, B_EL = FBN * BK, SLOT = A_EL + B_EL;   // NT_ = n-tiles per wave
   constexpr int NA = FBM * 8 / 64 / NWL, NB_TOT = FBN * 8 / 64, NB = (NB_TOT + NWL - 1) / NWL;
   extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(512 + 64 * NWL) void k_gemm8l(const __bf16* __restr
     }
     return;
   }
-  const int wm = wave12;
+  const int wm = wave12 / WN, wn = wave12 % WN;
   f32x4 acc[MT][NT_];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(512 + 64 * NWL) void k_gemm8l(const __bf16* __restr
       for (int mt = 0; mt < MT; ++mt) fa[mt] = frag(iA, wm * MT * 16 + mt * 16 + fr, ks * 4 + fg);
 #pragma unroll
       for (int nt = 0; nt < NT_; ++nt) {
-        const bf16x8 fb = frag(iB, nt * 16 + fr, ks * 4 + fg);
+        const bf16x8 fb = frag(iB, wn * NT_ * 16 + nt * 16 + fr, ks * 4 + fg);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[mt], acc[mt][nt], 0, 0, 0);
       }
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(512 + 64 * NWL) void k_gemm8l(const __bf16* __restr
 #pragma unroll
     for (int nt = 0; nt < NT_; ++nt) {
       const f32x4 v = acc[mt][nt];
-      *reinterpret_cast<bf16x4*>(C + (size_t)row * N + n0 + nt * 16 + 4 * fg) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+      *reinterpret_cast<bf16x4*>(C + (size_t)row * N + n0 + wn * NT_ * 16 + nt * 16 + 4 * fg) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
     }
   }
 }
@@ -562,13 +562,13 @@ void run4(const char* name, int M, int N, int K) {
   hipFree(dA); hipFree(dB); hipFree(dC);
 }
 
-template <int NT_, int FORM, int MODE = 0, int NWL = 4>
+template <int NT_, int FORM, int MODE = 0, int NWL = 4, int WN = 1>
 void run4l(const char* name, int M, int N, int K) {
-  constexpr int FBN = NT_ * 16;
+  constexpr int FBN = WN * NT_ * 16;
   const size_t lds = (size_t)3 * (FBM + FBN) * BK * 2 + 1024;
   if (N % FBN || lds > 160 * 1024) return;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm4l<NT_, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8l<NT_, MODE, NWL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8l<NT_, MODE, NWL, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   std::vector<uint16_t> hA((size_t)M * K), hB((size_t)N * K);
   uint32_t st = 31337u + N + K;
   auto rnd = [&]() { st = st * 1664525u + 1013904223u; return st >> 8; };
@@ -580,7 +580,7 @@ void run4l(const char* name, int M, int N, int K) {
   const dim3 grid((M / FBM) * (N / FBN));
   auto launch = [&]() {
     if (FORM == 4) hipLaunchKernelGGL((k_gemm4l<NT_, MODE>), grid, dim3(512), lds, 0, dA, dB, dC, M, N, K);
-    else hipLaunchKernelGGL((k_gemm8l<NT_, MODE, NWL>), grid, dim3(512 + 64 * NWL), lds, 0, dA, dB, dC, M, N, K);
+    else hipLaunchKernelGGL((k_gemm8l<NT_, MODE, NWL, WN>), grid, dim3(512 + 64 * NWL), lds, 0, dA, dB, dC, M, N, K);
   };
   hipMemset(dC, 0xff, (size_t)M * N * 2);
   launch(); hipDeviceSynchronize();
@@ -600,18 +600,30 @@ void run4l(const char* name, int M, int N, int K) {
   for (int i = 0; i < reps; ++i) launch();
   hipEventRecord(e1); hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
-  printf("%-16s tile 256x%-3d %d consumer waves + %d loader waves (mode %d: 1 = DMA only, 2 = compute only), 3 slots grid %4d: %7.1f us  %7.1f TFLOP/s   exact-integer check: %d / 6000 wrong\n", name, FBN,
-         FORM, NWL, MODE, (int)grid.x, ms * 1e3, 2.0 * M * N * K / ms / 1e9, bad);
+  printf("%-16s tile 256x%-3d %d consumer waves (%d x %d) + %d loader waves (mode %d: 1 = DMA only, 2 = compute only), 3 slots grid %4d: %7.1f us  %7.1f TFLOP/s   exact-integer check: %d / 6000 wrong\n", name, FBN,
+         FORM, 8 / WN, WN, NWL, MODE, (int)grid.x, ms * 1e3, 2.0 * M * N * K / ms / 1e9, bad);
   hipFree(dA); hipFree(dB); hipFree(dC);
 }
 
 int main() {
   const int M = 8192;
+  // (A) the block GEMMs of DiT-XL/2: shared-wave forms (plain / persistent), loader-wave forms and their floors (mode 1 = loaders only,
+  //     mode 2 = consumers only), 2 / 4 / 8 loader waves, four hand-pipelined consumer waves at 256 x 128
   struct Shape { const char* name; int N, K; } shapes[] = {{"qkv  1152->3456", 3456, 1152}, {"proj 1152->1152", 1152, 1152},
                                                            {"fc1  1152->4608", 4608, 1152}, {"fc2  4608->1152", 1152, 4608}};
   for (const Shape& s : shapes) {
     run<8, 1, 2, 9>(s.name, M, s.N, s.K);
-    run4l<8, 8>(s.name, M, s.N, s.K); run4l<8, 8, 1>(s.name, M, s.N, s.K); run4l<8, 8, 2>(s.name, M, s.N, s.K); run4l<8, 4>(s.name, M, s.N, s.K); run4l<8, 4, 1>(s.name, M, s.N, s.K); run4l<8, 4, 2>(s.name, M, s.N, s.K);
+    run4<9, 3>(s.name, M, s.N, s.K);
+    run4l<9, 8>(s.name, M, s.N, s.K); run4l<9, 8, 1>(s.name, M, s.N, s.K); run4l<9, 8, 2>(s.name, M, s.N, s.K);
+    run4l<9, 8, 0, 2>(s.name, M, s.N, s.K); run4l<9, 8, 0, 8>(s.name, M, s.N, s.K);
+    run4l<8, 4>(s.name, M, s.N, s.K); run4l<8, 4, 2>(s.name, M, s.N, s.K);
+  }
+  // (B) wave layout of the consumers, 256 x 160 (N a multiple of 160): 8 x 1 waves of 32 x 160 against 4 x 2 of 64 x 80 (3/4 of the LDS reads)
+  Shape shapes160[] = {{"qkv-like 1152->3520", 3520, 1152}, {"proj-like 1152->1280", 1280, 1152}, {"fc2-like 4608->1280", 1280, 4608}};
+  for (const Shape& s : shapes160) {
+    run<8, 1, 2, 10>(s.name, M, s.N, s.K); run<4, 2, 4, 5>(s.name, M, s.N, s.K);
+    run4l<10, 8, 0, 4, 1>(s.name, M, s.N, s.K); run4l<5, 8, 0, 4, 2>(s.name, M, s.N, s.K);
+    run4l<10, 8, 2, 4, 1>(s.name, M, s.N, s.K); run4l<5, 8, 2, 4, 2>(s.name, M, s.N, s.K);
   }
   return 0;
 }
