@@ -122,6 +122,42 @@ def test_wgrad_gemms_at_baseline_shapes(name, N, K, rowsum):
         assert torch.equal(dW, dW2)
 
 
+@pytest.mark.parametrize("M", [8192, 1024])
+def test_loader_wave_gemms_are_bit_identical_to_the_shared_wave_form(M):
+    """The three-slot tiles of the dgrad / weight-gradient layouts run with four loader waves by default (csrc/gemm.hip k_gemm_pipe NL:
+    the multiplying waves issue no LDS-DMA).  Same products in the same order: every output bit equals the shared-wave form's."""
+    from sfron import ops, _lib
+    D, F_ = 1152, 4608
+    g = torch.Generator(device=DEV).manual_seed(M)
+    rnd = lambda *sh: torch.randn(*sh, device=DEV, generator=g).to(torch.bfloat16)
+    cases = []
+    for N, K in ((3 * D, D), (D, D), (F_, D)):                # dgrad: dX[M, K] = dY[M, N] W[N, K]
+        dY, W = rnd(M, N), rnd(N, K)
+        def run(dY=dY, W=W, N=N, K=K):
+            C = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
+            ops.gemm(dY, W, M, K, N, b_t=True, c_bf16=C)
+            return C
+        cases.append(run)
+    for N, K in ((3 * D, D), (D, D), (F_, D), (D, F_)):       # weight gradient: dW[N, K] = dY[M, N]^T X[M, K]
+        dY, X = rnd(M, N), rnd(M, K)
+        def run(dY=dY, X=X, N=N, K=K):
+            C = torch.empty(N, K, dtype=torch.float32, device=DEV)
+            ops.gemm(dY, X, N, K, M, a_t=True, b_t=True, epilogue=_lib.EPI_F32, c_f32=C)
+            return C
+        cases.append(run)
+    L = _lib.lib()
+    old = L.sfron_gemm_loader_waves(0)
+    try:
+        assert old == 4                                        # the default
+        ref = [run() for run in cases]
+        L.sfron_gemm_loader_waves(4)
+        out = [run() for run in cases]
+    finally:
+        L.sfron_gemm_loader_waves(old)
+    for a, b in zip(ref, out):
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+
+
 def test_rowsum_small_shapes_and_rejections():
     from sfron import ops, _lib
     L = _lib.lib()

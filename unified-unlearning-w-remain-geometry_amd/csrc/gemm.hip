@@ -1238,6 +1238,7 @@ template __global__ void k_gemm_pipe<8, 1, 2, 9, false, true, 0, 2, 3, false, 4>
 template __global__ void k_gemm_pipe<8, 1, 2, 9, false, true, 1, 2, 3, false, 4>(GemmArgs);
 template __global__ void k_gemm_pipe<8, 1, 2, 9, false, true, 4, 2, 3, false, 4>(GemmArgs);
 template __global__ void k_gemm_pipe<4, 2, 3, 6, true, true, 0, 2, 2, false, 4>(GemmArgs);
+template __global__ void k_gemm_pipe<4, 2, 3, 6, false, false, 0, 2, 2, false, 4>(GemmArgs);   // (experiment: forward layout on the 4 x 2 tile)
 template __global__ void k_gemm_pipe<4, 2, 3, 6, true, true, 1, 2, 2, false, 4>(GemmArgs);
 
 namespace {
@@ -1372,6 +1373,7 @@ int launch_any(const GemmArgs& g, hipStream_t s, int force) {
       if constexpr ((A_TR && B_TR && (EPI == EPI_BF16 || EPI == EPI_F32)) || (!A_TR && !B_TR && EPI == EPI_BF16)) {
         if (g.K % g.kchunk == 0 && (g.kchunk / 64) >= 2 && ((g.kchunk / 64) - 2) % 3 == 0) {
           if constexpr (A_TR && B_TR) { if (g_loader_waves == 4 || g_loader_waves == 5) return launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI, 2, 2, false, 4>(g, s); }
+          if constexpr (!A_TR && !B_TR && EPI == EPI_BF16) { if (g_loader_waves == 7) return launch_pipe<4, 2, 3, 6, false, false, EPI_BF16, 2, 2, false, 4>(g, s); }   // (experiment)
           return launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI, 2>(g, s);
         }
       }
@@ -1407,7 +1409,7 @@ extern "C" int sfron_gemm_dgelu_colpart_rows(int M, int N, int K) {
 }
 
 extern "C" // test / A-B hook: 4 = loader-wave form of the three-slot tiles (0 = every wave issues its share of the LDS-DMA); returns the old value
-int sfron_gemm_loader_waves(int n) { const int old = g_loader_waves; g_loader_waves = (n >= 4 && n <= 6) ? n : 0; return old; }   // (5 / 6: weight gradients / dgrad only, A-B runs)
+int sfron_gemm_loader_waves(int n) { const int old = g_loader_waves; g_loader_waves = (n >= 4 && n <= 7) ? n : 0; return old; }   // (5 / 6: weight gradients / dgrad only, A-B runs)
 
 int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
   SFRON_CHECK_ARG(d && d->A && d->B && d->M > 0 && d->N > 0 && d->K > 0);
