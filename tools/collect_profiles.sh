@@ -15,6 +15,8 @@ rm -rf $OUT/stats
 python3 $ROOT/tools/pmc_traffic.py $OUT/pmc $TAG > $OUT/pmc_traffic.log 2>&1 || tail -5 $OUT/pmc_traffic.log
 cp $OUT/pmc/${TAG}_*traffic*.json $OUT/pmc/${TAG}_pmc_hbm_traffic_per_kernel.csv $OUT/ 2>/dev/null || true
 rm -rf $OUT/pmc
+# the bench lines below report `traffic` only from profiles/*_traffic.json of the SAME sources: put this run's there (on this box's copy)
+cp $OUT/${TAG}_*traffic*.json $ROOT/profiles/ 2>/dev/null || true
 # (2b) kernel stats of the fp8 run (config 5)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats8 -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --fp8 > /dev/null 2>&1 || true
 S8=$(ls $OUT/stats8/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$S8" ] && cp $S8 $OUT/${TAG}_fp8_bench_kernel_stats.csv; rm -rf $OUT/stats8
