@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: keep the synchronous bucketed all-reduce")
     ap.add_argument("--no-sweep-beside", action="store_true", help="A-B knob: forget-stage AdamW of the blocks on the main stream")
     ap.add_argument("--no-factored-ada", action="store_true", help="A-B knob: form the adaLN weight gradient by a GEMM + flat sweep")
+    ap.add_argument("--no-sweep-across-steps", action="store_true",
+                    help="A-B knob: the remain-stage AdamW + EMA of the blocks finishes inside its step instead of beside the next step's forward pass")
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE config 5: the four block GEMMs of every FORWARD pass on the fp8 (e4m3) matrix core, e4m3 weight shadow "
                          "re-quantised after each optimizer step; backward GEMMs stay bf16")
@@ -172,6 +174,9 @@ def main():
         runner.factored_ada = False
     if args.no_sweep_beside:
         runner.sweep_beside_forward = False
+    # steps run back to back here, as in the reference's training loop (forget.py:256-336 logs every N steps): the remain-stage sweep of
+    # the blocks overlaps the next step's forward pass; the timed region ends with torch.cuda.synchronize(), i.e. behind the last sweep
+    runner.sweep_across_steps = not args.no_sweep_across_steps and not args.no_sweep_beside
     if os.environ.get("SFRON_BENCH_LOADER_WAVES"):          # A-B knob (tools only): form of the three-slot GEMM tiles, 0 or 4
         from sfron import _lib
         _lib.lib().sfron_gemm_loader_waves(int(os.environ["SFRON_BENCH_LOADER_WAVES"]))
@@ -299,7 +304,11 @@ def main():
             "config": {"workload": f"{args.model} {args.image_size}px SFR-on step (forget+remain fwd/bwd, masked clipped AdamW x2, EMA), "
                                    f"batch {args.batch}/GPU, random-init weights (zero-init tensors re-drawn N(0,0.02)), 50% synthetic mask"
                                    + (" -- BASELINE config 5 (fp8 forward)" if args.fp8 else ""),
-                       "global_batch": gb, "tokens": T, "parallelism": f"dp{world}"},
+                       "global_batch": gb, "tokens": T, "parallelism": f"dp{world}",
+                       "schedule": {"forget_sweep_beside_remain_forward": bool(runner.sweep_beside_forward),
+                                    "remain_sweep_beside_next_forget_forward": bool(runner.sweep_across_steps and runner.sweep_beside_forward
+                                                                                    and world == 1 and not args.fp8),
+                                    "note": "every sweep is inside the timed region (it ends with torch.cuda.synchronize())"}},
             "finite_losses": loss_ok,
             "step_tflops_per_gpu": step_flops / (ms_per_step * 1e-3) / 1e12,
             "step_frac_of_bf16_mfma_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,

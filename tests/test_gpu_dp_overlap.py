@@ -125,3 +125,41 @@ def test_pipelined_synchronous_exchange_matches_plain_path():
     assert torch.allclose(s1, s0, rtol=1e-5)
     assert (p1 - p0).abs().max().item() <= 1e-6 and (e1 - e0).abs().max().item() <= 1e-6
     assert (g1 - g0).abs().max().item() <= 1e-6 * g0.abs().max().item()
+
+
+def test_remain_sweep_beside_the_next_step_gives_the_same_state():
+    """sweep_across_steps: the remain-stage AdamW + EMA of the block ranges runs on the sweep stream beside the NEXT step's forget
+    forward pass (which waits block by block); step() returns with it in flight.  Same kernels on the same operands: parameters,
+    moments, EMA and the bf16 shadow after four steps equal the in-step form bit for bit; the runner's accessors (checkpoint) order
+    themselves behind the sweep."""
+    from sfron import data, diffusion, step
+    from test_gpu_dit import CASES, build_pair
+    cfg = CASES["hd72"]
+    B = 4
+    kw = dict(global_batch=B, num_classes=cfg["num_classes"], forget_class=3, input_size=cfg["input_size"], device=DEV)
+    bat = lambda it: (data.synthetic_batch(6, it, "forget", **kw), data.synthetic_batch(6, it, "remain", **kw))
+    hp = dict(lr=2e-4, forget_alpha=0.3, grad_clip=1.0, ema_decay=0.99, mask=None, unlearn_loss="ga", forget_class=3)
+
+    def run(across):
+        _, model = build_pair(cfg, B, seed=29)
+        runner = step.DiTSFRon(model, diffusion.create_diffusion(""), **hp)
+        assert runner.sweep_across_steps is False          # opt-in
+        runner.sweep_across_steps = across
+        for it in range(4):
+            runner.step(*bat(it))
+        if across:
+            assert runner._ready_next is not None and model.engine._sweep_pending is not None
+        ck = runner.checkpoint()                           # drains the sweep before it reads
+        assert getattr(model.engine, "_sweep_pending", None) is None
+        torch.cuda.synchronize()
+        runner.guard.poll(block=True)
+        eng = model.engine
+        return (eng.params.clone(), runner.opt.m.clone(), runner.opt.v.clone(), runner.ema.clone(), eng.params_bf16.clone(), ck)
+
+    a, b = run(False), run(True)
+    for x, y in zip(a[:5], b[:5]):
+        assert torch.equal(x, y)
+    for k in a[5]["model"]:
+        assert torch.equal(a[5]["model"][k], b[5]["model"][k])
+    for k in a[5]["ema"]:
+        assert torch.equal(a[5]["ema"][k], b[5]["ema"][k])

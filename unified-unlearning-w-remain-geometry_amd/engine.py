@@ -213,12 +213,22 @@ class DitEngine:
                             stream=st, events=evs, handles=(ctypes.c_void_p * L)(*[e.cuda_event for e in evs]))
         return self._bs
 
+    def drain_sweep(self):
+        """The runner leaves the remain-stage AdamW of the block ranges in flight on the sweep stream when step() returns (the next
+        step's forward pass waits block by block); every OTHER reader of the parameters / optimizer state goes through here first."""
+        st = getattr(self, "_sweep_pending", None)
+        if st is not None:
+            torch.cuda.current_stream().wait_stream(st)
+            self._sweep_pending = None
+
     def forward(self, x_t, t, y, drop=None, out=None, block_ready=None):
         """block_ready: ctypes array of depth hipEvent_t handles -- block l waits for entry l before it touches its weights."""
         if out is None:
             out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
         if x_t.shape[0] != self.cfg.batch:
             raise _lib.SfronError(f"engine was built for batch {self.cfg.batch}, got {x_t.shape[0]}")
+        if block_ready is None:
+            self.drain_sweep()                 # a block sweep may still be rewriting the weights on its own stream (step.py)
         if block_ready is not None and self.fp8 is None:
             check(_lib.lib().sfron_dit_forward_after(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(x_t), ptr(t), ptr(y),
                                                      ptr(drop), ptr(self.workspace), ptr(out), block_ready, self.probe, stream_ptr()),

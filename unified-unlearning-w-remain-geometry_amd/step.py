@@ -61,6 +61,10 @@ class DiTSFRon:
         self._pipeline = None
         self.sweep_beside_forward = True
         self.sweep_beside_wg, self.sweep_beside_head = 256, 2
+        # opt-in: the remain-stage sweep of the block ranges runs beside the NEXT step's forget forward pass; step() then returns with it in
+        # flight -- read parameters / optimizer state through this runner (state_dict / checkpoint / sync()), not from the raw arenas
+        self.sweep_across_steps = False
+        self._ready_next = None                # block events of that sweep, consumed by the next step()'s first forward pass
         self.fp8 = bool(fp8)
         if self.fp8 and model.engine.fp8 is None:
             model.engine.enable_fp8()
@@ -383,7 +387,10 @@ class DiTSFRon:
         if self.method == "joint":
             return self._step_joint(forget, remain, y_f, sign)
         dp_sync = self._dp_active() and not self._overlap_enabled() and self.micro == 1
-        mse_f, vb_f = self._pass(forget, y_f, sign * self.forget_alpha, factored_ada=True, async_exchange=dp_sync)
+        ready, self._ready_next = self._ready_next, None
+        if ready is not None:
+            eng._sweep_pending = None          # this forward pass waits for the sweep block by block; its backward pass starts behind all of it
+        mse_f, vb_f = self._pass(forget, y_f, sign * self.forget_alpha, factored_ada=True, block_ready=ready, async_exchange=dp_sync)
         # The forget-stage AdamW of the 28 block ranges runs on a second stream, on a bounded grid, BESIDE the remain forward pass,
         # which waits for block l's event when it reaches block l; embedders / adaLN / final layer (needed at once) stay on this
         # stream.  Measured (tools/bench_sweep_beside.py): a full-grid sweep beside the GEMM chain gains nothing, one capped at
@@ -409,8 +416,19 @@ class DiTSFRon:
         pipe, self._pipeline = self._pipeline, None
         nt = eng.n_trainable
         self._fp8_before_sweep(fused_q)
+        # The remain-stage sweep of the block ranges goes the same way, beside the forget forward pass of the NEXT step() (same stream,
+        # same events: the remain forward pass above has consumed them).  step() then returns with that sweep in flight: the next
+        # step's forward pass waits block by block, every other reader of the state drains it first (engine.drain_sweep).
+        across = beside and self.sweep_across_steps and not fused_q
+        if across:
+            split_r = dict(ranges=bs["ranges"], stream=bs["stream"], events=bs["events"], max_workgroups=self.sweep_beside_wg,
+                           head=self.sweep_beside_head)
+        else:
+            split_r = dict(ranges=bs["ranges"], stream=None, quant=quant) if fused_q else None
         self.opt.step(max_norm=None, use_mask=False, ema=self.ema[:nt], ema_decay=self.ema_decay, ema_mode=1,   # :320,322
-                      split=dict(ranges=bs["ranges"], stream=None, quant=quant) if fused_q else None, pipeline=pipe)
+                      split=split_r, pipeline=pipe)
+        if across:
+            self._ready_next, eng._sweep_pending = bs["handles"], bs["stream"]
         if self.fp8 and not fused_q:
             self.model.engine.fp8_requantize()
         if eng.n_total > nt:
@@ -424,14 +442,21 @@ class DiTSFRon:
                 "forget_sign": sign, "stats": self.opt.stats}
 
     def ema_state_dict(self):
+        self.sync_sweep()
         eng = self.model.engine
         return {name: eng.view(self.ema, name).clone() for name in eng.index}
+
+    def sync_sweep(self):
+        """Order the current stream behind a block sweep that step() left in flight (sweep_across_steps)."""
+        self.model.engine.drain_sweep()
+        self._ready_next = None
 
     # ------------------------------------------------------------------ checkpoint (DiT/forget.py:346-353 format)
     def opt_state_dict(self):
         """The shared AdamW state in torch.optim's state_dict layout over ``model.parameters()`` (forget.py:199): entries
         only for parameters that received gradients (pos_embed has none), so the reference's
         ``torch.optim.AdamW(model.parameters(), ...).load_state_dict(ckpt["opt"])`` accepts it."""
+        self.sync_sweep()
         eng = self.model.engine
         names = [n for n, _ in self.model.named_parameters()]
         state = {}
@@ -450,12 +475,14 @@ class DiTSFRon:
         saves ``model.state_dict()`` of its nn.DataParallel wrapper (forget.py:193,347), whose keys carry a "module."
         prefix; ``data_parallel_prefix=True`` writes them that way ("ema" is the unwrapped copy there too: no prefix)."""
         pre = "module." if data_parallel_prefix else ""
+        self.sync_sweep()
         return {"model": {pre + k: v.clone() for k, v in self.model.state_dict().items()}, "ema": self.ema_state_dict(),
                 "opt": self.opt_state_dict(), "args": args}
 
     def load_checkpoint(self, ckpt):
         """Resume from a checkpoint in that format: ours, or one written by the reference, whose "model" keys carry the
         nn.DataParallel "module." prefix (DiT.load_state_dict strips it)."""
+        self.sync_sweep()
         eng = self.model.engine
         self.model.load_state_dict(ckpt["model"])
         for name, v in ckpt["ema"].items():
