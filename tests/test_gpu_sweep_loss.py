@@ -145,7 +145,7 @@ def test_ddpm_ema_and_fisher(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("R,NM,D", [(4, 64, 128), (32, 16 * 13, 1152), (3, 48, 36)])
+@pytest.mark.parametrize("R,NM,D", [(4, 64, 128), (32, 16 * 13, 1152), (3, 48, 36), (32, 256, 1152), (5, 128, 256), (40, 384, 128)])
 def test_lowrank_gradient_sweeps_vs_flat_kernels(R, NM, D):
     """sfron_sumsq_lowrank / sfron_adam_lowrank form dW = dmod^T sc (bf16 factors, fp32 accumulation) inside the sweep; against the
     flat kernels fed with the same product computed by torch in fp32 (mask, clip coefficient, AdamW, bf16 shadow, EMA)."""
@@ -165,7 +165,8 @@ def test_lowrank_gradient_sweeps_vs_flat_kernels(R, NM, D):
     stats_a, stats_b = torch.zeros(4, device=dev), torch.zeros(4, device=dev)
     nb = ctypes.c_int(0)
     check(L.sfron_sumsq_lowrank(ptr(dmod), ptr(sc), R, NM, D, ptr(mask), ptr(part), ctypes.byref(nb), stream_ptr()), "sumsq_lowrank")
-    assert nb.value == NM // 8
+    # one partial per 8 rows (vector kernel) or per 128 x 128 tile (matrix-core form, taken when both extents are multiples of 128)
+    assert nb.value == ((NM // 128) * (D // 128) if NM % 128 == 0 and D % 128 == 0 else NM // 8)
     check(L.sfron_clip_coef(ptr(part), nb.value, 0.01, ptr(stats_a), stream_ptr()), "clip")
     check(L.sfron_sumsq_masked(ptr(grad), None, ptr(mask), n, ptr(part), ctypes.byref(nb), stream_ptr()), "sumsq")
     check(L.sfron_clip_coef(ptr(part), nb.value, 0.01, ptr(stats_b), stream_ptr()), "clip")

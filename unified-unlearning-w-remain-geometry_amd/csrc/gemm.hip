@@ -48,6 +48,8 @@ struct GemmArgs {
 #ifdef SFRON_DEBUG_KNOBS
   int dbg_same;             // timing experiments only (see k_gemm_pipe)
 #endif
+  const uint8_t* sq_mask;   // EPI_SUMSQ: byte mask [M][N] (ld = N) or null; sq_out[workgroup] = sum over the tile of (mask ? c : 0)^2
+  double* sq_out;
   float* colpart;           // EPI_DGELU on the 256-row pipelined tiles: colpart[tm * N + n] = sum over the tile's 256 rows of the
                             // fp32 output (before bf16 rounding) -- per-tile-row partials of the fc1 bias gradient, or null
 };
@@ -58,7 +60,7 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int NT = 256;
 constexpr int TILE_ELEMS = 128 * 64;   // both image kinds hold 8192 bf16 = 16 KiB
 
-enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_GATE_RES = 3, EPI_DGELU = 4, EPI_POS = 5 };
+enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_GATE_RES = 3, EPI_DGELU = 4, EPI_POS = 5, EPI_SUMSQ = 6 };
 
 
 
@@ -274,15 +276,46 @@ __global__ __launch_bounds__(NT) void k_gemm(GemmArgs g) {
   }
 
   // ---- epilogue: lane holds C[m = mt*16 + (lane&15)][n = nt*16 + 4*(lane>>4) + 0..3]
+  if constexpr (EPI == EPI_SUMSQ) {
+    // the product is never stored: masked sum of squares of the tile (the clip-norm pre-pass over a gradient that exists only as its
+    // two factors: sweep.hip sfron_sumsq_lowrank).  All 16 mask words of a lane are fetched before the first use; lanes, then waves,
+    // are summed in a fixed order (double from the wave sums on): bitwise reproducible.
+    uchar4 mk[4][4];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int row = m0 + wm * 64 + mt * 16 + (lane & 15);
-    if (row >= g.M) continue;
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int col = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
-      if (col >= g.N) continue;
-      epilogue_store<EPI>(g, row, col, acc[mt][nt]);
+      for (int nt = 0; nt < 4; ++nt) {
+        const int row = m0 + wm * 64 + mt * 16 + (lane & 15), col = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
+        const bool in = row < g.M && col < g.N;
+        const unsigned char one = in ? 1 : 0;
+        mk[mt][nt] = make_uchar4(one, one, one, one);
+        if (g.sq_mask && in) mk[mt][nt] = *reinterpret_cast<const uchar4*>(g.sq_mask + (size_t)row * g.N + col);
+      }
+    float sq = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const f32x4 v = acc[mt][nt] * g.alpha;
+        const uchar4 m4 = mk[mt][nt];
+        sq += (m4.x ? v[0] * v[0] : 0.f) + (m4.y ? v[1] * v[1] : 0.f) + (m4.z ? v[2] * v[2] : 0.f) + (m4.w ? v[3] * v[3] : 0.f);
+      }
+    double d = wave_sum_d((double)sq);
+    double* red = reinterpret_cast<double*>(smem);          // (the main loop ended with a barrier: the staging images are free)
+    if (lane == 0) red[wave] = d;
+    __syncthreads();
+    if (tid == 0) g.sq_out[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int row = m0 + wm * 64 + mt * 16 + (lane & 15);
+      if (row >= g.M) continue;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int col = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
+        if (col >= g.N) continue;
+        epilogue_store<EPI>(g, row, col, acc[mt][nt]);
+      }
     }
   }
 }
@@ -1406,6 +1439,19 @@ extern "C" int sfron_gemm_dgelu_colpart_rows(int M, int N, int K) {
   if (t == 42) return M / 256;
   if (t == 62) return (K % 192 == 0 || tile_fits(g, 2)) ? M / 256 : 0;
   return 0;
+}
+
+// Masked sum of squares of W' = A^T B (A bf16 [R][NM], B bf16 [R][D], contraction over the R rows) without storing W': one fp64 partial per
+// 128 x 128 tile, partials[0 .. *nblk).  C++ linkage: called by sweep.hip (sfron_sumsq_lowrank), not part of the C ABI.
+int gemm_sumsq_lowrank(const uint16_t* a, const uint16_t* b, int R, int NM, int D, const uint8_t* mask, double* partials, int* nblk, void* stream) {
+  GemmArgs g{};
+  g.A = (const __bf16*)a; g.B = (const __bf16*)b;
+  g.M = NM; g.N = D; g.K = R; g.lda = NM; g.ldb = D;
+  g.alpha = 1.0f; g.kchunk = R; g.T = 1;
+  g.ntm = cdiv(NM, BM); g.ntn = cdiv(D, BN);
+  g.sq_mask = mask; g.sq_out = partials;
+  *nblk = g.ntm * g.ntn;
+  return launch<true, true, EPI_SUMSQ>(g, (hipStream_t)stream);
 }
 
 extern "C" // test / A-B hook: 4 = loader-wave form of the three-slot tiles (0 = every wave issues its share of the LDS-DMA); returns the old value

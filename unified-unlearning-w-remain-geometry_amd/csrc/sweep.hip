@@ -16,6 +16,9 @@
 #include "common.h"
 #include "../../include/sfron.h"
 
+// gemm.hip (C++ linkage, not part of the C ABI): masked sum of squares of A^T B, one fp64 partial per 128 x 128 tile
+int gemm_sumsq_lowrank(const uint16_t* a, const uint16_t* b, int R, int NM, int D, const uint8_t* mask, double* partials, int* nblk, void* stream);
+
 namespace {
 
 constexpr int TPB = 256;
@@ -383,6 +386,11 @@ int sfron_sumsq_lowrank(const uint16_t* dmod, const uint16_t* sc, int R, int NM,
                         int* nblk_out, void* stream) {
   SFRON_CHECK_ARG(dmod && sc && partials && nblk_out && R > 0 && NM > 0 && D > 0 && NM % LR_ROWS == 0 && D % 4 == 0 && D <= 4096);
   SFRON_CHECK_ARG((((uintptr_t)dmod) & 15) == 0 && (((uintptr_t)sc) & 7) == 0 && (!mask || ((uintptr_t)mask & 3) == 0));
+  // The norm pre-pass only needs sum (mask g)^2: on the matrix core the rank-R product is one 16 x 16 x 32 step per output tile and is
+  // never stored (gemm.hip EPI_SUMSQ: 128 x 128 tiles, one fp64 partial each; was 32 vector FMAs per element: 480 -> ~100 us at DiT-XL/2).
+  // Its partial count must fit the NM / LR_ROWS doubles the caller holds for this segment.
+  if (NM % 128 == 0 && D % 128 == 0 && D <= 128 * (128 / LR_ROWS) && NM % 8 == 0 && D % 8 == 0)
+    return gemm_sumsq_lowrank(dmod, sc, R, NM, D, mask, partials, nblk_out, stream);
   const int threads = (D / 4 + 63) / 64 * 64;
   *nblk_out = NM / LR_ROWS;
   hipLaunchKernelGGL(k_sumsq_lowrank, dim3(NM / LR_ROWS), dim3(threads), 0, (hipStream_t)stream, (const __bf16*)dmod, (const __bf16*)sc, R, NM, D,
