@@ -22,10 +22,22 @@ static constexpr int WAVE = 64;
 __device__ __forceinline__ float bf2f(__bf16 x) { return (float)x; }
 __device__ __forceinline__ __bf16 f2bf(float x) { return (__bf16)x; }   // v_cvt_pk_bf16_f32: RNE, NaN-preserving
 
+// Sum over the 64 lanes, every lane gets it.  Data-parallel-primitive form: four adds inside the 16-lane rows (quad swaps, half-row and
+// row mirrors), two row broadcasts, one readlane -- seven short vector operations in a fixed order (bitwise reproducible).  The
+// `__shfl_xor` butterfly compiles to six DEPENDENT ds_bpermute_b32 (an LDS-crossbar round trip each, ~700 cycles per sum): the row
+// kernels take two sums per token row.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_get(float v) {       // lanes of rows outside ROW_MASK get 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_get<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+  v += dpp_get<0x141, 0xf>(v);     // row_half_mirror
+  v += dpp_get<0x140, 0xf>(v);     // row_mirror: every lane of a row holds the row's sum
+  v += dpp_get<0x142, 0xa>(v);     // row_bcast15 into rows 1 and 3
+  v += dpp_get<0x143, 0xc>(v);     // row_bcast31 into rows 2 and 3: lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

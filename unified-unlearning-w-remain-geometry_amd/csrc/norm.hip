@@ -68,20 +68,24 @@ __global__ __launch_bounds__(TPB) void k_ln_mod_fwd(const float* __restrict__ x,
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int row0 = (blockIdx.x * 4 + wave) * RPW;
   if (row0 >= M) return;
-  // branch-free: one-row buffer descriptors (see row_rsrc), every load of the wave's rows -- x, shift, scale -- before the first use
-  RowRegs r[RPW], sh[RPW], sc[RPW];
-#pragma unroll
-  for (int k = 0; k < RPW; ++k) {
-    const int row = row0 + k < M ? row0 + k : M - 1;
-    const int b = row / T;
-    const __amdgpu_buffer_rsrc_t rx = row_rsrc(x + (size_t)row * D, D * 4);
+  // branch-free: one-row buffer descriptors (see row_rsrc), every load of the wave's rows before the first use.  The shift / scale rows
+  // of the sample (2 x 4.6 KB against 4.6 KB of x per token row) are fetched ONCE per wave: the launcher picks RPW so that the wave's
+  // rows belong to one sample (RPW | tokens).
+  RowRegs r[RPW], sh, sc;
+  {
+    const int b = row0 / T;
     const __amdgpu_buffer_rsrc_t rh = row_rsrc(shift + (size_t)b * ldmod, D * 4), rc = row_rsrc(scale + (size_t)b * ldmod, D * 4);
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) r[k].v[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, lane * 16 + 1024 * i, 0, 0));
+    for (int k = 0; k < RPW; ++k) {
+      const int row = row0 + k < M ? row0 + k : M - 1;
+      const __amdgpu_buffer_rsrc_t rx = row_rsrc(x + (size_t)row * D, D * 4);
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) r[k].v[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, lane * 16 + 1024 * i, 0, 0));
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      sh[k].v[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rh, lane * 16 + 1024 * i, 0, 0));
-      sc[k].v[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rc, lane * 16 + 1024 * i, 0, 0));
+      sh.v[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rh, lane * 16 + 1024 * i, 0, 0));
+      sc.v[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rc, lane * 16 + 1024 * i, 0, 0));
     }
   }
 #pragma unroll
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(TPB) void k_ln_mod_fwd(const float* __restrict__ x,
     const __amdgpu_buffer_rsrc_t ro = row_rsrc(out + (size_t)row * D, D * 2);
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const float4 h = sh[k].v[i], g = sc[k].v[i];
+      const float4 h = sh.v[i], g = sc.v[i];
       const bf16x4 o = {f2bf((r[k].v[i].x - mean) * rstd * (1.0f + g.x) + h.x), f2bf((r[k].v[i].y - mean) * rstd * (1.0f + g.y) + h.y),
                         f2bf((r[k].v[i].z - mean) * rstd * (1.0f + g.z) + h.z), f2bf((r[k].v[i].w - mean) * rstd * (1.0f + g.w) + h.w)};
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ro, lane * 8 + 512 * i, 0, 0);
@@ -487,7 +491,11 @@ int sfron_ln_modulate_fwd(const float* x, const float* shift, const float* scale
   SFRON_CHECK_ARG(x && shift && scale && out && mean && rstd && M > 0 && tokens > 0);
   SFRON_CHECK_ARG(D % 4 == 0 && D <= 64 * 4 * NCH && ldmod % 4 == 0);
   SFRON_CHECK_ARG((((uintptr_t)x | (uintptr_t)shift | (uintptr_t)scale) & 15) == 0 && ((uintptr_t)out & 7) == 0);
-  if (M >= 4096)       // enough rows to fill the chip with two-row waves
+  // rows per wave: as many as divide the token count (one sample per wave) while the launch still fills the chip
+  if (M >= 8192 && tokens % 4 == 0)
+    hipLaunchKernelGGL(k_ln_mod_fwd<4>, dim3(cdiv(M, 16)), dim3(TPB), 0, (hipStream_t)stream, x, shift, scale, ldmod, tokens, M, D,
+                       (__bf16*)out, mean, rstd);
+  else if (M >= 4096 && tokens % 2 == 0)
     hipLaunchKernelGGL(k_ln_mod_fwd<2>, dim3(cdiv(M, 8)), dim3(TPB), 0, (hipStream_t)stream, x, shift, scale, ldmod, tokens, M, D,
                        (__bf16*)out, mean, rstd);
   else
