@@ -172,7 +172,10 @@ __device__ __forceinline__ bf16x8 frag_rows_global(const __bf16* base, int ld, i
   if (d >= hd) return z;
   return *reinterpret_cast<const bf16x8*>(base + (size_t)(row0 + (lane & 15)) * ld + d);
 }
-__device__ __forceinline__ float group_max(float v) {      // over the 4 lane groups holding one softmax row
+// over the 4 lane groups (lanes i, i + 16, i + 32, i + 48) that hold one softmax row.  (gfx950's v_permlane16_swap / v_permlane32_swap do
+// the same in two vector operations per step instead of a ds_bpermute round trip; measured: no change -- forward 31.9 us either way -- and
+// the instructions need care under hipcc 7.2, tools/probes/permlane_probe.hip; the shuffles stay.)
+__device__ __forceinline__ float group_max(float v) {
   v = fmaxf(v, __shfl_xor(v, 16, 64));
   return fmaxf(v, __shfl_xor(v, 32, 64));
 }
@@ -903,7 +906,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float x = v[j];
-            x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+            x = row16_sum(x);
             v[j] = x;
           }
           if ((lane & 15) == 0) {
@@ -942,8 +945,8 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float x = sk[j], y = sv[j];
-        x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
-        y += __shfl_xor(y, 1, 64); y += __shfl_xor(y, 2, 64); y += __shfl_xor(y, 4, 64); y += __shfl_xor(y, 8, 64);
+        x = row16_sum(x);
+        y = row16_sum(y);
         sk[j] = x; sv[j] = y;
       }
       if ((lane & 15) == 0) {

@@ -30,6 +30,14 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_get(float v) {       // lanes of rows outside ROW_MASK get 0
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
 }
+// sum over the 16 lanes of a row (lanes that share lane >> 4), every lane of the row gets it: the same pairing -- the same bits -- as the
+// xor 1 / 2 / 4 / 8 butterfly
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_get<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+  v += dpp_get<0x141, 0xf>(v);     // row_half_mirror
+  return v + dpp_get<0x140, 0xf>(v);   // row_mirror
+}
 __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_get<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
   v += dpp_get<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]

@@ -1166,7 +1166,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float x = cs[nt][j];
-          x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+          x = row16_sum(x);
           cs[nt][j] = x;
         }
       __syncthreads();
