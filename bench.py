@@ -319,7 +319,7 @@ def main():
                        "global_batch": gb, "tokens": T, "parallelism": f"dp{world}",
                        "schedule": {"forget_sweep_beside_remain_forward": bool(runner.sweep_beside_forward),
                                     "remain_sweep_beside_next_forget_forward": bool(runner.sweep_across_steps and runner.sweep_beside_forward
-                                                                                    and world == 1 and not args.fp8),
+                                                                                    and world == 1),
                                     "note": "every sweep is inside the timed region (it ends with torch.cuda.synchronize())"}},
             "finite_losses": loss_ok,
             "step_tflops_per_gpu": step_flops / (ms_per_step * 1e-3) / 1e12,

@@ -127,14 +127,16 @@ def test_pipelined_synchronous_exchange_matches_plain_path():
     assert (g1 - g0).abs().max().item() <= 1e-6 * g0.abs().max().item()
 
 
-def test_remain_sweep_beside_the_next_step_gives_the_same_state():
+@pytest.mark.parametrize("fp8", [False, True])
+def test_remain_sweep_beside_the_next_step_gives_the_same_state(fp8):
     """sweep_across_steps: the remain-stage AdamW + EMA of the block ranges runs on the sweep stream beside the NEXT step's forget
     forward pass (which waits block by block); step() returns with it in flight.  Same kernels on the same operands: parameters,
     moments, EMA and the bf16 shadow after four steps equal the in-step form bit for bit; the runner's accessors (checkpoint) order
     themselves behind the sweep."""
     from sfron import data, diffusion, step
     from test_gpu_dit import CASES, build_pair
-    cfg = CASES["hd72"]
+    # fp8: a width the e4m3 tile takes (hidden 128, 64 tokens, batch 4 -> M = 256: tests/test_gpu_fp8.py CFG)
+    cfg = dict(input_size=16, patch_size=2, in_channels=4, hidden_size=128, depth=2, num_heads=2, num_classes=10) if fp8 else CASES["hd72"]
     B = 4
     kw = dict(global_batch=B, num_classes=cfg["num_classes"], forget_class=3, input_size=cfg["input_size"], device=DEV)
     bat = lambda it: (data.synthetic_batch(6, it, "forget", **kw), data.synthetic_batch(6, it, "remain", **kw))
@@ -142,7 +144,7 @@ def test_remain_sweep_beside_the_next_step_gives_the_same_state():
 
     def run(across):
         _, model = build_pair(cfg, B, seed=29)
-        runner = step.DiTSFRon(model, diffusion.create_diffusion(""), **hp)
+        runner = step.DiTSFRon(model, diffusion.create_diffusion(""), fp8=fp8, **hp)     # fp8: the sweeps also rewrite the e4m3 shadow
         assert runner.sweep_across_steps is False          # opt-in
         runner.sweep_across_steps = across
         for it in range(4):

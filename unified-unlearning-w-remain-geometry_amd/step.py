@@ -419,10 +419,10 @@ class DiTSFRon:
         # The remain-stage sweep of the block ranges goes the same way, beside the forget forward pass of the NEXT step() (same stream,
         # same events: the remain forward pass above has consumed them).  step() then returns with that sweep in flight: the next
         # step's forward pass waits block by block, every other reader of the state drains it first (engine.drain_sweep).
-        across = beside and self.sweep_across_steps and not fused_q
+        across = beside and self.sweep_across_steps
         if across:
             split_r = dict(ranges=bs["ranges"], stream=bs["stream"], events=bs["events"], max_workgroups=self.sweep_beside_wg,
-                           head=self.sweep_beside_head)
+                           head=self.sweep_beside_head, quant=quant)
         else:
             split_r = dict(ranges=bs["ranges"], stream=None, quant=quant) if fused_q else None
         self.opt.step(max_norm=None, use_mask=False, ema=self.ema[:nt], ema_decay=self.ema_decay, ema_mode=1,   # :320,322
