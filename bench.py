@@ -229,6 +229,7 @@ def main():
     loss_ok = bool(torch.isfinite(out["remain_mse"]).all().item() and torch.isfinite(out["forget_mse"]).all().item())
     n_probe, probe_ms = eng.probe_read()
     n_wp, wp_ms = eng.wgrad_probe_read()
+    sched_across = bool(runner.sweep_across_steps and runner.sweep_beside_forward and world == 1)      # as the timed region ran
     sweep_where = "inside the timed region"
     if not any(whole for _, _, whole in runner.opt.timed) and world == 1:
         # the remain-stage sweep of the blocks ran split across the step boundary (config.schedule): for the `others.hbm` roofline time
@@ -266,7 +267,7 @@ def main():
     n_ada = (6 * L + 2) * D * D if runner.factored_ada and world == 1 else 0
     sweep_bytes = 38.0 * nt - 4.0 * n_ada
     sw_ms = sum(sweep_ms) / max(1, len(sweep_ms))
-    sw_ach = sweep_bytes / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else 0.0
+    sw_ach = sweep_bytes / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else None    # None: no whole-arena launch to time (config 5 sweeps tensor by tensor)
 
     # HBM traffic of the probed kernels: PMC counters need their own rocprofv3 passes (FETCH_SIZE, WRITE_SIZE), so the numbers are
     # measured offline on this same command (tools/pmc_traffic.py) and committed under profiles/ TOGETHER WITH the hash of the HIP
@@ -318,8 +319,7 @@ def main():
                                    + (" -- BASELINE config 5 (fp8 forward)" if args.fp8 else ""),
                        "global_batch": gb, "tokens": T, "parallelism": f"dp{world}",
                        "schedule": {"forget_sweep_beside_remain_forward": bool(runner.sweep_beside_forward),
-                                    "remain_sweep_beside_next_forget_forward": bool(runner.sweep_across_steps and runner.sweep_beside_forward
-                                                                                    and world == 1),
+                                    "remain_sweep_beside_next_forget_forward": sched_across,
                                     "note": "every sweep is inside the timed region (it ends with torch.cuda.synchronize())"}},
             "finite_losses": loss_ok,
             "step_tflops_per_gpu": step_flops / (ms_per_step * 1e-3) / 1e12,
@@ -340,7 +340,7 @@ def main():
                                               "flops_per_launch": fc1_flops, "avg_launch_ms": avg_ms, "launches_timed": n_probe},
                              "hbm": {"bound": "hbm", "kernel": "remain-stage parameter sweep: k_masked_clip_adam (AdamW + EMA + bf16 shadow, 38 B/param) over the flat arenas "
                                      "+ k_adam_lowrank over the adaLN matrix (gradient formed from its two factors: 34 B/param)", "achieved": sw_ach, "peak": HBM_PEAK_GBS,
-                                     "unit": "GB/s", "frac": sw_ach / HBM_PEAK_GBS, "traffic": None,
+                                     "unit": "GB/s", "frac": (sw_ach / HBM_PEAK_GBS) if sw_ach is not None else None, "traffic": None,
                                      "traffic_all_sweeps_per_step": committed_traffic("r03_sweep_traffic.json", "traffic_bytes_per_step"),
                                      "algorithmic_all_sweeps_per_step": committed_traffic("r03_sweep_traffic.json", "algorithmic_bytes_per_step"),
                                      "bytes_per_launch": sweep_bytes, "avg_launch_ms": sw_ms, "launches_timed": len(sweep_ms),
