@@ -8,7 +8,8 @@ import torch
 from sfron import ops, _lib
 DEV = "cuda:0"; D, F = 1152, 4608
 g = torch.Generator(device=DEV).manual_seed(0)
-rnd = lambda *s: torch.randn(*s, device=DEV, generator=g).to(torch.bfloat16)
+ZERO = len(sys.argv) > 1 and sys.argv[1] == "zeros"      # zero-filled operands: same instructions, far fewer toggling bits (power)
+rnd = lambda *s: torch.zeros(*s, device=DEV, dtype=torch.bfloat16) if ZERO else torch.randn(*s, device=DEV, generator=g).to(torch.bfloat16)
 def timeit(fn, iters=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
