@@ -134,6 +134,22 @@ def test_fp8_gemm_epilogues_vs_torch(M, N, K):
     check(L.sfron_fp8_gemm(ctypes.byref(d), stream_ptr()), "fp8_gemm")
     assert _rel(a1, want) < 3e-3
     assert _rel(x1, resid + gate.repeat_interleave(Tk, 0) * want) < 2e-5
+    # the loader-wave form of the fp8 tiles (off by default, sfron_gemm_loader_waves(9)): the same bits from all three epilogues
+    keep = [t.clone() for t in (C, H, HP, H8, x1, a1)]
+    old = L.sfron_gemm_loader_waves(9)
+    try:
+        for t in (C, H, HP, H8, x1, a1):
+            t.zero_()
+        d = desc(_lib.EPI_BF16); d.c_bf16, d.ldc_bf16 = C.data_ptr(), N
+        check(L.sfron_fp8_gemm(ctypes.byref(d), stream_ptr()), "fp8_gemm")
+        d = desc(_lib.EPI_GELU); d.c_bf16, d.ldc_bf16, d.aux, d.ldaux, d.c_e4m3, d.c_e4m3_scale = H.data_ptr(), N, HP.data_ptr(), N, H8.data_ptr(), sh
+        check(L.sfron_fp8_gemm(ctypes.byref(d), stream_ptr()), "fp8_gemm")
+        d = desc(_lib.EPI_GATE_RES); d.c_f32, d.ldc_f32, d.resid, d.aux, d.ldaux, d.gate, d.ldgate = x1.data_ptr(), N, resid.data_ptr(), a1.data_ptr(), N, gate.data_ptr(), N
+        check(L.sfron_fp8_gemm(ctypes.byref(d), stream_ptr()), "fp8_gemm")
+    finally:
+        L.sfron_gemm_loader_waves(old)
+    for a, b in zip(keep, (C, H, HP, H8, x1, a1)):
+        assert torch.equal(a, b)
 
 
 CFG = dict(input_size=16, patch_size=2, in_channels=4, hidden_size=128, depth=2, num_heads=2, num_classes=10)     # 64 tokens; batch 4 -> M = 256

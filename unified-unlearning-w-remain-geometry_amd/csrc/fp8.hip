@@ -184,10 +184,18 @@ __device__ __forceinline__ i32x8 frag32(const uint8_t* img, int row, int g) {
 
 }  // namespace
 
-template <int EPI, int NTL>
-__global__ __launch_bounds__(512) void k_gemm8(Gemm8Args g) {
+// NL > 0: NL extra LOADER waves issue every LDS-DMA piece of the ring; the eight multiplying waves none (as csrc/gemm.hip k_gemm_pipe NL;
+// tools/probes/persist_gemm_probe.hip measured this compiler-scheduled loop 13-22 % faster that way in bf16).  Twelve waves: <= 168
+// registers, so the consumers fetch the bias after the main loop.  With e4m3 operands a K-step carries half the DMA pieces per FLOP
+// and the split bought nothing in the step (g_fp8_loader_waves): kept as a switchable form, off by default.
+template <int EPI, int NTL, int NL = 0>
+__global__ __launch_bounds__(512 + 64 * NL) void k_gemm8(Gemm8Args g) {
   using TL = Tile8<NTL>;
-  constexpr int FBN = TL::FBN, SLOT = TL::SLOT, NB = TL::NB, NT8 = NTL, NDMA8 = TL::NDMA;
+  constexpr int FBN = TL::FBN, SLOT = TL::SLOT, NT8 = NTL;
+  constexpr int NWD = NL > 0 ? NL : NW;                                  // waves that issue LDS-DMA
+  constexpr int NA_ = FBM * 8 / 64 / NWD, NB = (TL::NB_TOTAL + NWD - 1) / NWD, NDMA8 = NA_ + NB;
+  constexpr bool EVEN_ = TL::NB_TOTAL % NWD == 0;
+  constexpr size_t DUMMY_AT = (size_t)NSLOT8 * SLOT;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -202,46 +210,66 @@ __global__ __launch_bounds__(512) void k_gemm8(Gemm8Args g) {
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, g.M * K, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, g.N * K, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsNull = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, 0, 0x00020000);
-  uint8_t* const dummy = smem8 + NSLOT8 * SLOT;
+  uint8_t* const dummy = smem8 + DUMMY_AT;
   const int lc16 = ((lane & 7) ^ ((lane >> 3) & 7)) << 4;
-  int a_off[NA], b_off[NB];
+  const int dwave = NL > 0 ? wave - NW : wave;                       // (consumers of the loader form never use their plan)
+  int a_off[NA_], b_off[NB];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) a_off[i] = (m0 + (wave + i * NW) * 8 + (lane >> 3)) * K + lc16;
+  for (int i = 0; i < NA_; ++i) a_off[i] = (m0 + (dwave + i * NWD) * 8 + (lane >> 3)) * K + lc16;
 #pragma unroll
-  for (int i = 0; i < NB; ++i) b_off[i] = (n0 + (wave + i * NW) * 8 + (lane >> 3)) * K + lc16;
+  for (int i = 0; i < NB; ++i) b_off[i] = (n0 + (dwave + i * NWD) * 8 + (lane >> 3)) * K + lc16;
   auto issue = [&](int slot, int k0) {
     uint8_t* iA = smem8 + slot * SLOT;
     uint8_t* iB = iA + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) dma16b(rsA, iA + (wave + i * NW) * 1024, a_off[i], k0);
+    for (int i = 0; i < NA_; ++i) dma16b(rsA, iA + (dwave + i * NWD) * 1024, a_off[i], k0);
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      if constexpr (TL::EVEN) dma16b(rsB, iB + (wave + i * NW) * 1024, b_off[i], k0);
+      if constexpr (EVEN_) dma16b(rsB, iB + (dwave + i * NWD) * 1024, b_off[i], k0);
       else {
-        const bool ok = wave + i * NW < TL::NB_TOTAL;               // wave-uniform
-        dma16b(ok ? rsB : rsNull, ok ? iB + (wave + i * NW) * 1024 : dummy, b_off[i], k0);
+        const bool ok = dwave + i * NWD < TL::NB_TOTAL;             // wave-uniform
+        dma16b(ok ? rsB : rsNull, ok ? iB + (dwave + i * NWD) * 1024 : dummy, b_off[i], k0);
       }
     }
   };
+  if constexpr (NL > 0) {
+    if (wave >= NW) {                                                // ---- loader wave
+      if (nk > 0) issue(0, 0);
+      if (nk > 1) issue(1, BKB);
+      int slot2 = 2;
+      for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) wait_vm<NDMA8>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) issue(slot2, (kt + 2) * BKB);
+        slot2 = slot2 == 2 ? 0 : slot2 + 1;
+      }
+      return;
+    }
+  }
   f32x4 acc[2][NT8];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < NT8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, fg = lane >> 4;
-  // this lane's output columns: bias fetched ahead of the main loop
+  // this lane's output columns: bias fetched ahead of the main loop (loader form: behind it, the registers are short)
   float4 bias_v[NT8];
+  auto load_bias = [&]() {
 #pragma unroll
-  for (int nt = 0; nt < NT8; ++nt)
-    bias_v[nt] = g.bias ? *reinterpret_cast<const float4*>(g.bias + n0 + nt * 16 + 4 * fg) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int nt = 0; nt < NT8; ++nt)
+      bias_v[nt] = g.bias ? *reinterpret_cast<const float4*>(g.bias + n0 + nt * 16 + 4 * fg) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  if constexpr (NL == 0) load_bias();
   const float deq = 1.0f / (g.a_scale * *g.w_scale);
-  if (nk > 0) issue(0, 0);
-  if (nk > 1) issue(1, BKB);
+  if constexpr (NL == 0) {
+    if (nk > 0) issue(0, 0);
+    if (nk > 1) issue(1, BKB);
+  }
   int slot = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) wait_vm<NDMA8>(); else wait_vm<0>();
+    if constexpr (NL == 0) { if (kt + 1 < nk) wait_vm<NDMA8>(); else wait_vm<0>(); }
     __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) issue(slot >= 1 ? slot - 1 : 2, (kt + 2) * BKB);
+    if constexpr (NL == 0) { if (kt + 2 < nk) issue(slot >= 1 ? slot - 1 : 2, (kt + 2) * BKB); }
     const uint8_t* iA = smem8 + slot * SLOT;
     const uint8_t* iB = iA + A_BYTES;
     const i32x8 fa0 = frag32(iA, wave * 32 + fr, fg), fa1 = frag32(iA, wave * 32 + 16 + fr, fg);
@@ -254,15 +282,36 @@ __global__ __launch_bounds__(512) void k_gemm8(Gemm8Args g) {
     }
     slot = slot == 2 ? 0 : slot + 1;
   }
+  constexpr bool BIAS_BY_HALF = NL > 0 && EPI == E8_GATE_RES;       // (that epilogue also holds gate + residual words: bias with them, half a row at a time)
+  if constexpr (NL > 0 && !BIAS_BY_HALF) load_bias();
   // lane holds C[m0 + 32 wave + 16 mt + fr][n0 + 16 nt + 4 fg .. +3]
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int row = m0 + wave * 32 + mt * 16 + fr;
+    // gated residual: the row's gate and residual words are fetched for all NT8 tiles before the first store (resid may alias Cf, so hipcc
+    // keeps each load behind the previous store: one exposed latency per tile otherwise)
+    // (in two halves: 2 x NT8 float4 on top of the accumulators do not fit the 168 registers of the loader form)
+    constexpr int NH = (NT8 + 1) / 2;
+    float4 gtv[EPI == E8_GATE_RES ? NH : 1], xrv[EPI == E8_GATE_RES ? NH : 1];
 #pragma unroll
     for (int nt = 0; nt < NT8; ++nt) {
+      if constexpr (EPI == E8_GATE_RES) {
+        if (nt % NH == 0) {
+#pragma unroll
+          for (int u = 0; u < NH; ++u) {
+            if (nt + u < NT8) {
+              const int colu = n0 + (nt + u) * 16 + 4 * fg;
+              gtv[u] = *reinterpret_cast<const float4*>(g.gate + (size_t)(row / g.T) * g.ldgate + colu);
+              xrv[u] = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldcf + colu);
+              if constexpr (BIAS_BY_HALF) bias_v[u] = g.bias ? *reinterpret_cast<const float4*>(g.bias + colu) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+          }
+        }
+      }
       const int col = n0 + nt * 16 + 4 * fg;
       f32x4 v = acc[mt][nt] * deq;
-      v[0] += bias_v[nt].x; v[1] += bias_v[nt].y; v[2] += bias_v[nt].z; v[3] += bias_v[nt].w;
+      const float4 bv = bias_v[BIAS_BY_HALF ? nt % NH : nt];
+      v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
       if constexpr (EPI == E8_BF16) {
         *reinterpret_cast<bf16x4*>(g.Cb + (size_t)row * g.ldcb + col) = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
       } else if constexpr (EPI == E8_GELU) {
@@ -272,8 +321,8 @@ __global__ __launch_bounds__(512) void k_gemm8(Gemm8Args g) {
         *reinterpret_cast<uint32_t*>(g.C8 + (size_t)row * g.N + col) = pack_e4m3(h0 * g.c8_scale, h1 * g.c8_scale, h2 * g.c8_scale, h3 * g.c8_scale);
       } else {
         *reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col) = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        const float4 gt = *reinterpret_cast<const float4*>(g.gate + (size_t)(row / g.T) * g.ldgate + col);
-        float4 x = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldcf + col);
+        const float4 gt = gtv[nt % NH];
+        float4 x = xrv[nt % NH];
         x.x += gt.x * v[0]; x.y += gt.y * v[1]; x.z += gt.z * v[2]; x.w += gt.w * v[3];
         *reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col) = x;
       }
@@ -286,20 +335,29 @@ template __global__ void k_gemm8<E8_GATE_RES, 8>(Gemm8Args);
 template __global__ void k_gemm8<E8_BF16, 9>(Gemm8Args);
 template __global__ void k_gemm8<E8_GELU, 9>(Gemm8Args);
 template __global__ void k_gemm8<E8_GATE_RES, 9>(Gemm8Args);
+template __global__ void k_gemm8<E8_BF16, 8, 4>(Gemm8Args);
+template __global__ void k_gemm8<E8_GELU, 8, 4>(Gemm8Args);
+template __global__ void k_gemm8<E8_GATE_RES, 8, 4>(Gemm8Args);
+template __global__ void k_gemm8<E8_BF16, 9, 4>(Gemm8Args);
+template __global__ void k_gemm8<E8_GELU, 9, 4>(Gemm8Args);
+template __global__ void k_gemm8<E8_GATE_RES, 9, 4>(Gemm8Args);
+
+int g_fp8_loader_waves = 0;     // process-wide form of the fp8 tiles: 4 = loader waves (sfron_gemm_loader_waves(9)); measured in the config-5 step:
+                                // 65.2 / 64.0 / 64.8 ms against 63.5 / 64.1 / 64.1 for the shared-wave form -- off
 
 namespace {
-template <int EPI, int NTL>
+template <int EPI, int NTL, int NL>
 int launch8t(const Gemm8Args& g, hipStream_t s) {
-  const size_t lds = Tile8<NTL>::LDS;
+  const size_t lds = (size_t)NSLOT8 * Tile8<NTL>::SLOT + 1024;      // (+ the dummy kilobyte of uneven DMA plans)
   static std::atomic<uint64_t> done{0};
   int dev = 0;
   (void)hipGetDevice(&dev);
   const uint64_t bit = 1ull << (dev & 63);
   if ((done.fetch_or(bit) & bit) == 0) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, NTL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, NTL, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return (int)hipGetLastError();
   }
-  hipLaunchKernelGGL((k_gemm8<EPI, NTL>), dim3((g.M / FBM) * (g.N / (NTL * 16))), dim3(512), lds, s, g);
+  hipLaunchKernelGGL((k_gemm8<EPI, NTL, NL>), dim3((g.M / FBM) * (g.N / (NTL * 16))), dim3(512 + 64 * NL), lds, s, g);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
 }
@@ -315,7 +373,8 @@ inline int pick_ntl(int M, int N) {
 }
 template <int EPI>
 int launch8(const Gemm8Args& g, hipStream_t s) {
-  return pick_ntl(g.M, g.N) == 9 ? launch8t<EPI, 9>(g, s) : launch8t<EPI, 8>(g, s);
+  if (g_fp8_loader_waves == 4) return pick_ntl(g.M, g.N) == 9 ? launch8t<EPI, 9, 4>(g, s) : launch8t<EPI, 8, 4>(g, s);
+  return pick_ntl(g.M, g.N) == 9 ? launch8t<EPI, 9, 0>(g, s) : launch8t<EPI, 8, 0>(g, s);
 }
 inline int grid_for(int64_t items) { int64_t b = (items + TPB - 1) / TPB; return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
 }  // namespace
