@@ -111,7 +111,14 @@ class DiT(nn.Module):
             self.pos_embed.copy_(torch.from_numpy(pe).float().unsqueeze(0))
         eng.sync_bf16()
 
+    def state_dict(self, *a, **kw):
+        # the parameters are views into the arena: order this stream behind a block sweep a runner may have left in flight
+        # (DiTSFRon.sweep_across_steps) before anybody copies them
+        self.engine.drain_sweep()
+        return super().state_dict(*a, **kw)
+
     def load_state_dict(self, state_dict, strict=True, **kw):
+        self.engine.drain_sweep()
         # checkpoints written by the reference come from an nn.DataParallel wrapper (DiT/forget.py:193,347): "module." keys
         if state_dict and all(k.startswith("module.") for k in state_dict):
             state_dict = {k[len("module."):]: v for k, v in state_dict.items()}
@@ -124,6 +131,7 @@ class DiT(nn.Module):
         if batch_size == self.engine.cfg.batch:
             return
         old = self.engine
+        old.drain_sweep()
         new = DitEngine(batch_size, share=old, grads=old.grads, **self._engine_args)     # same parameter AND gradient arenas
         new.probe, old.probe = old.probe, None
         new._share_fp8(old)
