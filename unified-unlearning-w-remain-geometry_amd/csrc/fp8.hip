@@ -98,48 +98,64 @@ __global__ __launch_bounds__(TPB) void k_cast_e4m3_f32(const float* __restrict__
 
 // ---------------------------------------------------------------- LayerNorm + modulate with the e4m3 copy (norm.hip's k_ln_mod_fwd + one store)
 constexpr int NCHQ = 5;            // row chunks of 256 floats: D <= 1280
+// (as norm.hip k_ln_mod_fwd: one-row buffer descriptors -- branch-free --, RPW rows of one sample per wave, every load before the first use,
+// the sample's shift / scale rows fetched once per wave)
+typedef unsigned int q_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t q_row_rsrc(const void* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+template <int RPW>
 __global__ __launch_bounds__(TPB) void k_ln_mod_fwd_q(const float* __restrict__ x, const float* __restrict__ shift,
                                                       const float* __restrict__ scale, int ldmod, int T, int M, int D,
                                                       __bf16* __restrict__ out, uint8_t* __restrict__ out8, float s8,
                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= M) return;
-  const int D4 = D >> 2;
-  float4 v[NCHQ];
-  float s = 0.f;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row0 = (blockIdx.x * 4 + wave) * RPW;
+  if (row0 >= M) return;
+  float4 v[RPW][NCHQ], sh[NCHQ], sc[NCHQ];
+  {
+    const int b = row0 / T;
+    const __amdgpu_buffer_rsrc_t rh = q_row_rsrc(shift + (size_t)b * ldmod, D * 4), rc = q_row_rsrc(scale + (size_t)b * ldmod, D * 4);
 #pragma unroll
-  for (int i = 0; i < NCHQ; ++i) {
-    const int c = lane + 64 * i;
-    v[i] = c < D4 ? reinterpret_cast<const float4*>(x + (size_t)row * D)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-    s += v[i].x + v[i].y + v[i].z + v[i].w;
-  }
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
+    for (int k = 0; k < RPW; ++k) {
+      const int row = row0 + k < M ? row0 + k : M - 1;
+      const __amdgpu_buffer_rsrc_t rx = q_row_rsrc(x + (size_t)row * D, D * 4);
 #pragma unroll
-  for (int i = 0; i < NCHQ; ++i) {
-    if (lane + 64 * i < D4) {
-      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-      q += a * a + b * b + c * c + d * d;
+      for (int i = 0; i < NCHQ; ++i) v[k][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, lane * 16 + 1024 * i, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < NCHQ; ++i) {
+      sh[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rh, lane * 16 + 1024 * i, 0, 0));
+      sc[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rc, lane * 16 + 1024 * i, 0, 0));
     }
   }
-  const float var = wave_sum(q) / (float)D;
-  const float rstd = 1.0f / sqrtf(var + 1e-6f);
-  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
-  const int b = row / T;
-  const float* sh = shift + (size_t)b * ldmod;
-  const float* sc = scale + (size_t)b * ldmod;
 #pragma unroll
-  for (int i = 0; i < NCHQ; ++i) {
-    const int c = lane + 64 * i;
-    if (c < D4) {
-      const float4 h = reinterpret_cast<const float4*>(sh)[c];
-      const float4 g = reinterpret_cast<const float4*>(sc)[c];
-      const float o0 = (v[i].x - mean) * rstd * (1.0f + g.x) + h.x, o1 = (v[i].y - mean) * rstd * (1.0f + g.y) + h.y;
-      const float o2 = (v[i].z - mean) * rstd * (1.0f + g.z) + h.z, o3 = (v[i].w - mean) * rstd * (1.0f + g.w) + h.w;
-      bf16x4 o = {f2bf(o0), f2bf(o1), f2bf(o2), f2bf(o3)};
-      reinterpret_cast<bf16x4*>(out + (size_t)row * D)[c] = o;
-      reinterpret_cast<uint32_t*>(out8 + (size_t)row * D)[c] = pack_e4m3(o0 * s8, o1 * s8, o2 * s8, o3 * s8);
+  for (int k = 0; k < RPW; ++k) {
+    const int row = row0 + k;
+    if (row >= M) break;                           // wave-uniform
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCHQ; ++i) s += v[k][i].x + v[k][i].y + v[k][i].z + v[k][i].w;      // zeros past the row end
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCHQ; ++i) {
+      const float live = lane + 64 * i < (D >> 2) ? 1.0f : 0.0f;
+      const float a = v[k][i].x - mean, b = v[k][i].y - mean, c = v[k][i].z - mean, d = v[k][i].w - mean;
+      q += live * (a * a + b * b + c * c + d * d);
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + 1e-6f);
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    const __amdgpu_buffer_rsrc_t ro = q_row_rsrc(out + (size_t)row * D, D * 2), r8 = q_row_rsrc(out8 + (size_t)row * D, D);
+#pragma unroll
+    for (int i = 0; i < NCHQ; ++i) {
+      const float4 h = sh[i], g = sc[i];
+      const float o0 = (v[k][i].x - mean) * rstd * (1.0f + g.x) + h.x, o1 = (v[k][i].y - mean) * rstd * (1.0f + g.y) + h.y;
+      const float o2 = (v[k][i].z - mean) * rstd * (1.0f + g.z) + h.z, o3 = (v[k][i].w - mean) * rstd * (1.0f + g.w) + h.w;
+      const bf16x4 o = {f2bf(o0), f2bf(o1), f2bf(o2), f2bf(o3)};
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(q_u32x2, o), ro, lane * 8 + 512 * i, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(pack_e4m3(o0 * s8, o1 * s8, o2 * s8, o3 * s8), r8, lane * 4 + 256 * i, 0, 0);
     }
   }
 }
@@ -444,7 +460,14 @@ int sfron_ln_modulate_fwd_q(const float* x, const float* shift, const float* sca
   SFRON_CHECK_ARG(x && shift && scale && out && out_e4m3 && mean && rstd && M > 0 && tokens > 0 && e4m3_scale > 0.f);
   SFRON_CHECK_ARG(D % 4 == 0 && D <= 64 * 4 * NCHQ && ldmod % 4 == 0);
   SFRON_CHECK_ARG((((uintptr_t)x | (uintptr_t)shift | (uintptr_t)scale) & 15) == 0 && ((uintptr_t)out & 7) == 0 && ((uintptr_t)out_e4m3 & 3) == 0);
-  hipLaunchKernelGGL(k_ln_mod_fwd_q, dim3(cdiv(M, 4)), dim3(TPB), 0, (hipStream_t)stream, x, shift, scale, ldmod, tokens, M, D, (__bf16*)out,
+  if (M >= 8192 && tokens % 4 == 0)
+    hipLaunchKernelGGL(k_ln_mod_fwd_q<4>, dim3(cdiv(M, 16)), dim3(TPB), 0, (hipStream_t)stream, x, shift, scale, ldmod, tokens, M, D, (__bf16*)out,
+                     out_e4m3, e4m3_scale, mean, rstd);
+  else if (M >= 4096 && tokens % 2 == 0)
+    hipLaunchKernelGGL(k_ln_mod_fwd_q<2>, dim3(cdiv(M, 8)), dim3(TPB), 0, (hipStream_t)stream, x, shift, scale, ldmod, tokens, M, D, (__bf16*)out,
+                     out_e4m3, e4m3_scale, mean, rstd);
+  else
+    hipLaunchKernelGGL(k_ln_mod_fwd_q<1>, dim3(cdiv(M, 4)), dim3(TPB), 0, (hipStream_t)stream, x, shift, scale, ldmod, tokens, M, D, (__bf16*)out,
                      out_e4m3, e4m3_scale, mean, rstd);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
