@@ -8,6 +8,8 @@ import torch
 ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=20)
 a = ap.parse_args()
 from sfron import _lib, unet
+if os.environ.get("SFRON_LOADER_WAVES"):            # A-B knob: 10 = convolution tiles in the shared-wave form
+    from sfron import _lib as _L; _L.lib().sfron_gemm_loader_waves(int(os.environ["SFRON_LOADER_WAVES"]))
 from sfron._lib import check, ptr, stream_ptr
 L = _lib.lib()
 DEV = "cuda"

@@ -322,8 +322,10 @@ struct CTile {
   static constexpr size_t LDS = (size_t)NSLOT * SLOT * sizeof(__bf16) + (EVEN ? 0 : 1024);
 };
 
-template <int NT_, int EPI, bool CONV>
-__global__ __launch_bounds__(512) void k_cgemm(BGemmArgs g, unsigned a_bytes, unsigned b_bytes) {
+// NL > 0: NL extra waves (8 .. 8 + NL - 1) issue every LDS-DMA and do the im2col address arithmetic; the 8 MFMA waves only wait at
+// the barrier (the loader / consumer split of gemm.hip k_gemm_pipe)
+template <int NT_, int EPI, bool CONV, int NL = 0>
+__global__ __launch_bounds__(512 + 64 * NL) void k_cgemm(BGemmArgs g, unsigned a_bytes, unsigned b_bytes) {
   using CT = CTile<NT_>;
   extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -350,11 +352,17 @@ __global__ __launch_bounds__(512) void k_cgemm(BGemmArgs g, unsigned a_bytes, un
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, 0, 0x00020000);
   __bf16* dummy = smem + CT::NSLOT * CT::SLOT;
 
+  constexpr int NWD = NL ? NL : CT::NW;                       // waves that issue DMA
+  constexpr int NA_ = CT::FBM * 8 / 64 / NWD, NB_ = (CT::NB_TOT + NWD - 1) / NWD, NDMA_ = NA_ + NB_;
+  constexpr bool EVEN_ = CT::NB_TOT % NWD == 0;
+  static_assert(NL == 0 || EVEN_, "loader waves: no dummy slot");
+  const bool loader = NL && wave >= CT::NW;
+  const int dwave = NL ? (wave - CT::NW) & (NWD - 1) : wave;
   const int lc8 = ((lane & 7) ^ ((lane >> 3) & 7)) << 3;      // logical 8-element chunk this lane fetches (rows start at multiples of 8)
-  int a_off[CT::NA], a_h0[CT::NA], a_w0[CT::NA], a_pb[CT::NA], b_off[CT::NB];
+  int a_off[NA_], a_h0[NA_], a_w0[NA_], a_pb[NA_], b_off[NB_];
 #pragma unroll
-  for (int i = 0; i < CT::NA; ++i) {
-    const int gr = m0 + (wave + i * CT::NW) * 8 + (lane >> 3);
+  for (int i = 0; i < NA_; ++i) {
+    const int gr = m0 + (dwave + i * NWD) * 8 + (lane >> 3);
     if (!CONV) a_off[i] = 2 * (gr * g.lda + lc8);
     else {
       const int wo = gr % g.cg.Wo, t = gr / g.cg.Wo, ho = t % g.cg.Ho, b = t / g.cg.Ho;
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(512) void k_cgemm(BGemmArgs g, unsigned a_bytes, un
     }
   }
 #pragma unroll
-  for (int i = 0; i < CT::NB; ++i) b_off[i] = 2 * ((n0 + (wave + i * CT::NW) * 8 + (lane >> 3)) * g.ldb + lc8);
+  for (int i = 0; i < NB_; ++i) b_off[i] = 2 * ((n0 + (dwave + i * NWD) * 8 + (lane >> 3)) * g.ldb + lc8);
 
   const int Hv = (g.cg.up | g.cg.dil) ? 2 * g.cg.Hs : g.cg.Hs, Wv = (g.cg.up | g.cg.dil) ? 2 * g.cg.Ws : g.cg.Ws;
   // tile kt -> slot: the A source of a convolution advances tap by tap, channel block by channel block
@@ -374,7 +382,7 @@ __global__ __launch_bounds__(512) void k_cgemm(BGemmArgs g, unsigned a_bytes, un
     int kh = 0, kw = 0;
     if (CONV && g.cg.taps == 9) { const int tt = g.cg.flip ? 8 - tap : tap; kh = (tt * 11) >> 5; kw = tt - 3 * kh; }
 #pragma unroll
-    for (int i = 0; i < CT::NA; ++i) {
+    for (int i = 0; i < NA_; ++i) {
       int voff = 0;
       if (!CONV) voff = a_off[i];
       else {
@@ -384,15 +392,15 @@ __global__ __launch_bounds__(512) void k_cgemm(BGemmArgs g, unsigned a_bytes, un
         if (g.cg.up | g.cg.dil) { hi >>= 1; wi >>= 1; }
         voff = ok ? 2 * ((a_pb[i] + hi * g.cg.Ws + wi) * g.lda + lc8) : 0x7ffffff0;
       }
-      dma16(rsA, iA + (wave + i * CT::NW) * 512, voff, 2 * (CONV ? c0 : k0));
+      dma16(rsA, iA + (dwave + i * NWD) * 512, voff, 2 * (CONV ? c0 : k0));
     }
 #pragma unroll
-    for (int i = 0; i < CT::NB; ++i) {
-      if (CT::EVEN || i + 1 < CT::NB) {
-        dma16(rsB, iB + (wave + i * CT::NW) * 512, b_off[i], 2 * k0);
+    for (int i = 0; i < NB_; ++i) {
+      if (EVEN_ || i + 1 < NB_) {
+        dma16(rsB, iB + (dwave + i * NWD) * 512, b_off[i], 2 * k0);
       } else {
-        const bool ok = wave + i * CT::NW < CT::NB_TOT;     // wave-uniform
-        dma16(ok ? rsB : rs0, ok ? iB + (wave + i * CT::NW) * 512 : dummy, b_off[i], 2 * k0);
+        const bool ok = dwave + i * NWD < CT::NB_TOT;     // wave-uniform
+        dma16(ok ? rsB : rs0, ok ? iB + (dwave + i * NWD) * 512 : dummy, b_off[i], 2 * k0);
       }
     }
     if (CONV) { c0 += BK; if (c0 >= g.cg.C) { c0 = 0; ++tap; } }
@@ -427,16 +435,38 @@ __global__ __launch_bounds__(512) void k_cgemm(BGemmArgs g, unsigned a_bytes, un
     }
   };
 
-  if (nk > 0) issue(0, kbeg);
-  if (nk > 1) issue(1, kbeg + BK);
-  int slot = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) wait_vmcnt<CT::NDMA>();
-    else             wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) issue(slot >= 1 ? slot - 1 : 2, kbeg + (kt + 2) * BK);       // (kt + 2) % 3
-    compute(slot);
-    slot = slot == 2 ? 0 : slot + 1;
+  if (NL) {
+    if (loader) {
+      if (nk > 0) issue(0, kbeg);
+      if (nk > 1) issue(1, kbeg + BK);
+      int slot = 0;
+      for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) wait_vmcnt<NDMA_>();
+        else             wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) issue(slot >= 1 ? slot - 1 : 2, kbeg + (kt + 2) * BK);
+        slot = slot == 2 ? 0 : slot + 1;
+      }
+      return;
+    }
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      compute(slot);
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+  } else {
+    if (nk > 0) issue(0, kbeg);
+    if (nk > 1) issue(1, kbeg + BK);
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) wait_vmcnt<NDMA_>();
+      else             wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < nk) issue(slot >= 1 ? slot - 1 : 2, kbeg + (kt + 2) * BK);       // (kt + 2) % 3
+      compute(slot);
+      slot = slot == 2 ? 0 : slot + 1;
+    }
   }
 
 #pragma unroll
@@ -458,6 +488,14 @@ template __global__ void k_cgemm<10, EPI_BF16, false>(BGemmArgs, unsigned, unsig
 template __global__ void k_cgemm<10, EPI_RES, false>(BGemmArgs, unsigned, unsigned);
 template __global__ void k_cgemm<10, EPI_BF16, true>(BGemmArgs, unsigned, unsigned);
 template __global__ void k_cgemm<10, EPI_RES, true>(BGemmArgs, unsigned, unsigned);
+template __global__ void k_cgemm<8, EPI_BF16, false, 4>(BGemmArgs, unsigned, unsigned);
+template __global__ void k_cgemm<8, EPI_RES, false, 4>(BGemmArgs, unsigned, unsigned);
+template __global__ void k_cgemm<8, EPI_BF16, true, 4>(BGemmArgs, unsigned, unsigned);
+template __global__ void k_cgemm<8, EPI_RES, true, 4>(BGemmArgs, unsigned, unsigned);
+template __global__ void k_cgemm<10, EPI_BF16, false, 4>(BGemmArgs, unsigned, unsigned);
+template __global__ void k_cgemm<10, EPI_RES, false, 4>(BGemmArgs, unsigned, unsigned);
+template __global__ void k_cgemm<10, EPI_BF16, true, 4>(BGemmArgs, unsigned, unsigned);
+template __global__ void k_cgemm<10, EPI_RES, true, 4>(BGemmArgs, unsigned, unsigned);
 
 // ---- the same pipeline for the products with a TRANSPOSED-READ operand (contraction index = matrix row):
 //   T[p][q] = sum_k P[.][.] Q[k][q],  tile 256 (p) x 128 (q) x 64 (k), 8 waves as 4 x 2 (64 x 64 each), three slots
@@ -500,13 +538,17 @@ struct TTile {
   static constexpr size_t LDS = (size_t)NSLOT * SLOT * sizeof(__bf16);
 };
 
-template <bool P_TR, bool CONVP, bool SWAP, int EPI>
-__global__ __launch_bounds__(512) void k_cgemm_t(BGemmArgs g, unsigned p_bytes, unsigned q_bytes, unsigned magic_w, unsigned magic_h) {
+template <bool P_TR, bool CONVP, bool SWAP, int EPI, int NL = 0>        // NL: loader waves, as k_cgemm
+__global__ __launch_bounds__(512 + 64 * NL) void k_cgemm_t(BGemmArgs g, unsigned p_bytes, unsigned q_bytes, unsigned magic_w, unsigned magic_h) {
   using TT = TTile;
   extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wp = wave >> 1, wq = wave & 1;
+  const int wp = (wave >> 1) & 3, wq = wave & 1;
+  constexpr int NWD = NL ? NL : TT::NW;                       // waves that issue DMA
+  constexpr int NP_ = TT::NP * TT::NW / NWD, NQ_ = TT::NQ * TT::NW / NWD, NDMA_ = NP_ + NQ_;
+  const bool loader = NL && wave >= TT::NW;
+  const int dwave = NL ? (wave - TT::NW) & (NWD - 1) : wave;
   // P / Q roles: the descriptor's A is P unless SWAP (then its B -- the im2col operand -- is P and the output is stored transposed)
   const __bf16* Pp = SWAP ? g.B : g.A;
   const __bf16* Qp = SWAP ? g.A : g.B;
@@ -533,11 +575,11 @@ __global__ __launch_bounds__(512) void k_cgemm_t(BGemmArgs g, unsigned p_bytes, 
   // ---- DMA plan.  Direct P image [256 p][64 k] (8 chunks per row, chunk ^= row & 7); transposed-read images [64 k][256 | 128]
   // (32 | 16 chunks per row, low four chunk bits ^= swz_tr(k row)).  Out-of-range columns of a ragged last tile read the next
   // row's data or zeros; their outputs are never stored.
-  int p_off[TT::NP], q_off[TT::NQ];
-  int p_kh[TT::NP], p_kw[TT::NP], p_ci[TT::NP];           // CONVP: tap and channel offset of the lane's column chunk (tap < 0: none)
+  int p_off[NP_], q_off[NQ_];
+  int p_kh[NP_], p_kw[NP_], p_ci[NP_];           // CONVP: tap and channel offset of the lane's column chunk (tap < 0: none)
 #pragma unroll
-  for (int i = 0; i < TT::NP; ++i) {
-    const int j = wave + i * TT::NW;
+  for (int i = 0; i < NP_; ++i) {
+    const int j = dwave + i * NWD;
     if (!P_TR) {
       const int row = j * 8 + (lane >> 3);
       p_off[i] = 2 * ((p0 + row) * ldp + (((lane & 7) ^ ((lane >> 3) & 7)) << 3));
@@ -557,8 +599,8 @@ __global__ __launch_bounds__(512) void k_cgemm_t(BGemmArgs g, unsigned p_bytes, 
     }
   }
 #pragma unroll
-  for (int i = 0; i < TT::NQ; ++i) {
-    const int j = wave + i * TT::NW;
+  for (int i = 0; i < NQ_; ++i) {
+    const int j = dwave + i * NWD;
     const int krow = 4 * j + (lane >> 4), pch = lane & 15;
     q_off[i] = 2 * (krow * ldq + q0 + ((pch ^ swz_tr(krow)) << 3));
   }
@@ -567,7 +609,7 @@ __global__ __launch_bounds__(512) void k_cgemm_t(BGemmArgs g, unsigned p_bytes, 
     __bf16* iP = smem + slot * TT::SLOT;
     __bf16* iQ = iP + TT::P_ELEMS;
 #pragma unroll
-    for (int i = 0; i < TT::NP; ++i) {
+    for (int i = 0; i < NP_; ++i) {
       int voff = p_off[i], soff = 0;
       if (!P_TR) soff = 2 * k0;
       else if (!CONVP) soff = 2 * k0 * ldp;
@@ -581,10 +623,10 @@ __global__ __launch_bounds__(512) void k_cgemm_t(BGemmArgs g, unsigned p_bytes, 
         if (g.cg.up | g.cg.dil) { hi >>= 1; wi >>= 1; }
         voff = ok ? 2 * (((int)b * g.cg.Hs * g.cg.Ws + hi * g.cg.Ws + wi) * ldp + p_ci[i]) : 0x7ffffff0;
       }
-      dma16(rsP, iP + (wave + i * TT::NW) * 512, voff, soff);
+      dma16(rsP, iP + (dwave + i * NWD) * 512, voff, soff);
     }
 #pragma unroll
-    for (int i = 0; i < TT::NQ; ++i) dma16(rsQ, iQ + (wave + i * TT::NW) * 512, q_off[i], 2 * k0 * ldq);
+    for (int i = 0; i < NQ_; ++i) dma16(rsQ, iQ + (dwave + i * NWD) * 512, q_off[i], 2 * k0 * ldq);
   };
 
   // ---- fragment addresses (bytes, relative to the slot): transposed-read fragments of 16 columns x 32 k
@@ -646,16 +688,38 @@ __global__ __launch_bounds__(512) void k_cgemm_t(BGemmArgs g, unsigned p_bytes, 
     });
   };
 
-  if (nk > 0) issue(0, kbeg);
-  if (nk > 1) issue(1, kbeg + BK);
-  int slot = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) wait_vmcnt<TT::NDMA>();
-    else             wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) issue(slot >= 1 ? slot - 1 : 2, kbeg + (kt + 2) * BK);
-    compute(slot);
-    slot = slot == 2 ? 0 : slot + 1;
+  if (NL) {
+    if (loader) {
+      if (nk > 0) issue(0, kbeg);
+      if (nk > 1) issue(1, kbeg + BK);
+      int slot = 0;
+      for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) wait_vmcnt<NDMA_>();
+        else             wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) issue(slot >= 1 ? slot - 1 : 2, kbeg + (kt + 2) * BK);
+        slot = slot == 2 ? 0 : slot + 1;
+      }
+      return;
+    }
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      compute(slot);
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+  } else {
+    if (nk > 0) issue(0, kbeg);
+    if (nk > 1) issue(1, kbeg + BK);
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) wait_vmcnt<NDMA_>();
+      else             wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < nk) issue(slot >= 1 ? slot - 1 : 2, kbeg + (kt + 2) * BK);
+      compute(slot);
+      slot = slot == 2 ? 0 : slot + 1;
+    }
   }
 
   if constexpr (SWAP) {
@@ -693,7 +757,12 @@ template __global__ void k_cgemm_t<false, false, false, EPI_BF16>(BGemmArgs, uns
 template __global__ void k_cgemm_t<false, false, false, EPI_RES>(BGemmArgs, unsigned, unsigned, unsigned, unsigned);
 template __global__ void k_cgemm_t<true, false, false, EPI_RES>(BGemmArgs, unsigned, unsigned, unsigned, unsigned);
 template __global__ void k_cgemm_t<true, true, true, EPI_RES>(BGemmArgs, unsigned, unsigned, unsigned, unsigned);
+template __global__ void k_cgemm_t<false, false, false, EPI_BF16, 4>(BGemmArgs, unsigned, unsigned, unsigned, unsigned);
+template __global__ void k_cgemm_t<false, false, false, EPI_RES, 4>(BGemmArgs, unsigned, unsigned, unsigned, unsigned);
+template __global__ void k_cgemm_t<true, false, false, EPI_RES, 4>(BGemmArgs, unsigned, unsigned, unsigned, unsigned);
+template __global__ void k_cgemm_t<true, true, true, EPI_RES, 4>(BGemmArgs, unsigned, unsigned, unsigned, unsigned);
 
+int g_conv_loader_waves = 3;       // sfron_gemm_loader_waves(): bit 0 k_cgemm, bit 1 k_cgemm_t in the loader-wave form (0 = every wave issues its own DMA)
 namespace {
 
 constexpr int TPB = 256;
@@ -1685,19 +1754,26 @@ inline bool need_attr(std::atomic<uint64_t>& mask) {
   const uint64_t bit = 1ull << (dev & 63);
   return (mask.fetch_or(bit) & bit) == 0;
 }
-template <int NT_, int EPI, bool CONV>
-int launch_cgemm_t(const BGemmArgs& g, unsigned a_bytes, unsigned b_bytes, int nsplit, hipStream_t s) {
+template <int NT_, int EPI, bool CONV, int NL>
+int launch_cgemm_nl(const BGemmArgs& g, unsigned a_bytes, unsigned b_bytes, int nsplit, hipStream_t s) {
   using CT = CTile<NT_>;
   static std::atomic<uint64_t> done{0};        // per instantiation, one bit per device
   if (need_attr(done)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cgemm<NT_, EPI, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT::LDS) !=
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cgemm<NT_, EPI, CONV, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT::LDS) !=
         hipSuccess)
       return (int)hipGetLastError();
   }
   const int ntm = g.M / CT::FBM, ntn = (g.N + CT::FBN - 1) / CT::FBN;
-  hipLaunchKernelGGL((k_cgemm<NT_, EPI, CONV>), dim3(ntm * ntn, nsplit), dim3(512), CT::LDS, s, g, a_bytes, b_bytes);
+  hipLaunchKernelGGL((k_cgemm<NT_, EPI, CONV, NL>), dim3(ntm * ntn, nsplit), dim3(512 + 64 * NL), CT::LDS, s, g, a_bytes, b_bytes);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
+}
+template <int NT_, int EPI, bool CONV>
+int launch_cgemm_t(const BGemmArgs& g, unsigned a_bytes, unsigned b_bytes, int nsplit, hipStream_t s) {
+  // a short contraction is all prologue: four loaders take twice as long to put the first two tiles in flight as eight waves do
+  const int nk = (g.kchunk > 0 ? g.kchunk : g.K) / BK;
+  return (g_conv_loader_waves & 1) && nk >= 8 ? launch_cgemm_nl<NT_, EPI, CONV, 4>(g, a_bytes, b_bytes, nsplit, s)
+                                              : launch_cgemm_nl<NT_, EPI, CONV, 0>(g, a_bytes, b_bytes, nsplit, s);
 }
 // the pipelined tile when the product qualifies (-1: it does not, the caller launches k_bgemm)
 int try_cgemm(const BGemmArgs& g, bool conv, size_t a_rows, int nsplit, hipStream_t s) {
@@ -1717,19 +1793,25 @@ int try_cgemm(const BGemmArgs& g, bool conv, size_t a_rows, int nsplit, hipStrea
 #undef SFRON_CG
 }
 
-template <bool P_TR, bool CONVP, bool SWAP, int EPI>
-int launch_cgemm_tt(const BGemmArgs& g, size_t p_bytes, size_t q_bytes, unsigned mw, unsigned mh, int nsplit, hipStream_t s) {
+template <bool P_TR, bool CONVP, bool SWAP, int EPI, int NL>
+int launch_cgemm_tt_nl(const BGemmArgs& g, size_t p_bytes, size_t q_bytes, unsigned mw, unsigned mh, int nsplit, hipStream_t s) {
   static std::atomic<uint64_t> done{0};
   if (need_attr(done)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cgemm_t<P_TR, CONVP, SWAP, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cgemm_t<P_TR, CONVP, SWAP, EPI, NL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)TTile::LDS) != hipSuccess)
       return (int)hipGetLastError();
   }
   const int np = SWAP ? g.N : g.M, nq = SWAP ? g.M : g.N;
   const int tiles = ((np + TTile::FBP - 1) / TTile::FBP) * ((nq + TTile::FBQ - 1) / TTile::FBQ);
-  hipLaunchKernelGGL((k_cgemm_t<P_TR, CONVP, SWAP, EPI>), dim3(tiles, nsplit), dim3(512), TTile::LDS, s, g, (unsigned)p_bytes, (unsigned)q_bytes, mw, mh);
+  hipLaunchKernelGGL((k_cgemm_t<P_TR, CONVP, SWAP, EPI, NL>), dim3(tiles, nsplit), dim3(512 + 64 * NL), TTile::LDS, s, g, (unsigned)p_bytes, (unsigned)q_bytes, mw, mh);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
+}
+template <bool P_TR, bool CONVP, bool SWAP, int EPI>
+int launch_cgemm_tt(const BGemmArgs& g, size_t p_bytes, size_t q_bytes, unsigned mw, unsigned mh, int nsplit, hipStream_t s) {
+  const int nk = (g.kchunk > 0 ? g.kchunk : g.K) / BK;
+  return (g_conv_loader_waves & 2) && nk >= 8 ? launch_cgemm_tt_nl<P_TR, CONVP, SWAP, EPI, 4>(g, p_bytes, q_bytes, mw, mh, nsplit, s)
+                                              : launch_cgemm_tt_nl<P_TR, CONVP, SWAP, EPI, 0>(g, p_bytes, q_bytes, mw, mh, nsplit, s);
 }
 inline bool fits31(size_t b) { return b < 0x7ffffff0ull; }
 // Linear input gradient (A direct [M][K], B read transposed [K][N]) on the pipelined tile; -1 = not eligible

@@ -15,6 +15,7 @@
 #include "common.h"
 #include "../../include/sfron.h"
 
+extern int g_conv_loader_waves;     // conv.hip: k_cgemm
 extern int g_fp8_loader_waves;      // fp8.hip: the fp8 tiles switch form together with the bf16 ones (sfron_gemm_loader_waves)
 #include <atomic>
 
@@ -1457,7 +1458,7 @@ int gemm_sumsq_lowrank(const uint16_t* a, const uint16_t* b, int R, int NM, int 
 }
 
 extern "C" // test / A-B hook: 4 = loader-wave form of the three-slot tiles (0 = every wave issues its share of the LDS-DMA); returns the old value
-int sfron_gemm_loader_waves(int n) { const int old = g_loader_waves; g_loader_waves = n == 9 ? 4 : (n >= 4 && n <= 7) ? n : 0; g_fp8_loader_waves = n == 9 ? 4 : 0; return old; }   // (9: as 4, and the fp8 tiles in their loader form too -- measured no faster)   // (5 / 6: weight gradients / dgrad only, A-B runs)
+int sfron_gemm_loader_waves(int n) { const int old = g_loader_waves; g_loader_waves = (n >= 9 && n <= 12) ? 4 : (n >= 4 && n <= 7) ? n : 0; g_fp8_loader_waves = n == 9 ? 4 : 0; g_conv_loader_waves = (n == 0 || n == 10) ? 0 : n == 11 ? 1 : n == 12 ? 2 : 3; return old; }   // (10 / 11 / 12: as 4, with none / only k_cgemm / only k_cgemm_t of the convolution tiles in the loader form)   // (9: as 4, and the fp8 tiles in their loader form too -- measured no faster)   // (5 / 6: weight gradients / dgrad only, A-B runs)
 
 int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
   SFRON_CHECK_ARG(d && d->A && d->B && d->M > 0 && d->N > 0 && d->K > 0);
