@@ -460,6 +460,37 @@ def test_unet_forward_backward_bitwise_reproducible():
         assert not bad, bad[:8]
 
 
+def test_conv_tiles_loader_wave_form_is_bit_identical_to_the_shared_wave_form():
+    """The pipelined convolution tiles (csrc/conv.hip k_cgemm / k_cgemm_t) run by default with four extra waves that issue every
+    LDS-DMA and do the im2col address arithmetic; the eight multiplying waves see the same tiles in the same order, so a whole
+    U-Net forward + backward (cifar10_sfron.yml model, batch 16: contractions of >= 8 K-tiles in all three
+    products) gives the same bits as the form in which every wave issues its share (sfron_gemm_loader_waves(10))."""
+    from sfron import _lib
+    _, model = _pair(dict(CIFAR, dropout=0.0), seed=41)
+    model.train()
+    g = torch.Generator().manual_seed(2)
+    B = 16
+    x, t = torch.randn(B, 3, 32, 32, generator=g).to(DEV), torch.randint(0, 1000, (B,), generator=g).float().to(DEV)
+    c, keep = torch.randint(0, 10, (B,), generator=g).to(DEV), torch.ones(B, dtype=torch.uint8, device=DEV)
+    w = torch.randn(B, 3, 32, 32, generator=g).to(DEV)
+    L = _lib.lib()
+    res = {}
+    old = L.sfron_gemm_loader_waves(10)
+    try:
+        assert old == 4
+        for form in (10, 4):
+            L.sfron_gemm_loader_waves(form)
+            out, bwd = model._run(x, t, c, keep, None, need_grad=True)
+            bwd(w.clone())
+            torch.cuda.synchronize()
+            res[form] = (out.clone(), model.grads.clone())
+    finally:
+        L.sfron_gemm_loader_waves(old)
+    assert torch.isfinite(res[4][0]).all() and torch.equal(res[10][0], res[4][0])
+    bad = [n for n in model.index if not torch.equal(model.view(res[10][1], n), model.view(res[4][1], n))]
+    assert not bad, bad[:8]
+
+
 def test_unet_test_mode_guidance_matches_oracle():
     ref, model = _pair(SMALL, seed=5)
     ref.eval(); model.eval()
