@@ -316,6 +316,50 @@ __global__ __launch_bounds__(TPB) void k_reduce_chunks(const float* __restrict__
   *o = accumulate ? *o + s : s;
 }
 
+// the same for MANY partials of FEW columns (bias gradients: 512 row chunks of a 128-wide d_out): one thread per column walks
+// per_group dependent rounds of loads on one or two waves while the rest of the chip idles (6.7 us for 512 x 128).  Here a
+// workgroup of 16 waves serves 64 columns, wave w sums the contiguous range [per_group w / 16, per_group (w + 1) / 16) with 8 loads
+// in flight, and the 16 range sums meet in LDS in wave order: a fixed order again (not the order of k_reduce_chunks)
+constexpr int RC_WAVES = 16;
+__global__ __launch_bounds__(64 * RC_WAVES) void k_reduce_chunks_wide(const float* __restrict__ P, int per_group, int D, float* __restrict__ out,
+                                                                      int ldout, int accumulate) {
+  __shared__ float sh[RC_WAVES][64];
+  const int g = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int j0 = (int)((long)per_group * wave / RC_WAVES), j1 = (int)((long)per_group * (wave + 1) / RC_WAVES);
+  float s = 0.f;
+  if (c < D) {
+    const float* p = P + (size_t)g * per_group * D + c;
+    int j = j0;
+    for (; j + 8 <= j1; j += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(j + u) * D];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; j < j1; ++j) s += p[(size_t)j * D];
+  }
+  sh[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < D) {
+    float a = sh[0][lane];
+#pragma unroll
+    for (int w = 1; w < RC_WAVES; ++w) a += sh[w][lane];
+    float* o = out + (size_t)g * ldout + c;
+    *o = accumulate ? *o + a : a;
+  }
+}
+// which of the two forms a reduction takes (a pure function of its shape: the same call always sums in the same order)
+static inline bool reduce_chunks_wide(int groups, int per_group, int D) { return per_group >= 64 && (long)cdiv(D, 64) * groups <= 512; }
+static inline void launch_reduce_chunks(const float* partials, int groups, int per_group, int D, float* out, int ldout, int accumulate,
+                                        hipStream_t hs) {
+  if (reduce_chunks_wide(groups, per_group, D))
+    hipLaunchKernelGGL(k_reduce_chunks_wide, dim3(cdiv(D, 64), groups), dim3(64 * RC_WAVES), 0, hs, partials, per_group, D, out, ldout, accumulate);
+  else
+    hipLaunchKernelGGL(k_reduce_chunks, dim3(cdiv(D, TPB), groups), dim3(TPB), 0, hs, partials, per_group, D, out, ldout, accumulate);
+}
+
 // out[c] = sum_b w[b * ldw + c] * sum_{j < per_group} P[(b * per_group + j) * D + c]   (bias grad behind a gate)
 __global__ __launch_bounds__(TPB) void k_weighted_reduce(const float* __restrict__ P, int groups, int per_group, int D,
                                                          const float* __restrict__ w, int ldw, float* __restrict__ out) {
@@ -544,8 +588,7 @@ int sfron_ln_gate_bwd(const uint16_t* d_out, const float* x, const float* mean, 
 int sfron_reduce_chunks(const float* partials, int groups, int per_group, int D, float* out, int ldout, int accumulate,
                         void* stream) {
   SFRON_CHECK_ARG(partials && out && groups > 0 && per_group > 0 && D > 0);
-  hipLaunchKernelGGL(k_reduce_chunks, dim3(cdiv(D, TPB), groups), dim3(TPB), 0, (hipStream_t)stream, partials, per_group, D,
-                     out, ldout, accumulate);
+  launch_reduce_chunks(partials, groups, per_group, D, out, ldout, accumulate, (hipStream_t)stream);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }
@@ -606,7 +649,7 @@ int sfron_colsum(const void* X, int is_bf16, int M, int N, int ld, float* partia
   else
     hipLaunchKernelGGL((k_colsum_partial<float, 4>), dim3(cdiv(N, 256), chunks), dim3(TPB), 0, hs, (const float*)X, M, N, ld, rpb, partials);
   SFRON_LAUNCH_STATUS();
-  hipLaunchKernelGGL(k_reduce_chunks, dim3(cdiv(N, TPB), 1), dim3(TPB), 0, hs, partials, chunks, N, out, N, 0);
+  launch_reduce_chunks(partials, 1, chunks, N, out, N, 0, hs);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }
