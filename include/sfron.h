@@ -330,6 +330,13 @@ int sfron_groupnorm_fwd(const float* x, int ldx, const float* gamma, const float
 int sfron_groupnorm_bwd(const float* dy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
                         const float* rstd, int B, int HW, int C, int groups, int swish, const uint8_t* drop_mask, float drop_scale,
                         float* dx, int lddx, int accumulate, float* part_gamma, float* part_beta, void* scratch, void* stream);
+/* the same with one more term: dx (+)= extra + gradient wrt x, extra fp32 [B * HW][ld_extra] (the residual branch's share of x's
+ * gradient -- ResnetBlock `x + h`, DDPM/models/diffusion.py:145 -- that a separate pass would add; same bits as
+ * sfron_copy_cols(extra -> dx, accumulate) followed by sfron_groupnorm_bwd(accumulate = 1)).  extra == NULL: sfron_groupnorm_bwd. */
+int sfron_groupnorm_bwd_res(const float* dy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
+                            const float* rstd, int B, int HW, int C, int groups, int swish, const uint8_t* drop_mask, float drop_scale,
+                            float* dx, int lddx, int accumulate, const float* extra, int ld_extra, float* part_gamma, float* part_beta,
+                            void* scratch, void* stream);
 int64_t sfron_groupnorm_scratch_bytes(int B, int HW, int C, int groups);
 /* p = bf16(softmax(scale * s)) over rows of length n; ds = bf16(scale * p * (dp - sum(p * dp)))   (AttnBlock, :168-186) */
 int sfron_softmax_fwd(const float* s, int64_t rows, int n, int n_valid /* keys; columns beyond get probability 0 */, float scale, uint16_t* p,

@@ -152,6 +152,8 @@ _PROTOS.update({
     "sfron_groupnorm_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, c_float, _P, _P, _P, _P, _S]),
     "sfron_groupnorm_bwd": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, c_int, c_int,
                                     _P, _P, _P, _S]),
+    "sfron_groupnorm_bwd_res": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, c_int, c_int,
+                                        _P, c_int, _P, _P, _P, _S]),
     "sfron_groupnorm_scratch_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "sfron_softmax_fwd": (c_int, [_P, c_int64, c_int, c_int, c_float, _P, _S]),
     "sfron_layernorm_fwd": (c_int, [_P, _P, _P, c_int64, c_int, c_float, _P, _P, _P, _S]),

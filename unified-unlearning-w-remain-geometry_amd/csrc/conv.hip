@@ -1193,7 +1193,8 @@ __global__ __launch_bounds__(GNB) void k_gn2_bwd_apply(const float* __restrict__
                                                        const float* __restrict__ mean, const float* __restrict__ rstd, int HW, int C, int G,
                                                        int swish, const uint8_t* __restrict__ mask, float drop_scale, int nchunk,
                                                        const float* __restrict__ part, float* __restrict__ dx, int lddx, int accumulate,
-                                                       float* __restrict__ pg, float* __restrict__ pb) {
+                                                       float* __restrict__ pg, float* __restrict__ pb, const float* __restrict__ extra,
+                                                       int ldextra) {
   extern __shared__ float shf[];                // [C][2] channel sums, then [G][2] group means
   const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk, cg = C / G;
   float* kk = shf + 2 * C;
@@ -1239,6 +1240,7 @@ __global__ __launch_bounds__(GNB) void k_gn2_bwd_apply(const float* __restrict__
   const float* dyb = dy + (size_t)b * HW * C;
   const uint8_t* mb = mask ? mask + (size_t)b * HW * C : nullptr;
   float* dxb = dx + (size_t)b * HW * lddx;
+  const float* exb = extra ? extra + (size_t)b * HW * ldextra : nullptr;
   for (int p = p0 + m.r; p < p1; p += m.rpp) {
 #pragma unroll
     for (int j = 0; j < GN_MAXQ; ++j)
@@ -1253,6 +1255,11 @@ __global__ __launch_bounds__(GNB) void k_gn2_bwd_apply(const float* __restrict__
         float4* op = reinterpret_cast<float4*>(dxb + (size_t)p * lddx + c0);
         float o[4] = {0.f, 0.f, 0.f, 0.f};
         if (accumulate) { const float4 c = *op; o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w; }
+        if (exb) {             // the term a separate dx (+)= extra pass would have added first: (dx + extra) + this layer's gradient
+          const float4 c = *reinterpret_cast<const float4*>(exb + (size_t)p * ldextra + c0);
+          o[0] += c.x; o[1] += c.y; o[2] += c.z; o[3] += c.w;
+        }
+        const bool acc = accumulate || exb;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float xh = (xv[e] - mu[j][e]) * rs[j][e];
@@ -1260,7 +1267,7 @@ __global__ __launch_bounds__(GNB) void k_gn2_bwd_apply(const float* __restrict__
           if (mb) d = mke[e] ? d * drop_scale : 0.f;
           if (swish) d *= silu_grad(xh * ga[j][e] + be[j][e]);
           const float vv = rs[j][e] * (d * ga[j][e] - k1[j][e] - xh * k2[j][e]);
-          o[e] = accumulate ? o[e] + vv : vv;
+          o[e] = acc ? o[e] + vv : vv;
         }
         *op = make_float4(o[0], o[1], o[2], o[3]);
       }
@@ -2150,18 +2157,32 @@ int sfron_groupnorm_fwd(const float* x, int ldx, const float* gamma, const float
 int sfron_groupnorm_bwd(const float* dy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
                         const float* rstd, int B, int HW, int C, int groups, int swish, const uint8_t* drop_mask, float drop_scale,
                         float* dx, int lddx, int accumulate, float* part_gamma, float* part_beta, void* scratch, void* stream) {
+  return sfron_groupnorm_bwd_res(dy, x, ldx, gamma, beta, mean, rstd, B, HW, C, groups, swish, drop_mask, drop_scale, dx, lddx, accumulate, nullptr, 0,
+                                 part_gamma, part_beta, scratch, stream);
+}
+int sfron_groupnorm_bwd_res(const float* dy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
+                            const float* rstd, int B, int HW, int C, int groups, int swish, const uint8_t* drop_mask, float drop_scale,
+                            float* dx, int lddx, int accumulate, const float* extra, int ld_extra, float* part_gamma, float* part_beta,
+                            void* scratch, void* stream) {
   SFRON_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && part_gamma && part_beta && groups > 0 && C % groups == 0);
   const int cg = C / groups;
   SFRON_CHECK_ARG(cg <= TPB);
-  if (gn2_ok(ldx, lddx, C, groups, scratch) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0 &&
-      (!drop_mask || ((uintptr_t)drop_mask & 3) == 0)) {
+  SFRON_CHECK_ARG(!extra || (ld_extra >= C && extra != dx));
+  const bool fused = gn2_ok(ldx, lddx, C, groups, scratch) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0 &&
+                     (!drop_mask || ((uintptr_t)drop_mask & 3) == 0);
+  if (extra && !(fused && ld_extra % 4 == 0 && ((uintptr_t)extra & 15) == 0)) {       // the same sum as two passes
+    const int rc = sfron_copy_cols(extra, ld_extra, (int64_t)B * HW, C, dx, lddx, accumulate, stream);
+    if (rc) return rc;
+    extra = nullptr; accumulate = 1;
+  }
+  if (fused) {
     const int nchunk = gn_chunks(B, HW);
     hipLaunchKernelGGL(k_gn2_bwd_stats, dim3(B * nchunk), dim3(GNB), gn2_lds(C, sizeof(float)), (hipStream_t)stream, dy, x, ldx, gamma, beta, mean, rstd,
                        HW, C, groups, swish, drop_mask, drop_scale, nchunk, (float*)scratch);
     SFRON_LAUNCH_STATUS();
     hipLaunchKernelGGL(k_gn2_bwd_apply, dim3(B * nchunk), dim3(GNB), (size_t)(3 * C + 2 * groups) * sizeof(float), (hipStream_t)stream, dy, x, ldx, gamma,
                        beta, mean, rstd, HW, C, groups, swish, drop_mask, drop_scale, nchunk, (const float*)scratch, dx, lddx, accumulate,
-                       part_gamma, part_beta);
+                       part_gamma, part_beta, extra, ld_extra);
     SFRON_LAUNCH_STATUS();
     return SFRON_OK;
   }

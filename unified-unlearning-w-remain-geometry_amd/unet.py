@@ -289,13 +289,16 @@ class _TapeNet(nn.Module):
         check(_L().sfron_groupnorm_fwd(ptr(x.t), x.C, gam, bet, x.B, x.H * x.W, x.C, 32, eps, int(swish), ptr(drop_mask), scale, ptr(y),
                                        ptr(mean), ptr(rstd), ptr(ws), stream_ptr()), "groupnorm_fwd")
 
-        def bwd(dy):           # dy: fp32 [rows][C]
+        def bwd(dy, extra=None, ld_extra=0):
+            """dy: fp32 [rows][C]; extra: fp32 [rows][ld_extra], one more term of x's gradient (the residual branch's) added in
+            the same pass instead of a separate x.grad (+)= extra."""
             gbuf, acc = x.grad_buf()
             pg = torch.empty(x.B, x.C, dtype=torch.float32, device=dev)
             pb = torch.empty_like(pg)
             ws2 = torch.empty(_L().sfron_groupnorm_scratch_bytes(x.B, x.H * x.W, x.C, 32) // 8 + 2, dtype=torch.float64, device=dev)
-            check(_L().sfron_groupnorm_bwd(ptr(dy), ptr(x.t), x.C, gam, bet, ptr(mean), ptr(rstd), x.B, x.H * x.W, x.C, 32, int(swish),
-                                           ptr(drop_mask), scale, ptr(gbuf), x.C, acc, ptr(pg), ptr(pb), ptr(ws2), stream_ptr()), "groupnorm_bwd")
+            check(_L().sfron_groupnorm_bwd_res(ptr(dy), ptr(x.t), x.C, gam, bet, ptr(mean), ptr(rstd), x.B, x.H * x.W, x.C, 32, int(swish),
+                                               ptr(drop_mask), scale, ptr(gbuf), x.C, acc, ptr(extra), ld_extra, ptr(pg), ptr(pb), ptr(ws2),
+                                               stream_ptr()), "groupnorm_bwd")
             check(_L().sfron_reduce2(ptr(pg), ptr(pb), 1, x.B, x.C, self._g(name + ".weight"), x.C, self._g(name + ".bias"), x.C, stream_ptr()), "reduce2")
         return y, bwd
 
@@ -427,20 +430,14 @@ class _TapeNet(nn.Module):
         def bwd():
             d_out = out.grad
             d_a2 = conv2_b(d_out)
-            if sc_b is None:
-                g, acc = x.grad_buf()
-                check(_L().sfron_copy_cols(ptr(d_out), cout, x.rows, cout, ptr(g), cout, acc, stream_ptr()), "copy_cols")
-            else:
-                dx = sc_b(d_out, cout)
-                g, acc = x.grad_buf()
-                check(_L().sfron_copy_cols(ptr(dx), cin, x.rows, cin, ptr(g), cin, acc, stream_ptr()), "copy_cols")
+            d_skip = d_out if sc_b is None else sc_b(d_out, cout)      # the shortcut's share of x.grad: added by norm1's backward pass below
             gn2_b(d_a2)                                   # -> h1.grad
             dh1 = h1.grad
             check(_L().sfron_sample_colsum(ptr(dh1), cout, B, H * W, cout, d_proj.data_ptr() + 4 * c0, self.proj_total, ptr(self._cs), self._cs.numel(),
                                            stream_ptr()),
                   "sample_colsum")
             d_a1 = conv1_b(dh1)
-            gn1_b(d_a1)                                   # -> x.grad (+=)
+            gn1_b(d_a1, d_skip, cin)                      # -> x.grad (+)= d_skip + norm1's gradient
         tape.append(bwd)
         return out
 
@@ -638,8 +635,6 @@ class Conditional_Model(_TapeNet):
         def bwd():
             q, k, v = qkv.data_ptr(), qkv.data_ptr() + 2 * C, qkv.data_ptr() + 4 * C     # (the closure keeps qkv alive)
             d_out = out.grad
-            g, acc = x.grad_buf()
-            check(_L().sfron_copy_cols(ptr(d_out), C, rows, C, ptr(g), C, acc, stream_ptr()), "copy_cols")          # residual
             d_bf = cast_rows(d_out, C, rows, C, dev)
             colsum_f32(d_out, rows, C, C, self._g(name + ".proj_out.bias"), self._cs)
             bgemm(d_bf, O, C, C, rows, lda=C, ldb=C, a_t=True, b_t=True, c_f32=self._g(name + ".proj_out.weight"), ldc=C)
@@ -658,7 +653,7 @@ class Conditional_Model(_TapeNet):
             bgemm(dqkv, hn, 3 * C, C, rows, lda=3 * C, ldb=C, a_t=True, b_t=True, c_f32=self._g(name + ".q.weight"), ldc=C)
             d_hn = torch.empty(rows, C, dtype=torch.float32, device=dev)
             bgemm(dqkv, self._w(name + ".q.weight"), rows, C, 3 * C, lda=3 * C, ldb=C, b_t=True, c_f32=d_hn, ldc=C)
-            gn_b(d_hn)
+            gn_b(d_hn, d_out, C)                          # x.grad (+)= d_out (residual) + the norm's gradient
         tape.append(bwd)
         return out
 
