@@ -335,8 +335,9 @@ def main():
                          "traffic": traffic, "flops_per_launch": wg_flops, "avg_launch_ms": wg_ms, "launches_timed": n_wp,
                          "others": {
                              "fwd_fc1_gelu": {"bound": "mfma", "kernel": f"k_gemm_pipe<4,2,4,6,false,false,2,1,2>: Mlp.fc1 + GELU-tanh [{M}x{D}]x[{D}x{F}], block 0 of "
-                                              "every forward pass (main stream, nothing beside it)", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
-                                              "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": committed_traffic("r03_fc1_traffic.json"),
+                                              "every forward pass (main stream, nothing beside it; not launched by the fp8 path)", "achieved": achieved if n_probe else None,
+                                              "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": (achieved / MFMA_BF16_PEAK_TFLOPS) if n_probe else None,
+                                              "traffic": committed_traffic("r03_fc1_traffic.json") if n_probe else None,
                                               "flops_per_launch": fc1_flops, "avg_launch_ms": avg_ms, "launches_timed": n_probe},
                              "hbm": {"bound": "hbm", "kernel": "remain-stage parameter sweep: k_masked_clip_adam (AdamW + EMA + bf16 shadow, 38 B/param) over the flat arenas "
                                      "+ k_adam_lowrank over the adaLN matrix (gradient formed from its two factors: 34 B/param)", "achieved": sw_ach, "peak": HBM_PEAK_GBS,

@@ -485,7 +485,9 @@ int sfron_attn_bwd_form(int form);
 /* Process-wide form of the three-slot GEMM tiles (256 x 144 forward / dgrad, 192 x 192 weight gradient): 4 = four extra LOADER waves per
  * workgroup issue every LDS-DMA piece and the eight multiplying waves none (csrc/gemm.hip k_gemm_pipe NL; taken by the dgrad and
  * weight-gradient layouts, where it measured faster) -- the default; 0 = every wave issues its share (5 / 6: weight gradients / dgrad
- * only, 9: the fp8 tiles in their loader form too -- for A-B runs).  Same results bit for bit (same products, same summation order).  Returns the previous value. */
+ * only, 9: the fp8 tiles in their loader form too -- for A-B runs).  The pipelined convolution tiles (csrc/conv.hip k_cgemm / k_cgemm_t,
+ * contractions of >= 8 K-tiles) follow: loader form unless n == 0 (10 / 11 / 12: as 4 with none / only k_cgemm / only k_cgemm_t of
+ * them in the loader form).  Same results bit for bit (same products, same summation order).  Returns the previous value. */
 int sfron_gemm_loader_waves(int n);
 
 /* ------------------------------------------------------------------ whole-model DiT pass (dit_engine.hip)

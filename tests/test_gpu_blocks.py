@@ -230,3 +230,24 @@ def test_attention_backward_with_qkv_bias_partials(B, T, H, hd):
     # against the column sums of the bf16 output itself (what the old column-sum launch formed): same numbers up to the rounding
     old = plain.float().view(B, T, 3 * D).sum(1)
     assert ((part - old).abs() <= 2.0 ** -8 * plain.float().abs().view(B, T, 3 * D).sum(1) + 1e-6).all()
+
+
+@pytest.mark.parametrize("groups,per,D", [(1, 512, 128), (3, 64, 200), (1, 100, 1280), (2, 63, 128), (1, 7, 4608), (64, 96, 320)])
+def test_reduce_chunks_both_forms(groups, per, D):
+    """out[g][c] (+)= sum_j P[g][j][c]: the one-thread-per-column form and the 16-waves-per-64-columns form that many partials of few
+    columns take (csrc/norm.hip reduce_chunks_wide: per_group >= 64 and at most 512 workgroups); each sums in a fixed order -- the same
+    bits on every call -- and agrees with a float64 sum to fp32 rounding of the running sums."""
+    from sfron import ops
+    gen = torch.Generator().manual_seed(groups * per + D)
+    P = torch.randn(groups, per, D, generator=gen).to(DEV)
+    ref = P.double().sum(1)
+    ld = D + 4
+    for acc in (False, True):
+        out = torch.full((groups, ld), 2.0, dtype=torch.float32, device=DEV)
+        ops.reduce_chunks(P, groups, per, D, out, ld, accumulate=acc)
+        again = torch.full((groups, ld), 2.0, dtype=torch.float32, device=DEV)
+        ops.reduce_chunks(P, groups, per, D, again, ld, accumulate=acc)
+        assert torch.equal(out, again)
+        assert float((out[:, D:] - 2.0).abs().max()) == 0.0                      # columns beyond D untouched
+        want = ref + (2.0 if acc else 0.0)
+        close(out[:, :D], want, rtol=1e-5, atol=1e-5 * per ** 0.5)

@@ -159,6 +159,21 @@ def test_groupnorm_swish_dropout_fwd_bwd(C, HW, swish, drop, form):
     np.testing.assert_allclose(dx.cpu().numpy() - 0.5, xt.grad.numpy(), rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(pg.sum(0).cpu().numpy(), gt.grad.numpy(), rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(pb.sum(0).cpu().numpy(), bt.grad.numpy(), rtol=2e-4, atol=2e-4)
+    # the residual form: dx (+)= extra + gradient in ONE pass gives the bits of  dx (+)= extra  followed by  dx += gradient
+    # (extra read with its own row stride: a column slice of a wider buffer)
+    wide = torch.randn(B * HW, C + 8, generator=g).to(DEV)
+    extra = wide[:, 8:]
+    for acc in (0, 1):
+        two = torch.full((B * HW, C), 0.25, dtype=torch.float32, device=DEV)
+        one = two.clone()
+        check(L.sfron_copy_cols(extra.data_ptr(), C + 8, B * HW, C, ptr(two), C, acc, stream_ptr()), "copy_cols")
+        check(L.sfron_groupnorm_bwd(ptr(dy_d), ptr(xd), C, ptr(gd), ptr(bd), ptr(mean), ptr(rstd), B, HW, C, 32, swish, ptr(md), scale,
+                                    ptr(two), C, 1, ptr(pg), ptr(pb), ptr(ws), stream_ptr()), "gn_bwd")
+        check(L.sfron_groupnorm_bwd_res(ptr(dy_d), ptr(xd), C, ptr(gd), ptr(bd), ptr(mean), ptr(rstd), B, HW, C, 32, swish, ptr(md), scale,
+                                        ptr(one), C, acc, extra.data_ptr(), C + 8, ptr(pg), ptr(pb), ptr(ws), stream_ptr()), "gn_bwd_res")
+        assert torch.equal(one, two)
+        ref = xt.grad.numpy() + extra.cpu().numpy() + (0.25 if acc else 0.0)
+        np.testing.assert_allclose(one.cpu().numpy(), ref, rtol=2e-4, atol=2e-5)
 
 
 @pytest.mark.parametrize("M,N,K,out", [(512, 320, 1280, "f32"), (1024, 640, 320, "bf16"), (256, 200, 128, "f32"), (768, 2560, 64, "bf16")])
