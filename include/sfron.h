@@ -337,6 +337,16 @@ int sfron_groupnorm_bwd_res(const float* dy, const float* x, int ldx, const floa
                             const float* rstd, int B, int HW, int C, int groups, int swish, const uint8_t* drop_mask, float drop_scale,
                             float* dx, int lddx, int accumulate, const float* extra, int ld_extra, float* part_gamma, float* part_beta,
                             void* scratch, void* stream);
+/* the backward pass for an x with ONE consumer whose gradient feeds a GEMM: dx leaves as the bf16 operand [B * HW][C] (no fp32 copy),
+ * with its column sums per (sample, pixel chunk): col_partials fp32 [B][sfron_groupnorm_chunks(B, HW)][C] -- summed over everything
+ * the bias gradient of the layer that produced x, summed per sample the gradient of a per-sample vector added to x (the
+ * temb / class-embedding projection of ResnetBlock, DDPM/models/diffusion.py:120-124): sfron_reduce_chunks finishes both.  Replaces
+ * sfron_groupnorm_bwd + sfron_cast_rows_colsum + sfron_sample_colsum over an fp32 dx.  Needs sfron_groupnorm_bwd_cast_ok(). */
+int sfron_groupnorm_bwd_cast(const float* dy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
+                             const float* rstd, int B, int HW, int C, int groups, int swish, const uint8_t* drop_mask, float drop_scale,
+                             uint16_t* dx_bf16, float* col_partials, float* part_gamma, float* part_beta, void* scratch, void* stream);
+int sfron_groupnorm_bwd_cast_ok(int ldx, int C, int groups);
+int sfron_groupnorm_chunks(int B, int HW);
 int64_t sfron_groupnorm_scratch_bytes(int B, int HW, int C, int groups);
 /* p = bf16(softmax(scale * s)) over rows of length n; ds = bf16(scale * p * (dp - sum(p * dp)))   (AttnBlock, :168-186) */
 int sfron_softmax_fwd(const float* s, int64_t rows, int n, int n_valid /* keys; columns beyond get probability 0 */, float scale, uint16_t* p,

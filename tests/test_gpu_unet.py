@@ -174,6 +174,22 @@ def test_groupnorm_swish_dropout_fwd_bwd(C, HW, swish, drop, form):
         assert torch.equal(one, two)
         ref = xt.grad.numpy() + extra.cpu().numpy() + (0.25 if acc else 0.0)
         np.testing.assert_allclose(one.cpu().numpy(), ref, rtol=2e-4, atol=2e-5)
+    # the operand form: dx as bf16 (the rounding of the fp32 result, bit for bit) + its column sums per (sample, chunk)
+    if form == "rows" and L.sfron_groupnorm_bwd_cast_ok(C, C, 32):
+        plain = torch.empty(B * HW, C, dtype=torch.float32, device=DEV)
+        check(L.sfron_groupnorm_bwd(ptr(dy_d), ptr(xd), C, ptr(gd), ptr(bd), ptr(mean), ptr(rstd), B, HW, C, 32, swish, ptr(md), scale,
+                                    ptr(plain), C, 0, ptr(pg), ptr(pb), ptr(ws), stream_ptr()), "gn_bwd")
+        nch = L.sfron_groupnorm_chunks(B, HW)
+        d16 = torch.empty(B * HW, C, dtype=torch.bfloat16, device=DEV)
+        cpart = torch.full((B * nch, C), float("nan"), dtype=torch.float32, device=DEV)
+        pg2, pb2 = torch.empty_like(pg), torch.empty_like(pb)
+        check(L.sfron_groupnorm_bwd_cast(ptr(dy_d), ptr(xd), C, ptr(gd), ptr(bd), ptr(mean), ptr(rstd), B, HW, C, 32, swish, ptr(md), scale,
+                                         ptr(d16), ptr(cpart), ptr(pg2), ptr(pb2), ptr(ws), stream_ptr()), "gn_bwd_cast")
+        assert torch.equal(d16, plain.to(torch.bfloat16)) and torch.equal(pg2, pg) and torch.equal(pb2, pb)
+        per_sample = cpart.view(B, nch, C).double().sum(1)
+        np.testing.assert_allclose(per_sample.cpu().numpy(), plain.view(B, HW, C).double().sum(1).cpu().numpy(), rtol=1e-5, atol=1e-5 * HW ** 0.5)
+    else:
+        assert form != "rows" or C > 2048
 
 
 @pytest.mark.parametrize("M,N,K,out", [(512, 320, 1280, "f32"), (1024, 640, 320, "bf16"), (256, 200, 128, "f32"), (768, 2560, 64, "bf16")])

@@ -154,6 +154,9 @@ _PROTOS.update({
                                     _P, _P, _P, _S]),
     "sfron_groupnorm_bwd_res": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, c_int, c_int,
                                         _P, c_int, _P, _P, _P, _S]),
+    "sfron_groupnorm_bwd_cast": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, _P, _P, _P, _P, _S]),
+    "sfron_groupnorm_bwd_cast_ok": (c_int, [c_int, c_int, c_int]),
+    "sfron_groupnorm_chunks": (c_int, [c_int, c_int]),
     "sfron_groupnorm_scratch_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "sfron_softmax_fwd": (c_int, [_P, c_int64, c_int, c_int, c_float, _P, _S]),
     "sfron_layernorm_fwd": (c_int, [_P, _P, _P, c_int64, c_int, c_float, _P, _P, _P, _S]),

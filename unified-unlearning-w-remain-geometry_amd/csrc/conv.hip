@@ -1194,7 +1194,10 @@ __global__ __launch_bounds__(GNB) void k_gn2_bwd_apply(const float* __restrict__
                                                        int swish, const uint8_t* __restrict__ mask, float drop_scale, int nchunk,
                                                        const float* __restrict__ part, float* __restrict__ dx, int lddx, int accumulate,
                                                        float* __restrict__ pg, float* __restrict__ pb, const float* __restrict__ extra,
-                                                       int ldextra) {
+                                                       int ldextra, __bf16* __restrict__ dx16, float* __restrict__ colpart) {
+  // dx16 / colpart (sfron_groupnorm_bwd_cast): the gradient also (or only: dx == nullptr) as the bf16 GEMM operand [rows][C] of the
+  // convolution that produced x, and its column sums per (sample, chunk) -- that layer's bias gradient and, per sample, the gradient
+  // of a per-sample vector added to x -- which a cast pass and two column-sum passes over an fp32 dx would form otherwise
   extern __shared__ float shf[];                // [C][2] channel sums, then [G][2] group means
   const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk, cg = C / G;
   float* kk = shf + 2 * C;
@@ -1239,8 +1242,14 @@ __global__ __launch_bounds__(GNB) void k_gn2_bwd_apply(const float* __restrict__
   const float* xb = x + (size_t)b * HW * ldx;
   const float* dyb = dy + (size_t)b * HW * C;
   const uint8_t* mb = mask ? mask + (size_t)b * HW * C : nullptr;
-  float* dxb = dx + (size_t)b * HW * lddx;
+  float* dxb = dx ? dx + (size_t)b * HW * lddx : nullptr;
+  __bf16* d16b = dx16 ? dx16 + (size_t)b * HW * C : nullptr;
   const float* exb = extra ? extra + (size_t)b * HW * ldextra : nullptr;
+  float cs[GN_MAXQ][4];
+#pragma unroll
+  for (int j = 0; j < GN_MAXQ; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cs[j][e] = 0.f;
   for (int p = p0 + m.r; p < p1; p += m.rpp) {
 #pragma unroll
     for (int j = 0; j < GN_MAXQ; ++j)
@@ -1252,7 +1261,7 @@ __global__ __launch_bounds__(GNB) void k_gn2_bwd_apply(const float* __restrict__
         if (mb) mk = *reinterpret_cast<const uchar4*>(mb + (size_t)p * C + c0);
         const float xv[4] = {v.x, v.y, v.z, v.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
         const uint8_t mke[4] = {mk.x, mk.y, mk.z, mk.w};
-        float4* op = reinterpret_cast<float4*>(dxb + (size_t)p * lddx + c0);
+        float4* op = dxb ? reinterpret_cast<float4*>(dxb + (size_t)p * lddx + c0) : nullptr;
         float o[4] = {0.f, 0.f, 0.f, 0.f};
         if (accumulate) { const float4 c = *op; o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w; }
         if (exb) {             // the term a separate dx (+)= extra pass would have added first: (dx + extra) + this layer's gradient
@@ -1269,8 +1278,29 @@ __global__ __launch_bounds__(GNB) void k_gn2_bwd_apply(const float* __restrict__
           const float vv = rs[j][e] * (d * ga[j][e] - k1[j][e] - xh * k2[j][e]);
           o[e] = acc ? o[e] + vv : vv;
         }
-        *op = make_float4(o[0], o[1], o[2], o[3]);
+        if (op) *op = make_float4(o[0], o[1], o[2], o[3]);
+        if (d16b) *reinterpret_cast<bf16x4*>(d16b + (size_t)p * C + c0) = bf16x4{f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+        if (colpart) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cs[j][e] += o[e];
+        }
       }
+  }
+  if (colpart) {                                // the row replicas' column sums meet in LDS in replica order (fixed order)
+    float* red = shf + 3 * C + 2 * G;           // [rpp][C]
+    if (m.r < m.rpp) {
+#pragma unroll
+      for (int j = 0; j < GN_MAXQ; ++j)
+        if (j < m.nq)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) red[(size_t)m.r * C + 4 * (m.ql + j * m.qw) + e] = cs[j][e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += GNB) {
+      float a = 0.f;
+      for (int r = 0; r < m.rpp; ++r) a += red[(size_t)r * C + c];
+      colpart[((size_t)b * nchunk + ch) * C + c] = a;
+    }
   }
 }
 
@@ -2182,13 +2212,36 @@ int sfron_groupnorm_bwd_res(const float* dy, const float* x, int ldx, const floa
     SFRON_LAUNCH_STATUS();
     hipLaunchKernelGGL(k_gn2_bwd_apply, dim3(B * nchunk), dim3(GNB), (size_t)(3 * C + 2 * groups) * sizeof(float), (hipStream_t)stream, dy, x, ldx, gamma,
                        beta, mean, rstd, HW, C, groups, swish, drop_mask, drop_scale, nchunk, (const float*)scratch, dx, lddx, accumulate,
-                       part_gamma, part_beta, extra, ld_extra);
+                       part_gamma, part_beta, extra, ld_extra, (__bf16*)nullptr, (float*)nullptr);
     SFRON_LAUNCH_STATUS();
     return SFRON_OK;
   }
   const size_t lds = (2 * (TPB / 64) + 2 * cg + 2 * TPB) * sizeof(float);
   hipLaunchKernelGGL(k_gn_bwd, dim3(B * groups), dim3(TPB), lds, (hipStream_t)stream, dy, x, ldx, gamma, beta, mean, rstd, HW, C, groups, swish,
                      drop_mask, drop_scale, dx, lddx, accumulate, part_gamma, part_beta);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_groupnorm_chunks(int B, int HW) { return (B > 0 && HW > 0) ? gn_chunks(B, HW) : 0; }
+int sfron_groupnorm_bwd_cast_ok(int ldx, int C, int groups) {
+  return C > 0 && groups > 0 && C % groups == 0 && C % 4 == 0 && ldx % 4 == 0 && C <= 2048 && C <= GN_MAXQ * 4 * GNB && groups <= 64;
+}
+int sfron_groupnorm_bwd_cast(const float* dy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
+                             const float* rstd, int B, int HW, int C, int groups, int swish, const uint8_t* drop_mask, float drop_scale,
+                             uint16_t* dx_bf16, float* col_partials, float* part_gamma, float* part_beta, void* scratch, void* stream) {
+  SFRON_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx_bf16 && col_partials && part_gamma && part_beta && scratch);
+  SFRON_CHECK_ARG(sfron_groupnorm_bwd_cast_ok(ldx, C, groups) && B > 0 && HW > 0);
+  SFRON_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)scratch) & 15) == 0 && ((uintptr_t)dx_bf16 & 7) == 0 &&
+                  (!drop_mask || ((uintptr_t)drop_mask & 3) == 0));
+  const int nchunk = gn_chunks(B, HW);
+  hipLaunchKernelGGL(k_gn2_bwd_stats, dim3(B * nchunk), dim3(GNB), gn2_lds(C, sizeof(float)), (hipStream_t)stream, dy, x, ldx, gamma, beta, mean, rstd,
+                     HW, C, groups, swish, drop_mask, drop_scale, nchunk, (float*)scratch);
+  SFRON_LAUNCH_STATUS();
+  const size_t lds = (size_t)(3 * C + 2 * groups + 4 * GNB) * sizeof(float);          // + [rows per pass][C] for the column sums
+  hipLaunchKernelGGL(k_gn2_bwd_apply, dim3(B * nchunk), dim3(GNB), lds, (hipStream_t)stream, dy, x, ldx, gamma, beta, mean, rstd, HW, C, groups, swish,
+                     drop_mask, drop_scale, nchunk, (const float*)scratch, (float*)nullptr, C, 0, part_gamma, part_beta, (const float*)nullptr, 0,
+                     (__bf16*)dx_bf16, col_partials);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

@@ -300,6 +300,25 @@ class _TapeNet(nn.Module):
                                                ptr(drop_mask), scale, ptr(gbuf), x.C, acc, ptr(extra), ld_extra, ptr(pg), ptr(pb), ptr(ws2),
                                                stream_ptr()), "groupnorm_bwd")
             check(_L().sfron_reduce2(ptr(pg), ptr(pb), 1, x.B, x.C, self._g(name + ".weight"), x.C, self._g(name + ".bias"), x.C, stream_ptr()), "reduce2")
+
+        def bwd_cast(dy):
+            """For an x that only this norm consumes and that a convolution produced: x's gradient as that convolution's bf16 d_out
+            operand plus its column sums per (sample, pixel chunk) -- (d_x bf16 [rows][C], partials fp32 [B][chunks][C], chunks) --
+            without an fp32 x.grad; None when the shape is not eligible (the caller then takes bwd and casts)."""
+            if not _L().sfron_groupnorm_bwd_cast_ok(x.C, x.C, 32):
+                return None
+            nch = _L().sfron_groupnorm_chunks(x.B, x.H * x.W)
+            d16 = torch.empty(x.rows, x.C, dtype=torch.bfloat16, device=dev)
+            cpart = torch.empty(x.B * nch, x.C, dtype=torch.float32, device=dev)
+            pg = torch.empty(x.B, x.C, dtype=torch.float32, device=dev)
+            pb = torch.empty_like(pg)
+            ws2 = torch.empty(_L().sfron_groupnorm_scratch_bytes(x.B, x.H * x.W, x.C, 32) // 8 + 2, dtype=torch.float64, device=dev)
+            check(_L().sfron_groupnorm_bwd_cast(ptr(dy), ptr(x.t), x.C, gam, bet, ptr(mean), ptr(rstd), x.B, x.H * x.W, x.C, 32, int(swish),
+                                                ptr(drop_mask), scale, ptr(d16), ptr(cpart), ptr(pg), ptr(pb), ptr(ws2), stream_ptr()),
+                  "groupnorm_bwd_cast")
+            check(_L().sfron_reduce2(ptr(pg), ptr(pb), 1, x.B, x.C, self._g(name + ".weight"), x.C, self._g(name + ".bias"), x.C, stream_ptr()), "reduce2")
+            return d16, cpart, nch
+        bwd.cast = bwd_cast
         return y, bwd
 
     def _conv3(self, src, B, hs, ws, name, ho, wo, stride=1, pad=1, up=0, vec=None, ld_vec=0, resid=None):
@@ -320,12 +339,16 @@ class _TapeNet(nn.Module):
 
         trains = self._trains(name + ".weight")          # decided when the tape is built, not when it runs
 
-        def bwd(d_out, want_dsrc=True):
-            if trains and v["cop"] == v["co"] and v["co"] % 4 == 0:
+        def bwd(d_out, want_dsrc=True, d_bf=None):
+            """d_bf: d_out as the bf16 operand [rows][Cout_p] when the caller has it already (then d_out is not read and the bias
+            gradient is the caller's: _resblock forms both in the GroupNorm backward, sfron_groupnorm_bwd_cast)."""
+            if d_bf is not None:
+                dyb = d_bf
+            elif trains and v["cop"] == v["co"] and v["co"] % 4 == 0:
                 dyb = cast_rows_colsum(d_out, v["cop"], rows, v["cop"], dev, self._g(name + ".bias"), self._cs)     # bf16 operand + bias gradient
             else:
                 dyb = cast_rows(d_out, v["cop"], rows, v["cop"], dev)
-            if not trains:
+            if not trains or d_bf is not None:
                 pass                                     # frozen kernel: only the input gradient below
             elif v["cop"] == v["co"] and v["co"] % 4 == 0:
                 pass
@@ -431,12 +454,22 @@ class _TapeNet(nn.Module):
             d_out = out.grad
             d_a2 = conv2_b(d_out)
             d_skip = d_out if sc_b is None else sc_b(d_out, cout)      # the shortcut's share of x.grad: added by norm1's backward pass below
-            gn2_b(d_a2)                                   # -> h1.grad
-            dh1 = h1.grad
-            check(_L().sfron_sample_colsum(ptr(dh1), cout, B, H * W, cout, d_proj.data_ptr() + 4 * c0, self.proj_total, ptr(self._cs), self._cs.numel(),
-                                           stream_ptr()),
-                  "sample_colsum")
-            d_a1 = conv1_b(dh1)
+            v1 = self.conv3[n_conv1]
+            fused = gn2_b.cast(d_a2) if v1["cop"] == v1["co"] == cout else None
+            if fused is not None:
+                # h1 = conv1(.) + proj has one consumer (norm2): its gradient leaves norm2's backward pass as conv1's bf16 d_out,
+                # with column sums per (sample, chunk) that finish as d_proj's slice (per sample) and conv1's bias gradient (all)
+                dh1_bf, cpart, nch = fused
+                check(_L().sfron_reduce_chunks(ptr(cpart), B, nch, cout, d_proj.data_ptr() + 4 * c0, self.proj_total, 0, stream_ptr()), "reduce_chunks")
+                if self._trains(n_conv1 + ".weight"):
+                    check(_L().sfron_reduce_chunks(ptr(cpart), 1, B * nch, cout, self._g(n_conv1 + ".bias"), cout, 0, stream_ptr()), "reduce_chunks")
+                d_a1 = conv1_b(None, d_bf=dh1_bf)
+            else:
+                gn2_b(d_a2)                               # -> h1.grad
+                dh1 = h1.grad
+                check(_L().sfron_sample_colsum(ptr(dh1), cout, B, H * W, cout, d_proj.data_ptr() + 4 * c0, self.proj_total, ptr(self._cs),
+                                               self._cs.numel(), stream_ptr()), "sample_colsum")
+                d_a1 = conv1_b(dh1)
             gn1_b(d_a1, d_skip, cin)                      # -> x.grad (+)= d_skip + norm1's gradient
         tape.append(bwd)
         return out
