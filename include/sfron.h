@@ -358,6 +358,10 @@ int sfron_layernorm_fwd(const float* x, const float* gamma, const float* beta, i
 int sfron_layernorm_rows_per_block(int64_t rows);
 int sfron_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, int64_t rows, int D, float* dx,
                         int accumulate, float* part_gamma, float* part_beta, void* stream);
+/* the same with one more term of x's gradient, extra fp32 [rows][D] (the residual stream's share, x + attn(norm(x)),
+ * SD/ldm/modules/attention.py:271-273): dx (+)= extra + gradient, the bits of a separate dx (+)= extra pass followed by sfron_layernorm_bwd */
+int sfron_layernorm_bwd_res(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, int64_t rows, int D, float* dx,
+                            int accumulate, const float* extra, float* part_gamma, float* part_beta, void* stream);
 /* GEGLU (attention.py:37-45): h fp32 [rows][2F] = value || gate; out = bf16(value * gelu_erf(gate)); backward dh bf16 [rows][2F] */
 int sfron_geglu_fwd(const float* h, int64_t rows, int F, uint16_t* out, void* stream);
 int sfron_geglu_bwd(const float* d_out, const float* h, int64_t rows, int F, uint16_t* dh, void* stream);

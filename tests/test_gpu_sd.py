@@ -48,6 +48,21 @@ def test_layernorm_affine_fwd_bwd(rows, D):
     np.testing.assert_allclose(dx.cpu().numpy() - 0.25, xt.grad.numpy(), rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(pg.sum(0).cpu().numpy(), gt.grad.numpy(), rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(pb.sum(0).cpu().numpy(), bt.grad.numpy(), rtol=2e-4, atol=2e-4)
+    # the residual form: dx (+)= extra + gradient in one pass = the bits of dx (+)= extra, then dx += gradient; the parameter-gradient
+    # partials finish on the 16-wave form of sfron_reduce2 when there are >= 64 of them
+    extra = torch.randn(rows, D, generator=g).to(DEV)
+    for acc in (0, 1):
+        two = torch.full((rows, D), 0.5, device=DEV)
+        one = two.clone()
+        check(L.sfron_copy_cols(ptr(extra), D, rows, D, ptr(two), D, acc, stream_ptr()), "copy_cols")
+        check(L.sfron_layernorm_bwd(ptr(dyd), ptr(xd), ptr(gd), ptr(mean), ptr(rstd), rows, D, ptr(two), 1, ptr(pg), ptr(pb), stream_ptr()), "ln_bwd")
+        check(L.sfron_layernorm_bwd_res(ptr(dyd), ptr(xd), ptr(gd), ptr(mean), ptr(rstd), rows, D, ptr(one), acc, ptr(extra), ptr(pg), ptr(pb),
+                                        stream_ptr()), "ln_bwd_res")
+        assert torch.equal(one, two)
+    dg, db = torch.empty(D, device=DEV), torch.empty(D, device=DEV)
+    check(L.sfron_reduce2(ptr(pg), ptr(pb), 1, nblk, D, ptr(dg), D, ptr(db), D, stream_ptr()), "reduce2")
+    np.testing.assert_allclose(dg.cpu().numpy(), gt.grad.numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), bt.grad.numpy(), rtol=2e-4, atol=2e-4)
 
 
 def test_geglu_fwd_bwd():

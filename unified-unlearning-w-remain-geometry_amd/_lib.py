@@ -162,6 +162,7 @@ _PROTOS.update({
     "sfron_layernorm_fwd": (c_int, [_P, _P, _P, c_int64, c_int, c_float, _P, _P, _P, _S]),
     "sfron_layernorm_rows_per_block": (c_int, [c_int64]),
     "sfron_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P, _P, _S]),
+    "sfron_layernorm_bwd_res": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P, _P, _P, _S]),
     "sfron_geglu_fwd": (c_int, [_P, c_int64, c_int, _P, _S]),
     "sfron_geglu_bwd": (c_int, [_P, _P, c_int64, c_int, _P, _S]),
     "sfron_softmax_bwd": (c_int, [_P, _P, c_int64, c_int, c_float, _P, _S]),

@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__(TPB) void k_layernorm_fwd_r(const float* __restrict
 __global__ __launch_bounds__(TPB) void k_layernorm_bwd(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd, int64_t rows, int D,
                                                        float* __restrict__ dx, int accumulate, float* __restrict__ pg, float* __restrict__ pb,
-                                                       int rows_per_block) {
+                                                       int rows_per_block, const float* __restrict__ extra) {
   extern __shared__ float sh[];                     // [4 waves][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* ag = sh + (size_t)wave * 2 * D;
@@ -1411,7 +1411,8 @@ __global__ __launch_bounds__(TPB) void k_layernorm_bwd(const float* __restrict__
       const float xh = (xr[i] - m) * r;
       const float v = r * (dr[i] * gamma[i] - s1 - xh * s2);
       float* o = dx + row * D + i;
-      *o = accumulate ? *o + v : v;
+      if (extra) { const float e = extra[row * D + i]; *o = v + (accumulate ? *o + e : e); }     // (dx + extra) + this layer's gradient
+      else *o = accumulate ? *o + v : v;
     }
   }
   __syncthreads();
@@ -1427,7 +1428,7 @@ template <int NC>      // float4 chunks per lane: D <= 256 * NC, D % 4 == 0
 __global__ __launch_bounds__(TPB) void k_layernorm_bwd_r(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd, int64_t rows, int D,
                                                          float* __restrict__ dx, int accumulate, float* __restrict__ pg, float* __restrict__ pb,
-                                                         int rows_per_block) {
+                                                         int rows_per_block, const float* __restrict__ extra) {
   extern __shared__ float sh[];                     // [4 waves][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, D4 = D >> 2;
   float4 ag[NC], ab[NC], gm[NC];
@@ -1466,7 +1467,11 @@ __global__ __launch_bounds__(TPB) void k_layernorm_bwd_r(const float* __restrict
         float4 v = make_float4(r * (dv[j].x * gm[j].x - s1 - xh[j].x * s2), r * (dv[j].y * gm[j].y - s1 - xh[j].y * s2),
                                r * (dv[j].z * gm[j].z - s1 - xh[j].z * s2), r * (dv[j].w * gm[j].w - s1 - xh[j].w * s2));
         float4* o = reinterpret_cast<float4*>(dx + row * D) + c;
-        if (accumulate) { const float4 p = *o; v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+        if (extra) {                 // (dx + extra) + this layer's gradient: the bits of a separate dx (+)= extra pass before this one
+          float4 e = reinterpret_cast<const float4*>(extra + row * D)[c];
+          if (accumulate) { const float4 p = *o; e.x += p.x; e.y += p.y; e.z += p.z; e.w += p.w; }
+          v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+        } else if (accumulate) { const float4 p = *o; v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
         *o = v;
       }
     }
@@ -2271,15 +2276,20 @@ int sfron_layernorm_rows_per_block(int64_t rows) {
 }
 int sfron_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, int64_t rows, int D, float* dx,
                         int accumulate, float* part_gamma, float* part_beta, void* stream) {
+  return sfron_layernorm_bwd_res(dy, x, gamma, mean, rstd, rows, D, dx, accumulate, nullptr, part_gamma, part_beta, stream);
+}
+int sfron_layernorm_bwd_res(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, int64_t rows, int D, float* dx,
+                            int accumulate, const float* extra, float* part_gamma, float* part_beta, void* stream) {
   SFRON_CHECK_ARG(dy && x && gamma && mean && rstd && dx && part_gamma && part_beta && rows > 0 && D > 0 && D <= 4096);
+  SFRON_CHECK_ARG(extra != dx);
   const int rpb = sfron_layernorm_rows_per_block(rows);
   const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
   const size_t lds = (size_t)(TPB / 64) * 2 * D * sizeof(float);
-  const bool v4 = D % 4 == 0 && ((((uintptr_t)dy) | ((uintptr_t)x) | ((uintptr_t)dx) | ((uintptr_t)gamma)) & 15) == 0;
-  if (v4 && D <= 512)       hipLaunchKernelGGL(k_layernorm_bwd_r<2>, grid, dim3(TPB), lds, (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb);
-  else if (v4 && D <= 768)  hipLaunchKernelGGL(k_layernorm_bwd_r<3>, grid, dim3(TPB), lds, (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb);
-  else if (v4 && D <= 1280) hipLaunchKernelGGL(k_layernorm_bwd_r<5>, grid, dim3(TPB), lds, (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb);
-  else hipLaunchKernelGGL(k_layernorm_bwd, grid, dim3(TPB), lds, (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb);
+  const bool v4 = D % 4 == 0 && ((((uintptr_t)dy) | ((uintptr_t)x) | ((uintptr_t)dx) | ((uintptr_t)gamma) | ((uintptr_t)extra)) & 15) == 0;
+  if (v4 && D <= 512)       hipLaunchKernelGGL(k_layernorm_bwd_r<2>, grid, dim3(TPB), lds, (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb, extra);
+  else if (v4 && D <= 768)  hipLaunchKernelGGL(k_layernorm_bwd_r<3>, grid, dim3(TPB), lds, (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb, extra);
+  else if (v4 && D <= 1280) hipLaunchKernelGGL(k_layernorm_bwd_r<5>, grid, dim3(TPB), lds, (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb, extra);
+  else hipLaunchKernelGGL(k_layernorm_bwd, grid, dim3(TPB), lds, (hipStream_t)stream, dy, x, gamma, mean, rstd, rows, D, dx, accumulate, part_gamma, part_beta, rpb, extra);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

@@ -396,6 +396,38 @@ __global__ __launch_bounds__(TPB) void k_reduce2(const float* __restrict__ P0, c
   out1[(size_t)g * ld1 + c] = s1;
 }
 
+// the same on 16 waves per 64 columns when many partial rows meet few columns (LayerNorm parameter gradients of the LDM transformer
+// blocks: up to 512 partial rows of 320 .. 1280 columns) -- the split of k_reduce_chunks_wide, same selection rule
+__global__ __launch_bounds__(64 * RC_WAVES) void k_reduce2_wide(const float* __restrict__ P0, const float* __restrict__ P1, int per_group, int D,
+                                                                float* __restrict__ out0, int ld0, float* __restrict__ out1, int ld1) {
+  __shared__ float sh[2][RC_WAVES][64];
+  const int g = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int j0 = (int)((long)per_group * wave / RC_WAVES), j1 = (int)((long)per_group * (wave + 1) / RC_WAVES);
+  float s0 = 0.f, s1 = 0.f;
+  if (c < D) {
+    const size_t base = (size_t)g * per_group * D + c;
+    int j = j0;
+    for (; j + 4 <= j1; j += 4) {
+      float v0[4], v1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { v0[u] = P0[base + (size_t)(j + u) * D]; v1[u] = P1[base + (size_t)(j + u) * D]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s0 += v0[u]; s1 += v1[u]; }
+    }
+    for (; j < j1; ++j) { s0 += P0[base + (size_t)j * D]; s1 += P1[base + (size_t)j * D]; }
+  }
+  sh[0][wave][lane] = s0; sh[1][wave][lane] = s1;
+  __syncthreads();
+  if (wave < 2 && c < D) {
+    float a = sh[wave][0][lane];
+#pragma unroll
+    for (int w = 1; w < RC_WAVES; ++w) a += sh[wave][w][lane];
+    if (wave == 0) out0[(size_t)g * ld0 + c] = a;
+    else           out1[(size_t)g * ld1 + c] = a;
+  }
+}
+
 // bias gradients behind the gates of every block in one launch:
 //   out[l * out_stride + which * out_which + c] = sum_b gate[b * ldg + l * gate_stride + which * gate_which + c] * S[((l*2+which)*B + b) * D + c]
 __global__ __launch_bounds__(TPB) void k_gated_bias_grads(const float* __restrict__ S, const float* __restrict__ gate, int ldg,
@@ -596,8 +628,12 @@ int sfron_reduce_chunks(const float* partials, int groups, int per_group, int D,
 int sfron_reduce2(const float* p0, const float* p1, int groups, int per_group, int D, float* out0, int ld0, float* out1,
                   int ld1, void* stream) {
   SFRON_CHECK_ARG(p0 && p1 && out0 && out1 && groups > 0 && per_group > 0 && D > 0);
-  hipLaunchKernelGGL(k_reduce2, dim3(cdiv(D, TPB), groups), dim3(TPB), 0, (hipStream_t)stream, p0, p1, per_group, D, out0, ld0,
-                     out1, ld1);
+  if (reduce_chunks_wide(groups, per_group, D))
+    hipLaunchKernelGGL(k_reduce2_wide, dim3(cdiv(D, 64), groups), dim3(64 * RC_WAVES), 0, (hipStream_t)stream, p0, p1, per_group, D, out0, ld0, out1,
+                       ld1);
+  else
+    hipLaunchKernelGGL(k_reduce2, dim3(cdiv(D, TPB), groups), dim3(TPB), 0, (hipStream_t)stream, p0, p1, per_group, D, out0, ld0,
+                       out1, ld1);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

@@ -170,14 +170,15 @@ class UNetModel(_TapeNet):
         gam, bet = self._p(name + ".weight"), self._p(name + ".bias")
         check(_L().sfron_layernorm_fwd(ptr(x.t), gam, bet, rows, D, 1e-5, ptr(y), ptr(mean), ptr(rstd), stream_ptr()), "layernorm_fwd")
 
-        def bwd(dy):
+        def bwd(dy, extra=None):
+            """extra: fp32 [rows][D], the residual stream's share of x's gradient, added in the same pass (x.grad (+)= extra + d norm)."""
             g, acc = x.grad_buf()
             rpb = _L().sfron_layernorm_rows_per_block(rows)
             nblk = (rows + rpb - 1) // rpb
             pg = torch.empty(nblk, D, dtype=torch.float32, device=dev)
             pb = torch.empty_like(pg)
-            check(_L().sfron_layernorm_bwd(ptr(dy), ptr(x.t), gam, ptr(mean), ptr(rstd), rows, D, ptr(g), acc, ptr(pg), ptr(pb), stream_ptr()),
-                  "layernorm_bwd")
+            check(_L().sfron_layernorm_bwd_res(ptr(dy), ptr(x.t), gam, ptr(mean), ptr(rstd), rows, D, ptr(g), acc, ptr(extra), ptr(pg), ptr(pb),
+                                               stream_ptr()), "layernorm_bwd")
             check(_L().sfron_reduce2(ptr(pg), ptr(pb), 1, nblk, D, self._g(name + ".weight"), D, self._g(name + ".bias"), D, stream_ptr()), "reduce2")
         return y, bwd
 
@@ -267,21 +268,16 @@ class UNetModel(_TapeNet):
 
         trains_qkv1 = self._trains(t + ".attn1.to_q.weight")
 
-        def add(dst, src, cols):
-            g, acc = dst.grad_buf()
-            check(_L().sfron_copy_cols(ptr(src), cols, rows, cols, ptr(g), cols, acc, stream_ptr()), "copy_cols")
-
         def bwd():
+            # the residual stream's share of each gradient (x_in, X2, X1, X0) is added by the norm's backward pass that writes the same
+            # tensor (sfron_layernorm_bwd_res / sfron_groupnorm_bwd_res), not by a pass of its own
             d_out = out.grad
-            add(x, d_out, C)                                           # + x_in
             d3 = pout_b(d_out, C)                                      # d X3
-            add(X2, d3, C)                                             # ff residual
             d_gg = ff2_b(d3, C)                                        # fp32 [rows][4C]
             dh = torch.empty(rows, 8 * C, dtype=torch.bfloat16, device=dev)
             check(_L().sfron_geglu_bwd(ptr(d_gg), ptr(hff), rows, 4 * C, ptr(dh), stream_ptr()), "geglu_bwd")
-            ln3_b(ff0_b(None, 8 * C, d_bf=dh))                         # -> X2.grad
+            ln3_b(ff0_b(None, 8 * C, d_bf=dh), d3)                     # -> X2.grad = d3 (ff residual) + d norm3
             d2 = X2.grad
-            add(X1, d2, C)
             dO2 = o2_b(d2, C)
             dO2b = cast_rows(dO2, C, rows, C, dev)
             dq2 = torch.empty(rows, C, dtype=torch.bfloat16, device=dev)
@@ -292,9 +288,8 @@ class UNetModel(_TapeNet):
             bgemm(dq2, n2, C, C, rows, lda=C, ldb=C, a_t=True, b_t=True, c_f32=self._g(t + ".attn2.to_q.weight"), ldc=C)
             dn2 = torch.empty(rows, C, dtype=torch.float32, device=dev)
             bgemm(dq2, self._w(t + ".attn2.to_q.weight"), rows, C, C, lda=C, ldb=C, b_t=True, c_f32=dn2, ldc=C)
-            ln2_b(dn2)                                                 # -> X1.grad
+            ln2_b(dn2, d2)                                             # -> X1.grad = d2 + d norm2
             d1 = X1.grad
-            add(X0, d1, C)
             dO1 = o1_b(d1, C)
             dO1b = cast_rows(dO1, C, rows, C, dev)
             dqkv = torch.empty(rows, 3 * C, dtype=torch.bfloat16, device=dev)
@@ -303,8 +298,8 @@ class UNetModel(_TapeNet):
                 bgemm(dqkv, n1, 3 * C, C, rows, lda=3 * C, ldb=C, a_t=True, b_t=True, c_f32=self._g(t + ".attn1.to_q.weight"), ldc=C)
             dn1 = torch.empty(rows, C, dtype=torch.float32, device=dev)
             bgemm(dqkv, wqkv, rows, C, 3 * C, lda=3 * C, ldb=C, b_t=True, c_f32=dn1, ldc=C)
-            ln1_b(dn1)                                                 # -> X0.grad
-            gn_b(pin_b(X0.grad, C))                                    # -> x.grad
+            ln1_b(dn1, d1)                                             # -> X0.grad = d1 + d norm1
+            gn_b(pin_b(X0.grad, C), d_out, C)                          # -> x.grad (+)= d_out (+ x_in) + d norm
         tape.append(bwd)
         return out
 
