@@ -278,8 +278,7 @@ class UNetModel(_TapeNet):
             check(_L().sfron_geglu_bwd(ptr(d_gg), ptr(hff), rows, 4 * C, ptr(dh), stream_ptr()), "geglu_bwd")
             ln3_b(ff0_b(None, 8 * C, d_bf=dh), d3)                     # -> X2.grad = d3 (ff residual) + d norm3
             d2 = X2.grad
-            dO2 = o2_b(d2, C)
-            dO2b = cast_rows(dO2, C, rows, C, dev)
+            dO2b = o2_b(d2, C, dx_bf16=True)                           # bf16 [rows][C]: the attention backward's d_o operand
             dq2 = torch.empty(rows, C, dtype=torch.bfloat16, device=dev)
             dkv = torch.empty(B * Lp, 2 * C, dtype=torch.bfloat16, device=dev)
             att2_b(dO2b, dq2.data_ptr(), dkv.data_ptr(), dkv.data_ptr() + 2 * C)
@@ -290,8 +289,7 @@ class UNetModel(_TapeNet):
             bgemm(dq2, self._w(t + ".attn2.to_q.weight"), rows, C, C, lda=C, ldb=C, b_t=True, c_f32=dn2, ldc=C)
             ln2_b(dn2, d2)                                             # -> X1.grad = d2 + d norm2
             d1 = X1.grad
-            dO1 = o1_b(d1, C)
-            dO1b = cast_rows(dO1, C, rows, C, dev)
+            dO1b = o1_b(d1, C, dx_bf16=True)
             dqkv = torch.empty(rows, 3 * C, dtype=torch.bfloat16, device=dev)
             att1_b(dO1b, dqkv.data_ptr(), dqkv.data_ptr() + 2 * C, dqkv.data_ptr() + 4 * C)
             if trains_qkv1:

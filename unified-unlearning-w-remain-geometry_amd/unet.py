@@ -405,8 +405,9 @@ class _TapeNet(nn.Module):
 
         frozen = name is not None and not self._trains(name + ".weight")      # decided when the tape is built
 
-        def bwd(d_out, ld_d, want_dx=True, d_bf=None):
-            """d_out fp32 [rows][ld_d] (or None when only the bf16 form d_bf [rows][cout] exists)."""
+        def bwd(d_out, ld_d, want_dx=True, d_bf=None, dx_bf16=False):
+            """d_out fp32 [rows][ld_d] (or None when only the bf16 form d_bf [rows][cout] exists).  dx_bf16: the input gradient
+            leaves the product as bf16 [rows][cin] (its consumer is another product's operand: the rounding a cast pass would do)."""
             fused = d_bf is None and bias and not frozen and cout % 4 == 0 and ld_d % 4 == 0 and not isinstance(d_out, int)
             if fused:
                 d_bf = cast_rows_colsum(d_out, ld_d, rows, cout, dev, gb, self._cs)
@@ -424,6 +425,10 @@ class _TapeNet(nn.Module):
                 bgemm(d_bf, x_bf, cout, cin, rows, lda=cout, ldb=lda, a_t=True, b_t=True, c_f32=gw, ldc=cin)
             if not want_dx:
                 return None
+            if dx_bf16:
+                dx = torch.empty(rows, cin, dtype=torch.bfloat16, device=dev)
+                bgemm(d_bf, w, rows, cin, cout, lda=cout, ldb=cin, b_t=True, c_bf16=dx, ldc=cin)
+                return dx
             dx = torch.empty(rows, cin, dtype=torch.float32, device=dev)
             bgemm(d_bf, w, rows, cin, cout, lda=cout, ldb=cin, b_t=True, c_f32=dx, ldc=cin)
             return dx
