@@ -455,18 +455,20 @@ class _TapeNet(nn.Module):
         out_t, conv2_b = self._conv3(a2, B, H, W, n_conv2, H, W, resid=sc)
         out = Act(out_t, B, H, W, cout)
 
+        v1 = self.conv3[n_conv1]
+        trains1 = self._trains(n_conv1 + ".weight")       # decided when the tape is built, as in _conv3
+
         def bwd():
             d_out = out.grad
             d_a2 = conv2_b(d_out)
             d_skip = d_out if sc_b is None else sc_b(d_out, cout)      # the shortcut's share of x.grad: added by norm1's backward pass below
-            v1 = self.conv3[n_conv1]
             fused = gn2_b.cast(d_a2) if v1["cop"] == v1["co"] == cout else None
             if fused is not None:
                 # h1 = conv1(.) + proj has one consumer (norm2): its gradient leaves norm2's backward pass as conv1's bf16 d_out,
                 # with column sums per (sample, chunk) that finish as d_proj's slice (per sample) and conv1's bias gradient (all)
                 dh1_bf, cpart, nch = fused
                 check(_L().sfron_reduce_chunks(ptr(cpart), B, nch, cout, d_proj.data_ptr() + 4 * c0, self.proj_total, 0, stream_ptr()), "reduce_chunks")
-                if self._trains(n_conv1 + ".weight"):
+                if trains1:
                     check(_L().sfron_reduce_chunks(ptr(cpart), 1, B * nch, cout, self._g(n_conv1 + ".bias"), cout, 0, stream_ptr()), "reduce_chunks")
                 d_a1 = conv1_b(None, d_bf=dh1_bf)
             else:
