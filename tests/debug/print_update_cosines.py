@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""GPU: the per-tensor update cosines / norm ratios of the two reference-trajectory tests (tests/test_gpu_reference_fixtures.py), all
+of them, worst first -- what the bounds DIT_UPDATE_COS_MIN / DDPM_UPDATE_COS_MIN are set from."""
+import os
+import sys
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import test_gpu_reference_fixtures as T  # noqa: E402
+
+for name, fn in (("dit", T.test_dit_sfron_trajectory_vs_reference_fixture), ("ddpm", T.test_ddpm_sfron_trajectory_vs_reference_fixture)):
+    try:
+        fn()
+        print(f"== {name}: test passed")
+    except AssertionError as e:
+        print(f"== {name}: assertion: {str(e)[:300]}")
+    cs = T._LAST.get(name, {})
+    rows = sorted(cs.items(), key=lambda kv: kv[1][0])
+    print(f"{name}: {len(rows)} tensors; min cosine {rows[0][1][0]:.4f}; max |norm ratio - 1| {max(abs(v[1] - 1) for v in cs.values()):.4f}; "
+          f"min ref rms/lr {min(v[2] for v in cs.values()):.3f}")
+    for n, (c, r, rms) in rows[:12]:
+        print(f"   {n:50s} cos {c:.4f}  norm ratio {r:.4f}  ref rms/lr {rms:.3f}")

@@ -230,6 +230,21 @@ def _proj(t, name):
     return float((t.double().flatten() * torch.randn(t.numel(), generator=g, dtype=torch.float64)).sum())
 
 
+def _save_updates(fname, names, fin, p0, lr, cap=1 << 30):
+    """Every trainable tensor's UPDATE of a trajectory, (p_final - p0) / lr, as int8 in units of 1/20 (an Adam step moves a coordinate by
+    at most ~lr: a handful of steps stay inside +-6.35; resolution 0.05 lr) -- enough for a per-tensor cosine against the HIP path's
+    update (tests/test_gpu_reference_fixtures.py); the norms are stored exactly.  A tensor with more than `cap` coordinates is stored as a
+    strided sample (every tensor still has an entry; the test samples the same way).  Separate file: the older fixtures keep their bits."""
+    out = dict(names=np.array(names), lr=np.array(lr), scale=np.array(20.0), cap=np.array(cap))
+    for n in names:
+        u = ((fin[n].detach() - p0[n]).double() / lr).numpy().ravel()
+        out["norm::" + n] = np.array(float(np.linalg.norm(u)))          # of the WHOLE tensor
+        stride = -(-u.size // cap)                                       # tensors above `cap` coordinates: every stride-th one
+        out["upd::" + n] = np.clip(np.rint(u[::stride] * 20.0), -127, 127).astype(np.int8)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, "written:", sum(int(np.prod(fin[n].shape)) for n in names), "update coordinates")
+
+
 def gen_dit_gpu(ref_models, ref_diffusion):
     """The reference DiT class at a shape the HIP engine takes (16 x 16 latents, patch 2 -> 64 tokens, D 128, 2 heads of 64, depth 2):
     forward (eval / train with explicit drop ids), backward, and 3 SFR-on iterations in DiT/forget.py:256-322 order -- so that the
@@ -327,6 +342,7 @@ def gen_dit_gpu(ref_models, ref_diffusion):
                traj_final_ema_proj1_bias=dict(ema.named_parameters())["blocks.1.attn.proj.bias"].detach().numpy(),
                **{"traj_" + k: np.array(v) for k, v in rec.items()})
     np.savez_compressed(os.path.join(HERE, "dit_gpu.npz"), **out)
+    _save_updates("dit_gpu_updates.npz", tn, fin, p0, 1e-3)
     print("dit_gpu.npz:", len(out), "entries;", "traj", rec)
 
 
@@ -589,6 +605,7 @@ def gen_ddpm_gpu():
                traj_final_conv_out_bias=model.conv_out.bias.detach().numpy(),
                traj_final_shadow_norm_out=helper.shadow["norm_out.weight"].numpy())
     np.savez_compressed(os.path.join(HERE, "ddpm_gpu.npz"), **out)
+    _save_updates("ddpm_gpu_updates.npz", tn, fin, p0, 1e-3, cap=32768)
     print("ddpm_gpu.npz:", len(out), "entries; traj", rec)
 
 

@@ -150,7 +150,7 @@ def test_remain_sweep_beside_the_next_step_gives_the_same_state(fp8):
         for it in range(4):
             runner.step(*bat(it))
         if across:
-            assert runner._ready_next is not None and model.engine._sweep_pending is not None
+            assert runner._ready_owner is not None and model.engine._sweep_pending is not None
         ck = runner.checkpoint()                           # drains the sweep before it reads
         assert getattr(model.engine, "_sweep_pending", None) is None
         torch.cuda.synchronize()
@@ -165,3 +165,56 @@ def test_remain_sweep_beside_the_next_step_gives_the_same_state(fp8):
         assert torch.equal(a[5]["model"][k], b[5]["model"][k])
     for k in a[5]["ema"]:
         assert torch.equal(a[5]["ema"][k], b[5]["ema"][k])
+
+
+def test_batch_size_change_while_the_remain_sweep_is_in_flight():
+    """with sweep_across_steps the runner keeps the per-block events of the sweep it left in flight; a batch-size
+    change between two steps replaces the engine (the old one is drained and closed, its events destroyed).  The next step must not
+    hand the stale handles to hipStreamWaitEvent: it runs on the new engine, and the state equals a run without the cross-step
+    sweep bit for bit (same kernels on the same operands)."""
+    from sfron import data, diffusion, step
+    from test_gpu_dit import CASES, build_pair
+    cfg = CASES["hd72"]
+    hp = dict(lr=2e-4, forget_alpha=0.3, grad_clip=1.0, ema_decay=0.99, mask=None, unlearn_loss="ga", forget_class=3)
+    sizes = [4, 4, 2, 2, 4]
+
+    def bat(it, B):
+        kw = dict(global_batch=B, num_classes=cfg["num_classes"], forget_class=3, input_size=cfg["input_size"], device=DEV)
+        return data.synthetic_batch(8, it, "forget", **kw), data.synthetic_batch(8, it, "remain", **kw)
+
+    def run(across, user_resize=False):
+        _, model = build_pair(cfg, sizes[0], seed=31)
+        runner = step.DiTSFRon(model, diffusion.create_diffusion(""), **hp)
+        runner.sweep_across_steps = across
+        for it, B in enumerate(sizes):
+            if user_resize and it > 0 and B != sizes[it - 1]:
+                model.set_batch_size(B)                    # the user resizes between two steps (step() would do the same)
+            runner.step(*bat(it, B))
+        runner.sync_sweep()
+        torch.cuda.synchronize()
+        runner.guard.poll(block=True)
+        eng = model.engine
+        return eng.params.clone(), runner.opt.m.clone(), runner.opt.v.clone(), runner.ema.clone(), eng.params_bf16.clone()
+
+    ref = run(False)
+    for got in (run(True), run(True, user_resize=True)):
+        for x, y in zip(ref, got):
+            assert torch.equal(x, y)
+
+
+def test_guard_rejects_non_int64_labels_and_length_mismatch():
+    """k_guard_inputs reads y and t as int64 vectors of one length; anything else raises instead of being
+    reinterpreted."""
+    from sfron import guard
+    from sfron._lib import SfronError
+    g = guard.StepGuard(torch.device(DEV))
+    y = torch.zeros(4, dtype=torch.int64, device=DEV)
+    t = torch.zeros(4, dtype=torch.int64, device=DEV)
+    ys, ts = g.check_inputs(y, t, 10, 1000)
+    assert ys.dtype == torch.int64 and torch.equal(ys, y) and torch.equal(ts, t)
+    with pytest.raises(SfronError):
+        g.check_inputs(y.to(torch.int32), t, 10, 1000)
+    with pytest.raises(SfronError):
+        g.check_inputs(y, t.to(torch.int32), 10, 1000)
+    with pytest.raises(SfronError):
+        g.check_inputs(y, t[:3], 10, 1000)

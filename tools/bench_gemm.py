@@ -3,7 +3,9 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from sfron import _lib
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ab_lib
+_lib = ab_lib.select()
 if os.environ.get("SFRON_DBG_LIB"):       # the debug-knob build (SFRON_GEMM_SAME_TILE ...): `make -C .../csrc dbg`
     _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libsfron_dbg.so")
 from sfron import ops

@@ -716,6 +716,22 @@ template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+// Where the memory operations of a segment sit among its NM MFMAs.  They used to be spread evenly up to the LAST MFMA, so the
+// `s_waitcnt lgkmcnt(0)` that closes the segment exposed one full LDS latency per k-step on BOTH waves of a SIMD at once (the two
+// run the same code from the same barrier: neither has MFMAs left to cover the other).  Now the operations are packed into the
+// first NM - SFRON_RD_TAIL MFMA gaps (at least ceil(NOPS / 2) gaps: two per gap), which leaves RD_TAIL MFMAs = RD_TAIL x 32 cycles at
+// two waves per SIMD between the last read's issue and the wait.  op_cut(i) = operations issued before MFMA i's gap closes.
+#ifndef SFRON_RD_TAIL
+#define SFRON_RD_TAIL 4
+#endif
+constexpr int op_span(int nops, int nm) {
+  int span = nm - SFRON_RD_TAIL;
+  const int min_span = (nops + 1) / 2;
+  if (span < min_span) span = min_span;
+  if (span > nm || SFRON_RD_TAIL <= 0) span = nm;
+  return span < 1 ? 1 : span;
+}
+constexpr int op_cut(int i, int nops, int nm) { return i >= op_span(nops, nm) ? nops : i * nops / op_span(nops, nm); }
 __device__ __forceinline__ void lds_reads_done() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -1004,7 +1020,14 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
       }
     };
     auto mfma1 = [&](const Frags& f, auto ic) {
+      // the operand with MORE fragments is the outer index: its registers die two (MT) MFMAs apart, so the reads of the next k-step --
+      // which follow the same order -- can take them over one by one (front-loaded reads would otherwise need both fragment sets whole)
+#ifdef SFRON_MFMA_MT_MAJOR      // (A-B builds: the round-3 order)
       constexpr int mt = decltype(ic)::value / NT, nt = decltype(ic)::value % NT;
+#else
+      constexpr int mt = NT >= MT ? decltype(ic)::value % MT : decltype(ic)::value / NT;
+      constexpr int nt = NT >= MT ? decltype(ic)::value / MT : decltype(ic)::value % NT;
+#endif
       // asm, accumulating in place: through the builtin hipcc renames every accumulator here (vdst != srcC) and spills ~150 VGPRs
       f32x4& c = acc[mt][nt];
       const bf16x8 fb = f.b[nt], fa = f.a[mt];
@@ -1058,7 +1081,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
         static_for<NOPS1>(op1);
       } else {
         static_for<NM>([&](auto ic) {
-          constexpr int i = decltype(ic)::value, lo = i * NOPS1 / NM, hi = (i + 1) * NOPS1 / NM;
+          constexpr int i = decltype(ic)::value, lo = op_cut(i, NOPS1, NM), hi = op_cut(i + 1, NOPS1, NM);
           mfma1(f1, ic);                                       // k-step 1 of the previous tile
           static_for<hi - lo>([&](auto jc) { op1(std::integral_constant<int, lo + decltype(jc)::value>{}); });
           __builtin_amdgcn_sched_barrier(0);
@@ -1070,7 +1093,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
       bs_c = bs_c + 1 == g.ntn ? 0 : bs_c + 1;                 // now: (this k-tile) mod ntn
       constexpr int NOPS2 = NRA + NRB;
       static_for<NM>([&](auto ic) {
-        constexpr int i = decltype(ic)::value, lo = i * NOPS2 / NM, hi = (i + 1) * NOPS2 / NM;
+        constexpr int i = decltype(ic)::value, lo = op_cut(i, NOPS2, NM), hi = op_cut(i + 1, NOPS2, NM);
         mfma1(f0, ic);
         static_for<hi - lo>([&](auto jc) {
           read(bufc, std::integral_constant<int, 1>{}, f1, std::integral_constant<int, lo + decltype(jc)::value>{});
@@ -1398,7 +1421,7 @@ int launch_any(const GemmArgs& g, hipStream_t s, int force) {
         if (g.kchunk == g.K && g.K % 192 == 0)
           // loader waves: measured faster where an operand is read transposed (dgrad: qkv 68 -> 57 us, proj 28.4 -> 26.1, fc1 76.9 -> 72.6), slower
           // or equal on the forward layouts (qkv 76 -> 83)
-          return ((g_loader_waves == 4 || g_loader_waves == 6) && B_TR) ? launch_pipe<8, 1, 2, 9, A_TR, B_TR, EPI, 2, 3, false, 4>(g, s) : launch_pipe<8, 1, 2, 9, A_TR, B_TR, EPI, 2, 3>(g, s);
+          return (((g_loader_waves == 4 || g_loader_waves == 6) && B_TR) || g_loader_waves == 8) ? launch_pipe<8, 1, 2, 9, A_TR, B_TR, EPI, 2, 3, false, 4>(g, s) : launch_pipe<8, 1, 2, 9, A_TR, B_TR, EPI, 2, 3>(g, s);
       }
       if (!tile_fits(g, 2)) return launch<A_TR, B_TR, EPI>(g, s);
       return g.K % 128 == 0 && g.kchunk == g.K ? launch_pipe<4, 2, 4, 6, A_TR, B_TR, EPI, 1>(g, s) : launch_pipe<4, 2, 4, 6, A_TR, B_TR, EPI>(g, s);
@@ -1408,7 +1431,7 @@ int launch_any(const GemmArgs& g, hipStream_t s, int force) {
       }
       if constexpr ((A_TR && B_TR && (EPI == EPI_BF16 || EPI == EPI_F32)) || (!A_TR && !B_TR && EPI == EPI_BF16)) {
         if (g.K % g.kchunk == 0 && (g.kchunk / 64) >= 2 && ((g.kchunk / 64) - 2) % 3 == 0) {
-          if constexpr (A_TR && B_TR) { if (g_loader_waves == 4 || g_loader_waves == 5) return launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI, 2, 2, false, 4>(g, s); }
+          if constexpr (A_TR && B_TR) { if (g_loader_waves == 4 || g_loader_waves == 5 || g_loader_waves == 8) return launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI, 2, 2, false, 4>(g, s); }
           if constexpr (!A_TR && !B_TR && EPI == EPI_BF16) { if (g_loader_waves == 7) return launch_pipe<4, 2, 3, 6, false, false, EPI_BF16, 2, 2, false, 4>(g, s); }   // (experiment)
           return launch_pipe<4, 2, 3, 6, A_TR, B_TR, EPI, 2>(g, s);
         }
@@ -1458,7 +1481,7 @@ int gemm_sumsq_lowrank(const uint16_t* a, const uint16_t* b, int R, int NM, int 
 }
 
 extern "C" // test / A-B hook: 4 = loader-wave form of the three-slot tiles (0 = every wave issues its share of the LDS-DMA); returns the old value
-int sfron_gemm_loader_waves(int n) { const int old = g_loader_waves; g_loader_waves = (n >= 9 && n <= 12) ? 4 : (n >= 4 && n <= 7) ? n : 0; g_fp8_loader_waves = n == 9 ? 4 : 0; g_conv_loader_waves = (n == 0 || n == 10) ? 0 : n == 11 ? 1 : n == 12 ? 2 : 3; return old; }   // (10 / 11 / 12: as 4, with none / only k_cgemm / only k_cgemm_t of the convolution tiles in the loader form)   // (9: as 4, and the fp8 tiles in their loader form too -- measured no faster)   // (5 / 6: weight gradients / dgrad only, A-B runs)
+int sfron_gemm_loader_waves(int n) { const int old = g_loader_waves; g_loader_waves = (n >= 9 && n <= 12) ? 4 : (n >= 4 && n <= 8) ? n : 0; g_fp8_loader_waves = n == 9 ? 4 : 0; g_conv_loader_waves = (n == 0 || n == 10) ? 0 : n == 11 ? 1 : n == 12 ? 2 : 3; return old; }   // (10 / 11 / 12: as 4, with none / only k_cgemm / only k_cgemm_t of the convolution tiles in the loader form)   // (9: as 4, and the fp8 tiles in their loader form too -- measured no faster)   // (5 / 6: weight gradients / dgrad only, A-B runs; 8: as 4 + the forward layouts of the 256 x 144 tile)
 
 int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
   SFRON_CHECK_ARG(d && d->A && d->B && d->M > 0 && d->N > 0 && d->K > 0);

@@ -27,6 +27,12 @@ class StepGuard:
 
     def check_inputs(self, y, t, num_classes, num_timesteps):
         """Labels / timesteps clamped into range (new tensors) + the violation counters, in ONE launch (csrc/embed.hip)."""
+        # the kernel reads both as int64 vectors of one length (the reference indexes nn.Embedding / the schedule tables with
+        # LongTensors: models.py:89-93, gaussian_diffusion.py:861-873): anything else is a caller error, not something to reinterpret
+        if y.dtype != torch.int64 or t.dtype != torch.int64:
+            raise SfronError(f"labels / timesteps must be int64 tensors (got {y.dtype}, {t.dtype})")
+        if y.numel() != t.numel():
+            raise SfronError(f"labels and timesteps differ in length ({y.numel()} vs {t.numel()})")
         y, t = y.contiguous(), t.contiguous()
         y_safe, t_safe = torch.empty_like(y), torch.empty_like(t)
         check(_lib.lib().sfron_guard_inputs(ptr(y), ptr(t), y.numel(), int(num_classes), int(num_timesteps), ptr(y_safe), ptr(t_safe),

@@ -64,7 +64,7 @@ class DiTSFRon:
         # opt-in: the remain-stage sweep of the block ranges runs beside the NEXT step's forget forward pass; step() then returns with it in
         # flight -- read parameters / optimizer state through this runner (state_dict / checkpoint / sync()), not from the raw arenas
         self.sweep_across_steps = False
-        self._ready_next = None                # block events of that sweep, consumed by the next step()'s first forward pass
+        self._ready_owner = None               # (engine, block events) of that sweep, consumed by the next step()'s first forward pass
         self.fp8 = bool(fp8)
         if self.fp8 and model.engine.fp8 is None:
             model.engine.enable_fp8()
@@ -387,7 +387,15 @@ class DiTSFRon:
         if self.method == "joint":
             return self._step_joint(forget, remain, y_f, sign)
         dp_sync = self._dp_active() and not self._overlap_enabled() and self.micro == 1
-        ready, self._ready_next = self._ready_next, None
+        ready = None
+        if self._ready_owner is not None:
+            # the events of a sweep left in flight belong to the engine that armed it.  A batch-size change (set_batch_size above, or
+            # by the user between two steps) replaced that engine: it was drained and closed -- its events are destroyed -- so there
+            # is nothing to wait for and the stale handles must not reach hipStreamWaitEvent
+            owner, handles = self._ready_owner
+            self._ready_owner = None
+            if owner is eng and getattr(eng, "_sweep_pending", None) is not None:
+                ready = handles
         if ready is not None:
             eng._sweep_pending = None          # this forward pass waits for the sweep block by block; its backward pass starts behind all of it
         mse_f, vb_f = self._pass(forget, y_f, sign * self.forget_alpha, factored_ada=True, block_ready=ready, async_exchange=dp_sync)
@@ -428,7 +436,7 @@ class DiTSFRon:
         self.opt.step(max_norm=None, use_mask=False, ema=self.ema[:nt], ema_decay=self.ema_decay, ema_mode=1,   # :320,322
                       split=split_r, pipeline=pipe)
         if across:
-            self._ready_next, eng._sweep_pending = bs["handles"], bs["stream"]
+            self._ready_owner, eng._sweep_pending = (eng, bs["handles"]), bs["stream"]
         if self.fp8 and not fused_q:
             self.model.engine.fp8_requantize()
         if eng.n_total > nt:
@@ -449,7 +457,7 @@ class DiTSFRon:
     def sync_sweep(self):
         """Order the current stream behind a block sweep that step() left in flight (sweep_across_steps)."""
         self.model.engine.drain_sweep()
-        self._ready_next = None
+        self._ready_owner = None
 
     # ------------------------------------------------------------------ checkpoint (DiT/forget.py:346-353 format)
     def opt_state_dict(self):
