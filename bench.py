@@ -9,7 +9,7 @@ remain fwd/bwd -> AdamW, EMA; synthetic latents / labels / timesteps / noise alr
 Weak scaling: every rank runs batch 32 (global batch 32*N), gradients SUM-all-reduced over RCCL; "value" counts the batch-32 steps
 of ALL ranks per second (N x the iteration rate), "ms_per_step" is the wall time of one synchronous iteration.
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline"     -- the kernel with the largest share of GPU time (profiles/r03_kernel_table.md): the weight-gradient GEMM
+  "roofline"     -- the kernel with the largest share of GPU time (profiles/r04_kernel_table.md): the weight-gradient GEMM
                     (one kernel for the four products dW = dY^T X of a block), timed live with HIP event pairs recorded on the
                     weight-gradient stream it is launched on (all four GEMMs of every 9th block of every backward pass inside
                     the timed region); "others" holds the same measurement for the fc1 forward GEMM (main stream) and an "hbm"
@@ -54,6 +54,8 @@ def parse():
                     help="BASELINE config 5: the four block GEMMs of every FORWARD pass on the fp8 (e4m3) matrix core, e4m3 weight shadow "
                          "re-quantised after each optimizer step; backward GEMMs stay bf16")
     ap.add_argument("--grad-transport", default="fp32", choices=("fp32", "bf16"), help="N > 1: precision of the gradient exchange")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the bounded runs of BASELINE configs 1, 2, 4, 5 behind the headline region (roofline.others.configs)")
     ap.add_argument("--check", action="store_true",
                     help="N-rank == 1-rank parity: after the run every rank also computes the gradient of the WHOLE global batch "
                          "of step 0 by itself and compares it with the all-reduced gradient of the sharded run")
@@ -105,6 +107,143 @@ def cpu_baseline(model_name, latent, batch_full, cpu_batch):
             "sample": f"1 timed SFR-on iteration of {model_name} (oracle, CPU fp32 eager, {cores} threads) at batch "
                       f"{cpu_batch} took {dt:.2f} s; value = (1/t) * {cpu_batch}/{batch_full} (linear in batch); "
                       f"model build {build_s:.1f} s not counted"}
+
+
+def _dit_leg(model_name, batch, latent, dev, fp8, steps, warmup):
+    """One more DiT configuration through the same runner as the headline (BASELINE configs 2 and 5): ms / step, TFLOP/s, fraction of peak."""
+    from sfron import data, diffusion, dit, step
+    model = dit.DiT_models[model_name](input_size=latent, num_classes=1000, batch_size=batch, device=dev)
+    torch.manual_seed(1234)
+    model.initialize_weights()
+    dit.randomize_zero_init(model, std=0.02, seed=1)
+    model.train()
+    eng = model.engine
+    gm = torch.Generator().manual_seed(0)
+    runner = step.DiTSFRon(model, diffusion.create_diffusion("", device=dev), lr=1e-4, forget_alpha=1e-3, grad_clip=1.0, ema_decay=0.9999,
+                           mask=None, unlearn_loss="ga", forget_class=207, fp8=fp8)
+    runner.mask_arena = runner.opt.mask = (torch.rand(eng.n_trainable, generator=gm) < 0.5).to(torch.uint8).to(dev)
+    runner.sweep_across_steps = True
+    bt = [(data.synthetic_batch(0, i, "forget", batch, 0, 1, input_size=latent, device=dev),
+           data.synthetic_batch(0, i, "remain", batch, 0, 1, input_size=latent, device=dev)) for i in range(2)]
+    for i in range(warmup):
+        runner.step(*bt[i % 2])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = runner.step(*bt[i % 2])
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    runner.guard.poll(block=True)
+    c = eng.cfg
+    T, D, L, F = eng.tokens, c.hidden, c.depth, c.mlp_hidden
+    flops = 6.0 * batch * L * (2 * T * D * (3 * D + D + 2 * F) + 4 * T * T * D + 2 * D * 6 * D)
+    ok = bool(torch.isfinite(out["remain_mse"]).all().item() and torch.isfinite(out["forget_mse"]).all().item())
+    runner.sync_sweep()
+    eng.close()
+    return {"ms_per_step": ms, "steps_per_s": 1e3 / ms, "steps": steps, "batch": batch, "tflops": flops / ms / 1e9,
+            "frac_of_bf16_mfma_peak": flops / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, "finite_losses": ok}
+
+
+def _ddpm_leg(dev, steps=50, batch=64):
+    """BASELINE config 1 as worded: DDPM CIFAR-10 class-forget, 50 SFR-on steps at batch 64 (cifar10_sfron.yml U-Net, adaga, cosine alpha,
+    clip in both stages, EMA; DDPM/runners/diffusion.py:1075-1180), stage graphs replayed."""
+    from sfron import ddpm, unet
+    torch.manual_seed(1234)
+    model = unet.Conditional_Model(unet.config_namespace())
+    run = ddpm.DDPMSFRon(model, lr=1e-4, forget_alpha=10.0, grad_clip=1.0, ema_rate=1e-4, mask=None, unlearn_loss="adaga", lambd=0.5,
+                         n_iters=steps, use_graphs=True)
+    g = torch.Generator().manual_seed(1)
+
+    def synth(stream):
+        t = torch.randint(0, 1000, (batch // 2 + 1,), generator=g)
+        c = torch.zeros(batch, dtype=torch.int64) if stream == "forget" else torch.randint(1, 10, (batch,), generator=g)
+        d = dict(x0=torch.rand(batch, 3, 32, 32, generator=g) * 2 - 1, e=torch.randn(batch, 3, 32, 32, generator=g),
+                 t=torch.cat([t, 1000 - t - 1])[:batch], c=c)                   # antithetic timesteps (runners/diffusion.py:1091-1094)
+        return {k: v.to(dev) for k, v in d.items()}
+    bt = [(synth("forget"), synth("remain")) for _ in range(2)]
+    unet.PRODUCT_FLOPS = [0.0]
+    run.step(0, *bt[0])                      # eager: the tape's Python runs once -> the products of one iteration are counted
+    flops, unet.PRODUCT_FLOPS = unet.PRODUCT_FLOPS[0], None
+    for i in range(2):                       # capture + first replay
+        run.step(i, *bt[i % 2])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = run.step(i, *bt[i % 2])
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"ms_per_step": ms, "steps_per_s": 1e3 / ms, "steps": steps, "batch": batch, "product_tflop_per_step": flops / 1e12,
+            "tflops": flops / ms / 1e9, "frac_of_bf16_mfma_peak": flops / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS,
+            "finite_losses": bool(torch.isfinite(out["forget_loss"]).item() and torch.isfinite(out["remain_loss"]).item())}
+
+
+def _sd_leg(dev, batches=(2, 8), steps=4):
+    """BASELINE config 4: SD v1 UNet (859.5 M parameters, 64 x 64 latents, 77-token context) SFR-on iterations of
+    SD/train-scripts/nsfw_removal.py:108-173 (train_method full), at the README's batch 2 and the script's default batch 8."""
+    from sfron import sd, sd_unet, unet
+    torch.manual_seed(0)
+    model = sd_unet.UNetModel()
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for p in model.parameters():
+            if not bool(p.any()):
+                p.copy_((torch.randn(p.shape, generator=g) * 0.02).to(p.device))
+    model.sync_bf16()
+    gd = torch.Generator(device=dev).manual_seed(2)
+    rn = lambda *sh: torch.randn(*sh, device=dev, generator=gd)
+    res = {}
+    for B in batches:
+        run = sd.SDSFRon(model, lr=1e-5, train_method="full", use_graphs=True)
+        c_f, c_p = rn(1, 77, 768).expand(B, -1, -1).contiguous(), rn(1, 77, 768).expand(B, -1, -1).contiguous()
+
+        def batch():
+            xf = rn(B, 4, 64, 64)
+            return (dict(x_f=xf, x_p=xf, c_f=c_f, c_p=c_p, t=torch.randint(0, 1000, (B,), device=dev, generator=gd), noise=rn(B, 4, 64, 64)),
+                    dict(x=rn(B, 4, 64, 64), c=c_p, t=torch.randint(0, 1000, (B,), device=dev, generator=gd), noise=rn(B, 4, 64, 64)))
+        bt = [batch() for _ in range(2)]
+        unet.PRODUCT_FLOPS = [0.0]
+        run.step(*bt[0])                     # eager (counts the products of one iteration)
+        flops, unet.PRODUCT_FLOPS = unet.PRODUCT_FLOPS[0], None
+        for i in range(2):
+            run.step(*bt[i % 2])             # capture + first replay
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out = run.step(*bt[i % 2])
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        res[f"batch{B}"] = {"ms_per_iteration": ms, "iterations_per_s": 1e3 / ms, "steps": steps, "product_tflop_per_iteration": flops / 1e12,
+                            "tflops": flops / ms / 1e9, "frac_of_bf16_mfma_peak": flops / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS,
+                            "finite_losses": bool(all(torch.isfinite(v).all().item() for v in out.values() if torch.is_tensor(v)))}
+        del run
+        torch.cuda.empty_cache()
+    return res
+
+
+def other_configs(dev, latent, budget_s=75.0):
+    """BASELINE configs 1, 2, 4, 5 behind the headline region, each through its own runner on synthetic inputs, bounded in time; a leg that
+    fails or no longer fits the budget reports why instead of a number (the headline line is never at risk)."""
+    import gc
+    t_start = time.perf_counter()
+    out = {"note": "measured after the headline's timed region in the same process; product FLOPs of the U-Net legs are counted from the "
+                   "launches of one iteration (zero-dilated / channel-padded operands included)"}
+    legs = [("config2_dit_b4_bs32", lambda: _dit_leg("DiT-B/4", 32, latent, dev, False, 20, 4)),
+            ("config5_dit_xl2_fp8_bs32", lambda: _dit_leg("DiT-XL/2", 32, latent, dev, True, 10, 3)),
+            ("config1_ddpm_cifar10_bs64_50steps", lambda: _ddpm_leg(dev)),
+            ("config4_sd_v1_unet", lambda: _sd_leg(dev))]
+    for name, fn in legs:
+        if time.perf_counter() - t_start > budget_s:
+            out[name] = {"skipped": f"time budget of {budget_s:.0f} s used up by the legs before it"}
+            continue
+        try:
+            t0 = time.perf_counter()
+            out[name] = fn()
+            out[name]["leg_wall_s"] = time.perf_counter() - t0
+        except Exception as e:      # noqa: BLE001 -- report, keep the headline
+            out[name] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
 
 
 def launch_ranks(n):
@@ -255,7 +394,7 @@ def main():
     step_flops = 6.0 * fwd_per_sample * args.batch
     ms_per_step = elapsed / args.steps * 1e3
 
-    # dominant kernel by GPU time (profiles/r03_kernel_table.md): the weight-gradient GEMM k_gemm_pipe<4,2,3,6,true,true,1,2,2>, one
+    # dominant kernel by GPU time (profiles/r04_kernel_table.md): the weight-gradient GEMM k_gemm_pipe<4,2,3,6,true,true,1,2,2>, one
     # kernel name for the four shapes dW = dY^T X of a block (qkv 65.2, proj 21.7, fc1 87.0, fc2 87.0 GFLOP): the probe brackets all
     # four, so the mean launch does their mean
     wg_flops = 0.25 * (2.0 * M * 3 * D * D + 2.0 * M * D * D + 2 * 2.0 * M * F * D)
@@ -283,7 +422,19 @@ def main():
             if j.get("csrc_sha") == tree_sha:
                 return j.get(key)
         return None
-    traffic = committed_traffic("r03_wgrad_traffic.json")
+    traffic = committed_traffic("r04_wgrad_traffic.json")
+
+    def sane_sweep_traffic():
+        """the committed PMC figure of all sweeps of a step, or None with the reason when it cannot be true: scaled to the remain-stage
+        sweep timed above it must not imply more than the HBM peak (round 3's figure did: its tool divided by the wrong step count)"""
+        tr, alg = committed_traffic("r04_sweep_traffic.json", "traffic_bytes_per_step"), committed_traffic("r04_sweep_traffic.json", "algorithmic_bytes_per_step")
+        if tr is None or alg is None or sw_ach is None:
+            return tr, alg, None
+        implied = tr / alg * sw_ach
+        if implied > HBM_PEAK_GBS:
+            return None, alg, f"refused: {tr / 1e9:.1f} GB per step at the measured sweep rate would be {implied:.0f} GB/s > the {HBM_PEAK_GBS:.0f} GB/s peak"
+        return tr, alg, None
+    sweep_traffic, sweep_alg, sweep_traffic_note = sane_sweep_traffic()
 
     check_res = None
     if args.check and world > 1:
@@ -329,7 +480,7 @@ def main():
                          "kernel": "k_gemm_pipe<4,2,3,6,true,true,1,2,2,false,4> = 192x192 tile, three LDS slots, eight multiplying waves + four loader waves "
                                    "that issue the LDS-DMA: the weight "
                                    f"gradients dW = dY^T X of a block (qkv [{3 * D}x{D}], proj [{D}x{D}], fc1 [{F}x{D}], fc2 [{D}x{F}], contraction over "
-                                   f"{M} token rows; mean {wg_flops / 1e9:.1f} GFLOP per launch); largest share of GPU time (profiles/r03_kernel_table.md); "
+                                   f"{M} token rows; mean {wg_flops / 1e9:.1f} GFLOP per launch); largest share of GPU time (profiles/r04_kernel_table.md); "
                                    "it runs on the weight-gradient stream BESIDE the dgrad chain, so its duration is shared-CU time",
                          "achieved": wg_ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": wg_ach / MFMA_BF16_PEAK_TFLOPS,
                          "traffic": traffic, "flops_per_launch": wg_flops, "avg_launch_ms": wg_ms, "launches_timed": n_wp,
@@ -337,16 +488,25 @@ def main():
                              "fwd_fc1_gelu": {"bound": "mfma", "kernel": f"k_gemm_pipe<4,2,4,6,false,false,2,1,2>: Mlp.fc1 + GELU-tanh [{M}x{D}]x[{D}x{F}], block 0 of "
                                               "every forward pass (main stream, nothing beside it; not launched by the fp8 path)", "achieved": achieved if n_probe else None,
                                               "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": (achieved / MFMA_BF16_PEAK_TFLOPS) if n_probe else None,
-                                              "traffic": committed_traffic("r03_fc1_traffic.json") if n_probe else None,
+                                              "traffic": committed_traffic("r04_fc1_traffic.json") if n_probe else None,
                                               "flops_per_launch": fc1_flops, "avg_launch_ms": avg_ms, "launches_timed": n_probe},
                              "hbm": {"bound": "hbm", "kernel": "remain-stage parameter sweep: k_masked_clip_adam (AdamW + EMA + bf16 shadow, 38 B/param) over the flat arenas "
                                      "+ k_adam_lowrank over the adaLN matrix (gradient formed from its two factors: 34 B/param)", "achieved": sw_ach, "peak": HBM_PEAK_GBS,
                                      "unit": "GB/s", "frac": (sw_ach / HBM_PEAK_GBS) if sw_ach is not None else None, "traffic": None,
-                                     "traffic_all_sweeps_per_step": committed_traffic("r03_sweep_traffic.json", "traffic_bytes_per_step"),
-                                     "algorithmic_all_sweeps_per_step": committed_traffic("r03_sweep_traffic.json", "algorithmic_bytes_per_step"),
+                                     "traffic_all_sweeps_per_step": sweep_traffic, "algorithmic_all_sweeps_per_step": sweep_alg,
+                                     "traffic_note": sweep_traffic_note,
                                      "bytes_per_launch": sweep_bytes, "avg_launch_ms": sw_ms, "launches_timed": len(sweep_ms),
                                      "measured": sweep_where}}},
         }
+        if world == 1 and not args.no_configs and args.model == "DiT-XL/2" and not args.fp8:
+            # the other BASELINE configurations, on the same box right after the headline: free the headline's arenas first
+            import gc
+            runner.sync_sweep()
+            eng.close()
+            del runner, model, eng, batches, out, mask_arena
+            gc.collect()
+            torch.cuda.empty_cache()
+            res["roofline"]["others"]["configs"] = other_configs(dev, latent)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.model, latent, args.batch, args.cpu_batch)
         else:

@@ -135,8 +135,9 @@ class DDPMSfronOracle:
 
     def __init__(self, model, betas, lr=1e-4, forget_alpha=10.0, remain_alpha=1.0, grad_clip=1.0,
                  ema_mu=1e-4, mask=None, unlearn_loss="adaga", lambd=0.5, n_iters=50, decay_forget_alpha=True, label_to_forget=0,
-                 n_classes=10):
+                 n_classes=10, method="ron"):
         self.label_to_forget, self.n_classes = label_to_forget, n_classes
+        self.method = method        # "joint": runners/diffusion.py:1160-1167 -- ONE clipped Adam step on remain_loss + forget_loss
         self.model = model
         self.b = betas
         # DDPM/functions/__init__.py:9-18 with cifar10_sfron.yml:48-56
@@ -170,18 +171,31 @@ class DDPMSfronOracle:
                 ori_forget = -ddpm_adaptive_loss(per, self.lambd)
             else:
                 raise ValueError(self.unlearn_loss)
-        self.opt.zero_grad()
-        (alpha * ori_forget).backward()
-        if self.mask is not None:
-            for name, p in m.named_parameters():
-                if p.grad is not None and name in self.mask:
-                    p.grad *= self.mask[name]
-        torch.nn.utils.clip_grad_norm_(m.parameters(), self.grad_clip)
-        self.opt.step()
+        forget_loss = alpha * ori_forget
+        if self.method == "ron":                                      # :1122-1139
+            self.opt.zero_grad()
+            forget_loss.backward()
+            if self.mask is not None:
+                for name, p in m.named_parameters():
+                    if p.grad is not None and name in self.mask:
+                        p.grad *= self.mask[name]
+            torch.nn.utils.clip_grad_norm_(m.parameters(), self.grad_clip)
+            self.opt.step()
         fn_r = lambda x, tf: m(x, tf, remain["c"], remain["drop"])
         ori_remain = ddpm_loss_per_sample(fn_r, remain["x0"], remain["t"], remain["e"], self.b).mean(dim=0)
-        self.opt.zero_grad()
-        (self.remain_alpha * ori_remain).backward()
+        if self.method == "ron":
+            self.opt.zero_grad()
+            (self.remain_alpha * ori_remain).backward()
+        else:
+            # :1160-1167 as written: the mask loop runs on the STALE gradients of the previous step and zero_grad() follows it, so
+            # the mask has no effect on the update; both graphs are back-propagated from the same (not yet updated) weights
+            loss = self.remain_alpha * ori_remain + forget_loss
+            if self.mask is not None:
+                for name, p in m.named_parameters():
+                    if p.grad is not None and name in self.mask:
+                        p.grad *= self.mask[name]
+            self.opt.zero_grad()
+            loss.backward()
         torch.nn.utils.clip_grad_norm_(m.parameters(), self.grad_clip)
         self.opt.step()
         with torch.no_grad():

@@ -283,3 +283,91 @@ def test_config5_tolerance_against_config3_dit_xl2():
     assert torch.isfinite(out5).all() and torch.isfinite(g5).all()
     assert e < 6e-2, e
     assert cos > 0.99, cos
+
+
+def test_config5_as_worded_fisher_mask_into_fp8_sfron():
+    """BASELINE config 5 as BASELINE.json words it -- "fp8 weights ..., Fisher mask from generate_fisher.py": the pipeline
+    FisherAccumulator (DiT/generate_fisher.py:216-291) -> masks_from_fisher (DiT/generate_mask.py:27-46) -> DiTSFRon(fp8=True) for three
+    iterations, against the fake-quantised oracle stepping with THE SAME mask (the mask is data once generated; its own parity is
+    tests/test_gpu_fisher_and_acceptance.py and the bit-exact fixture test)."""
+    from oracle import diffusion_ref as dref
+    from oracle import sfron_ref
+    from sfron import data, diffusion, fisher, step
+    B, n_iters = 4, 2
+    ref, fq, model = _pair(CFG, B, seed=17)
+    kw = dict(global_batch=B, num_classes=10, forget_class=3, input_size=16)
+    # ---- Fisher of the forget / remain streams on the HIP path (the engine's own passes: fp8 forward, bf16 backward), then the mask
+    model.eval()
+    diff = diffusion.create_diffusion("")
+    acc = {s_: fisher.FisherAccumulator(model, diff, n_iters) for s_ in ("forget", "remain")}
+    for s_ in ("forget", "remain"):
+        for it in range(n_iters):
+            b = {k: v.to(DEV) for k, v in data.synthetic_batch(21, it, s_, **kw).items()}
+            b["drop"] = None
+            acc[s_].accumulate(b)
+    mask = fisher.masks_from_fisher(acc["forget"].state_dict(), acc["remain"].state_dict(), 1.0)
+    assert mask["module.pos_embed"] == 0
+    frac = torch.cat([m.flatten().float() for m in mask.values() if torch.is_tensor(m)]).mean().item()
+    assert 0.05 < frac < 0.95, frac                   # a mask that selects something and leaves something out
+    mask_cpu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in mask.items()}
+    # ---- three SFR-on iterations under that mask: fp8 HIP path vs fake-quant oracle
+    model.train()
+    hp = dict(lr=2e-4, forget_alpha=0.3, grad_clip=1.0, ema_decay=0.99, unlearn_loss="ga", forget_class=3)
+    orc = sfron_ref.DiTSfronOracle(fq, dref.DiffusionTables(1000), mask=mask_cpu, **hp)
+    runner = step.DiTSFRon(model, diff, fp8=True, mask=mask, **hp)
+    p0 = {n: p.detach().clone() for n, p in fq.named_parameters()}
+    for it in range(3):
+        f, r = data.synthetic_batch(23, it, "forget", **kw), data.synthetic_batch(23, it, "remain", **kw)
+        _pin_scales(fq, model.engine)
+        want = orc.step({k: v.long() if k == "drop" else v for k, v in f.items()}, {k: v.long() if k == "drop" else v for k, v in r.items()})
+        got = runner.step({k: v.to(DEV) for k, v in f.items()}, {k: v.to(DEV) for k, v in r.items()})
+        assert got["forget_mse"].mean().item() == pytest.approx(want["forget_mse"], rel=3e-2)
+        assert got["remain_mse"].mean().item() == pytest.approx(want["remain_mse"], rel=3e-2)
+        assert got["stats"][0].item() == pytest.approx(want["forget_gnorm"], rel=6e-2)
+    runner.guard.poll(block=True)
+    eng = model.engine
+    same = tot = 0
+    for n, q in fq.named_parameters():
+        if not q.requires_grad or n.endswith("attn.qkv.bias"):
+            continue
+        du_ref, du = (q.detach() - p0[n]).flatten(), (eng.view(eng.params, n).cpu() - p0[n]).flatten()
+        big = du_ref.abs() > 0.05 * du_ref.abs().max()
+        same += int((torch.sign(du[big]) == torch.sign(du_ref[big])).sum()); tot += int(big.sum())
+    assert same / tot > 0.97, same / tot
+
+
+def test_config5_xl2_batch32_iteration_reproducible_and_shadow_consistent():
+    """Config 5 at the BASELINE size (DiT-XL/2, batch 32): two fresh runs of a whole fp8 SFR-on iteration agree bit for bit (the amax
+    collection is an integer atomicMax -- order-free), every value is finite, and the e4m3 shadow the NEXT forward pass would read is the
+    e4m3 image of the current fp32 masters under the scales in use, for every block tensor."""
+    from oracle import fp8_ref
+    from sfron import data, dit, diffusion, step
+    res = []
+    for run in range(2):
+        torch.manual_seed(0)
+        model = dit.DiT_models["DiT-XL/2"](input_size=32, num_classes=1000, batch_size=32)
+        dit.randomize_zero_init(model, std=0.02, seed=1)
+        eng = model.engine
+        mask = (torch.rand(eng.n_trainable, generator=torch.Generator().manual_seed(5)) < 0.5).to(torch.uint8).to(DEV)
+        runner = step.DiTSFRon(model, diffusion.create_diffusion("", device=DEV), lr=1e-4, forget_alpha=1e-3, grad_clip=1.0, mask=None,
+                               unlearn_loss="ga", forget_class=207, fp8=True)
+        runner.mask_arena = runner.opt.mask = mask
+        out = runner.step(data.synthetic_batch(7, 0, "forget", 32, device=DEV), data.synthetic_batch(7, 0, "remain", 32, device=DEV))
+        torch.cuda.synchronize()
+        runner.guard.poll(block=True)
+        assert torch.isfinite(out["forget_mse"]).all() and torch.isfinite(out["remain_mse"]).all()
+        res.append((eng.params[:eng.n_trainable].clone(), eng.fp8["w8"].clone(), eng.fp8["scales"].clone()))
+        if run == 1:
+            lay, c = eng.layout, eng.cfg
+            D, F = c.hidden, c.mlp_hidden
+            for l in (0, 13, 27):
+                b = lay["blocks"] + l * lay["blk_stride"]
+                for i, (off, n) in enumerate(((lay["qkv_w"], 3 * D * D), (lay["proj_w"], D * D), (lay["fc1_w"], F * D), (lay["fc2_w"], D * F))):
+                    want8 = fp8_ref.e4m3_bytes(eng.params[b + off:b + off + n].cpu(), float(eng.fp8["scales"][4 * l + i]))
+                    got8 = eng.fp8["w8"][b + off:b + off + n].cpu()
+                    assert ((got8 == want8) | (((got8 & 0x7F) == 0) & ((want8 & 0x7F) == 0))).all(), (l, i)      # +0 == -0
+        del runner, model
+        torch.cuda.empty_cache()
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b), "two fresh runs of the same fp8 iteration must agree bit for bit"
+    assert torch.isfinite(res[0][0]).all()

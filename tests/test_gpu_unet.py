@@ -38,7 +38,11 @@ def _nchw(r, B, H, W):
 # zero-dilated sources, flipped taps; 160-column tiles for the 320-wide output, 128-column tiles with a ragged last tile for 192)
 CONV_FORMS = {"same": (3, 8, 32, 64), "down": (3, 8, 32, 32), "up": (3, 8, 32, 32), "rgb_in": (3, 8, 3, 32), "rgb_out": (3, 8, 32, 3),
               "same_big": (16, 16, 64, 128),                     # 4096 pixels -> also the weight gradient's split-K path
-              "down_big": (4, 16, 64, 64), "up_big": (4, 8, 64, 128), "wide": (4, 16, 128, 320), "ragged": (4, 8, 64, 192)}
+              "down_big": (4, 16, 64, 64), "up_big": (4, 8, 64, 128), "wide": (4, 16, 128, 320), "ragged": (4, 8, 64, 192),
+              # SD v1's hot shapes (timed in tools/bench_conv.py, now compared): 320 -> 320 at 64 x 64, 1280 -> 1280 at
+              # 8 x 8 (split-K), and the concatenation convolutions 2560 -> 1280 at 16 x 16 / 1920 -> 640 at 32 x 32
+              "sd320": (1, 64, 320, 320), "sd1280": (2, 8, 1280, 1280), "sdcat16": (1, 16, 2560, 1280), "sdcat32": (1, 32, 1920, 640),
+              "sd_down": (1, 32, 640, 640), "sd_up": (1, 16, 1280, 1280)}
 
 
 @pytest.mark.parametrize("form", list(CONV_FORMS))
@@ -49,7 +53,7 @@ def test_conv3x3_forward_dgrad_wgrad(form):
     L = _lib.lib()
     g = torch.Generator().manual_seed(len(form))
     B, H, ci, co = CONV_FORMS[form]
-    form = form.split("_")[0] if form.endswith("_big") else form
+    form = form.split("_")[0] if form.endswith("_big") else form.split("_")[1] if form.startswith("sd_") else form
     cip, cop = unet._pad8(ci), unet._pad8(co)
     x = torch.randn(B, ci, H, H, generator=g).to(torch.bfloat16).float()
     w = (torch.randn(co, ci, 3, 3, generator=g) * 0.1)
@@ -594,6 +598,55 @@ def test_ddpm_sfron_iterations_native_denoiser_vs_oracle(loss):
         assert not torch.equal(sh[n], views[n])
 
 
+def test_ddpm_joint_method_vs_oracle():
+    """--method joint of the DDPM runner (runners/diffusion.py:1160-1167): one clipped Adam step per iteration on remain_alpha * remain_loss +
+    alpha * forget_loss, both graphs from the same weights, the mask loop a no-op (it runs on stale gradients in front of zero_grad()):
+    three iterations on a small U-Net against the oracle restating those lines; one optimizer step per iteration; the result differs
+    from the "ron" method's."""
+    from oracle import sfron_ref
+    from sfron import ddpm
+    cfg = dict(SMALL, dropout=0.0)
+    B, n_it = 8, 3
+    betas = torch.from_numpy(np.linspace(1e-4, 2e-2, 1000, dtype=np.float64)).float()
+    res = {}
+    for method in ("joint", "ron"):
+        ref, model = _pair(cfg, seed=51)
+        gm = torch.Generator().manual_seed(52)
+        mask = {n: (torch.rand(p.shape, generator=gm) < 0.5) for n, p in ref.named_parameters()}
+        hp = dict(lr=1e-4, forget_alpha=10.0, grad_clip=1.0, mask=mask, unlearn_loss="adaga", lambd=0.5, n_iters=n_it, decay_forget_alpha=True)
+        fwd = ref.forward
+        ref.forward = lambda x, tf, c, drop, fwd=fwd: fwd(x, tf, c, mode="train", keep_mask=~drop)
+        orc = sfron_ref.DDPMSfronOracle(ref, betas, ema_mu=1e-4, method=method, **hp)
+        run = ddpm.DDPMSFRon(model, betas=betas.to(DEV), ema_rate=1e-4, method=method, **hp)
+        g = torch.Generator().manual_seed(53)
+        p0 = {n: p.detach().clone() for n, p in ref.named_parameters()}
+        for it in range(n_it):
+            f, r = _synthetic(it, "forget", B, g), _synthetic(it, "remain", B, g)
+            for b in (f, r):
+                b["x0"], b["e"] = b["x0"][:, :, :16, :16].contiguous(), b["e"][:, :, :16, :16].contiguous()
+                b["drop"] = (torch.rand(B, generator=g) < 0.1)
+            want = orc.step(it, dict(f), dict(r))
+            fd = {k: v.to(DEV) for k, v in f.items()}; rd = {k: v.to(DEV) for k, v in r.items()}
+            fd["keep_mask"], rd["keep_mask"] = ~f["drop"], ~r["drop"]
+            got = run.step(it, fd, rd)
+            assert got["forget_loss"].item() == pytest.approx(want["forget_loss"], rel=3e-2, abs=1e-3)
+            assert got["remain_loss"].item() == pytest.approx(want["remain_loss"], rel=3e-2)
+        assert run.opt.step_count == (n_it if method == "joint" else 2 * n_it)
+        same = tot = 0
+        views = run.flat.named_views(run.flat.p)
+        for n, q in ref.named_parameters():
+            if n.endswith(".k.bias"):
+                continue
+            du_ref, du = (q.detach() - p0[n]).flatten(), (views[n].cpu() - p0[n]).flatten()
+            big = du_ref.abs() > 0.05 * du_ref.abs().max()
+            same += int((torch.sign(du[big]) == torch.sign(du_ref[big])).sum()); tot += int(big.sum())
+        assert same / tot > 0.985, (method, same / tot)
+        res[method] = run.flat.p.clone()
+    assert not torch.equal(res["joint"], res["ron"])
+    with pytest.raises(ValueError):
+        ddpm.DDPMSFRon(model, method="alternate")
+
+
 @pytest.mark.parametrize("loss", ["adaga", "rl"])
 def test_ddpm_graph_replay_matches_eager(loss):
     """The forget / remain stages replayed as HIP graphs (sfron.graphs; the decayed alpha as a device scalar) against the eager loop:
@@ -695,16 +748,34 @@ def test_config1_fifty_sfron_steps_batch64_native():
     assert run.opt.step_count == 100
 
 
-def test_unet_test_mode_backward_raises_clear_error():
-    """mode="test" is inference-only here (the reference's is differentiable: models/diffusion.py:340-357): a backward() through it
-    must fail with a message that points to DDPMFisherAccumulator, not with a missing-gradient surprise later."""
-    from sfron import _lib
-    _, model = _pair(SMALL, seed=6)
-    model.eval()
-    x, t, c = torch.randn(2, 3, 16, 16, device=DEV), torch.tensor([3.0, 700.0], device=DEV), torch.tensor([1, 2], device=DEV)
-    out = model(x, t, c, mode="test", cond_scale=2.0)
-    assert out.requires_grad
-    with pytest.raises(_lib.SfronError, match="DDPMFisherAccumulator"):
-        out.sum().backward()
+def test_unet_test_mode_is_differentiable_like_the_reference():
+    """mode="test" (models/diffusion.py:340-357) carries gradients through BOTH guidance branches, as the reference's Fisher loop needs
+    (runners/diffusion.py:1260-1276): every parameter gradient of sum(w * ((1 + s) f_cond - s f_null)) against the oracle's autograd,
+    for s = 2 and for s = 0 (conditional branch alone); under no_grad the result carries no graph."""
+    ref, model = _pair(SMALL, seed=6)
+    ref.eval(); model.eval()
+    g = torch.Generator().manual_seed(16)
+    x, t, c = torch.randn(2, 3, 16, 16, generator=g), torch.tensor([3.0, 700.0]), torch.tensor([1, 2])
+    w = torch.randn(2, 3, 16, 16, generator=g) * 0.1
+    for s_ in (2.0, 0.0):
+        ref.zero_grad()
+        want = ref(x, t, c, mode="test", cond_scale=s_)
+        (want * w).sum().backward()
+        model.zero_grad()
+        out = model(x.to(DEV), t.to(DEV), c.to(DEV), mode="test", cond_scale=s_)
+        assert out.requires_grad and _rel(out, want) < (3e-2 if s_ else 1.5e-2)
+        (out * w.to(DEV)).sum().backward()
+        dots = na = nb = 0.0
+        gmed = float(torch.tensor([q.grad.norm().item() for q in ref.parameters() if q.grad is not None]).median())
+        for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            if q.grad is None:
+                continue
+            ga, gb = p.grad.detach().cpu().flatten().double(), q.grad.flatten().double()
+            dots += torch.dot(ga, gb).item(); na += ga.pow(2).sum().item(); nb += gb.pow(2).sum().item()
+            if gb.norm().item() < 2e-3 * gmed:       # analytically zero (a key bias, a constant in front of a normalisation): noise on both sides
+                continue
+            # the two branches' bf16 errors add with weights (1 + s) and s while the difference is no larger than one branch
+            assert ((ga - gb).norm() / gb.norm()).item() < (0.15 if s_ else 6e-2), (s_, n, ((ga - gb).norm() / gb.norm()).item())
+        assert dots / math.sqrt(na * nb) > (0.998 if s_ else 0.9995), (s_, dots / math.sqrt(na * nb))
     with torch.no_grad():
-        assert not model(x, t, c, mode="test", cond_scale=2.0).requires_grad
+        assert not model(x.to(DEV), t.to(DEV), c.to(DEV), mode="test", cond_scale=2.0).requires_grad

@@ -13,7 +13,7 @@ os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     subprocess.run(["rocprofv3", "--pmc", c, "--output-format", "csv", "-d", os.path.join(out, c), "--", "python3", os.path.join(ROOT, "bench.py"),
-                    "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                    "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-configs"], cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 agg = collections.defaultdict(lambda: [0.0, 0])
 for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(path, newline="")):
@@ -32,10 +32,18 @@ tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
 for (c, k), (sm, n) in agg.items():
     if any(x in k for x in ("k_masked_clip_adam", "k_adam_lowrank", "k_sumsq_masked", "k_sumsq_lowrank")):
         tot[c] += sm
+# steps in the profiled run: NOT the 3 of the command line -- when the timed steps split their remain-stage sweep across the step boundary,
+# bench.py appends two more steps to time that sweep whole (round 3 divided by 3 and reported 5/3 of the traffic: 78.7 GB against 47.2 GB
+# algorithmic, which would have been more than the HBM peak).  k_adam_lowrank runs exactly twice per step (forget + remain stage).
+n_lowrank = max([n for (c, k), (sm, n) in agg.items() if c == "FETCH_SIZE" and "k_adam_lowrank" in k] or [0])
+n_steps = n_lowrank / 2.0 if n_lowrank else 3.0
 json.dump({"kernel": "k_sumsq_masked + k_sumsq_lowrank + k_masked_clip_adam + k_adam_lowrank, all launches of one SFR-on step",
-           "traffic_bytes_per_step": (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / 3.0,
+           "steps_in_run": n_steps,
+           "fetch_raw_bytes_per_step": tot["FETCH_SIZE"] * 1024.0 / n_steps, "write_bytes_per_step": tot["WRITE_SIZE"] * 1024.0 / n_steps,
+           "traffic_bytes_per_step": (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / n_steps,
            "algorithmic_bytes_per_step": (5 + 31 + 38) * nt - (4 + 4 + 4) * n_ada, "csrc_sha": sha,
-           "note": "same passes; totals over the three steps of the run / 3.  Algorithmic: norm pre-pass 5 B/param (g, mask), forget "
+           "note": "same passes; totals over the run / its step count (launches of k_adam_lowrank / 2); FETCH_SIZE x2 (the kernels' reads are "
+                   "16-B-per-lane streams but for the 1-B-per-parameter mask), WRITE_SIZE exact.  Algorithmic: norm pre-pass 5 B/param (g, mask), forget "
                    "AdamW 31, remain AdamW + EMA 38, minus the gradient reads of the adaLN matrix (formed inside the sweep from its factors)"},
           open(os.path.join(out, f"{tag}_sweep_traffic.json"), "w"), indent=1)
 probes.pop("sweep")

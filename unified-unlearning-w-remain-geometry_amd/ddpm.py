@@ -207,9 +207,15 @@ class DDPMSFRon:
 
     def __init__(self, model, betas=None, lr=1e-4, forget_alpha=10.0, remain_alpha=1.0, grad_clip=1.0, ema_rate=None, mask=None,
                  unlearn_loss="adaga", lambd=0.5, n_iters=50, decay_forget_alpha=True, cond_drop_prob=0.1, process_group=None,
-                 label_to_forget=0, n_classes=10, use_graphs=False):
+                 label_to_forget=0, n_classes=10, use_graphs=False, method="ron"):
         from . import dp, sweep
         self.use_graphs, self._graphs, self._pool = bool(use_graphs), {}, None
+        # method "joint" (runners/diffusion.py:1160-1167): ONE clipped Adam step per iteration on remain_alpha * remain_loss +
+        # alpha * forget_loss, both back-propagated from the same weights; the reference's mask loop there runs on the stale gradients
+        # of the previous step, just before zero_grad(), so the mask does not touch the update
+        if method not in ("ron", "joint"):
+            raise ValueError(f"unsupported method {method!r} (DDPM/runners/diffusion.py:1121,1154-1167 defines 'ron' and 'joint')")
+        self.method, self._g_forget = method, None
         if unlearn_loss not in ("ga", "adaga", "rl"):
             raise ValueError(f"unsupported unlearn_loss {unlearn_loss!r} (DDPM/runners/diffusion.py:1095-1120 defines ga, rl, adaga)")
         self.label_to_forget, self.n_classes = label_to_forget, n_classes
@@ -291,14 +297,27 @@ class DDPMSFRon:
         keys = ("x0", "c", "t", "e", "keep_mask")
         a_dev = torch.full((), float(alpha), dtype=torch.float32, device=self.flat.p.device) if self.use_graphs else alpha
         ori_forget = self._stage("forget", self._forget_pass, alpha=a_dev, **{k: forget.get(k) for k in keys})
-        if self.world > 1:
-            self._dp.allreduce_flat_(self.flat.g, 64 << 20, self.pg)
-        self.opt.step(max_norm=self.grad_clip, use_mask=True)
-        self._weights_updated()
+        if self.method == "joint":
+            # the forget stage's gradient is parked (the remain stage zeroes the arena) and handed to the sweep as its second gradient
+            # arena: the norm pre-pass and the Adam kernel add the two (csrc/sweep.hip g2)
+            if self._g_forget is None:
+                self._g_forget = torch.empty_like(self.flat.g)
+            self._g_forget.copy_(self.flat.g)
+        else:
+            if self.world > 1:
+                self._dp.allreduce_flat_(self.flat.g, 64 << 20, self.pg)
+            self.opt.step(max_norm=self.grad_clip, use_mask=True)
+            self._weights_updated()
         ori_remain = self._stage("remain", self._remain_pass, **{k: remain.get(k) for k in keys})
+        if self.method == "joint":
+            if self.world > 1:
+                self.flat.g.add_(self._g_forget)
+            else:
+                self.opt.g2 = self._g_forget
         if self.world > 1:
             self._dp.allreduce_flat_(self.flat.g, 64 << 20, self.pg)
         self.opt.step(max_norm=self.grad_clip, use_mask=False, ema=self.shadow, ema_decay=self.mu if self.mu is not None else 0.0, ema_mode=2)
+        self.opt.g2 = None
         self._weights_updated()
         return {"forget_loss": ori_forget, "remain_loss": ori_remain, "alpha": alpha}
 

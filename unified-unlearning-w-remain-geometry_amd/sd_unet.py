@@ -23,7 +23,7 @@ import torch
 
 from . import _lib
 from ._lib import check, ptr, stream_ptr
-from .unet import Act, _TapeNet, _L, _pad8, bgemm, cast_rows
+from .unet import Act, _TapeNet, _L, _pad8, bgemm, cast_rows, count_flops
 
 
 class UNetModel(_TapeNet):
@@ -221,11 +221,13 @@ class UNetModel(_TapeNet):
         dev = self.device_
         O = torch.empty(B * N, C, dtype=torch.bfloat16, device=dev)
         lse = torch.empty(B * h * N, dtype=torch.float32, device=dev)
+        count_flops(4.0 * N * N * d * h * B)
         check(_L().sfron_attn_fwd(ptr(qkv), ptr(O), ptr(lse), B, N, h, d, stream_ptr()), "attn_fwd")
 
         def bwd(dO, dq, dk, dv):
             # the kernel writes the whole dqkv matrix: dq is its base address (dk = dq + C, dv = dq + 2C by construction)
             delta = torch.empty(B * h * N, dtype=torch.float32, device=dev)
+            count_flops(8.0 * N * N * d * h * B)          # dS, dQ, dK, dV (the recomputed S is not algorithmic work)
             check(_L().sfron_attn_bwd(ptr(qkv), ptr(O), ptr(dO), ptr(lse), ptr(delta), dq, B, N, h, d, stream_ptr()), "attn_bwd")
         return O, bwd
 

@@ -58,6 +58,16 @@ def _pad8(n):
 
 
 # ------------------------------------------------------------------------------------------------ thin kernel wrappers
+# bench.py: a one-element list here makes every product the tape launches add its algorithmic FLOPs (2 M N K; 2 rows n_out taps c_src
+# for a convolution; 4 T^2 d per head forward / 10 T^2 d backward for the flash attention kernels) -- None in normal use
+PRODUCT_FLOPS = None
+
+
+def count_flops(x):
+    if PRODUCT_FLOPS is not None:
+        PRODUCT_FLOPS[0] += float(x)
+
+
 def bgemm(A, B, M, N, K, *, lda, ldb, a_t=False, b_t=False, batch=1, sa=0, sb=0, sc=0, batch2=1, sa2=0, sb2=0, sc2=0, alpha=1.0, bias=None,
           c_bf16=None, c_f32=None, ldc=None, resid=None, vec=None, ld_vec=0, rows_per_sample=1, accumulate=False):
     """A / B / outputs may be tensors or raw device addresses (column-slice views are passed as address + leading dimension)."""
@@ -78,6 +88,7 @@ def bgemm(A, B, M, N, K, *, lda, ldb, a_t=False, b_t=False, batch=1, sa=0, sb=0,
     elif a_t and b_t and c_bf16 is not None and batch * batch2 > 1 and K >= 1024 and M <= 128 and N <= 256 and not isinstance(A, int):
         ws, nsl = _split_scratch(M * N * batch * batch2, A)          # head-batched single-tile products: split the contraction
         d.split_ws, d.split_ws_slabs = ws.data_ptr(), nsl * batch * batch2
+    count_flops(2.0 * M * N * K * batch * batch2)
     check(_L().sfron_bgemm_bf16(ctypes.byref(d), stream_ptr()), "bgemm_bf16")
 
 
@@ -123,6 +134,7 @@ def _conv_desc(B, hs, ws, cs, ho, wo, n_out, taps=9, stride=1, pad=1, up=0, dil=
     d.bias, d.resid, d.sample_vec, d.ld_vec = _addr(bias), _addr(resid), _addr(vec), ld_vec
     d.out_bf16, d.out_f32, d.ld_out, d.accumulate = _addr(out_bf16), _addr(out_f32), ld_out or 0, int(accumulate)
     rows, t = B * ho * wo, out_f32 if out_f32 is not None else out_bf16
+    count_flops(2.0 * rows * n_out * taps * cs)          # every descriptor is launched exactly once
     if t is not None and not isinstance(t, int) and rows * n_out <= (1 << 23) and taps * cs >= 2048 and ld_out == n_out:
         ws, nsl = _split_scratch(rows * n_out, t)            # few output tiles, deep contraction: split-K slabs
         d.split_ws, d.split_ws_slabs = ws.data_ptr(), nsl
@@ -482,16 +494,39 @@ class _TapeNet(nn.Module):
         return out
 
 
-class _GuidedNoBackward(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, out, anchor):
-        return out.view_as(out)
+class _GuidedFn(torch.autograd.Function):
+    """mode="test" with gradients: out = (1 + s) f(x, t, c | keep all) - s f(x, t, c | drop all) through BOTH branches, as the
+    reference's _forward_with_cond_scale (DDPM/models/diffusion.py:340-357), which its Fisher loop back-propagates through
+    (runners/diffusion.py:1260-1276).  Two tapes over the same weights; the backward pass runs them one after the other with d_out
+    scaled by (1 + s) and -s -- each overwrites the gradient arena, so the first branch's arena is parked and added back."""
 
     @staticmethod
-    def backward(ctx, g):
-        raise _lib.SfronError("Conditional_Model(mode='test') is inference-only here: its backward pass is not implemented.  For the Fisher "
-                              "pass of DDPM/runners/diffusion.py:1244-1299 use sfron.fisher.DDPMFisherAccumulator (both guidance branches, "
-                              "gradients summed in the arena); for sampling wrap the call in torch.no_grad().")
+    def forward(ctx, anchor, model, x, t, c, cond_scale):
+        B, dev = x.shape[0], model.device_
+        out_c, bwd_c = model._run(x, t, c, torch.ones(B, dtype=torch.uint8, device=dev), None, need_grad=True)
+        if cond_scale == 0:                          # models/diffusion.py:349-350: the conditional branch alone
+            ctx.model, ctx.bwd, ctx.s = model, (bwd_c, None), 0.0
+            return out_c
+        out_n, bwd_n = model._run(x, t, c, torch.zeros(B, dtype=torch.uint8, device=dev), None, need_grad=True)
+        out = torch.empty_like(out_c)
+        check(_L().sfron_axpby(ptr(out_c), ptr(out_n), 1.0 + cond_scale, -float(cond_scale), out.numel(), ptr(out), stream_ptr()), "axpby")
+        ctx.model, ctx.bwd, ctx.s = model, (bwd_c, bwd_n), float(cond_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        m, (bwd_c, bwd_n), s = ctx.model, ctx.bwd, ctx.s
+        d_out = d_out.float().contiguous()
+        if bwd_n is None:
+            bwd_c(d_out)
+        else:
+            bwd_c(d_out * (1.0 + s))
+            first = m.grads.clone()
+            bwd_n(d_out * (-s))
+            m.grads.add_(first)
+        m.publish_grads()
+        ctx.bwd = None
+        return None, None, None, None, None, None
 
 
 class Conditional_Model(_TapeNet):
@@ -889,19 +924,16 @@ class Conditional_Model(_TapeNet):
             return self._forward(x, t, c, cond_drop_prob=kwargs.get("cond_drop_prob"), keep_mask=kwargs.get("keep_mask"),
                                  dropout_masks=kwargs.get("dropout_masks"))
         cond_scale = kwargs.get("cond_scale", 1.0)
-        with torch.no_grad():
-            B = x.shape[0]
-            logits = self._forward(x, t, c, keep_mask=torch.ones(B, dtype=torch.uint8, device=self.device_))
-            if cond_scale == 0:
-                return logits
-            null = self._forward(x, t, c, keep_mask=torch.zeros(B, dtype=torch.uint8, device=self.device_))
-            out = torch.empty_like(logits)
-            check(_L().sfron_axpby(ptr(logits), ptr(null), 1.0 + cond_scale, -float(cond_scale), logits.numel(), ptr(out), stream_ptr()), "axpby")
         if torch.is_grad_enabled():
-            # the reference's mode="test" (_forward_with_cond_scale, models/diffusion.py:340-357) is differentiable and its Fisher loop
-            # back-propagates through it (runners/diffusion.py:1260-1276); here the guided forward is inference-only.  The result
-            # carries an autograd edge whose backward says so, instead of a tensor that silently has no gradient.
-            return _GuidedNoBackward.apply(out, self._anchor())
+            # differentiable, as the reference's (models/diffusion.py:340-357): gradients flow through both guidance branches
+            return _GuidedFn.apply(self._anchor(), self, x, t, c, float(cond_scale))
+        B = x.shape[0]
+        logits = self._forward(x, t, c, keep_mask=torch.ones(B, dtype=torch.uint8, device=self.device_))
+        if cond_scale == 0:
+            return logits
+        null = self._forward(x, t, c, keep_mask=torch.zeros(B, dtype=torch.uint8, device=self.device_))
+        out = torch.empty_like(logits)
+        check(_L().sfron_axpby(ptr(logits), ptr(null), 1.0 + cond_scale, -float(cond_scale), logits.numel(), ptr(out), stream_ptr()), "axpby")
         return out
 
 
