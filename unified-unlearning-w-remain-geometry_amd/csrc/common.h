@@ -91,4 +91,35 @@ __device__ __forceinline__ float silu_grad(float x) {
   return s * (1.0f + x * (1.0f - s));
 }
 
+
+// ---- 16-byte epilogue accesses for the D^T accumulator layout (MI355X guide T21) ------------------------------------------------
+// After an MFMA 16x16 issued as D^T = B^T A^T a lane holds row (lane & 15), columns 4 g .. 4 g + 3 (g = lane >> 4) of a 16 x 16 tile:
+// 8 bytes of bf16, so the natural store covers 16 rows x 32 B per wave-instruction and a tile row needs one instruction per tile.  The
+// store tail of a GEMM / attention workgroup is ISSUE-bound (instruction count, not bytes).  v_permlane16_swap_b32 x, y leaves
+// x = {x.row0, y.row0, x.row2, y.row2}, y = {x.row1, y.row1, x.row3, y.row3} (rows = 16-lane groups; tools/probes/permlane_probe.hip),
+// so with x / y the packed dwords of two horizontally adjacent tiles k, k + 1 a lane ends up with 16 CONTIGUOUS bytes:
+//   g = 0: tile k cols 0..7   g = 1: tile k+1 cols 0..7   g = 2: tile k cols 8..15   g = 3: tile k+1 cols 8..15
+// i.e. element offset pair_col(g) = 16 (g & 1) + 8 (g >> 1) from tile k's first column: ONE 16-byte access per lane and tile pair.
+// The swap is an involution: the same two swaps turn a 16-byte load at that offset back into the two tiles' native fragments.
+// (asm with separate tied outputs: under hipcc 7.2 the builtin and the "+v" forms returned the first register twice; s_nop 1 pads the
+// VALU-write -> permlane-read hazard the compiler cannot see inside asm.)
+__device__ __forceinline__ void permlane16_swap(unsigned& x, unsigned& y) {
+  unsigned xo, yo;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "=v"(xo), "=v"(yo) : "0"(x), "1"(y));
+  x = xo; y = yo;
+}
+__device__ __forceinline__ int pair_col(int g) { return 16 * (g & 1) + 8 * (g >> 1); }
+__device__ __forceinline__ uint4 pair_pack(bf16x4 a, bf16x4 b) {          // a = tile k, b = tile k + 1 (this lane's 4 columns of each)
+  uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+  permlane16_swap(ua.x, ub.x);
+  permlane16_swap(ua.y, ub.y);
+  return make_uint4(ua.x, ua.y, ub.x, ub.y);
+}
+__device__ __forceinline__ void pair_unpack(uint4 v, bf16x4& a, bf16x4& b) {
+  uint2 ua = make_uint2(v.x, v.y), ub = make_uint2(v.z, v.w);
+  permlane16_swap(ua.x, ub.x);
+  permlane16_swap(ua.y, ub.y);
+  a = __builtin_bit_cast(bf16x4, ua); b = __builtin_bit_cast(bf16x4, ub);
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1162,18 +1162,41 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
       for (int mt = 0; mt < MT; ++mt) g.bsum[(size_t)tn * g.M + row_b + mt * 16] = bacc[mt][0] * g.alpha;
     }
   }
+  // 16-byte epilogue accesses (common.h pair_pack / pair_unpack): two horizontally adjacent 16 x 16 tiles per access where the leading
+  // dimension keeps the pieces 16-B aligned (kernel-uniform); an odd last tile and other leading dimensions take the 8-byte form
+  const int lane_g = lane >> 4;
+  const int col_p = n0 + wn * NT * 16 + pair_col(lane_g);          // this lane's column of a tile PAIR's 16-byte piece (+ nt * 16)
+  constexpr int NP = NT / 2;                                       // tile pairs; tile NT - 1 is alone when NT is odd
   if constexpr (EPI == EPI_DGELU) {
+    const bool wide = ((g.ldaux | g.ldcb) & 7) == 0;
     bf16x4 hx[MT][NT];
+    if (wide) {
+      uint4 hp[MT][NP > 0 ? NP : 1];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        hx[mt][nt] = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)(row_b + mt * 16) * g.ldaux + col_b + nt * 16);
+        for (int np = 0; np < NP; ++np)
+          hp[mt][np] = *reinterpret_cast<const uint4*>(g.aux + (size_t)(row_b + mt * 16) * g.ldaux + col_p + np * 32);
+        if constexpr (NT & 1)
+          hx[mt][NT - 1] = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)(row_b + mt * 16) * g.ldaux + col_b + (NT - 1) * 16);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int np = 0; np < NP; ++np) pair_unpack(hp[mt][np], hx[mt][2 * np], hx[mt][2 * np + 1]);
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          hx[mt][nt] = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)(row_b + mt * 16) * g.ldaux + col_b + nt * 16);
+    }
     f32x4 cs[NT];                                  // this lane's column sums over its MT rows (fc1 bias gradient partials)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) cs[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
+      bf16x4 ob[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const f32x4 v = acc[mt][nt] * g.alpha;
@@ -1181,9 +1204,18 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
         const f32x4 r = {v[0] * gelu_tanh_grad(bf2f(h[0])), v[1] * gelu_tanh_grad(bf2f(h[1])),
                          v[2] * gelu_tanh_grad(bf2f(h[2])), v[3] * gelu_tanh_grad(bf2f(h[3]))};
         cs[nt] += r;
-        bf16x4 o = {f2bf(r[0]), f2bf(r[1]), f2bf(r[2]), f2bf(r[3])};
-        *reinterpret_cast<bf16x4*>(g.Cb + (size_t)(row_b + mt * 16) * g.ldcb + col_b + nt * 16) = o;
+        ob[nt] = bf16x4{f2bf(r[0]), f2bf(r[1]), f2bf(r[2]), f2bf(r[3])};
       }
+      __bf16* const crow = g.Cb + (size_t)(row_b + mt * 16) * g.ldcb;
+      if (wide) {
+#pragma unroll
+        for (int np = 0; np < NP; ++np) *reinterpret_cast<uint4*>(crow + col_p + np * 32) = pair_pack(ob[2 * np], ob[2 * np + 1]);
+        if constexpr (NT & 1) *reinterpret_cast<bf16x4*>(crow + col_b + (NT - 1) * 16) = ob[NT - 1];
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<bf16x4*>(crow + col_b + nt * 16) = ob[nt];
+      }
+    }
     if (g.colpart) {                               // kernel-uniform
       // rows of a wave: the 16 lanes that share lane >> 4 hold the same 4 columns -> butterfly over lane & 15, then the WM
       // waves stacked over the rows meet in LDS (free now: every wave is past the main loop after the barrier); fixed order
@@ -1220,6 +1252,8 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
         xr[nt] = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldcf + col_b + nt * 16);
         gt[nt] = *reinterpret_cast<const float4*>(g.gate + (size_t)(row / g.T) * g.ldgate + col_b + nt * 16);
       }
+      const bool wide = (g.ldaux & 7) == 0 && !(g.nt_out & 1);
+      bf16x4 ab[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int col = col_b + nt * 16;
@@ -1227,11 +1261,56 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
         if constexpr (PRE_BIAS) { const float4 b = bias_v[nt]; v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
         else if constexpr (LATE_BIAS) { const float4 b = bias_l[nt]; v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
         else if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-        bf16x4 a = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        nt_store(reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col), a, g.nt_out & 1);
+        ab[nt] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        if (!wide) nt_store(reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col), ab[nt], g.nt_out & 1);
         float4 x = xr[nt];
         x.x += gt[nt].x * v[0]; x.y += gt[nt].y * v[1]; x.z += gt[nt].z * v[2]; x.w += gt[nt].w * v[3];
         *reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col) = x;
+      }
+      if (wide) {                                  // the bf16 branch output (read again by the backward pass): 16-byte pieces
+        __bf16* const arow = g.aux + (size_t)row * g.ldaux;
+#pragma unroll
+        for (int np = 0; np < NP; ++np) *reinterpret_cast<uint4*>(arow + col_p + np * 32) = pair_pack(ab[2 * np], ab[2 * np + 1]);
+        if constexpr (NT & 1) *reinterpret_cast<bf16x4*>(arow + col_b + (NT - 1) * 16) = ab[NT - 1];
+      }
+    }
+  } else if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
+    const bool wide = (g.ldcb & 7) == 0 && (EPI != EPI_GELU || ((g.ldaux & 7) == 0 && !(g.nt_out & 1)));
+    if (!wide) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          epilogue_store<EPI>(g, row_b + mt * 16, col_b + nt * 16, acc[mt][nt],
+                              PRE_BIAS ? &bias_v[PRE_BIAS ? nt : 0] : LATE_BIAS ? &bias_l[LATE_BIAS ? nt : 0] : nullptr);
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = row_b + mt * 16;
+        bf16x4 ob[NT], hb[EPI == EPI_GELU ? NT : 1];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          f32x4 v = acc[mt][nt] * g.alpha;
+          if constexpr (PRE_BIAS) { const float4 b = bias_v[nt]; v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+          else if constexpr (LATE_BIAS) { const float4 b = bias_l[nt]; v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+          else if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + col_b + nt * 16); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+          if constexpr (EPI == EPI_GELU) {
+            hb[nt] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};                       // pre-activation (the backward pass reads it)
+            ob[nt] = bf16x4{f2bf(gelu_tanh(v[0])), f2bf(gelu_tanh(v[1])), f2bf(gelu_tanh(v[2])), f2bf(gelu_tanh(v[3]))};
+          } else {
+            ob[nt] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+          }
+        }
+        __bf16* const crow = g.Cb + (size_t)row * g.ldcb;
+#pragma unroll
+        for (int np = 0; np < NP; ++np) *reinterpret_cast<uint4*>(crow + col_p + np * 32) = pair_pack(ob[2 * np], ob[2 * np + 1]);
+        if constexpr (NT & 1) *reinterpret_cast<bf16x4*>(crow + col_b + (NT - 1) * 16) = ob[NT - 1];
+        if constexpr (EPI == EPI_GELU) {
+          __bf16* const arow = g.aux + (size_t)row * g.ldaux;
+#pragma unroll
+          for (int np = 0; np < NP; ++np) *reinterpret_cast<uint4*>(arow + col_p + np * 32) = pair_pack(hb[2 * np], hb[2 * np + 1]);
+          if constexpr (NT & 1) *reinterpret_cast<bf16x4*>(arow + col_b + (NT - 1) * 16) = hb[NT - 1];
+        }
       }
     }
   } else {
