@@ -185,6 +185,23 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// One row block of NDT horizontally adjacent 16 x 16 bf16 tiles -> global: v[dt] = this lane's 4 columns (4 g ..) of tile dt.  Tile pairs
+// leave as ONE 16-byte store per lane (common.h pair_pack: the store tail of these kernels is issue-bound), an odd last tile as 8 bytes;
+// columns >= hd (hd % 8 == 0, so a piece is valid whole or not at all) are not written.  Every lane runs the swaps; only stores are masked.
+template <int NDT> __device__ __forceinline__ void store_tiles(__bf16* row, const bf16x4 (&v)[NDT], int hd, int g) {
+#pragma unroll
+  for (int np = 0; np < NDT / 2; ++np) {
+    const uint4 pk = pair_pack(v[2 * np], v[2 * np + 1]);
+    const int c = 32 * np + pair_col(g);
+    if (c < hd) *reinterpret_cast<uint4*>(row + c) = pk;
+  }
+  if constexpr (NDT & 1) {
+    const int d = (NDT - 1) * 16 + 4 * g;
+    if (d < hd) *reinterpret_cast<bf16x4*>(row + d) = v[NDT - 1];
+  }
+}
+__device__ __forceinline__ bf16x4 to_bf16x4(const f32x4& v) { return bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; }
+
 // Ring driver shared by the three kernels.  Two images (X0, X1) per slot.  Usage per chunk c:
 //   ring_wait<...>(c, n) ; barrier ; ring_issue(c + 2) ; compute(slot c % 3)
 template <int HDP>
@@ -322,15 +339,10 @@ __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv,
     const float inv = 1.0f / lt;
     const int q = q0 + 16 * qi + (lane & 15);
     __bf16* orow = o + ((size_t)b * T + q) * D + h * hd;
+    bf16x4 ov[NDT];
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) {
-      const int d = dt * 16 + 4 * g;
-      if (d < hd) {
-        const f32x4 v = oacc[qi][dt] * inv;
-        bf16x4 ov = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        *reinterpret_cast<bf16x4*>(orow + d) = ov;
-      }
-    }
+    for (int dt = 0; dt < NDT; ++dt) ov[dt] = to_bf16x4(oacc[qi][dt] * inv);
+    store_tiles<NDT>(orow, ov, hd, g);
     if (g == 0) lse[(size_t)bh * T + q] = m[qi] * scale + logf(lt);
   }
 }
@@ -454,15 +466,10 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dq(const __bf16* __restrict__ q
   for (int qi = 0; qi < QT; ++qi) {
     const int q = q0 + 16 * qi + (lane & 15);
     __bf16* row = dqkv + ((size_t)b * T + q) * ld + h * hd;
+    bf16x4 ov[NDT];
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) {
-      const int d = dt * 16 + 4 * g;
-      if (d < hd) {
-        const f32x4 v = dq[qi][dt];
-        bf16x4 ov = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        *reinterpret_cast<bf16x4*>(row + d) = ov;
-      }
-    }
+    for (int dt = 0; dt < NDT; ++dt) ov[dt] = to_bf16x4(dq[qi][dt]);
+    store_tiles<NDT>(row, ov, hd, g);
   }
 }
 
@@ -590,17 +597,11 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dkv(const __bf16* __restrict__ 
   for (int ki = 0; ki < KT; ++ki) {
     const int key = k0 + 16 * ki + (lane & 15);
     __bf16* row = dqkv + ((size_t)b * T + key) * ld + h * hd;
+    bf16x4 ka[NDT], va[NDT];
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) {
-      const int d = dt * 16 + 4 * g;
-      if (d < hd) {
-        const f32x4 a = dk[ki][dt], v = dv[ki][dt];
-        bf16x4 ka = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3])};
-        bf16x4 va = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        *reinterpret_cast<bf16x4*>(row + D + d) = ka;
-        *reinterpret_cast<bf16x4*>(row + 2 * D + d) = va;
-      }
-    }
+    for (int dt = 0; dt < NDT; ++dt) { ka[dt] = to_bf16x4(dk[ki][dt]); va[dt] = to_bf16x4(dv[ki][dt]); }
+    store_tiles<NDT>(row + D, ka, hd, g);
+    store_tiles<NDT>(row + 2 * D, va, hd, g);
   }
 }
 
@@ -888,13 +889,20 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
       });
       const int q = qc * 64 + 16 * qi + (lane & 15);
       __bf16* row = dqkv + ((size_t)b * T + q) * ld + h * hd;
+      {
+        bf16x4 ov[ND0];
 #pragma unroll
-      for (int i = 0; i < ND0; ++i) {
-        const int d = (dt0 + i) * 16 + 4 * g;
-        if (i < nd && d < hd) {
-          const f32x4 v = dq[i];
-          bf16x4 ov = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-          *reinterpret_cast<bf16x4*>(row + d) = ov;
+        for (int i = 0; i < ND0; ++i) ov[i] = to_bf16x4(dq[i]);
+#pragma unroll
+        for (int i = 0; i + 1 < ND0; i += 2) {               // pairs of this wave's d-tiles as 16-byte pieces (all lanes swap, stores are masked)
+          const uint4 pk = pair_pack(ov[i], ov[i + 1]);
+          const int c = (dt0 + i) * 16 + pair_col(g), d = (dt0 + i) * 16 + 4 * g;
+          if (i + 1 < nd) { if (c < hd) *reinterpret_cast<uint4*>(row + c) = pk; }
+          else if (i < nd && d < hd) *reinterpret_cast<bf16x4*>(row + d) = ov[i];
+        }
+        if constexpr (ND0 & 1) {
+          const int d = (dt0 + ND0 - 1) * 16 + 4 * g;
+          if (ND0 - 1 < nd && d < hd) *reinterpret_cast<bf16x4*>(row + d) = ov[ND0 - 1];
         }
       }
       if (bias_part) {
@@ -921,17 +929,11 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
   for (int ki = 0; ki < KT; ++ki) {
     const int key = k0 + 16 * ki + (lane & 15);
     __bf16* row = dqkv + ((size_t)b * T + key) * ld + h * hd;
+    bf16x4 ka[NDT], va[NDT];
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) {
-      const int d = dt * 16 + 4 * g;
-      if (d < hd) {
-        const f32x4 a = dk[ki][dt], v = dv[ki][dt];
-        bf16x4 ka = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3])};
-        bf16x4 va = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        *reinterpret_cast<bf16x4*>(row + D + d) = ka;
-        *reinterpret_cast<bf16x4*>(row + 2 * D + d) = va;
-      }
-    }
+    for (int dt = 0; dt < NDT; ++dt) { ka[dt] = to_bf16x4(dk[ki][dt]); va[dt] = to_bf16x4(dv[ki][dt]); }
+    store_tiles<NDT>(row + D, ka, hd, g);
+    store_tiles<NDT>(row + 2 * D, va, hd, g);
   }
   if (bias_part) {
     // K / V parts: this wave's 16 KT keys summed per column, then the eight waves meet in LDS.  The Q / dO ring is free: its last

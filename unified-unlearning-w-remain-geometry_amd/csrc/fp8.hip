@@ -309,6 +309,8 @@ __global__ __launch_bounds__(512 + 64 * NL) void k_gemm8(Gemm8Args g) {
     // (in two halves: 2 x NT8 float4 on top of the accumulators do not fit the 168 registers of the loader form)
     constexpr int NH = (NT8 + 1) / 2;
     float4 gtv[EPI == E8_GATE_RES ? NH : 1], xrv[EPI == E8_GATE_RES ? NH : 1];
+    bf16x4 ob[NT8], ab[NT8];
+    unsigned c8[NT8];
 #pragma unroll
     for (int nt = 0; nt < NT8; ++nt) {
       if constexpr (EPI == E8_GATE_RES) {
@@ -328,20 +330,46 @@ __global__ __launch_bounds__(512 + 64 * NL) void k_gemm8(Gemm8Args g) {
       f32x4 v = acc[mt][nt] * deq;
       const float4 bv = bias_v[BIAS_BY_HALF ? nt % NH : nt];
       v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+      // bf16 / e4m3 results are kept per tile and leave in PAIRS of tiles after the loop (common.h pair_pack: 16-byte bf16 pieces, 8-byte
+      // e4m3 pieces; the store tail is issue-bound)
       if constexpr (EPI == E8_BF16) {
-        *reinterpret_cast<bf16x4*>(g.Cb + (size_t)row * g.ldcb + col) = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        ob[nt] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
       } else if constexpr (EPI == E8_GELU) {
-        *reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col) = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        ab[nt] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
         const float h0 = gelu_tanh(v[0]), h1 = gelu_tanh(v[1]), h2 = gelu_tanh(v[2]), h3 = gelu_tanh(v[3]);
-        *reinterpret_cast<bf16x4*>(g.Cb + (size_t)row * g.ldcb + col) = bf16x4{f2bf(h0), f2bf(h1), f2bf(h2), f2bf(h3)};
-        *reinterpret_cast<uint32_t*>(g.C8 + (size_t)row * g.N + col) = pack_e4m3(h0 * g.c8_scale, h1 * g.c8_scale, h2 * g.c8_scale, h3 * g.c8_scale);
+        ob[nt] = bf16x4{f2bf(h0), f2bf(h1), f2bf(h2), f2bf(h3)};
+        c8[nt] = pack_e4m3(h0 * g.c8_scale, h1 * g.c8_scale, h2 * g.c8_scale, h3 * g.c8_scale);
       } else {
-        *reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col) = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        ab[nt] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
         const float4 gt = gtv[nt % NH];
         float4 x = xrv[nt % NH];
         x.x += gt.x * v[0]; x.y += gt.y * v[1]; x.z += gt.z * v[2]; x.w += gt.w * v[3];
         *reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col) = x;
       }
+    }
+    const int colp = n0 + pair_col(fg);
+    auto put = [&](__bf16* base, int ld, const bf16x4 (&t)[NT8]) {
+      __bf16* const r = base + (size_t)row * ld;
+      if ((ld & 7) == 0) {
+#pragma unroll
+        for (int np = 0; np < NT8 / 2; ++np) *reinterpret_cast<uint4*>(r + colp + np * 32) = pair_pack(t[2 * np], t[2 * np + 1]);
+        if constexpr (NT8 & 1) *reinterpret_cast<bf16x4*>(r + n0 + (NT8 - 1) * 16 + 4 * fg) = t[NT8 - 1];
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < NT8; ++nt) *reinterpret_cast<bf16x4*>(r + n0 + nt * 16 + 4 * fg) = t[nt];
+      }
+    };
+    if constexpr (EPI == E8_BF16 || EPI == E8_GELU) put(g.Cb, g.ldcb, ob);
+    if constexpr (EPI == E8_GELU || EPI == E8_GATE_RES) put(g.aux, g.ldaux, ab);
+    if constexpr (EPI == E8_GELU) {
+      uint8_t* const r8 = g.C8 + (size_t)row * g.N;
+#pragma unroll
+      for (int np = 0; np < NT8 / 2; ++np) {
+        unsigned x = c8[2 * np], y = c8[2 * np + 1];
+        permlane16_swap(x, y);                       // this lane: 8 contiguous e4m3 columns of the pair (the same piece map as the bf16 form)
+        *reinterpret_cast<uint2*>(r8 + colp + np * 32) = make_uint2(x, y);
+      }
+      if constexpr (NT8 & 1) *reinterpret_cast<uint32_t*>(r8 + n0 + (NT8 - 1) * 16 + 4 * fg) = c8[NT8 - 1];
     }
   }
 }
