@@ -1146,6 +1146,11 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
   }
   if constexpr (SCHED == 0) mfmas(f1);
 
+#ifdef SFRON_DEBUG_KNOBS
+  // timing experiment (results are not written): SFRON_GEMM_SAME_TILE bit 2 ends the kernel in front of its epilogue -- what a perfectly
+  // overlapped epilogue would leave (one accumulator element is stored so that the main loop stays live)
+  if (g.dbg_same & 4) { if (acc[0][0][0] == 12345.678f && g.Cf) g.Cf[0] = 1.0f; return; }
+#endif
   const int row_b = m0 + wm * MT * 16 + (lane & 15), col_b = n0 + wn * NT * 16 + 4 * (lane >> 4);
   // loader form, forward layouts: the bias columns of this lane, all NT loads issued together now that the fragment registers are free
   // (a load inside each store's `if (bias)` would be waited for one by one: NT x MT exposed L2 latencies per tile)
@@ -1243,14 +1248,22 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
       }
     }
   } else if constexpr (EPI == EPI_GATE_RES) {
+    // all rows of a tile belong to one sample when the token count is a multiple of the tile's rows (DiT: 256 tokens, 256-row tiles): the
+    // gate row is then fetched once per n-tile, not once per 16-row block (MT x fewer 16-byte loads in an issue-bound tail)
+    const bool one_sample = (g.T % FBM) == 0;
+    float4 gt[NT];
+    if (one_sample) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) gt[nt] = *reinterpret_cast<const float4*>(g.gate + (size_t)(row_b / g.T) * g.ldgate + col_b + nt * 16);
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int row = row_b + mt * 16;
-      float4 xr[NT], gt[NT];
+      float4 xr[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         xr[nt] = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldcf + col_b + nt * 16);
-        gt[nt] = *reinterpret_cast<const float4*>(g.gate + (size_t)(row / g.T) * g.ldgate + col_b + nt * 16);
+        if (!one_sample) gt[nt] = *reinterpret_cast<const float4*>(g.gate + (size_t)(row / g.T) * g.ldgate + col_b + nt * 16);
       }
       const bool wide = (g.ldaux & 7) == 0 && !(g.nt_out & 1);
       bf16x4 ab[NT];
