@@ -53,7 +53,8 @@ def parse():
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE config 5: the four block GEMMs of every FORWARD pass on the fp8 (e4m3) matrix core, e4m3 weight shadow "
                          "re-quantised after each optimizer step; backward GEMMs stay bf16")
-    ap.add_argument("--grad-transport", default="fp32", choices=("fp32", "bf16"), help="N > 1: precision of the gradient exchange")
+    ap.add_argument("--grad-transport", default="auto", choices=("auto", "fp32", "bf16"),
+                    help="N > 1: precision of the gradient exchange; auto = bf16 from four ranks on, the exact fp32 sum below that")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the bounded runs of BASELINE configs 1, 2, 4, 5 behind the headline region (roofline.others.configs)")
     ap.add_argument("--check", action="store_true",
@@ -368,7 +369,7 @@ def main():
     loss_ok = bool(torch.isfinite(out["remain_mse"]).all().item() and torch.isfinite(out["forget_mse"]).all().item())
     n_probe, probe_ms = eng.probe_read()
     n_wp, wp_ms = eng.wgrad_probe_read()
-    sched_across = bool(runner.sweep_across_steps and runner.sweep_beside_forward and world == 1)      # as the timed region ran
+    sched_across = bool(runner.sweep_across_steps and runner.sweep_beside_forward)      # as the timed region ran (data-parallel ranks too)
     sweep_where = "inside the timed region"
     if not any(whole for _, _, whole in runner.opt.timed) and world == 1:
         # the remain-stage sweep of the blocks ran split across the step boundary (config.schedule): for the `others.hbm` roofline time
@@ -403,7 +404,7 @@ def main():
     # parameter sweep, remain stage: 38 B/param (g, p, m, v, EMA in; p, m, v, EMA, bf16 out) over the arena, minus the 4 B/param
     # gradient read of the adaLN matrix, whose gradient the sweep forms from its two factors (k_adam_lowrank)
     nt = eng.n_trainable
-    n_ada = (6 * L + 2) * D * D if runner.factored_ada and world == 1 else 0
+    n_ada = (6 * L + 2) * D * D if runner.factored_ada else 0
     sweep_bytes = 38.0 * nt - 4.0 * n_ada
     sw_ms = sum(sweep_ms) / max(1, len(sweep_ms))
     sw_ach = sweep_bytes / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else None    # None: no whole-arena launch to time (config 5 sweeps tensor by tensor)
@@ -475,7 +476,7 @@ def main():
             "finite_losses": loss_ok,
             "step_tflops_per_gpu": step_flops / (ms_per_step * 1e-3) / 1e12,
             "step_frac_of_bf16_mfma_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-            "dp_overlap": dp_overlap, "check": check_res,
+            "dp_overlap": dp_overlap, "grad_transport": runner.grad_transport if world > 1 else None, "check": check_res,
             "roofline": {"bound": "mfma",
                          "kernel": "k_gemm_pipe<4,2,3,6,true,true,1,2,2,false,4> = 192x192 tile, three LDS slots, eight multiplying waves + four loader waves "
                                    "that issue the LDS-DMA: the weight "

@@ -218,3 +218,75 @@ def test_guard_rejects_non_int64_labels_and_length_mismatch():
         g.check_inputs(y, t.to(torch.int32), 10, 1000)
     with pytest.raises(SfronError):
         g.check_inputs(y, t[:3], 10, 1000)
+
+
+def test_data_parallel_rank_runs_the_single_process_kernel_sequence():
+    """an N > 1 rank must not be slower than the N = 1 rank before a byte crosses the links.  With gradients exchanged
+    (force_dp at world size 1 over RCCL: every collective is an identity) the step keeps the single-process shortcuts -- the adaLN
+    gradient as its two all-GATHERED factors swept as a rank-(world x batch) product, the block sweeps beside the next forward pass,
+    the remain-stage sweep across the step boundary -- so the state after three steps equals the plain single-process run BIT FOR BIT
+    (the same kernels on the same operands), for the overlapped exchange and for the synchronous one."""
+    from sfron import data, diffusion, step
+    from test_gpu_dit import CASES, build_pair
+    cfg = CASES["hd72"]
+    B = 4
+    kw = dict(global_batch=B, num_classes=cfg["num_classes"], forget_class=3, input_size=cfg["input_size"], device=DEV)
+    bat = lambda it: (data.synthetic_batch(12, it, "forget", **kw), data.synthetic_batch(12, it, "remain", **kw))
+    hp = dict(lr=2e-4, forget_alpha=0.3, grad_clip=1.0, ema_decay=0.99, mask=None, unlearn_loss="ga", forget_class=3)
+
+    def run(force, overlap):
+        _, model = build_pair(cfg, B, seed=33)
+        runner = step.DiTSFRon(model, diffusion.create_diffusion(""), overlap_allreduce=overlap, grad_transport="auto", **hp)
+        assert runner.grad_transport == "fp32"             # the rule: bf16 from four ranks on
+        assert runner.factored_ada and runner.sweep_beside_forward
+        runner.sweep_across_steps = True
+        runner.force_dp = force
+        for it in range(3):
+            runner.step(*bat(it))
+        if force:
+            assert runner._ada_all is not None             # the factors were gathered, not reduced
+        runner.sync_sweep()
+        torch.cuda.synchronize()
+        runner.guard.poll(block=True)
+        eng = model.engine
+        return eng.params.clone(), runner.opt.m.clone(), runner.opt.v.clone(), runner.ema.clone(), eng.params_bf16.clone()
+
+    ref = run(False, False)
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = str(_free_port())
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        created = True
+    try:
+        for overlap in (True, False):
+            got = run(True, overlap)
+            for a, b in zip(ref, got):
+                assert torch.equal(a, b), f"overlap={overlap}"
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_sibling_engine_orders_itself_behind_a_sweep_in_flight():
+    """ADVICE r3 (engine.py): the pending-sweep stream belongs to the shared parameter arenas.  A sibling() engine over the same
+    parameters (micro-batch chain, joint method) sees it and its forward pass drains it first -- the output equals the one computed
+    after an explicit synchronisation, bit for bit."""
+    from sfron import data, diffusion, step
+    from test_gpu_dit import CASES, build_pair
+    cfg = CASES["hd72"]
+    B = 4
+    kw = dict(global_batch=B, num_classes=cfg["num_classes"], forget_class=3, input_size=cfg["input_size"], device=DEV)
+    _, model = build_pair(cfg, B, seed=41)
+    runner = step.DiTSFRon(model, diffusion.create_diffusion(""), lr=2e-4, forget_alpha=0.3, grad_clip=1.0, ema_decay=0.99, mask=None)
+    runner.sweep_across_steps = True
+    runner.step(data.synthetic_batch(14, 0, "forget", **kw), data.synthetic_batch(14, 0, "remain", **kw))
+    eng = model.engine
+    sib = eng.sibling(B)
+    assert eng._sweep_pending is not None and sib._sweep_pending is eng._sweep_pending
+    b = data.synthetic_batch(14, 1, "remain", **kw)
+    out = sib.forward(b["x0"], b["t"], b["y"], b["drop"]).clone()          # drains the sweep first
+    assert eng._sweep_pending is None and sib._sweep_pending is None
+    torch.cuda.synchronize()
+    assert torch.equal(out, sib.forward(b["x0"], b["t"], b["y"], b["drop"]))
+    sib.close()

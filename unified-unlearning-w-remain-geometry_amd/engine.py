@@ -44,9 +44,14 @@ class DitEngine:
         if share is None:
             self.params = torch.zeros(self.n_total, dtype=torch.float32, device=self.device)
             self.params_bf16 = torch.zeros(self.n_total, dtype=torch.bfloat16, device=self.device)
+            # state that belongs to the PARAMETER ARENAS, not to one engine over them: the stream of an optimizer sweep that a runner
+            # left in flight (step.DiTSFRon.sweep_across_steps).  Every engine over the same arenas -- a sibling() of a micro-batch chain
+            # or of the joint method, the replacement set_batch_size() builds -- orders itself behind it (drain_sweep)
+            self._shared = {"sweep": None}
         else:
             assert share.n_total == self.n_total
             self.params, self.params_bf16 = share.params, share.params_bf16
+            self._shared = share._shared
         self.grads = grads if grads is not None else torch.zeros(self.n_total, dtype=torch.float32, device=self.device)
         assert self.grads.numel() == self.n_total
         ws = L.sfron_dit_workspace_bytes(ctypes.byref(c))
@@ -213,13 +218,21 @@ class DitEngine:
                             stream=st, events=evs, handles=(ctypes.c_void_p * L)(*[e.cuda_event for e in evs]))
         return self._bs
 
+    @property
+    def _sweep_pending(self):
+        return self._shared["sweep"]
+
+    @_sweep_pending.setter
+    def _sweep_pending(self, stream):
+        self._shared["sweep"] = stream
+
     def drain_sweep(self):
         """The runner leaves the remain-stage AdamW of the block ranges in flight on the sweep stream when step() returns (the next
         step's forward pass waits block by block); every OTHER reader of the parameters / optimizer state goes through here first."""
-        st = getattr(self, "_sweep_pending", None)
+        st = self._shared["sweep"]
         if st is not None:
             torch.cuda.current_stream().wait_stream(st)
-            self._sweep_pending = None
+            self._shared["sweep"] = None
 
     def forward(self, x_t, t, y, drop=None, out=None, block_ready=None):
         """block_ready: ctypes array of depth hipEvent_t handles -- block l waits for entry l before it touches its weights."""

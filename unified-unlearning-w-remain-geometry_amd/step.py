@@ -87,9 +87,11 @@ class DiTSFRon:
         # of that very run, that it reproduces the synchronous bucketed exchange.
         self.overlap = bool(overlap_allreduce)
         # grad_transport "bf16": gradient ranges cross the xGMI links as bf16 (half the bytes; dp.allreduce_); "fp32" = exact sum
-        if grad_transport not in ("fp32", "bf16"):
-            raise ValueError("grad_transport must be 'fp32' or 'bf16'")
-        self.grad_transport = grad_transport
+        # "auto": by rule -- bf16 from four ranks on (xGMI is point-to-point: a ring all-reduce is per-link bound and the payload grows
+        # as 2 (N - 1) / N of the arena; at N >= 4 that is >= 1.5 x 2 x 1.8 GB per step in fp32), the exact fp32 sum below that
+        if grad_transport not in ("fp32", "bf16", "auto"):
+            raise ValueError("grad_transport must be 'fp32', 'bf16' or 'auto'")
+        self.grad_transport = ("bf16" if dp.world_size(process_group) >= 4 else "fp32") if grad_transport == "auto" else grad_transport
         self._tx_scratch = None
         self._chains = None
         self._comm = None
@@ -188,17 +190,20 @@ class DiTSFRon:
             self._pass(batch, y, -self.forget_alpha)
             diff = (eng.grads[:nt] - g_sync).norm() / (g_sync.norm() + 1e-30)
             ok = (torch.isfinite(diff) & (diff < rtol)).to(torch.float32)
-        except Exception as e:      # a host-side failure on THIS rank (allocation, library error): vote "no" instead of leaving
-            import sys              # the other ranks alone in the MIN all-reduce below
-            print(f"[sfron] verify_overlap failed on this rank ({type(e).__name__}: {e}); voting for the synchronous path",
-                  file=sys.stderr, flush=True)
-            ok = torch.zeros((), dtype=torch.float32, device=eng.device)
+        except Exception as e:
+            # The two passes issue collectives themselves (bucketed all-reduces, the per-block exchange): a rank that fails part-way
+            # cannot rejoin its peers at the vote below -- its MIN all-reduce would pair with a gradient bucket on the other ranks.  So
+            # a failure here ends THIS rank non-zero (the launcher tears the job down; the peers' watchdog, dp.Watchdog, ends them
+            # with exit 124 if they sit in a collective).  Only the message is added here.
+            import sys
+            print(f"[sfron] verify_overlap failed on this rank ({type(e).__name__}: {e}); leaving the job", file=sys.stderr, flush=True)
+            raise
         finally:
             self.overlap = keep
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.pg)
         return bool(ok.item())
 
-    def _backward_allreduce_overlapped(self, d_out, y, drop):
+    def _backward_allreduce_overlapped(self, d_out, y, drop, factored_ada=False):
         """Backward + gradient exchange.  The library records one event per block on its weight-gradient stream when that
         block's arena range is final (all but proj.bias / fc2.bias, which it parks in ``late_bias``); a communication stream
         waits for each event and SUM-all-reduces the block's range (64 MB for DiT-XL/2) while the backward pass of the earlier
@@ -230,8 +235,13 @@ class DiTSFRon:
         _, dmod_all, sc_all = self._ada_all
         dist.all_gather_into_tensor(dmod_all, eng.ada_dmod, group=self.pg)
         dist.all_gather_into_tensor(sc_all, eng.ada_sc, group=self.pg)
-        ada_w = eng.grads[lay["ada_w"]:lay["ada_w"] + NM * D].view(NM, D)
-        ops.gemm(dmod_all, sc_all, NM, D, self.world * B, a_t=True, b_t=True, epilogue=_lib.EPI_F32, c_f32=ada_w)
+        if factored_ada:
+            # ... and not even the product is formed: the optimizer sweep takes the gathered factors as a rank-(world x batch) gradient
+            # (csrc/sweep.hip k_adam_lowrank / the EPI_SUMSQ norm pre-pass), exactly as the single-process step does with its own batch
+            self.opt.lowrank = dict(lo=lay["ada_w"], NM=NM, D=D, dmod=dmod_all, sc=sc_all, R=self.world * B)
+        else:
+            ada_w = eng.grads[lay["ada_w"]:lay["ada_w"] + NM * D].view(NM, D)
+            ops.gemm(dmod_all, sc_all, NM, D, self.world * B, a_t=True, b_t=True, epilogue=_lib.EPI_F32, c_f32=ada_w)
         # everything else outside the blocks (embedders, label table, adaLN bias, final layer) and the late biases
         self._ar(eng.grads[:lay["ada_w"]])
         self._ar(eng.grads[lay["ada_b"]:b_lo])
@@ -311,9 +321,25 @@ class DiTSFRon:
         out = eng.forward(x_t, batch["t"], y, batch.get("drop"), block_ready=block_ready)
         mse, vb, d_out = diff.loss_fwd_bwd(out, batch["x0"], batch["t"], batch["noise"], sign_alpha / n_global)
         if self._overlap_enabled():
-            self._backward_allreduce_overlapped(d_out, y, batch.get("drop"))
+            self._backward_allreduce_overlapped(d_out, y, batch.get("drop"), factored_ada=factored_ada and self.factored_ada)
         elif factored_ada and not self._dp_active() and self.factored_ada:
             self.opt.lowrank = eng.backward_factored_ada(d_out, y, batch.get("drop"))
+        elif factored_ada and self.factored_ada and not async_exchange:
+            # data parallel, synchronous exchange: the factors are all-gathered (12.5 MB + 72 KB per rank at DiT-XL/2 instead of 892 MB
+            # all-reduced), every other range of the arena is all-reduced in buckets
+            lr = eng.backward_factored_ada(d_out, y, batch.get("drop"))
+            B, NM, D = lr["R"], lr["NM"], lr["D"]
+            key = (self.world, B, NM, D)
+            if self._ada_all is None or self._ada_all[0] != key:
+                self._ada_all = (key, torch.empty(self.world * B, NM, dtype=torch.bfloat16, device=eng.device),
+                                 torch.empty(self.world * B, D, dtype=torch.bfloat16, device=eng.device))
+            _, dmod_all, sc_all = self._ada_all
+            dist.all_gather_into_tensor(dmod_all, lr["dmod"], group=self.pg)
+            dist.all_gather_into_tensor(sc_all, lr["sc"], group=self.pg)
+            self.opt.lowrank = dict(lo=lr["lo"], NM=NM, D=D, dmod=dmod_all, sc=sc_all, R=self.world * B)
+            nt, lo, hi = eng.n_trainable, lr["lo"], lr["lo"] + NM * D
+            dp.allreduce_ranges_(eng.grads, [(0, lo), (hi, nt)], self.bucket_elems, self.pg, transport=self.grad_transport if self.world > 1 else "fp32",
+                                 scratch=self._scratch(self.bucket_elems))
         else:
             eng.backward(d_out, y, batch.get("drop"))
             if async_exchange and self._dp_active():
@@ -386,7 +412,9 @@ class DiTSFRon:
             y_f, sign = torch.full_like(forget["y"], (self.forget_class + 100) % 1000), 1.0  # forget.py:274-282
         if self.method == "joint":
             return self._step_joint(forget, remain, y_f, sign)
-        dp_sync = self._dp_active() and not self._overlap_enabled() and self.micro == 1
+        # synchronous data-parallel exchange: pipelined bucket by bucket into the sweep (FlatAdam.step(pipeline=...)) when the adaLN
+        # gradient is exchanged as part of the arena; with the factored form (the default) the pass exchanges everything itself
+        dp_sync = self._dp_active() and not self._overlap_enabled() and self.micro == 1 and not self.factored_ada
         ready = None
         if self._ready_owner is not None:
             # the events of a sweep left in flight belong to the engine that armed it.  A batch-size change (set_batch_size above, or
@@ -404,12 +432,14 @@ class DiTSFRon:
         # stream.  Measured (tools/bench_sweep_beside.py): a full-grid sweep beside the GEMM chain gains nothing, one capped at
         # 256 workgroups hides ~0.8 ms of its 2.6 ms.  Single-chain, single-process, bf16 passes only.
         split = None
-        fused_q = self.fp8 and self.micro == 1 and not self._dp_active()      # config 5: the sweeps write the e4m3 shadow themselves
+        fused_q = self.fp8 and self.micro == 1                                # config 5: the sweeps write the e4m3 shadow themselves
         quant = None
         if fused_q:
             f8 = self.model.engine.fp8
             quant = dict(tensors=f8["tensors"], w8=f8["w8"], scales=f8["scales"])
-        if self.micro == 1 and not self._dp_active() and (self.sweep_beside_forward or fused_q):
+        # (data-parallel runs too: the gradients a sweep reads are final -- the pass has waited for its exchange -- so an N-rank step is
+        # the single-process kernel sequence plus the collectives)
+        if self.micro == 1 and dp_sync is False and (self.sweep_beside_forward or fused_q):
             bs = self.model.engine.block_sweep_setup()
             split = dict(ranges=bs["ranges"], stream=bs["stream"] if self.sweep_beside_forward else None, events=bs["events"],
                          max_workgroups=self.sweep_beside_wg, head=self.sweep_beside_head, quant=quant)
