@@ -50,6 +50,7 @@ struct GemmArgs {
   float* bsum;              // weight-gradient layout: bsum[m] = sum_k op(A)[m][k] (bias gradient), or null
 #ifdef SFRON_DEBUG_KNOBS
   int dbg_same;             // timing experiments only (see k_gemm_pipe)
+  long long* dbg_clk;       // in-kernel clock stamps: [layout class 3][1024 workgroups][2] = (delta s_memtime, delta s_memrealtime) of the K-loop
 #endif
   const uint8_t* sq_mask;   // EPI_SUMSQ: byte mask [M][N] (ld = N) or null; sq_out[workgroup] = sum over the tile of (mask ? c : 0)^2
   double* sq_out;
@@ -1104,6 +1105,11 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
       bsum_step(f0, bs_c);                                     // f0 is refilled only after the next barrier
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+#ifdef SFRON_DEBUG_KNOBS
+    // diagnostic build only (MI355X guide, DVFS item 6): the clock this workgroup's K-loop ran at = delta s_memtime / delta s_memrealtime x 100 MHz
+    long long clk_t0 = 0, clk_r0 = 0;
+    if (g.dbg_clk) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
     // nk is even and >= 2 here (the launcher routes other k ranges to the plain schedule): no conditional tail, whose
     // control-flow merge made hipcc spill fragment registers that an asynchronous ds_read had not filled yet
     body(I0{}, std::true_type{}, 0);
@@ -1128,6 +1134,13 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
     bsum_step(f1, bs_c);
     // the asm MFMAs are invisible to hipcc's hazard recogniser: let the last results land before the epilogue reads them
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#ifdef SFRON_DEBUG_KNOBS
+    if (g.dbg_clk && tid == 0 && blockIdx.y == 0) {            // (memory nothing else reads: the stamps never reach an output)
+      const long long dt = __builtin_amdgcn_s_memtime() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
+      long long* const o = g.dbg_clk + ((A_TR ? 2 : B_TR ? 1 : 0) * 1024 + (blockIdx.x & 1023)) * 2;
+      o[0] = dt; o[1] = dr;
+    }
+#endif
   } else
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
@@ -1392,6 +1405,33 @@ template __global__ void k_gemm_pipe<4, 2, 3, 6, true, true, 0, 2, 2, false, 4>(
 template __global__ void k_gemm_pipe<4, 2, 3, 6, false, false, 0, 2, 2, false, 4>(GemmArgs);   // (experiment: forward layout on the 4 x 2 tile)
 template __global__ void k_gemm_pipe<4, 2, 3, 6, true, true, 1, 2, 2, false, 4>(GemmArgs);
 
+#ifdef SFRON_DEBUG_KNOBS
+// diagnostic build: SFRON_GEMM_CLK=1 makes every interleaved-schedule GEMM leave the clock stamps of its K-loop (last launch of each layout
+// class wins a slot); sfron_dbg_gemm_clock() returns the median clock in MHz per class {forward, dgrad, weight gradient}
+static long long* dbg_clk_buffer() {
+  static long long* buf = [] {
+    long long* p = nullptr;
+    if (getenv("SFRON_GEMM_CLK") && hipMalloc(&p, 3 * 1024 * 2 * sizeof(long long)) == hipSuccess) (void)hipMemset(p, 0, 3 * 1024 * 2 * sizeof(long long));
+    return p;
+  }();
+  return buf;
+}
+extern "C" int sfron_dbg_gemm_clock(double* mhz3, int* n3) {
+  long long* d = dbg_clk_buffer();
+  if (!d || !mhz3 || !n3) return SFRON_ERR_ARG;
+  static long long host[3 * 1024 * 2];
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host, d, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return (int)hipGetLastError();
+  for (int c = 0; c < 3; ++c) {
+    double v[1024]; int n = 0;
+    for (int i = 0; i < 1024; ++i) { const long long dt = host[(c * 1024 + i) * 2], dr = host[(c * 1024 + i) * 2 + 1]; if (dr > 0) v[n++] = 100.0 * (double)dt / (double)dr; }
+    for (int i = 1; i < n; ++i) { double x = v[i]; int j = i - 1; while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; --j; } v[j + 1] = x; }
+    mhz3[c] = n ? v[n / 2] : 0.0; n3[c] = n;
+  }
+  (void)hipMemset(d, 0, sizeof(host));
+  return SFRON_OK;
+}
+#endif
+
 namespace {
 
 template <int WM, int WN, int MT, int NT, bool A_TR, bool B_TR, int EPI, int SCHED = 0, int PRO = 2, bool BSUM = false, int NL = 0>
@@ -1400,6 +1440,7 @@ int launch_pipe(GemmArgs g, hipStream_t s) {
   g.ntm = g.M / FBM; g.ntn = g.N / FBN;
 #ifdef SFRON_DEBUG_KNOBS
   { static const int same = getenv("SFRON_GEMM_SAME_TILE") ? atoi(getenv("SFRON_GEMM_SAME_TILE")) : 0; g.dbg_same = same; }
+  g.dbg_clk = dbg_clk_buffer();
 #endif
   {
     const double per_xcd = (double)g.ntm * g.ntn / 8.0;
