@@ -320,6 +320,9 @@ def main():
     if os.environ.get("SFRON_BENCH_LOADER_WAVES"):          # A-B knob (tools only): form of the three-slot GEMM tiles, 0 or 4
         from sfron import _lib
         _lib.lib().sfron_gemm_loader_waves(int(os.environ["SFRON_BENCH_LOADER_WAVES"]))
+    if os.environ.get("SFRON_BENCH_ATTN_FWD"):              # A-B knob (tools only): 4 = the four-wave attention forward kernel
+        from sfron import _lib
+        _lib.lib().sfron_attn_fwd_form(int(os.environ["SFRON_BENCH_ATTN_FWD"]))
     if os.environ.get("SFRON_BENCH_SWEEP_BESIDE"):          # tuning knob (tools only): "workgroups,head"
         runner.sweep_beside_wg, runner.sweep_beside_head = (int(v) for v in os.environ["SFRON_BENCH_SWEEP_BESIDE"].split(","))
 

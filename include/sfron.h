@@ -477,7 +477,7 @@ int sfron_unpatchify(const float* rows, int ld, int n, int C, int H, int W, int 
 /* ------------------------------------------------------------------ attention (attn.hip)
  * qkv [B*T][3*H*hd] bf16 (column = which*D + head*hd + d), o / d_o [B*T][H*hd] bf16, lse [B][H][T] fp32.
  * softmax(q k^T * hd^-0.5) v, non-causal (timm Attention as used at DiT/models.py:108,120).
- * Supported: T % 64 == 0 with head_dim a multiple of 8 up to 96 (DiT 64 / 72; the LDM UNet's 40 / 80) on the tiled kernels; T < 64
+ * Supported: T % 64 == 0 with head_dim a multiple of 8 up to 80 (DiT 64 / 72; the LDM UNet's 40 / 80) on the tiled kernels; T < 64
  * (any T, head_dim <= 128: the patch-8 DiT models at 256 px have 16 tokens) on plain-FMA kernels, one workgroup per (batch, head). */
 int sfron_attn_fwd(const uint16_t* qkv, uint16_t* o, float* lse, int B, int T, int H, int hd, void* stream);
 /* dqkv [B*T][3*H*hd] bf16 = gradient wrt qkv; delta_scratch fp32 [B*H*T] (used by the two-kernel form only).
@@ -496,6 +496,9 @@ int sfron_attn_bwd_bias(const uint16_t* qkv, const uint16_t* o, const uint16_t* 
 
 /* test hook: 2 = always the two-kernel backward, 0 = default; returns the previous setting (process-wide, not thread-safe) */
 int sfron_attn_bwd_form(int form);
+/* test / A-B hook: 0 (default) = by rule (the forward kernel with eight waves of 16 query rows per workgroup for sequences of 512 tokens or
+ * more, four waves of 32 rows below), 4 / 8 = force one form (bit-identical results); returns the previous setting */
+int sfron_attn_fwd_form(int form);
 /* Process-wide form of the three-slot GEMM tiles (256 x 144 forward / dgrad, 192 x 192 weight gradient): 4 = four extra LOADER waves per
  * workgroup issue every LDS-DMA piece and the eight multiplying waves none (csrc/gemm.hip k_gemm_pipe NL; taken by the dgrad and
  * weight-gradient layouts, where it measured faster) -- the default; 0 = every wave issues its share (5 / 6: weight gradients / dgrad

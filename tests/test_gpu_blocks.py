@@ -133,6 +133,28 @@ def test_conditioning_and_layout():
     close(ops.unpatchify(r2.float(), 2, 8, 8, 8, 2), im8.to(torch.bfloat16).float(), 0, 0)
 
 
+@pytest.mark.parametrize("B,T,H,hd", [(2, 256, 16, 72), (1, 128, 3, 72), (1, 256, 4, 64), (1, 1024, 8, 40), (2, 256, 4, 80), (1, 384, 2, 48)])
+def test_attention_forward_eight_wave_form_is_bit_identical(B, T, H, hd):
+    """k_attn_fwd8 (round 4: eight waves of 16 query rows per workgroup, sixteen waves per CU) against the four-wave kernel: the same
+    products and the same softmax arithmetic per row -> the same bits in O and LSE."""
+    from sfron import _lib, ops
+    L = _lib.lib()
+    gen = torch.Generator().manual_seed(T * H + hd)
+    D = H * hd
+    qkv = (torch.randn(B * T, 3 * D, generator=gen) * 1.5).to(torch.bfloat16).to(DEV)
+    res = []
+    for form in (4, 8):
+        old = L.sfron_attn_fwd_form(form)
+        try:
+            o, lse = ops.attn_fwd(qkv, B, T, H, hd)
+            torch.cuda.synchronize()
+            res.append((o.clone(), lse.clone()))
+        finally:
+            L.sfron_attn_fwd_form(old)
+    assert torch.isfinite(res[0][0].float()).all() and torch.isfinite(res[0][1]).all()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("B,T,H,hd", [(2, 64, 2, 64), (1, 128, 3, 72), (2, 256, 2, 72), (1, 256, 4, 64), (1, 192, 1, 64),
                                       (1, 1024, 8, 40), (2, 256, 4, 80), (1, 320, 2, 40), (1, 128, 2, 48)])
 def test_attention_fwd_bwd(B, T, H, hd):
@@ -251,3 +273,14 @@ def test_reduce_chunks_both_forms(groups, per, D):
         assert float((out[:, D:] - 2.0).abs().max()) == 0.0                      # columns beyond D untouched
         want = ref + (2.0 if acc else 0.0)
         close(out[:, :D], want, rtol=1e-5, atol=1e-5 * per ** 0.5)
+
+
+def test_attention_rejects_head_widths_without_a_kernel():
+    """Head widths 88 / 96 at T >= 64 would need a sixth output d-tile: rounds 1-3 accepted them and left columns 80.. unwritten (found in
+    round 4 by the bit-identity test above).  They are refused now; the LDM UNet's wider heads (160) take the batched-GEMM path."""
+    from sfron import ops
+    from sfron._lib import SfronError
+    for hd in (88, 96):
+        qkv = torch.zeros(128, 3 * hd, dtype=torch.bfloat16, device=DEV)
+        with pytest.raises(SfronError):
+            ops.attn_fwd(qkv, 1, 128, 1, hd)

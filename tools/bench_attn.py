@@ -19,9 +19,12 @@ def timeit(fn, iters=20):
     for _ in range(iters): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters
+from sfron import _lib
 o, lse = ops.attn_fwd(qkv, B, T, H, hd)
 fl = 4.0 * B * H * T * T * hd
-ms = timeit(lambda: ops.attn_fwd(qkv, B, T, H, hd))
-print(f"attn fwd  B{B} T{T} H{H} hd{hd}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s")
+for form in (4, 8):
+    _lib.lib().sfron_attn_fwd_form(form)
+    ms = timeit(lambda: ops.attn_fwd(qkv, B, T, H, hd))
+    print(f"attn fwd  B{B} T{T} H{H} hd{hd}, {form}-wave workgroups: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s")
 ms = timeit(lambda: ops.attn_bwd(qkv, o, d_o, lse, B, T, H, hd))
 print(f"attn bwd  (delta+dq+dkv)      : {ms*1e3:8.1f} us  {2.5*fl/ms/1e9:7.1f} TFLOP/s (2.5x fwd flops)")

@@ -95,6 +95,7 @@ _PROTOS.update({
     "sfron_attn_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _S]),
     "sfron_attn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _S]),
     "sfron_attn_bwd_form": (c_int, [c_int]),
+    "sfron_attn_fwd_form": (c_int, [c_int]),
     "sfron_gemm_loader_waves": (c_int, [c_int]),
     "sfron_attn_bwd_bias_supported": (c_int, [c_int]),
     "sfron_attn_bwd_bias": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _S]),

@@ -31,9 +31,9 @@ inline int make_dims(const sfron_dit_cfg* c, Dims& d) {
   // token counts: multiples of 64 (tiled attention) or fewer than 64 (the registry's patch-8 models at 256 px: 16 tokens -- plain-FMA
   // attention kernels, generic GEMM tiles); T must be even for the row-kernel chunking
   if (d.Kp % 8 || d.Po % 8 || (d.T % 64 && d.T > 64) || (d.T & 1)) return SFRON_ERR_UNSUPPORTED;
-  // head widths the attention kernels take: multiples of 8 up to 96 on the tiled kernels (DiT 64 / 72), anything up to 128 on the
+  // head widths the attention kernels take: multiples of 8 up to 80 on the tiled kernels (DiT 64 / 72), anything up to 128 on the
   // short-sequence kernels
-  if (d.T >= 64 ? (d.hd % 8 || d.hd > 96) : d.hd > 128) return SFRON_ERR_UNSUPPORTED;
+  if (d.T >= 64 ? (d.hd % 8 || d.hd > 80) : d.hd > 128) return SFRON_ERR_UNSUPPORTED;
   return SFRON_OK;
 }
 

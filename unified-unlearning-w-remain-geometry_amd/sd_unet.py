@@ -243,7 +243,7 @@ class UNetModel(_TapeNet):
         qkv = torch.empty(rows, 3 * C, dtype=torch.bfloat16, device=dev)
         wqkv = self._w(t + ".attn1.to_q.weight")
         bgemm(n1, wqkv, rows, 3 * C, C, lda=C, ldb=C, c_bf16=qkv, ldc=3 * C)
-        if (C // self.heads) <= 96 and (C // self.heads) % 8 == 0 and N % 64 == 0:
+        if (C // self.heads) <= 80 and (C // self.heads) % 8 == 0 and N % 64 == 0:
             O1, att1_b = self._flash_self_attention(qkv, B, N, C)       # scores never leave the chip (4096 tokens at 64x64)
         else:
             O1, att1_b = self._mha(qkv.data_ptr(), 3 * C, qkv.data_ptr() + 2 * C, 3 * C, qkv.data_ptr() + 4 * C, 3 * C, B, N, N, N, C, keep=(qkv,))
