@@ -1264,7 +1264,7 @@ int launch_bwd_fused(const __bf16* qkv, const __bf16* o, const __bf16* d_o, cons
   const size_t lds = (size_t)(NSLOT * 2 * 64 * HDP + T * HDP + T * 64) * sizeof(__bf16) + 2 * T * sizeof(float) +
                      FNW * ((NDT + 1) / 2) * 16 * sizeof(float);
   int rc = set_lds(&k_attn_bwd_fused<HDP, KS, NDT, KT>, lds); if (rc) return rc;
-  hipLaunchKernelGGL((k_attn_bwd_fused<HDP, KS, NDT, KT>), dim3(B * H), dim3(FNT), lds, s, qkv, o, d_o, lse, dqkv, H, hd, scale, bias_part);
+  SFRON_LAUNCH_EV((k_attn_bwd_fused<HDP, KS, NDT, KT>), dim3(B * H), dim3(FNT), lds, s, qkv, o, d_o, lse, dqkv, H, hd, scale, bias_part);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
 }

@@ -122,4 +122,20 @@ __device__ __forceinline__ void pair_unpack(uint4 v, bf16x4& a, bf16x4& b) {
   a = __builtin_bit_cast(bf16x4, ua); b = __builtin_bit_cast(bf16x4, ub);
 }
 
+// ---- a completion event carried by the producing kernel's own dispatch ----------------------------------------------------------
+// hipEventRecord puts a marker packet into the stream behind the kernel it follows: ~5 us of the main stream per hand-off to the
+// weight-gradient stream, four per DiT block (csrc/dit_engine.hip produced()).  hipExtLaunchKernelGGL attaches the event to the kernel's own
+// dispatch packet instead: nothing extra in the producing stream.  The engine ARMS an event (sfron_arm_stop_event) right before it calls the
+// library entry point whose ONE kernel produces the tensor; SFRON_LAUNCH_EV in that entry point's launcher takes it.  An entry point that
+// launches through another path leaves it armed: the engine then records it the old way (sfron_take_stop_event() != null).  Per host thread.
+#include <hip/hip_ext.h>
+void sfron_arm_stop_event(hipEvent_t ev);
+hipEvent_t sfron_take_stop_event();
+#define SFRON_LAUNCH_EV(kernel, grid, block, lds, stream, ...)                                                         \
+  do {                                                                                                                 \
+    hipEvent_t ev__ = sfron_take_stop_event();                                                                         \
+    if (ev__) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, ev__, 0, __VA_ARGS__);                  \
+    else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                            \
+  } while (0)
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -531,7 +531,18 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
   // buffer i (0 d_br mlp, 1 d_hpre, 2 d_br attn, 3 dqkv) of block l lives in copy l & 1: main records produced[i] after
   // writing it, the side stream waits for it before reading; the side stream records consumed[i][l & 1], and main waits
   // for that before block l - 2 overwrites the copy -- so main stalls only when the side stream is a whole block behind.
-  auto produced = [&](int i) { if (ax) { (void)hipEventRecord(ax->produced[i], hs); (void)hipStreamWaitEvent(ax->side, ax->produced[i], 0); } };
+  // produced(i): buffer i is written -> the weight-gradient stream may read it.  arm(i) in front of the entry point whose ONE kernel writes it
+  // lets that kernel's own dispatch carry the event (common.h SFRON_LAUNCH_EV: no marker packet in this stream, ~5 us each, four per
+  // block); if that launch did not take it (another kernel path) the event is recorded the old way.
+  bool armed = false;
+  auto arm = [&](int i) { if (ax) { sfron_arm_stop_event(ax->produced[i]); armed = true; } };
+  auto produced = [&](int i) {
+    if (!ax) return;
+    const bool left = sfron_take_stop_event() != nullptr;                     // armed, but the launch did not take it
+    if (!armed || left) (void)hipEventRecord(ax->produced[i], hs);            // ... or never armed: record in the stream
+    armed = false;
+    (void)hipStreamWaitEvent(ax->side, ax->produced[i], 0);
+  };
   auto consumed = [&](int i, int l) { if (ax) (void)hipEventRecord(ax->consumed[2 * i + (l & 1)], ax->side); };
   // The weight-gradient stream is in order, so its LAST event of block l + 2 (buffer 3) covers buffers 0..2 of that block too:
   // one wait per block on the main stream (buffer 0 of block l is written at the end of block l + 1 and waits there) instead
@@ -572,6 +583,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
   // previous block's MLP gate (only block 0's attention LN stands alone).
   {
     const int l = d.L - 1;
+    if (fuse) arm(0);
     RUN(ln_gate(w.xs + (size_t)(2 * d.L) * M * D, w.mean + (size_t)(2 * d.L) * M, w.rstd + (size_t)(2 * d.L) * M, modf + D, 0,
                 slot(d.L, 3, 0), slot(d.L, 3, 1), w.a2 + (size_t)l * M * D, w.mod + (size_t)l * 6 * D + 5 * D, w.d_br[l & 1],
                 slot(l, 0, 0), slot(l, 0, 1)));
@@ -604,6 +616,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     // bf16 rounding); the side stream only adds the M / 256 partial rows (was: a second 75 MB pass over d_hpre per block)
     float* const bp_fc1 = w.bpart + (size_t)pl * fc1_rows * d.F;
     if (fc1_rows) g.col_partials = bp_fc1;
+    arm(1);
     RUN(sfron_gemm_bf16(&g, stream));
     produced(1);
     if (delay_fc2) {
@@ -620,6 +633,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     RUN(sfron_gemm_bf16(&g, stream));
     // ---- attention branch: x1 = x0 + gate_msa * proj(attn(qkv(xmod1)))
     before_overwrite(2, l);
+    if (fuse) arm(2);
     RUN(ln_gate(x1, w.mean + (size_t)(2 * l + 1) * M, w.rstd + (size_t)(2 * l + 1) * M, mod + 4 * D, 1, slot(l, 1, 0),
                 slot(l, 1, 1), a1, mod + 2 * D, w.d_br2[pl], slot(l, 2, 0), slot(l, 2, 1)));
     produced(2);
@@ -642,6 +656,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
       // qkv.bias gradient = token sums of dqkv: the attention backward kernel leaves one partial row per sample (it holds dQ / dK / dV
       // of a whole (sample, head) in registers); the side stream adds the B rows (was: a second 57 MB pass over dqkv per block)
       float* const bp = w.bpart_qkv + (size_t)pl * B * 3 * D;
+      arm(3);
       RUN(sfron_attn_bwd_bias((const uint16_t*)qkv, (const uint16_t*)o, (const uint16_t*)w.d_o, w.lse + (size_t)l * B * d.H * T,
                               (uint16_t*)w.dqkv[pl], bp, B, T, d.H, d.hd, stream));
       produced(3);
@@ -666,6 +681,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     RUN(sfron_gemm_bf16(&g, stream));
     if (l > 0) {
       before_overwrite(0, l - 1);
+      if (fuse) arm(0);                     // consumed by produced(0) at the top of block l - 1
       RUN(ln_gate(x0, w.mean + (size_t)(2 * l) * M, w.rstd + (size_t)(2 * l) * M, mod + D, 1, slot(l, 3, 0), slot(l, 3, 1),
                   w.a2 + (size_t)(l - 1) * M * D, w.mod + (size_t)(l - 1) * 6 * D + 5 * D, w.d_br[(l - 1) & 1], slot(l - 1, 0, 0),
                   slot(l - 1, 0, 1)));

@@ -1458,7 +1458,7 @@ int launch_pipe(GemmArgs g, hipStream_t s) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return (int)hipGetLastError();
   }
-  hipLaunchKernelGGL((k_gemm_pipe<WM, WN, MT, NT, A_TR, B_TR, EPI, SCHED, PRO, BSUM, NL>), dim3(g.ntm * g.ntn, cdiv(g.K, g.kchunk)), dim3((WM * WN + NL) * 64), lds, s, g);
+  SFRON_LAUNCH_EV((k_gemm_pipe<WM, WN, MT, NT, A_TR, B_TR, EPI, SCHED, PRO, BSUM, NL>), dim3(g.ntm * g.ntn, cdiv(g.K, g.kchunk)), dim3((WM * WN + NL) * 64), lds, s, g);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
 }

@@ -525,8 +525,8 @@ template <bool LN, bool GATE>
 int launch_row_bwd(RowBwdArgs a, void* stream) {
   const ChunkPlan cp = pick_chunk(a.T);
   a.rpw = cp.rpw; a.combine = cp.combine;
-  if (cp.combine) hipLaunchKernelGGL((k_row_bwd<LN, GATE, true>), dim3(cdiv(a.M / cp.rpw, 4)), dim3(TPB), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((k_row_bwd<LN, GATE, false>), dim3(cdiv(a.M / cp.rpw, 4)), dim3(TPB), 0, (hipStream_t)stream, a);
+  if (cp.combine) SFRON_LAUNCH_EV((k_row_bwd<LN, GATE, true>), dim3(cdiv(a.M / cp.rpw, 4)), dim3(TPB), 0, (hipStream_t)stream, a);
+  else SFRON_LAUNCH_EV((k_row_bwd<LN, GATE, false>), dim3(cdiv(a.M / cp.rpw, 4)), dim3(TPB), 0, (hipStream_t)stream, a);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }
