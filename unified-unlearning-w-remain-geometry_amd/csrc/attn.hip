@@ -66,15 +66,23 @@ struct ChunkDma {
   }
 };
 
-// Zero the PAD chunk positions of n_img images (source chunk index >= hd/8).  The DMA never writes them and writes
-// nothing else than the valid positions, so zeroing and DMA touch disjoint LDS bytes and need no ordering between them.
-template <int HDP> __device__ __forceinline__ void zero_pads(__bf16* p, int n_img, int hd, int tid) {
+// Zero the PAD chunk positions (source chunk index >= hd/8) of n_img images that lie IMG_STEP images apart.  The DMA never writes them and
+// writes nothing else than the valid positions, so zeroing and DMA touch disjoint LDS bytes and need no ordering between them.  One thread
+// per image row writes that row's pad chunks directly (position = chunk ^ swizzle(row)): rounds 1-3 walked every chunk position of every
+// image with a predicate -- 18 iterations of index arithmetic per thread, 2.0 of the 12.4 us a forward workgroup lives
+// (tools/attn_probe.py, profiles/r04_attn_phases.txt).
+// Which images need it: a ROW fragment of k-step hd/32 reaches into the pad columns, and 0 x garbage is NaN when the garbage is -- so every
+// image read by rows (K; Q / dO / V in the backward kernels).  An image read only by COLUMN fragments (V in the forward pass) feeds pad
+// columns into output columns >= hd, which are never stored: it needs no zeroing.
+template <int HDP, int NTHR, int IMG_STEP = 1> __device__ __forceinline__ void zero_pads(__bf16* p, int n_img, int hd, int tid) {
   constexpr int CPR = HDP / 8;
   if (hd >= HDP) return;
   const uint4 z = make_uint4(0, 0, 0, 0);
-  for (int e = tid; e < n_img * 64 * CPR; e += NT) {
-    const int row = (e / CPR) & 63, pos = e % CPR;
-    if (((pos ^ aswz<HDP>(row)) << 3) >= hd) reinterpret_cast<uint4*>(p)[e] = z;
+  const int c0 = hd >> 3;
+  for (int r = tid; r < n_img * 64; r += NTHR) {
+    const int sw = aswz<HDP>(r & 63);
+    uint4* const rowp = reinterpret_cast<uint4*>(p) + ((r >> 6) * IMG_STEP * 64 + (r & 63)) * CPR;
+    for (int c = c0; c < CPR; ++c) rowp[c ^ sw] = z;
   }
 }
 
@@ -214,6 +222,27 @@ struct Ring {
 
 }  // namespace (kernel templates have external linkage + explicit instantiations below: see gemm.hip)
 
+#ifdef SFRON_DEBUG_KNOBS
+// diagnostic build only (tools/attn_probe.py): per-workgroup phase stamps of the constant 100 MHz counter, [workgroup][8]; slot 7 = HW_ID.
+// The stamps go to a buffer of their own; no output value depends on them.
+__device__ long long* d_attn_clk = nullptr;
+#define ATTN_STAMP(i) do { if (clk__) clk__[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define ATTN_STAMP_INIT() long long* clk__ = (d_attn_clk && threadIdx.x == 0 && blockIdx.x < 4096) ? d_attn_clk + 8 * blockIdx.x : nullptr; \
+  if (clk__) clk__[7] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(63508) << 32)
+#if defined(SFRON_ATTN_PROBE) && SFRON_ATTN_PROBE == 2      // second stamp set: inside the prologue (slots 1..4), the loop's stamps off
+#define ATTN_STAMP_P(i) ATTN_STAMP(i)
+#define ATTN_STAMP_L(i) do { } while (0)
+#else
+#define ATTN_STAMP_P(i) do { } while (0)
+#define ATTN_STAMP_L(i) ATTN_STAMP(i)
+#endif
+#else
+#define ATTN_STAMP(i) do { } while (0)
+#define ATTN_STAMP_P(i) do { } while (0)
+#define ATTN_STAMP_L(i) do { } while (0)
+#define ATTN_STAMP_INIT() do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------- forward
 template <int HDP, int KS, int NDT, int QT>
 __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv, __bf16* __restrict__ o,
@@ -222,6 +251,7 @@ __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv,
   Ring<HDP> ring{smem};
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  ATTN_STAMP_INIT(); ATTN_STAMP(0);
   // 1-D grid.  Workgroup ids go round-robin over the 8 XCDs: id -> (id & 7) * (n / 8) + (id >> 3) gives each XCD one contiguous run of
   // (batch, head, query block) triples, so the query blocks of a head (same K / V) and the neighbouring heads of a sample (neighbouring
   // 144-B column slices of the same rows: shared 128-B lines) meet in ONE L2
@@ -250,10 +280,13 @@ __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv,
   for (int qi = 0; qi < QT; ++qi)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) fq[qi][ks] = frag_rows_global(base, ld, q0 + 16 * qi, ks, hd, lane);
+  ATTN_STAMP_P(1);
   issue(0);                              // first two chunks stream in while the pads are zeroed
   if (nchunk > 1) issue(1);
-  zero_pads<HDP>(smem, NSLOT * 2, hd, tid);
+  ATTN_STAMP_P(2);
+  zero_pads<HDP, NT, 2>(smem, NSLOT, hd, tid);             // the K images (even ring images); V is read by columns only
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // pad zeros written before the first barrier of the loop
+  ATTN_STAMP_P(3);
 
   f32x4 oacc[QT][NDT];
   float m[QT], l[QT];
@@ -267,6 +300,8 @@ __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv,
   for (int kc = 0; kc < nchunk; ++kc) {
     if (kc + 1 < nchunk) wait_vmcnt<Ring<HDP>::PER_CHUNK>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    if (kc == 0) ATTN_STAMP_P(4);
+    if (kc < 5) ATTN_STAMP_L(1 + kc);
     if (kc + 2 < nchunk) issue(kc + 2);
     const __bf16* iK = ring.img(kc % NSLOT, 0);
     const __bf16* iV = ring.img(kc % NSLOT, 1);
@@ -333,6 +368,7 @@ __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv,
       for (int qi = 0; qi < QT; ++qi)
         oacc[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1[dt], pf[qi][1], oacc[qi][dt], 0, 0, 0);
   }
+  ATTN_STAMP(5);
 #pragma unroll
   for (int qi = 0; qi < QT; ++qi) {
     const float lt = group_sum(l[qi]);
@@ -345,6 +381,7 @@ __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv,
     store_tiles<NDT>(orow, ov, hd, g);
     if (g == 0) lse[(size_t)bh * T + q] = m[qi] * scale + logf(lt);
   }
+  ATTN_STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------- dQ
@@ -400,7 +437,7 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dq(const __bf16* __restrict__ q
     dl[qi] = group_sum(dsum);
     if (lane < 16) delta[(size_t)bh * T + q] = dl[qi];
   }
-  zero_pads<HDP>(smem, NSLOT * 2, hd, tid);
+  zero_pads<HDP, NT>(smem, NSLOT * 2, hd, tid);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   f32x4 dq[QT][NDT];
@@ -516,7 +553,7 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dkv(const __bf16* __restrict__ 
       fv[ki][ks] = frag_rows_global(base + 2 * D, ld, k0 + 16 * ki, ks, hd, lane);
     }
   for (int i = tid; i < T; i += NT) { s_lse[i] = -lse[(size_t)bh * T + i] * LOG2E; s_del[i] = delta[(size_t)bh * T + i]; }
-  zero_pads<HDP>(smem, NSLOT * 2, hd, tid);
+  zero_pads<HDP, NT>(smem, NSLOT * 2, hd, tid);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   f32x4 dk[KT][NDT], dv[KT][NDT];
@@ -685,13 +722,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_fwd8(const __bf16* __restrict__
   for (int ks = 0; ks < KS; ++ks) fq[ks] = frag_rows_global(base, ld, q0, ks, hd, lane);
   issue(0);
   if (nchunk > 1) issue(1);
-  if (hd < HDP) {                                        // pad chunk positions of the ring (never written by the DMA)
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    for (int e = tid; e < NSLOT * 2 * 64 * CPR; e += 512) {
-      const int row = (e / CPR) & 63, pos = e % CPR;
-      if (((pos ^ aswz<HDP>(row)) << 3) >= hd) reinterpret_cast<uint4*>(smem)[e] = z;
-    }
-  }
+  zero_pads<HDP, 512, 2>(smem, NSLOT, hd, tid);          // pad chunk positions of the K images (never written by the DMA)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   f32x4 oacc[NDT];
@@ -780,6 +811,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
   float* const s_dq = s_del + T;                             // [FNW][ND0 * 16]: token sums of this wave's dQ columns (qkv.bias partials)
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  ATTN_STAMP_INIT(); ATTN_STAMP(0);
   // neighbouring heads of one sample read neighbouring 144-B column slices of the same rows: keep them on one XCD's L2
   const int nblk = gridDim.x;
   const int bh = (nblk & 7) == 0 ? (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3) : blockIdx.x;
@@ -829,6 +861,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
     if (dmaK.valid[i])
       dma16(rsK, imgK + img * IMG + jj * 512, dmaK.off[i], img * 64 * ld * 2);
   }
+  ATTN_STAMP_P(1);
   issue_chunk(0);
   if (NCH > 1) issue_chunk(1);
 
@@ -853,18 +886,11 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
     dsum += __shfl_xor(dsum, 1, 64);
     if (!(tid & 1) && d_q < T) s_del[d_q] = dsum;
   }
+  ATTN_STAMP_P(2);
   // pad columns of the ring and of the K image (never written by the DMA)
-  {
-    constexpr int NIMG = NSLOT * 2 + NCH;
-    if (hd < HDP) {
-      const uint4 z = make_uint4(0, 0, 0, 0);
-      for (int e = tid; e < NIMG * 64 * CPR; e += FNT) {
-        const int row = (e / CPR) & 63, pos = e % CPR;
-        if (((pos ^ aswz<HDP>(row)) << 3) >= hd) reinterpret_cast<uint4*>(smem)[e] = z;
-      }
-    }
-  }
+  zero_pads<HDP, FNT>(smem, NSLOT * 2 + NCH, hd, tid);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  ATTN_STAMP_P(3);
 
   f32x4 dk[KT][NDT], dv[KT][NDT];
 #pragma unroll
@@ -907,6 +933,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
     else if (qc + 1 < NCH) wait_vmcnt<PC + 1>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    if (qc == 0) { ATTN_STAMP_P(4); ATTN_STAMP_L(1); }
     if (qc + 2 < NCH) issue_chunk(qc + 2);
     const __bf16* iQ = ringb + (qc % NSLOT) * 2 * IMG;
     const __bf16* iO = iQ + IMG;
@@ -943,6 +970,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
         asm_write_b64(wr_addr[ki] + 8 * ((4 * qt + g) ^ wr_pi), sv);
       }
     }
+    if (qc == 0) ATTN_STAMP_L(2);
     {
       // dV^T += dO^T P, dK^T += Q^T dS: dO^T / Q^T column fragments of d-tile dt + 1 are read under the MFMAs of d-tile dt
       unsigned aQ[ColPerm<HDP>::NB], aO[ColPerm<HDP>::NB];
@@ -976,6 +1004,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    if (qc == 0) ATTN_STAMP_L(3);
     {
       // dQ[64 qc + 16 qi + ..][16 (dt0 + i) + ..] = sum over all T keys of dS[q][key] K[key][d]
       f32x4 dq[ND0];
@@ -1042,7 +1071,9 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
         }
       }
     }
+    if (qc == 0) ATTN_STAMP_L(4);
   }
+  ATTN_STAMP(5);
 #pragma unroll
   for (int ki = 0; ki < KT; ++ki) {
     const int key = k0 + 16 * ki + (lane & 15);
@@ -1092,6 +1123,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
       out[which * D + d] = x;
     }
   }
+  ATTN_STAMP(6);
 }
 
 template __global__ void k_attn_bwd_fused<64, 2, 4, 2>(const __bf16*, const __bf16*, const __bf16*, const float*, __bf16*, int, int, float, float*);
@@ -1309,6 +1341,20 @@ int sfron_attn_fwd(const uint16_t* qkv, uint16_t* o, float* lse, int B, int T, i
   if (hd <= 80) return launch_fwd<96, 3, 5>((const __bf16*)qkv, (__bf16*)o, lse, B, T, H, hd, scale, s);
   return SFRON_ERR_UNSUPPORTED;          // (88 / 96 would need a sixth output d-tile: rounds 1-3 accepted them and left columns 80.. unwritten)
 }
+
+#ifdef SFRON_DEBUG_KNOBS
+/* diagnostic build: arm (out == null) or read back n_wg x 8 stamps (tools/attn_probe.py) */
+int sfron_dbg_attn_clock(long long* out, int n_wg) {
+  static long long* buf = nullptr;
+  if (!buf) {
+    if (hipMalloc(&buf, 4096 * 8 * sizeof(long long)) != hipSuccess) return (int)hipGetLastError();
+    (void)hipMemset(buf, 0, 4096 * 8 * sizeof(long long));
+    if (hipMemcpyToSymbol(HIP_SYMBOL(d_attn_clk), &buf, sizeof(buf)) != hipSuccess) return (int)hipGetLastError();
+  }
+  if (out) { (void)hipDeviceSynchronize(); if (hipMemcpy(out, buf, (size_t)(n_wg > 4096 ? 4096 : n_wg) * 8 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return (int)hipGetLastError(); }
+  return SFRON_OK;
+}
+#endif
 
 /* test hook: 2 = force the two-kernel backward (dQ, then dK/dV) for every T; 0 = default (fused where T is 128 or 256) */
 int sfron_attn_bwd_form(int form) { const int old = g_bwd_form; g_bwd_form = form; return old; }
