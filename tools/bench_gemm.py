@@ -61,9 +61,28 @@ def gate_res(name, N, K):
                                                          gate=gate[:, 2 * N:], ldgate=6 * N, tokens=256, tile_hint=HINT)))
 dgelu("dgrad fc2 + GELU'  ->4608", D, F)
 gate_res("fwd proj + gate-res N1152", D, D); gate_res("fwd fc2 + gate-res K4608", D, F)
+# phases of a workgroup's life (diagnostic build + SFRON_GEMM_CLK=1: SFRON_DBG_LIB=1 SFRON_GEMM_CLK=1 python3 tools/bench_gemm.py):
+# stamps of the constant 100 MHz counter at entry / K-loop start / K-loop end / last store issued (csrc/gemm.hip sfron_dbg_gemm_phases)
+PH = bool(os.environ.get("SFRON_DBG_LIB") and os.environ.get("SFRON_GEMM_CLK"))
+def phases(name):
+    import ctypes, numpy as np
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    raw.sfron_dbg_gemm_phases.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    cls = 2 if name.startswith("wgrad") else 1 if name.startswith("dgrad") else 0
+    a = np.zeros((1024, 6), dtype=np.int64)
+    assert raw.sfron_dbg_gemm_phases(cls, a.ctypes.data) == 0
+    a = a[(a[:, 1] > 0) & (a[:, 5] > 0)]
+    if not len(a): return ""
+    t = a[:, 2:6].astype(np.float64) / 100.0
+    t0 = t[:, 0].min()
+    late = (t[:, 0] - t0) > 1.0
+    med = lambda x: float(np.median(x))
+    return (f"   | {len(a)} wg ({int(late.sum())} start > 1 us late), life {med(t[:, 3] - t[:, 0]):5.1f} us = prologue {med(t[:, 1] - t[:, 0]):4.1f}"
+            f" + K-loop {med(t[:, 2] - t[:, 1]):5.1f} + epilogue {med(t[:, 3] - t[:, 2]):4.1f}; last exit {(t[:, 3] - t0).max():5.1f} us"
+            f"; clock {med(100.0 * a[:, 0] / a[:, 1]):4.0f} MHz")
 tot_f = tot_t = 0
 for name, fl, fn in cases:
     ms = timeit(fn)
     tot_f += fl; tot_t += ms
-    print(f"{name:28s} {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s")
+    print(f"{name:28s} {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s" + (phases(name) if PH else ""))
 print(f"hint {HINT} {'block total':21s} {tot_t*1e3:8.1f} us  {tot_f/tot_t/1e9:7.1f} TFLOP/s")

@@ -85,6 +85,33 @@ __device__ __forceinline__ float gelu_tanh_grad(float x) {
   const float du2 = __builtin_fmaf(t, 6.0f * k0 * k1, 2.0f * k0);        // 2 du/dx
   return __builtin_fmaf((x * s) * (e * s), du2, s);                      // s + x s (1-s) 2 du
 }
+// The same two functions on the 4 accumulator values of a lane, written with vector operations so that hipcc emits the PACKED forms
+// (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two values per VALU slot): the fused GELU epilogues are VALU-bound -- 5.8 of the 30 us an
+// fc1 workgroup lives, 6.0 of 25.8 in the fc2 dgrad (tools/bench_gemm.py phases, profiles/r04_gemm_phases.txt).  Operation for
+// operation the scalar sequence above: bit-identical results.
+__device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
+__device__ __forceinline__ f32x4 gelu_tanh4(f32x4 x) {
+  const float c0 = -2.0f * 1.4426950408889634f * 0.7978845608028654f, c1 = c0 * 0.044715f;
+  const f32x4 a = x * __builtin_elementwise_fma(x * x, splat4(c1), splat4(c0));
+  const f32x4 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1]), __builtin_amdgcn_exp2f(a[2]), __builtin_amdgcn_exp2f(a[3])};
+  const f32x4 d = splat4(1.0f) + e;
+  const f32x4 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
+  return x * r;
+}
+__device__ __forceinline__ f32x4 gelu_tanh_grad4(f32x4 x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  const float c0 = -2.0f * 1.4426950408889634f * k0, c1 = c0 * k1;
+  const f32x4 t = x * x;
+  const f32x4 a = x * __builtin_elementwise_fma(t, splat4(c1), splat4(c0));
+  const f32x4 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1]), __builtin_amdgcn_exp2f(a[2]), __builtin_amdgcn_exp2f(a[3])};
+  const f32x4 d = splat4(1.0f) + e;
+  const f32x4 s = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
+  const f32x4 du2 = __builtin_elementwise_fma(t, splat4(6.0f * k0 * k1), splat4(2.0f * k0));
+  return __builtin_elementwise_fma((x * s) * (e * s), du2, s);
+}
+__device__ __forceinline__ f32x4 bf2f4(bf16x4 h) { return f32x4{bf2f(h[0]), bf2f(h[1]), bf2f(h[2]), bf2f(h[3])}; }
+__device__ __forceinline__ bf16x4 f2bf4(f32x4 v) { return bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; }
+__device__ __forceinline__ f32x4 as4(float4 b) { return f32x4{b.x, b.y, b.z, b.w}; }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_grad(float x) {
   float s = 1.0f / (1.0f + __expf(-x));

@@ -176,7 +176,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int row, int c
   } else if (EPI == EPI_GELU) {
     bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
     nt_store(reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col), h, g.nt_out & 1);   // read again only by the backward pass
-    bf16x4 o = {f2bf(gelu_tanh(v[0])), f2bf(gelu_tanh(v[1])), f2bf(gelu_tanh(v[2])), f2bf(gelu_tanh(v[3]))};
+    const bf16x4 o = f2bf4(gelu_tanh4(v));
     *reinterpret_cast<bf16x4*>(g.Cb + (size_t)row * g.ldcb + col) = o;
   } else if (EPI == EPI_GATE_RES) {
     bf16x4 a = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
@@ -187,8 +187,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int row, int c
     *reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col) = x;
   } else if (EPI == EPI_DGELU) {
     const bf16x4 h = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)row * g.ldaux + col);
-    bf16x4 o = {f2bf(v[0] * gelu_tanh_grad(bf2f(h[0]))), f2bf(v[1] * gelu_tanh_grad(bf2f(h[1]))),
-                f2bf(v[2] * gelu_tanh_grad(bf2f(h[2]))), f2bf(v[3] * gelu_tanh_grad(bf2f(h[3])))};
+    const bf16x4 o = f2bf4(v * gelu_tanh_grad4(bf2f4(h)));
     *reinterpret_cast<bf16x4*>(g.Cb + (size_t)row * g.ldcb + col) = o;
   } else if (EPI == EPI_POS) {
     const float4 pe = *reinterpret_cast<const float4*>(g.pos + (size_t)(row % g.T) * g.N + col);
@@ -585,8 +584,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_fast(GemmArgs g) {
       for (int nt = 0; nt < NT; ++nt) {
         const f32x4 v = acc[mt][nt] * g.alpha;
         const bf16x4 h = hx[mt][nt];
-        bf16x4 o = {f2bf(v[0] * gelu_tanh_grad(bf2f(h[0]))), f2bf(v[1] * gelu_tanh_grad(bf2f(h[1]))),
-                    f2bf(v[2] * gelu_tanh_grad(bf2f(h[2]))), f2bf(v[3] * gelu_tanh_grad(bf2f(h[3])))};
+        const bf16x4 o = f2bf4(v * gelu_tanh_grad4(bf2f4(h)));
         *reinterpret_cast<bf16x4*>(g.Cb + (size_t)(row_b + mt * 16) * g.ldcb + col_b + nt * 16) = o;
       }
   } else if constexpr (EPI == EPI_GATE_RES) {
@@ -775,6 +773,9 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef SFRON_DEBUG_KNOBS
+  const long long clk_e = g.dbg_clk ? (long long)__builtin_amdgcn_s_memrealtime() : 0;      // workgroup entry (constant 100 MHz counter)
+#endif
   const int wm = wave / WN, wn = wave % WN;
   const int nblk = gridDim.x;
   int id;
@@ -1137,8 +1138,8 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
 #ifdef SFRON_DEBUG_KNOBS
     if (g.dbg_clk && tid == 0 && blockIdx.y == 0) {            // (memory nothing else reads: the stamps never reach an output)
       const long long dt = __builtin_amdgcn_s_memtime() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
-      long long* const o = g.dbg_clk + ((A_TR ? 2 : B_TR ? 1 : 0) * 1024 + (blockIdx.x & 1023)) * 2;
-      o[0] = dt; o[1] = dr;
+      long long* const o = g.dbg_clk + ((A_TR ? 2 : B_TR ? 1 : 0) * 1024 + (blockIdx.x & 1023)) * 6;
+      o[0] = dt; o[1] = dr; o[2] = clk_e; o[3] = clk_r0; o[4] = clk_r0 + dr;
     }
 #endif
   } else
@@ -1219,10 +1220,9 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
       for (int nt = 0; nt < NT; ++nt) {
         const f32x4 v = acc[mt][nt] * g.alpha;
         const bf16x4 h = hx[mt][nt];
-        const f32x4 r = {v[0] * gelu_tanh_grad(bf2f(h[0])), v[1] * gelu_tanh_grad(bf2f(h[1])),
-                         v[2] * gelu_tanh_grad(bf2f(h[2])), v[3] * gelu_tanh_grad(bf2f(h[3]))};
+        const f32x4 r = v * gelu_tanh_grad4(bf2f4(h));
         cs[nt] += r;
-        ob[nt] = bf16x4{f2bf(r[0]), f2bf(r[1]), f2bf(r[2]), f2bf(r[3])};
+        ob[nt] = f2bf4(r);
       }
       __bf16* const crow = g.Cb + (size_t)(row_b + mt * 16) * g.ldcb;
       if (wide) {
@@ -1269,6 +1269,9 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) gt[nt] = *reinterpret_cast<const float4*>(g.gate + (size_t)(row_b / g.T) * g.ldgate + col_b + nt * 16);
     }
+    // (The residual loads stay per 16-row block.  Issuing all MT x NT of the tile up front saves one exposed latency -- and takes the 256 x 144
+    // kernel from 206 to 234 registers = 240 allocated: two of its waves then leave a SIMD 32 registers, the parameter sweep that runs
+    // beside the forward pass needs 48 per wave and loses every CU this kernel is on: +2.7 ms per step, profiles/r04_ab_log.txt.)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int row = row_b + mt * 16;
@@ -1284,14 +1287,13 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
       for (int nt = 0; nt < NT; ++nt) {
         const int col = col_b + nt * 16;
         f32x4 v = acc[mt][nt] * g.alpha;
-        if constexpr (PRE_BIAS) { const float4 b = bias_v[nt]; v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-        else if constexpr (LATE_BIAS) { const float4 b = bias_l[nt]; v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-        else if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-        ab[nt] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        if constexpr (PRE_BIAS) v += as4(bias_v[nt]);
+        else if constexpr (LATE_BIAS) v += as4(bias_l[nt]);
+        else if (g.bias) v += as4(*reinterpret_cast<const float4*>(g.bias + col));
+        ab[nt] = f2bf4(v);
         if (!wide) nt_store(reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col), ab[nt], g.nt_out & 1);
-        float4 x = xr[nt];
-        x.x += gt[nt].x * v[0]; x.y += gt[nt].y * v[1]; x.z += gt[nt].z * v[2]; x.w += gt[nt].w * v[3];
-        *reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col) = x;
+        const f32x4 x = as4(xr[nt]) + as4(gt[nt]) * v;
+        *reinterpret_cast<f32x4*>(g.Cf + (size_t)row * g.ldcf + col) = x;
       }
       if (wide) {                                  // the bf16 branch output (read again by the backward pass): 16-byte pieces
         __bf16* const arow = g.aux + (size_t)row * g.ldaux;
@@ -1317,14 +1319,14 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           f32x4 v = acc[mt][nt] * g.alpha;
-          if constexpr (PRE_BIAS) { const float4 b = bias_v[nt]; v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-          else if constexpr (LATE_BIAS) { const float4 b = bias_l[nt]; v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-          else if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + col_b + nt * 16); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+          if constexpr (PRE_BIAS) v += as4(bias_v[nt]);
+          else if constexpr (LATE_BIAS) v += as4(bias_l[nt]);
+          else if (g.bias) v += as4(*reinterpret_cast<const float4*>(g.bias + col_b + nt * 16));
           if constexpr (EPI == EPI_GELU) {
-            hb[nt] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};                       // pre-activation (the backward pass reads it)
-            ob[nt] = bf16x4{f2bf(gelu_tanh(v[0])), f2bf(gelu_tanh(v[1])), f2bf(gelu_tanh(v[2])), f2bf(gelu_tanh(v[3]))};
+            hb[nt] = f2bf4(v);                                  // pre-activation (the backward pass reads it)
+            ob[nt] = f2bf4(gelu_tanh4(v));
           } else {
-            ob[nt] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            ob[nt] = f2bf4(v);
           }
         }
         __bf16* const crow = g.Cb + (size_t)row * g.ldcb;
@@ -1347,6 +1349,10 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
         epilogue_store<EPI>(g, row_b + mt * 16, col_b + nt * 16, acc[mt][nt],
                             PRE_BIAS ? &bias_v[PRE_BIAS ? nt : 0] : LATE_BIAS ? &bias_l[LATE_BIAS ? nt : 0] : nullptr);
   }
+#ifdef SFRON_DEBUG_KNOBS
+  if (g.dbg_clk && tid == 0 && blockIdx.y == 0)               // every store of wave 0 issued (not necessarily written)
+    g.dbg_clk[((A_TR ? 2 : B_TR ? 1 : 0) * 1024 + (blockIdx.x & 1023)) * 6 + 5] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 #define SFRON_INST_PIPE(WM, WN, MT, NT)                                              \
@@ -1411,7 +1417,7 @@ template __global__ void k_gemm_pipe<4, 2, 3, 6, true, true, 1, 2, 2, false, 4>(
 static long long* dbg_clk_buffer() {
   static long long* buf = [] {
     long long* p = nullptr;
-    if (getenv("SFRON_GEMM_CLK") && hipMalloc(&p, 3 * 1024 * 2 * sizeof(long long)) == hipSuccess) (void)hipMemset(p, 0, 3 * 1024 * 2 * sizeof(long long));
+    if (getenv("SFRON_GEMM_CLK") && hipMalloc(&p, 3 * 1024 * 6 * sizeof(long long)) == hipSuccess) (void)hipMemset(p, 0, 3 * 1024 * 6 * sizeof(long long));
     return p;
   }();
   return buf;
@@ -1419,15 +1425,24 @@ static long long* dbg_clk_buffer() {
 extern "C" int sfron_dbg_gemm_clock(double* mhz3, int* n3) {
   long long* d = dbg_clk_buffer();
   if (!d || !mhz3 || !n3) return SFRON_ERR_ARG;
-  static long long host[3 * 1024 * 2];
+  static long long host[3 * 1024 * 6];
   if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host, d, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return (int)hipGetLastError();
   for (int c = 0; c < 3; ++c) {
     double v[1024]; int n = 0;
-    for (int i = 0; i < 1024; ++i) { const long long dt = host[(c * 1024 + i) * 2], dr = host[(c * 1024 + i) * 2 + 1]; if (dr > 0) v[n++] = 100.0 * (double)dt / (double)dr; }
+    for (int i = 0; i < 1024; ++i) { const long long dt = host[(c * 1024 + i) * 6], dr = host[(c * 1024 + i) * 6 + 1]; if (dr > 0) v[n++] = 100.0 * (double)dt / (double)dr; }
     for (int i = 1; i < n; ++i) { double x = v[i]; int j = i - 1; while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; --j; } v[j + 1] = x; }
     mhz3[c] = n ? v[n / 2] : 0.0; n3[c] = n;
   }
   (void)hipMemset(d, 0, sizeof(host));
+  return SFRON_OK;
+}
+// the raw stamps of one layout class: [1024][6] = (K-loop delta s_memtime, delta s_memrealtime, entry, loop start, loop end, exit; 100 MHz ticks)
+extern "C" int sfron_dbg_gemm_phases(int cls, long long* out) {
+  long long* d = dbg_clk_buffer();
+  if (!d || !out || cls < 0 || cls > 2) return SFRON_ERR_ARG;
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, d + (size_t)cls * 1024 * 6, 1024 * 6 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess)
+    return (int)hipGetLastError();
+  (void)hipMemset(d + (size_t)cls * 1024 * 6, 0, 1024 * 6 * sizeof(long long));
   return SFRON_OK;
 }
 #endif
