@@ -195,7 +195,7 @@ int64_t sfron_dit_workspace_bytes(const sfron_dit_cfg* cfg) {
 }
 
 // SFRON_ABLATE (debug / A-B measurement only): bit 0 = run LN backward and gate backward as separate kernels,
-// bit 1 = split-K in the block weight gradients (off by default), bit 2 = side stream at the lowest priority, bit 3 = fc2 weight gradient after the fc2 dgrad, bit 4 = no split-K for the two small-output weight gradients, bit 5 = bias row sums inside the weight-gradient GEMM, bit 6 = fc1 bias gradient by a separate column-sum launch, bit 7 = qkv bias gradient likewise, bit 8 = proj weight gradient before (not beside) the attention backward
+// bit 1 = split-K in the block weight gradients (off by default), bit 2 = side stream at the lowest priority, bit 3 = fc2 weight gradient after the fc2 dgrad, bit 4 = no split-K for the two small-output weight gradients, bit 5 = bias row sums inside the weight-gradient GEMM, bit 6 = fc1 bias gradient by a separate column-sum launch, bit 7 = qkv bias gradient likewise, bit 8 = proj weight gradient before (not beside) the attention backward, bit 9 = fc1 / fc2 weight gradients on 256 x 192 tiles (108 workgroups)
 static int ablate_mask() {
 #ifdef SFRON_DEBUG_KNOBS
   static const int m = [] { const char* e = getenv("SFRON_ABLATE"); return e ? atoi(e) : 0; }();
@@ -507,6 +507,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     // the slab traffic + reductions make the step 0.5-2 ms SLOWER -> off unless SFRON_ABLATE bit 1 asks for the A-B run
     const int sp = (ablate_mask() & 2) ? wgrad_splits(N, K, M) : 1;
     if (sp > 1) { q.c_f32 = w.wslab; q.split_k = sp; q.split_stride = (long)N * K; }
+    if ((ablate_mask() & 512) && N % 256 == 0 && K % 192 == 0) q.tile_hint = 42;      // A-B knob: 256 x 192 tiles (fc1 / fc2: 108 workgroups instead of 144)
     RUN(sfron_gemm_bf16(&q, side));
     if (sp > 1) RUN(sfron_reduce_chunks(w.wslab, 1, sp, N * K, dW, N * K, 0, side));
     return SFRON_OK;
