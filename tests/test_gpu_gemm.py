@@ -284,3 +284,49 @@ def test_tile_256x144_epilogues():
     ops.gemm(P.to(DEV), Wp.to(DEV), M, D, 192, epilogue=_lib.EPI_POS, bias=b2.to(DEV), c_f32=xo, pos=pos.to(DEV), tokens=T, tile_hint=62)
     want = P.float() @ Wp.float().t() + b2 + pos.repeat(Bsz, 1)
     np.testing.assert_allclose(xo.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 6912, 1152), (32, 1152, 256), (5, 48, 64), (17, 16, 32), (32, 195840, 1152)])
+def test_skinny_rows_kernel(M, N, K):
+    """At most 32 output rows, fp32 out (csrc/gemm.hip k_gemm_skinny: the conditioning path of the DiT forward pass): exact on small
+    integers (catches a swapped row / column map or a wrong fragment address), and against torch fp32 and the generic kernel on random
+    bf16 data; rows beyond M are neither read nor written."""
+    from sfron import ops, _lib
+    r = torch.arange(N, dtype=torch.float32).view(N, 1)
+    c = torch.arange(K, dtype=torch.float32).view(1, K)
+    m = torch.arange(M, dtype=torch.float32).view(M, 1)
+    Bi = ((3 * r + 5 * c) % 7 - 3).to(torch.bfloat16)                    # [N, K]
+    Ai = ((2 * m + c) % 5 - 2).to(torch.bfloat16)                        # [M, K]
+    want = Ai.float() @ Bi.float().t()                                   # |sum| < 2^24: exact in fp32
+    guard = torch.full((M + 3, N), 777.0, device=DEV)
+    ops.gemm(Ai.to(DEV), Bi.to(DEV), M, N, K, epilogue=_lib.EPI_F32, c_f32=guard[:M])
+    assert torch.equal(guard[:M].cpu(), want)
+    assert torch.all(guard[M:] == 777.0)
+    gen = torch.Generator().manual_seed(M + N + K)
+    A, B = _rand((M, K), gen), _rand((N, K), gen, 0.05)
+    bias = torch.randn(N, generator=gen)
+    want = A.float() @ B.float().t() + bias
+    Cf = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(A.to(DEV), B.to(DEV), M, N, K, bias=bias.to(DEV), epilogue=_lib.EPI_F32, c_f32=Cf)
+    np.testing.assert_allclose(Cf.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4 * K ** 0.5)
+    Cg = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(A.to(DEV), B.to(DEV), M, N, K, bias=bias.to(DEV), epilogue=_lib.EPI_F32, c_f32=Cg, tile_hint=-1)   # the generic tile
+    np.testing.assert_allclose(Cf.cpu().numpy(), Cg.cpu().numpy(), rtol=1e-5, atol=1e-5 * K ** 0.5)
+
+
+@pytest.mark.parametrize("M,N,K,T", [(8192, 1152, 16, 256), (96, 48, 16, 32), (40, 16, 8, 8), (512, 768, 32, 64)])
+def test_short_contraction_kernel(M, N, K, T):
+    """Patch-embedding shape (csrc/gemm.hip k_gemm_shortk: K <= 32, bias + positional table in the epilogue): bit-identical to the generic
+    kernel, exact on small integers, ragged row counts."""
+    from sfron import ops, _lib
+    gen = torch.Generator().manual_seed(M + N + K)
+    A, B = _rand((M, K), gen), _rand((N, K), gen, 0.25)
+    bias, pos = torch.randn(N, generator=gen), torch.randn(T, N, generator=gen)
+    want = A.float() @ B.float().t() + bias + pos.repeat(M // T, 1)
+    guard = torch.full((M + 2, N), 777.0, device=DEV)
+    ops.gemm(A.to(DEV), B.to(DEV), M, N, K, epilogue=_lib.EPI_POS, bias=bias.to(DEV), c_f32=guard[:M], pos=pos.to(DEV), tokens=T)
+    np.testing.assert_allclose(guard[:M].cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+    assert torch.all(guard[M:] == 777.0)
+    ref = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(A.to(DEV), B.to(DEV), M, N, K, epilogue=_lib.EPI_POS, bias=bias.to(DEV), c_f32=ref, pos=pos.to(DEV), tokens=T, tile_hint=-1)
+    assert torch.equal(guard[:M], ref)

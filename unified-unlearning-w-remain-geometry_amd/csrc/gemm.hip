@@ -323,6 +323,141 @@ __global__ __launch_bounds__(NT) void k_gemm(GemmArgs g) {
   }
 }
 
+// =================================================================================================
+// Skinny product: C[M <= 32][N] = alpha * A[M][K] W[N][K]^T + bias, fp32 out -- the conditioning path of the DiT forward pass: the adaLN
+// modulation of every block at once ([32 x 1152] x [1152 x 195 840]: 446 MB of bf16 weight read once) and the two Linears of the timestep
+// MLP.  On the 128 x 128 generic tile three quarters of the matrix work was padding and the two-deep staging kept 2.5 TB/s of weight
+// rows in flight (179 us, on the critical stream in front of block 0: profiles/r04_stage_boundary.txt).  Here the rows of W are the MFMA's
+// ROW operand, read straight from global memory as fragments (lane = row n0 + (lane & 15), 16 bytes of k-step ks at 8 (lane >> 4)): no
+// staging, twelve 1 KB loads in flight per wave.  The activations (32 x K bf16, zero rows beyond M) sit in LDS once per workgroup, rows
+// padded by 16 bytes (row stride = 4 banks mod 64: a 16-lane group's ds_read_b128 covers the 64 banks exactly).  A lane ends up with
+// C[m = lane & 15 (+ 16)][n0 + 4 g .. + 3]: 16-byte stores.  Each wave walks `ntw` consecutive 16-row tiles of W.
+constexpr int SK_KB = 12;
+__global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs g, int ntw) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 sk_a[];          // [32][K + 8]
+  const int K = g.K, ldl = K + 8, kc = K >> 3;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int e = tid; e < 32 * kc; e += 256) {
+    const int m = e / kc, c = e - m * kc;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (m < g.M) v = *reinterpret_cast<const uint4*>(g.A + (size_t)m * g.lda + c * 8);
+    *reinterpret_cast<uint4*>(sk_a + m * ldl + c * 8) = v;
+  }
+  __syncthreads();
+  const int nks = K >> 5, ntiles = g.N >> 4;
+  const __bf16* const a0p = sk_a + r * ldl + 8 * q;
+  const __bf16* const a1p = sk_a + (16 + r) * ldl + 8 * q;
+  for (int t = 0; t < ntw; ++t) {
+    const int nt = (blockIdx.x * 4 + wave) * ntw + t;                      // wave-uniform
+    if (nt >= ntiles) break;
+    const __bf16* const wrow = g.B + (size_t)(nt * 16 + r) * g.ldb + 8 * q;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < nks; k0 += SK_KB) {
+      bf16x8 wf[SK_KB];
+#pragma unroll
+      for (int u = 0; u < SK_KB; ++u)
+        if (k0 + u < nks) wf[u] = *reinterpret_cast<const bf16x8*>(wrow + 32 * (k0 + u));
+#pragma unroll
+      for (int u = 0; u < SK_KB; ++u)
+        if (k0 + u < nks) {
+          const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(a0p + 32 * (k0 + u));
+          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(a1p + 32 * (k0 + u));
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], a0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], a1, acc1, 0, 0, 0);
+        }
+    }
+    const int col = nt * 16 + 4 * q;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) b4 = as4(*reinterpret_cast<const float4*>(g.bias + col));
+    if (r < g.M) *reinterpret_cast<f32x4*>(g.Cf + (size_t)r * g.ldcf + col) = acc0 * g.alpha + b4;
+    if (16 + r < g.M) *reinterpret_cast<f32x4*>(g.Cf + (size_t)(16 + r) * g.ldcf + col) = acc1 * g.alpha + b4;
+  }
+}
+inline bool skinny_ok(const GemmArgs& g) {
+  return g.M <= 32 && g.N % 16 == 0 && g.K % 32 == 0 && g.K <= 2048 && g.ldb % 8 == 0 && g.lda % 8 == 0 && g.ldcf % 4 == 0 && g.kchunk == g.K &&
+         !g.accumulate && (((uintptr_t)g.Cf | (uintptr_t)g.bias) & 15) == 0;
+}
+inline int launch_skinny(const GemmArgs& g, hipStream_t s) {
+  const int ntiles = g.N / 16;
+  int ntw = cdiv(ntiles, 4 * 512);                    // one round of two workgroups per CU where the problem is that large
+  if (ntw < 1) ntw = 1;
+  const size_t lds = (size_t)32 * (g.K + 8) * sizeof(__bf16);
+  // once per process, for the largest K this kernel takes (skinny_ok): the attribute call in front of EVERY launch left the stream idle for
+  // ~60 us (profiles/r04_stage_boundary.txt's successor trace)
+  static const int lds_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                32 * (2048 + 8) * (int)sizeof(__bf16)) == hipSuccess ? SFRON_OK : (int)hipGetLastError();
+  if (lds_rc != SFRON_OK) return lds_rc;
+  hipLaunchKernelGGL(k_gemm_skinny, dim3(cdiv(ntiles, 4 * ntw)), dim3(256), lds, s, g, ntw);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SFRON_OK : (int)e;
+}
+
+// Short contraction: C[M][N] = alpha * A[M][K <= 32] W[N][K]^T + bias + pos[(row % T)][col], fp32 out -- the patch embedding of the DiT
+// forward pass (K = patch^2 * channels = 16: 37.7 MB of output from 0.3 MB of operands; 68 us on the generic tile, which stages 64-deep
+// K-tiles of mostly padding).  ONE MFMA k-step per 16 x 16 output tile (k beyond K zero in both fragments -- the same products and the
+// same accumulation as the generic kernel's zero-padded tiles: bit-identical), W as the row operand so that a lane holds four consecutive
+// columns of one output row: the kernel is its 16-byte stores.  A wave = 16 rows x `cols_per_wave` columns.
+__global__ __launch_bounds__(256) void k_gemm_shortk(GemmArgs g, int nt_per_wave) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wid = blockIdx.x * 4 + wave;
+  const int ntiles = g.N >> 4, parts = (ntiles + nt_per_wave - 1) / nt_per_wave;
+  const int mt = wid / parts, part = wid - mt * parts;
+  if (mt * 16 >= g.M) return;
+  bf16x8 z;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.0f;
+  const int row = mt * 16 + r;
+  const bool kin = 8 * q < g.K;
+  bf16x8 af = z;
+  if (kin && row < g.M) af = *reinterpret_cast<const bf16x8*>(g.A + (size_t)row * g.lda + 8 * q);
+  const float* const prow = g.pos ? g.pos + (size_t)(row % g.T) * g.N : nullptr;
+  float* const crow = g.Cf + (size_t)row * g.ldcf;
+  const int nt1 = min(ntiles, (part + 1) * nt_per_wave);
+  for (int nt0 = part * nt_per_wave; nt0 < nt1; nt0 += 4) {             // four tiles per trip: their loads go out together
+    bf16x8 wf[4];
+    f32x4 add[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int nt = nt0 + u < nt1 ? nt0 + u : nt1 - 1;
+      wf[u] = kin ? *reinterpret_cast<const bf16x8*>(g.B + (size_t)(nt * 16 + r) * g.ldb + 8 * q) : z;
+      const int col = nt * 16 + 4 * q;
+      add[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (g.bias) add[u] = as4(*reinterpret_cast<const float4*>(g.bias + col));
+    }
+    f32x4 pe[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int nt = nt0 + u < nt1 ? nt0 + u : nt1 - 1;
+      pe[u] = (prow && row < g.M) ? as4(*reinterpret_cast<const float4*>(prow + nt * 16 + 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (nt0 + u >= nt1) break;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af, acc, 0, 0, 0);
+      // lane: C[row = mt * 16 + r][(nt0 + u) * 16 + 4 q + j]; the generic epilogue's order: (acc * alpha + bias) + pos
+      const f32x4 v = (acc * g.alpha + add[u]) + pe[u];
+      if (row < g.M) *reinterpret_cast<f32x4*>(crow + (nt0 + u) * 16 + 4 * q) = v;
+    }
+  }
+}
+inline bool shortk_ok(const GemmArgs& g) {
+  return g.K <= 32 && g.K % 8 == 0 && g.N % 16 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldcf % 4 == 0 && g.kchunk == g.K && !g.accumulate &&
+         (((uintptr_t)g.Cf | (uintptr_t)g.bias | (uintptr_t)g.pos) & 15) == 0;
+}
+inline int launch_shortk(const GemmArgs& g, hipStream_t s) {
+  const int ntiles = g.N / 16, mtiles = cdiv(g.M, 16);
+  int parts = 1;
+  while (mtiles * parts < 2048 && parts * 2 <= ntiles / 4) parts *= 2;     // >= 2 048 waves where the output is that large
+  const int per = cdiv(cdiv(ntiles, parts), 4) * 4;
+  const int waves = mtiles * cdiv(ntiles, per);
+  hipLaunchKernelGGL(k_gemm_shortk, dim3(cdiv(waves, 4)), dim3(256), 0, s, g, per);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SFRON_OK : (int)e;
+}
+
 template <bool A_TR, bool B_TR, int EPI>
 int launch(const GemmArgs& g, hipStream_t s) {
   const size_t lds = 4 * TILE_ELEMS * sizeof(__bf16);
@@ -1688,6 +1823,7 @@ int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
       return dispatch_layout<EPI_BF16>(d->a_transposed, d->b_transposed, g, s, force);
     case SFRON_EPI_F32:
       SFRON_CHECK_ARG(g.Cf && g.ldcf % 4 == 0);
+      if (!d->a_transposed && !d->b_transposed && force == 0 && skinny_ok(g)) return launch_skinny(g, s);      // at most 32 output rows
       return dispatch_layout<EPI_F32>(d->a_transposed, d->b_transposed, g, s, force);
     case SFRON_EPI_GELU:
       SFRON_CHECK_ARG(g.Cb && g.aux && g.ldcb % 4 == 0 && g.ldaux % 4 == 0 && !d->a_transposed && !d->b_transposed);
@@ -1701,6 +1837,7 @@ int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
       return launch_any<false, true, EPI_DGELU>(g, s, force);
     case SFRON_EPI_POS:
       SFRON_CHECK_ARG(g.Cf && g.pos && g.ldcf % 4 == 0 && !d->a_transposed && !d->b_transposed);
+      if (force == 0 && shortk_ok(g)) return launch_shortk(g, s);          // the patch embedding: K = 16
       return launch_any<false, false, EPI_POS>(g, s, force);
     default:
       return SFRON_ERR_UNSUPPORTED;

@@ -544,7 +544,14 @@ __global__ __launch_bounds__(TPB) void k_reduce_slots(const float* __restrict__ 
   const float* p = parts + (size_t)slot * slot_stride + (size_t)b * per * D + c;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   int j = 0;
-  for (; j + 4 <= per; j += 4) {                                // four loads in flight, summed in index order
+  for (; j + 8 <= per; j += 8) {                                // eight loads in flight (528 MB per pass at DiT-XL/2: 3.4 TB/s with four), summed in index order
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(j + u) * D);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  for (; j + 4 <= per; j += 4) {
     float4 v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(j + u) * D);
