@@ -137,7 +137,10 @@ struct RowBwdArgs {
 // weight-gradient workgroup (2 x 160 registers per SIMD) on the same CU -- left alone hipcc takes 256 and the kernel then runs only on
 // CUs without one
 template <bool LN, bool GATE, bool COMBINE>
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_num_vgpr(96))) void k_row_bwd(const RowBwdArgs a) {
+#ifndef SFRON_ROWBWD_VGPR
+#define SFRON_ROWBWD_VGPR 96
+#endif
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_num_vgpr(SFRON_ROWBWD_VGPR))) void k_row_bwd(const RowBwdArgs a) {
   constexpr int NACC = (LN ? 2 : 0) + (GATE ? 2 : 0);
   // 12 KB of LDS, so that a workgroup still fits on a CU next to a weight-gradient GEMM workgroup (3 x 48 KB slots):
   // these kernels run beside the side stream's GEMMs and are memory-bound, extra resident waves are what they need
