@@ -140,9 +140,11 @@ def _dit_leg(model_name, batch, latent, dev, fp8, steps, warmup):
     flops = 6.0 * batch * L * (2 * T * D * (3 * D + D + 2 * F) + 4 * T * T * D + 2 * D * 6 * D)
     ok = bool(torch.isfinite(out["remain_mse"]).all().item() and torch.isfinite(out["forget_mse"]).all().item())
     runner.sync_sweep()
+    rng = eng.fp8_activation_range() if fp8 else None
     eng.close()
     return {"ms_per_step": ms, "steps_per_s": 1e3 / ms, "steps": steps, "batch": batch, "tflops": flops / ms / 1e9,
-            "frac_of_bf16_mfma_peak": flops / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, "finite_losses": ok}
+            "frac_of_bf16_mfma_peak": flops / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, "finite_losses": ok,
+            **({"fp8_activation_range": rng} if fp8 else {})}
 
 
 def _ddpm_leg(dev, steps=50, batch=64):
@@ -477,6 +479,8 @@ def main():
                                     "remain_sweep_beside_next_forget_forward": sched_across,
                                     "note": "every sweep is inside the timed region (it ends with torch.cuda.synchronize())"}},
             "finite_losses": loss_ok,
+            # config 5: fraction of the e4m3 range the activations reached in this run (static activation scales, saturating conversion)
+            "fp8_activation_range": model.engine.fp8_activation_range() if args.fp8 else None,
             "step_tflops_per_gpu": step_flops / (ms_per_step * 1e-3) / 1e12,
             "step_frac_of_bf16_mfma_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
             "dp_overlap": dp_overlap, "grad_transport": runner.grad_transport if world > 1 else None, "check": check_res,

@@ -215,6 +215,12 @@ int sfron_fp8_quant_tensors(const float* params, const int64_t* table, int n_ten
                             uint8_t* dst, int mode, void* stream);
 /* scales[t] = 2^floor(log2(224 / amax_t)) (2x headroom under 448; 1 for an all-zero tensor); clears amax_bits */
 int sfron_fp8_update_scales(uint32_t* amax_bits, int n_tensors, float* scales, void* stream);
+/* How much of the e4m3 range the ACTIVATIONS of config 5 used since the last reset: out3[site] (HOST out) = max |x * scale| over every value
+ * quantised at site 0 = sfron_ln_modulate_fwd_q's output, 1 = sfron_cast_e4m3, 2 = the e4m3 GELU output of sfron_fp8_gemm (c_e4m3).  The
+ * conversion saturates at 448: a value above it means values WERE clipped (the reference has no fp8 path: nothing there to mirror).  Process-
+ * wide counters; synchronises `stream`.  reset != 0 clears them. */
+int sfron_fp8_activation_amax(float* out3 /* HOST out, 3 floats */, int reset, void* stream);
+
 /* dst[i] = e4m3(src[i] * scale); src bf16 (src_is_bf16 = 1) or fp32; n % 8 == 0 */
 int sfron_cast_e4m3(const void* src, int src_is_bf16, int64_t n, float scale, uint8_t* dst, void* stream);
 /* sfron_ln_modulate_fwd that also writes out_e4m3 = e4m3(value * e4m3_scale) from the fp32 value (the A operand of the next GEMM) */

@@ -371,3 +371,45 @@ def test_config5_xl2_batch32_iteration_reproducible_and_shadow_consistent():
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b), "two fresh runs of the same fp8 iteration must agree bit for bit"
     assert torch.isfinite(res[0][0]).all()
+
+
+def test_activation_range_is_reported_and_flags_saturation():
+    """The activation scales of config 5 are static and the e4m3 conversion saturates: sfron_fp8_activation_amax (engine.
+    fp8_activation_range) says how much of the range each quantisation site used and whether values were clipped."""
+    import ctypes
+    from sfron import _lib, ops
+    L = _lib.lib()
+    out = (ctypes.c_float * 3)()
+    assert L.sfron_fp8_activation_amax(out, 1, None) == 0                      # reset
+    n = 4096
+    x = torch.linspace(-3.0, 5.0, n, device=DEV)
+    dst = torch.empty(n, dtype=torch.uint8, device=DEV)
+    assert L.sfron_cast_e4m3(ctypes.c_void_p(x.data_ptr()), 0, n, ctypes.c_float(32.0), ctypes.c_void_p(dst.data_ptr()), None) == 0
+    assert L.sfron_fp8_activation_amax(out, 0, None) == 0
+    assert out[0] == 0.0 and out[2] == 0.0 and abs(out[1] - 160.0) < 1e-3        # 5 * 32: inside the range
+    xb = (x * 4).to(torch.bfloat16)                                              # up to 20 * 32 = 640 > 448: clipped
+    assert L.sfron_cast_e4m3(ctypes.c_void_p(xb.data_ptr()), 1, n, ctypes.c_float(32.0), ctypes.c_void_p(dst.data_ptr()), None) == 0
+    assert L.sfron_fp8_activation_amax(out, 1, None) == 0
+    assert abs(out[1] - 640.0) < 1.0
+    assert L.sfron_fp8_activation_amax(out, 0, None) == 0
+    assert out[0] == 0.0 and out[1] == 0.0 and out[2] == 0.0                     # the read above reset them
+    # through the engine: a small DiT forward pass in fp8 fills all three sites; random-init activations stay inside the range
+    from sfron import dit
+    model = dit.DiT_models["DiT-S/2"](input_size=16, num_classes=10, batch_size=8, device=DEV)
+    torch.manual_seed(0)
+    model.initialize_weights()
+    dit.randomize_zero_init(model, std=0.02, seed=1)
+    eng = model.engine
+    eng.enable_fp8()
+    g = torch.Generator().manual_seed(1)
+    xin = torch.randn(8, 4, 16, 16, generator=g).to(DEV)
+    t = torch.randint(0, 1000, (8,), generator=g).to(DEV)
+    y = torch.randint(0, 10, (8,), generator=g).to(DEV)
+    eng.forward(xin, t, y, None)
+    r = eng.fp8_activation_range()
+    assert 0.0 < r["ln_modulate"] <= 1.0 and 0.0 < r["attention_out"] <= 1.0 and 0.0 < r["gelu"] <= 1.0 and r["saturated"] is False
+    eng.enable_fp8(act_scales=(4096.0, 32.0, 16.0))                              # a scale that cannot hold LN outputs of a few units
+    eng.forward(xin, t, y, None)
+    r = eng.fp8_activation_range()
+    assert r["ln_modulate"] > 1.0 and r["saturated"] is True
+    eng.close()

@@ -199,6 +199,7 @@ _PROTOS.update({
     "sfron_aux_create": (c_int, [POINTER(c_void_p)]),
     "sfron_aux_destroy": (c_int, [c_void_p]),
     "sfron_aux_set_probe": (c_int, [c_void_p, c_void_p]),
+    "sfron_fp8_activation_amax": (c_int, [POINTER(c_float), c_int, c_void_p]),
     "sfron_dit_forward_probed": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_dit_forward_after": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_dit_fp8_workspace_bytes": (c_int64, [POINTER(DitCfg)]),

@@ -17,6 +17,7 @@
 // exact-integer verified there), plus the epilogues the block needs: bias -> bf16 (qkv); bias, GELU-tanh, pre-activation + bf16 + e4m3
 // outputs (fc1); bias, gate, residual -> fp32 stream + bf16 branch output (proj, fc2).
 #include "common.h"
+#include <string.h>
 #include "../../include/sfron.h"
 #include <atomic>
 
@@ -30,6 +31,21 @@ constexpr float E4M3_MAX = 448.0f;
 constexpr int TPB = 256;
 
 __device__ __forceinline__ float sat8(float x) { return fminf(fmaxf(x, -E4M3_MAX), E4M3_MAX); }
+
+// ---- how much of the e4m3 range the ACTIVATIONS use: the activation scales are static (engine.py: 8 / 32 / 16), the conversion saturates, and
+// nothing else would tell a run on real weights that its LN + modulate outputs left the range.  Every kernel that quantises an activation
+// keeps the maximum of |x * scale| per thread (one v_max per value), a wave reduces it and ONE lane per wave raises the site's word with
+// atomicMax on the bit pattern (non-negative floats order like unsigned integers).  sfron_fp8_activation_amax reads (and resets) the three
+// words: a value above 448 means that values were clipped since the last reset.  Process-wide, like the form knobs of this file.
+// site 0 = LN + modulate output (the A operand of qkv / fc1), 1 = sfron_cast_e4m3 (attention output -> proj), 2 = GELU output (-> fc2)
+__device__ unsigned int g_act_amax[3];
+__device__ __forceinline__ void amax4(float& m, float a, float b, float c, float d) {
+  m = fmaxf(m, fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d))));
+}
+__device__ __forceinline__ void amax_report(int site, float m) {
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(&g_act_amax[site], __float_as_uint(m));
+}
 // four fp32 -> four e4m3 bytes (little endian: a in bits 0..7)
 __device__ __forceinline__ uint32_t pack_e4m3(float a, float b, float c, float d) {
   int v = 0;
@@ -80,20 +96,28 @@ __global__ void k_fp8_update_scales(unsigned* __restrict__ amax_bits, int n, flo
 
 __global__ __launch_bounds__(TPB) void k_cast_e4m3_bf16(const __bf16* __restrict__ src, int64_t n, float scale, uint8_t* __restrict__ dst) {
   const int64_t n8 = n >> 3;
+  float am = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (int64_t)gridDim.x * TPB) {
     const bf16x8 v = reinterpret_cast<const bf16x8*>(src)[i];
+    const float f0 = bf2f(v[0]) * scale, f1 = bf2f(v[1]) * scale, f2 = bf2f(v[2]) * scale, f3 = bf2f(v[3]) * scale;
+    const float f4 = bf2f(v[4]) * scale, f5 = bf2f(v[5]) * scale, f6 = bf2f(v[6]) * scale, f7 = bf2f(v[7]) * scale;
+    amax4(am, f0, f1, f2, f3); amax4(am, f4, f5, f6, f7);
     uint2 o;
-    o.x = pack_e4m3(bf2f(v[0]) * scale, bf2f(v[1]) * scale, bf2f(v[2]) * scale, bf2f(v[3]) * scale);
-    o.y = pack_e4m3(bf2f(v[4]) * scale, bf2f(v[5]) * scale, bf2f(v[6]) * scale, bf2f(v[7]) * scale);
+    o.x = pack_e4m3(f0, f1, f2, f3);
+    o.y = pack_e4m3(f4, f5, f6, f7);
     reinterpret_cast<uint2*>(dst)[i] = o;
   }
+  amax_report(1, am);
 }
 __global__ __launch_bounds__(TPB) void k_cast_e4m3_f32(const float* __restrict__ src, int64_t n, float scale, uint8_t* __restrict__ dst) {
   const int64_t n4 = n >> 2;
+  float am = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
     const float4 v = reinterpret_cast<const float4*>(src)[i];
+    amax4(am, v.x * scale, v.y * scale, v.z * scale, v.w * scale);
     reinterpret_cast<uint32_t*>(dst)[i] = pack_e4m3(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
   }
+  amax_report(1, am);
 }
 
 // ---------------------------------------------------------------- LayerNorm + modulate with the e4m3 copy (norm.hip's k_ln_mod_fwd + one store)
@@ -112,6 +136,7 @@ __global__ __launch_bounds__(TPB) void k_ln_mod_fwd_q(const float* __restrict__ 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int row0 = (blockIdx.x * 4 + wave) * RPW;
   if (row0 >= M) return;
+  float am = 0.f;
   float4 v[RPW][NCHQ], sh[NCHQ], sc[NCHQ];
   {
     const int b = row0 / T;
@@ -155,9 +180,11 @@ __global__ __launch_bounds__(TPB) void k_ln_mod_fwd_q(const float* __restrict__ 
       const float o2 = (v[k][i].z - mean) * rstd * (1.0f + g.z) + h.z, o3 = (v[k][i].w - mean) * rstd * (1.0f + g.w) + h.w;
       const bf16x4 o = {f2bf(o0), f2bf(o1), f2bf(o2), f2bf(o3)};
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(q_u32x2, o), ro, lane * 8 + 512 * i, 0, 0);
+      if (lane + 64 * i < (D >> 2)) amax4(am, o0 * s8, o1 * s8, o2 * s8, o3 * s8);        // (lanes past the row end hold the shift, not data)
       __builtin_amdgcn_raw_buffer_store_b32(pack_e4m3(o0 * s8, o1 * s8, o2 * s8, o3 * s8), r8, lane * 4 + 256 * i, 0, 0);
     }
   }
+  amax_report(0, am);
 }
 
 // ---------------------------------------------------------------- fp8 x fp8 GEMM
@@ -301,6 +328,7 @@ __global__ __launch_bounds__(512 + 64 * NL) void k_gemm8(Gemm8Args g) {
   constexpr bool BIAS_BY_HALF = NL > 0 && EPI == E8_GATE_RES;       // (that epilogue also holds gate + residual words: bias with them, half a row at a time)
   if constexpr (NL > 0 && !BIAS_BY_HALF) load_bias();
   // lane holds C[m0 + 32 wave + 16 mt + fr][n0 + 16 nt + 4 fg .. +3]
+  [[maybe_unused]] float act_am = 0.f;          // E8_GELU: max |gelu * c8_scale| of this thread's values (g_act_amax site 2)
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int row = m0 + wave * 32 + mt * 16 + fr;
@@ -338,6 +366,7 @@ __global__ __launch_bounds__(512 + 64 * NL) void k_gemm8(Gemm8Args g) {
         ab[nt] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
         const float h0 = gelu_tanh(v[0]), h1 = gelu_tanh(v[1]), h2 = gelu_tanh(v[2]), h3 = gelu_tanh(v[3]);
         ob[nt] = bf16x4{f2bf(h0), f2bf(h1), f2bf(h2), f2bf(h3)};
+        amax4(act_am, h0 * g.c8_scale, h1 * g.c8_scale, h2 * g.c8_scale, h3 * g.c8_scale);
         c8[nt] = pack_e4m3(h0 * g.c8_scale, h1 * g.c8_scale, h2 * g.c8_scale, h3 * g.c8_scale);
       } else {
         ab[nt] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
@@ -372,6 +401,7 @@ __global__ __launch_bounds__(512 + 64 * NL) void k_gemm8(Gemm8Args g) {
       if constexpr (NT8 & 1) *reinterpret_cast<uint32_t*>(r8 + n0 + (NT8 - 1) * 16 + 4 * fg) = c8[NT8 - 1];
     }
   }
+  if constexpr (EPI == E8_GELU) amax_report(2, act_am);
 }
 template __global__ void k_gemm8<E8_BF16, 8>(Gemm8Args);
 template __global__ void k_gemm8<E8_GELU, 8>(Gemm8Args);
@@ -470,6 +500,21 @@ int sfron_fp8_update_scales(uint32_t* amax_bits, int n_tensors, float* scales, v
   SFRON_CHECK_ARG(amax_bits && scales && n_tensors > 0);
   hipLaunchKernelGGL(k_fp8_update_scales, dim3(cdiv(n_tensors, 64)), dim3(64), 0, (hipStream_t)stream, amax_bits, n_tensors, scales);
   SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_fp8_activation_amax(float* out3, int reset, void* stream) {
+  SFRON_CHECK_ARG(out3);
+  hipStream_t s = (hipStream_t)stream;
+  unsigned int bits[3] = {0u, 0u, 0u};
+  if (hipMemcpyFromSymbolAsync(bits, HIP_SYMBOL(g_act_amax), sizeof(bits), 0, hipMemcpyDeviceToHost, s) != hipSuccess) return (int)hipGetLastError();
+  if (hipStreamSynchronize(s) != hipSuccess) return (int)hipGetLastError();
+  for (int i = 0; i < 3; ++i) { float f; memcpy(&f, &bits[i], sizeof(f)); out3[i] = f; }
+  if (reset) {
+    const unsigned int z[3] = {0u, 0u, 0u};
+    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_act_amax), z, sizeof(z), 0, hipMemcpyHostToDevice, s) != hipSuccess) return (int)hipGetLastError();
+    if (hipStreamSynchronize(s) != hipSuccess) return (int)hipGetLastError();
+  }
   return SFRON_OK;
 }
 

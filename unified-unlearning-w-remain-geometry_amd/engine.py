@@ -177,6 +177,17 @@ class DitEngine:
         self.fp8_requantize(fresh=True)
         return self
 
+    def fp8_activation_range(self, reset=True):
+        """How much of the e4m3 range the activations used since the last reset (the activation scales are static and the conversion
+        saturates silently): dict site -> max |x * scale| / 448 for the LayerNorm+modulate outputs, the attention output and gelu(fc1), plus
+        ``saturated`` (any site above 1: values were clipped -- raise the matching entry of FP8_ACT_SCALES' divisor, i.e. pass a smaller
+        scale to enable_fp8(act_scales=...)).  Process-wide counters (include/sfron.h sfron_fp8_activation_amax); synchronises the stream."""
+        out = (ctypes.c_float * 3)()
+        check(_lib.lib().sfron_fp8_activation_amax(out, int(bool(reset)), stream_ptr()), "fp8_activation_amax")
+        r = {"ln_modulate": out[0] / 448.0, "attention_out": out[1] / 448.0, "gelu": out[2] / 448.0}
+        r["saturated"] = any(v > 1.0 for v in r.values())
+        return r
+
     def fp8_requantize(self, fresh=False):
         """e4m3 shadow <- fp32 masters, after every optimizer step.  One pass: the scales come from the amax the PREVIOUS call
         collected (delayed scaling: a weight moves by at most lr per step and the scale keeps 2x headroom under 448), and this
