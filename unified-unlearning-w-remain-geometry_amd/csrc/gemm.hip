@@ -728,20 +728,29 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_fast(GemmArgs g) {
     for (int nt = 0; nt < NT; ++nt)      // all rows of a tile belong to one sample when tokens % tile rows == 0; else per row
       gt[nt] = *reinterpret_cast<const float4*>(g.gate + (size_t)(row_b / g.T) * g.ldgate + col_b + nt * 16);
     const bool uniform_sample = (g.T % FBM) == 0;
+    // the bias words and (token counts below the tile's rows: DiT-B/4 has 64) the row's gate words go out with the residual loads, before
+    // the first use: inside the column loop each was a load-use pair -- MT x NT exposed latencies per tile (44 us for a 96-tile launch)
+    float4 bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = g.bias ? *reinterpret_cast<const float4*>(g.bias + col_b + nt * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int row = row_b + mt * 16;
       float4 xr[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) xr[nt] = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldcf + col_b + nt * 16);
+      if (!uniform_sample) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) gt[nt] = *reinterpret_cast<const float4*>(g.gate + (size_t)(row / g.T) * g.ldgate + col_b + nt * 16);
+      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int col = col_b + nt * 16;
         f32x4 v = acc[mt][nt] * g.alpha;
-        if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+        if (g.bias) { const float4 b = bv[nt]; v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
         bf16x4 a = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
         nt_store(reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col), a, g.nt_out & 1);
-        const float4 gg = uniform_sample ? gt[nt] : *reinterpret_cast<const float4*>(g.gate + (size_t)(row / g.T) * g.ldgate + col);
+        const float4 gg = gt[nt];
         float4 x = xr[nt];
         x.x += gg.x * v[0]; x.y += gg.y * v[1]; x.z += gg.z * v[2]; x.w += gg.w * v[3];
         *reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col) = x;
