@@ -44,7 +44,10 @@ __device__ __forceinline__ void amax4(float& m, float a, float b, float c, float
 }
 __device__ __forceinline__ void amax_report(int site, float m) {
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(&g_act_amax[site], __float_as_uint(m));
+  // the atomic only when this wave would RAISE the word: thousands of waves hitting one address serialise in L2 (the unconditional form cost
+  // config 5 six ms per step); a stale read of the word can only cause a surplus atomic, never a lost maximum
+  if ((threadIdx.x & 63) == 0 && m > __uint_as_float(__builtin_nontemporal_load(&g_act_amax[site])))
+    atomicMax(&g_act_amax[site], __float_as_uint(m));
 }
 // four fp32 -> four e4m3 bytes (little endian: a in bits 0..7)
 __device__ __forceinline__ uint32_t pack_e4m3(float a, float b, float c, float d) {
