@@ -220,6 +220,28 @@ struct Ring {
   __device__ __forceinline__ __bf16* img(int slot, int which) const { return base + (slot * 2 + which) * IMG; }
 };
 
+constexpr int FNW = 8, FNT = FNW * 64;
+// LDS-DMA plan for a group of 64-row images (each [64][hd] rows of a row-major tensor): instruction j of the group fills
+// piece (j % CPR) of image (j / CPR); the FNW waves take j = wave + FNW * i.
+template <int HDP, int NIMG>
+struct GroupDma {
+  static constexpr int CPR = HDP / 8;
+  static constexpr int PER_WAVE = NIMG * CPR / FNW;
+  static_assert((NIMG * CPR) % FNW == 0, "pieces must split over the waves");
+  int off[PER_WAVE];
+  bool valid[PER_WAVE];
+  // ld_of(img) / base offset (elements) of image img are wave-uniform
+  template <class LD> __device__ __forceinline__ void init(LD ld_of, int hd, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int j = wave + FNW * i, img = j / CPR, jj = j % CPR;
+      const int e = jj * 64 + lane, row = e / CPR, p = e % CPR;
+      const int c = p ^ aswz<HDP>(row);
+      valid[i] = c * 8 < hd;
+      off[i] = 2 * (row * ld_of(img) + c * 8);
+    }
+  }
+};
 }  // namespace (kernel templates have external linkage + explicit instantiations below: see gemm.hip)
 
 #ifdef SFRON_DEBUG_KNOBS
@@ -244,9 +266,14 @@ __device__ long long* d_attn_clk = nullptr;
 #endif
 
 // ------------------------------------------------------------------------------------- forward
-template <int HDP, int KS, int NDT, int QT>
-__global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv, __bf16* __restrict__ o,
-                                                 float* __restrict__ lse, int T, int H, int hd, float scale) {
+// NWV = 4: a workgroup = 4 waves = 64 QT query rows.  NWV = 8 (round 4 experiment, sfron_attn_fwd_form(16)): eight waves = 128 QT rows = with
+// QT = 2 the WHOLE head at T = 256, so its K / V chunks are brought in once, not once per query block (per CU the memory-bound start of a round
+// moves 73 KB instead of 110, profiles/r04_attn_phases.txt).  Same products, same order per row: bit-identical -- and slower (one workgroup
+// per CU instead of two, eight waves behind each chunk's barrier): kept as a form the tests compare, not taken by rule.
+template <int HDP, int KS, int NDT, int QT, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void k_attn_fwd(const __bf16* __restrict__ qkv, __bf16* __restrict__ o,
+                                                       float* __restrict__ lse, int T, int H, int hd, float scale) {
+  static_assert(NWV == 4 || NWV == FNW, "four or eight waves");
   extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
   Ring<HDP> ring{smem};
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
@@ -255,23 +282,35 @@ __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv,
   // 1-D grid.  Workgroup ids go round-robin over the 8 XCDs: id -> (id & 7) * (n / 8) + (id >> 3) gives each XCD one contiguous run of
   // (batch, head, query block) triples, so the query blocks of a head (same K / V) and the neighbouring heads of a sample (neighbouring
   // 144-B column slices of the same rows: shared 128-B lines) meet in ONE L2
-  const int nblk = gridDim.x, nqb = T / (64 * QT);
+  const int nblk = gridDim.x, nqb = T / (NWV * 16 * QT);
   const int wid = (nblk & 7) == 0 ? (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   const int bh = wid / nqb, b = bh / H, h = bh % H;
   const int D = H * hd, ld = 3 * D;
-  const int q0 = (wid % nqb) * (64 * QT) + wave * (16 * QT);
+  const int q0 = (wid % nqb) * (NWV * 16 * QT) + wave * (16 * QT);
   const __bf16* base = qkv + (size_t)b * T * ld + h * hd;
   const float c = scale * LOG2E;
   const int nchunk = T / 64;
 
-  ChunkDma<HDP> dma;
-  dma.init(ld, hd, wave, lane);
   const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(base + D), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(base + 2 * D), 0, 0x7fffffff, 0x00020000);
+  ChunkDma<HDP> dma;                  // four waves: each wave fills its share of the K image, then of the V image
+  GroupDma<HDP, 2> dma8;              // eight waves: the pieces of the (K, V) image pair dealt over the waves
+  if constexpr (NWV == 4) dma.init(ld, hd, wave, lane);
+  else dma8.init([&](int) { return ld; }, hd, wave, lane);
+  constexpr int PER_CHUNK = NWV == 4 ? Ring<HDP>::PER_CHUNK : GroupDma<HDP, 2>::PER_WAVE;      // DMA instructions per wave and chunk
   auto issue = [&](int ch) {
     const int slot = ch % NSLOT, soff = ch * 64 * ld * 2;
-    dma.issue(rsK, soff, ring.img(slot, 0), wave);
-    dma.issue(rsV, soff, ring.img(slot, 1), wave);
+    if constexpr (NWV == 4) {
+      dma.issue(rsK, soff, ring.img(slot, 0), wave);
+      dma.issue(rsV, soff, ring.img(slot, 1), wave);
+    } else {
+      constexpr int CPR = HDP / 8;
+#pragma unroll
+      for (int i = 0; i < GroupDma<HDP, 2>::PER_WAVE; ++i) {
+        const int j = wave + FNW * i, img = j / CPR, jj = j % CPR;
+        if (dma8.valid[i]) dma16(img ? rsV : rsK, ring.img(slot, img) + jj * 512, dma8.off[i], soff);
+      }
+    }
   };
   // the Q fragments go out BEFORE the LDS-DMA of the first two K / V chunks: vector-memory operations retire in order, so loads
   // issued behind the DMA would keep the first S = Q K^T waiting for chunk 1 as well
@@ -284,7 +323,7 @@ __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv,
   issue(0);                              // first two chunks stream in while the pads are zeroed
   if (nchunk > 1) issue(1);
   ATTN_STAMP_P(2);
-  zero_pads<HDP, NT, 2>(smem, NSLOT, hd, tid);             // the K images (even ring images); V is read by columns only
+  zero_pads<HDP, NWV * 64, 2>(smem, NSLOT, hd, tid);       // the K images (even ring images); V is read by columns only
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // pad zeros written before the first barrier of the loop
   ATTN_STAMP_P(3);
 
@@ -298,7 +337,7 @@ __global__ __launch_bounds__(NT) void k_attn_fwd(const __bf16* __restrict__ qkv,
   }
 
   for (int kc = 0; kc < nchunk; ++kc) {
-    if (kc + 1 < nchunk) wait_vmcnt<Ring<HDP>::PER_CHUNK>(); else wait_vmcnt<0>();
+    if (kc + 1 < nchunk) wait_vmcnt<PER_CHUNK>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (kc == 0) ATTN_STAMP_P(4);
     if (kc < 5) ATTN_STAMP_L(1 + kc);
@@ -653,7 +692,6 @@ __global__ __launch_bounds__(NT) void k_attn_bwd_dkv(const __bf16* __restrict__ 
 // no delta round trip through HBM (delta = rowsum(dO * O) is computed in the prologue into LDS).
 // No float atomics: dQ of a chunk is summed over all keys inside one wave's accumulators (fixed order).
 namespace {
-constexpr int FNW = 8, FNT = FNW * 64;
 
 // dS^T image [keys][64 queries], 128-B rows of 16 slots x 4 queries; slot ^= pi(key & 15), pi = bit permutation
 // (b2 b1 | b3 b0): 16 consecutive keys x one slot -> 16 distinct slots (ds_write_b64, banks mod 32), and the 8 consecutive
@@ -661,27 +699,6 @@ constexpr int FNW = 8, FNT = FNW * 64;
 __device__ __forceinline__ int ds_pi(int key) { return (((key >> 1) & 3) << 2) | (key & 1) | (((key >> 3) & 1) << 1); }
 __device__ __forceinline__ int ds_off(int key, int slot) { return key * 64 + ((slot ^ ds_pi(key)) << 2); }
 
-// LDS-DMA plan for a group of 64-row images (each [64][hd] rows of a row-major tensor): instruction j of the group fills
-// piece (j % CPR) of image (j / CPR); the FNW waves take j = wave + FNW * i.
-template <int HDP, int NIMG>
-struct GroupDma {
-  static constexpr int CPR = HDP / 8;
-  static constexpr int PER_WAVE = NIMG * CPR / FNW;
-  static_assert((NIMG * CPR) % FNW == 0, "pieces must split over the waves");
-  int off[PER_WAVE];
-  bool valid[PER_WAVE];
-  // ld_of(img) / base offset (elements) of image img are wave-uniform
-  template <class LD> __device__ __forceinline__ void init(LD ld_of, int hd, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) {
-      const int j = wave + FNW * i, img = j / CPR, jj = j % CPR;
-      const int e = jj * 64 + lane, row = e / CPR, p = e % CPR;
-      const int c = p ^ aswz<HDP>(row);
-      valid[i] = c * 8 < hd;
-      off[i] = 2 * (row * ld_of(img) + c * 8);
-    }
-  }
-};
 }  // namespace
 
 // ------------------------------------------------------------------------------------- forward, eight-wave form (round 4)
@@ -1136,6 +1153,7 @@ template __global__ void k_attn_bwd_fused<96, 3, 5, 1>(const __bf16*, const __bf
 #define SFRON_INST_ATTN(HDP, KS, NDT)                                                                              \
   template __global__ void k_attn_fwd<HDP, KS, NDT, 1>(const __bf16*, __bf16*, float*, int, int, int, float);      \
   template __global__ void k_attn_fwd<HDP, KS, NDT, 2>(const __bf16*, __bf16*, float*, int, int, int, float);      \
+  template __global__ void k_attn_fwd<HDP, KS, NDT, 2, 8>(const __bf16*, __bf16*, float*, int, int, int, float);   \
   template __global__ void k_attn_bwd_dq<HDP, KS, NDT, 1>(const __bf16*, const __bf16*, const __bf16*, const float*, float*, __bf16*, int, int, int, float); \
   template __global__ void k_attn_bwd_dq<HDP, KS, NDT, 2>(const __bf16*, const __bf16*, const __bf16*, const float*, float*, __bf16*, int, int, int, float); \
   template __global__ void k_attn_bwd_dkv<HDP, KS, NDT, 1>(const __bf16*, const __bf16*, const float*, const float*, __bf16*, int, int, int, float);
@@ -1279,6 +1297,10 @@ int launch_fwd(const __bf16* qkv, __bf16* o, float* lse, int B, int T, int H, in
   if (T % 128 == 0 && (g_fwd_form == 8 || (g_fwd_form == 0 && T >= 512))) {                 // eight waves of 16 query rows over the same ring: sixteen waves per CU
     int rc = set_lds(&k_attn_fwd8<HDP, KS, NDT>, lds); if (rc) return rc;
     hipLaunchKernelGGL((k_attn_fwd8<HDP, KS, NDT>), dim3(T / 128 * B * H), dim3(512), lds, s, qkv, o, lse, T, H, hd, scale);
+  } else if (T % 256 == 0 && g_fwd_form == 16) {      // eight waves of 32 query rows (a whole head per workgroup at T = 256): measured, not the rule --
+                                                       // 29.9 us against 27.3 alone, +0.2 ms in the step: one workgroup per CU, eight waves per barrier
+    int rc = set_lds(&k_attn_fwd<HDP, KS, NDT, 2, 8>, lds); if (rc) return rc;
+    hipLaunchKernelGGL((k_attn_fwd<HDP, KS, NDT, 2, 8>), dim3(T / 256 * B * H), dim3(512), lds, s, qkv, o, lse, T, H, hd, scale);
   } else if (T % 128 == 0) {
     int rc = set_lds(&k_attn_fwd<HDP, KS, NDT, 2>, lds); if (rc) return rc;
     hipLaunchKernelGGL((k_attn_fwd<HDP, KS, NDT, 2>), dim3(T / 128 * B * H), dim3(NT), lds, s, qkv, o, lse, T, H, hd, scale);
@@ -1358,7 +1380,7 @@ int sfron_dbg_attn_clock(long long* out, int n_wg) {
 
 /* test hook: 2 = force the two-kernel backward (dQ, then dK/dV) for every T; 0 = default (fused where T is 128 or 256) */
 int sfron_attn_bwd_form(int form) { const int old = g_bwd_form; g_bwd_form = form; return old; }
-int sfron_attn_fwd_form(int form) { const int old = g_fwd_form; g_fwd_form = (form == 4 || form == 8) ? form : 0; return old; }
+int sfron_attn_fwd_form(int form) { const int old = g_fwd_form; g_fwd_form = (form == 4 || form == 8 || form == 16) ? form : 0; return old; }
 
 int sfron_attn_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* delta_scratch,
                    uint16_t* dqkv, int B, int T, int H, int hd, void* stream) {
