@@ -943,6 +943,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
     }
   }
 
+  bf16x8 fkr[KT][KS];
   for (int qc = 0; qc < NCH; ++qc) {
     // chunk qc has landed (younger: the next chunk's DMA and the dQ stores of the chunks since -- with the 16-byte pairs a wave issues as few
     // as ONE store per chunk, so only one is counted on; a smaller count only waits for more)
@@ -954,6 +955,14 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
     if (qc + 2 < NCH) issue_chunk(qc + 2);
     const __bf16* iQ = ringb + (qc % NSLOT) * 2 * IMG;
     const __bf16* iO = iQ + IMG;
+    if (qc == 0) {
+      // this wave's K row fragments, once (the K image has landed with chunk 0): re-read per (query tile, key tile) they were 24 load-use
+      // pairs per chunk in front of the S MFMAs (round 4: MFMA results in architectural VGPRs left the registers for them)
+#pragma unroll
+      for (int ki = 0; ki < KT; ++ki)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) fkr[ki][ks] = frag_rows<HDP>(imgK, k0 + 16 * ki, ks, lane);
+    }
     bf16x8 pp[KT][2], sp[KT][2];          // P and dS of this chunk, bf16, in the k-slot order of the transposed fragments
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
@@ -965,13 +974,10 @@ __global__ __launch_bounds__(512) void k_attn_bwd_fused(const __bf16* __restrict
       const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq_[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
       for (int ki = 0; ki < KT; ++ki) {
-        bf16x8 fk[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) fk[ks] = frag_rows<HDP>(imgK, k0 + 16 * ki, ks, lane);
         f32x4 a = {0.f, 0.f, 0.f, 0.f}, p = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqr[ks], fk[ks], a, 0, 0, 0);        // S[q = 4g+j][key = lane&15]
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqr[ks], fkr[ki][ks], a, 0, 0, 0);   // S[q = 4g+j][key = lane&15]
           p = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fdr[ks], fv[ki][ks], p, 0, 0, 0);    // dP
         }
         bf16x4 sv;
