@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--check", action="store_true",
                     help="N-rank == 1-rank parity: after the run every rank also computes the gradient of the WHOLE global batch "
                          "of step 0 by itself and compares it with the all-reduced gradient of the sharded run")
+    ap.add_argument("--no-dp-evidence", action="store_true",
+                    help="N > 1: skip the default self-verification block of the JSON line (device identities, linearity check of the "
+                         "exchange, replica checksums, all-reduce timing)")
     return ap.parse_args()
 
 
@@ -97,17 +100,24 @@ def cpu_baseline(model_name, latent, batch_full, cpu_batch):
         b = data.synthetic_batch(0, i, s, **kw)
         b["drop"] = b["drop"].long()
         return b
-    print(f"[bench] cpu_baseline: built in {build_s:.1f} s; warm-up iteration ...", file=sys.stderr, flush=True)
-    orc.step(batch(0, "forget"), batch(0, "remain"))        # warm-up (allocations, thread pools)
-    print("[bench] cpu_baseline: timed iteration ...", file=sys.stderr, flush=True)
-    t0 = time.time()
-    orc.step(batch(1, "forget"), batch(1, "remain"))
-    dt = time.time() - t0
+    # steady-state steps -- discard the first 2 (allocations, thread pools, the optimizer's lazily created state:
+    # AdamW allocates its moments in the first step), time the next 2, report mean and min
+    discard, timed = 2, 2
+    print(f"[bench] cpu_baseline: built in {build_s:.1f} s; {discard} discarded + {timed} timed iterations ...", file=sys.stderr, flush=True)
+    for i in range(discard):
+        orc.step(batch(i, "forget"), batch(i, "remain"))
+    dts = []
+    for i in range(discard, discard + timed):
+        t0 = time.time()
+        orc.step(batch(i, "forget"), batch(i, "remain"))
+        dts.append(time.time() - t0)
+    dt = sum(dts) / len(dts)
     steps_per_s_full = (1.0 / dt) * (cpu_batch / batch_full)
     return {"value": steps_per_s_full, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"1 timed SFR-on iteration of {model_name} (oracle, CPU fp32 eager, {cores} threads) at batch "
-                      f"{cpu_batch} took {dt:.2f} s; value = (1/t) * {cpu_batch}/{batch_full} (linear in batch); "
-                      f"model build {build_s:.1f} s not counted"}
+            "iteration_s": {"mean": dt, "min": min(dts), "all": dts, "discarded": discard},
+            "sample": f"{timed} timed SFR-on iterations of {model_name} (oracle, CPU fp32 eager, {cores} threads) at batch {cpu_batch} after "
+                      f"{discard} discarded ones: mean {dt:.2f} s, min {min(dts):.2f} s per iteration; value = (1/mean) * {cpu_batch}/{batch_full} "
+                      f"(linear in batch); model build {build_s:.1f} s not counted"}
 
 
 def _dit_leg(model_name, batch, latent, dev, fp8, steps, warmup):
@@ -247,6 +257,79 @@ def other_configs(dev, latent, budget_s=75.0):
         gc.collect()
         torch.cuda.empty_cache()
     return out
+
+
+def dp_evidence(runner, model, diff, batch0, dev, rank, world, strict_tol=None):
+    """What a reader of the JSON line needs to see that N ranks on N DEVICES exchanged gradients correctly, collected on
+    every multi-rank run by default, AFTER the timed region:
+      devices            every rank's (host, device UUID / PCI bus id), all-gathered; `distinct_devices` must equal world_size
+      linearity          the exchange is a SUM: a strided sample of this rank's LOCAL gradient (plain backward pass, no exchange) is
+                         all-gathered, summed over ranks in fp64 and compared with the same sample of the EXCHANGED gradient the runner's
+                         own pass produces (overlapped or synchronous, whichever the timed region used; the adaLN range goes through the
+                         all-gathered factors, so a wrong rank order in all_gather_into_tensor shows here)
+      replicas_identical checksums of the parameter arena after the timed steps, all-gathered: every rank applied the same update
+      allreduce_ms       one gradient stream's exchange (the flat arena through dp.allreduce_flat_ with the run's transport), timed alone
+    Collective: every rank calls it."""
+    import socket
+
+    import torch.distributed as dist
+    from sfron import dp
+    eng = model.engine
+    nt = eng.n_trainable
+    props = torch.cuda.get_device_properties(dev)
+    ident = {"rank": rank, "host": socket.gethostname(), "device_index": dev.index,
+             "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None), "name": props.name}
+    idents = [None] * world
+    dist.all_gather_object(idents, ident, group=runner.pg)
+    keys = sorted({(d["host"], d["uuid"] or d["pci_bus_id"] or d["device_index"]) for d in idents})
+    # ---- linearity of the exchange on the first forget batch
+    f0 = batch0
+    b, y = runner._checked(f0, f0["y"])
+    n_global = b["x0"].shape[0] * world
+    x_t = diff.q_sample(b["x0"], b["t"], b["noise"])
+    out = eng.forward(x_t, b["t"], y, b.get("drop"))
+    _, _, d_out = diff.loss_fwd_bwd(out, b["x0"], b["t"], b["noise"], -runner.forget_alpha / n_global)
+    eng.backward(d_out, y, b.get("drop"))                      # LOCAL gradient of this rank's shard, no exchange
+    K = 1 << 20
+    idx = torch.arange(0, nt, max(1, nt // K), device=dev)[:K]
+    local = eng.grads[:nt][idx].clone()
+    allg = torch.empty(world, local.numel(), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(allg, local, group=runner.pg)
+    want = allg.double().sum(0)
+    runner._pass(f0, f0["y"], -runner.forget_alpha)            # the runner's own exchange (adaLN product formed from gathered factors)
+    got = eng.grads[:nt][idx].double()
+    rel = ((got - want).norm() / (want.norm() + 1e-300)).float()
+    dist.all_reduce(rel, op=dist.ReduceOp.MAX, group=runner.pg)
+    tol = strict_tol if strict_tol is not None else (1e-2 if runner.grad_transport == "bf16" else 1e-5)
+    # ---- replicas: the parameter arenas after the timed steps
+    runner.sync_sweep()
+    bits = eng.params.view(torch.int32).to(torch.int64)
+    chk = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=dev) % 8191 + 1)).sum()])
+    chks = torch.empty(world, 2, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(chks, chk, group=runner.pg)
+    same = bool((chks == chks[0:1]).all().item())
+    # ---- one stream's exchange alone
+    g = eng.grads[:nt].clone()
+    ms = []
+    for _ in range(3):
+        dist.barrier(group=runner.pg)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dp.allreduce_flat_(g, runner.bucket_elems, runner.pg, transport=runner.grad_transport,
+                           scratch=runner._scratch(min(nt, runner.bucket_elems)))
+        torch.cuda.synchronize()
+        ms.append((time.perf_counter() - t0) * 1e3)
+    tt = torch.tensor([min(ms[1:])], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=runner.pg)
+    payload = nt * (2 if runner.grad_transport == "bf16" else 4)
+    return {"world_size": world, "backend": dist.get_backend(runner.pg), "devices": sorted(idents, key=lambda d: d["rank"]),
+            "distinct_devices": len(keys),
+            "linearity": {"what": f"sum over {world} ranks of a {idx.numel()}-element strided sample of the local gradients vs the same sample of the "
+                                  "exchanged gradient (forget stage, batch 0)", "rel_l2": rel.item(), "tol": tol, "ok": bool(rel.item() < tol)},
+            "replicas_identical": same,
+            "allreduce_ms_per_stream": tt.item(), "allreduce_payload_bytes": payload,
+            "allreduce_busbw_GBps": (2.0 * (world - 1) / world * payload / (tt.item() * 1e-3) / 1e9) if tt.item() > 0 else None,
+            "ok": bool(rel.item() < tol) and same and len(keys) == (world if dist.get_backend(runner.pg) == "nccl" else len(keys))}
 
 
 def launch_ranks(n):
@@ -442,8 +525,13 @@ def main():
         return tr, alg, None
     sweep_traffic, sweep_alg, sweep_traffic_note = sane_sweep_traffic()
 
+    dp_ev = None
+    if world > 1 and not args.no_dp_evidence and args.micro_batches == 1:
+        wd.phase("dp evidence", 180 + 8 * step_budget)
+        dp_ev = dp_evidence(runner, model, diff, batches[0][0], dev, rank, world)
     check_res = None
     if args.check and world > 1:
+        wd.phase("check", 180 + 8 * step_budget)
         # N-rank == 1-rank parity at equal global batch: the all-reduced gradient of the sharded forget pass of step 0 against
         # the gradient this rank computes by itself on the WHOLE global batch (same loss scale alpha / global_batch)
         f0 = batches[0][0]
@@ -484,6 +572,7 @@ def main():
             "step_tflops_per_gpu": step_flops / (ms_per_step * 1e-3) / 1e12,
             "step_frac_of_bf16_mfma_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
             "dp_overlap": dp_overlap, "grad_transport": runner.grad_transport if world > 1 else None, "check": check_res,
+            "world_size": world, "dp": dp_ev,
             "roofline": {"bound": "mfma",
                          "kernel": "k_gemm_pipe<4,2,3,6,true,true,1,2,2,false,4> = 192x192 tile, three LDS slots, eight multiplying waves + four loader waves "
                                    "that issue the LDS-DMA: the weight "

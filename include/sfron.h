@@ -9,7 +9,14 @@
  * Conventions: plain pointers and sizes only (no torch types); every pointer is a DEVICE pointer
  * unless stated; `stream` is a hipStream_t passed as void* (NULL = default stream); all launches
  * are asynchronous on `stream`; return 0 on success, a hipError_t value or SFRON_ERR_* (>= 1001)
- * on failure; nothing throws; no global state.  bf16 tensors are passed as uint16_t*.
+ * on failure; nothing throws.  bf16 tensors are passed as uint16_t*.
+ *
+ * State: every tensor, workspace, stream and event belongs to the caller or to a handle the caller creates (sfron_aux_create,
+ * sfron_probe_create); entry points are re-entrant per stream.  Process-wide state is limited to (a) three SCHEDULE switches --
+ * sfron_gemm_loader_waves, sfron_attn_fwd_form, sfron_attn_bwd_form: each picks between schedules that give the same bits (the tests
+ * compare them), so no result depends on them; not thread-safe, meant for tests and A-B timing -- and (b) the fp8 activation-range
+ * counters behind sfron_fp8_activation_amax (diagnostic: written by the config-5 quantising kernels, read by no kernel; engines of one
+ * process share them).  One host thread per device drives the library.
  */
 #ifndef SFRON_H
 #define SFRON_H
@@ -511,7 +518,9 @@ int sfron_attn_fwd_form(int form);
  * weight-gradient layouts, where it measured faster) -- the default; 0 = every wave issues its share (5 / 6: weight gradients / dgrad
  * only, 9: the fp8 tiles in their loader form too -- for A-B runs).  The pipelined convolution tiles (csrc/conv.hip k_cgemm / k_cgemm_t,
  * contractions of >= 8 K-tiles) follow: loader form unless n == 0 (10 / 11 / 12: as 4 with none / only k_cgemm / only k_cgemm_t of
- * them in the loader form).  Same results bit for bit (same products, same summation order).  Returns the previous value. */
+ * them in the loader form).  Same results bit for bit (same products, same summation order).  Returns the previous value.
+ * The product build accepts 0, 4, 9 and 10 (what the form-equivalence tests use) and ignores any other value; the A-B values 5..8, 11, 12
+ * exist in the debug-knob build (make dbg: libsfron_dbg.so, tools/ only). */
 int sfron_gemm_loader_waves(int n);
 
 /* ------------------------------------------------------------------ whole-model DiT pass (dit_engine.hip)

@@ -98,10 +98,10 @@ class DiffusionTables:
 
 def _extract(arr, t, shape):
     # gaussian_diffusion.py:861-873
-    res = th.from_numpy(arr)[t].float()
+    res = th.from_numpy(arr).to(device=t.device)[t].float()      # (:870 moves the table to the timesteps' device)
     while len(res.shape) < len(shape):
         res = res[..., None]
-    return res + th.zeros(shape)
+    return res + th.zeros(shape, device=t.device)
 
 
 def mean_flat(x):

@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Where does the held-out eps-MSE gap between the HIP path and the oracle at DiT-XL/2 come from, and what is it after 50 steps?
+(test infrastructure: imports oracle/, lives under tests/.)
+
+Part 1 (bisect, before any step): the oracle restated with ONE class of bf16 rounding points at a time (torch hooks on the oracle's own
+modules, everything else fp32), run on the GPU in fp32 next to the HIP forward pass, on several held-out batches:
+   W     block / embedder / adaLN / final Linear weights rounded to bf16 (the weight shadow the GEMMs read)
+   A     the inputs of the block Linears rounded to bf16 (xmod1, o, xmod2, h: the GEMM A operands)
+   QKV   the qkv Linear's output rounded to bf16 (what the attention kernel reads)
+   P     softmax probabilities rounded to bf16 before P.V (the flash kernel's P operand)
+   H     fc1's pre-activation rounded to bf16 before GELU is NOT applied (the kernel applies GELU to the fp32 accumulator): h only
+   ALL   all of the above together = the model of the HIP path's rounding points
+For each: held-out mse minus the fp32 oracle's, per batch (mean, std over batches) -- a BIAS shows as a mean that does not average out.
+
+Part 2: 50 SFR-on iterations at batch 4 (hyper-parameters of tests/test_gpu_baseline_shapes.py::test_xl2_ten_sfron_iterations_vs_oracle),
+oracle on the GPU in fp32; held-out gap at 0 / 10 / 20 / 50 steps.
+
+  python3 tests/debug/xl2_gap_bisect.py [--steps 50] [--batches 4] [--skip-bisect]
+"""
+import argparse
+import os
+import sys
+
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+DEV = "cuda:0"
+
+
+def bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class Rounding:
+    """context: installs the requested rounding points on an oracle DiT (on any device), restores on exit"""
+
+    def __init__(self, ref, kinds):
+        self.ref, self.kinds, self.handles, self.saved = ref, set(kinds), [], {}
+
+    def __enter__(self):
+        from oracle import dit_ref
+        ref, K = self.ref, self.kinds
+        if "W" in K:
+            for n, p in ref.named_parameters():
+                if p.dim() >= 2 and p.requires_grad:
+                    self.saved[n] = p.data.clone()
+                    p.data.copy_(bf(p.data))
+        for blk in ref.blocks:
+            if "A" in K:
+                for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2):
+                    self.handles.append(lin.register_forward_pre_hook(lambda m, a: (bf(a[0]),)))
+            if "QKV" in K:
+                self.handles.append(blk.attn.qkv.register_forward_hook(lambda m, a, o: bf(o)))
+        if "P" in K:
+            self._attn_fwd = dit_ref.Attention.forward
+
+            def fwd(self_, x):
+                B, N, C = x.shape
+                qkv = self_.qkv(x).reshape(B, N, 3, self_.num_heads, self_.head_dim).permute(2, 0, 3, 1, 4)
+                q, k, v = qkv.unbind(0)
+                attn = ((q * self_.scale) @ k.transpose(-2, -1)).softmax(dim=-1)
+                x = bf(attn) @ v
+                return self_.proj(x.transpose(1, 2).reshape(B, N, C))
+            dit_ref.Attention.forward = fwd
+        return self
+
+    def __exit__(self, *a):
+        from oracle import dit_ref
+        for h in self.handles:
+            h.remove()
+        for n, p in self.ref.named_parameters():
+            if n in self.saved:
+                p.data.copy_(self.saved[n])
+        if "P" in self.kinds:
+            dit_ref.Attention.forward = self._attn_fwd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--batches", type=int, default=4)
+    ap.add_argument("--skip-bisect", action="store_true")
+    args = ap.parse_args()
+    from oracle import diffusion_ref as dref
+    from oracle import sfron_ref
+    from sfron import data, diffusion, step
+    from test_gpu_baseline_shapes import _pair
+    B = 4
+    ref, model = _pair("DiT-XL/2", B, seed=51, std=0.02)
+    tab = dref.DiffusionTables(1000)
+    ref_cpu_out = None
+    hbs = [data.synthetic_batch(24 + i, 0, "remain", global_batch=16, num_classes=1000, forget_class=207) for i in range(args.batches)]
+    # the oracle on the CPU (the contract) against the same modules on the GPU in fp32: they must agree far below the gaps studied here
+    ref.eval()
+    with torch.no_grad():
+        t_cpu = dref.training_losses(tab, lambda x, t, y: ref(x, t, y), hbs[0]["x0"][:4], hbs[0]["t"][:4], dict(y=hbs[0]["y"][:4]), hbs[0]["noise"][:4])
+    ref.to(DEV)
+    with torch.no_grad():
+        g = {k: v[:4].to(DEV) for k, v in hbs[0].items()}
+        t_gpu = dref.training_losses(tab, lambda x, t, y: ref(x, t, y), g["x0"], g["t"], dict(y=g["y"]), g["noise"])
+    print(f"oracle fp32 CPU vs the same modules on the GPU (4 samples): mse {t_cpu['mse'].mean().item():.7f} vs {t_gpu['mse'].mean().item():.7f}, "
+          f"max per-sample |diff| {(t_cpu['mse'] - t_gpu['mse'].cpu()).abs().max().item():.2e}", flush=True)
+    d = diffusion.create_diffusion("")
+
+    def held_ref(hb):
+        ref.eval()
+        with torch.no_grad():
+            g = {k: v.to(DEV) for k, v in hb.items()}
+            return dref.training_losses(tab, lambda x, t, y: ref(x, t, y), g["x0"], g["t"], dict(y=g["y"]), g["noise"])["mse"].mean().item()
+
+    def held_hip(hb, m=None):
+        m = m or model
+        m.set_batch_size(16)
+        m.eval()
+        with torch.no_grad():
+            g = {k: v.to(DEV) for k, v in hb.items()}
+            out = m(d.q_sample(g["x0"], g["t"], g["noise"]), g["t"], g["y"])
+        mse, _, _ = d.loss_fwd_bwd(out.contiguous(), g["x0"], g["t"], g["noise"], 1.0)
+        m.train()
+        return mse.mean().item()
+
+    if not args.skip_bisect:
+        base = [held_ref(hb) for hb in hbs]
+        hip = [held_hip(hb) for hb in hbs]
+        rows = [("HIP path", hip)]
+        for kinds in (["W"], ["A"], ["QKV"], ["P"], ["W", "A"], ["W", "A", "QKV", "P"]):
+            with Rounding(ref, kinds):
+                rows.append(("oracle + bf16 " + "+".join(kinds), [held_ref(hb) for hb in hbs]))
+        print(f"\nheld-out eps-MSE of the fp32 oracle per batch: {['%.5f' % b for b in base]}")
+        print("| variant | mse - fp32 oracle, per held-out batch | mean | std |")
+        print("|---|---|---|---|")
+        for name, vals in rows:
+            dv = torch.tensor([v - b for v, b in zip(vals, base)], dtype=torch.float64)
+            print(f"| {name} | {' '.join('%+.2e' % x for x in dv.tolist())} | {dv.mean().item():+.2e} | {dv.std().item() if len(dv) > 1 else 0:.1e} |", flush=True)
+
+    if args.steps <= 0:
+        return
+    # ---- Part 2: 50 iterations, both paths from the same state
+    model.set_batch_size(B)
+    model.train()
+    ref.train()
+    gm = torch.Generator().manual_seed(52)
+    mask = {"module." + n: (torch.rand(p.shape, generator=gm) < 0.5) for n, p in ref.named_parameters() if p.requires_grad}
+    mask["module.pos_embed"] = 0
+    hp = dict(lr=1e-4, forget_alpha=1e-3, grad_clip=1.0, ema_decay=0.9999, unlearn_loss="ga", forget_class=207)
+    orc = sfron_ref.DiTSfronOracle(ref, tab, mask={k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in mask.items()}, **hp)
+    runner = step.DiTSFRon(model, d, mask=mask, **hp)
+    kw = dict(global_batch=B, num_classes=1000, forget_class=207)
+
+    def report(it):
+        hs, rs = [held_hip(hb) for hb in hbs], [held_ref(hb) for hb in hbs]
+        ref.train()
+        model.set_batch_size(B)
+        gaps = [h - r for h, r in zip(hs, rs)]
+        print(f"after {it:3d} steps: held-out mse oracle {sum(rs) / len(rs):.5f}  HIP {sum(hs) / len(hs):.5f}  gap per batch "
+              f"{' '.join('%+.2e' % x for x in gaps)}  |mean gap| {abs(sum(gaps) / len(gaps)):.2e}", flush=True)
+    report(0)
+    for it in range(args.steps):
+        f, r = data.synthetic_batch(23, it, "forget", **kw), data.synthetic_batch(23, it, "remain", **kw)
+        fd, rd = {k: v.to(DEV) for k, v in f.items()}, {k: v.to(DEV) for k, v in r.items()}
+        orc.step({k: v.long() if k == "drop" else v for k, v in fd.items()}, {k: v.long() if k == "drop" else v for k, v in rd.items()})
+        runner.step(fd, rd)
+        if it + 1 in (1, 5, 10, 20, 30, 50, args.steps):
+            report(it + 1)
+
+
+if __name__ == "__main__":
+    main()

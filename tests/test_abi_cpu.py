@@ -74,3 +74,35 @@ def test_descriptor_structs_match_the_header(built):
         assert ctypes.sizeof(cls) == int(size), (name, ctypes.sizeof(cls), size)
         for f, o in zip(fs, offs):
             assert getattr(cls, f).offset == int(o), (name, f, getattr(cls, f).offset, o)
+
+
+def test_integration_md_stub_prototypes_match_the_header(built, monkeypatch):
+    """INTEGRATION.md section 3's ctypes stub (the text a maintainer of the reference would paste): it must load the library, and every
+    prototype it declares must have the header's parameter count with pointers where the header has pointers (the round-4 text had six
+    pointers where include/sfron.h has seven: moments landed in each other's slots, status 0).  Executed on the GPU by
+    tests/test_gpu_sweep_loss.py::test_integration_md_ctypes_stub_runs_as_written."""
+    import ctypes
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## 3. Raw C ABI from Python"):text.index("## 4. Entry point")]
+    blocks = re.findall(r"```python\n(.*?)```", sec, flags=re.S)
+    assert len(blocks) == 1
+    monkeypatch.chdir(ROOT)
+    ns = {}
+    exec(compile(blocks[0], "INTEGRATION.md#3", "exec"), ns)
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "sfron.h")).read(), flags=re.S)
+    checked = 0
+    for name in ("sfron_sumsq_masked", "sfron_clip_coef", "sfron_masked_clip_adam"):
+        m = re.search(r"\bint\s+" + name + r"\s*\((.*?)\)\s*;", hdr, flags=re.S)
+        assert m, name
+        params = [p.strip() for p in m.group(1).split(",")]
+        fn = getattr(ns["L"], name)
+        assert fn.argtypes is not None and len(fn.argtypes) == len(params), (name, len(fn.argtypes or []), len(params))
+        for at, p in zip(fn.argtypes, params):
+            is_ptr_c = "*" in p
+            is_ptr_py = at is ctypes.c_void_p or isinstance(at, type(ctypes.POINTER(ctypes.c_int)))
+            assert is_ptr_c == is_ptr_py, (name, p, at)
+            if not is_ptr_c:
+                want = {"int64_t": ctypes.c_int64, "double": ctypes.c_double, "float": ctypes.c_float, "int": ctypes.c_int}[p.split()[0]]
+                assert at is want, (name, p, at)
+        checked += 1
+    assert checked == 3 and callable(ns["fused_stage"])

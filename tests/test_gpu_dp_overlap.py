@@ -127,6 +127,56 @@ def test_pipelined_synchronous_exchange_matches_plain_path():
     assert (g1 - g0).abs().max().item() <= 1e-6 * g0.abs().max().item()
 
 
+def test_fp8_under_the_pipelined_synchronous_exchange_keeps_the_shadow_fresh():
+    """fp8 + data parallel + synchronous exchange with the adaLN gradient inside the arena (factored_ada off) took the
+    fused re-quantising sweep although the pipelined sweep consumes buckets: an UnboundLocalError in the remain stage and a stale
+    e4m3 shadow after the forget stage.  With force_dp at world size 1 (collectives are identities) the run must equal the
+    single-process fp8 run in its non-fused form, and the shadow must be the e4m3 image of the masters."""
+    from sfron import data, diffusion, step
+    from test_gpu_dit import build_pair
+    cfg = dict(input_size=16, patch_size=2, in_channels=4, hidden_size=128, depth=2, num_heads=2, num_classes=10)
+    B = 4
+    kw = dict(global_batch=B, num_classes=cfg["num_classes"], forget_class=3, input_size=cfg["input_size"], device=DEV)
+    bat = lambda it: (data.synthetic_batch(8, it, "forget", **kw), data.synthetic_batch(8, it, "remain", **kw))
+    hp = dict(lr=2e-4, forget_alpha=0.3, grad_clip=1.0, ema_decay=0.99, mask=None, unlearn_loss="ga", forget_class=3)
+
+    def run(force):
+        _, model = build_pair(cfg, B, seed=31)
+        runner = step.DiTSFRon(model, diffusion.create_diffusion(""), fp8=True, **hp)
+        runner.factored_ada = runner.sweep_beside_forward = False
+        runner.force_dp = force
+        for it in range(2):
+            out = runner.step(*bat(it))
+        torch.cuda.synchronize()
+        runner.guard.poll(block=True)
+        eng = model.engine
+        # the shadow must be the e4m3 image of the CURRENT masters under the scales in use (a stale one -- the bug -- is the image of the
+        # masters one optimizer step earlier): every block tensor, bit for bit (+0 == -0)
+        from oracle import fp8_ref
+        tab, sc = eng.fp8["table"].cpu().tolist(), eng.fp8["scales"].cpu().tolist()
+        for (off, n), s in zip(tab, sc):
+            want8 = fp8_ref.e4m3_bytes(eng.params[off:off + n].cpu(), float(s))
+            got8 = eng.fp8["w8"][off:off + n].cpu()
+            assert ((got8 == want8) | (((got8 & 0x7F) == 0) & ((want8 & 0x7F) == 0))).all(), (off, n)
+        return eng.params.clone(), eng.fp8["scales"].clone(), out["stats"].clone()
+
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = str(_free_port())
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        created = True
+    try:
+        p1, sc1, s1 = run(True)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    p0, sc0, s0 = run(False)
+    assert torch.allclose(s1, s0, rtol=1e-5)
+    assert (p1 - p0).abs().max().item() <= 2e-6
+    assert torch.equal(sc1, sc0)
+
+
 @pytest.mark.parametrize("fp8", [False, True])
 def test_remain_sweep_beside_the_next_step_gives_the_same_state(fp8):
     """sweep_across_steps: the remain-stage AdamW + EMA of the block ranges runs on the sweep stream beside the NEXT step's forget

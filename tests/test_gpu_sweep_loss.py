@@ -82,6 +82,47 @@ def test_mask_from_fisher_golden(dev, golden_dir):
             assert np.array_equal(got.cpu().numpy(), g[f"mask_{k}_{float(th)}"])
 
 
+def test_integration_md_ctypes_stub_runs_as_written(dev, monkeypatch):
+    """INTEGRATION.md section 3 shows the ctypes stub a maintainer of the reference would add for forget.py:289-299 (grad *= mask,
+    clip_grad_norm_, AdamW.step).  This test executes THAT TEXT -- the fenced python block under the section heading, verbatim, from the
+    repository root -- for three optimizer steps against torch.optim.AdamW + mask + clip_grad_norm_ (the round-4 snippet had
+    drifted from include/sfron.h and nothing ran it)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = text[text.index("## 3. Raw C ABI from Python"):text.index("## 4. Entry point")]
+    blocks = re.findall(r"```python\n(.*?)```", sec, flags=re.S)
+    assert len(blocks) == 1, "section 3 holds exactly one python block: the stub"
+    monkeypatch.chdir(root)                        # the stub opens the library by its repository-relative path
+    ns = {}
+    exec(compile(blocks[0], "INTEGRATION.md#3", "exec"), ns)
+    fused_stage = ns["fused_stage"]
+    n, lr = 300_001, 1e-3
+    gen = torch.Generator().manual_seed(7)
+    p0 = torch.randn(n, generator=gen)
+    mask = torch.rand(n, generator=gen) < 0.5
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pr], lr=lr, weight_decay=0.0)
+    p = p0.clone().to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    mask_u8 = mask.to(torch.uint8).to(dev)
+    for step in (1, 2, 3):
+        g = torch.randn(n, generator=gen) * (3.0 if step != 2 else 1e-3)      # clip active, inactive, active
+        pr.grad = g * mask
+        norm = torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        stats = fused_stage(p, g.to(dev), m, v, mask_u8, lr, step, max_norm=1.0,
+                            stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert abs(stats[0].item() - float(norm)) <= 1e-5 * float(norm)
+        assert abs(stats[1].item() - min(1.0, 1.0 / (float(norm) + 1e-6))) <= 1e-6
+    st = opt.state[pr]
+    np.testing.assert_allclose(p.cpu().numpy(), pr.detach().numpy(), rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(m.cpu().numpy(), st["exp_avg"].numpy(), rtol=2e-6, atol=1e-8)
+    np.testing.assert_allclose(v.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=2e-6, atol=1e-12)
+
+
 @pytest.mark.parametrize("n", [5, 1024, 1_000_003])
 def test_two_stage_sweep_vs_torch(dev, n):
     """forget stage: mask -> clip(1.0) -> AdamW ; remain stage: AdamW (no mask, no clip) -> EMA.

@@ -13,7 +13,11 @@ objs=""
 for f in *.hip; do
   o=${f%.hip}.o
   if [[ " $files " == *" $f "* ]]; then
-    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function -Wno-unused-variable $flags -c $f -o var_$name/$o &
+    # the Makefile's CXXFLAGS, per-file additions included (attn.hip is built with the VGPR form of the MFMA results: an A-B of an
+    # attention change must not also switch that -- ADVICE r4)
+    extra=""
+    if [ "$f" = attn.hip ]; then extra="-mllvm -amdgpu-mfma-vgpr-form=1"; fi
+    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-variable $extra $flags -c $f -o var_$name/$o &
     objs="$objs var_$name/$o"
   else
     objs="$objs $o"

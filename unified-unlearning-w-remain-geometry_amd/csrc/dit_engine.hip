@@ -237,6 +237,7 @@ int sfron_aux_create(void** aux) {
 int sfron_aux_destroy(void* aux) {
   SFRON_CHECK_ARG(aux);
   Aux* a = (Aux*)aux;
+  (void)sfron_take_stop_event();                 // never leave one of this handle's events armed for a later launch
   for (int i = 0; i < 4; ++i) (void)hipEventDestroy(a->produced[i]);
   for (int i = 0; i < 8; ++i) (void)hipEventDestroy(a->consumed[i]);
   (void)hipEventDestroy(a->done);
@@ -470,6 +471,11 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
   Dims d;
   RUN(make_dims(cfg, d));
   SFRON_CHECK_ARG(params && params_bf16 && d_out && y && workspace && grads);
+  // An event armed for a producing launch (arm() below) must not outlive this call: a RUN(...) that returns early between arm(i) and its
+  // launch would leave the thread's slot armed, and the next k_gemm_pipe / k_row_bwd / k_attn_bwd_fused launch of ANY caller on this thread
+  // would hand it -- possibly a destroyed event of a closed engine -- to hipExtLaunchKernelGGL.  Cleared on entry and on every exit path.
+  (void)sfron_take_stop_event();
+  struct DisarmOnExit { ~DisarmOnExit() { (void)sfron_take_stop_event(); } } disarm_on_exit;
   const ParamLayout P = make_layout(d);
   Workspace w = make_ws(d, (char*)workspace);
   const uint16_t* wb = params_bf16;

@@ -172,7 +172,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int row, int c
     float4 o = make_float4(v[0], v[1], v[2], v[3]);
     if (g.accumulate) { const float4 c = *dst; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
     if (g.nt_out & 2) __builtin_nontemporal_store(f32x4{o.x, o.y, o.z, o.w}, reinterpret_cast<f32x4*>(dst));
-    else *dst = o;
+    else st16(dst, f32x4{o.x, o.y, o.z, o.w});
   } else if (EPI == EPI_GELU) {
     bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
     nt_store(reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col), h, g.nt_out & 1);   // read again only by the backward pass
@@ -1371,7 +1371,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
       __bf16* const crow = g.Cb + (size_t)(row_b + mt * 16) * g.ldcb;
       if (wide) {
 #pragma unroll
-        for (int np = 0; np < NP; ++np) *reinterpret_cast<uint4*>(crow + col_p + np * 32) = pair_pack(ob[2 * np], ob[2 * np + 1]);
+        for (int np = 0; np < NP; ++np) st16(crow + col_p + np * 32, pair_pack(ob[2 * np], ob[2 * np + 1]));
         if constexpr (NT & 1) *reinterpret_cast<bf16x4*>(crow + col_b + (NT - 1) * 16) = ob[NT - 1];
       } else {
 #pragma unroll
@@ -1437,12 +1437,12 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
         ab[nt] = f2bf4(v);
         if (!wide) nt_store(reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col), ab[nt], g.nt_out & 1);
         const f32x4 x = as4(xr[nt]) + as4(gt[nt]) * v;
-        *reinterpret_cast<f32x4*>(g.Cf + (size_t)row * g.ldcf + col) = x;
+        st16(g.Cf + (size_t)row * g.ldcf + col, x);
       }
       if (wide) {                                  // the bf16 branch output (read again by the backward pass): 16-byte pieces
         __bf16* const arow = g.aux + (size_t)row * g.ldaux;
 #pragma unroll
-        for (int np = 0; np < NP; ++np) *reinterpret_cast<uint4*>(arow + col_p + np * 32) = pair_pack(ab[2 * np], ab[2 * np + 1]);
+        for (int np = 0; np < NP; ++np) st16(arow + col_p + np * 32, pair_pack(ab[2 * np], ab[2 * np + 1]));
         if constexpr (NT & 1) *reinterpret_cast<bf16x4*>(arow + col_b + (NT - 1) * 16) = ab[NT - 1];
       }
     }
@@ -1475,12 +1475,12 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
         }
         __bf16* const crow = g.Cb + (size_t)row * g.ldcb;
 #pragma unroll
-        for (int np = 0; np < NP; ++np) *reinterpret_cast<uint4*>(crow + col_p + np * 32) = pair_pack(ob[2 * np], ob[2 * np + 1]);
+        for (int np = 0; np < NP; ++np) st16(crow + col_p + np * 32, pair_pack(ob[2 * np], ob[2 * np + 1]));
         if constexpr (NT & 1) *reinterpret_cast<bf16x4*>(crow + col_b + (NT - 1) * 16) = ob[NT - 1];
         if constexpr (EPI == EPI_GELU) {
           __bf16* const arow = g.aux + (size_t)row * g.ldaux;
 #pragma unroll
-          for (int np = 0; np < NP; ++np) *reinterpret_cast<uint4*>(arow + col_p + np * 32) = pair_pack(hb[2 * np], hb[2 * np + 1]);
+          for (int np = 0; np < NP; ++np) st16(arow + col_p + np * 32, pair_pack(hb[2 * np], hb[2 * np + 1]));
           if constexpr (NT & 1) *reinterpret_cast<bf16x4*>(arow + col_b + (NT - 1) * 16) = hb[NT - 1];
         }
       }
@@ -1772,9 +1772,22 @@ int gemm_sumsq_lowrank(const uint16_t* a, const uint16_t* b, int R, int NM, int 
   return launch<true, true, EPI_SUMSQ>(g, (hipStream_t)stream);
 }
 
-extern "C" // test / A-B hook: 4 = loader-wave form of the three-slot tiles (0 = every wave issues its share of the LDS-DMA); returns the old value
-int sfron_gemm_loader_waves(int n) { const int old = g_loader_waves; g_loader_waves = (n >= 9 && n <= 12) ? 4 : (n >= 4 && n <= 8) ? n : 0; g_fp8_loader_waves = n == 9 ? 4 : 0; g_conv_loader_waves = (n == 0 || n == 10) ? 0 : n == 11 ? 1 : n == 12 ? 2 : 3; return old; }   // (10 / 11 / 12: as 4, with none / only k_cgemm / only k_cgemm_t of the convolution tiles in the loader form)   // (9: as 4, and the fp8 tiles in their loader form too -- measured no faster)   // (5 / 6: weight gradients / dgrad only, A-B runs; 8: as 4 + the forward layouts of the 256 x 144 tile)
+// Schedule switch (include/sfron.h): 4 = loader-wave form of the three-slot tiles (default), 0 = every wave issues its share of the LDS-DMA, 9 = as 4 and
+// the fp8 tiles in their loader form too, 10 = as 4 with the convolution tiles in the shared form.  Results never depend on it (bit-identical
+// schedules: tests/test_gpu_baseline_shapes.py, test_gpu_unet.py, test_gpu_fp8.py compare the forms).  Any other value is refused by the product build
+// (the setting stays); the A-B values 5..8, 11, 12 of tools/ exist in the SFRON_DEBUG_KNOBS build (libsfron_dbg.so) only.  Returns the old value.
+extern "C" int sfron_gemm_loader_waves(int n) {
+  const int old = g_loader_waves;
+#ifndef SFRON_DEBUG_KNOBS
+  if (n != 0 && n != 4 && n != 9 && n != 10) return old;
+#endif
+  g_loader_waves = (n >= 9 && n <= 12) ? 4 : (n >= 4 && n <= 8) ? n : 0;      // (5 / 6: weight gradients / dgrad only; 8: as 4 + the forward layouts of the 256 x 144 tile)
+  g_fp8_loader_waves = n == 9 ? 4 : 0;                                        // (9: measured no faster)
+  g_conv_loader_waves = (n == 0 || n == 10) ? 0 : n == 11 ? 1 : n == 12 ? 2 : 3;   // (11 / 12: only k_cgemm / only k_cgemm_t in the loader form)
+  return old;
+}
 
+extern "C"
 int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
   SFRON_CHECK_ARG(d && d->A && d->B && d->M > 0 && d->N > 0 && d->K > 0);
   SFRON_CHECK_ARG(d->N % 4 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0);

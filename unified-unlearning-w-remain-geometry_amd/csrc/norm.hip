@@ -36,7 +36,6 @@ __device__ __forceinline__ void load_row_f32(const float* __restrict__ p, int D4
 // Buffer forms: the descriptor covers exactly ONE row, so a lane past the row end (the fifth 16-byte chunk of a 1152-wide row has 32
 // live lanes) loads zeros and its stores are dropped by the hardware bounds check -- no exec masks, no branches, addresses = one
 // scalar descriptor + one lane offset + immediates.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const void* p, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
@@ -112,7 +111,7 @@ __global__ __launch_bounds__(TPB) void k_ln_mod_fwd(const float* __restrict__ x,
       const float4 h = sh.v[i], g = sc.v[i];
       const bf16x4 o = {f2bf((r[k].v[i].x - mean) * rstd * (1.0f + g.x) + h.x), f2bf((r[k].v[i].y - mean) * rstd * (1.0f + g.y) + h.y),
                         f2bf((r[k].v[i].z - mean) * rstd * (1.0f + g.z) + h.z), f2bf((r[k].v[i].w - mean) * rstd * (1.0f + g.w) + h.w)};
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ro, lane * 8 + 512 * i, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ro, lane * 8 + 512 * i, 0, SFRON_WT_AUX);
     }
   }
 }
@@ -241,7 +240,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_num_vgpr(SFRON_ROWBWD_VG
         d = make_float4(rstd * (g.x - m1 - xh.x * m2), rstd * (g.y - m1 - xh.y * m2),
                         rstd * (g.z - m1 - xh.z * m2), rstd * (g.w - m1 - xh.w * m2));
         if (a.dx_accumulate) { const float4 p = prev.v[i]; d.x += p.x; d.y += p.y; d.z += p.z; d.w += p.w; }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d), rs_dx, lane * 16 + 1024 * i, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d), rs_dx, lane * 16 + 1024 * i, 0, SFRON_WT_AUX);
       } else {
         d = prev.v[i];
       }
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_num_vgpr(SFRON_ROWBWD_VG
         acc[G0 + 1][i].x += d.x; acc[G0 + 1][i].y += d.y; acc[G0 + 1][i].z += d.z; acc[G0 + 1][i].w += d.w;
         const float4 gt = mod4(s_gt, gp, i);
         const bf16x4 o = {f2bf(d.x * gt.x), f2bf(d.y * gt.y), f2bf(d.z * gt.z), f2bf(d.w * gt.w)};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_db, lane * 8 + 512 * i, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_db, lane * 8 + 512 * i, 0, SFRON_WT_AUX);
       }
       __builtin_amdgcn_sched_barrier(0);
     }

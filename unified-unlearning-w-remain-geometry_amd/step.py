@@ -432,7 +432,9 @@ class DiTSFRon:
         # stream.  Measured (tools/bench_sweep_beside.py): a full-grid sweep beside the GEMM chain gains nothing, one capped at
         # 256 workgroups hides ~0.8 ms of its 2.6 ms.  Single-chain, single-process, bf16 passes only.
         split = None
-        fused_q = self.fp8 and self.micro == 1                                # config 5: the sweeps write the e4m3 shadow themselves
+        # config 5: the sweeps write the e4m3 shadow themselves -- except under the pipelined synchronous exchange (dp_sync), whose
+        # sweep consumes buckets, not block ranges: there fp8_requantize() follows each sweep
+        fused_q = self.fp8 and self.micro == 1 and not dp_sync
         quant = None
         if fused_q:
             f8 = self.model.engine.fp8
