@@ -43,6 +43,11 @@ int sfron_sweep_partials_len(void);
 int sfron_sumsq_masked(const float* g, const float* g2, const uint8_t* mask, int64_t n, double* partials, int* nblk_out,
                        void* stream);
 
+/* the same partial sums over a table of element ranges: ranges (DEVICE) int64 [n_ranges][2] = {offset, length} into g / mask (multiples of 4;
+ * a range is summed by ONE workgroup: split tensors above ~64 K elements); partials[r] = sum over range r of (mask ? g : 0)^2.  What the clip
+ * norm still reads when the weight-gradient GEMMs leave their own sums (sfron_gemm_desc.sumsq_partials, sfron_aux_arm_sumsq). */
+int sfron_sumsq_masked_ranges(const float* g, const uint8_t* mask, const int64_t* ranges, int n_ranges, double* partials, void* stream);
+
 /* stats[0] = ||g||_2, stats[1] = min(1, max_norm / (norm + 1e-6)), stats[2] = sum of squares
  * (torch.nn.utils.clip_grad_norm_ semantics; DiT/forget.py:293-298) */
 int sfron_clip_coef(const double* partials, int nblk, float max_norm, float* stats, void* stream);
@@ -200,12 +205,19 @@ typedef struct sfron_gemm_desc {
                                         sums of output rows 256 r .. 256 r + 255 (fp32, before the bf16 rounding): partials of the fc1
                                         bias gradient sum_rows d_hpre, formed where d_hpre is produced instead of by a second pass
                                         over it (sum them with sfron_reduce_chunks).  NULL = not wanted. */
+  const uint8_t* sumsq_mask;         /* with sumsq_partials: byte mask over the OUTPUT (same layout as c_f32: element (m, n) at m * ldc_f32 + n) or NULL */
+  double* sumsq_partials;            /* weight-gradient layout only (a_transposed = b_transposed = 1, EPI_F32, no split, no a_rowsum): fp64
+                                        [sfron_gemm_sumsq_partials(M, N, K)], partial t = sum over output tile t of (mask ? c : 0)^2 -- the masked
+                                        sum of squares clip_grad_norm_ needs (DiT/forget.py:289-298), formed where the gradient is produced
+                                        instead of by a pass over the gradient arena; combine with sfron_clip_coef.  NULL = not wanted. */
 } sfron_gemm_desc;
 int sfron_gemm_bf16(const sfron_gemm_desc* desc /* HOST pointer */, void* stream);
 /* number of partial rows an EPI_DGELU product of this shape writes to col_partials (M / 256), 0 = shape unsupported: use sfron_colsum */
 int sfron_gemm_dgelu_colpart_rows(int M, int N, int K);
 /* 1 when a weight-gradient GEMM dW[M][N] = dY[K][M]^T X[K][N] of this shape can also produce a_rowsum (else use sfron_colsum) */
 int sfron_gemm_rowsum_supported(int M, int N, int K);
+/* number of fp64 partials a weight-gradient GEMM dW[M][N] = dY[K][M]^T X[K][N] of this shape writes to sumsq_partials, 0 = shape unsupported */
+int sfron_gemm_sumsq_partials(int M, int N, int K);
 
 
 /* ------------------------------------------------------------------ fp8 (e4m3) forward GEMMs (fp8.hip) -- BASELINE config 5
@@ -600,6 +612,14 @@ int sfron_aux_create(void** aux /* HOST out */);
  * stream around each of the four weight-gradient GEMMs (qkv, proj, fc1, fc2) of every 9th block -- the kernel that holds the
  * largest share of GPU time -- for bench.py's live roofline figure */
 int sfron_aux_set_probe(void* aux, void* probe);
+/* One-shot: the NEXT sfron_dit_backward / _dp call through this handle also leaves the masked sum of squares of every block weight gradient
+ * (qkv / proj / fc1 / fc2 weights of all blocks) in `partials` -- fp64 [sfron_dit_sumsq_partials_len(cfg)], one per 192 x 192 output tile, every
+ * entry rewritten by the pass -- taken from the accumulators of the weight-gradient GEMMs (sfron_gemm_desc.sumsq_partials).  mask_arena: byte mask
+ * indexed like the parameter / gradient arena (NULL = no mask).  The clip norm of DiT/forget.py:289-298 then needs a pass only over what is left
+ * (biases, embedders, final layer: sfron_sumsq_masked_ranges) plus sfron_clip_coef.  Single-process runs only: a data-parallel run must take the
+ * norm of the REDUCED gradient.  sfron_dit_sumsq_partials_len returns 0 when a block shape does not run on the 192 x 192 weight-gradient tile. */
+int sfron_dit_sumsq_partials_len(const sfron_dit_cfg* cfg);
+int sfron_aux_arm_sumsq(void* aux, const uint8_t* mask_arena, double* partials);
 int sfron_aux_destroy(void* aux);
 
 #ifdef __cplusplus

@@ -8,7 +8,10 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import test_gpu_reference_fixtures as T  # noqa: E402
 
-for name, fn in (("dit", T.test_dit_sfron_trajectory_vs_reference_fixture), ("ddpm", T.test_ddpm_sfron_trajectory_vs_reference_fixture)):
+NROWS = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+for name, fn in (("dit", T.test_dit_sfron_trajectory_vs_reference_fixture), ("ddpm", T.test_ddpm_sfron_trajectory_vs_reference_fixture),
+                 ("sd_xattn", lambda: T.test_sd_nsfw_removal_trajectory_vs_reference_fixture("xattn")),
+                 ("sd_full", lambda: T.test_sd_nsfw_removal_trajectory_vs_reference_fixture("full"))):
     try:
         fn()
         print(f"== {name}: test passed")
@@ -18,5 +21,5 @@ for name, fn in (("dit", T.test_dit_sfron_trajectory_vs_reference_fixture), ("dd
     rows = sorted(cs.items(), key=lambda kv: kv[1][0])
     print(f"{name}: {len(rows)} tensors; min cosine {rows[0][1][0]:.4f}; max |norm ratio - 1| {max(abs(v[1] - 1) for v in cs.values()):.4f}; "
           f"min ref rms/lr {min(v[2] for v in cs.values()):.3f}")
-    for n, (c, r, rms) in rows[:12]:
+    for n, (c, r, rms) in rows[:NROWS]:
         print(f"   {n:50s} cos {c:.4f}  norm ratio {r:.4f}  ref rms/lr {rms:.3f}")

@@ -9,6 +9,8 @@ modules, everything else fp32), run on the GPU in fp32 next to the HIP forward p
    QKV   the qkv Linear's output rounded to bf16 (what the attention kernel reads)
    P     softmax probabilities rounded to bf16 before P.V (the flash kernel's P operand)
    H     fc1's pre-activation rounded to bf16 before GELU is NOT applied (the kernel applies GELU to the fp32 accumulator): h only
+   E     the GEMM inputs OUTSIDE the blocks: patch-embedding input, timestep frequencies, silu(h1), silu(c) into every adaLN Linear, final
+         Linear input (the HIP path feeds all of them to its GEMMs as bf16)
    ALL   all of the above together = the model of the HIP path's rounding points
 For each: held-out mse minus the fp32 oracle's, per batch (mean, std over batches) -- a BIAS shows as a mean that does not average out.
 
@@ -54,6 +56,12 @@ class Rounding:
                     self.handles.append(lin.register_forward_pre_hook(lambda m, a: (bf(a[0]),)))
             if "QKV" in K:
                 self.handles.append(blk.attn.qkv.register_forward_hook(lambda m, a, o: bf(o)))
+        if "E" in K:
+            pre = lambda m, a: (bf(a[0]),)
+            mods = [ref.x_embedder.proj, ref.t_embedder.mlp[0], ref.t_embedder.mlp[2], ref.final_layer.linear, ref.final_layer.adaLN_modulation[1]]
+            mods += [blk.adaLN_modulation[1] for blk in ref.blocks]
+            for m in mods:
+                self.handles.append(m.register_forward_pre_hook(pre))
         if "P" in K:
             self._attn_fwd = dit_ref.Attention.forward
 
@@ -83,6 +91,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--batches", type=int, default=4)
     ap.add_argument("--skip-bisect", action="store_true")
+    ap.add_argument("--sensitivity", action="store_true",
+                    help="Part 3: how far do two fp32-ORACLE trajectories drift apart over the same 50 steps when they differ by (a) one fp32 ulp "
+                         "of every weight at step 0, (b) bf16 rounding of weights + GEMM inputs in the forward pass (fake-quant oracle)")
     args = ap.parse_args()
     from oracle import diffusion_ref as dref
     from oracle import sfron_ref
@@ -126,7 +137,7 @@ def main():
         base = [held_ref(hb) for hb in hbs]
         hip = [held_hip(hb) for hb in hbs]
         rows = [("HIP path", hip)]
-        for kinds in (["W"], ["A"], ["QKV"], ["P"], ["W", "A"], ["W", "A", "QKV", "P"]):
+        for kinds in (["W"], ["A"], ["QKV"], ["P"], ["E"], ["W", "A"], ["W", "A", "QKV", "P", "E"]):
             with Rounding(ref, kinds):
                 rows.append(("oracle + bf16 " + "+".join(kinds), [held_ref(hb) for hb in hbs]))
         print(f"\nheld-out eps-MSE of the fp32 oracle per batch: {['%.5f' % b for b in base]}")
@@ -136,6 +147,13 @@ def main():
             dv = torch.tensor([v - b for v, b in zip(vals, base)], dtype=torch.float64)
             print(f"| {name} | {' '.join('%+.2e' % x for x in dv.tolist())} | {dv.mean().item():+.2e} | {dv.std().item() if len(dv) > 1 else 0:.1e} |", flush=True)
 
+    if args.sensitivity:
+        del model
+        ref.cpu()
+        del ref
+        torch.cuda.empty_cache()
+        sensitivity(args.steps, hbs)
+        return
     if args.steps <= 0:
         return
     # ---- Part 2: 50 iterations, both paths from the same state
@@ -165,6 +183,102 @@ def main():
         runner.step(fd, rd)
         if it + 1 in (1, 5, 10, 20, 30, 50, args.steps):
             report(it + 1)
+
+
+def sensitivity(steps, hbs):
+    """Three oracles on the GPU from the same initial weights over the same batches: fp32; fp32 with every weight moved by one ulp at
+    step 0; fp32 masters with bf16-rounded weights and GEMM inputs in every forward pass (W + A + E: what ANY bf16-operand implementation
+    of this model does).  Prints each one's held-out gap against the first."""
+    import copy
+    from oracle import diffusion_ref as dref
+    from oracle import sfron_ref
+    from sfron import data
+    from test_gpu_baseline_shapes import _pair
+    B = 4
+    ref, model = _pair("DiT-XL/2", B, seed=51, std=0.02)
+    del model
+    tab = dref.DiffusionTables(1000)
+    gm = torch.Generator().manual_seed(52)
+    mask = {"module." + n: (torch.rand(p.shape, generator=gm) < 0.5).to(DEV) for n, p in ref.named_parameters() if p.requires_grad}
+    mask["module.pos_embed"] = 0
+    hp = dict(lr=1e-4, forget_alpha=1e-3, grad_clip=1.0, ema_decay=0.9999, unlearn_loss="ga", forget_class=207)
+    refs = {"fp32": ref.to(DEV)}
+    refs["fp32 + 1 ulp"] = copy.deepcopy(ref)
+    with torch.no_grad():
+        for p in refs["fp32 + 1 ulp"].parameters():
+            if p.requires_grad:
+                p.copy_(torch.nextafter(p, torch.full_like(p, float("inf"))))
+    refs["bf16 W+A+E forward"] = copy.deepcopy(ref)
+    orcs = {k: sfron_ref.DiTSfronOracle(m, tab, mask=mask, **hp) for k, m in refs.items()}
+    kw = dict(global_batch=B, num_classes=1000, forget_class=207)
+
+    def held(m, fake):
+        m.eval()
+        vals = []
+        with torch.no_grad():
+            for hb in hbs:
+                g = {k: v.to(DEV) for k, v in hb.items()}
+                if fake:
+                    with Rounding(m, ["W", "A", "E"]):
+                        vals.append(dref.training_losses(tab, lambda x, t, y: m(x, t, y), g["x0"], g["t"], dict(y=g["y"]), g["noise"])["mse"].mean().item())
+                else:
+                    vals.append(dref.training_losses(tab, lambda x, t, y: m(x, t, y), g["x0"], g["t"], dict(y=g["y"]), g["noise"])["mse"].mean().item())
+        m.train()
+        return sum(vals) / len(vals)
+
+    def report(it):
+        base = held(refs["fp32"], False)
+        line = f"after {it:3d} steps: fp32 oracle {base:.5f}"
+        for k in list(refs)[1:]:
+            line += f" | {k}: gap {held(refs[k], k.startswith('bf16')) - base:+.2e}"
+        print(line, flush=True)
+    print("\nPart 3: sensitivity of the 50-step trajectory itself (all three are the ORACLE, fp32 arithmetic on the GPU)")
+    report(0)
+    for it in range(steps):
+        f, r = data.synthetic_batch(23, it, "forget", **kw), data.synthetic_batch(23, it, "remain", **kw)
+        fd = {k: (v.long() if k == "drop" else v).to(DEV) for k, v in f.items()}
+        rd = {k: (v.long() if k == "drop" else v).to(DEV) for k, v in r.items()}
+        for k, o in orcs.items():
+            if k.startswith("bf16"):
+                with Rounding(refs[k], ["A", "E"]):
+                    # weights: fp32 masters, bf16 copies in the forward / backward passes (restored before the optimizer sweeps)
+                    _step_with_rounded_weights(o, refs[k], fd, rd)
+            else:
+                o.step(fd, rd)
+        if it + 1 in (1, 5, 10, 20, 30, 50, steps):
+            report(it + 1)
+
+
+def _step_with_rounded_weights(orc, m, fd, rd):
+    """DiTSfronOracle.step with bf16-rounded weights inside each stage's forward + backward and fp32 masters in the optimizer: the
+    optimizer's step() is wrapped to restore the masters first and to round again afterwards."""
+    masters = {}
+
+    def round_in():
+        for n, p in m.named_parameters():
+            if p.dim() >= 2 and p.requires_grad:
+                masters[n] = p.data.clone()
+                p.data.copy_(bf(p.data))
+
+    def restore():
+        for n, p in m.named_parameters():
+            if n in masters:
+                p.data.copy_(masters[n])
+        masters.clear()
+    opt_step = orc.opt.step
+
+    def wrapped(*a, **k):
+        restore()
+        r = opt_step(*a, **k)
+        round_in()
+        return r
+    orc.opt.step = wrapped
+    round_in()
+    try:
+        orc.step(fd, rd)
+    finally:
+        orc.opt.step = opt_step
+        restore()
 
 
 if __name__ == "__main__":

@@ -25,6 +25,8 @@ Outputs (small .npz files, inputs + expected outputs only -- no reference source
   sd_unet.npz         SD/ldm/modules/diffusionmodules/openaimodel.py UNetModel (+ attention.py, util.py): parameter spec of the
                       v1-inference.yaml UNet (meta device), forward/backward on a tiny config, the "linear" LDM schedule, and a
                       2-iteration trajectory of the nsfw_removal.py loop body composed from the reference UNet
+  sd_unet_updates.npz every trainable tensor's update over that trajectory (train_method "xattn") and over the same batches with
+                      train_method "full" (+ its losses): per-tensor cosines / norm ratios on the GPU (test_gpu_reference_fixtures.py)
 """
 import argparse
 import importlib
@@ -810,6 +812,76 @@ def gen_sd():
 
 
 
+def gen_sd_updates():
+    """sd_unet_updates.npz: every trainable tensor's UPDATE over the 2-iteration nsfw_removal.py:108-173 trajectory of the reference
+    UNetModel -- (a) train_method "xattn" (the attn2 tensors): the SAME trajectory sd_unet.npz holds (same seeds, recomputed here and
+    checked against that file's losses; sd_unet.npz itself is not rewritten), (b) train_method "full" (every parameter,
+    nsfw_removal.py:67-77) on the same batches, with its losses.  Separate file: the older fixture keeps its bits."""
+    om, ut = import_ref_sd()
+    sd = sd_tiny_weights()
+    old = np.load(os.path.join(HERE, "sd_unet.npz"))
+    betas = ut.make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
+    ac = np.cumprod(1.0 - betas, axis=0)
+    sa, sb = torch.tensor(np.sqrt(ac), dtype=torch.float32), torch.tensor(np.sqrt(1.0 - ac), dtype=torch.float32)
+    c_f, c_p = torch.from_numpy(old["traj_c_f"]).expand(2, -1, -1), torch.from_numpy(old["traj_c_p"]).expand(2, -1, -1)
+    q = lambda x0, t_, n_: ut.extract_into_tensor(sa, t_, x0.shape) * x0 + ut.extract_into_tensor(sb, t_, x0.shape) * n_
+    out = {}
+    for method in ("xattn", "full"):
+        ref = om.UNetModel(**SD_TINY)
+        ref.load_state_dict(sd)
+        ref.train()
+        named = [(n, p) for n, p in ref.named_parameters() if method == "full" or "attn2" in n]      # nsfw_removal.py:67-77
+        p0 = {n: p.detach().clone() for n, p in named}
+        opt = torch.optim.Adam([p for _, p in named], lr=1e-3)
+        traj = []
+        gn = {}
+        for it in range(2):
+            xf, xr = torch.from_numpy(old["traj_xf"][it]), torch.from_numpy(old["traj_xr"][it])
+            tt, nf = torch.from_numpy(old["traj_t_f"][it]), torch.from_numpy(old["traj_noise_f"][it])
+            tr, nr = torch.from_numpy(old["traj_t_r"][it]), torch.from_numpy(old["traj_noise_r"][it])
+            opt.zero_grad()
+            f_out = ref(q(xf, tt, nf), timesteps=tt, context=c_f)
+            p_out = ref(q(xf, tt, nf), timesteps=tt, context=c_p).detach()
+            lf = torch.nn.MSELoss()(f_out, p_out)
+            (1.0 * lf).backward()
+            if it == 0:
+                gn["forget"] = np.array([p.grad.double().norm().item() for _, p in named])
+            opt.step()
+            opt.zero_grad()
+            r_out = ref(q(xr, tr, nr), timesteps=tr, context=c_p)
+            lr_ = torch.nn.functional.mse_loss(nr, r_out, reduction="none").mean([1, 2, 3]).mean()
+            (1.0 * lr_).backward()
+            if it == 0:
+                gn["remain"] = np.array([p.grad.double().norm().item() for _, p in named])
+            opt.step()
+            traj.append((lf.item(), lr_.item()))
+        traj = np.array(traj, dtype=np.float64)
+        if method == "xattn":
+            assert np.allclose(traj, old["traj_losses"], rtol=1e-5, atol=0), (traj, old["traj_losses"])
+            k = "input_blocks.1.1.transformer_blocks.0.attn2.to_v.weight"
+            assert np.allclose(dict(named)[k].detach().numpy(), old["traj_final/" + k], rtol=0, atol=2e-6)
+        out[method] = (traj, [n for n, _ in named], {n: p for n, p in named}, p0, gn)
+    blob = dict(lr=np.array(1e-3), scale=np.array(20.0), cap=np.array(32768))
+    for method, (traj, names, fin, p0, gn) in out.items():
+        blob[method + "::losses"] = traj
+        blob[method + "::names"] = np.array(names)
+        # the reference's own gradient norm per tensor in the first forget / remain stage: a tensor whose gradient is EXACTLY zero
+        # analytically (a per-channel constant in front of a GroupNorm with one channel per group: SD_TINY's 32-channel levels) holds
+        # fp32 cancellation noise there, and its "update" is Adam's normalisation of that noise -- the GPU test compares those by size
+        blob[method + "::gnorm_forget"], blob[method + "::gnorm_remain"] = gn["forget"], gn["remain"]
+        for n in names:
+            u = ((fin[n].detach() - p0[n]).double() / 1e-3).numpy().ravel()
+            blob[f"{method}::norm::{n}"] = np.array(float(np.linalg.norm(u)))
+            stride = -(-u.size // 32768)
+            blob[f"{method}::upd::{n}"] = np.clip(np.rint(u[::stride] * 20.0), -127, 127).astype(np.int8)
+    np.savez_compressed(os.path.join(HERE, "sd_unet_updates.npz"), **blob)
+    print("sd_unet_updates.npz written:", {m: (len(v[1]), v[0].tolist()) for m, v in out.items()})
+    g = out["full"][4]
+    med = np.median(g["remain"])
+    print("full: tensors with a remain-stage gradient norm below 1e-4 x the median:",
+          [(n, float(a), float(b)) for n, a, b in zip(out["full"][1], g["forget"], g["remain"]) if b < 1e-4 * med][:40])
+
+
 def import_ref_convert():
     """SD/train-scripts/convertModels.py needs diffusers / transformers / omegaconf only for NAMES imported at module top (the
     UNet key conversion itself is plain dict manipulation): the harness supplies empty stand-in classes."""
@@ -890,6 +962,8 @@ if __name__ == "__main__":
         gen_ddpm_sampler()
     if want("sd"):
         gen_sd()
+    if want("sd_updates"):
+        gen_sd_updates()
     if want("compvis_export"):
         gen_compvis_export()
     print("golden vectors written to", HERE)

@@ -386,3 +386,38 @@ def test_joint_method_vs_oracle():
         assert rel_err(eng.view(runner.ema, n), orc.ema[n]) < 2e-2, n
     with pytest.raises(ValueError):
         step.DiTSFRon(model, diffusion.create_diffusion(""), method="sa")
+
+
+def test_fused_clip_norm_equals_the_pass_over_the_gradient_arena():
+    """step.DiTSFRon.fuse_clip_norm (single-process runs): the forget stage's clip norm is assembled from the weight-gradient GEMMs' own masked
+    sums of squares + one launch over biases / embedders / final layer + the rank-(batch) adaLN range, instead of a pass over the gradient
+    arena.  Same values in another summation order: the norm agrees to 1e-6, the parameters after three iterations to lr * 1e-5."""
+    from sfron import data, diffusion, step
+    cfg = dict(input_size=16, patch_size=2, in_channels=4, hidden_size=192, depth=2, num_heads=3, num_classes=10)      # widths the 192 x 192 tile takes
+    B = 4
+    kw = dict(global_batch=B, num_classes=cfg["num_classes"], forget_class=3, input_size=cfg["input_size"], device=DEV)
+    gm = torch.Generator().manual_seed(77)
+
+    def run(fused):
+        ref, model = build_pair(cfg, B, seed=41)
+        mask = {n: (torch.rand(p.shape, generator=torch.Generator().manual_seed(5 + i)) < 0.5) for i, (n, p) in enumerate(ref.named_parameters())
+                if p.requires_grad}
+        mask["pos_embed"] = 0
+        runner = step.DiTSFRon(model, diffusion.create_diffusion(""), lr=2e-4, forget_alpha=0.3, grad_clip=1.0, ema_decay=0.99, mask=mask,
+                               unlearn_loss="ga", forget_class=3)
+        runner.fuse_clip_norm = fused
+        assert (model.engine.fused_sumsq_plan() is not None)
+        norms = []
+        for it in range(3):
+            out = runner.step(data.synthetic_batch(9, it, "forget", **kw), data.synthetic_batch(9, it, "remain", **kw))
+            norms.append(out["stats"][0].item())
+            if fused:
+                assert runner._sq_buf is not None
+        torch.cuda.synchronize()
+        runner.guard.poll(block=True)
+        return model.engine.params.clone(), norms
+    p1, n1 = run(True)
+    p0, n0 = run(False)
+    for a, b in zip(n1, n0):
+        assert a > 0 and abs(a - b) <= 1e-6 * b, (n1, n0)
+    assert (p1 - p0).abs().max().item() <= 2e-4 * 1e-5

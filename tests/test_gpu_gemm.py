@@ -330,3 +330,42 @@ def test_short_contraction_kernel(M, N, K, T):
     ref = torch.empty(M, N, dtype=torch.float32, device=DEV)
     ops.gemm(A.to(DEV), B.to(DEV), M, N, K, epilogue=_lib.EPI_POS, bias=bias.to(DEV), c_f32=ref, pos=pos.to(DEV), tokens=T, tile_hint=-1)
     assert torch.equal(guard[:M], ref)
+
+
+@pytest.mark.parametrize("N,K,M,masked", [(384, 192, 512, True), (1152, 4608, 8192, True), (3456, 1152, 8192, False), (768, 768, 2048, True)])
+def test_wgrad_leaves_masked_sum_of_squares_of_its_tiles(N, K, M, masked):
+    """sfron_gemm_desc.sumsq_partials: the weight-gradient product dW[N][K] = dY[M][N]^T X[M][K] also leaves, per 192 x 192 output tile, the sum of
+    (mask ? dW : 0)^2 -- the masked sum of squares that clip_grad_norm_ needs after `grad *= mask` (DiT/forget.py:289-298) -- with dW itself
+    unchanged bit for bit.  Against torch on the stored fp32 result (same values, another summation order: 1e-6) and run twice (same bits)."""
+    from sfron import _lib, ops
+    g = torch.Generator(device=DEV).manual_seed(N + K)
+    dY = (torch.randn(M, N, generator=g, device=DEV) * 0.1).to(torch.bfloat16)
+    X = torch.randn(M, K, generator=g, device=DEV).to(torch.bfloat16)
+    mask = (torch.rand(N, K, generator=g, device=DEV) < 0.5).to(torch.uint8) if masked else None
+    n = _lib.lib().sfron_gemm_sumsq_partials(N, K, M)
+    assert n == (N // 192) * (K // 192)
+    ref = torch.empty(N, K, dtype=torch.float32, device=DEV)
+    ops.gemm(dY, X, N, K, M, a_t=True, b_t=True, epilogue=_lib.EPI_F32, c_f32=ref)
+    outs = []
+    for _ in range(2):
+        C = torch.empty(N, K, dtype=torch.float32, device=DEV)
+        part = torch.full((n,), float("nan"), dtype=torch.float64, device=DEV)
+        ops.gemm(dY, X, N, K, M, a_t=True, b_t=True, epilogue=_lib.EPI_F32, c_f32=C, sumsq_partials=part, sumsq_mask=mask)
+        torch.cuda.synchronize()
+        assert torch.equal(C, ref)
+        outs.append(part.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()
+    want = (ref.double() * (mask.double() if masked else 1.0)).pow(2).sum().item()
+    assert abs(outs[0].sum().item() - want) <= 1e-6 * want
+    # per tile: every partial belongs to exactly one 192 x 192 tile (any order)
+    tiles = (ref.double() * (mask.double() if masked else 1.0)).pow(2).view(N // 192, 192, K // 192, 192).sum((1, 3)).flatten()
+    assert torch.allclose(outs[0].sort().values, tiles.sort().values, rtol=1e-6)
+
+
+def test_sumsq_partials_refused_where_the_shape_takes_another_tile():
+    from sfron import _lib, ops
+    assert _lib.lib().sfron_gemm_sumsq_partials(128, 192, 256) == 0
+    dY, X = torch.zeros(256, 128, dtype=torch.bfloat16, device=DEV), torch.zeros(256, 192, dtype=torch.bfloat16, device=DEV)
+    C, part = torch.empty(128, 192, device=DEV), torch.zeros(4, dtype=torch.float64, device=DEV)
+    with pytest.raises(_lib.SfronError):
+        ops.gemm(dY, X, 128, 192, 256, a_t=True, b_t=True, epilogue=_lib.EPI_F32, c_f32=C, sumsq_partials=part)

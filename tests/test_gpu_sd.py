@@ -174,6 +174,9 @@ def test_sd_unet_forward_backward_vs_oracle(cfg, B, S, Lc):
     _compare_unet(ref, model, x, t, ctx, w, f"SD UNet mc={cfg['model_channels']} B={B} {S}x{S} ctx {Lc}")
 
 
+SD_ORACLE_UPDATE_COS_MIN, SD_ORACLE_UPDATE_NORM_TOL = 0.90, 0.05       # 2 x worst measured on MI355X (round 5), see the print below
+
+
 @pytest.mark.parametrize("method,mask_mode", [("xattn", "as_written"), ("full", "intended")])
 def test_sd_nsfw_removal_iterations_vs_oracle(method, mask_mode):
     from oracle import sd_ref
@@ -187,6 +190,17 @@ def test_sd_nsfw_removal_iterations_vs_oracle(method, mask_mode):
     p0 = {n: p.detach().clone() for n, p in ref.named_parameters()}
     g = torch.Generator().manual_seed(16)
     B, S, Lc = 4, 8, 6
+    # tensors whose gradient is exactly zero analytically (a per-channel constant in front of a GroupNorm with one channel per group: the
+    # 32-channel levels of SMALL): a probe backward pass of the oracle leaves fp32 cancellation noise there -- found by size, compared by size
+    gp = torch.Generator().manual_seed(99)
+    (ref(torch.randn(B, 4, S, S, generator=gp), timesteps=torch.randint(0, 1000, (B,), generator=gp),
+         context=torch.randn(B, Lc, 24, generator=gp)) * torch.randn(B, 4, S, S, generator=gp)).sum().backward()
+    gnorm = {n: p.grad.double().norm().item() for n, p in ref.named_parameters()}
+    med = float(np.median(list(gnorm.values())))
+    zero_grad_tensors = {n for n, v in gnorm.items() if v < 1e-4 * med}
+    assert len(zero_grad_tensors) <= 13, sorted(zero_grad_tensors)
+    for p in ref.parameters():
+        p.grad = None
     c_f, c_p = torch.randn(1, Lc, 24, generator=g).expand(B, -1, -1).contiguous(), torch.randn(1, Lc, 24, generator=g).expand(B, -1, -1).contiguous()
     for it in range(3):
         xf = torch.randn(B, 4, S, S, generator=g)
@@ -196,19 +210,31 @@ def test_sd_nsfw_removal_iterations_vs_oracle(method, mask_mode):
         got = run.step({k: v.to(DEV) for k, v in forget.items()}, {k: v.to(DEV) for k, v in remain.items()})
         assert got["forget_loss"].item() == pytest.approx(want["forget_loss"], rel=4e-2, abs=1e-5)
         assert got["remain_loss"].item() == pytest.approx(want["remain_loss"], rel=3e-2)
-    same = tot = 0
-    num = den = 0.0
+    # EVERY trainable tensor's update against the oracle's: cosine + ratio of the norms (the pooled sign / bulk metric
+    # could not fail on a wrong small tensor).  Bounds = 2 x the worst measured (printed below).
+    worst_cos, worst_ratio = (2.0, None), (0.0, None)
     for n, q in ref.named_parameters():
         mine = model.view(model.params, n).cpu()
-        du_ref, du = (q.detach() - p0[n]).flatten(), (mine - p0[n]).flatten()
+        du_ref, du = (q.detach() - p0[n]).flatten().double(), (mine - p0[n]).flatten().double()
         if method == "xattn" and "attn2" not in n:
             assert torch.equal(mine, p0[n]), n                  # untouched by the optimizer
             continue
-        big = du_ref.abs() > 0.05 * du_ref.abs().max()
-        same += int((torch.sign(du[big]) == torch.sign(du_ref[big])).sum()); tot += int(big.sum())
-        num += (du - du_ref).double().pow(2).sum().item(); den += du_ref.double().pow(2).sum().item()
-    print(f"SD {method}/{mask_mode}: update sign agreement {same / tot:.4f}, bulk relative error {(num / den) ** 0.5:.3f}")
-    assert same / tot > 0.97 and (num / den) ** 0.5 < 0.3
+        if mask_mode == "intended":
+            # masked-out coordinates still move in the forget stage through momentum -- both paths' updates include that
+            pass
+        if n in zero_grad_tensors:
+            assert du.abs().max().item() <= 6.5 * hp["lr"], n          # six Adam steps of at most lr along a direction the function ignores
+            continue
+        cos = float((du * du_ref).sum() / (du.norm() * du_ref.norm() + 1e-30))
+        ratio = float(du.norm() / (du_ref.norm() + 1e-30))
+        assert du_ref.norm().item() > 0, n
+        if cos < worst_cos[0]:
+            worst_cos = (cos, n)
+        if abs(ratio - 1.0) > abs(worst_ratio[0] - 1.0) or worst_ratio[1] is None:
+            worst_ratio = (ratio, n)
+        assert cos >= SD_ORACLE_UPDATE_COS_MIN, (n, cos)
+        assert abs(ratio - 1.0) < SD_ORACLE_UPDATE_NORM_TOL, (n, ratio)
+    print(f"SD {method}/{mask_mode}: min per-tensor update cosine {worst_cos[0]:.4f} ({worst_cos[1]}), worst norm ratio {worst_ratio[0]:.4f} ({worst_ratio[1]})")
 
 
 def test_latent_diffusion_surface_p_losses_vs_oracle():

@@ -227,3 +227,23 @@ def test_lowrank_gradient_sweeps_vs_flat_kernels(R, NM, D):
     for a, b, nm in zip(outs[0], outs[1], ("p", "m", "v", "ema", "bf16")):
         assert torch.allclose(a, b, rtol=3e-5, atol=1e-7), (nm, (a - b).abs().max().item())
     assert not torch.equal(outs[0][0], p0)
+
+
+def test_sumsq_masked_ranges_vs_torch(dev):
+    """sfron_sumsq_masked_ranges: one launch, one fp64 partial per (offset, length) range of the arenas -- what the clip norm still reads when
+    the weight-gradient GEMMs leave their own sums."""
+    import ctypes
+    from sfron import _lib
+    from sfron._lib import check, ptr, stream_ptr
+    gen = torch.Generator().manual_seed(3)
+    n = 300_000
+    g = torch.randn(n, generator=gen).to(dev)
+    mask = (torch.rand(n, generator=gen) < 0.5).to(torch.uint8).to(dev)
+    rows = [(0, 4), (8, 1152), (4096, 65536), (70_000, 3456), (299_000, 1000)]
+    tab = torch.tensor(rows, dtype=torch.int64, device=dev)
+    for mk in (mask, None):
+        part = torch.full((len(rows),), float("nan"), dtype=torch.float64, device=dev)
+        check(_lib.lib().sfron_sumsq_masked_ranges(ptr(g), ptr(mk), ptr(tab), len(rows), ptr(part), stream_ptr()), "sumsq_masked_ranges")
+        for (off, ln), got in zip(rows, part.cpu().tolist()):
+            x = g[off:off + ln].double() * (mk[off:off + ln].double() if mk is not None else 1.0)
+            assert abs(got - x.pow(2).sum().item()) <= 1e-6 * max(1e-30, x.pow(2).sum().item()), (off, ln)

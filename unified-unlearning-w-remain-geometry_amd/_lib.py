@@ -60,13 +60,15 @@ class GemmDesc(ctypes.Structure):
                 ("aux", c_void_p), ("ldaux", c_int), ("gate", c_void_p), ("ldgate", c_int), ("pos", c_void_p),
                 ("tokens", c_int), ("accumulate", c_int), ("resid", c_void_p), ("split_k", c_int),
                 ("split_stride", ctypes.c_long), ("tile_hint", c_int), ("a_rowsum", c_void_p),
-                ("rowsum_ws", c_void_p), ("col_partials", c_void_p)]
+                ("rowsum_ws", c_void_p), ("col_partials", c_void_p), ("sumsq_mask", c_void_p), ("sumsq_partials", c_void_p)]
 
 
 EPI_BF16, EPI_F32, EPI_GELU, EPI_GATE_RES, EPI_DGELU, EPI_POS = range(6)
 
 _PROTOS["sfron_gemm_bf16"] = (c_int, [POINTER(GemmDesc), _S])
 _PROTOS["sfron_gemm_rowsum_supported"] = (c_int, [c_int, c_int, c_int])
+_PROTOS["sfron_gemm_sumsq_partials"] = (c_int, [c_int, c_int, c_int])
+_PROTOS["sfron_sumsq_masked_ranges"] = (c_int, [_P, _P, _P, c_int, _P, _S])
 _PROTOS["sfron_gemm_dgelu_colpart_rows"] = (c_int, [c_int, c_int, c_int])
 _PROTOS.update({
     "sfron_rows_per_chunk": (c_int, [c_int]),
@@ -192,6 +194,7 @@ DIT_LAYOUT_LEN = 24
 _PROTOS.update({
     "sfron_dit_param_layout": (c_int, [POINTER(DitCfg), POINTER(c_int64), c_int]),
     "sfron_dit_workspace_bytes": (c_int64, [POINTER(DitCfg)]),
+    "sfron_dit_sumsq_partials_len": (c_int, [POINTER(DitCfg)]),
     "sfron_dit_forward": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_dit_backward": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_dit_backward_dp": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _S]),
@@ -199,6 +202,7 @@ _PROTOS.update({
     "sfron_aux_create": (c_int, [POINTER(c_void_p)]),
     "sfron_aux_destroy": (c_int, [c_void_p]),
     "sfron_aux_set_probe": (c_int, [c_void_p, c_void_p]),
+    "sfron_aux_arm_sumsq": (c_int, [c_void_p, _P, _P]),
     "sfron_fp8_activation_amax": (c_int, [POINTER(c_float), c_int, c_void_p]),
     "sfron_dit_forward_probed": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_dit_forward_after": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _S]),

@@ -208,7 +208,7 @@ static int ablate_mask() {
 // ---- aux: a side stream + events so the weight-gradient GEMMs (which nothing downstream in the backward chain
 // depends on) run concurrently with the dgrad / elementwise chain and fill the CUs its tile counts leave idle
 struct Probe;
-struct Aux { hipStream_t side, side2; hipEvent_t produced[4], consumed[8], done, join2; Probe* probe; };
+struct Aux { hipStream_t side, side2; hipEvent_t produced[4], consumed[8], done, join2; Probe* probe; const uint8_t* sq_mask; double* sq_partials; };
 
 int sfron_aux_create(void** aux) {
   SFRON_CHECK_ARG(aux);
@@ -256,6 +256,29 @@ struct Probe { hipEvent_t* ev; int cap, used; };
 int sfron_aux_set_probe(void* aux, void* probe) {
   SFRON_CHECK_ARG(aux);
   ((Aux*)aux)->probe = (Probe*)probe;
+  return SFRON_OK;
+}
+
+// per block: number of sum-of-squares partials of its four weight gradients (qkv, proj, fc1, fc2), 0 if one of the shapes is unsupported
+static int sumsq_counts(const Dims& d, int cnt[4]) {
+  const int N[4] = {3 * d.D, d.D, d.F, d.D}, K[4] = {d.D, d.D, d.D, d.F};
+  int tot = 0;
+  for (int j = 0; j < 4; ++j) {
+    cnt[j] = sfron_gemm_sumsq_partials(N[j], K[j], d.M);
+    if (cnt[j] <= 0) return 0;
+    tot += cnt[j];
+  }
+  return tot;
+}
+int sfron_dit_sumsq_partials_len(const sfron_dit_cfg* cfg) {
+  Dims d;
+  if (make_dims(cfg, d) != SFRON_OK) return 0;
+  int cnt[4];
+  return sumsq_counts(d, cnt) * d.L;
+}
+int sfron_aux_arm_sumsq(void* aux, const uint8_t* mask_arena, double* partials) {
+  SFRON_CHECK_ARG(aux && partials);
+  ((Aux*)aux)->sq_mask = mask_arena; ((Aux*)aux)->sq_partials = partials;
   return SFRON_OK;
 }
 
@@ -493,6 +516,16 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
   // side stream for weight/bias gradients (falls back to the main stream without an aux handle)
   Aux* ax = (Aux*)aux;
   void* side = ax ? (void*)ax->side : stream;
+  // one-shot (sfron_aux_arm_sumsq): this pass's block weight gradients also leave their masked sums of squares
+  const uint8_t* const sq_mask = ax ? ax->sq_mask : nullptr;
+  double* const sq_partials = ax ? ax->sq_partials : nullptr;
+  if (ax) { ax->sq_mask = nullptr; ax->sq_partials = nullptr; }
+  int sq_cnt[4] = {0, 0, 0, 0}, sq_per_block = 0;
+  if (sq_partials) {
+    sq_per_block = sumsq_counts(d, sq_cnt);
+    if (sq_per_block == 0) return SFRON_ERR_UNSUPPORTED;
+  }
+  double* sq_next = nullptr;                        // set by the caller of wgrad_on for the block weight gradients
   // block weight gradient on the side stream, reduction split per wgrad_splits() into fp32 slabs + fixed-order sum
   // db (optional): the bias gradient sum_rows dY of the same Linear.  Where the three-slot weight-gradient kernel takes the
   // shape it comes out of that GEMM (row sums of dY^T against a ones fragment); otherwise a column-sum launch precedes it.
@@ -514,12 +547,24 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     const int sp = (ablate_mask() & 2) ? wgrad_splits(N, K, M) : 1;
     if (sp > 1) { q.c_f32 = w.wslab; q.split_k = sp; q.split_stride = (long)N * K; }
     if ((ablate_mask() & 512) && N % 256 == 0 && K % 192 == 0) q.tile_hint = 42;      // A-B knob: 256 x 192 tiles (fc1 / fc2: 108 workgroups instead of 144)
+    if (sq_next && sp == 1 && q.tile_hint == 0 && !q.a_rowsum) {
+      q.sumsq_partials = sq_next;
+      q.sumsq_mask = sq_mask ? sq_mask + (dW - grads) : nullptr;
+    } else if (sq_next) return SFRON_ERR_UNSUPPORTED;       // (debug-knob builds only: an ablation that changes the weight-gradient form)
+    sq_next = nullptr;
     RUN(sfron_gemm_bf16(&q, side));
     if (sp > 1) RUN(sfron_reduce_chunks(w.wslab, 1, sp, N * K, dW, N * K, 0, side));
     return SFRON_OK;
   };
   auto wgrad_side = [&](const void* dY, const void* X, int N, int K, float* dW, float* db = nullptr) -> int {
     return wgrad_on(side, dY, X, N, K, dW, db);
+  };
+  // partials of matrix j (0 qkv, 1 proj, 2 fc1, 3 fc2) of block l, or null when the pass is not armed
+  auto sq_slot = [&](int l, int j) -> double* {
+    if (!sq_partials) return nullptr;
+    int o = 0;
+    for (int i = 0; i < j; ++i) o += sq_cnt[i];
+    return sq_partials + (size_t)l * sq_per_block + o;
   };
   // The attention backward needs a whole CU's LDS per workgroup (157 KB), and so does a weight-gradient workgroup (144 KB): beside the
   // 36-tile proj weight gradient it gets 220 CUs = 2.3 rounds of its 512 workgroups.  So proj waits for the attention backward and
@@ -613,6 +658,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     const bool delay_fc2 = ablate_mask() & 8;      // A-B knob: start the fc2 weight gradient only after the fc2 dgrad (768 tiles)
     if (!delay_fc2) {
       produced(0);                                // d_br was written by the fused LN+gate kernel just before this block
+      sq_next = sq_slot(l, 3);
       RUN(wgrad_side(w.d_br[pl], h, D, d.F, grads + pb + P.o_fc2_w));
       consumed(0, l);
     }
@@ -627,9 +673,11 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     RUN(sfron_gemm_bf16(&g, stream));
     produced(1);
     if (delay_fc2) {
+      sq_next = sq_slot(l, 3);
       RUN(wgrad_side(w.d_br[pl], h, D, d.F, grads + pb + P.o_fc2_w));
       consumed(0, l);
     }
+    sq_next = sq_slot(l, 2);
     if (fc1_rows) {
       RUN(sfron_reduce_chunks(bp_fc1, 1, fc1_rows, d.F, grads + pb + P.o_fc1_b, d.F, 0, side));
       RUN(wgrad_side(w.d_hpre[pl], xmod2, d.F, D, grads + pb + P.o_fc1_w));
@@ -645,6 +693,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
                 slot(l, 1, 1), a1, mod + 2 * D, w.d_br2[pl], slot(l, 2, 0), slot(l, 2, 1)));
     produced(2);
     if (!pair_proj) {
+      sq_next = sq_slot(l, 1);
       RUN(wgrad_side(w.d_br2[pl], o, D, D, grads + pb + P.o_proj_w));
       consumed(2, l);
     }
@@ -656,6 +705,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     auto proj_beside = [&]() {
       if (!pair_proj) return;
       (void)hipStreamWaitEvent(ax->side2, ax->produced[3], 0);       // recorded after produced[2] on the same stream: covers d_br2
+      sq_next = sq_slot(l, 1);
       proj_rc = wgrad_on((void*)ax->side2, w.d_br2[pl], o, D, D, grads + pb + P.o_proj_w, nullptr);
       (void)hipEventRecord(ax->join2, ax->side2);
     };
@@ -669,12 +719,14 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
       produced(3);
       proj_beside();
       RUN(sfron_reduce_chunks(bp, 1, B, 3 * D, grads + pb + P.o_qkv_b, 3 * D, 0, side));
+      sq_next = sq_slot(l, 0);
       RUN(wgrad_side(w.dqkv[pl], xmod1, 3 * D, D, grads + pb + P.o_qkv_w));
     } else {
       RUN(sfron_attn_bwd((const uint16_t*)qkv, (const uint16_t*)o, (const uint16_t*)w.d_o, w.lse + (size_t)l * B * d.H * T,
                          w.delta, (uint16_t*)w.dqkv[pl], B, T, d.H, d.hd, stream));
       produced(3);
       proj_beside();
+      sq_next = sq_slot(l, 0);
       RUN(wgrad_side(w.dqkv[pl], xmod1, 3 * D, D, grads + pb + P.o_qkv_w, grads + pb + P.o_qkv_b));
     }
     if (pair_proj) { (void)hipStreamWaitEvent(ax->side, ax->join2, 0); consumed(2, l); }   // the in-order stream's later events cover proj too

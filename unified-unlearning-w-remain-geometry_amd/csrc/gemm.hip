@@ -172,7 +172,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int row, int c
     float4 o = make_float4(v[0], v[1], v[2], v[3]);
     if (g.accumulate) { const float4 c = *dst; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
     if (g.nt_out & 2) __builtin_nontemporal_store(f32x4{o.x, o.y, o.z, o.w}, reinterpret_cast<f32x4*>(dst));
-    else st16(dst, f32x4{o.x, o.y, o.z, o.w});
+    else *dst = o;
   } else if (EPI == EPI_GELU) {
     bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
     nt_store(reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col), h, g.nt_out & 1);   // read again only by the backward pass
@@ -1013,6 +1013,9 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
       if constexpr (EPI == EPI_DGELU) {                        // the consumers' column-partial reduction meets at two more barriers
         if (g.colpart) { __syncthreads(); __syncthreads(); }
       }
+      if constexpr (EPI == EPI_F32 && A_TR && B_TR) {          // ... and so does the masked sum of squares of a weight gradient
+        if (g.sq_out) { __syncthreads(); __syncthreads(); }
+      }
       return;
     }
   }
@@ -1371,7 +1374,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
       __bf16* const crow = g.Cb + (size_t)(row_b + mt * 16) * g.ldcb;
       if (wide) {
 #pragma unroll
-        for (int np = 0; np < NP; ++np) st16(crow + col_p + np * 32, pair_pack(ob[2 * np], ob[2 * np + 1]));
+        for (int np = 0; np < NP; ++np) *reinterpret_cast<uint4*>(crow + col_p + np * 32) = pair_pack(ob[2 * np], ob[2 * np + 1]);
         if constexpr (NT & 1) *reinterpret_cast<bf16x4*>(crow + col_b + (NT - 1) * 16) = ob[NT - 1];
       } else {
 #pragma unroll
@@ -1437,12 +1440,12 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
         ab[nt] = f2bf4(v);
         if (!wide) nt_store(reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col), ab[nt], g.nt_out & 1);
         const f32x4 x = as4(xr[nt]) + as4(gt[nt]) * v;
-        st16(g.Cf + (size_t)row * g.ldcf + col, x);
+        *reinterpret_cast<f32x4*>(g.Cf + (size_t)row * g.ldcf + col) = x;
       }
       if (wide) {                                  // the bf16 branch output (read again by the backward pass): 16-byte pieces
         __bf16* const arow = g.aux + (size_t)row * g.ldaux;
 #pragma unroll
-        for (int np = 0; np < NP; ++np) st16(arow + col_p + np * 32, pair_pack(ab[2 * np], ab[2 * np + 1]));
+        for (int np = 0; np < NP; ++np) *reinterpret_cast<uint4*>(arow + col_p + np * 32) = pair_pack(ab[2 * np], ab[2 * np + 1]);
         if constexpr (NT & 1) *reinterpret_cast<bf16x4*>(arow + col_b + (NT - 1) * 16) = ab[NT - 1];
       }
     }
@@ -1475,23 +1478,63 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
         }
         __bf16* const crow = g.Cb + (size_t)row * g.ldcb;
 #pragma unroll
-        for (int np = 0; np < NP; ++np) st16(crow + col_p + np * 32, pair_pack(ob[2 * np], ob[2 * np + 1]));
+        for (int np = 0; np < NP; ++np) *reinterpret_cast<uint4*>(crow + col_p + np * 32) = pair_pack(ob[2 * np], ob[2 * np + 1]);
         if constexpr (NT & 1) *reinterpret_cast<bf16x4*>(crow + col_b + (NT - 1) * 16) = ob[NT - 1];
         if constexpr (EPI == EPI_GELU) {
           __bf16* const arow = g.aux + (size_t)row * g.ldaux;
 #pragma unroll
-          for (int np = 0; np < NP; ++np) st16(arow + col_p + np * 32, pair_pack(hb[2 * np], hb[2 * np + 1]));
+          for (int np = 0; np < NP; ++np) *reinterpret_cast<uint4*>(arow + col_p + np * 32) = pair_pack(hb[2 * np], hb[2 * np + 1]);
           if constexpr (NT & 1) *reinterpret_cast<bf16x4*>(arow + col_b + (NT - 1) * 16) = hb[NT - 1];
         }
       }
     }
   } else {
+    // weight gradients (dW = dY^T X, fp32 into the gradient arena): the clip norm's masked sum of squares of this tile, taken from the
+    // accumulators that are about to be stored -- sq_out[workgroup] = sum over the tile of (mask ? dW : 0)^2 (fp64 from the wave sums on,
+    // fixed order: bitwise reproducible).  Replaces the forget stage's pass over the whole block range of the gradient arena
+    // (sweep.hip k_sumsq_masked: 450 M floats + mask bytes, 350 us on the critical stream at DiT-XL/2); the mask bytes (same offsets as
+    // dW: ld = ldcf) are all requested before the first use.  Kernel-uniform branch.
+    [[maybe_unused]] float sq = 0.f;
+    if constexpr (EPI == EPI_F32 && A_TR && B_TR && !BSUM) {
+      if (g.sq_out) {
+        uchar4 mk[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            mk[mt][nt] = g.sq_mask ? *reinterpret_cast<const uchar4*>(g.sq_mask + (size_t)(row_b + mt * 16) * g.ldcf + col_b + nt * 16)
+                                   : make_uchar4(1, 1, 1, 1);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 v = acc[mt][nt] * g.alpha;
+            const uchar4 m4 = mk[mt][nt];
+            sq += (m4.x ? v[0] * v[0] : 0.f) + (m4.y ? v[1] * v[1] : 0.f) + (m4.z ? v[2] * v[2] : 0.f) + (m4.w ? v[3] * v[3] : 0.f);
+          }
+      }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         epilogue_store<EPI>(g, row_b + mt * 16, col_b + nt * 16, acc[mt][nt],
                             PRE_BIAS ? &bias_v[PRE_BIAS ? nt : 0] : LATE_BIAS ? &bias_l[LATE_BIAS ? nt : 0] : nullptr);
+    if constexpr (EPI == EPI_F32 && A_TR && B_TR && !BSUM) {
+      if (g.sq_out) {
+        const double d = wave_sum_d((double)sq);
+        __syncthreads();                                       // every wave is past the main loop: the staging images are free
+        double* red = reinterpret_cast<double*>(smem);
+        if (lane == 0) red[wave] = d;
+        __syncthreads();
+        if (tid == 0) {
+          double t = red[0];
+#pragma unroll
+          for (int w2 = 1; w2 < NW; ++w2) t += red[w2];
+          g.sq_out[blockIdx.x] = t;
+        }
+      }
+    }
   }
 #ifdef SFRON_DEBUG_KNOBS
   if (g.dbg_clk && tid == 0 && blockIdx.y == 0)               // every store of wave 0 issued (not necessarily written)
@@ -1746,6 +1789,13 @@ int dispatch_layout(int a_tr, int b_tr, const GemmArgs& g, hipStream_t s, int fo
 
 extern "C" int sfron_gemm_rowsum_supported(int M, int N, int K) { return rowsum_ok(M, N, K) ? 1 : 0; }
 
+// Weight gradients dW[M][N] = dY[K][M]^T X[K][N] whose automatic tile is the 192 x 192 pipelined one can also leave the masked sum of squares of
+// their output, one fp64 partial per tile: returns the number of partials (M / 192 * N / 192), or 0 when the shape goes another way.
+extern "C" int sfron_gemm_sumsq_partials(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || M % 192 || N % 192 || K % 64) return 0;
+  return (M / 192) * (N / 192);
+}
+
 // EPI_DGELU products dX[M][N] = dY[M][K] W[K][N] (B read transposed) whose automatic tile is one of the 256-row pipelined tiles can
 // also write the per-tile-row column sums of their output: returns the number of partial rows (M / 256), or 0 when the shape goes
 // to another kernel (the caller then uses sfron_colsum)
@@ -1827,6 +1877,13 @@ int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
     SFRON_CHECK_ARG(d->epilogue == SFRON_EPI_DGELU && d->split_k <= 1 && d->tile_hint == 0);
     if (sfron_gemm_dgelu_colpart_rows(d->M, d->N, d->K) == 0) return SFRON_ERR_UNSUPPORTED;
     g.colpart = d->col_partials;
+  }
+  g.sq_mask = nullptr; g.sq_out = nullptr;
+  if (d->sumsq_partials) {  // only the auto-dispatched 192 x 192 weight-gradient tiles form it (sfron_gemm_sumsq_partials)
+    SFRON_CHECK_ARG(d->a_transposed && d->b_transposed && d->epilogue == SFRON_EPI_F32 && d->split_k <= 1 && d->tile_hint == 0 && !d->a_rowsum &&
+                    !d->accumulate);
+    if (sfron_gemm_sumsq_partials(d->M, d->N, d->K) == 0) return SFRON_ERR_UNSUPPORTED;
+    g.sq_mask = d->sumsq_mask; g.sq_out = d->sumsq_partials;
   }
   if (d->a_rowsum) {        // only the auto-dispatched three-slot weight-gradient kernel forms it
     SFRON_CHECK_ARG(d->rowsum_ws && d->a_transposed && d->b_transposed && d->epilogue == SFRON_EPI_F32 && d->split_k <= 1 &&

@@ -36,6 +36,7 @@ __device__ __forceinline__ void load_row_f32(const float* __restrict__ p, int D4
 // Buffer forms: the descriptor covers exactly ONE row, so a lane past the row end (the fifth 16-byte chunk of a 1152-wide row has 32
 // live lanes) loads zeros and its stores are dropped by the hardware bounds check -- no exec masks, no branches, addresses = one
 // scalar descriptor + one lane offset + immediates.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const void* p, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(TPB) void k_ln_mod_fwd(const float* __restrict__ x,
       const float4 h = sh.v[i], g = sc.v[i];
       const bf16x4 o = {f2bf((r[k].v[i].x - mean) * rstd * (1.0f + g.x) + h.x), f2bf((r[k].v[i].y - mean) * rstd * (1.0f + g.y) + h.y),
                         f2bf((r[k].v[i].z - mean) * rstd * (1.0f + g.z) + h.z), f2bf((r[k].v[i].w - mean) * rstd * (1.0f + g.w) + h.w)};
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ro, lane * 8 + 512 * i, 0, SFRON_WT_AUX);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ro, lane * 8 + 512 * i, 0, 0);
     }
   }
 }
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_num_vgpr(SFRON_ROWBWD_VG
         d = make_float4(rstd * (g.x - m1 - xh.x * m2), rstd * (g.y - m1 - xh.y * m2),
                         rstd * (g.z - m1 - xh.z * m2), rstd * (g.w - m1 - xh.w * m2));
         if (a.dx_accumulate) { const float4 p = prev.v[i]; d.x += p.x; d.y += p.y; d.z += p.z; d.w += p.w; }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d), rs_dx, lane * 16 + 1024 * i, 0, SFRON_WT_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d), rs_dx, lane * 16 + 1024 * i, 0, 0);
       } else {
         d = prev.v[i];
       }
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_num_vgpr(SFRON_ROWBWD_VG
         acc[G0 + 1][i].x += d.x; acc[G0 + 1][i].y += d.y; acc[G0 + 1][i].z += d.z; acc[G0 + 1][i].w += d.w;
         const float4 gt = mod4(s_gt, gp, i);
         const bf16x4 o = {f2bf(d.x * gt.x), f2bf(d.y * gt.y), f2bf(d.z * gt.z), f2bf(d.w * gt.w)};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_db, lane * 8 + 512 * i, 0, SFRON_WT_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_db, lane * 8 + 512 * i, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -538,20 +539,25 @@ struct SlotArgs { SlotDst dst[8]; };      // [kind 0..3][buf 0..1]
 
 // One launch for the whole backward pass: slot s = (layer, kind, buf) holds per-chunk partials [B*per][D];
 // out[dst(kind,buf).base + layer*stride + b*ld + c] = sum_j partial[(b*per + j)*D + c]
-__global__ __launch_bounds__(TPB) void k_reduce_slots(const float* __restrict__ parts, long slot_stride, int per, int D, SlotArgs a) {
-  const int slot = blockIdx.z, b = blockIdx.y;
-  const int c = (blockIdx.x * TPB + threadIdx.x) * 4;          // four columns per thread (D % 4 == 0), 16-byte loads
+// A workgroup = one (slot, sample) row: blockDim = D / 4 threads rounded up to whole waves (DiT-XL/2: 288 of 320), a thread owns four columns.
+// Round 5: every partial row of the sample (per <= RS_MAX: 16 at 256 tokens) is requested before the first add -- 16 x 4.6 KB in flight per
+// workgroup instead of 8 per thread behind a 1024-column split that left every second workgroup with 32 live threads: 178 -> ~100 us for the
+// 528 MB of a DiT-XL/2 pass (profiles/r05_stage_boundary.txt).  Summed in index order as before: the same bits.
+constexpr int RS_MAX = 16;
+__global__ __launch_bounds__(512) void k_reduce_slots(const float* __restrict__ parts, long slot_stride, int per, int D, SlotArgs a) {
+  const int slot = blockIdx.y, b = blockIdx.x;
+  const int c = threadIdx.x * 4;                               // four columns per thread (D % 4 == 0), 16-byte loads
   if (c >= D) return;
   const int layer = slot >> 3, kb = slot & 7;
   const float* p = parts + (size_t)slot * slot_stride + (size_t)b * per * D + c;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   int j = 0;
-  for (; j + 8 <= per; j += 8) {                                // eight loads in flight (528 MB per pass at DiT-XL/2: 3.4 TB/s with four), summed in index order
-    float4 v[8];
+  for (; j + RS_MAX <= per; j += RS_MAX) {
+    float4 v[RS_MAX];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(j + u) * D);
+    for (int u = 0; u < RS_MAX; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(j + u) * D);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    for (int u = 0; u < RS_MAX; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
   }
   for (; j + 4 <= per; j += 4) {
     float4 v[4];
@@ -663,7 +669,8 @@ int sfron_reduce_slots(const float* parts, long slot_stride, int n_slots, int gr
   for (int i = 0; i < 8; ++i) a.dst[i] = SlotDst{dst_base[i], dst_layer_stride[i], dst_ld[i]};
   SFRON_CHECK_ARG(D % 4 == 0);
   for (int i = 0; i < 8; ++i) SFRON_CHECK_ARG(((uintptr_t)dst_base[i] & 15) == 0 && dst_layer_stride[i] % 4 == 0 && dst_ld[i] % 4 == 0);
-  hipLaunchKernelGGL(k_reduce_slots, dim3(cdiv(D, 4 * TPB), groups, n_slots), dim3(TPB), 0, (hipStream_t)stream, parts, slot_stride,
+  SFRON_CHECK_ARG(D <= 4 * 512);
+  hipLaunchKernelGGL(k_reduce_slots, dim3(groups, n_slots), dim3(cdiv(D / 4, 64) * 64), 0, (hipStream_t)stream, parts, slot_stride,
                      per_group, D, a);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;

@@ -58,17 +58,54 @@ __global__ __launch_bounds__(TPB) void k_sumsq_masked(const float* __restrict__ 
 }
 
 // stats[0] = total L2 norm, stats[1] = clip coefficient min(1, max_norm/(norm+1e-6)), stats[2] = sum of squares
-__global__ __launch_bounds__(TPB) void k_clip_coef(const double* __restrict__ partials, int nblk, float max_norm,
-                                                   float* __restrict__ stats) {
+// The same partial sums over a TABLE of element ranges of the arenas (tab[r] = {offset, length}, multiples of 4, DEVICE memory): one workgroup and one
+// partial per range.  For what the clip norm still has to read once the weight-gradient GEMMs leave their own masked sums of squares
+// (sfron_gemm_desc.sumsq_partials): biases, embedders, the final layer -- a hundred small ranges in ONE launch.  Ranges of up to ~64 K elements
+// (the host splits longer tensors).
+__global__ __launch_bounds__(TPB) void k_sumsq_ranges(const float* __restrict__ g, const uint8_t* __restrict__ mask, const long long* __restrict__ tab,
+                                                       double* __restrict__ partials) {
   __shared__ double sh[TPB / 64];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < nblk; i += TPB) acc += partials[i];
-  acc = wave_sum_d(acc);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  const long long off = tab[2 * blockIdx.x], n4 = tab[2 * blockIdx.x + 1] >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g + off);
+  const uchar4* m4 = reinterpret_cast<const uchar4*>(mask ? mask + off : nullptr);
+  float acc = 0.f;
+  for (long long i = threadIdx.x; i < n4; i += TPB) {
+    float4 x = g4[i];
+    if (mask) {
+      const uchar4 mk = m4[i];
+      x.x = mk.x ? x.x : 0.f; x.y = mk.y ? x.y : 0.f; x.z = mk.z ? x.z : 0.f; x.w = mk.w ? x.w : 0.f;
+    }
+    acc += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+  }
+  const double d = wave_sum_d((double)acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = d;
   __syncthreads();
   if (threadIdx.x == 0) {
     double t = 0.0;
     for (int i = 0; i < TPB / 64; ++i) t += sh[i];
+    partials[blockIdx.x] = t;
+  }
+}
+
+// 1024 threads, four independent partial sums per thread (the DiT-XL/2 forget stage hands over ~26 000 partials: 24 480 of the rank-(batch)
+// range + the flat ranges'; 256 threads walking them with one dependent add per load took 29 us on the critical stream), fixed order.
+constexpr int CC_TPB = 1024;
+__global__ __launch_bounds__(CC_TPB) void k_clip_coef(const double* __restrict__ partials, int nblk, float max_norm,
+                                                      float* __restrict__ stats) {
+  __shared__ double sh[CC_TPB / 64];
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3 * CC_TPB < nblk; i += 4 * CC_TPB) {
+    const double v0 = partials[i], v1 = partials[i + CC_TPB], v2 = partials[i + 2 * CC_TPB], v3 = partials[i + 3 * CC_TPB];
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+  }
+  for (; i < nblk; i += CC_TPB) a0 += partials[i];
+  double acc = wave_sum_d((a0 + a1) + (a2 + a3));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < CC_TPB / 64; ++w) t += sh[w];
     float norm = (float)sqrt(t);
     float coef = max_norm / (norm + 1e-6f);          // torch: clip_coef = max_norm / (total_norm + 1e-6)
     coef = coef > 1.0f ? 1.0f : coef;                // torch.clamp(clip_coef, max=1.0)
@@ -325,9 +362,17 @@ int sfron_sumsq_masked(const float* g, const float* g2, const uint8_t* mask, int
   return SFRON_OK;
 }
 
+int sfron_sumsq_masked_ranges(const float* g, const uint8_t* mask, const int64_t* ranges, int n_ranges, double* partials, void* stream) {
+  SFRON_CHECK_ARG(g && ranges && partials && n_ranges > 0);
+  SFRON_CHECK_ARG(((uintptr_t)g & 15) == 0 && (!mask || ((uintptr_t)mask & 3) == 0));
+  hipLaunchKernelGGL(k_sumsq_ranges, dim3(n_ranges), dim3(TPB), 0, (hipStream_t)stream, g, mask, (const long long*)ranges, partials);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
 int sfron_clip_coef(const double* partials, int nblk, float max_norm, float* stats, void* stream) {
   SFRON_CHECK_ARG(partials && stats && nblk > 0);
-  hipLaunchKernelGGL(k_clip_coef, dim3(1), dim3(TPB), 0, (hipStream_t)stream, partials, nblk, max_norm, stats);
+  hipLaunchKernelGGL(k_clip_coef, dim3(1), dim3(CC_TPB), 0, (hipStream_t)stream, partials, nblk, max_norm, stats);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

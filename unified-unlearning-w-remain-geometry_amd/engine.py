@@ -334,6 +334,43 @@ class DitEngine:
                                                stream_ptr()), "dit_backward (factored adaLN gradient)")
         return dict(lo=self.layout["ada_w"], NM=dmod.shape[1], D=self.cfg.hidden, dmod=dmod, sc=sc, R=self.cfg.batch)
 
+    # ------------------------------------------------------------------ clip norm taken where the gradients are produced
+    def fused_sumsq_plan(self):
+        """What a single-process forget stage needs so that clip_grad_norm_ (DiT/forget.py:293-298) costs no pass over the block range of the
+        gradient arena: ``n_gemm`` fp64 partials that the next backward pass's weight-gradient GEMMs write (arm_sumsq), and a device table
+        of the element ranges of everything ELSE that is trainable outside the adaLN weight matrix (embedders, label table, adaLN bias, every
+        block's four bias vectors, final layer), split into pieces of at most 64 K elements -- one sfron_sumsq_masked_ranges launch.  None
+        when a block shape does not run on the 192 x 192 weight-gradient tile."""
+        if getattr(self, "_sq_plan", None) is None:
+            n_gemm = _lib.lib().sfron_dit_sumsq_partials_len(ctypes.byref(self.cfg))
+            if n_gemm <= 0:
+                self._sq_plan = False
+            else:
+                lay, c = self.layout, self.cfg
+                D, F, L = c.hidden, c.mlp_hidden, c.depth
+                NM = (6 * L + 2) * D
+                spans = [(0, lay["ada_w"]), (lay["ada_b"], lay["blocks"])]
+                for l in range(L):
+                    b = lay["blocks"] + l * lay["blk_stride"]
+                    spans += [(b + lay["qkv_b"], b + lay["qkv_b"] + 3 * D), (b + lay["proj_b"], b + lay["proj_b"] + D),
+                              (b + lay["fc1_b"], b + lay["fc1_b"] + F), (b + lay["fc2_b"], b + lay["fc2_b"] + D)]
+                spans.append((lay["fin_w"], self.n_trainable))
+                covered = sum(hi - lo for lo, hi in spans) + NM * D + L * (3 * D * D + D * D + 2 * F * D)
+                # arena padding (tensor offsets are multiples of 8) holds zero gradients: a span may include it, none may be missing
+                assert covered <= self.n_trainable and all(lo % 4 == 0 and (hi - lo) % 4 == 0 for lo, hi in spans), "sumsq plan: layout"
+                rows = []
+                for lo, hi in spans:
+                    for s0 in range(lo, hi, 65536):
+                        rows.append((s0, min(65536, hi - s0)))
+                self._sq_plan = dict(n_gemm=int(n_gemm), n_ranges=len(rows),
+                                     ranges=torch.tensor(rows, dtype=torch.int64, device=self.device))
+        return self._sq_plan or None
+
+    def arm_sumsq(self, mask_arena, partials):
+        """One-shot: the next backward pass through this engine leaves the masked sums of squares of its block weight gradients in ``partials``
+        (fp64, fused_sumsq_plan()["n_gemm"] entries)."""
+        check(_lib.lib().sfron_aux_arm_sumsq(self.aux, ptr(mask_arena), ptr(partials)), "aux_arm_sumsq")
+
     def scatter_late_bias(self):
         check(_lib.lib().sfron_dit_scatter_late_bias(ctypes.byref(self.cfg), ptr(self.late_bias), ptr(self.grads), stream_ptr()),
               "dit_scatter_late_bias")

@@ -10,7 +10,8 @@ from ._lib import check, ptr, stream_ptr
 
 def gemm(A, B, M, N, K, *, a_t=False, b_t=False, epilogue=_lib.EPI_BF16, alpha=1.0, bias=None, c_bf16=None,
          c_f32=None, aux=None, gate=None, pos=None, tokens=1, accumulate=False, resid=None, split_k=1, split_stride=0, tile_hint=0,
-         lda=None, ldb=None, ldc_bf16=None, ldc_f32=None, ldaux=None, ldgate=None, a_rowsum=None, col_partials=None):
+         lda=None, ldb=None, ldc_bf16=None, ldc_f32=None, ldaux=None, ldgate=None, a_rowsum=None, col_partials=None,
+         sumsq_partials=None, sumsq_mask=None):
     """C[M,N] = alpha * op(A) op(B) with the epilogues of include/sfron.h.  A/B are bf16 2-D tensors (or views
     described by explicit leading dimensions)."""
     d = _lib.GemmDesc()
@@ -42,7 +43,9 @@ def gemm(A, B, M, N, K, *, a_t=False, b_t=False, epilogue=_lib.EPI_BF16, alpha=1
         d.a_rowsum, d.rowsum_ws = a_rowsum.data_ptr(), ws.data_ptr()
     if col_partials is not None:
         d.col_partials = col_partials.data_ptr()
-    for t in (A, B, c_bf16, c_f32, aux, gate, pos, a_rowsum, col_partials):
+    if sumsq_partials is not None:         # weight-gradient layout: masked sums of squares of the output tiles (sfron_gemm_sumsq_partials)
+        d.sumsq_partials, d.sumsq_mask = sumsq_partials.data_ptr(), ptr(sumsq_mask)
+    for t in (A, B, c_bf16, c_f32, aux, gate, pos, a_rowsum, col_partials, sumsq_partials, sumsq_mask):
         if t is not None and not t.is_cuda:
             raise _lib.SfronError("sfron ops need GPU tensors (no CPU fallback)")
     check(_lib.lib().sfron_gemm_bf16(ctypes.byref(d), stream_ptr()), "gemm_bf16")

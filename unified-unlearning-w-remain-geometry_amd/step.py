@@ -64,6 +64,11 @@ class DiTSFRon:
         # opt-in: the remain-stage sweep of the block ranges runs beside the NEXT step's forget forward pass; step() then returns with it in
         # flight -- read parameters / optimizer state through this runner (state_dict / checkpoint / sync()), not from the raw arenas
         self.sweep_across_steps = False
+        # single-process runs: the forget stage's clip norm (forget.py:293-298) is taken where the gradients are produced -- the block
+        # weight-gradient GEMMs leave the masked sums of squares of their tiles (engine.arm_sumsq), one small launch covers biases /
+        # embedders / final layer, the rank-(batch) adaLN range is summed from its factors: no pass over the 1.8 GB block range of the arena
+        self.fuse_clip_norm = True
+        self._sq_buf = None
         self._ready_owner = None               # (engine, block events) of that sweep, consumed by the next step()'s first forward pass
         self.fp8 = bool(fp8)
         if self.fp8 and model.engine.fp8 is None:
@@ -426,7 +431,18 @@ class DiTSFRon:
                 ready = handles
         if ready is not None:
             eng._sweep_pending = None          # this forward pass waits for the sweep block by block; its backward pass starts behind all of it
+        sq_plan = None
+        if (self.fuse_clip_norm and self.grad_clip is not None and self.micro == 1 and self.factored_ada and not self._dp_active()):
+            sq_plan = eng.fused_sumsq_plan()
+        if sq_plan is not None:
+            need = sq_plan["n_gemm"] + sq_plan["n_ranges"] + ((6 * eng.cfg.depth + 2) * eng.cfg.hidden) // 8
+            if self._sq_buf is None or self._sq_buf.numel() < need:
+                self._sq_buf = torch.empty(need, dtype=torch.float64, device=eng.device)
+            eng.arm_sumsq(self.opt.mask, self._sq_buf[:sq_plan["n_gemm"]])        # consumed by the forget pass's backward
         mse_f, vb_f = self._pass(forget, y_f, sign * self.forget_alpha, factored_ada=True, block_ready=ready, async_exchange=dp_sync)
+        if sq_plan is not None and self.opt.lowrank is not None:
+            self.opt.fused_sumsq = dict(partials=self._sq_buf[:sq_plan["n_gemm"]], buffer=self._sq_buf, ranges=sq_plan["ranges"],
+                                        n_ranges=sq_plan["n_ranges"])
         # The forget-stage AdamW of the 28 block ranges runs on a second stream, on a bounded grid, BESIDE the remain forward pass,
         # which waits for block l's event when it reaches block l; embedders / adaLN / final layer (needed at once) stay on this
         # stream.  Measured (tools/bench_sweep_beside.py): a full-grid sweep beside the GEMM chain gains nothing, one capped at

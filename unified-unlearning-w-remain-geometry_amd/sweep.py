@@ -40,6 +40,11 @@ class FlatAdam:
         # dict(lo=element offset of W [NM][D], NM=, D=, dmod=bf16 [R][NM], sc=bf16 [R][D], R=) -- the gradient arena is NOT read
         # over [lo, lo + NM * D): the sweep forms dmod^T sc itself (csrc/sweep.hip k_adam_lowrank)
         self.lowrank = None
+        # optional (set per step by the caller, cleared by step()): the masked sums of squares of PART of the arena were already written by
+        # the kernels that produced those gradients -- dict(partials=fp64 tensor [n_gemm] (filled on this stream before step() is called),
+        # ranges=int64 device table [n_ranges][2] of the element ranges they do NOT cover, n_ranges=) -- engine.fused_sumsq_plan().  With
+        # `lowrank` set as well the norm pre-pass then reads no gradient of the covered matrices at all.
+        self.fused_sumsq = None
         self.timed = None           # bench.py: a list that receives a (start, end) torch event pair per sweep launch
         L = _lib.lib()
         self._partials = torch.empty(L.sfron_sweep_partials_len(), dtype=torch.float64, device=params.device)
@@ -69,6 +74,20 @@ class FlatAdam:
         L = _lib.lib()
         mask = self.mask if use_mask else None
         s = stream_ptr()
+        fs = self.fused_sumsq
+        if fs is not None:
+            # [GEMM-written partials | ranges | rank-R product]: the first block was filled by the backward pass
+            assert self.g2 is None and self.lowrank is not None, "fused sums of squares: single-chain pass with the factored adaLN gradient"
+            q, n_gemm, n_rng = self.lowrank, fs["partials"].numel(), fs["n_ranges"]
+            buf = fs["buffer"]
+            assert buf.numel() >= n_gemm + n_rng + q["NM"] // 8 and fs["partials"].data_ptr() == buf.data_ptr()
+            check(L.sfron_sumsq_masked_ranges(ptr(self.g), ptr(mask), ptr(fs["ranges"]), n_rng, ptr(buf[n_gemm:]), s), "sumsq_masked_ranges")
+            nblk = ctypes.c_int(0)
+            lo, hi = q["lo"], q["lo"] + q["NM"] * q["D"]
+            check(L.sfron_sumsq_lowrank(ptr(q["dmod"]), ptr(q["sc"]), q["R"], q["NM"], q["D"], ptr(None if mask is None else mask[lo:hi]),
+                                        ptr(buf[n_gemm + n_rng:]), ctypes.byref(nblk), s), "sumsq_lowrank")
+            check(L.sfron_clip_coef(ptr(buf), n_gemm + n_rng + nblk.value, float(max_norm), ptr(self.stats), s), "clip_coef")
+            return
         segs = self._segments()
         need = sum((self.lowrank["NM"] // 8) if lr else L.sfron_sweep_partials_len() for _, _, lr in segs)
         if self._partials.numel() < need:
@@ -186,6 +205,7 @@ class FlatAdam:
                         sweep_range(i, side_p, cap)
                         split["events"][i].record(side)
             self.lowrank = None
+        self.fused_sumsq = None
         if ev is not None:
             ev[1].record()
             # (start, end, whole): whole = a remain-stage step (EMA fused) whose every byte went through the current stream in ONE pass
