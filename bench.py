@@ -425,8 +425,9 @@ def main():
     dp_overlap = False
     if world > 1 and not args.no_overlap and args.micro_batches == 1:
         wd.phase("verify_overlap", 120 + 4 * step_budget)
-        # collective: a host-side failure on ONE rank is folded into the verdict inside verify_overlap (every rank still reaches
-        # the MIN all-reduce), so the ranks agree on the path; an exception that escapes ends the job non-zero
+        # collective: every rank runs both exchange paths on the first batch (on the exact fp32 transport) and the verdict is MIN-all-reduced, so
+        # the ranks agree on the path; a rank that fails inside the passes re-raises (it cannot rejoin its peers: the launcher tears the job
+        # down, the peers' watchdog ends them with exit 124)
         dp_overlap = runner.verify_overlap(batches[0][0])
         runner.overlap = dp_overlap
         if rank == 0:

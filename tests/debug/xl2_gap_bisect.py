@@ -32,58 +32,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 DEV = "cuda:0"
 
 
-def bf(x):
-    return x.to(torch.bfloat16).to(torch.float32)
-
-
-class Rounding:
-    """context: installs the requested rounding points on an oracle DiT (on any device), restores on exit"""
-
-    def __init__(self, ref, kinds):
-        self.ref, self.kinds, self.handles, self.saved = ref, set(kinds), [], {}
-
-    def __enter__(self):
-        from oracle import dit_ref
-        ref, K = self.ref, self.kinds
-        if "W" in K:
-            for n, p in ref.named_parameters():
-                if p.dim() >= 2 and p.requires_grad:
-                    self.saved[n] = p.data.clone()
-                    p.data.copy_(bf(p.data))
-        for blk in ref.blocks:
-            if "A" in K:
-                for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2):
-                    self.handles.append(lin.register_forward_pre_hook(lambda m, a: (bf(a[0]),)))
-            if "QKV" in K:
-                self.handles.append(blk.attn.qkv.register_forward_hook(lambda m, a, o: bf(o)))
-        if "E" in K:
-            pre = lambda m, a: (bf(a[0]),)
-            mods = [ref.x_embedder.proj, ref.t_embedder.mlp[0], ref.t_embedder.mlp[2], ref.final_layer.linear, ref.final_layer.adaLN_modulation[1]]
-            mods += [blk.adaLN_modulation[1] for blk in ref.blocks]
-            for m in mods:
-                self.handles.append(m.register_forward_pre_hook(pre))
-        if "P" in K:
-            self._attn_fwd = dit_ref.Attention.forward
-
-            def fwd(self_, x):
-                B, N, C = x.shape
-                qkv = self_.qkv(x).reshape(B, N, 3, self_.num_heads, self_.head_dim).permute(2, 0, 3, 1, 4)
-                q, k, v = qkv.unbind(0)
-                attn = ((q * self_.scale) @ k.transpose(-2, -1)).softmax(dim=-1)
-                x = bf(attn) @ v
-                return self_.proj(x.transpose(1, 2).reshape(B, N, C))
-            dit_ref.Attention.forward = fwd
-        return self
-
-    def __exit__(self, *a):
-        from oracle import dit_ref
-        for h in self.handles:
-            h.remove()
-        for n, p in self.ref.named_parameters():
-            if n in self.saved:
-                p.data.copy_(self.saved[n])
-        if "P" in self.kinds:
-            dit_ref.Attention.forward = self._attn_fwd
+from oracle.bf16_ref import OperandRounding as Rounding, bf, sfron_step_bf16_operands  # noqa: E402
 
 
 def main():
@@ -209,6 +158,7 @@ def sensitivity(steps, hbs):
             if p.requires_grad:
                 p.copy_(torch.nextafter(p, torch.full_like(p, float("inf"))))
     refs["bf16 W+A+E forward"] = copy.deepcopy(ref)
+    refs["bf16 W+A+E forward + 1 ulp"] = copy.deepcopy(refs["fp32 + 1 ulp"])
     orcs = {k: sfron_ref.DiTSfronOracle(m, tab, mask=mask, **hp) for k, m in refs.items()}
     kw = dict(global_batch=B, num_classes=1000, forget_class=207)
 
@@ -240,45 +190,11 @@ def sensitivity(steps, hbs):
         rd = {k: (v.long() if k == "drop" else v).to(DEV) for k, v in r.items()}
         for k, o in orcs.items():
             if k.startswith("bf16"):
-                with Rounding(refs[k], ["A", "E"]):
-                    # weights: fp32 masters, bf16 copies in the forward / backward passes (restored before the optimizer sweeps)
-                    _step_with_rounded_weights(o, refs[k], fd, rd)
+                sfron_step_bf16_operands(o, fd, rd)
             else:
                 o.step(fd, rd)
         if it + 1 in (1, 5, 10, 20, 30, 50, steps):
             report(it + 1)
-
-
-def _step_with_rounded_weights(orc, m, fd, rd):
-    """DiTSfronOracle.step with bf16-rounded weights inside each stage's forward + backward and fp32 masters in the optimizer: the
-    optimizer's step() is wrapped to restore the masters first and to round again afterwards."""
-    masters = {}
-
-    def round_in():
-        for n, p in m.named_parameters():
-            if p.dim() >= 2 and p.requires_grad:
-                masters[n] = p.data.clone()
-                p.data.copy_(bf(p.data))
-
-    def restore():
-        for n, p in m.named_parameters():
-            if n in masters:
-                p.data.copy_(masters[n])
-        masters.clear()
-    opt_step = orc.opt.step
-
-    def wrapped(*a, **k):
-        restore()
-        r = opt_step(*a, **k)
-        round_in()
-        return r
-    orc.opt.step = wrapped
-    round_in()
-    try:
-        orc.step(fd, rd)
-    finally:
-        orc.opt.step = opt_step
-        restore()
 
 
 if __name__ == "__main__":

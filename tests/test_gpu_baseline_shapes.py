@@ -228,9 +228,11 @@ def test_xl2_batch32_forward_backward_vs_oracle():
         norms_b += gb.double().pow(2).sum().item()
     cos = dots / (norms_a ** 0.5 * norms_b ** 0.5)
     print(f"DiT-XL/2 B=32: output rel-L2 {e_out:.3e}; worst per-tensor gradient rel-L2 {worst:.3e} ({worst_name}); cosine {cos:.6f}")
-    assert e_out < 1.5e-2, e_out
-    assert worst < 4e-2, (worst_name, worst)
-    assert cos > 0.9995, cos
+    # bounds = 2 x measured on MI355X (output rel-L2 2.8e-3, worst per-tensor gradient 6.2e-3, 1 - cosine 6e-6; VERDICT r4 weak #2: the
+    # bounds of the small cases, 1.5e-2 / 4e-2 / 0.9995, were 5-6 x what this size measures)
+    assert e_out < 6e-3, e_out
+    assert worst < 1.3e-2, (worst_name, worst)
+    assert cos > 0.99998, cos
 
 
 B4 = dict(input_size=32, patch_size=4, in_channels=4, hidden_size=768, depth=12, num_heads=12, num_classes=1000)
@@ -390,3 +392,112 @@ def test_xl2_ten_sfron_iterations_vs_oracle():
     assert gap < 1e-3 and gap0 < 5e-4, (gap0, gap)
     assert worst < 3e-3, worst          # per-step training-batch mse on 4 samples (bf16 forward noise on a loss of O(1))
     assert runner.opt.step_count == 20
+
+
+def test_xl2_fifty_sfron_iterations_vs_oracles():
+    """The north-star acceptance WHERE IT IS STATED -- DiT-XL/2, 50 SFR-on iterations (DiT/forget.py:256-322), held-out eps-pred MSE
+    (gaussian_diffusion.py:746-783 "mse") against the reference path -- with the reason for what is found (bisect and
+    sensitivity runs: tests/debug/xl2_gap_bisect.py, table in DESIGN.md section 3).
+
+    Three trajectories from the same weights over the same 50 batches (batch 4; hyper-parameters of the ten-iteration test above):
+      HIP      the fused runner (bf16 GEMM operands as north_star prescribes, fp32 everything else)
+      fp32     oracle.sfron_ref.DiTSfronOracle, fp32 throughout -- the reference path
+      bf16-op  the same oracle with bf16-rounded weights and product inputs in its forward / backward passes and fp32 masters in the
+               optimizer (oracle/bf16_ref.py): what the prescribed operand type alone does to the reference
+    The two oracles run on the GPU in fp32 (same torch modules as on the CPU; checked here: one forward pass on both devices agrees to 1e-6)
+    so that 2 x 50 iterations of DiT-XL/2 take a minute instead of ten.
+
+    Measured on MI355X (mean over 4 held-out batches of 16): the bf16-op oracle is 1.3e-4 from the fp32 oracle before any step (the WEIGHT
+    rounding: 1.07e-4 of it) and 7e-4 ... 9e-4 after 50 steps of a trajectory along which the held-out MSE itself moves 1.44 -> 0.50; the HIP
+    path follows the bf16-op oracle to 2e-6 ... 1.6e-4 over the checkpoints.  That is also how far two runs of the bf16-op ORACLE ITSELF end up
+    from each other (-7.1e-4 and -9.1e-4 at step 50 in two runs that differ only in the order of torch's fp32 atomics in the embedding
+    backward; tests/debug/xl2_gap_bisect.py --sensitivity perturbs one ulp deliberately): a 1e-7 perturbation flips bf16 roundings of
+    weights, each flip is a 2^-8 relative step.  The fp32 trajectory is NOT chaotic (one ulp on every initial weight moves it by < 3e-7 at
+    every checkpoint), so with fp32 operands the north-star's 1e-4 would be a meaningful bound at this size; with the bf16 operands it
+    prescribes, the reference's own trajectory is only defined to ~2e-4 here, and 1e-4 is met where the loss moves slowly (BASELINE config 2,
+    test_dit_b4_fifty_step_eps_mse_within_1e4_of_oracle: 1.1e-5).  Asserted:
+      * HIP against the bf16-op oracle at every checkpoint: 3e-4 (2 x the worst measured, = the bf16-op oracle's own run-to-run spread);
+      * HIP against the fp32 oracle: no further than the bf16-op oracle is + 3e-4 (the operand type's cost, not the implementation's);
+      * the operand type's own cost is not zero (> 5e-5 before any step, > 2e-4 after 50): the header's claim is checked, not assumed."""
+    import copy
+    from oracle import bf16_ref
+    from oracle import diffusion_ref as dref
+    from oracle import sfron_ref
+    from sfron import data, diffusion, step
+    B = 4
+    ref, model = _pair("DiT-XL/2", B, seed=51, std=0.02)
+    tab = dref.DiffusionTables(1000)
+    hbs = [data.synthetic_batch(24 + i, 0, "remain", global_batch=16, num_classes=1000, forget_class=207) for i in range(4)]
+    # the oracle on the CPU (the contract) and the same modules on the GPU
+    ref.eval()
+    with torch.no_grad():
+        c4 = {k: v[:4] for k, v in hbs[0].items()}
+        t_cpu = dref.training_losses(tab, lambda x, t, y: ref(x, t, y), c4["x0"], c4["t"], dict(y=c4["y"]), c4["noise"])["mse"]
+        ref.to(DEV)
+        g4 = {k: v.to(DEV) for k, v in c4.items()}
+        t_gpu = dref.training_losses(tab, lambda x, t, y: ref(x, t, y), g4["x0"], g4["t"], dict(y=g4["y"]), g4["noise"])["mse"].cpu()
+    assert (t_cpu - t_gpu).abs().max().item() < 1e-6, (t_cpu, t_gpu)
+    ref.train()
+    model.train()
+    refb = copy.deepcopy(ref)
+    gm = torch.Generator().manual_seed(52)
+    mask = {"module." + n: (torch.rand(p.shape, generator=gm) < 0.5) for n, p in ref.named_parameters() if p.requires_grad}
+    mask["module.pos_embed"] = 0
+    mask_dev = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in mask.items()}
+    hp = dict(lr=1e-4, forget_alpha=1e-3, grad_clip=1.0, ema_decay=0.9999, unlearn_loss="ga", forget_class=207)
+    orc = sfron_ref.DiTSfronOracle(ref, tab, mask=mask_dev, **hp)
+    orcb = sfron_ref.DiTSfronOracle(refb, tab, mask=mask_dev, **hp)
+    d = diffusion.create_diffusion("")
+    runner = step.DiTSFRon(model, d, mask=mask, **hp)
+    kw = dict(global_batch=B, num_classes=1000, forget_class=207)
+
+    def held_oracle(m, rounded):
+        m.eval()
+        vals = []
+        with torch.no_grad():
+            for hb in hbs:
+                g = {k: v.to(DEV) for k, v in hb.items()}
+                fn = lambda: dref.training_losses(tab, lambda x, t, y: m(x, t, y), g["x0"], g["t"], dict(y=g["y"]), g["noise"])["mse"].mean().item()
+                if rounded:
+                    with bf16_ref.OperandRounding(m, ("W", "A", "E")):
+                        vals.append(fn())
+                else:
+                    vals.append(fn())
+        m.train()
+        return sum(vals) / len(vals)
+
+    def held_hip():
+        model.eval()
+        vals = []
+        with torch.no_grad():
+            for hb in hbs:
+                g = {k: v.to(DEV) for k, v in hb.items()}
+                out = model(d.q_sample(g["x0"], g["t"], g["noise"]), g["t"], g["y"])
+                vals.append(d.loss_fwd_bwd(out.contiguous(), g["x0"], g["t"], g["noise"], 1.0)[0].mean().item())
+        model.train()
+        model.set_batch_size(B)
+        return sum(vals) / len(vals)
+
+    rows = []
+
+    def checkpoint(it):
+        f32, b16, hip = held_oracle(ref, False), held_oracle(refb, True), held_hip()
+        rows.append((it, f32, b16 - f32, hip - f32, hip - b16))
+        print(f"DiT-XL/2 after {it:2d} iterations: held-out eps-MSE fp32 oracle {f32:.5f} | bf16-operand oracle {b16 - f32:+.2e} | HIP {hip - f32:+.2e} | "
+              f"HIP - bf16-operand oracle {hip - b16:+.2e}", flush=True)
+    checkpoint(0)
+    for it in range(50):
+        f, r = data.synthetic_batch(23, it, "forget", **kw), data.synthetic_batch(23, it, "remain", **kw)
+        fd, rd = {k: v.to(DEV) for k, v in f.items()}, {k: v.to(DEV) for k, v in r.items()}
+        fo, ro = ({k: v.long() if k == "drop" else v for k, v in b.items()} for b in (fd, rd))
+        orc.step(fo, ro)
+        bf16_ref.sfron_step_bf16_operands(orcb, fo, ro)
+        runner.step(fd, rd)
+        if it + 1 in (10, 20, 30, 50):
+            checkpoint(it + 1)
+    runner.guard.poll(block=True)
+    assert runner.opt.step_count == 100
+    for it, f32, d_b16, d_hip, d_hb in rows:
+        assert abs(d_hb) < 3e-4, (it, d_hb)
+        assert abs(d_hip) < abs(d_b16) + 3e-4, (it, d_hip, d_b16)
+    assert abs(rows[0][2]) > 5e-5 and abs(rows[-1][2]) > 2e-4      # the operand type's own cost is what the header says it is (not zero)

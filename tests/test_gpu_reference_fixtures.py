@@ -37,16 +37,20 @@ def _proj(t, name):
 
 def _check_grads(named_grads, G, tol, what):
     """every gradient tensor against the reference's norm and seeded projection (|<g - g_ref, r>| <= tol * |g_ref| * O(1): r is
-    a unit-variance Gaussian vector, so the projection of an error of relative size e is ~ e * |g_ref|), ten tensors element-wise"""
+    a unit-variance Gaussian vector, so the projection of an error of relative size e is ~ e * |g_ref|), ten tensors element-wise.
+    Prints the worst measured value of each kind (what `tol` is set from: 2 x the worst)."""
     names, norms, projs = list(G["grad_names"]), G["grad_norms"], G["grad_proj"]
     gmax = float(norms.max())
     seen = 0
+    w_norm = w_proj = w_elem = 0.0
     for n, gn, gp in zip(names, norms, projs):
         g = named_grads[str(n)]
         assert g is not None and torch.isfinite(g).all(), n
         if gn < 1e-3 * gmax:                      # (near-)zero gradients: compared by magnitude
             assert g.norm().item() < 3e-2 * gmax + 3 * gn, (what, n, g.norm().item(), gn)
             continue
+        w_norm = max(w_norm, abs(g.double().norm().item() - gn) / gn)
+        w_proj = max(w_proj, abs(_proj(g, str(n)) - gp) / (4.0 * gn))
         assert abs(g.double().norm().item() - gn) < tol * gn, (what, n, g.norm().item(), gn)
         assert abs(_proj(g, str(n)) - gp) < 4.0 * tol * gn, (what, n, _proj(g, str(n)), gp, gn)
         seen += 1
@@ -57,7 +61,10 @@ def _check_grads(named_grads, G, tol, what):
             want = torch.from_numpy(G[k])
             if want.norm().item() < 1e-3 * gmax:
                 continue
+            w_elem = max(w_elem, _rel(named_grads[n], want))
             assert _rel(named_grads[n], want) < tol, (what, n, _rel(named_grads[n], want))
+    print(f"{what} gradients vs the reference fixture: worst norm error {w_norm:.2e}, worst projection error / 4 {w_proj:.2e}, worst element-wise "
+          f"rel-L2 {w_elem:.2e} (bound {tol:.1e})")
 
 
 
@@ -284,9 +291,12 @@ def test_sd_unet_forward_backward_vs_reference_fixture():
             assert _rel(grads[k[len("grad/"):]], G[k]) < 6e-2, (k, _rel(grads[k[len("grad/"):]], G[k]))
 
 
-# bounds = 2 x the worst value measured on MI355X (round 5; tests/debug/print_update_cosines.py prints the per-tensor numbers)
-SD_UPDATE_COS_MIN = {"xattn": 0.90, "full": 0.90}
-SD_UPDATE_NORM_TOL = {"xattn": 0.05, "full": 0.05}
+# bounds = 2 x the worst value measured on MI355X (round 5; tests/debug/print_update_cosines.py prints the per-tensor numbers: "xattn" 35
+# tensors, min cosine 0.9743, norm ratios within 1.5 %; "full" 273 tensors, min cosine 0.9435, norm ratios within 6.0 %).  Looser than the
+# DiT / DDPM trajectories: the forget-stage loss of this script is an MSE between two eps-predictions of the SAME network (0.0066 here), so
+# its gradients are small differences of bf16-rounded activations which Adam normalises to full-size steps.
+SD_UPDATE_COS_MIN = {"xattn": 0.949, "full": 0.887}
+SD_UPDATE_NORM_TOL = {"xattn": 0.031, "full": 0.12}
 
 
 @pytest.mark.parametrize("method", ["xattn", "full"])

@@ -174,7 +174,10 @@ def test_sd_unet_forward_backward_vs_oracle(cfg, B, S, Lc):
     _compare_unet(ref, model, x, t, ctx, w, f"SD UNet mc={cfg['model_channels']} B={B} {S}x{S} ctx {Lc}")
 
 
-SD_ORACLE_UPDATE_COS_MIN, SD_ORACLE_UPDATE_NORM_TOL = 0.90, 0.05       # 2 x worst measured on MI355X (round 5), see the print below
+# 2 x the worst per-tensor value measured on MI355X (round 5; printed by the test): xattn / as_written min cosine 0.9870, norm ratios within
+# 1.7 %; full / intended min cosine 0.9117 (out.2.bias), norm ratios within 3.3 %
+SD_ORACLE_UPDATE_COS_MIN = {"xattn": 0.974, "full": 0.823}
+SD_ORACLE_UPDATE_NORM_TOL = {"xattn": 0.034, "full": 0.066}
 
 
 @pytest.mark.parametrize("method,mask_mode", [("xattn", "as_written"), ("full", "intended")])
@@ -232,8 +235,8 @@ def test_sd_nsfw_removal_iterations_vs_oracle(method, mask_mode):
             worst_cos = (cos, n)
         if abs(ratio - 1.0) > abs(worst_ratio[0] - 1.0) or worst_ratio[1] is None:
             worst_ratio = (ratio, n)
-        assert cos >= SD_ORACLE_UPDATE_COS_MIN, (n, cos)
-        assert abs(ratio - 1.0) < SD_ORACLE_UPDATE_NORM_TOL, (n, ratio)
+        assert cos >= SD_ORACLE_UPDATE_COS_MIN[method], (n, cos)
+        assert abs(ratio - 1.0) < SD_ORACLE_UPDATE_NORM_TOL[method], (n, ratio)
     print(f"SD {method}/{mask_mode}: min per-tensor update cosine {worst_cos[0]:.4f} ({worst_cos[1]}), worst norm ratio {worst_ratio[0]:.4f} ({worst_ratio[1]})")
 
 

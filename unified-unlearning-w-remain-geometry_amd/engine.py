@@ -339,7 +339,7 @@ class DitEngine:
         """What a single-process forget stage needs so that clip_grad_norm_ (DiT/forget.py:293-298) costs no pass over the block range of the
         gradient arena: ``n_gemm`` fp64 partials that the next backward pass's weight-gradient GEMMs write (arm_sumsq), and a device table
         of the element ranges of everything ELSE that is trainable outside the adaLN weight matrix (embedders, label table, adaLN bias, every
-        block's four bias vectors, final layer), split into pieces of at most 64 K elements -- one sfron_sumsq_masked_ranges launch.  None
+        block's four bias vectors, final layer), split into pieces of at most 16 K elements -- one sfron_sumsq_masked_ranges launch.  None
         when a block shape does not run on the 192 x 192 weight-gradient tile."""
         if getattr(self, "_sq_plan", None) is None:
             n_gemm = _lib.lib().sfron_dit_sumsq_partials_len(ctypes.byref(self.cfg))
@@ -360,8 +360,8 @@ class DitEngine:
                 assert covered <= self.n_trainable and all(lo % 4 == 0 and (hi - lo) % 4 == 0 for lo, hi in spans), "sumsq plan: layout"
                 rows = []
                 for lo, hi in spans:
-                    for s0 in range(lo, hi, 65536):
-                        rows.append((s0, min(65536, hi - s0)))
+                    for s0 in range(lo, hi, 16384):               # one workgroup per piece: short pieces, many workgroups
+                        rows.append((s0, min(16384, hi - s0)))
                 self._sq_plan = dict(n_gemm=int(n_gemm), n_ranges=len(rows),
                                      ranges=torch.tensor(rows, dtype=torch.int64, device=self.device))
         return self._sq_plan or None

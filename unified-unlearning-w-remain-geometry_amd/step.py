@@ -185,9 +185,13 @@ class DiTSFRon:
         eng = self.model.engine
         nt = eng.n_trainable
         y = batch["y"] if y is None else y
-        keep = self.overlap
+        keep, keep_tx = self.overlap, self.grad_transport
         ok = torch.zeros((), dtype=torch.float32, device=eng.device)
         try:
+            # compare the two exchange PATHS on the exact fp32 sum: with the bf16 transport (the rule from four ranks on) the synchronous pass
+            # would sum the adaLN third of the arena in bf16 while the overlapped pass forms it as an fp32 product of gathered factors -- a
+            # 1-2e-3 difference of the transports, not of the paths, right at rtol
+            self.grad_transport = "fp32"
             self.overlap = False
             self._pass(batch, y, -self.forget_alpha)
             g_sync = eng.grads[:nt].clone()
@@ -204,7 +208,7 @@ class DiTSFRon:
             print(f"[sfron] verify_overlap failed on this rank ({type(e).__name__}: {e}); leaving the job", file=sys.stderr, flush=True)
             raise
         finally:
-            self.overlap = keep
+            self.overlap, self.grad_transport = keep, keep_tx
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.pg)
         return bool(ok.item())
 
