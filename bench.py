@@ -293,9 +293,9 @@ def dp_evidence(runner, model, diff, batch0, dev, rank, world, strict_tol=None):
     K = 1 << 20
     idx = torch.arange(0, nt, max(1, nt // K), device=dev)[:K]
     local = eng.grads[:nt][idx].clone()
-    allg = torch.empty(world, local.numel(), dtype=torch.float32, device=dev)
+    allg = torch.empty(world * local.numel(), dtype=torch.float32, device=dev)       # flat: gloo checks the chunk shape against the input's
     dist.all_gather_into_tensor(allg, local, group=runner.pg)
-    want = allg.double().sum(0)
+    want = allg.view(world, -1).double().sum(0)
     runner._pass(f0, f0["y"], -runner.forget_alpha)            # the runner's own exchange (adaLN product formed from gathered factors)
     got = eng.grads[:nt][idx].double()
     rel = ((got - want).norm() / (want.norm() + 1e-300)).float()
@@ -305,8 +305,9 @@ def dp_evidence(runner, model, diff, batch0, dev, rank, world, strict_tol=None):
     runner.sync_sweep()
     bits = eng.params.view(torch.int32).to(torch.int64)
     chk = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=dev) % 8191 + 1)).sum()])
-    chks = torch.empty(world, 2, dtype=torch.int64, device=dev)
+    chks = torch.empty(world * 2, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(chks, chk, group=runner.pg)
+    chks = chks.view(world, 2)
     same = bool((chks == chks[0:1]).all().item())
     # ---- one stream's exchange alone
     g = eng.grads[:nt].clone()
@@ -529,7 +530,11 @@ def main():
     dp_ev = None
     if world > 1 and not args.no_dp_evidence and args.micro_batches == 1:
         wd.phase("dp evidence", 180 + 8 * step_budget)
-        dp_ev = dp_evidence(runner, model, diff, batches[0][0], dev, rank, world)
+        try:
+            dp_ev = dp_evidence(runner, model, diff, batches[0][0], dev, rank, world)
+        except Exception as e:      # noqa: BLE001 -- the timed result above stands; a one-sided failure leaves the peers to the watchdog
+            dp_ev = {"ok": False, "error": f"{type(e).__name__}: {str(e)[:300]}"}
+            print(f"[bench] rank {rank}: dp evidence failed: {dp_ev['error']}", file=sys.stderr, flush=True)
     check_res = None
     if args.check and world > 1:
         wd.phase("check", 180 + 8 * step_budget)

@@ -216,6 +216,15 @@ int sfron_gemm_bf16(const sfron_gemm_desc* desc /* HOST pointer */, void* stream
 int sfron_gemm_dgelu_colpart_rows(int M, int N, int K);
 /* 1 when a weight-gradient GEMM dW[M][N] = dY[K][M]^T X[K][N] of this shape can also produce a_rowsum (else use sfron_colsum) */
 int sfron_gemm_rowsum_supported(int M, int N, int K);
+/* Finish of a split-K product (sfron_gemm_desc.split_k > 1 leaves n_splits fp32 slabs, split_stride elements apart): the slabs summed in index
+ * order (bitwise reproducible) and written (a) as bf16 [n] -- an input gradient that the next product reads as its operand (autograd of the
+ * nn.Linear layers, DiT/models.py:108-121) -- or (b) through the gated-residual epilogue of the forward proj / fc2 products (models.py:120-121):
+ * v = sum + bias; branch (bf16 [M][N]) = v; out (fp32 [M][N]) = resid + gate[(row / tokens) * ldgate + col] * v.  n_splits <= 8.  What the
+ * few-tile products of a small batch * tokens (BASELINE config 2: DiT-B/4, 2048 token rows) use to fill the chip (csrc/dit_engine.hip). */
+int sfron_split_sum_bf16(const float* slabs, int n_splits, int64_t n, int64_t split_stride, uint16_t* out, void* stream);
+int sfron_split_gate_res(const float* slabs, int n_splits, int64_t split_stride, const float* bias, const float* gate, int ldgate, int tokens,
+                         const float* resid, float* out, uint16_t* branch, int M, int N, void* stream);
+
 /* number of fp64 partials a weight-gradient GEMM dW[M][N] = dY[K][M]^T X[K][N] of this shape writes to sumsq_partials, 0 = shape unsupported */
 int sfron_gemm_sumsq_partials(int M, int N, int K);
 

@@ -369,3 +369,49 @@ def test_sumsq_partials_refused_where_the_shape_takes_another_tile():
     C, part = torch.empty(128, 192, device=DEV), torch.zeros(4, dtype=torch.float64, device=DEV)
     with pytest.raises(_lib.SfronError):
         ops.gemm(dY, X, 128, 192, 256, a_t=True, b_t=True, epilogue=_lib.EPI_F32, c_f32=C, sumsq_partials=part)
+
+
+@pytest.mark.parametrize("K,S", [(768, 6), (3072, 8), (2304, 6)])
+def test_split_k_products_with_their_finish_kernels(K, S):
+    """Few-tile products of a small batch * tokens (BASELINE config 2: [2048 x 768] outputs = 32 tiles of 256 x 192): the contraction split over S
+    workgroups per tile on the pipelined tile + sfron_split_sum_bf16 (an input gradient as the next product's bf16 operand) /
+    sfron_split_gate_res (the gated-residual epilogue of the forward proj / fc2 products, DiT/models.py:120-121), against the one-launch
+    products with the same epilogues: the same sums in another order (fp32 1e-5; bf16 one rounding), twice the same bits."""
+    from sfron import _lib, ops
+    from sfron._lib import check, ptr, stream_ptr
+    M, N, T = 2048, 768, 64
+    g = torch.Generator(device=DEV).manual_seed(K)
+    X = torch.randn(M, K, generator=g, device=DEV).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g, device=DEV) * 0.03).to(torch.bfloat16)
+    Wt = (torch.randn(K, N, generator=g, device=DEV) * 0.03).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g, device=DEV) * 0.1
+    gate = torch.randn(M // T, N, generator=g, device=DEV)
+    resid = torch.randn(M, N, generator=g, device=DEV)
+    L = _lib.lib()
+    slabs = torch.empty(S, M, N, dtype=torch.float32, device=DEV)
+    # (a) forward layout + gated residual
+    x1, a1 = torch.empty(M, N, device=DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(X, W, M, N, K, epilogue=_lib.EPI_GATE_RES, bias=bias, c_f32=x1, resid=resid, aux=a1, gate=gate, ldgate=N, tokens=T)
+    outs = []
+    for _ in range(2):
+        slabs.fill_(float("nan"))
+        ops.gemm(X, W, M, N, K, epilogue=_lib.EPI_F32, c_f32=slabs, ldc_f32=N, split_k=S, split_stride=M * N)
+        x2, a2 = torch.empty(M, N, device=DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        check(L.sfron_split_gate_res(ptr(slabs), S, M * N, ptr(bias), ptr(gate), N, T, ptr(resid), ptr(x2), ptr(a2), M, N, stream_ptr()), "split_gate_res")
+        torch.cuda.synchronize()
+        outs.append((x2, a2))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.isfinite(outs[0][0]).all()
+    assert ((outs[0][0] - x1).norm() / x1.norm()).item() < 1e-5
+    assert ((outs[0][1].float() - a1.float()).norm() / a1.float().norm()).item() < 3e-3
+    # (b) input-gradient layout (W read transposed) + bf16 finish
+    dY = X
+    want = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(dY, Wt, M, N, K, b_t=True, c_bf16=want)
+    slabs.fill_(float("nan"))
+    ops.gemm(dY, Wt, M, N, K, b_t=True, epilogue=_lib.EPI_F32, c_f32=slabs, ldc_f32=N, split_k=S, split_stride=M * N)
+    got = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    check(L.sfron_split_sum_bf16(ptr(slabs), S, M * N, M * N, ptr(got), stream_ptr()), "split_sum_bf16")
+    ref32 = dY.float() @ Wt.float()
+    assert ((got.float() - ref32).norm() / ref32.norm()).item() < 4e-3
+    assert ((got.float() - want.float()).norm() / want.float().norm()).item() < 4e-3

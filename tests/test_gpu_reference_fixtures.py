@@ -11,7 +11,7 @@ SD/ldm/modules/diffusionmodules/openaimodel.py:428-846) at shapes the HIP kernel
                 the nsfw_removal.py:108-173 loop body (xattn)
 The weights are inputs: regenerated here with the generator the fixture script used (oracle classes under a seed) and checked
 against the fixture's per-tensor sums before use.  Tolerances are those of bf16 GEMM operands (2^-9 per element): outputs
-1.5e-2 rel-L2, per-tensor gradients 4e-2 (DiT) / 6e-2 (U-Nets), stated at each assert."""
+1.5e-2 rel-L2, per-tensor gradients 1.2e-2 (DiT) / 3.5e-2 (DDPM) / 6e-2 (LDM UNet) = 2 x the worst measured, stated at each assert."""
 import math
 import os
 import zlib
@@ -124,7 +124,8 @@ def test_dit_forward_backward_vs_reference_fixture():
     assert _rel(out, G["out_drop"]) < 1.5e-2
     model.zero_grad()
     (out * w).sum().backward()
-    _check_grads({n: p.grad for n, p in model.named_parameters()}, G, 4e-2, "DiT")
+    # 2 x the worst measured on MI355X (round 5: norm 1.3e-3, projection / 4 2.7e-3, element-wise 5.5e-3; the bound was 4e-2)
+    _check_grads({n: p.grad for n, p in model.named_parameters()}, G, 1.2e-2, "DiT")
 
 
 def test_dit_sfron_trajectory_vs_reference_fixture():
@@ -213,7 +214,8 @@ def test_ddpm_unet_forward_backward_vs_reference_fixture():
     out = model(x, t, c, mode="train", cond_drop_prob=0.0)
     assert _rel(out, G["out_train_nodrop"]) < 1.5e-2
     (out * w).sum().backward()
-    _check_grads({n: p.grad for n, p in model.named_parameters()}, G, 6e-2, "DDPM")
+    # 2 x the worst measured on MI355X (round 5: norm 3.6e-3, projection / 4 1.7e-2, element-wise 1.6e-2; the bound was 6e-2)
+    _check_grads({n: p.grad for n, p in model.named_parameters()}, G, 3.5e-2, "DDPM")
 
 
 def test_ddpm_sfron_trajectory_vs_reference_fixture():

@@ -68,6 +68,8 @@ EPI_BF16, EPI_F32, EPI_GELU, EPI_GATE_RES, EPI_DGELU, EPI_POS = range(6)
 _PROTOS["sfron_gemm_bf16"] = (c_int, [POINTER(GemmDesc), _S])
 _PROTOS["sfron_gemm_rowsum_supported"] = (c_int, [c_int, c_int, c_int])
 _PROTOS["sfron_gemm_sumsq_partials"] = (c_int, [c_int, c_int, c_int])
+_PROTOS["sfron_split_sum_bf16"] = (c_int, [_P, c_int, c_int64, c_int64, _P, _S])
+_PROTOS["sfron_split_gate_res"] = (c_int, [_P, c_int, c_int64, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int, _S])
 _PROTOS["sfron_sumsq_masked_ranges"] = (c_int, [_P, _P, _P, c_int, _P, _S])
 _PROTOS["sfron_gemm_dgelu_colpart_rows"] = (c_int, [c_int, c_int, c_int])
 _PROTOS.update({

@@ -79,6 +79,7 @@ struct Workspace {
   float* tok;
   // backward temporaries
   float *dx, *dmod, *d_sc, *d_c, *d_h1s, *delta, *part, *csum, *csum2, *slabs, *wslab, *dysum, *bpart, *bpart_qkv;
+  float* kslab;              // split-K slabs of the few-tile products of a small batch * tokens (small_m_splits), or null
   __bf16 *d_tok, *d_xmod, *d_o, *dmod_bf, *d_c_bf, *d_h1_bf, *dx_bf;
   __bf16 *d_br[2], *d_br2[2], *d_hpre[2], *dqkv[2];   // read by the side stream: double-buffered by block parity so the
                                                        // dgrad chain may run one block ahead of the weight gradients
@@ -96,6 +97,22 @@ inline int wgrad_splits(int N, int K, int Mred) {
   if (s > 4) s = 4;
   while (s > 1 && (Mred / 64) % s) --s;
   return s < 1 ? 1 : s;
+}
+
+// Few-tile products: a [M x N] output with M = batch * tokens small offers the pipelined 256 x 192 tile fewer than 128 workgroups (DiT-B/4 at
+// batch 32: [2048 x 768] = 32 tiles on 256 CUs -- the dispatcher then takes 96 tiles of the register-staged 128 x 128 kernel at 37 us).  Instead the
+// contraction is split over S workgroups per tile (each an even number >= 2 of 64-deep K-tiles: the interleaved schedule), S fp32 slabs are summed in
+// index order by a finish kernel that also applies the epilogue (norm.hip k_split_sum_bf16 / k_split_gate_res).  1 = no split (every DiT-XL/2 shape).
+inline int small_m_splits(int M, int N, int K) {
+  if (M % 256 || N % 192 || K % 128) return 1;
+  if (N % 144 == 0 && K % 192 == 0 && (M / 256) * (N / 144) >= 128) return 1;     // the 256 x 144 three-slot tile fills half the chip by itself
+  const int tiles = (M / 256) * (N / 192);
+  if (tiles >= 128) return 1;
+  int best = 1;
+  const int kt = K / 64;
+  for (int s = 2; s <= 8; ++s)
+    if (kt % s == 0 && (kt / s) % 2 == 0 && tiles * s <= 256) best = s;
+  return best;
 }
 
 inline Workspace make_ws(const Dims& d, char* base) {
@@ -133,6 +150,12 @@ inline Workspace make_ws(const Dims& d, char* base) {
     size_t mx = 0;
     for (auto& sh : shapes) { const size_t n = wgrad_splits((int)sh[0], (int)sh[1], (int)M) * sh[0] * sh[1]; mx = n > mx ? n : mx; }
     w.wslab = (float*)take(mx * 4);
+  }
+  {
+    // the [M x D] outputs that may split: forward proj (K = D) / fc2 (K = F), dgrad qkv (K = 3D) / proj (K = D) / fc1 (K = F)
+    int smax = 1;
+    for (const int k : {d.D, d.F, 3 * d.D}) { const int sp = small_m_splits(d.M, d.D, k); smax = sp > smax ? sp : smax; }
+    w.kslab = smax > 1 ? (float*)take((size_t)smax * M * D * 4) : nullptr;
   }
   w.dysum = (float*)take((L + 1) * 2 * B * D * 4);                       // [L][proj|fc2][B][D] token sums of dy (gated bias grads)
   // per-tile-row partials of the fc1 / qkv bias gradients, written by the kernels that PRODUCE d_hpre / dqkv (double-buffered
@@ -400,6 +423,21 @@ static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const
   g.epilogue = SFRON_EPI_F32; g.bias = params + P.ada_b; g.c_f32 = w.mod; g.ldc_f32 = NM;
   RUN(sfron_gemm_bf16(&g, stream));
 
+  // x_next = x + gate * (X W^T + b), branch output saved for the backward pass (models.py:120-121): one product with the gated-residual
+  // epilogue, or -- few-tile shapes -- a split-K product + its finish kernel
+  auto gate_res = [&](const void* X, const void* W, int K, const float* bias, float* x_next, const float* x_in, __bf16* branch,
+                      const float* gate) -> int {
+    sfron_gemm_desc q = fwd_desc(X, W, M, D, K);
+    const int sp = w.kslab ? small_m_splits(M, D, K) : 1;
+    if (sp > 1) {
+      q.epilogue = SFRON_EPI_F32; q.c_f32 = w.kslab; q.ldc_f32 = D; q.split_k = sp; q.split_stride = (long)M * D;
+      RUN(sfron_gemm_bf16(&q, stream));
+      return sfron_split_gate_res(w.kslab, sp, (int64_t)M * D, bias, gate, NM, T, x_in, x_next, (uint16_t*)branch, M, D, stream);
+    }
+    q.epilogue = SFRON_EPI_GATE_RES; q.bias = bias; q.c_f32 = x_next; q.ldc_f32 = D; q.resid = x_in;
+    q.aux = (uint16_t*)branch; q.ldaux = D; q.gate = gate; q.ldgate = NM; q.tokens = T;
+    return sfron_gemm_bf16(&q, stream);
+  };
   for (int l = 0; l < d.L; ++l) {
     const int64_t pb = P.blocks + (int64_t)l * P.blk_stride;
     // block l's weights may still be under an optimizer sweep that runs on another stream (sfron_dit_forward_after): wait for ITS event
@@ -452,10 +490,7 @@ static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const
     g.bias = params + pb + P.o_qkv_b; g.c_bf16 = (uint16_t*)qkv; g.ldc_bf16 = 3 * D;
     RUN(sfron_gemm_bf16(&g, stream));
     RUN(sfron_attn_fwd((const uint16_t*)qkv, (uint16_t*)o, w.lse + (size_t)l * d.B * d.H * T, d.B, T, d.H, d.hd, stream));
-    g = fwd_desc(o, wb + pb + P.o_proj_w, M, D, D);
-    g.epilogue = SFRON_EPI_GATE_RES; g.bias = params + pb + P.o_proj_b; g.c_f32 = x1; g.ldc_f32 = D; g.resid = x0;
-    g.aux = (uint16_t*)a1; g.ldaux = D; g.gate = mod + 2 * D; g.ldgate = NM; g.tokens = T;
-    RUN(sfron_gemm_bf16(&g, stream));
+    RUN(gate_res(o, wb + pb + P.o_proj_w, D, params + pb + P.o_proj_b, x1, x0, a1, mod + 2 * D));
     // x = x + gate_mlp * mlp(modulate(norm2(x), shift_mlp, scale_mlp))    (models.py:121)
     RUN(sfron_ln_modulate_fwd(x1, mod + 3 * D, mod + 4 * D, NM, T, M, D, (uint16_t*)xmod2, w.mean + (size_t)(2 * l + 1) * M,
                               w.rstd + (size_t)(2 * l + 1) * M, stream));
@@ -467,10 +502,7 @@ static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const
     if (probing) (void)hipEventRecord(pr->ev[2 * pr->used], (hipStream_t)stream);
     RUN(sfron_gemm_bf16(&g, stream));
     if (probing) { (void)hipEventRecord(pr->ev[2 * pr->used + 1], (hipStream_t)stream); pr->used++; }
-    g = fwd_desc(h, wb + pb + P.o_fc2_w, M, D, d.F);
-    g.epilogue = SFRON_EPI_GATE_RES; g.bias = params + pb + P.o_fc2_b; g.c_f32 = x2; g.ldc_f32 = D; g.resid = x1;
-    g.aux = (uint16_t*)a2; g.ldaux = D; g.gate = mod + 5 * D; g.ldgate = NM; g.tokens = T;
-    RUN(sfron_gemm_bf16(&g, stream));
+    RUN(gate_res(h, wb + pb + P.o_fc2_w, d.F, params + pb + P.o_fc2_b, x2, x1, a2, mod + 5 * D));
   }
   // final layer + unpatchify                                              (models.py:138-142,218-231,247-248)
   const float* modf = w.mod + (size_t)6 * d.L * D;
@@ -565,6 +597,18 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     int o = 0;
     for (int i = 0; i < j; ++i) o += sq_cnt[i];
     return sq_partials + (size_t)l * sq_per_block + o;
+  };
+  // dX [M x D] (bf16) = dY [M x N] W [N x D]: one product, or -- few-tile shapes -- a split-K product + its bf16-writing finish
+  auto dgrad_bf16 = [&](const void* dY, const void* W, int N, __bf16* dX) -> int {
+    sfron_gemm_desc q = dgrad_desc(dY, W, M, N, D);
+    const int sp = w.kslab ? small_m_splits(M, D, N) : 1;
+    if (sp > 1) {
+      q.epilogue = SFRON_EPI_F32; q.c_f32 = w.kslab; q.ldc_f32 = D; q.split_k = sp; q.split_stride = (long)M * D;
+      RUN(sfron_gemm_bf16(&q, stream));
+      return sfron_split_sum_bf16(w.kslab, sp, (int64_t)M * D, (int64_t)M * D, (uint16_t*)dX, stream);
+    }
+    q.c_bf16 = (uint16_t*)dX; q.ldc_bf16 = D;
+    return sfron_gemm_bf16(&q, stream);
   };
   // The attention backward needs a whole CU's LDS per workgroup (157 KB), and so does a weight-gradient workgroup (144 KB): beside the
   // 36-tile proj weight gradient it gets 220 CUs = 2.3 rounds of its 512 workgroups.  So proj waits for the attention backward and
@@ -683,9 +727,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
       RUN(wgrad_side(w.d_hpre[pl], xmod2, d.F, D, grads + pb + P.o_fc1_w));
     } else RUN(wgrad_side(w.d_hpre[pl], xmod2, d.F, D, grads + pb + P.o_fc1_w, grads + pb + P.o_fc1_b));
     consumed(1, l);
-    g = dgrad_desc(w.d_hpre[pl], wb + pb + P.o_fc1_w, M, d.F, D);
-    g.c_bf16 = (uint16_t*)w.d_xmod; g.ldc_bf16 = D;
-    RUN(sfron_gemm_bf16(&g, stream));
+    RUN(dgrad_bf16(w.d_hpre[pl], wb + pb + P.o_fc1_w, d.F, w.d_xmod));
     // ---- attention branch: x1 = x0 + gate_msa * proj(attn(qkv(xmod1)))
     before_overwrite(2, l);
     if (fuse) arm(2);
@@ -697,9 +739,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
       RUN(wgrad_side(w.d_br2[pl], o, D, D, grads + pb + P.o_proj_w));
       consumed(2, l);
     }
-    g = dgrad_desc(w.d_br2[pl], wb + pb + P.o_proj_w, M, D, D);
-    g.c_bf16 = (uint16_t*)w.d_o; g.ldc_bf16 = D;
-    RUN(sfron_gemm_bf16(&g, stream));
+    RUN(dgrad_bf16(w.d_br2[pl], wb + pb + P.o_proj_w, D, w.d_o));
     before_overwrite(3, l);
     int proj_rc = SFRON_OK;
     auto proj_beside = [&]() {
@@ -735,9 +775,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     if (block_events && block_events[l]) {                 // block l: the four weight gradients, qkv.bias and fc1.bias are final
       if (hipEventRecord((hipEvent_t)block_events[l], (hipStream_t)side) != hipSuccess) return (int)hipGetLastError();
     }
-    g = dgrad_desc(w.dqkv[pl], wb + pb + P.o_qkv_w, M, 3 * D, D);
-    g.c_bf16 = (uint16_t*)w.d_xmod; g.ldc_bf16 = D;
-    RUN(sfron_gemm_bf16(&g, stream));
+    RUN(dgrad_bf16(w.dqkv[pl], wb + pb + P.o_qkv_w, 3 * D, w.d_xmod));
     if (l > 0) {
       before_overwrite(0, l - 1);
       if (fuse) arm(0);                     // consumed by produced(0) at the top of block l - 1

@@ -1688,7 +1688,7 @@ inline int pick_fast_tile(const GemmArgs& g, int force, int transposed_operands)
     if (force == 32 || force == 35) return tile_fits(g, force - 30) ? force : 0;
     if (force != 0) return 0;
     if (transposed_operands == 2 && tile_fits(g, 5)) return 55;      // 55 -> 45 -> 35 and 42 -> 32 fall back by k-tile count
-    if (transposed_operands == 1 && tile_fits(g, 2)) return 42;
+    if (transposed_operands <= 1 && tile_fits(g, 2)) return 42;      // (round 5: the forward layout too -- few-tile products of a small batch)
     return 0;
   }
   if (force == 21 || force == 22) return tile_fits(g, 2) ? force : 0;            // timing ablations of tile 2

@@ -571,9 +571,72 @@ __global__ __launch_bounds__(512) void k_reduce_slots(const float* __restrict__ 
   *reinterpret_cast<float4*>(d.base + (size_t)layer * d.layer_stride + (size_t)b * d.ld + c) = s;
 }
 
+// ---------------------------------------------------------------- finish of a split-K product (few-tile GEMMs: small batch * tokens)
+// out = sum of the S fp32 slabs in index order (fixed: bitwise reproducible), written as bf16 (an input gradient that the next product
+// reads as its operand) ...
+constexpr int SPLIT_MAX = 8;
+__global__ __launch_bounds__(TPB) void k_split_sum_bf16(const float* __restrict__ slabs, int S, long n4, long stride, __bf16* __restrict__ out) {
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long)gridDim.x * TPB) {
+    float4 v[SPLIT_MAX];
+#pragma unroll
+    for (int s = 0; s < SPLIT_MAX; ++s) v[s] = s < S ? reinterpret_cast<const float4*>(slabs + (size_t)s * stride)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a = v[0];
+#pragma unroll
+    for (int s = 1; s < SPLIT_MAX; ++s)
+      if (s < S) { a.x += v[s].x; a.y += v[s].y; a.z += v[s].z; a.w += v[s].w; }
+    reinterpret_cast<bf16x4*>(out)[i] = bf16x4{f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w)};
+  }
+}
+// ... or through the gated-residual epilogue of the forward proj / fc2 products (DiT/models.py:120-121): v = sum + bias; branch (bf16) = v;
+// x_next = resid + gate[sample] * v -- operation for operation gemm.hip's EPI_GATE_RES on the summed accumulator
+__global__ __launch_bounds__(TPB) void k_split_gate_res(const float* __restrict__ slabs, int S, long stride, const float* __restrict__ bias,
+                                                        const float* __restrict__ gate, int ldgate, int T, const float* __restrict__ resid,
+                                                        float* __restrict__ out, __bf16* __restrict__ branch, int M, int N) {
+  const int n4 = N >> 2;
+  const long tot = (long)M * n4;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < tot; i += (long)gridDim.x * TPB) {
+    const int row = (int)(i / n4), c4 = (int)(i - (long)row * n4);
+    float4 v[SPLIT_MAX];
+#pragma unroll
+    for (int s = 0; s < SPLIT_MAX; ++s) v[s] = s < S ? reinterpret_cast<const float4*>(slabs + (size_t)s * stride)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 x = reinterpret_cast<const float4*>(resid)[i];
+    const float4 gt = reinterpret_cast<const float4*>(gate + (size_t)(row / T) * ldgate)[c4];
+    float4 a = v[0];
+#pragma unroll
+    for (int s = 1; s < SPLIT_MAX; ++s)
+      if (s < S) { a.x += v[s].x; a.y += v[s].y; a.z += v[s].z; a.w += v[s].w; }
+    if (bias) { const float4 b = reinterpret_cast<const float4*>(bias)[c4]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    reinterpret_cast<bf16x4*>(branch)[i] = bf16x4{f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w)};
+    reinterpret_cast<float4*>(out)[i] = make_float4(x.x + gt.x * a.x, x.y + gt.y * a.y, x.z + gt.z * a.z, x.w + gt.w * a.w);
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int sfron_split_sum_bf16(const float* slabs, int n_splits, int64_t n, int64_t split_stride, uint16_t* out, void* stream) {
+  SFRON_CHECK_ARG(slabs && out && n_splits >= 1 && n_splits <= SPLIT_MAX && n > 0 && n % 4 == 0 && split_stride % 4 == 0 && split_stride >= n);
+  SFRON_CHECK_ARG(((uintptr_t)slabs & 15) == 0 && ((uintptr_t)out & 7) == 0);
+  const long n4 = n >> 2;
+  const int grid = (int)(n4 / TPB < 1 ? 1 : (n4 / TPB > 2048 ? 2048 : n4 / TPB));
+  hipLaunchKernelGGL(k_split_sum_bf16, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, slabs, n_splits, n4, (long)split_stride, (__bf16*)out);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_split_gate_res(const float* slabs, int n_splits, int64_t split_stride, const float* bias, const float* gate, int ldgate, int tokens,
+                         const float* resid, float* out, uint16_t* branch, int M, int N, void* stream) {
+  SFRON_CHECK_ARG(slabs && gate && resid && out && branch && n_splits >= 1 && n_splits <= SPLIT_MAX && M > 0 && N > 0 && N % 4 == 0 && tokens > 0);
+  SFRON_CHECK_ARG(split_stride % 4 == 0 && split_stride >= (int64_t)M * N && ldgate % 4 == 0);
+  SFRON_CHECK_ARG((((uintptr_t)slabs | (uintptr_t)gate | (uintptr_t)resid | (uintptr_t)out | (uintptr_t)bias) & 15) == 0 && ((uintptr_t)branch & 7) == 0);
+  const long tot = (long)M * (N >> 2);
+  const int grid = (int)(tot / TPB < 1 ? 1 : (tot / TPB > 2048 ? 2048 : tot / TPB));
+  hipLaunchKernelGGL(k_split_gate_res, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, slabs, n_splits, (long)split_stride, bias, gate, ldgate, tokens,
+                     resid, out, (__bf16*)branch, M, N);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
 
 int sfron_rows_per_chunk(int tokens) { return tokens > 0 ? pick_chunk(tokens).rows : 0; }
 
