@@ -869,6 +869,11 @@ __device__ __forceinline__ void lds_reads_done();
 // addresses -- and reads its fragments from there (asm reads: hipcc would drain vmcnt(0) in front of a builtin LDS read while a DMA is in
 // flight); the activation fragments of ALL k-steps sit in registers (8 VGPRs per k-step: one wave per SIMD, up to 512 registers), so the four
 // waves of a workgroup never meet at a barrier.  Same products in the same order as k_gemm_skinny: the same bits.
+// one 1-KiB LDS-DMA piece: lane l's 16 bytes from rsrc[voff + soff] land at img + 16 l  (a __device__ function: the builtin does not exist in the
+// host pass, and a lambda inside a kernel template is instantiated there too)
+__device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rsrc, __bf16* img, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t*)img, 16, voff, soff, 0, 0);
+}
 template <int KSTEPS, int NSPLIT>
 __global__ __launch_bounds__(256) void k_gemm_skinny2(GemmArgs g, int tpw) {
   constexpr int K = KSTEPS * 32, KS = K / NSPLIT, CPR = KS / 8, NI = 16 * CPR / 64, SU = KSTEPS / NSPLIT;   // stage: 16 rows x KS, NI DMA pieces, SU k-steps
@@ -902,8 +907,7 @@ __global__ __launch_bounds__(256) void k_gemm_skinny2(GemmArgs g, int tpw) {
   auto issue = [&](int tile, int st, int buf) {
     const int soff = (tile * 16 * K + st * KS) * 2;
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t*)(ring + buf * 16 * KS + i * 512), 16, off[i], soff, 0, 0);
+    for (int i = 0; i < NI; ++i) dma_piece(rs, ring + buf * 16 * KS + i * 512, off[i], soff);
   };
   // fragment addresses: k-step ul of a stage reads chunk (4 ul + q) ^ (r & 7) of row r = ((ul >> 1) << 3) + ((4 (ul & 1) + q) ^ (r & 7))
   const unsigned rowb = lds_addr(ring) + 2 * (r * KS);
@@ -970,6 +974,8 @@ inline int launch_skinny2_t(const GemmArgs& g, hipStream_t s) {
 inline int launch_skinny2(const GemmArgs& g, hipStream_t s) {
   return g.K == 1152 ? launch_skinny2_t<36, 2>(g, s) : launch_skinny2_t<8, 1>(g, s);
 }
+template __global__ void k_gemm_skinny2<36, 2>(GemmArgs, int);      // K = 1152 (DiT-XL hidden size): two 18-KiB stages per 16-row tile
+template __global__ void k_gemm_skinny2<8, 1>(GemmArgs, int);       // K = 256 (timestep frequency embedding)
 
 // Where the memory operations of a segment sit among its NM MFMAs.  They used to be spread evenly up to the LAST MFMA, so the
 // `s_waitcnt lgkmcnt(0)` that closes the segment exposed one full LDS latency per k-step on BOTH waves of a SIMD at once (the two
