@@ -874,6 +874,7 @@ __device__ __forceinline__ void lds_reads_done();
 __device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rsrc, __bf16* img, int voff, int soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t*)img, 16, voff, soff, 0, 0);
 }
+constexpr int SK2_TPW_MAX = 16;          // tiles per wave (bias staging in LDS)
 template <int KSTEPS, int NSPLIT>
 __global__ __launch_bounds__(256) void k_gemm_skinny2(GemmArgs g, int tpw) {
   constexpr int K = KSTEPS * 32, KS = K / NSPLIT, CPR = KS / 8, NI = 16 * CPR / 64, SU = KSTEPS / NSPLIT;   // stage: 16 rows x KS, NI DMA pieces, SU k-steps
@@ -885,6 +886,12 @@ __global__ __launch_bounds__(256) void k_gemm_skinny2(GemmArgs g, int tpw) {
   const int t0 = (blockIdx.x * 4 + wave) * tpw, t1 = min(ntiles, t0 + tpw);
   if (t0 >= t1) return;                                                      // wave-uniform; no barrier anywhere in this kernel
   __bf16* const ring = sk2 + (size_t)wave * 2 * 16 * KS;
+  // the bias columns of this wave's tiles go to LDS BEFORE the first DMA piece is issued: a global load in the epilogue would sit behind the
+  // pieces of the next stage in the wave's in-order vector-memory queue, and waiting for it would drain the ring (measured: 2.7 TB/s, the
+  // round-4 kernel's rate, with the load in the epilogue)
+  float* const sbias = reinterpret_cast<float*>(sk2 + (size_t)4 * 2 * 16 * KS) + wave * 16 * SK2_TPW_MAX;
+  for (int i = lane; i < (t1 - t0) * 16; i += 64) sbias[i] = g.bias ? g.bias[t0 * 16 + i] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   bf16x8 a0[KSTEPS], a1[KSTEPS];
   {
     bf16x8 z;
@@ -942,8 +949,8 @@ __global__ __launch_bounds__(256) void k_gemm_skinny2(GemmArgs g, int tpw) {
       });
       if constexpr (st == NSPLIT - 1) {                                      // the tile is complete: bias, 16-byte stores (older than the next pieces)
         const int col = tile * 16 + 4 * q;
-        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-        if (g.bias) b4 = as4(*reinterpret_cast<const float4*>(g.bias + col));
+        f32x4 b4;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(b4) : "v"(lds_addr(reinterpret_cast<const __bf16*>(sbias + (tile - t0) * 16 + 4 * q))));
         if (r < g.M) *reinterpret_cast<f32x4*>(g.Cf + (size_t)r * g.ldcf + col) = acc0 * g.alpha + b4;
         if (16 + r < g.M) *reinterpret_cast<f32x4*>(g.Cf + (size_t)(16 + r) * g.ldcf + col) = acc1 * g.alpha + b4;
       }
@@ -960,13 +967,14 @@ inline bool skinny2_ok(const GemmArgs& g) { return g.ldb == g.K && (g.K == 1152 
 template <int KSTEPS, int NSPLIT>
 inline int launch_skinny2_t(const GemmArgs& g, hipStream_t s) {
   constexpr int KS = KSTEPS * 32 / NSPLIT;
-  const int lds = 4 * 2 * 16 * KS * (int)sizeof(__bf16);
+  const int lds = 4 * 2 * 16 * KS * (int)sizeof(__bf16) + 4 * 16 * SK2_TPW_MAX * (int)sizeof(float);
   static const int rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny2<KSTEPS, NSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             lds) == hipSuccess ? SFRON_OK : (int)hipGetLastError();
   if (rc != SFRON_OK) return rc;
   const int ntiles = g.N / 16;
   int tpw = cdiv(ntiles, 4 * 256);                        // one workgroup of four independent waves per CU where the problem is that large
   if (tpw < 1) tpw = 1;
+  if (tpw > SK2_TPW_MAX) tpw = SK2_TPW_MAX;               // (more tiles: more workgroups)
   hipLaunchKernelGGL((k_gemm_skinny2<KSTEPS, NSPLIT>), dim3(cdiv(ntiles, 4 * tpw)), dim3(256), lds, s, g, tpw);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
