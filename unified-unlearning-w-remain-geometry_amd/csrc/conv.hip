@@ -1023,7 +1023,7 @@ __host__ __device__ inline int gn_chunks(int B, int HW) {
 }
 
 // phase 1 forward: partial (sum, sum of squares) per (sample, chunk, group), fp64
-__device__ __forceinline__ void gn2_stats_body(const float* __restrict__ x, int ldx, int HW, int C, int G, int nchunk, double* __restrict__ part) {
+__global__ __launch_bounds__(GNB) void k_gn2_stats(const float* __restrict__ x, int ldx, int HW, int C, int G, int nchunk, double* __restrict__ part) {
   extern __shared__ double shd[];               // [rpp][C][2]
   const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk, cg = C / G;
   const int p0 = (int)((long)HW * ch / nchunk), p1 = (int)((long)HW * (ch + 1) / nchunk);
@@ -1068,14 +1068,11 @@ __device__ __forceinline__ void gn2_stats_body(const float* __restrict__ x, int 
     if (lane == 0) { double* o = part + (((size_t)b * nchunk + ch) * G + g) * 2; o[0] = a; o[1] = q; }
   }
 }
-__global__ __launch_bounds__(GNB) void k_gn2_stats(const float* __restrict__ x, int ldx, int HW, int C, int G, int nchunk, double* __restrict__ part) {
-  gn2_stats_body(x, ldx, HW, C, G, nchunk, part);
-}
 // phase 2 forward: mean / rstd from the partials (every workgroup of a sample forms them the same way; chunk 0 stores them), apply
-__device__ __forceinline__ void gn2_apply_body(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                               int HW, int C, int G, float eps, int swish, const uint8_t* __restrict__ mask, float drop_scale,
-                                               int nchunk, const double* __restrict__ part, __bf16* __restrict__ y, float* __restrict__ mean,
-                                               float* __restrict__ rstd) {
+__global__ __launch_bounds__(GNB) void k_gn2_apply(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   int HW, int C, int G, float eps, int swish, const uint8_t* __restrict__ mask, float drop_scale,
+                                                   int nchunk, const double* __restrict__ part, __bf16* __restrict__ y, float* __restrict__ mean,
+                                                   float* __restrict__ rstd) {
   __shared__ float st[2][64];
   __shared__ double sp[32 * 64 * 2];            // [chunk][group][2]: every partial of the sample, fetched by nchunk * G threads at once
   const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk, cg = C / G;
@@ -1126,33 +1123,12 @@ __device__ __forceinline__ void gn2_apply_body(const float* __restrict__ x, int 
       }
   }
 }
-__global__ __launch_bounds__(GNB) void k_gn2_apply(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                   int HW, int C, int G, float eps, int swish, const uint8_t* __restrict__ mask, float drop_scale,
-                                                   int nchunk, const double* __restrict__ part, __bf16* __restrict__ y, float* __restrict__ mean,
-                                                   float* __restrict__ rstd) {
-  gn2_apply_body(x, ldx, gamma, beta, HW, C, G, eps, swish, mask, drop_scale, nchunk, part, y, mean, rstd);
-}
-// Round 5 -- both phases in ONE launch, one workgroup per sample (the sample's rows are its only chunk): for samples of at most GN1_MAX_ELEMS
-// elements in a batch of at least GN1_MIN_BATCH (the 16 x 16 ... 4 x 4 levels of the DDPM U-Net at batch 64: 37 of its 51 GroupNorms).  A
-// dependent chain pays ~5 us per kernel boundary whatever the kernel does (tools/trace_gaps.py: the DDPM step is 2 060 launches of 12.9 us
-// mean): the second pass over <= 256 KB that this workgroup has just read costs less than the boundary it removes.  Same arithmetic as the
-// two-launch form with nchunk = 1 (the partial sums of the one chunk go through the scratch buffer as before: written and read by the
-// same workgroup on either side of a barrier).
-constexpr int GN1_MAX_ELEMS = 65536, GN1_MIN_BATCH = 32;
-__global__ __launch_bounds__(GNB) void k_gn1_fwd(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                 int HW, int C, int G, float eps, int swish, const uint8_t* __restrict__ mask, float drop_scale,
-                                                 double* __restrict__ part, __bf16* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
-  gn2_stats_body(x, ldx, HW, C, G, 1, part);
-  __threadfence_block();
-  __syncthreads();
-  gn2_apply_body(x, ldx, gamma, beta, HW, C, G, eps, swish, mask, drop_scale, 1, part, y, mean, rstd);
-}
 // phase 1 backward: per (sample, chunk, channel) partial sums of dz * xhat and dz, dz = dy * act'(z) (* dropout)
-__device__ __forceinline__ void gn2_bwd_stats_body(const float* __restrict__ dy, const float* __restrict__ x, int ldx,
-                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                   const float* __restrict__ mean, const float* __restrict__ rstd, int HW, int C, int G,
-                                                   int swish, const uint8_t* __restrict__ mask, float drop_scale, int nchunk,
-                                                   float* __restrict__ part) {
+__global__ __launch_bounds__(GNB) void k_gn2_bwd_stats(const float* __restrict__ dy, const float* __restrict__ x, int ldx,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd, int HW, int C, int G,
+                                                       int swish, const uint8_t* __restrict__ mask, float drop_scale, int nchunk,
+                                                       float* __restrict__ part) {
   extern __shared__ float shf[];                // [rpp][C][2]
   const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk, cg = C / G;
   const int p0 = (int)((long)HW * ch / nchunk), p1 = (int)((long)HW * (ch + 1) / nchunk);
@@ -1210,22 +1186,15 @@ __device__ __forceinline__ void gn2_bwd_stats_body(const float* __restrict__ dy,
     o[0] = a; o[1] = q;
   }
 }
-__global__ __launch_bounds__(GNB) void k_gn2_bwd_stats(const float* __restrict__ dy, const float* __restrict__ x, int ldx,
+// phase 2 backward: per-channel sums over the chunks -> (chunk 0) the per-sample parameter-gradient partials, the group means
+// k1 = mean(dz gamma), k2 = mean(dz gamma xhat); dx (+)= rstd (dz gamma - k1 - xhat k2)
+__global__ __launch_bounds__(GNB) void k_gn2_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, int ldx,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd, int HW, int C, int G,
                                                        int swish, const uint8_t* __restrict__ mask, float drop_scale, int nchunk,
-                                                       float* __restrict__ part) {
-  gn2_bwd_stats_body(dy, x, ldx, gamma, beta, mean, rstd, HW, C, G, swish, mask, drop_scale, nchunk, part);
-}
-// phase 2 backward: per-channel sums over the chunks -> (chunk 0) the per-sample parameter-gradient partials, the group means
-// k1 = mean(dz gamma), k2 = mean(dz gamma xhat); dx (+)= rstd (dz gamma - k1 - xhat k2)
-__device__ __forceinline__ void gn2_bwd_apply_body(const float* __restrict__ dy, const float* __restrict__ x, int ldx,
-                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                   const float* __restrict__ mean, const float* __restrict__ rstd, int HW, int C, int G,
-                                                   int swish, const uint8_t* __restrict__ mask, float drop_scale, int nchunk,
-                                                   const float* __restrict__ part, float* __restrict__ dx, int lddx, int accumulate,
-                                                   float* __restrict__ pg, float* __restrict__ pb, const float* __restrict__ extra,
-                                                   int ldextra, __bf16* __restrict__ dx16, float* __restrict__ colpart) {
+                                                       const float* __restrict__ part, float* __restrict__ dx, int lddx, int accumulate,
+                                                       float* __restrict__ pg, float* __restrict__ pb, const float* __restrict__ extra,
+                                                       int ldextra, __bf16* __restrict__ dx16, float* __restrict__ colpart) {
   // dx16 / colpart (sfron_groupnorm_bwd_cast): the gradient also (or only: dx == nullptr) as the bf16 GEMM operand [rows][C] of the
   // convolution that produced x, and its column sums per (sample, chunk) -- that layer's bias gradient and, per sample, the gradient
   // of a per-sample vector added to x -- which a cast pass and two column-sum passes over an fp32 dx would form otherwise
@@ -1333,29 +1302,6 @@ __device__ __forceinline__ void gn2_bwd_apply_body(const float* __restrict__ dy,
       colpart[((size_t)b * nchunk + ch) * C + c] = a;
     }
   }
-}
-__global__ __launch_bounds__(GNB) void k_gn2_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, int ldx,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ mean, const float* __restrict__ rstd, int HW, int C, int G,
-                                                       int swish, const uint8_t* __restrict__ mask, float drop_scale, int nchunk,
-                                                       const float* __restrict__ part, float* __restrict__ dx, int lddx, int accumulate,
-                                                       float* __restrict__ pg, float* __restrict__ pb, const float* __restrict__ extra,
-                                                       int ldextra, __bf16* __restrict__ dx16, float* __restrict__ colpart) {
-  gn2_bwd_apply_body(dy, x, ldx, gamma, beta, mean, rstd, HW, C, G, swish, mask, drop_scale, nchunk, part, dx, lddx, accumulate, pg, pb, extra, ldextra,
-                     dx16, colpart);
-}
-// both backward phases in one launch, one workgroup per sample (see k_gn1_fwd); the fp32-dx forms only (sfron_groupnorm_bwd / _bwd_res): the bf16 /
-// column-sum form keeps its (sample, chunk) partial layout, which its caller sizes by sfron_groupnorm_chunks
-__global__ __launch_bounds__(GNB) void k_gn1_bwd(const float* __restrict__ dy, const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
-                                                 const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd, int HW,
-                                                 int C, int G, int swish, const uint8_t* __restrict__ mask, float drop_scale, float* __restrict__ part,
-                                                 float* __restrict__ dx, int lddx, int accumulate, float* __restrict__ pg, float* __restrict__ pb,
-                                                 const float* __restrict__ extra, int ldextra) {
-  gn2_bwd_stats_body(dy, x, ldx, gamma, beta, mean, rstd, HW, C, G, swish, mask, drop_scale, 1, part);
-  __threadfence_block();
-  __syncthreads();
-  gn2_bwd_apply_body(dy, x, ldx, gamma, beta, mean, rstd, HW, C, G, swish, mask, drop_scale, 1, part, dx, lddx, accumulate, pg, pb, extra, ldextra,
-                     (__bf16*)nullptr, (float*)nullptr);
 }
 
 // ---- softmax over rows of length n (fp32 in, bf16 out), one wave per row; backward dS = scale * P * (dP - sum(P dP))
@@ -2229,12 +2175,6 @@ int sfron_groupnorm_fwd(const float* x, int ldx, const float* gamma, const float
                         void* stream) {
   SFRON_CHECK_ARG(x && gamma && beta && y && mean && rstd && groups > 0 && C % groups == 0 && ldx >= C && C / groups <= TPB);
   if (gn2_ok(ldx, C, C, groups, scratch) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 && (!drop_mask || ((uintptr_t)drop_mask & 3) == 0)) {
-    if (B >= GN1_MIN_BATCH && (int64_t)HW * C <= GN1_MAX_ELEMS) {           // one launch, one workgroup per sample
-      hipLaunchKernelGGL(k_gn1_fwd, dim3(B), dim3(GNB), gn2_lds(C, sizeof(double)), (hipStream_t)stream, x, ldx, gamma, beta, HW, C, groups, eps, swish,
-                         drop_mask, drop_scale, (double*)scratch, (__bf16*)y, mean, rstd);
-      SFRON_LAUNCH_STATUS();
-      return SFRON_OK;
-    }
     const int nchunk = gn_chunks(B, HW);
     hipLaunchKernelGGL(k_gn2_stats, dim3(B * nchunk), dim3(GNB), gn2_lds(C, sizeof(double)), (hipStream_t)stream, x, ldx, HW, C, groups, nchunk,
                        (double*)scratch);
@@ -2269,13 +2209,6 @@ int sfron_groupnorm_bwd_res(const float* dy, const float* x, int ldx, const floa
     const int rc = sfron_copy_cols(extra, ld_extra, (int64_t)B * HW, C, dx, lddx, accumulate, stream);
     if (rc) return rc;
     extra = nullptr; accumulate = 1;
-  }
-  if (fused && B >= GN1_MIN_BATCH && (int64_t)HW * C <= GN1_MAX_ELEMS) {        // one launch, one workgroup per sample
-    const size_t l1 = gn2_lds(C, sizeof(float)), l2 = (size_t)(3 * C + 2 * groups) * sizeof(float);
-    hipLaunchKernelGGL(k_gn1_bwd, dim3(B), dim3(GNB), l1 > l2 ? l1 : l2, (hipStream_t)stream, dy, x, ldx, gamma, beta, mean, rstd, HW, C, groups, swish,
-                       drop_mask, drop_scale, (float*)scratch, dx, lddx, accumulate, part_gamma, part_beta, extra, ld_extra);
-    SFRON_LAUNCH_STATUS();
-    return SFRON_OK;
   }
   if (fused) {
     const int nchunk = gn_chunks(B, HW);

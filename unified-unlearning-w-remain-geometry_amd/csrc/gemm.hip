@@ -883,14 +883,19 @@ __global__ __launch_bounds__(256) void k_gemm_skinny2(GemmArgs g, int tpw) {
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntiles = g.N >> 4;
-  const int t0 = (blockIdx.x * 4 + wave) * tpw, t1 = min(ntiles, t0 + tpw);
-  if (t0 >= t1) return;                                                      // wave-uniform; no barrier anywhere in this kernel
+  // wave `wid` takes tiles wid, wid + nwv, wid + 2 nwv, ...: at any moment the chip streams ONE contiguous window of W rows (1 020 separate
+  // sequential streams, 442 KB apart, ran at 2.7 TB/s alone -- the round-4 kernel's rate too; profiles/r05_ab_log.txt)
+  const int wid = blockIdx.x * 4 + wave, nwv = gridDim.x * 4;
+  (void)tpw;
+  const int cnt = wid < ntiles ? (ntiles - 1 - wid) / nwv + 1 : 0;           // tiles of this wave
+  if (cnt == 0) return;                                                      // wave-uniform; no barrier anywhere in this kernel
+  auto tile_of = [&](int i) { return wid + i * nwv; };
   __bf16* const ring = sk2 + (size_t)wave * 2 * 16 * KS;
   // the bias columns of this wave's tiles go to LDS BEFORE the first DMA piece is issued: a global load in the epilogue would sit behind the
   // pieces of the next stage in the wave's in-order vector-memory queue, and waiting for it would drain the ring (measured: 2.7 TB/s, the
   // round-4 kernel's rate, with the load in the epilogue)
   float* const sbias = reinterpret_cast<float*>(sk2 + (size_t)4 * 2 * 16 * KS) + wave * 16 * SK2_TPW_MAX;
-  for (int i = lane; i < (t1 - t0) * 16; i += 64) sbias[i] = g.bias ? g.bias[t0 * 16 + i] : 0.f;
+  for (int i = lane; i < cnt * 16; i += 64) sbias[i] = g.bias ? g.bias[tile_of(i >> 4) * 16 + (i & 15)] : 0.f;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   bf16x8 a0[KSTEPS], a1[KSTEPS];
   {
@@ -919,11 +924,12 @@ __global__ __launch_bounds__(256) void k_gemm_skinny2(GemmArgs g, int tpw) {
   // fragment addresses: k-step ul of a stage reads chunk (4 ul + q) ^ (r & 7) of row r = ((ul >> 1) << 3) + ((4 (ul & 1) + q) ^ (r & 7))
   const unsigned rowb = lds_addr(ring) + 2 * (r * KS);
   const unsigned ad_e = rowb + 16 * (q ^ (r & 7)), ad_o = rowb + 16 * ((4 + q) ^ (r & 7));
-  const int nst = (t1 - t0) * NSPLIT;
-  issue(t0, 0, 0);
-  if (nst > 1) issue(NSPLIT > 1 ? t0 : t0 + 1, NSPLIT > 1 ? 1 : 0, 1);
+  const int nst = cnt * NSPLIT;
+  issue(tile_of(0), 0, 0);
+  if (nst > 1) issue(NSPLIT > 1 ? tile_of(0) : tile_of(1), NSPLIT > 1 ? 1 : 0, 1);
   int j = 0;
-  for (int tile = t0; tile < t1; ++tile) {
+  for (int ti = 0; ti < cnt; ++ti) {
+    const int tile = tile_of(ti);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     static_for<NSPLIT>([&](auto st_) {
       constexpr int st = decltype(st_)::value;
@@ -950,14 +956,14 @@ __global__ __launch_bounds__(256) void k_gemm_skinny2(GemmArgs g, int tpw) {
       if constexpr (st == NSPLIT - 1) {                                      // the tile is complete: bias, 16-byte stores (older than the next pieces)
         const int col = tile * 16 + 4 * q;
         f32x4 b4;
-        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(b4) : "v"(lds_addr(reinterpret_cast<const __bf16*>(sbias + (tile - t0) * 16 + 4 * q))));
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(b4) : "v"(lds_addr(reinterpret_cast<const __bf16*>(sbias + ti * 16 + 4 * q))));
         if (r < g.M) *reinterpret_cast<f32x4*>(g.Cf + (size_t)r * g.ldcf + col) = acc0 * g.alpha + b4;
         if (16 + r < g.M) *reinterpret_cast<f32x4*>(g.Cf + (size_t)(16 + r) * g.ldcf + col) = acc1 * g.alpha + b4;
       }
       // this stage's buffer is free (its reads are in registers): refill it with stage j + 2
       if (j + 2 < nst) {
         const int jn = j + 2;
-        issue(t0 + jn / NSPLIT, jn % NSPLIT, buf);
+        issue(tile_of(jn / NSPLIT), jn % NSPLIT, buf);
       }
       ++j;
     });
