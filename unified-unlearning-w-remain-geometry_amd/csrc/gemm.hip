@@ -859,138 +859,6 @@ template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-__device__ __forceinline__ void lds_reads_done();
-// =================================================================================================
-// Skinny product, round 5: the same C[M <= 32][N] = alpha * A W^T + bias, with W streamed at the HBM rate.  k_gemm_skinny reads W as MFMA
-// fragments straight from global memory: one wave-instruction = 16 rows x 64 bytes -- half a 128-byte line per row, sixteen lines per
-// instruction -- and the adaLN modulation of all blocks ([32 x 1152] x [1152 x 195 840], 451 MB of weight rows) ran at 2.5 TB/s, 178 us on the
-// critical stream in front of block 0 (profiles/r05_stage_boundary.txt).  Here every wave owns a private two-stage ring in LDS that it fills by
-// LDS-DMA with WHOLE 1-KiB pieces of the (contiguous: ldb == K) 16-row tile -- the XOR swizzle of the 16-byte chunks lives in the source
-// addresses -- and reads its fragments from there (asm reads: hipcc would drain vmcnt(0) in front of a builtin LDS read while a DMA is in
-// flight); the activation fragments of ALL k-steps sit in registers (8 VGPRs per k-step: one wave per SIMD, up to 512 registers), so the four
-// waves of a workgroup never meet at a barrier.  Same products in the same order as k_gemm_skinny: the same bits.
-// one 1-KiB LDS-DMA piece: lane l's 16 bytes from rsrc[voff + soff] land at img + 16 l  (a __device__ function: the builtin does not exist in the
-// host pass, and a lambda inside a kernel template is instantiated there too)
-__device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rsrc, __bf16* img, int voff, int soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t*)img, 16, voff, soff, 0, 0);
-}
-constexpr int SK2_TPW_MAX = 16;          // tiles per wave (bias staging in LDS)
-template <int KSTEPS, int NSPLIT>
-__global__ __launch_bounds__(256) void k_gemm_skinny2(GemmArgs g, int tpw) {
-  constexpr int K = KSTEPS * 32, KS = K / NSPLIT, CPR = KS / 8, NI = 16 * CPR / 64, SU = KSTEPS / NSPLIT;   // stage: 16 rows x KS, NI DMA pieces, SU k-steps
-  static_assert(KSTEPS % NSPLIT == 0 && (16 * CPR) % 64 == 0 && CPR % 8 == 0 && SU % 2 == 0, "stage geometry");
-  extern __shared__ __attribute__((aligned(16))) __bf16 sk2[];               // [4 waves][2 stages][16][KS]
-  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntiles = g.N >> 4;
-  // wave `wid` takes tiles wid, wid + nwv, wid + 2 nwv, ...: at any moment the chip streams ONE contiguous window of W rows (1 020 separate
-  // sequential streams, 442 KB apart, ran at 2.7 TB/s alone -- the round-4 kernel's rate too; profiles/r05_ab_log.txt)
-  const int wid = blockIdx.x * 4 + wave, nwv = gridDim.x * 4;
-  (void)tpw;
-  const int cnt = wid < ntiles ? (ntiles - 1 - wid) / nwv + 1 : 0;           // tiles of this wave
-  if (cnt == 0) return;                                                      // wave-uniform; no barrier anywhere in this kernel
-  auto tile_of = [&](int i) { return wid + i * nwv; };
-  __bf16* const ring = sk2 + (size_t)wave * 2 * 16 * KS;
-  // the bias columns of this wave's tiles go to LDS BEFORE the first DMA piece is issued: a global load in the epilogue would sit behind the
-  // pieces of the next stage in the wave's in-order vector-memory queue, and waiting for it would drain the ring (measured: 2.7 TB/s, the
-  // round-4 kernel's rate, with the load in the epilogue)
-  float* const sbias = reinterpret_cast<float*>(sk2 + (size_t)4 * 2 * 16 * KS) + wave * 16 * SK2_TPW_MAX;
-  for (int i = lane; i < cnt * 16; i += 64) sbias[i] = g.bias ? g.bias[tile_of(i >> 4) * 16 + (i & 15)] : 0.f;
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  bf16x8 a0[KSTEPS], a1[KSTEPS];
-  {
-    bf16x8 z;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.0f;
-#pragma unroll
-    for (int u = 0; u < KSTEPS; ++u) {
-      a0[u] = r < g.M ? *reinterpret_cast<const bf16x8*>(g.A + (size_t)r * g.lda + 32 * u + 8 * q) : z;
-      a1[u] = 16 + r < g.M ? *reinterpret_cast<const bf16x8*>(g.A + (size_t)(16 + r) * g.lda + 32 * u + 8 * q) : z;
-    }
-  }
-  // piece i of a stage: LDS chunk e = i * 64 + lane = (row e / CPR, position e % CPR) holds the row's logical chunk position ^ (row & 7)
-  int off[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int e = i * 64 + lane, rr = e / CPR, c = (e % CPR) ^ (rr & 7);
-    off[i] = 2 * (rr * K + c * 8);
-  }
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, (int)((size_t)g.N * K * 2), 0x00020000);
-  auto issue = [&](int tile, int st, int buf) {
-    const int soff = (tile * 16 * K + st * KS) * 2;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) dma_piece(rs, ring + buf * 16 * KS + i * 512, off[i], soff);
-  };
-  // fragment addresses: k-step ul of a stage reads chunk (4 ul + q) ^ (r & 7) of row r = ((ul >> 1) << 3) + ((4 (ul & 1) + q) ^ (r & 7))
-  const unsigned rowb = lds_addr(ring) + 2 * (r * KS);
-  const unsigned ad_e = rowb + 16 * (q ^ (r & 7)), ad_o = rowb + 16 * ((4 + q) ^ (r & 7));
-  const int nst = cnt * NSPLIT;
-  issue(tile_of(0), 0, 0);
-  if (nst > 1) issue(NSPLIT > 1 ? tile_of(0) : tile_of(1), NSPLIT > 1 ? 1 : 0, 1);
-  int j = 0;
-  for (int ti = 0; ti < cnt; ++ti) {
-    const int tile = tile_of(ti);
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    static_for<NSPLIT>([&](auto st_) {
-      constexpr int st = decltype(st_)::value;
-      const int buf = j & 1;
-      // stage j has landed when at most the NI pieces of stage j + 1 (and nothing older) are outstanding
-      if (j + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned be = ad_e + buf * (2 * 16 * KS), bo = ad_o + buf * (2 * 16 * KS);
-      constexpr int GRP = 6;                                                 // fragment reads in flight per wait
-      static_for<(SU + GRP - 1) / GRP>([&](auto g_) {
-        constexpr int u0 = decltype(g_)::value * GRP, n = (SU - u0) < GRP ? (SU - u0) : GRP;
-        bf16x8 wf[GRP];
-        static_for<n>([&](auto i_) {
-          constexpr int ul = u0 + decltype(i_)::value;
-          wf[decltype(i_)::value] = (ul & 1) ? asm_read_b128_off<(ul >> 1) * 128>(bo) : asm_read_b128_off<(ul >> 1) * 128>(be);
-        });
-        lds_reads_done();
-        static_for<n>([&](auto i_) {
-          constexpr int ul = u0 + decltype(i_)::value, u = st * SU + ul;
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[decltype(i_)::value], a0[u], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[decltype(i_)::value], a1[u], acc1, 0, 0, 0);
-        });
-      });
-      if constexpr (st == NSPLIT - 1) {                                      // the tile is complete: bias, 16-byte stores (older than the next pieces)
-        const int col = tile * 16 + 4 * q;
-        f32x4 b4;
-        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(b4) : "v"(lds_addr(reinterpret_cast<const __bf16*>(sbias + ti * 16 + 4 * q))));
-        if (r < g.M) *reinterpret_cast<f32x4*>(g.Cf + (size_t)r * g.ldcf + col) = acc0 * g.alpha + b4;
-        if (16 + r < g.M) *reinterpret_cast<f32x4*>(g.Cf + (size_t)(16 + r) * g.ldcf + col) = acc1 * g.alpha + b4;
-      }
-      // this stage's buffer is free (its reads are in registers): refill it with stage j + 2
-      if (j + 2 < nst) {
-        const int jn = j + 2;
-        issue(tile_of(jn / NSPLIT), jn % NSPLIT, buf);
-      }
-      ++j;
-    });
-  }
-}
-inline bool skinny2_ok(const GemmArgs& g) { return g.ldb == g.K && (g.K == 1152 || g.K == 256) && (size_t)g.N * g.K * 2 < 0x7fffffffull; }
-template <int KSTEPS, int NSPLIT>
-inline int launch_skinny2_t(const GemmArgs& g, hipStream_t s) {
-  constexpr int KS = KSTEPS * 32 / NSPLIT;
-  const int lds = 4 * 2 * 16 * KS * (int)sizeof(__bf16) + 4 * 16 * SK2_TPW_MAX * (int)sizeof(float);
-  static const int rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny2<KSTEPS, NSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            lds) == hipSuccess ? SFRON_OK : (int)hipGetLastError();
-  if (rc != SFRON_OK) return rc;
-  const int ntiles = g.N / 16;
-  int tpw = cdiv(ntiles, 4 * 256);                        // one workgroup of four independent waves per CU where the problem is that large
-  if (tpw < 1) tpw = 1;
-  if (tpw > SK2_TPW_MAX) tpw = SK2_TPW_MAX;               // (more tiles: more workgroups)
-  hipLaunchKernelGGL((k_gemm_skinny2<KSTEPS, NSPLIT>), dim3(cdiv(ntiles, 4 * tpw)), dim3(256), lds, s, g, tpw);
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? SFRON_OK : (int)e;
-}
-inline int launch_skinny2(const GemmArgs& g, hipStream_t s) {
-  return g.K == 1152 ? launch_skinny2_t<36, 2>(g, s) : launch_skinny2_t<8, 1>(g, s);
-}
-template __global__ void k_gemm_skinny2<36, 2>(GemmArgs, int);      // K = 1152 (DiT-XL hidden size): two 18-KiB stages per 16-row tile
-template __global__ void k_gemm_skinny2<8, 1>(GemmArgs, int);       // K = 256 (timestep frequency embedding)
-
 // Where the memory operations of a segment sit among its NM MFMAs.  They used to be spread evenly up to the LAST MFMA, so the
 // `s_waitcnt lgkmcnt(0)` that closes the segment exposed one full LDS latency per k-step on BOTH waves of a SIMD at once (the two
 // run the same code from the same barrier: neither has MFMAs left to cover the other).  Now the operations are packed into the
@@ -2034,8 +1902,7 @@ int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
       return dispatch_layout<EPI_BF16>(d->a_transposed, d->b_transposed, g, s, force);
     case SFRON_EPI_F32:
       SFRON_CHECK_ARG(g.Cf && g.ldcf % 4 == 0);
-      if (!d->a_transposed && !d->b_transposed && force == 0 && skinny_ok(g)) return skinny2_ok(g) ? launch_skinny2(g, s) : launch_skinny(g, s);      // at most 32 output rows
-      if (!d->a_transposed && !d->b_transposed && force == 7 && skinny_ok(g)) return launch_skinny(g, s);      // (tests: the round-4 form, same bits)
+      if (!d->a_transposed && !d->b_transposed && force == 0 && skinny_ok(g)) return launch_skinny(g, s);      // at most 32 output rows
       return dispatch_layout<EPI_F32>(d->a_transposed, d->b_transposed, g, s, force);
     case SFRON_EPI_GELU:
       SFRON_CHECK_ARG(g.Cb && g.aux && g.ldcb % 4 == 0 && g.ldaux % 4 == 0 && !d->a_transposed && !d->b_transposed);
