@@ -409,8 +409,6 @@ def main():
     if os.environ.get("SFRON_BENCH_ATTN_FWD"):              # A-B knob (tools only): 4 = the four-wave attention forward kernel
         from sfron import _lib
         _lib.lib().sfron_attn_fwd_form(int(os.environ["SFRON_BENCH_ATTN_FWD"]))
-    if os.environ.get("SFRON_BENCH_ADA_SPLIT"):             # A-B knob (tools only): block in front of which the second part of the adaLN sweep must be done (0 = one part)
-        runner.ada_split_block = int(os.environ["SFRON_BENCH_ADA_SPLIT"])
     if os.environ.get("SFRON_BENCH_SWEEP_BESIDE"):          # tuning knob (tools only): "workgroups,head"
         runner.sweep_beside_wg, runner.sweep_beside_head = (int(v) for v in os.environ["SFRON_BENCH_SWEEP_BESIDE"].split(","))
 
