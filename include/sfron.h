@@ -89,13 +89,6 @@ int sfron_adam_lowrank(float* p, float* m, float* v, const uint8_t* mask, const 
                        int NM, int D, double beta1, double beta2, double eps, double step_size, double bc2_sqrt, double decay_mul,
                        uint16_t* w_bf16, float* ema, double ema_decay, int ema_mode, void* stream);
 
-/* the same update over the rows [row0, row0 + nrows) of W only (multiples of 8; pointers still at W's FIRST element, NM = all rows = the leading
- * dimension of dmod), on at most max_workgroups workgroups (0 = one per 8 rows): a sweep of the later blocks' adaLN rows that runs on a second stream
- * BESIDE the forward pass of the earlier blocks (sfron_dit_forward_split waits for it in front of the block whose modulation needs those rows) */
-int sfron_adam_lowrank_rows(float* p, float* m, float* v, const uint8_t* mask, const float* stats, const uint16_t* dmod, const uint16_t* sc, int R,
-                            int NM, int row0, int nrows, int D, double beta1, double beta2, double eps, double step_size, double bc2_sqrt,
-                            double decay_mul, uint16_t* w_bf16, float* ema, double ema_decay, int ema_mode, int max_workgroups, void* stream);
-
 /* stand-alone EMA (frozen parameters such as pos_embed; DiT/forget.py:60-62) */
 int sfron_ema_update(float* ema, const float* p, int64_t n, double decay, int ema_mode, void* stream);
 
@@ -586,13 +579,6 @@ int sfron_dit_forward(const sfron_dit_cfg* cfg, const float* params, const uint1
 int sfron_dit_forward_after(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
                             const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
                             void* const* block_ready, void* probe, void* stream);
-/* sfron_dit_forward_after whose adaLN modulation is formed in TWO parts: the rows of blocks [0, mod_split_block) in the preamble, the rows of the
- * later blocks and of the final layer in front of block mod_split_block, after a wait for mod_ready (hipEvent_t): the optimizer sweep of the
- * later blocks' adaLN_modulation rows (sfron_adam_lowrank_rows on another stream) then runs beside the first blocks' forward pass instead of in
- * front of it.  0 < mod_split_block < depth.  Same products: results equal sfron_dit_forward_after's bit for bit. */
-int sfron_dit_forward_split(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
-                            const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
-                            void* const* block_ready, int mod_split_block, void* mod_ready, void* probe, void* stream);
 /* Config 5: the same forward pass with the four block GEMMs on the fp8 matrix core.  params_e4m3: e4m3 shadow arena (same offsets as
  * params); w_scales: DEVICE fp32 [depth][4] = quantisation scales of {qkv, proj, fc1, fc2}.weight of each block; act_scales: HOST
  * fp32 [3] = static scales of {LayerNorm+modulate output, attention output, gelu(fc1)}; workspace_e4m3: sfron_dit_fp8_workspace_bytes.

@@ -344,36 +344,3 @@ def test_sibling_engine_orders_itself_behind_a_sweep_in_flight():
     torch.cuda.synchronize()
     assert torch.equal(out, sib.forward(b["x0"], b["t"], b["y"], b["drop"]))
     sib.close()
-
-
-def test_two_part_adaln_sweep_gives_the_same_state():
-    """step.DiTSFRon.ada_split_block: the adaLN_modulation matrix (a third of the parameters, its gradient a rank-(batch) product) is swept in two
-    parts -- the rows of the first blocks in front of the next forward pass, the rest on the sweep stream beside that pass's first blocks, whose
-    modulation is formed without them (sfron_adam_lowrank_rows + sfron_dit_forward_split).  The same per-element arithmetic and the same
-    modulation products: parameters, moments, EMA and the bf16 shadow after four steps equal the one-part form bit for bit, with and without
-    the remain-stage sweep across the step boundary."""
-    from sfron import data, diffusion, step
-    from test_gpu_dit import CASES, build_pair
-    cfg = CASES["hd72"]                                    # depth 3: blocks 0, 1 swept on the main stream (head), split in front of block 2
-    B = 4
-    kw = dict(global_batch=B, num_classes=cfg["num_classes"], forget_class=3, input_size=cfg["input_size"], device=DEV)
-    bat = lambda it: (data.synthetic_batch(16, it, "forget", **kw), data.synthetic_batch(16, it, "remain", **kw))
-    hp = dict(lr=2e-4, forget_alpha=0.3, grad_clip=1.0, ema_decay=0.99, mask=None, unlearn_loss="ga", forget_class=3)
-
-    def run(split_block, across):
-        _, model = build_pair(cfg, B, seed=35)
-        runner = step.DiTSFRon(model, diffusion.create_diffusion(""), **hp)
-        runner.ada_split_block = split_block
-        runner.sweep_across_steps = across
-        for it in range(4):
-            runner.step(*bat(it))
-        runner.sync_sweep()
-        torch.cuda.synchronize()
-        runner.guard.poll(block=True)
-        eng = model.engine
-        return eng.params.clone(), runner.opt.m.clone(), runner.opt.v.clone(), runner.ema.clone(), eng.params_bf16.clone()
-
-    for across in (False, True):
-        one, two = run(0, across), run(2, across)
-        for a, b in zip(one, two):
-            assert torch.equal(a, b), f"across={across}"

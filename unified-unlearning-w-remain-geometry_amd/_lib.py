@@ -197,9 +197,6 @@ _PROTOS.update({
     "sfron_dit_param_layout": (c_int, [POINTER(DitCfg), POINTER(c_int64), c_int]),
     "sfron_dit_workspace_bytes": (c_int64, [POINTER(DitCfg)]),
     "sfron_dit_sumsq_partials_len": (c_int, [POINTER(DitCfg)]),
-    "sfron_dit_forward_split": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, POINTER(c_void_p), c_int, c_void_p, c_void_p, _S]),
-    "sfron_adam_lowrank_rows": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_double,
-                                        c_double, _P, _P, c_double, c_int, c_int, _S]),
     "sfron_dit_forward": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_dit_backward": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_dit_backward_dp": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _S]),

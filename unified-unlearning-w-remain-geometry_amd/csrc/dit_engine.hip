@@ -350,8 +350,7 @@ static size_t fp8_ws(const Dims& d, char* base, Fp8Ctx* f) {
 
 static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
                             const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
-                            void* probe, const Fp8Ctx* f8, void* stream, void* const* block_wait = nullptr, int mod_split = 0,
-                            void* mod_ready = nullptr);
+                            void* probe, const Fp8Ctx* f8, void* stream, void* const* block_wait = nullptr);
 
 int sfron_dit_forward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
                       const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out, void* stream) {
@@ -369,13 +368,6 @@ int sfron_dit_forward_after(const sfron_dit_cfg* cfg, const float* params, const
                             void* const* block_ready, void* probe, void* stream) {
   SFRON_CHECK_ARG(block_ready);
   return dit_forward_impl(cfg, params, params_bf16, x_t, t, y, drop, workspace, out, probe, nullptr, stream, block_ready);
-}
-
-int sfron_dit_forward_split(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
-                            const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
-                            void* const* block_ready, int mod_split_block, void* mod_ready, void* probe, void* stream) {
-  SFRON_CHECK_ARG(block_ready && cfg && mod_split_block > 0 && mod_split_block < cfg->depth && mod_ready);
-  return dit_forward_impl(cfg, params, params_bf16, x_t, t, y, drop, workspace, out, probe, nullptr, stream, block_ready, mod_split_block, mod_ready);
 }
 
 int64_t sfron_dit_fp8_workspace_bytes(const sfron_dit_cfg* cfg) {
@@ -401,7 +393,7 @@ int sfron_dit_forward_fp8(const sfron_dit_cfg* cfg, const float* params, const u
 
 static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
                             const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
-                            void* probe, const Fp8Ctx* f8, void* stream, void* const* block_wait, int mod_split, void* mod_ready) {
+                            void* probe, const Fp8Ctx* f8, void* stream, void* const* block_wait) {
   Dims d;
   RUN(make_dims(cfg, d));
   SFRON_CHECK_ARG(params && params_bf16 && x_t && t && y && workspace && out);
@@ -427,16 +419,9 @@ static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const
   RUN(sfron_gemm_bf16(&g, stream));
   // c = t + y_embedder(y); SiLU(c) feeds every adaLN_modulation           (models.py:242-243,114,132)
   RUN(sfron_cond_fwd(w.temb, params + P.table, y, drop, d.ncls, d.B, D, w.c, (uint16_t*)w.sc, stream));
-  // modulation of every block + the final layer = rows of ONE product silu(c) W_ada^T (c is the same for all blocks).  mod_split > 0
-  // (sfron_dit_forward_split): only the rows of blocks [0, mod_split) are formed here; the rest -- whose weights an optimizer sweep may still be
-  // rewriting on another stream -- in front of block mod_split, behind mod_ready.  Same tiles, same products: the same bits either way.
-  auto modulation = [&](int row0, int nrows) -> int {
-    sfron_gemm_desc q = fwd_desc(w.sc, wb + P.ada_w + (size_t)row0 * D, d.B, nrows, D);
-    q.epilogue = SFRON_EPI_F32; q.bias = params + P.ada_b + row0; q.c_f32 = w.mod + row0; q.ldc_f32 = NM;
-    return sfron_gemm_bf16(&q, stream);
-  };
-  const int mod_rows0 = mod_split > 0 ? 6 * mod_split * D : NM;
-  RUN(modulation(0, mod_rows0));
+  g = fwd_desc(w.sc, wb + P.ada_w, d.B, NM, D);
+  g.epilogue = SFRON_EPI_F32; g.bias = params + P.ada_b; g.c_f32 = w.mod; g.ldc_f32 = NM;
+  RUN(sfron_gemm_bf16(&g, stream));
 
   // x_next = x + gate * (X W^T + b), branch output saved for the backward pass (models.py:120-121): one product with the gated-residual
   // epilogue, or -- few-tile shapes -- a split-K product + its finish kernel
@@ -458,10 +443,6 @@ static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const
     // block l's weights may still be under an optimizer sweep that runs on another stream (sfron_dit_forward_after): wait for ITS event
     if (block_wait && block_wait[l] && hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)block_wait[l], 0) != hipSuccess)
       return (int)hipGetLastError();
-    if (mod_split > 0 && l == mod_split) {
-      if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)mod_ready, 0) != hipSuccess) return (int)hipGetLastError();
-      RUN(modulation(mod_rows0, NM - mod_rows0));
-    }
     const float* mod = w.mod + (size_t)l * 6 * D;          // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     float* x0 = w.xs + (size_t)(2 * l) * M * D;
     float* x1 = x0 + (size_t)M * D;

@@ -258,15 +258,12 @@ __global__ void k_sumsq_lowrank(const __bf16* __restrict__ dmod, const __bf16* _
   }
 }
 
-// rows [row0, row0 + nrows) of W (NM = the leading dimension of dmod = all rows of W); workgroups stride over the row groups, so a launch
-// on a bounded grid (a sweep BESIDE a GEMM chain) takes a bounded share of the chip
 __global__ void k_adam_lowrank(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const uint8_t* __restrict__ mask,
                                const float* __restrict__ stats, const __bf16* __restrict__ dmod, const __bf16* __restrict__ sc, int R,
-                               int NM, int row0, int nrows, int D, AdamArgs a, uint16_t* __restrict__ wbf, float* __restrict__ ema) {
-  const int c = threadIdx.x;
+                               int NM, int D, AdamArgs a, uint16_t* __restrict__ wbf, float* __restrict__ ema) {
+  const int c = threadIdx.x, n0 = blockIdx.x * LR_ROWS;
   if (c >= (D >> 2)) return;
   const float coef = stats ? stats[1] : 1.0f;
-  for (int n0 = row0 + blockIdx.x * LR_ROWS; n0 < row0 + nrows; n0 += gridDim.x * LR_ROWS) {
   f32x4 g[LR_ROWS];
   lowrank_grad(dmod, sc, R, NM, D, n0, c, g);
 #pragma unroll
@@ -288,7 +285,6 @@ __global__ void k_adam_lowrank(float* __restrict__ p, float* __restrict__ m, flo
       ee.x = ema_one(ee.x, pp.x, a); ee.y = ema_one(ee.y, pp.y, a); ee.z = ema_one(ee.z, pp.z, a); ee.w = ema_one(ee.w, pp.w, a);
       reinterpret_cast<float4*>(ema)[i] = ee;
     }
-  }
   }
 }
 
@@ -451,14 +447,6 @@ int sfron_sumsq_lowrank(const uint16_t* dmod, const uint16_t* sc, int R, int NM,
 int sfron_adam_lowrank(float* p, float* m, float* v, const uint8_t* mask, const float* stats, const uint16_t* dmod, const uint16_t* sc, int R,
                        int NM, int D, double beta1, double beta2, double eps, double step_size, double bc2_sqrt, double decay_mul,
                        uint16_t* w_bf16, float* ema, double ema_decay, int ema_mode, void* stream) {
-  return sfron_adam_lowrank_rows(p, m, v, mask, stats, dmod, sc, R, NM, 0, NM, D, beta1, beta2, eps, step_size, bc2_sqrt, decay_mul, w_bf16, ema, ema_decay,
-                                 ema_mode, 0, stream);
-}
-
-int sfron_adam_lowrank_rows(float* p, float* m, float* v, const uint8_t* mask, const float* stats, const uint16_t* dmod, const uint16_t* sc, int R,
-                            int NM, int row0, int nrows, int D, double beta1, double beta2, double eps, double step_size, double bc2_sqrt,
-                            double decay_mul, uint16_t* w_bf16, float* ema, double ema_decay, int ema_mode, int max_workgroups, void* stream) {
-  SFRON_CHECK_ARG(row0 >= 0 && nrows > 0 && row0 % LR_ROWS == 0 && nrows % LR_ROWS == 0 && row0 + nrows <= NM && max_workgroups >= 0);
   SFRON_CHECK_ARG(p && m && v && dmod && sc && R > 0 && NM > 0 && D > 0 && NM % LR_ROWS == 0 && D % 4 == 0 && D <= 4096);
   SFRON_CHECK_ARG((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)dmod) & 15) == 0 && (((uintptr_t)sc) & 7) == 0);
   SFRON_CHECK_ARG((!mask || ((uintptr_t)mask & 3) == 0) && (!w_bf16 || ((uintptr_t)w_bf16 & 7) == 0));
@@ -466,10 +454,8 @@ int sfron_adam_lowrank_rows(float* p, float* m, float* v, const uint8_t* mask, c
   AdamArgs a{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)step_size, (float)bc2_sqrt,
              (float)decay_mul, (float)ema_decay, (float)(1.0 - ema_decay), ema_mode};
   const int threads = (D / 4 + 63) / 64 * 64;
-  int grid = nrows / LR_ROWS;
-  if (max_workgroups > 0 && grid > max_workgroups) grid = max_workgroups;
-  hipLaunchKernelGGL(k_adam_lowrank, dim3(grid), dim3(threads), 0, (hipStream_t)stream, p, m, v, mask, stats, (const __bf16*)dmod,
-                     (const __bf16*)sc, R, NM, row0, nrows, D, a, w_bf16, ema);
+  hipLaunchKernelGGL(k_adam_lowrank, dim3(NM / LR_ROWS), dim3(threads), 0, (hipStream_t)stream, p, m, v, mask, stats, (const __bf16*)dmod,
+                     (const __bf16*)sc, R, NM, D, a, w_bf16, ema);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

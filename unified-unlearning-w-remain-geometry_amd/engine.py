@@ -225,11 +225,8 @@ class DitEngine:
             st = torch.cuda.Stream(device=self.device)
             for e in evs:
                 e.record(st)
-            ada = torch.cuda.Event(enable_timing=False)      # "the later blocks' adaLN rows are swept" (FlatAdam.step(split=dict(ada=...)))
-            ada.record(st)
             self._bs = dict(ranges=[(lay["blocks"] + l * lay["blk_stride"], lay["blocks"] + (l + 1) * lay["blk_stride"]) for l in range(L)],
-                            stream=st, events=evs, handles=(ctypes.c_void_p * L)(*[e.cuda_event for e in evs]),
-                            ada_event=ada, ada_handle=ctypes.c_void_p(ada.cuda_event))
+                            stream=st, events=evs, handles=(ctypes.c_void_p * L)(*[e.cuda_event for e in evs]))
         return self._bs
 
     @property
@@ -248,21 +245,14 @@ class DitEngine:
             torch.cuda.current_stream().wait_stream(st)
             self._shared["sweep"] = None
 
-    def forward(self, x_t, t, y, drop=None, out=None, block_ready=None, mod_split=None):
-        """block_ready: ctypes array of depth hipEvent_t handles -- block l waits for entry l before it touches its weights.
-        mod_split (with block_ready, bf16 path): (block index sb, hipEvent_t handle) -- the adaLN modulation rows of blocks >= sb (and of the
-        final layer) are formed in front of block sb, behind that event (sfron_dit_forward_split)."""
+    def forward(self, x_t, t, y, drop=None, out=None, block_ready=None):
+        """block_ready: ctypes array of depth hipEvent_t handles -- block l waits for entry l before it touches its weights."""
         if out is None:
             out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
         if x_t.shape[0] != self.cfg.batch:
             raise _lib.SfronError(f"engine was built for batch {self.cfg.batch}, got {x_t.shape[0]}")
         if block_ready is None:
             self.drain_sweep()                 # a block sweep may still be rewriting the weights on its own stream (step.py)
-        if block_ready is not None and self.fp8 is None and mod_split is not None:
-            check(_lib.lib().sfron_dit_forward_split(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(x_t), ptr(t), ptr(y),
-                                                     ptr(drop), ptr(self.workspace), ptr(out), block_ready, int(mod_split[0]), mod_split[1],
-                                                     self.probe, stream_ptr()), "dit_forward_split")
-            return out
         if block_ready is not None and self.fp8 is None:
             check(_lib.lib().sfron_dit_forward_after(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(x_t), ptr(t), ptr(y),
                                                      ptr(drop), ptr(self.workspace), ptr(out), block_ready, self.probe, stream_ptr()),

@@ -69,9 +69,6 @@ class DiTSFRon:
         # embedders / final layer, the rank-(batch) adaLN range is summed from its factors: no pass over the 1.8 GB block range of the arena
         self.fuse_clip_norm = True
         self._sq_buf = None
-        # the adaLN_modulation matrix (a third of the parameters) is swept in two parts: the rows of blocks < ada_split_block in front of the next
-        # forward pass, the rest on the sweep stream beside that pass's first blocks, whose modulation does not need them (0 = one part)
-        self.ada_split_block = 7
         self._ready_owner = None               # (engine, block events) of that sweep, consumed by the next step()'s first forward pass
         self.fp8 = bool(fp8)
         if self.fp8 and model.engine.fp8 is None:
@@ -319,7 +316,7 @@ class DiTSFRon:
         y_safe, b["t"] = self.guard.check_inputs(y, b["t"], self.model.num_classes, self.diffusion.num_timesteps)
         return b, y_safe
 
-    def _pass(self, batch, y, sign_alpha, factored_ada=False, block_ready=None, async_exchange=False, mod_split=None):
+    def _pass(self, batch, y, sign_alpha, factored_ada=False, block_ready=None, async_exchange=False):
         """factored_ada (single process, single chain -- what step() uses): the backward pass leaves the adaLN_modulation weight
         gradient as its two bf16 factors and the next optimizer sweep forms the rank-(batch) product itself (engine.
         backward_factored_ada, csrc/sweep.hip k_adam_lowrank): 892 MB less to write and 892 MB (forget stage: twice) less to read
@@ -330,7 +327,7 @@ class DiTSFRon:
         eng, diff = self.model.engine, self.diffusion
         n_global = batch["x0"].shape[0] * self.world
         x_t = diff.q_sample(batch["x0"], batch["t"], batch["noise"])
-        out = eng.forward(x_t, batch["t"], y, batch.get("drop"), block_ready=block_ready, mod_split=mod_split)
+        out = eng.forward(x_t, batch["t"], y, batch.get("drop"), block_ready=block_ready)
         mse, vb, d_out = diff.loss_fwd_bwd(out, batch["x0"], batch["t"], batch["noise"], sign_alpha / n_global)
         if self._overlap_enabled():
             self._backward_allreduce_overlapped(d_out, y, batch.get("drop"), factored_ada=factored_ada and self.factored_ada)
@@ -427,17 +424,15 @@ class DiTSFRon:
         # synchronous data-parallel exchange: pipelined bucket by bucket into the sweep (FlatAdam.step(pipeline=...)) when the adaLN
         # gradient is exchanged as part of the arena; with the factored form (the default) the pass exchanges everything itself
         dp_sync = self._dp_active() and not self._overlap_enabled() and self.micro == 1 and not self.factored_ada
-        ready = ready_ada = None
+        ready = None
         if self._ready_owner is not None:
             # the events of a sweep left in flight belong to the engine that armed it.  A batch-size change (set_batch_size above, or
             # by the user between two steps) replaced that engine: it was drained and closed -- its events are destroyed -- so there
             # is nothing to wait for and the stale handles must not reach hipStreamWaitEvent
-            owner, handles, ready_ada = self._ready_owner
+            owner, handles = self._ready_owner
             self._ready_owner = None
             if owner is eng and getattr(eng, "_sweep_pending", None) is not None:
                 ready = handles
-            else:
-                ready_ada = None
         if ready is not None:
             eng._sweep_pending = None          # this forward pass waits for the sweep block by block; its backward pass starts behind all of it
         sq_plan = None
@@ -448,8 +443,7 @@ class DiTSFRon:
             if self._sq_buf is None or self._sq_buf.numel() < need:
                 self._sq_buf = torch.empty(need, dtype=torch.float64, device=eng.device)
             eng.arm_sumsq(self.opt.mask, self._sq_buf[:sq_plan["n_gemm"]])        # consumed by the forget pass's backward
-        mse_f, vb_f = self._pass(forget, y_f, sign * self.forget_alpha, factored_ada=True, block_ready=ready, async_exchange=dp_sync,
-                                 mod_split=ready_ada if ready is not None else None)
+        mse_f, vb_f = self._pass(forget, y_f, sign * self.forget_alpha, factored_ada=True, block_ready=ready, async_exchange=dp_sync)
         if sq_plan is not None and self.opt.lowrank is not None:
             self.opt.fused_sumsq = dict(partials=self._sq_buf[:sq_plan["n_gemm"]], buffer=self._sq_buf, ranges=sq_plan["ranges"],
                                         n_ranges=sq_plan["n_ranges"])
@@ -471,20 +465,14 @@ class DiTSFRon:
             bs = self.model.engine.block_sweep_setup()
             split = dict(ranges=bs["ranges"], stream=bs["stream"] if self.sweep_beside_forward else None, events=bs["events"],
                          max_workgroups=self.sweep_beside_wg, head=self.sweep_beside_head, quant=quant)
-            sb = int(self.ada_split_block)
-            ada = None
-            if (self.sweep_beside_forward and not self.fp8 and self.sweep_beside_head <= sb < eng.cfg.depth and sb > 0 and self.opt.lowrank is not None):
-                ada = dict(rows=6 * sb * eng.cfg.hidden, block=sb, event=bs["ada_event"], max_workgroups=self.sweep_beside_wg)
-                split["ada"] = ada
         self._fp8_before_sweep(fused_q)
         pipe, self._pipeline = self._pipeline, None
         self.opt.step(max_norm=self.grad_clip, use_mask=True, split=split, pipeline=pipe)   # forget.py:289-299
         if self.fp8 and not fused_q:
             self.model.engine.fp8_requantize()
         beside = split is not None and split["stream"] is not None
-        ada_on = beside and split.get("ada") is not None
         mse_r, vb_r = self._pass(remain, remain["y"], 1.0, factored_ada=True, block_ready=bs["handles"] if beside else None,
-                                 async_exchange=dp_sync, mod_split=(sb, bs["ada_handle"]) if ada_on else None)
+                                 async_exchange=dp_sync)
         pipe, self._pipeline = self._pipeline, None
         nt = eng.n_trainable
         self._fp8_before_sweep(fused_q)
@@ -492,18 +480,15 @@ class DiTSFRon:
         # same events: the remain forward pass above has consumed them).  step() then returns with that sweep in flight: the next
         # step's forward pass waits block by block, every other reader of the state drains it first (engine.drain_sweep).
         across = beside and self.sweep_across_steps
-        ada_r = across and ada_on and self.opt.lowrank is not None
         if across:
             split_r = dict(ranges=bs["ranges"], stream=bs["stream"], events=bs["events"], max_workgroups=self.sweep_beside_wg,
                            head=self.sweep_beside_head, quant=quant)
-            if ada_r:
-                split_r["ada"] = dict(rows=6 * sb * eng.cfg.hidden, block=sb, event=bs["ada_event"], max_workgroups=self.sweep_beside_wg)
         else:
             split_r = dict(ranges=bs["ranges"], stream=None, quant=quant) if fused_q else None
         self.opt.step(max_norm=None, use_mask=False, ema=self.ema[:nt], ema_decay=self.ema_decay, ema_mode=1,   # :320,322
                       split=split_r, pipeline=pipe)
         if across:
-            self._ready_owner, eng._sweep_pending = (eng, bs["handles"], (sb, bs["ada_handle"]) if ada_r else None), bs["stream"]
+            self._ready_owner, eng._sweep_pending = (eng, bs["handles"]), bs["stream"]
         if self.fp8 and not fused_q:
             self.model.engine.fp8_requantize()
         if eng.n_total > nt:

@@ -158,22 +158,8 @@ class FlatAdam:
                 head = int(split.get("head", 0)) if side is not None else len(rngs)
                 first_own = 0 if quant is not None else head
                 excl = (rngs[first_own][0], rngs[-1][1]) if first_own < len(rngs) else None
-            ada = split.get("ada") if (split is not None and split.get("stream") is not None and self.lowrank is not None) else None
-            ada_args = None
-
-            def lowrank_rows(q, lo, hi, row0, nrows, wg, sp):
-                check(L.sfron_adam_lowrank_rows(ptr(self.p[lo:hi]), ptr(self.m[lo:hi]), ptr(self.v[lo:hi]), ptr(sl(mask, lo, hi)), ptr(stats),
-                                                ptr(q["dmod"]), ptr(q["sc"]), q["R"], q["NM"], row0, nrows, q["D"], b1, b2, self.eps, step_size,
-                                                bc2_sqrt, decay_mul, ptr(sl(self.w_bf16, lo, hi)), ptr(sl(ema, lo, hi)), float(ema_decay), emode,
-                                                wg, sp), "adam_lowrank_rows")
             for lo, hi, lr in self._segments(excl):
-                if lr and ada is not None and 0 < ada["rows"] < self.lowrank["NM"]:
-                    # the rank-R matrix in two parts: the rows the first blocks' modulation needs now, on this stream; the rest on the second
-                    # stream in front of block ada["block"]'s range (below), bounded grid, beside the first blocks' forward pass
-                    q = self.lowrank
-                    lowrank_rows(q, lo, hi, 0, ada["rows"], 0, stream_ptr())
-                    ada_args = (q, lo, hi, ada["rows"], q["NM"] - ada["rows"])
-                elif lr:
+                if lr:
                     q = self.lowrank
                     check(L.sfron_adam_lowrank(ptr(self.p[lo:hi]), ptr(self.m[lo:hi]), ptr(self.v[lo:hi]), ptr(sl(mask, lo, hi)), ptr(stats),
                                                ptr(q["dmod"]), ptr(q["sc"]), q["R"], q["NM"], q["D"], b1, b2, self.eps, step_size, bc2_sqrt,
@@ -210,10 +196,6 @@ class FlatAdam:
                 cur_p = ctypes.c_void_p(cur.cuda_stream)
                 side_p = ctypes.c_void_p(side.cuda_stream) if side is not None else None
                 for i in range(len(rngs)):
-                    if ada_args is not None and i == max(head, min(ada["block"], len(rngs) - 1)):
-                        lowrank_rows(*ada_args, int(ada.get("max_workgroups", cap)), side_p)
-                        ada["event"].record(side)
-                        ada_args = None
                     if i < head:
                         if i >= first_own:
                             sweep_range(i, cur_p, 0)
@@ -222,7 +204,6 @@ class FlatAdam:
                     else:
                         sweep_range(i, side_p, cap)
                         split["events"][i].record(side)
-                assert ada_args is None
             self.lowrank = None
         self.fused_sumsq = None
         if ev is not None:
