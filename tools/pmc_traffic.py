@@ -28,23 +28,26 @@ sha = csrc_sha()
 # the parameter sweeps of a whole step (norm pre-pass + forget-stage AdamW + remain-stage AdamW / EMA, flat and rank-R kernels): totals
 # over the run / 3 steps (1 warm-up + 2)
 n_ada = (6 * 28 + 2) * D * D
+n_gemm = 28 * 12 * D * D      # the block GEMM weights: since round 5 their share of the clip norm is formed in the weight-gradient GEMMs' epilogues
 tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
 for (c, k), (sm, n) in agg.items():
-    if any(x in k for x in ("k_masked_clip_adam", "k_adam_lowrank", "k_sumsq_masked", "k_sumsq_lowrank")):
+    if any(x in k for x in ("k_masked_clip_adam", "k_adam_lowrank", "k_sumsq_masked", "k_sumsq_lowrank", "k_sumsq_ranges")):
         tot[c] += sm
 # steps in the profiled run: NOT the 3 of the command line -- when the timed steps split their remain-stage sweep across the step boundary,
 # bench.py appends two more steps to time that sweep whole (round 3 divided by 3 and reported 5/3 of the traffic: 78.7 GB against 47.2 GB
 # algorithmic, which would have been more than the HBM peak).  k_adam_lowrank runs exactly twice per step (forget + remain stage).
 n_lowrank = max([n for (c, k), (sm, n) in agg.items() if c == "FETCH_SIZE" and "k_adam_lowrank" in k] or [0])
 n_steps = n_lowrank / 2.0 if n_lowrank else 3.0
-json.dump({"kernel": "k_sumsq_masked + k_sumsq_lowrank + k_masked_clip_adam + k_adam_lowrank, all launches of one SFR-on step",
+json.dump({"kernel": "k_sumsq_ranges + k_sumsq_masked + k_sumsq_lowrank + k_masked_clip_adam + k_adam_lowrank, all launches of one SFR-on step",
            "steps_in_run": n_steps,
            "fetch_raw_bytes_per_step": tot["FETCH_SIZE"] * 1024.0 / n_steps, "write_bytes_per_step": tot["WRITE_SIZE"] * 1024.0 / n_steps,
            "traffic_bytes_per_step": (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / n_steps,
-           "algorithmic_bytes_per_step": (5 + 31 + 38) * nt - (4 + 4 + 4) * n_ada, "csrc_sha": sha,
+           "algorithmic_bytes_per_step": (31 + 38) * nt - (4 + 4) * n_ada + 5 * (nt - n_gemm - n_ada), "csrc_sha": sha,
            "note": "same passes; totals over the run / its step count (launches of k_adam_lowrank / 2); FETCH_SIZE x2 (the kernels' reads are "
-                   "16-B-per-lane streams but for the 1-B-per-parameter mask), WRITE_SIZE exact.  Algorithmic: norm pre-pass 5 B/param (g, mask), forget "
-                   "AdamW 31, remain AdamW + EMA 38, minus the gradient reads of the adaLN matrix (formed inside the sweep from its factors)"},
+                   "16-B-per-lane streams but for the 1-B-per-parameter mask), WRITE_SIZE exact.  Algorithmic: forget AdamW 31 B/param, remain AdamW + EMA "
+                   "38, minus the gradient reads of the adaLN matrix (formed inside the sweep from its factors), plus the norm pre-pass (g, mask: 5 B) "
+                   "over what is neither a block GEMM weight (summed in the weight-gradient GEMMs' epilogues) nor the adaLN matrix (summed on the "
+                   "matrix core from its factors by a GEMM launch that is not in this kernel list)"},
           open(os.path.join(out, f"{tag}_sweep_traffic.json"), "w"), indent=1)
 probes.pop("sweep")
 with open(os.path.join(out, f"{tag}_pmc_hbm_traffic_per_kernel.csv"), "w", newline="") as f:
