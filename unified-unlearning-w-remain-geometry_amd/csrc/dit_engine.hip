@@ -103,6 +103,9 @@ inline int wgrad_splits(int N, int K, int Mred) {
 // batch 32: [2048 x 768] = 32 tiles on 256 CUs -- the dispatcher then takes 96 tiles of the register-staged 128 x 128 kernel at 37 us).  Instead the
 // contraction is split over S workgroups per tile (each an even number >= 2 of 64-deep K-tiles: the interleaved schedule), S fp32 slabs are summed in
 // index order by a finish kernel that also applies the epilogue (norm.hip k_split_sum_bf16 / k_split_gate_res).  1 = no split (every DiT-XL/2 shape).
+#ifndef SFRON_SMALL_M_CAP
+#define SFRON_SMALL_M_CAP 4      // same-box A-B at DiT-B/4 batch 32: cap 8 9.88 / 9.81 ms per step, 6 9.70 / 9.87, 4 9.54 / 9.64, 3 9.63 / 9.48, 2 10.30 / 10.21 (the slabs are traffic too)
+#endif
 inline int small_m_splits(int M, int N, int K) {
   if (M % 256 || N % 192 || K % 128) return 1;
   if (N % 144 == 0 && K % 192 == 0 && (M / 256) * (N / 144) >= 128) return 1;     // the 256 x 144 three-slot tile fills half the chip by itself
@@ -110,7 +113,7 @@ inline int small_m_splits(int M, int N, int K) {
   if (tiles >= 128) return 1;
   int best = 1;
   const int kt = K / 64;
-  for (int s = 2; s <= 8; ++s)
+  for (int s = 2; s <= SFRON_SMALL_M_CAP; ++s)
     if (kt % s == 0 && (kt / s) % 2 == 0 && tiles * s <= 256) best = s;
   return best;
 }
