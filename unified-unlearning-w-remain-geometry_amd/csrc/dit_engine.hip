@@ -106,11 +106,15 @@ inline int wgrad_splits(int N, int K, int Mred) {
 #ifndef SFRON_SMALL_M_CAP
 #define SFRON_SMALL_M_CAP 4      // same-box A-B at DiT-B/4 batch 32: cap 8 9.88 / 9.81 ms per step, 6 9.70 / 9.87, 4 9.54 / 9.64, 3 9.63 / 9.48, 2 10.30 / 10.21 (the slabs are traffic too)
 #endif
+#ifndef SFRON_SMALL_M_MIN_K
+#define SFRON_SMALL_M_MIN_K 768   // a 12-K-tile product (proj forward / dgrad at D = 768) is faster as ONE launch: 15 us against 22-25 with its finish
+#endif
 inline int small_m_splits(int M, int N, int K) {
   if (M % 256 || N % 192 || K % 128) return 1;
   if (N % 144 == 0 && K % 192 == 0 && (M / 256) * (N / 144) >= 128) return 1;     // the 256 x 144 three-slot tile fills half the chip by itself
   const int tiles = (M / 256) * (N / 192);
   if (tiles >= 128) return 1;
+  if (K <= SFRON_SMALL_M_MIN_K) return 1;
   int best = 1;
   const int kt = K / 64;
   for (int s = 2; s <= SFRON_SMALL_M_CAP; ++s)
