@@ -19,6 +19,7 @@ With N > 1 the overlapped gradient exchange is switched on only after DiTSFRon.v
 exchange on the ranks of this very run ("dp_overlap" in the JSON says which path was timed).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -190,9 +191,10 @@ def _ddpm_leg(dev, steps=50, batch=64):
             "finite_losses": bool(torch.isfinite(out["forget_loss"]).item() and torch.isfinite(out["remain_loss"]).item())}
 
 
-def _sd_leg(dev, batches=(2, 8), steps=4):
+def _sd_leg(dev, cases=(("xattn", 2), ("full", 2), ("full", 8)), steps=4):
     """BASELINE config 4: SD v1 UNet (859.5 M parameters, 64 x 64 latents, 77-token context) SFR-on iterations of
-    SD/train-scripts/nsfw_removal.py:108-173 (train_method full), at the README's batch 2 and the script's default batch 8."""
+    SD/train-scripts/nsfw_removal.py:108-173: train_method xattn (the "cross-attn path" BASELINE.json names: only the attn2 layers
+    train, nsfw_removal.py:66-77) at the README's batch 2, and train_method full at batch 2 and the script's default batch 8."""
     from sfron import sd, sd_unet, unet
     torch.manual_seed(0)
     model = sd_unet.UNetModel()
@@ -205,8 +207,8 @@ def _sd_leg(dev, batches=(2, 8), steps=4):
     gd = torch.Generator(device=dev).manual_seed(2)
     rn = lambda *sh: torch.randn(*sh, device=dev, generator=gd)
     res = {}
-    for B in batches:
-        run = sd.SDSFRon(model, lr=1e-5, train_method="full", use_graphs=True)
+    for method, B in cases:
+        run = sd.SDSFRon(model, lr=1e-5, train_method=method, use_graphs=True)
         c_f, c_p = rn(1, 77, 768).expand(B, -1, -1).contiguous(), rn(1, 77, 768).expand(B, -1, -1).contiguous()
 
         def batch():
@@ -225,10 +227,11 @@ def _sd_leg(dev, batches=(2, 8), steps=4):
             out = run.step(*bt[i % 2])
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
-        res[f"batch{B}"] = {"ms_per_iteration": ms, "iterations_per_s": 1e3 / ms, "steps": steps, "product_tflop_per_iteration": flops / 1e12,
+        res[f"batch{B}" if method == "full" else f"{method}_batch{B}"] = {"train_method": method, "ms_per_iteration": ms, "iterations_per_s": 1e3 / ms, "steps": steps, "product_tflop_per_iteration": flops / 1e12,
                             "tflops": flops / ms / 1e9, "frac_of_bf16_mfma_peak": flops / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS,
                             "finite_losses": bool(all(torch.isfinite(v).all().item() for v in out.values() if torch.is_tensor(v)))}
         del run
+        gc.collect()                         # the runner's stage graphs die by the collector (closure cycles): now, not inside the next capture
         torch.cuda.empty_cache()
     return res
 
@@ -236,7 +239,6 @@ def _sd_leg(dev, batches=(2, 8), steps=4):
 def other_configs(dev, latent, budget_s=75.0):
     """BASELINE configs 1, 2, 4, 5 behind the headline region, each through its own runner on synthetic inputs, bounded in time; a leg that
     fails or no longer fits the budget reports why instead of a number (the headline line is never at risk)."""
-    import gc
     t_start = time.perf_counter()
     out = {"note": "measured after the headline's timed region in the same process; product FLOPs of the U-Net legs are counted from the "
                    "launches of one iteration (zero-dilated / channel-padded operands included)"}

@@ -10,6 +10,8 @@ share a memory pool overwrite each other's intermediates).  Everything a stage d
 synchronisation, no host-side scalars that change from step to step (the decayed forget alpha travels as a device scalar).  The
 optimizer sweep stays outside (its bias corrections are host scalars) and so does the data-parallel gradient exchange.
 """
+import gc
+
 import torch
 
 
@@ -35,8 +37,18 @@ class StageGraph:
             self.static_in = {k: v.clone() for k, v in inputs.items()}
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, pool=self.pool):
-                self.static_out = self.fn(**self.static_in)
+            # No cyclic garbage collection inside the capture: a dead CUDAGraph (an earlier loop's stage: the closures of a StageGraph form
+            # reference cycles, so it dies by the collector, not by reference count) destroyed WHILE a stream is capturing raises in its
+            # destructor and ends the process (hipErrorStreamCaptureUnsupported; torch.cuda.graph no longer collects on entry by default).
+            gc.collect()
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(self.graph, pool=self.pool):
+                    self.static_out = self.fn(**self.static_in)
+            finally:
+                if gc_was_on:
+                    gc.enable()
         else:
             for k, v in inputs.items():
                 self.static_in[k].copy_(v)
