@@ -517,6 +517,10 @@ inline ChunkPlan pick_chunk(int T) {
   static const int knob = getenv("SFRON_ROW_RPW") ? atoi(getenv("SFRON_ROW_RPW")) : 0;      // A-B of the rows per wave (tools/bench_dbg.py)
   if (knob > 0 && T % (4 * knob) == 0) return {knob, 1, 4 * knob};
 #endif
+  // long sequences: 8 rows per wave = 32 per workgroup -- half the partial rows for the slot reduction to read, and the step measures
+  // 0.2-0.3 ms faster at DiT-XL/2 (same box, three alternations: 62.49 / 62.45 / 62.66 -> 62.27 / 62.20 / 62.07; 16 rows per wave: 62.30 / 62.62 / 62.30;
+  // 2: +0.5 ms).  Short ones (DiT-B/4: 64 tokens) keep 4: their grids are small already
+  if (T % 32 == 0 && T >= 256) return {8, 1, 32};
   if (T % 16 == 0) return {4, 1, 16};
   if (T % 8 == 0) return {2, 1, 8};
   if (T % 4 == 0) return {1, 1, 4};
