@@ -411,6 +411,8 @@ def main():
     if os.environ.get("SFRON_BENCH_ATTN_FWD"):              # A-B knob (tools only): 4 = the four-wave attention forward kernel
         from sfron import _lib
         _lib.lib().sfron_attn_fwd_form(int(os.environ["SFRON_BENCH_ATTN_FWD"]))
+    if os.environ.get("SFRON_BENCH_EARLY_ADA"):             # A-B knob (tools only): 0 = the adaLN matrix's share of the clip norm on the caller's stream
+        runner.opt.early_ada = os.environ["SFRON_BENCH_EARLY_ADA"] != "0"
     if os.environ.get("SFRON_BENCH_SWEEP_BESIDE"):          # tuning knob (tools only): "workgroups,head"
         runner.sweep_beside_wg, runner.sweep_beside_head = (int(v) for v in os.environ["SFRON_BENCH_SWEEP_BESIDE"].split(","))
 

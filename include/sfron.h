@@ -629,6 +629,12 @@ int sfron_aux_set_probe(void* aux, void* probe);
  * norm of the REDUCED gradient.  sfron_dit_sumsq_partials_len returns 0 when a block shape does not run on the 192 x 192 weight-gradient tile. */
 int sfron_dit_sumsq_partials_len(const sfron_dit_cfg* cfg);
 int sfron_aux_arm_sumsq(void* aux, const uint8_t* mask_arena, double* partials);
+/* Orders `stream` behind the point of the LAST backward pass run with this handle after which the adaLN_modulation matrix (weights, bf16
+ * shadow) is not read and its gradient factors (sfron_dit_backward_dp: ada_dmod_out / ada_sc_out) are complete: the dgrad through that
+ * Linear.  What remains of the pass is the embedders' backward; the clip norm's share of the adaLN matrix (sfron_sumsq_lowrank) may run
+ * beside it on another stream (the host mirror does: -0.12 ms per step; sweeping the matrix itself there measured slower).  No-op before
+ * the first backward pass.  Replaces nothing in the reference: scheduling of DiT/forget.py:293-298. */
+int sfron_aux_wait_ada(void* aux, void* stream);
 int sfron_aux_destroy(void* aux);
 
 #ifdef __cplusplus

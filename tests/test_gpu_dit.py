@@ -398,7 +398,7 @@ def test_fused_clip_norm_equals_the_pass_over_the_gradient_arena():
     kw = dict(global_batch=B, num_classes=cfg["num_classes"], forget_class=3, input_size=cfg["input_size"], device=DEV)
     gm = torch.Generator().manual_seed(77)
 
-    def run(fused):
+    def run(fused, early=True):
         ref, model = build_pair(cfg, B, seed=41)
         mask = {n: (torch.rand(p.shape, generator=torch.Generator().manual_seed(5 + i)) < 0.5) for i, (n, p) in enumerate(ref.named_parameters())
                 if p.requires_grad}
@@ -406,6 +406,7 @@ def test_fused_clip_norm_equals_the_pass_over_the_gradient_arena():
         runner = step.DiTSFRon(model, diffusion.create_diffusion(""), lr=2e-4, forget_alpha=0.3, grad_clip=1.0, ema_decay=0.99, mask=mask,
                                unlearn_loss="ga", forget_class=3)
         runner.fuse_clip_norm = fused
+        runner.opt.early_ada = early            # the adaLN matrix's share of the norm on its own stream, behind sfron_aux_wait_ada (the default)
         assert (model.engine.fused_sumsq_plan() is not None)
         norms = []
         for it in range(3):
@@ -417,6 +418,8 @@ def test_fused_clip_norm_equals_the_pass_over_the_gradient_arena():
         runner.guard.poll(block=True)
         return model.engine.params.clone(), norms
     p1, n1 = run(True)
+    p2, n2 = run(True, early=False)
+    assert n1 == n2 and torch.equal(p1, p2)         # the same launches on another stream: the same bits
     p0, n0 = run(False)
     for a, b in zip(n1, n0):
         assert a > 0 and abs(a - b) <= 1e-6 * b, (n1, n0)

@@ -205,6 +205,7 @@ _PROTOS.update({
     "sfron_aux_destroy": (c_int, [c_void_p]),
     "sfron_aux_set_probe": (c_int, [c_void_p, c_void_p]),
     "sfron_aux_arm_sumsq": (c_int, [c_void_p, _P, _P]),
+    "sfron_aux_wait_ada": (c_int, [c_void_p, _S]),
     "sfron_fp8_activation_amax": (c_int, [POINTER(c_float), c_int, c_void_p]),
     "sfron_dit_forward_probed": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_dit_forward_after": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _S]),

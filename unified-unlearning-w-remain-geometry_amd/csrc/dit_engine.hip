@@ -238,7 +238,7 @@ static int ablate_mask() {
 // ---- aux: a side stream + events so the weight-gradient GEMMs (which nothing downstream in the backward chain
 // depends on) run concurrently with the dgrad / elementwise chain and fill the CUs its tile counts leave idle
 struct Probe;
-struct Aux { hipStream_t side, side2; hipEvent_t produced[4], consumed[8], done, join2; Probe* probe; const uint8_t* sq_mask; double* sq_partials; };
+struct Aux { hipStream_t side, side2; hipEvent_t produced[4], consumed[8], done, join2, ada_ready; Probe* probe; const uint8_t* sq_mask; double* sq_partials; };
 
 int sfron_aux_create(void** aux) {
   SFRON_CHECK_ARG(aux);
@@ -261,7 +261,13 @@ int sfron_aux_create(void** aux) {
     if (hipStreamCreateWithPriority(&a->side2, hipStreamNonBlocking, lo) != hipSuccess) return (int)hipGetLastError();
   } else if (hipStreamCreateWithFlags(&a->side2, hipStreamNonBlocking) != hipSuccess) return (int)hipGetLastError();
   if (hipEventCreateWithFlags(&a->join2, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+  if (hipEventCreateWithFlags(&a->ada_ready, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
   *aux = a;
+  return SFRON_OK;
+}
+int sfron_aux_wait_ada(void* aux, void* stream) {
+  SFRON_CHECK_ARG(aux);
+  if (hipStreamWaitEvent((hipStream_t)stream, ((Aux*)aux)->ada_ready, 0) != hipSuccess) return (int)hipGetLastError();
   return SFRON_OK;
 }
 int sfron_aux_destroy(void* aux) {
@@ -272,6 +278,7 @@ int sfron_aux_destroy(void* aux) {
   for (int i = 0; i < 8; ++i) (void)hipEventDestroy(a->consumed[i]);
   (void)hipEventDestroy(a->done);
   (void)hipEventDestroy(a->join2);
+  (void)hipEventDestroy(a->ada_ready);
   (void)hipStreamDestroy(a->side);
   (void)hipStreamDestroy(a->side2);
   delete a;
@@ -830,6 +837,10 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
   g = dgrad_desc(w.dmod_bf, wb + P.ada_w, B, NM, D);
   g.epilogue = SFRON_EPI_F32; g.c_f32 = w.slabs; g.ldc_f32 = D; g.split_k = SPLIT_K_ADA; g.split_stride = (long)B * D;
   RUN(sfron_gemm_bf16(&g, stream));
+  // From here on nothing in this pass reads the adaLN matrix (fp32 or bf16) or writes its gradient factors: a sweep of that matrix -- or the
+  // clip norm's share of it -- may start on another stream while the embedders' backward (a chain of ~25 small launches) is still running
+  // (sfron_aux_wait_ada)
+  if (ax) (void)hipEventRecord(ax->ada_ready, hs);
   {
     const int kchunk = cdiv(cdiv(NM, SPLIT_K_ADA), 64) * 64;
     RUN(sfron_reduce_chunks(w.slabs, 1, cdiv(NM, kchunk), B * D, w.d_sc, B * D, 0, stream));

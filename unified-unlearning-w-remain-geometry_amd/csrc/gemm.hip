@@ -234,6 +234,20 @@ __global__ __launch_bounds__(NT) void k_gemm(GemmArgs g) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (kend - kbeg + BK - 1) / BK;
+  // EPI_SUMSQ (a rank-R product: ONE K-tile): the tile's mask words are requested in front of the operand loads -- behind the K-loop they were a
+  // second exposed memory latency in a workgroup that lives for two (188 us for the adaLN matrix of DiT-XL/2, on the critical stream).  Branch-free:
+  // out-of-range positions read a clamped address and are zeroed below.
+  [[maybe_unused]] uint32_t mkw[4][4];
+  if constexpr (EPI == EPI_SUMSQ) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int row = m0 + wm * 64 + mt * 16 + (lane & 15), col = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
+        const int rc = row < g.M ? row : g.M - 1, cc = col < g.N ? col : g.N - 4;
+        mkw[mt][nt] = g.sq_mask ? *reinterpret_cast<const uint32_t*>(g.sq_mask + (size_t)rc * g.N + cc) : 0x01010101u;
+      }
+  }
   uint4 ra[4], rb[4];
   stA.template load<FULL>(ra, kbeg, kend);
   stB.template load<FULL>(rb, kbeg, kend);
@@ -283,25 +297,16 @@ __global__ __launch_bounds__(NT) void k_gemm(GemmArgs g) {
     // the product is never stored: masked sum of squares of the tile (the clip-norm pre-pass over a gradient that exists only as its
     // two factors: sweep.hip sfron_sumsq_lowrank).  All 16 mask words of a lane are fetched before the first use; lanes, then waves,
     // are summed in a fixed order (double from the wave sums on): bitwise reproducible.
-    uchar4 mk[4][4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int row = m0 + wm * 64 + mt * 16 + (lane & 15), col = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
-        const bool in = row < g.M && col < g.N;
-        const unsigned char one = in ? 1 : 0;
-        mk[mt][nt] = make_uchar4(one, one, one, one);
-        if (g.sq_mask && in) mk[mt][nt] = *reinterpret_cast<const uchar4*>(g.sq_mask + (size_t)row * g.N + col);
-      }
     float sq = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
+        const int row = m0 + wm * 64 + mt * 16 + (lane & 15), col = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
+        const uint32_t m4 = (row < g.M && col < g.N) ? mkw[mt][nt] : 0u;
         const f32x4 v = acc[mt][nt] * g.alpha;
-        const uchar4 m4 = mk[mt][nt];
-        sq += (m4.x ? v[0] * v[0] : 0.f) + (m4.y ? v[1] * v[1] : 0.f) + (m4.z ? v[2] * v[2] : 0.f) + (m4.w ? v[3] * v[3] : 0.f);
+        sq += ((m4 & 0xffu) ? v[0] * v[0] : 0.f) + ((m4 & 0xff00u) ? v[1] * v[1] : 0.f) + ((m4 & 0xff0000u) ? v[2] * v[2] : 0.f) +
+              ((m4 & 0xff000000u) ? v[3] * v[3] : 0.f);
       }
     double d = wave_sum_d((double)sq);
     double* red = reinterpret_cast<double*>(smem);          // (the main loop ended with a barrier: the staging images are free)

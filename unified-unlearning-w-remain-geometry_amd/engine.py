@@ -332,7 +332,12 @@ class DitEngine:
         check(_lib.lib().sfron_dit_backward_dp(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(d_out), ptr(y),
                                                ptr(drop), ptr(self.workspace), ptr(self.grads), self.aux, None, None, ptr(dmod), ptr(sc),
                                                stream_ptr()), "dit_backward (factored adaLN gradient)")
-        return dict(lo=self.layout["ada_w"], NM=dmod.shape[1], D=self.cfg.hidden, dmod=dmod, sc=sc, R=self.cfg.batch)
+        return dict(lo=self.layout["ada_w"], NM=dmod.shape[1], D=self.cfg.hidden, dmod=dmod, sc=sc, R=self.cfg.batch, wait=self.ada_wait)
+
+    def ada_wait(self, stream):
+        """Order ``stream`` (a torch stream) behind the point of the last backward pass after which nothing reads the adaLN matrix and its two
+        gradient factors are complete (sfron_aux_wait_ada): what is left of the pass then is the embedders' backward."""
+        check(_lib.lib().sfron_aux_wait_ada(self.aux, ctypes.c_void_p(stream.cuda_stream)), "aux_wait_ada")
 
     # ------------------------------------------------------------------ clip norm taken where the gradients are produced
     def fused_sumsq_plan(self):

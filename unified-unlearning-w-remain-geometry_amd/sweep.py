@@ -40,6 +40,10 @@ class FlatAdam:
         # dict(lo=element offset of W [NM][D], NM=, D=, dmod=bf16 [R][NM], sc=bf16 [R][D], R=) -- the gradient arena is NOT read
         # over [lo, lo + NM * D): the sweep forms dmod^T sc itself (csrc/sweep.hip k_adam_lowrank)
         self.lowrank = None
+        # the clip norm's share of the adaLN matrix does not depend on the end of the backward pass: it starts early, on a stream of its own
+        # (_early_stream).  NOT the remain-stage sweep of that matrix: started there it stretches the embedders' backward (25 small dependent
+        # launches under a bandwidth-saturating kernel) and the step measures 1.8 ms slower (profiles/r05_ab_log.txt)
+        self.early_ada, self._ada_stream = True, None
         # optional (set per step by the caller, cleared by step()): the masked sums of squares of PART of the arena were already written by
         # the kernels that produced those gradients -- dict(partials=fp64 tensor [n_gemm] (filled on this stream before step() is called),
         # ranges=int64 device table [n_ranges][2] of the element ranges they do NOT cover, n_ranges=) -- engine.fused_sumsq_plan().  With
@@ -69,6 +73,21 @@ class FlatAdam:
                 out.append((a, b, False))
         return [sg for sg in out if sg[1] > sg[0]]
 
+    def _early_stream(self, q):
+        """The stream for work on the adaLN matrix that may start before the backward pass has ended (``q`` = the low-rank description with the
+        engine's ``wait`` hook, single-process passes only), ordered behind that point; None = no such hook: the current stream."""
+        if not self.early_ada or q is None or q.get("wait") is None:
+            return None
+        if self._ada_stream is None:
+            self._ada_stream = torch.cuda.Stream()
+        q["wait"](self._ada_stream)
+        return self._ada_stream
+
+    def _join(self, side):
+        ev = torch.cuda.Event()
+        ev.record(side)
+        torch.cuda.current_stream().wait_event(ev)
+
     def grad_norm_clip_coef(self, max_norm, use_mask):
         """Launch the norm pre-pass; leaves (norm, coef, sumsq) in self.stats on device (no host sync)."""
         L = _lib.lib()
@@ -84,8 +103,14 @@ class FlatAdam:
             check(L.sfron_sumsq_masked_ranges(ptr(self.g), ptr(mask), ptr(fs["ranges"]), n_rng, ptr(buf[n_gemm:]), s), "sumsq_masked_ranges")
             nblk = ctypes.c_int(0)
             lo, hi = q["lo"], q["lo"] + q["NM"] * q["D"]
+            side = self._early_stream(q)
+            # the adaLN matrix's share (a rank-(batch) product on the matrix core, 0.17 ms at DiT-XL/2) beside the embedders' backward, which is
+            # still running on this stream: it needs the two factors only (engine.ada_wait)
             check(L.sfron_sumsq_lowrank(ptr(q["dmod"]), ptr(q["sc"]), q["R"], q["NM"], q["D"], ptr(None if mask is None else mask[lo:hi]),
-                                        ptr(buf[n_gemm + n_rng:]), ctypes.byref(nblk), s), "sumsq_lowrank")
+                                        ptr(buf[n_gemm + n_rng:]), ctypes.byref(nblk), s if side is None else ctypes.c_void_p(side.cuda_stream)),
+                  "sumsq_lowrank")
+            if side is not None:
+                self._join(side)
             check(L.sfron_clip_coef(ptr(buf), n_gemm + n_rng + nblk.value, float(max_norm), ptr(self.stats), s), "clip_coef")
             return
         segs = self._segments()
