@@ -10,6 +10,8 @@ Tolerances: fp32 outputs differ from torch by accumulation order only (rel-L2 < 
 rounding (2^-9 relative per element); whole-model bounds as in tests/test_gpu_dit.py (bf16 GEMM operands).
 The oracle's PatchEmbed / Attention / Mlp restate timm's published behaviour (timm is un-vendored and un-pinned by the reference):
 the 4e-2 per-tensor gradient bounds below are against that restatement -- parity unpinned at timm."""
+import os
+
 import pytest
 import torch
 
@@ -507,3 +509,20 @@ def test_xl2_fifty_sfron_iterations_vs_oracles():
         assert abs(d_hip) < max(abs(r[2]) for r in rows) + 3e-4, (it, d_hip, d_b16)
     # the operand type's own cost is what the header says it is (not zero)
     assert abs(rows[0][2]) > 5e-5 and max(abs(r[2]) for r in rows) > 2e-4
+
+
+@pytest.mark.gpu
+def test_xl2_headline_schedule_is_reproducible_bit_for_bit():
+    """The headline runner exactly as bench.py configures it (DiT-XL/2, batch 32, block sweeps beside the forward pass and across the step
+    boundary, weight gradients / the clip norm's adaLN share on their own streams, fused clip norm) for 12 steps, twice from the same weights
+    and batches: parameters, both moments and the EMA come out bit-identical.  Every overlap in the step is ordered by events only; a missing
+    one is a race, and a race shows as a difference (tools/soak_repro.py is the same run at any length: 60 steps measured identical)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("soak_repro", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools",
+                                                                              "soak_repro.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    a = mod.run(12)
+    b = mod.run(12)
+    assert a == b, (a, b)
+    assert all(x == x for x in a[1])            # finite losses
