@@ -416,6 +416,11 @@ int sfron_cast_rows_colsum(const float* x, int ldx, int64_t rows, int C, uint16_
 /* keep mask of nn.Dropout(p) (DDPM/models/diffusion.py:131), 1 = kept with probability 1 - p: a counter-based draw keyed by
  * (seed, counter[0] on the device, salt, element); the caller advances the device counter once per pass */
 int sfron_dropout_mask(uint64_t seed, const int64_t* counter, int64_t salt, int64_t n, float p, uint8_t* mask, void* stream);
+/* The same masks for n_items (salt, n) pairs in one launch: items_dev = DEVICE int64 triples [salt, n, byte offset into mask_base]
+ * (offsets multiples of 4), max_n = the largest n.  Bit for bit what n_items calls of sfron_dropout_mask write (the nn.Dropout of every
+ * ResnetBlock of a pass, DDPM/models/diffusion.py:131). */
+int sfron_dropout_mask_batch(uint64_t seed, const int64_t* counter, const int64_t* items_dev, int n_items, int64_t max_n, float p,
+                             uint8_t* mask_base, void* stream);
 int sfron_copy_cols(const float* x, int ldx, int64_t rows, int C, float* y, int ldy, int accumulate, void* stream);
 /* get_timestep_embedding (:17-35): bf16 [n][dim] = sin(t f) || cos(t f), f_j = exp(-ln(1e4) j / (dim/2 - 1)); t float */
 int sfron_ddpm_timestep_embed(const float* t, int n, int dim, uint16_t* out, void* stream);

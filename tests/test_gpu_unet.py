@@ -469,6 +469,39 @@ def test_dropout_mask_kernel_statistics_and_keys():
     assert abs(torch.corrcoef(torch.stack([x[:, :-1].flatten(), x[:, 1:].flatten()]))[0, 1].item()) < 5e-3
     odd = draw(7, 3, size=1001)                                                                   # tail that is not a multiple of four
     assert odd.shape[0] == 1001 and set(odd.unique().tolist()) <= {0, 1}
+    # every mask of a pass in one launch (sfron_dropout_mask_batch): the same bits as the launches it replaces
+    sizes = [64 * 32 * 32 * 128, 1001, 4, 7, 64 * 8 * 8 * 256]
+    items, off = [], 0
+    for k, sz in enumerate(sizes):
+        items.append((k + 1, sz, off))
+        off += (sz + 3) // 4 * 4
+    table = torch.tensor([v for it in items for v in it], dtype=torch.int64, device=DEV)
+    buf = torch.full((off,), 9, dtype=torch.uint8, device=DEV)
+    check(L.sfron_dropout_mask_batch(7, ptr(cnt), ptr(table), len(items), max(sizes), p, ptr(buf), stream_ptr()), "dropout_mask_batch")
+    for salt, sz, o in items:
+        assert torch.equal(buf[o:o + sz], draw(7, salt, size=sz)), (salt, sz)
+        assert bool((buf[o + sz:o + (sz + 3) // 4 * 4] == 9).all())                             # nothing written past a mask's end
+
+
+def test_unet_draws_its_dropout_masks_in_one_launch_from_the_second_pass_on():
+    """Conditional_Model in training mode draws its own nn.Dropout masks (models/diffusion.py:131): the first pass at a batch size asks mask by
+    mask and records the requests, later passes draw them with ONE launch -- the masks of a pass depend on (seed, pass counter, block) only,
+    so two models with the same seed see the same masks whichever way they were drawn: same outputs bit for bit."""
+    from sfron import unet
+    outs = []
+    for warm in (0, 1):
+        torch.manual_seed(123)
+        model = unet.Conditional_Model(ch=128, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(8,), dropout=0.3, resolution=16, n_classes=10)
+        model.train()
+        g = torch.Generator().manual_seed(5)
+        x, t, c = torch.randn(4, 3, 16, 16, generator=g).to(DEV), torch.randint(0, 1000, (4,), generator=g).float().to(DEV), torch.randint(0, 10, (4,), generator=g).to(DEV)
+        keep = torch.ones(4, dtype=torch.uint8, device=DEV)
+        if warm:                                   # an extra pass first: the compared pass is then a batched one -- rewind its counter
+            model(x, t, c, keep_mask=keep)
+            assert model._drop_plans and 4 in model._drop_plans
+            model._drop_counter.zero_()
+        outs.append(model(x, t, c, keep_mask=keep).detach().clone())
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_unet_forward_backward_bitwise_reproducible():

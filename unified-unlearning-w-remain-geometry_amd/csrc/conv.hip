@@ -1707,6 +1707,27 @@ __global__ __launch_bounds__(TPB) void k_dropout_mask(uint64_t seed, const int64
     else { const uint8_t e[4] = {m.x, m.y, m.z, m.w}; for (int k = 0; 4 * i + k < n; ++k) out[4 * i + k] = e[k]; }
   }
 }
+// Every dropout mask of a pass in ONE launch: item j = mask (salt, n elements) at byte offset `off` of one buffer (int64 triples [salt, n, off],
+// off % 4 == 0); blockIdx.y = item.  Bit for bit the masks k_dropout_mask draws for the same (seed, counter, salt): a U-Net pass asked for one
+// launch per ResnetBlock (44 launches of 5 us per DDPM SFR-on step).
+__global__ __launch_bounds__(TPB) void k_dropout_mask_batch(uint64_t seed, const int64_t* __restrict__ counter, const int64_t* __restrict__ items,
+                                                            unsigned thresh16, uint8_t* __restrict__ base_out) {
+  const int64_t salt = items[3 * blockIdx.y], n = items[3 * blockIdx.y + 1];
+  uint8_t* const out = base_out + items[3 * blockIdx.y + 2];
+  const uint64_t base = seed ^ ((uint64_t)counter[0] * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)salt * 0xD1B54A32D192ED03ull);
+  const int64_t nq = (n + 3) >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nq; i += (int64_t)gridDim.x * TPB) {
+    uint64_t z = base + (uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    uchar4 m;
+    m.x = (unsigned)(z & 0xffff) >= thresh16; m.y = (unsigned)((z >> 16) & 0xffff) >= thresh16;
+    m.z = (unsigned)((z >> 32) & 0xffff) >= thresh16; m.w = (unsigned)(z >> 48) >= thresh16;
+    if (4 * i + 3 < n) *reinterpret_cast<uchar4*>(out + 4 * i) = m;
+    else { const uint8_t e[4] = {m.x, m.y, m.z, m.w}; for (int k = 0; 4 * i + k < n; ++k) out[4 * i + k] = e[k]; }
+  }
+}
 // y[rows][ld_y] column slice <- x[rows][C] (channel concatenation) and back (+=)
 __global__ __launch_bounds__(TPB) void k_copy_cols(const float* __restrict__ x, int ldx, int64_t rows, int C, float* __restrict__ y, int ldy,
                                                    int accumulate) {
@@ -2392,6 +2413,17 @@ int sfron_dropout_mask(uint64_t seed, const int64_t* counter, int64_t salt, int6
   SFRON_CHECK_ARG(counter && mask && n > 0 && p >= 0.f && p < 1.f && (((uintptr_t)mask) & 3) == 0);
   const unsigned thresh = (unsigned)(p * 65536.0f + 0.5f);
   hipLaunchKernelGGL(k_dropout_mask, dim3(grid_for((n + 3) / 4)), dim3(TPB), 0, (hipStream_t)stream, seed, counter, salt, n, thresh, mask);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+int sfron_dropout_mask_batch(uint64_t seed, const int64_t* counter, const int64_t* items_dev, int n_items, int64_t max_n, float p, uint8_t* mask_base,
+                             void* stream) {
+  SFRON_CHECK_ARG(counter && items_dev && mask_base && n_items > 0 && n_items <= 65535 && max_n > 0 && p >= 0.f && p < 1.f &&
+                  (((uintptr_t)mask_base) & 3) == 0);
+  const unsigned thresh = (unsigned)(p * 65536.0f + 0.5f);
+  int gx = grid_for((max_n + 3) / 4);
+  if (gx > 64) gx = 64;                         // n_items rows of workgroups fill the chip
+  hipLaunchKernelGGL(k_dropout_mask_batch, dim3(gx, n_items), dim3(TPB), 0, (hipStream_t)stream, seed, counter, items_dev, thresh, mask_base);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

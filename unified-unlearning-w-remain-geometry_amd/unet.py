@@ -779,19 +779,35 @@ class Conditional_Model(_TapeNet):
                 m = next(masks)
                 return None if m is None else m.to(device=dev, dtype=torch.uint8).contiguous()
             if self.training and self.dropout_p > 0:
-                m = torch.empty(rows, C, dtype=torch.uint8, device=dev)
                 salt[0] += 1
+                if drop_plan is not None:                 # drawn by the one launch at the top of the pass
+                    psalt, n, off = drop_plan["items"][salt[0] - 1]
+                    if (psalt, n) != (salt[0], rows * C):
+                        raise RuntimeError("the dropout plan of this batch size does not match the pass (model changed after its first pass?)")
+                    return drawn[off:off + n].view(rows, C)
+                m = torch.empty(rows, C, dtype=torch.uint8, device=dev)
                 check(L.sfron_dropout_mask(self._drop_seed, ptr(self._drop_counter), salt[0], rows * C, self.dropout_p, ptr(m), stream_ptr()),
                       "dropout_mask")
+                recorded.append((salt[0], rows * C))
                 return m
             return None
 
         salt = [0]
+        drop_plan, drawn, recorded = None, None, []
+        if getattr(self, "_drop_plans", None) is None:
+            self._drop_plans = {}
         if masks is None and self.training and self.dropout_p > 0:
             if getattr(self, "_drop_counter", None) is None:
                 self._drop_seed = torch.initial_seed() & ((1 << 63) - 1)           # follows torch.manual_seed
                 self._drop_counter = torch.zeros(1, dtype=torch.int64, device=dev)
             self._drop_counter.add_(1)                                             # one device-side tick per pass (graph-replay safe)
+            # the first pass at a batch size draws mask by mask and records what it asked for; later passes draw all of them in ONE launch
+            # (the same bits: sfron_dropout_mask_batch)
+            drop_plan = self._drop_plans.get(B)
+            if drop_plan is not None:
+                drawn = torch.empty(drop_plan["bytes"], dtype=torch.uint8, device=dev)
+                check(L.sfron_dropout_mask_batch(self._drop_seed, ptr(self._drop_counter), ptr(drop_plan["table"]), len(drop_plan["items"]), drop_plan["max_n"],
+                                                 self.dropout_p, ptr(drawn), stream_ptr()), "dropout_mask_batch")
 
         # ---- input
         S = self.resolution
@@ -865,6 +881,13 @@ class Conditional_Model(_TapeNet):
         o_t, co_b = self._conv3(a, B, h.H, h.W, "conv_out", h.H, h.W)
         out = torch.empty(B, self.out_ch, h.H, h.W, dtype=torch.float32, device=dev)
         check(L.sfron_rows_to_nchw(ptr(o_t), v["cop"], B, self.out_ch, h.H * h.W, ptr(out), stream_ptr()), "rows_to_nchw")
+        if recorded and drop_plan is None:               # first pass at this batch size: remember what the pass asks for
+            items, off = [], 0
+            for sl_, n in recorded:
+                items.append((sl_, n, off))
+                off += (n + 3) // 4 * 4
+            self._drop_plans[B] = dict(items=items, bytes=off, max_n=max(n for _, n in recorded),
+                                       table=torch.tensor([v for it in items for v in it], dtype=torch.int64, device=dev))
         if not need_grad:
             return out, None
 
