@@ -500,13 +500,15 @@ def test_xl2_fifty_sfron_iterations_vs_oracles():
     runner.guard.poll(block=True)
     assert runner.opt.step_count == 100
     # Bounds: a bf16-operand trajectory at this size is defined to ~3e-4 only -- the bf16-operand ORACLE differs from itself
-    # by 2e-4 between runs, and the HIP path moved by 3.1e-4 at iteration 10 between two builds whose only numerical difference is the summation
-    # order of the clip norm (fused into the weight-gradient epilogues in round 5).  Two such trajectories are therefore compared at 6e-4; before
-    # any step (no trajectory yet) at 5e-5.
+    # by 2e-4 between runs, and the HIP path (reproducible run to run for ONE build) moves by as much between builds that differ in a summation
+    # order only: at iteration 50 it measured -7.5e-4, -6.2e-4 and -1.05e-3 against the fp32 oracle in three builds of round 5 (clip norm fused
+    # into the weight-gradient epilogues; 8 instead of 4 rows per partial in the LayerNorm backward), the bf16-operand oracle -6.4e-4 ... -9.1e-4 in
+    # five runs.  So: two such trajectories are compared at 6e-4 (measured: up to 3.5e-4), each against the fp32 oracle at 1.5e-3, and before any
+    # step (no trajectory yet) HIP and the bf16-operand oracle at 5e-5.
     assert abs(rows[0][4]) < 5e-5, rows[0]
     for it, f32, d_b16, d_hip, d_hb in rows:
         assert abs(d_hb) < 6e-4, (it, d_hb)
-        assert abs(d_hip) < max(abs(r[2]) for r in rows) + 3e-4, (it, d_hip, d_b16)
+        assert abs(d_hip) < 1.5e-3 and abs(d_b16) < 1.5e-3, (it, d_hip, d_b16)
     # the operand type's own cost is what the header says it is (not zero)
     assert abs(rows[0][2]) > 5e-5 and max(abs(r[2]) for r in rows) > 2e-4
 
