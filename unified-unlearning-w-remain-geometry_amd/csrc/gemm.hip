@@ -957,20 +957,6 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) { f32x4& c = acc[i][j]; asm volatile("" : "+v"(c)); }
   }
-#ifdef SFRON_DGELU_PREFETCH
-  // EPI_DGELU (dgrad through fc2 + GELU'): the pre-activation tile the epilogue multiplies with is requested inside the LAST K-tile -- the first
-  // DGP_N of the MT x NT/2 16-byte pieces of a lane; the rest go out when the epilogue starts and are used last.  Was: all of them behind the
-  // K-loop, one exposed memory latency per workgroup (epilogue 6.0 us against 2.5 without GELU').  Branch-free: a descriptor of length 0 when the
-  // leading dimensions do not keep the pieces 16-byte aligned (the epilogue then takes its 8-byte path and ignores these registers).
-  constexpr bool DGP = EPI == EPI_DGELU && NL == 0 && SCHED == 1 && (NT % 2) == 0;
-  constexpr int DGP_N = DGP ? (SFRON_DGELU_PREFETCH < MT * (NT / 2) ? SFRON_DGELU_PREFETCH : MT * (NT / 2)) : 0;
-  [[maybe_unused]] uint4 dgp[DGP_N > 0 ? DGP_N : 1];
-  [[maybe_unused]] const bool dgp_wide = ((g.ldaux | g.ldcb) & 7) == 0;
-  [[maybe_unused]] const __amdgpu_buffer_rsrc_t dgp_rs =
-      __builtin_amdgcn_make_buffer_rsrc((void*)g.aux, 0, DGP && dgp_wide ? 0x7fffffff : 0, 0x00020000);
-  [[maybe_unused]] const unsigned dgp_off = DGP ? 2u * ((unsigned)(m0 + wm * MT * 16 + (lane & 15)) * (unsigned)g.ldaux +
-                                                         (unsigned)(n0 + wn * NT * 16 + pair_col(lane >> 4))) : 0u;
-#endif
   f32x4 bacc[BSUM ? MT : 1];
   bf16x8 ones;
   const bool do_bs = BSUM && g.bsum != nullptr && wn == 0 && blockIdx.y == 0;     // wave-uniform
@@ -1218,7 +1204,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
     // end of the k range the request goes through a descriptor with num_records = 0, which makes every lane out of
     // range (an out-of-range raw buffer load fetches nothing), so every iteration runs the same straight-line code.
     const int kend = kbeg + nk * BK;
-    auto body = [&](auto bufc, auto firstc, int kt, auto lastc) {
+    auto body = [&](auto bufc, auto firstc, int kt) {
       constexpr int BUF = decltype(bufc)::value;
       constexpr bool FIRST = decltype(firstc)::value;
       // this wave's share of tile kt has landed
@@ -1228,15 +1214,6 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
                                                                                // (every wave issues NDA + NDB requests, no-ops included)
       __builtin_amdgcn_s_barrier();                           // everybody's has; the slot of tile kt-1 is free
       __builtin_amdgcn_sched_barrier(0);
-#ifdef SFRON_DGELU_PREFETCH
-      if constexpr (decltype(lastc)::value && DGP_N > 0) {
-        static_for<DGP_N>([&](auto ic) {
-          constexpr int i = decltype(ic)::value, mt = i / (NT / 2), np = i % (NT / 2);
-          dgp[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(dgp_rs, dgp_off + 2u * (unsigned)(mt * 16) * (unsigned)g.ldaux + np * 64, 0, 0));
-        });
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#endif
       constexpr int TGT = (BUF + NS - 1) % NS;                // slot the request of this iteration goes to
       const int knext = kbeg + (kt + NS - 1) * BK;
       const bool more = knext < kend;
@@ -1288,30 +1265,21 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
 #endif
     // nk is even and >= 2 here (the launcher routes other k ranges to the plain schedule): no conditional tail, whose
     // control-flow merge made hipcc spill fragment registers that an asynchronous ds_read had not filled yet
-    using NoLast = std::false_type;
-    body(I0{}, std::true_type{}, 0, NoLast{});
+    body(I0{}, std::true_type{}, 0);
+    body(I1{}, std::false_type{}, 1);
     if constexpr (NS == 2) {
-#ifdef SFRON_DGELU_PREFETCH
-      // (nk >= 4: the dispatcher keeps two-tile contractions off this build's EPI_DGELU instantiation)
-      body(I1{}, std::false_type{}, 1, NoLast{});
-      for (int kt = 2; kt < nk - 2; kt += 2) { body(I0{}, std::false_type{}, kt, NoLast{}); body(I1{}, std::false_type{}, kt + 1, NoLast{}); }
-      body(I0{}, std::false_type{}, nk - 2, NoLast{}); body(I1{}, std::false_type{}, nk - 1, std::true_type{});
-#else
-      body(I1{}, std::false_type{}, 1, NoLast{});
-      for (int kt = 2; kt < nk; kt += 2) { body(I0{}, std::false_type{}, kt, NoLast{}); body(I1{}, std::false_type{}, kt + 1, NoLast{}); }
-#endif
-    } else {
-      body(I1{}, std::false_type{}, 1, NoLast{});                                                  // nk >= PRO and (nk - PRO) % 3 == 0 guaranteed by the launcher
+      for (int kt = 2; kt < nk; kt += 2) { body(I0{}, std::false_type{}, kt); body(I1{}, std::false_type{}, kt + 1); }
+    } else {                                                  // nk >= PRO and (nk - PRO) % 3 == 0 guaranteed by the launcher
       using I2 = std::integral_constant<int, 2>;
       static_assert(PRO == 2 || PRO == 3, "prologue length");
       if constexpr (PRO == 2) {
         for (int kt = 2; kt < nk; kt += 3) {
-          body(I2{}, std::false_type{}, kt, NoLast{}); body(I0{}, std::false_type{}, kt + 1, NoLast{}); body(I1{}, std::false_type{}, kt + 2, NoLast{});
+          body(I2{}, std::false_type{}, kt); body(I0{}, std::false_type{}, kt + 1); body(I1{}, std::false_type{}, kt + 2);
         }
       } else {
-        body(I2{}, std::false_type{}, 2, NoLast{});
+        body(I2{}, std::false_type{}, 2);
         for (int kt = 3; kt < nk; kt += 3) {
-          body(I0{}, std::false_type{}, kt, NoLast{}); body(I1{}, std::false_type{}, kt + 1, NoLast{}); body(I2{}, std::false_type{}, kt + 2, NoLast{});
+          body(I0{}, std::false_type{}, kt); body(I1{}, std::false_type{}, kt + 1); body(I2{}, std::false_type{}, kt + 2);
         }
       }
     }
@@ -1378,12 +1346,8 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int np = 0; np < NP; ++np) {
-#ifdef SFRON_DGELU_PREFETCH
-          if (mt * NP + np < DGP_N) { hp[mt][np] = dgp[mt * NP + np < DGP_N ? mt * NP + np : 0]; continue; }
-#endif
+        for (int np = 0; np < NP; ++np)
           hp[mt][np] = *reinterpret_cast<const uint4*>(g.aux + (size_t)(row_b + mt * 16) * g.ldaux + col_p + np * 32);
-        }
         if constexpr (NT & 1)
           hx[mt][NT - 1] = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)(row_b + mt * 16) * g.ldaux + col_b + (NT - 1) * 16);
       }
