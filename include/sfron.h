@@ -422,6 +422,11 @@ int sfron_dropout_mask(uint64_t seed, const int64_t* counter, int64_t salt, int6
 int sfron_dropout_mask_batch(uint64_t seed, const int64_t* counter, const int64_t* items_dev, int n_items, int64_t max_n, float p,
                              uint8_t* mask_base, void* stream);
 int sfron_copy_cols(const float* x, int ldx, int64_t rows, int C, float* y, int ldy, int accumulate, void* stream);
+/* Two such copies in one launch: y0[rows][ldy0] columns [0, C0) (+)= x0, y1 columns [0, C1) (+)= x1 -- the up path's torch.cat([h, skip], dim=1)
+ * (DDPM/models/diffusion.py:403, openaimodel.py:791) with y0 / y1 the two column halves of the concatenated tensor, and its backward with x0 / x1
+ * the halves of its gradient. */
+int sfron_copy_cols2(const float* x0, int ldx0, int C0, float* y0, int ldy0, int accumulate0, const float* x1, int ldx1, int C1, float* y1,
+                     int ldy1, int accumulate1, int64_t rows, void* stream);
 /* get_timestep_embedding (:17-35): bf16 [n][dim] = sin(t f) || cos(t f), f_j = exp(-ln(1e4) j / (dim/2 - 1)); t float */
 int sfron_ddpm_timestep_embed(const float* t, int n, int dim, uint16_t* out, void* stream);
 /* out[b] = keep[b] ? table[c[b]] : null_emb (:370-376; keep NULL = all kept); backward accumulates into d_table (+=), writes d_null */

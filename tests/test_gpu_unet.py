@@ -812,3 +812,23 @@ def test_unet_test_mode_is_differentiable_like_the_reference():
         assert dots / math.sqrt(na * nb) > (0.998 if s_ else 0.9995), (s_, dots / math.sqrt(na * nb))
     with torch.no_grad():
         assert not model(x.to(DEV), t.to(DEV), c.to(DEV), mode="test", cond_scale=2.0).requires_grad
+
+
+def test_copy_cols2_is_cat_and_its_backward():
+    """sfron_copy_cols2: torch.cat([h, skip], dim=1) of the up path (models/diffusion.py:403) in one launch, and the backward that splits the
+    gradient into the two sources' buffers (one overwritten, one accumulated into) -- against torch, bit for bit; an unaligned width takes the
+    two plain launches behind the same entry point."""
+    from sfron import _lib
+    from sfron._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    for rows, c1, c2 in ((4096, 256, 128), (1000, 128, 256), (64, 6, 10)):
+        a, b = torch.randn(rows, c1, generator=g).to(DEV), torch.randn(rows, c2, generator=g).to(DEV)
+        cat = torch.full((rows, c1 + c2), float("nan"), device=DEV)
+        check(L.sfron_copy_cols2(ptr(a), c1, c1, ptr(cat), c1 + c2, 0, ptr(b), c2, c2, cat.data_ptr() + 4 * c1, c1 + c2, 0, rows, stream_ptr()), "copy_cols2")
+        assert torch.equal(cat, torch.cat([a, b], dim=1))
+        dcat = torch.randn(rows, c1 + c2, generator=g).to(DEV)
+        ga, gb0 = torch.full((rows, c1), float("nan"), device=DEV), torch.randn(rows, c2, generator=g).to(DEV)
+        gb = gb0.clone()
+        check(L.sfron_copy_cols2(ptr(dcat), c1 + c2, c1, ptr(ga), c1, 0, dcat.data_ptr() + 4 * c1, c1 + c2, c2, ptr(gb), c2, 1, rows, stream_ptr()), "copy_cols2")
+        assert torch.equal(ga, dcat[:, :c1]) and torch.equal(gb, gb0 + dcat[:, c1:])

@@ -181,6 +181,7 @@ _PROTOS.update({
     "sfron_conv_wprep_tiles": (c_int, [c_int, c_int]),
     "sfron_conv_wprep_batch": (c_int, [_P, c_int, c_int, _S]),
     "sfron_copy_cols": (c_int, [_P, c_int, c_int64, c_int, _P, c_int, c_int, _S]),
+    "sfron_copy_cols2": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int64, _S]),
     "sfron_ddpm_timestep_embed": (c_int, [_P, c_int, c_int, _P, _S]),
     "sfron_class_embed_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _S]),
     "sfron_class_embed_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _S]),

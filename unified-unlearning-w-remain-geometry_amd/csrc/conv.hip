@@ -1688,6 +1688,24 @@ __global__ __launch_bounds__(TPB) void k_copy_cols4(const float* __restrict__ x,
     *o = v;
   }
 }
+// Two column copies in ONE launch (blockIdx.z = piece): the channel concatenation torch.cat([h, skip], dim=1) of the up path (two sources into
+// the column halves of one destination) and its backward (the column halves of one source into two gradient buffers, each with its own
+// accumulate flag) were two launches of k_copy_cols4 each -- 5 us apiece on a chain that is bound by its launch count.
+struct CopyPiece { const float* x; int ldx; float* y; int ldy; int C; int accumulate; };
+__global__ __launch_bounds__(TPB) void k_copy_cols4x2(CopyPiece p0, CopyPiece p1, int64_t rows, int rows_per_block) {
+  const CopyPiece p = blockIdx.z ? p1 : p0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = (blockIdx.x * 64 + lane) * 4;
+  if (col >= p.C) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  for (int64_t r = r0 + wave; r < r1; r += TPB / 64) {
+    float4 v = *reinterpret_cast<const float4*>(p.x + r * p.ldx + col);
+    float4* o = reinterpret_cast<float4*>(p.y + r * p.ldy + col);
+    if (p.accumulate) { const float4 c = *o; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+    *o = v;
+  }
+}
 // Bernoulli keep mask of nn.Dropout(p) in one launch (torch.rand >= p -> uint8 takes three): element i of mask (seed, call, salt) is
 // kept when 16 bits of splitmix64(seed, counter, salt, i / 4) reach p * 65536.  `counter` lives on the device and is advanced by the
 // caller once per pass, so a captured graph draws fresh masks at every replay.
@@ -2437,6 +2455,22 @@ int sfron_copy_cols(const float* x, int ldx, int64_t rows, int C, float* y, int 
     return SFRON_OK;
   }
   hipLaunchKernelGGL(k_copy_cols, dim3(grid_for(rows * C)), dim3(TPB), 0, (hipStream_t)stream, x, ldx, rows, C, y, ldy, accumulate);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+int sfron_copy_cols2(const float* x0, int ldx0, int C0, float* y0, int ldy0, int acc0, const float* x1, int ldx1, int C1, float* y1, int ldy1,
+                     int acc1, int64_t rows, void* stream) {
+  SFRON_CHECK_ARG(x0 && y0 && x1 && y1 && rows > 0 && C0 > 0 && C1 > 0 && ldx0 >= C0 && ldy0 >= C0 && ldx1 >= C1 && ldy1 >= C1);
+  const bool wide = ((C0 | C1 | ldx0 | ldx1 | ldy0 | ldy1) & 3) == 0 &&
+                    ((((uintptr_t)x0) | ((uintptr_t)y0) | ((uintptr_t)x1) | ((uintptr_t)y1)) & 15) == 0;
+  if (!wide) {                                   // unaligned shapes: the two plain launches
+    const int rc = sfron_copy_cols(x0, ldx0, rows, C0, y0, ldy0, acc0, stream);
+    return rc != SFRON_OK ? rc : sfron_copy_cols(x1, ldx1, rows, C1, y1, ldy1, acc1, stream);
+  }
+  const int Cm = C0 > C1 ? C0 : C1;
+  const int rpb = rows_chunk(rows, Cm);
+  hipLaunchKernelGGL(k_copy_cols4x2, dim3((Cm + 255) / 256, (unsigned)((rows + rpb - 1) / rpb), 2), dim3(TPB), 0, (hipStream_t)stream,
+                     CopyPiece{x0, ldx0, y0, ldy0, C0, acc0}, CopyPiece{x1, ldx1, y1, ldy1, C1, acc1}, rows, rpb);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

@@ -851,15 +851,15 @@ class Conditional_Model(_TapeNet):
                 skip = hs.pop()
                 c1, c2 = h.C, skip.C
                 cat_t = torch.empty(h.rows, c1 + c2, dtype=torch.float32, device=dev)
-                check(L.sfron_copy_cols(ptr(h.t), c1, h.rows, c1, ptr(cat_t), c1 + c2, 0, stream_ptr()), "copy_cols")
-                check(L.sfron_copy_cols(ptr(skip.t), c2, h.rows, c2, cat_t.data_ptr() + 4 * c1, c1 + c2, 0, stream_ptr()), "copy_cols")
+                check(L.sfron_copy_cols2(ptr(h.t), c1, c1, ptr(cat_t), c1 + c2, 0, ptr(skip.t), c2, c2, cat_t.data_ptr() + 4 * c1, c1 + c2, 0, h.rows,
+                                           stream_ptr()), "copy_cols2")
                 ca = Act(cat_t, B, h.H, h.W, c1 + c2)
 
                 def cat_bwd(ca=ca, a=h, s=skip, c1=c1, c2=c2):
-                    g, acc = a.grad_buf()
-                    check(L.sfron_copy_cols(ptr(ca.grad), c1 + c2, a.rows, c1, ptr(g), c1, acc, stream_ptr()), "copy_cols")
-                    g, acc = s.grad_buf()
-                    check(L.sfron_copy_cols(ca.grad.data_ptr() + 4 * c1, c1 + c2, a.rows, c2, ptr(g), c2, acc, stream_ptr()), "copy_cols")
+                    ga, acc_a = a.grad_buf()
+                    gs, acc_s = s.grad_buf()
+                    check(L.sfron_copy_cols2(ptr(ca.grad), c1 + c2, c1, ptr(ga), c1, acc_a, ca.grad.data_ptr() + 4 * c1, c1 + c2, c2, ptr(gs), c2, acc_s,
+                                               a.rows, stream_ptr()), "copy_cols2")
                 tape.append(cat_bwd)
                 h = self._resblock(tape, blk, ca, cin, cout, proj, d_proj, next_mask(ca.rows, cout))
                 if att:
