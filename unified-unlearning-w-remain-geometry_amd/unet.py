@@ -297,6 +297,8 @@ class _TapeNet(nn.Module):
         rstd = torch.empty_like(mean)
         scale = 1.0 / (1.0 - self.dropout_p) if drop_mask is not None else 1.0
         gam, bet = self._p(name + ".weight"), self._p(name + ".bias")
+        trains = self._trains(name + ".weight")          # decided when the tape is built; a frozen norm (SD train_method "xattn") skips the
+                                                         # reduction of its affine gradients: nothing reads them
         ws = torch.empty(_L().sfron_groupnorm_scratch_bytes(x.B, x.H * x.W, x.C, 32) // 8 + 2, dtype=torch.float64, device=dev)   # per-chunk partial sums
         check(_L().sfron_groupnorm_fwd(ptr(x.t), x.C, gam, bet, x.B, x.H * x.W, x.C, 32, eps, int(swish), ptr(drop_mask), scale, ptr(y),
                                        ptr(mean), ptr(rstd), ptr(ws), stream_ptr()), "groupnorm_fwd")
@@ -311,7 +313,8 @@ class _TapeNet(nn.Module):
             check(_L().sfron_groupnorm_bwd_res(ptr(dy), ptr(x.t), x.C, gam, bet, ptr(mean), ptr(rstd), x.B, x.H * x.W, x.C, 32, int(swish),
                                                ptr(drop_mask), scale, ptr(gbuf), x.C, acc, ptr(extra), ld_extra, ptr(pg), ptr(pb), ptr(ws2),
                                                stream_ptr()), "groupnorm_bwd")
-            check(_L().sfron_reduce2(ptr(pg), ptr(pb), 1, x.B, x.C, self._g(name + ".weight"), x.C, self._g(name + ".bias"), x.C, stream_ptr()), "reduce2")
+            if trains:
+                check(_L().sfron_reduce2(ptr(pg), ptr(pb), 1, x.B, x.C, self._g(name + ".weight"), x.C, self._g(name + ".bias"), x.C, stream_ptr()), "reduce2")
 
         def bwd_cast(dy):
             """For an x that only this norm consumes and that a convolution produced: x's gradient as that convolution's bf16 d_out
@@ -328,7 +331,8 @@ class _TapeNet(nn.Module):
             check(_L().sfron_groupnorm_bwd_cast(ptr(dy), ptr(x.t), x.C, gam, bet, ptr(mean), ptr(rstd), x.B, x.H * x.W, x.C, 32, int(swish),
                                                 ptr(drop_mask), scale, ptr(d16), ptr(cpart), ptr(pg), ptr(pb), ptr(ws2), stream_ptr()),
                   "groupnorm_bwd_cast")
-            check(_L().sfron_reduce2(ptr(pg), ptr(pb), 1, x.B, x.C, self._g(name + ".weight"), x.C, self._g(name + ".bias"), x.C, stream_ptr()), "reduce2")
+            if trains:
+                check(_L().sfron_reduce2(ptr(pg), ptr(pb), 1, x.B, x.C, self._g(name + ".weight"), x.C, self._g(name + ".bias"), x.C, stream_ptr()), "reduce2")
             return d16, cpart, nch
         bwd.cast = bwd_cast
         return y, bwd
