@@ -168,6 +168,7 @@ class UNetModel(_TapeNet):
         mean = torch.empty(rows, dtype=torch.float32, device=dev)
         rstd = torch.empty_like(mean)
         gam, bet = self._p(name + ".weight"), self._p(name + ".bias")
+        trains = self._trains(name + ".weight")          # decided when the tape is built (a frozen norm's affine gradients are read by nobody)
         check(_L().sfron_layernorm_fwd(ptr(x.t), gam, bet, rows, D, 1e-5, ptr(y), ptr(mean), ptr(rstd), stream_ptr()), "layernorm_fwd")
 
         def bwd(dy, extra=None):
@@ -179,7 +180,8 @@ class UNetModel(_TapeNet):
             pb = torch.empty_like(pg)
             check(_L().sfron_layernorm_bwd_res(ptr(dy), ptr(x.t), gam, ptr(mean), ptr(rstd), rows, D, ptr(g), acc, ptr(extra), ptr(pg), ptr(pb),
                                                stream_ptr()), "layernorm_bwd")
-            check(_L().sfron_reduce2(ptr(pg), ptr(pb), 1, nblk, D, self._g(name + ".weight"), D, self._g(name + ".bias"), D, stream_ptr()), "reduce2")
+            if trains:
+                check(_L().sfron_reduce2(ptr(pg), ptr(pb), 1, nblk, D, self._g(name + ".weight"), D, self._g(name + ".bias"), D, stream_ptr()), "reduce2")
         return y, bwd
 
     def _mha(self, q, ldq, k, ldk, v, ldv, B, N, Lk, Lv, C, keep):
