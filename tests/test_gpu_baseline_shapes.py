@@ -518,7 +518,7 @@ def test_xl2_headline_schedule_is_reproducible_bit_for_bit():
     """The headline runner exactly as bench.py configures it (DiT-XL/2, batch 32, block sweeps beside the forward pass and across the step
     boundary, weight gradients / the clip norm's adaLN share on their own streams, fused clip norm) for 12 steps, twice from the same weights
     and batches: parameters, both moments and the EMA come out bit-identical.  Every overlap in the step is ordered by events only; a missing
-    one is a race, and a race shows as a difference (tools/soak_repro.py is the same run at any length: 60 steps measured identical)."""
+    one is a race, and a race shows as a difference (tools/soak_repro.py is the same run at any length: 60 and 300 steps measured identical)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("soak_repro", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools",
                                                                               "soak_repro.py"))
