@@ -191,7 +191,7 @@ def _ddpm_leg(dev, steps=50, batch=64):
             "finite_losses": bool(torch.isfinite(out["forget_loss"]).item() and torch.isfinite(out["remain_loss"]).item())}
 
 
-def _sd_leg(dev, cases=(("xattn", 2), ("full", 2), ("full", 8)), steps=4):
+def _sd_leg(dev, cases=(("xattn", 2), ("full", 2), ("full", 8)), steps=8):
     """BASELINE config 4: SD v1 UNet (859.5 M parameters, 64 x 64 latents, 77-token context) SFR-on iterations of
     SD/train-scripts/nsfw_removal.py:108-173: train_method xattn (the "cross-attn path" BASELINE.json names: only the attn2 layers
     train, nsfw_removal.py:66-77) at the README's batch 2, and train_method full at batch 2 and the script's default batch 8."""
@@ -243,7 +243,7 @@ def other_configs(dev, latent, budget_s=75.0):
     out = {"note": "measured after the headline's timed region in the same process; product FLOPs of the U-Net legs are counted from the "
                    "launches of one iteration (zero-dilated / channel-padded operands included)"}
     legs = [("config2_dit_b4_bs32", lambda: _dit_leg("DiT-B/4", 32, latent, dev, False, 20, 4)),
-            ("config5_dit_xl2_fp8_bs32", lambda: _dit_leg("DiT-XL/2", 32, latent, dev, True, 10, 3)),
+            ("config5_dit_xl2_fp8_bs32", lambda: _dit_leg("DiT-XL/2", 32, latent, dev, True, 20, 6)),
             ("config1_ddpm_cifar10_bs64_50steps", lambda: _ddpm_leg(dev)),
             ("config4_sd_v1_unet", lambda: _sd_leg(dev))]
     for name, fn in legs:

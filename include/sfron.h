@@ -636,7 +636,8 @@ int sfron_aux_set_probe(void* aux, void* probe);
  * entry rewritten by the pass -- taken from the accumulators of the weight-gradient GEMMs (sfron_gemm_desc.sumsq_partials).  mask_arena: byte mask
  * indexed like the parameter / gradient arena (NULL = no mask).  The clip norm of DiT/forget.py:289-298 then needs a pass only over what is left
  * (biases, embedders, final layer: sfron_sumsq_masked_ranges) plus sfron_clip_coef.  Single-process runs only: a data-parallel run must take the
- * norm of the REDUCED gradient.  sfron_dit_sumsq_partials_len returns 0 when a block shape does not run on the 192 x 192 weight-gradient tile. */
+ * norm of the REDUCED gradient.  sfron_dit_sumsq_partials_len returns 0 when a block shape does not run on the 192 x 192 weight-gradient tile.
+ * partials == NULL DISARMS the handle (a caller whose pass failed between arming and the backward pass must not leave the pointer behind). */
 int sfron_dit_sumsq_partials_len(const sfron_dit_cfg* cfg);
 int sfron_aux_arm_sumsq(void* aux, const uint8_t* mask_arena, double* partials);
 /* Orders `stream` behind the point of the LAST backward pass run with this handle after which the adaLN_modulation matrix (weights, bf16

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(built):
     for s in syms:
         assert hasattr(h, s), f"{s} declared in include/sfron.h but not exported by libsfron.so"
     assert sorted(built.declared_symbols()) == syms, "ctypes prototypes and include/sfron.h disagree"
-    assert h.sfron_abi_version() >= 1
+    assert h.sfron_abi_version() == built.ABI_VERSION          # _lib.lib() refuses a library of another version
     assert h.sfron_build_arch() == b"gfx950"
 
 

@@ -391,8 +391,10 @@ def test_xl2_ten_sfron_iterations_vs_oracle():
     # 1.169).  The two paths start 1.6e-4 apart (bf16 rounding of weights / activations through 28 blocks, before any step) and their
     # ten-step CHANGE differs by 2.1e-4 = 0.07 % of the change: bound = 0.2 % of the oracle's change + the north-star's 1e-4.
     assert drift < 2e-3 * abs(r1 - r0) + 1e-4, (drift, r0, r1)
-    assert gap < 1e-3 and gap0 < 5e-4, (gap0, gap)
-    assert worst < 3e-3, worst          # per-step training-batch mse on 4 samples (bf16 forward noise on a loss of O(1))
+    # 2 x measured, fixed: gap before the first step 1.6e-4 (the bf16 weight rounding, profiles/r05_xl2_gap_bisect.txt), after ten
+    # iterations up to 3.1e-4 over the round-5 builds, worst per-step training-batch gap 1.1e-3 (4 samples, loss of O(1))
+    assert gap0 < 3.2e-4 and gap < 6.2e-4, (gap0, gap)
+    assert worst < 2.2e-3, worst
     assert runner.opt.step_count == 20
 
 
@@ -417,10 +419,16 @@ def test_xl2_fifty_sfron_iterations_vs_oracles():
     weights, each flip is a 2^-8 relative step.  The fp32 trajectory is NOT chaotic (one ulp on every initial weight moves it by < 3e-7 at
     every checkpoint), so with fp32 operands the north-star's 1e-4 would be a meaningful bound at this size; with the bf16 operands it
     prescribes, the reference's own trajectory is only defined to ~2e-4 here, and 1e-4 is met where the loss moves slowly (BASELINE config 2,
-    test_dit_b4_fifty_step_eps_mse_within_1e4_of_oracle: 1.1e-5).  Asserted:
-      * HIP against the bf16-op oracle at every checkpoint: 3e-4 (2 x the worst measured, = the bf16-op oracle's own run-to-run spread);
-      * HIP against the fp32 oracle: no further than the bf16-op oracle is + 3e-4 (the operand type's cost, not the implementation's);
-      * the operand type's own cost is not zero (> 5e-5 before any step, > 2e-4 after 50): the header's claim is checked, not assumed."""
+    test_dit_b4_fifty_step_eps_mse_within_1e4_of_oracle: 1.1e-5; and at THIS geometry from a settled state:
+    test_xl2_fifty_sfron_iterations_from_a_settled_state below).
+
+    Asserted -- ONE set of bounds, fixed in round 5 from five oracle runs and three builds and not moved since (the derivation is the comment
+    above the asserts; a build that breaks them is a finding, not a reason to rebase them):
+      * before any step: HIP within 5e-5 of the bf16-operand oracle (no trajectory yet: pure forward-pass parity);
+      * at iterations 10 / 20 / 30 / 50: HIP within 6e-4 of the bf16-operand oracle (2 x the 3e-4 by which that oracle differs from ITSELF run
+        to run, = the largest build-to-build movement of the HIP path);
+      * HIP and the bf16-operand oracle each within 1.5e-3 of the fp32 oracle (1.5 x the worst of either over all runs, 1.05e-3);
+      * the operand type's own cost is not zero (> 5e-5 before any step, > 2e-4 along the trajectory): the claim above is checked, not assumed."""
     import copy
     from oracle import bf16_ref
     from oracle import diffusion_ref as dref
@@ -511,6 +519,125 @@ def test_xl2_fifty_sfron_iterations_vs_oracles():
         assert abs(d_hip) < 1.5e-3 and abs(d_b16) < 1.5e-3, (it, d_hip, d_b16)
     # the operand type's own cost is what the header says it is (not zero)
     assert abs(rows[0][2]) > 5e-5 and max(abs(r[2]) for r in rows) > 2e-4
+
+
+def test_xl2_fifty_sfron_iterations_from_a_settled_state():
+    """The north-star acceptance in the regime the reference runs in.  DiT/forget.py starts from PRETRAINED weights
+    (forget.py:183-187) and moves them slowly (lr 1e-4, forget_alpha 1e-3, 500-1000 iterations, DiT/README.md:62-68); the random-init
+    trajectory of the test above is the opposite regime (held-out loss 1.44 -> 0.50 in 50 iterations).  There is no checkpoint offline, so the
+    settled state is MADE here: WARM fp32-oracle SFR-on iterations on the GPU from the same random init (the loss has flattened by then), then
+    weights + both AdamW moments + step count + EMA go into the HIP runner through the reference's own checkpoint format
+    (step.load_checkpoint: forget.py:346-353) and into the bf16-operand oracle, and the 50 COMPARED iterations run on all three.
+
+    Also checked here: the GPU-resident fp32 oracle (torch on rocBLAS) against the CPU oracle -- the contract -- on one full TRAINING
+    ITERATION (both losses and the clipped forget-gradient norm), not one forward pass."""
+    import copy
+    from oracle import bf16_ref
+    from oracle import diffusion_ref as dref
+    from oracle import sfron_ref
+    from sfron import data, diffusion, step
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    B, WARM = 4, 250
+    ref, model = _pair("DiT-XL/2", B, seed=51, std=0.02)
+    tab = dref.DiffusionTables(1000)
+    gm = torch.Generator().manual_seed(52)
+    mask = {"module." + n: (torch.rand(p.shape, generator=gm) < 0.5) for n, p in ref.named_parameters() if p.requires_grad}
+    mask["module.pos_embed"] = 0
+    mask_dev = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in mask.items()}
+    hp = dict(lr=1e-4, forget_alpha=1e-3, grad_clip=1.0, ema_decay=0.9999, unlearn_loss="ga", forget_class=207)
+    kw = dict(global_batch=B, num_classes=1000, forget_class=207)
+
+    def batches(seed, it, dev):
+        f, r = data.synthetic_batch(seed, it, "forget", **kw), data.synthetic_batch(seed, it, "remain", **kw)
+        fd, rd = {k: v.to(dev) for k, v in f.items()}, {k: v.to(dev) for k, v in r.items()}
+        return fd, rd, {k: v.long() if k == "drop" else v for k, v in fd.items()}, {k: v.long() if k == "drop" else v for k, v in rd.items()}
+
+    # ---- the GPU-resident oracle against the CPU oracle on one full training iteration
+    ref_cpu = copy.deepcopy(ref)
+    orc_cpu = sfron_ref.DiTSfronOracle(ref_cpu, tab, mask=mask, **hp)
+    _, _, fo, ro = batches(33, 0, "cpu")
+    w_cpu = orc_cpu.step(fo, ro)
+    ref.to(DEV)
+    orc = sfron_ref.DiTSfronOracle(ref, tab, mask=mask_dev, **hp)
+    _, _, fo, ro = batches(33, 0, DEV)
+    w_gpu = orc.step(fo, ro)
+    print(f"oracle on CPU vs on the GPU, one SFR-on iteration of DiT-XL/2: forget mse {w_cpu['forget_mse']:.6f} / {w_gpu['forget_mse']:.6f}, "
+          f"remain mse {w_cpu['remain_mse']:.6f} / {w_gpu['remain_mse']:.6f}, forget gradient norm {w_cpu['forget_gnorm']:.6e} / "
+          f"{w_gpu['forget_gnorm']:.6e}", flush=True)
+    assert w_gpu["forget_mse"] == pytest.approx(w_cpu["forget_mse"], rel=2e-5)
+    assert w_gpu["remain_mse"] == pytest.approx(w_cpu["remain_mse"], rel=2e-5)
+    assert w_gpu["forget_gnorm"] == pytest.approx(w_cpu["forget_gnorm"], rel=2e-4)
+    del ref_cpu, orc_cpu
+
+    # ---- settle
+    for it in range(1, WARM):
+        _, _, fo, ro = batches(33, it, DEV)
+        w = orc.step(fo, ro)
+        if it % 50 == 0 or it == WARM - 1:
+            print(f"  warm-up iteration {it}: forget mse {w['forget_mse']:.4f}, remain mse {w['remain_mse']:.4f}", flush=True)
+    hbs = [data.synthetic_batch(24 + i, 0, "remain", global_batch=16, num_classes=1000, forget_class=207) for i in range(4)]
+
+    # ---- the settled state into the two other paths
+    refb = copy.deepcopy(ref)
+    orcb = sfron_ref.DiTSfronOracle(refb, tab, mask=mask_dev, **hp)
+    orcb.opt.load_state_dict(copy.deepcopy(orc.opt.state_dict()))
+    orcb.ema = {n: v.clone() for n, v in orc.ema.items()}
+    d = diffusion.create_diffusion("")
+    runner = step.DiTSFRon(model, d, mask=mask, **hp)
+    runner.load_checkpoint({"model": {k: v.detach().clone() for k, v in ref.state_dict().items()},
+                            "ema": {n: v.clone() for n, v in orc.ema.items()}, "opt": orc.opt.state_dict()})
+    assert runner.opt.step_count == 2 * WARM
+    model.train()
+
+    def held_oracle(m, rounded):
+        m.eval()
+        vals = []
+        with torch.no_grad():
+            for hb in hbs:
+                g = {k: v.to(DEV) for k, v in hb.items()}
+                fn = lambda: dref.training_losses(tab, lambda x, t, y: m(x, t, y), g["x0"], g["t"], dict(y=g["y"]), g["noise"])["mse"].mean().item()
+                if rounded:
+                    with bf16_ref.OperandRounding(m, ("W", "A", "E")):
+                        vals.append(fn())
+                else:
+                    vals.append(fn())
+        m.train()
+        return sum(vals) / len(vals)
+
+    def held_hip():
+        model.eval()
+        vals = []
+        with torch.no_grad():
+            for hb in hbs:
+                g = {k: v.to(DEV) for k, v in hb.items()}
+                out = model(d.q_sample(g["x0"], g["t"], g["noise"]), g["t"], g["y"])
+                vals.append(d.loss_fwd_bwd(out.contiguous(), g["x0"], g["t"], g["noise"], 1.0)[0].mean().item())
+        model.train()
+        model.set_batch_size(B)
+        return sum(vals) / len(vals)
+
+    rows = []
+
+    def checkpoint(it):
+        f32, b16, hip = held_oracle(ref, False), held_oracle(refb, True), held_hip()
+        rows.append((it, f32, b16 - f32, hip - f32, hip - b16))
+        print(f"DiT-XL/2 settled ({WARM} warm-up iterations) + {it:2d}: held-out eps-MSE fp32 oracle {f32:.5f} | bf16-operand oracle {b16 - f32:+.2e} | "
+              f"HIP {hip - f32:+.2e} | HIP - bf16-operand oracle {hip - b16:+.2e}", flush=True)
+    checkpoint(0)
+    for it in range(50):
+        fd, rd, fo, ro = batches(34, it, DEV)
+        orc.step(fo, ro)
+        bf16_ref.sfron_step_bf16_operands(orcb, fo, ro)
+        runner.step(fd, rd)
+        if it + 1 in (10, 50):
+            checkpoint(it + 1)
+    runner.guard.poll(block=True)
+    assert runner.opt.step_count == 2 * WARM + 100
+    moved = abs(rows[-1][1] - rows[0][1])
+    print(f"held-out eps-MSE of the fp32 oracle moved by {moved:.2e} over the 50 compared iterations", flush=True)
+    # PROVISIONAL (first measurement pending): the north-star's own number
+    for it, f32, d_b16, d_hip, d_hb in rows:
+        assert abs(d_hip) < 1e-4, (it, d_hip, d_b16, d_hb)
 
 
 @pytest.mark.gpu

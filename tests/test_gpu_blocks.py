@@ -277,6 +277,30 @@ def test_reduce_chunks_both_forms(groups, per, D):
         close(out[:, :D], want, rtol=1e-5, atol=1e-5 * per ** 0.5)
 
 
+@pytest.mark.parametrize("D,per,groups,layers", [(1152, 16, 4, 2), (2304, 4, 3, 1), (4104, 5, 2, 1)])
+def test_reduce_slots_any_width(D, per, groups, layers):
+    """The one-launch token reduction of a backward pass (csrc/norm.hip k_reduce_slots): slot (layer, kind, buf) holds [groups * per][D]
+    partials; out[kind, buf][layer][b][c] = sum_j partial[b * per + j][c] in index order.  Rows wider than 2048 columns (no registry model has
+    them) loop over column groups instead of failing in the middle of a backward pass."""
+    import ctypes
+    from sfron import _lib
+    from sfron._lib import check, ptr, stream_ptr
+    gen = torch.Generator().manual_seed(D + per)
+    n_slots = layers * 8
+    parts = torch.randn(n_slots, groups * per, D, generator=gen).to(DEV)
+    ld = D + 8
+    outs = [torch.full((layers, groups, ld), 3.0, dtype=torch.float32, device=DEV) for _ in range(8)]
+    base = (ctypes.c_void_p * 8)(*[o.data_ptr() for o in outs])
+    lstride = (ctypes.c_long * 8)(*[groups * ld] * 8)
+    lds = (ctypes.c_int * 8)(*[ld] * 8)
+    check(_lib.lib().sfron_reduce_slots(ptr(parts), groups * per * D, n_slots, groups, per, D, base, lstride, lds, stream_ptr()), "reduce_slots")
+    torch.cuda.synchronize()
+    want = parts.view(layers, 8, groups, per, D).double().sum(3)
+    for kb in range(8):
+        close(outs[kb][:, :, :D], want[:, kb], rtol=1e-5, atol=1e-5 * per ** 0.5)
+        assert float((outs[kb][:, :, D:] - 3.0).abs().max()) == 0.0
+
+
 def test_attention_rejects_head_widths_without_a_kernel():
     """Head widths 88 / 96 at T >= 64 would need a sixth output d-tile: rounds 1-3 accepted them and left columns 80.. unwritten (found in
     round 4 by the bit-identity test above).  They are refused now; the LDM UNet's wider heads (160) take the batched-GEMM path."""

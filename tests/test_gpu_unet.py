@@ -713,6 +713,38 @@ def test_ddpm_graph_replay_matches_eager(loss):
     assert (res[0][1] - res[1][1]).abs().max().item() < 1e-6
 
 
+def test_ddpm_graph_recapture_at_a_new_batch_size_builds_no_dropout_plan_inside_the_capture():
+    """graphs.StageGraph re-captures WITHOUT a warm-up pass when the input signature changes (a new batch size after the first
+    capture), so the first pass at that batch size runs under stream capture -- where the dropout plan's device table (a pageable
+    host-to-device copy) must not be built: the pass keeps its per-mask launches, no plan appears for the new size, the plan of the first
+    size keeps its table, and the loop goes on with finite losses at both sizes."""
+    from sfron import ddpm
+    cfg = dict(SMALL, dropout=0.1)
+    g = torch.Generator().manual_seed(43)
+
+    def pair(it, B):
+        out = []
+        for stream in ("forget", "remain"):
+            b = _synthetic(it, stream, B, g)
+            b["x0"], b["e"] = b["x0"][:, :, :16, :16].contiguous(), b["e"][:, :, :16, :16].contiguous()
+            out.append({k: v.to(DEV) for k, v in b.items()})
+        return out
+    _, model = _pair(cfg, seed=44)
+    run = ddpm.DDPMSFRon(model, lr=1e-4, forget_alpha=10.0, grad_clip=1.0, ema_rate=1e-4, unlearn_loss="ga", n_iters=12, use_graphs=True)
+    for it in range(4):                                   # eager warm-up passes build the plan of batch 8, then capture + replay
+        run.step(it, *pair(it, 8))
+    assert run._graphs["forget"].graph is not None and 8 in model._drop_plans
+    table8 = model._drop_plans[8]["table"].clone()
+    outs = [run.step(4 + it, *pair(4 + it, 4)) for it in range(3)]          # new signature: re-capture with no warm-up, then two replays
+    assert 4 not in model._drop_plans                                       # nothing was built while the stream was capturing
+    outs += [run.step(7 + it, *pair(7 + it, 8)) for it in range(2)]         # and back
+    torch.cuda.synchronize()
+    assert torch.equal(model._drop_plans[8]["table"], table8)
+    for o in outs:
+        assert torch.isfinite(o["forget_loss"]).item() and torch.isfinite(o["remain_loss"]).item()
+    assert torch.isfinite(run.flat.p).all().item()
+
+
 def test_ddpm_fisher_clip_before_square_guided_forward_vs_oracle():
     """DDPM/runners/diffusion.py:1244-1299: Fisher diagonal from the cond_scale-guided mode="test" forward (gradients through the
     conditional AND the null branch), gradients clipped to norm 1 before they are squared; then the saliency mask

@@ -14,6 +14,7 @@ class SfronError(RuntimeError):
 
 
 _lib = None
+ABI_VERSION = 15          # == sfron_abi_version() of the library these ctypes structs / prototypes were written for (checked on load)
 
 _P = c_void_p     # device pointer
 _S = c_void_p     # hipStream_t
@@ -245,6 +246,10 @@ def lib():
         for name, (res, args) in _PROTOS.items():
             fn = getattr(h, name)      # AttributeError if the symbol is missing: loud by design
             fn.restype, fn.argtypes = res, args
+        got = h.sfron_abi_version()
+        if got != ABI_VERSION:      # a stale build, or a variant library built from other sources: structs would be read past their end
+            raise SfronError(f"{LIB_PATH} reports ABI version {got}, this package's ctypes structs were written for {ABI_VERSION}: rebuild it "
+                             f"(python -c 'import __graft_entry__ as g; g.build()')")
         _lib = h
     return _lib
 

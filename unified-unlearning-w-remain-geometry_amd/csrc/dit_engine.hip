@@ -314,8 +314,9 @@ int sfron_dit_sumsq_partials_len(const sfron_dit_cfg* cfg) {
   return sumsq_counts(d, cnt) * d.L;
 }
 int sfron_aux_arm_sumsq(void* aux, const uint8_t* mask_arena, double* partials) {
-  SFRON_CHECK_ARG(aux && partials);
-  ((Aux*)aux)->sq_mask = mask_arena; ((Aux*)aux)->sq_partials = partials;
+  SFRON_CHECK_ARG(aux);
+  /* partials == NULL disarms (a pass that raised between the arm and its backward must not leave a raw pointer behind for the next one) */
+  ((Aux*)aux)->sq_mask = partials ? mask_arena : nullptr; ((Aux*)aux)->sq_partials = partials;
   return SFRON_OK;
 }
 

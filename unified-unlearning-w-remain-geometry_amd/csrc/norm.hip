@@ -550,9 +550,10 @@ struct SlotArgs { SlotDst dst[8]; };      // [kind 0..3][buf 0..1]
 constexpr int RS_MAX = 16;
 __global__ __launch_bounds__(512) void k_reduce_slots(const float* __restrict__ parts, long slot_stride, int per, int D, SlotArgs a) {
   const int slot = blockIdx.y, b = blockIdx.x;
-  const int c = threadIdx.x * 4;                               // four columns per thread (D % 4 == 0), 16-byte loads
-  if (c >= D) return;
   const int layer = slot >> 3, kb = slot & 7;
+  // four columns per thread (D % 4 == 0), 16-byte loads; one trip for D <= 4 * blockDim (every registry model), a column-group loop beyond
+  // (a wider model must not fail in the middle of a backward pass)
+  for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
   const float* p = parts + (size_t)slot * slot_stride + (size_t)b * per * D + c;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   int j = 0;
@@ -573,6 +574,7 @@ __global__ __launch_bounds__(512) void k_reduce_slots(const float* __restrict__ 
   for (; j < per; ++j) { const float4 v = *reinterpret_cast<const float4*>(p + (size_t)j * D); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
   const SlotDst d = a.dst[kb];
   *reinterpret_cast<float4*>(d.base + (size_t)layer * d.layer_stride + (size_t)b * d.ld + c) = s;
+  }
 }
 
 // ---------------------------------------------------------------- finish of a split-K product (few-tile GEMMs: small batch * tokens)
@@ -736,8 +738,8 @@ int sfron_reduce_slots(const float* parts, long slot_stride, int n_slots, int gr
   for (int i = 0; i < 8; ++i) a.dst[i] = SlotDst{dst_base[i], dst_layer_stride[i], dst_ld[i]};
   SFRON_CHECK_ARG(D % 4 == 0);
   for (int i = 0; i < 8; ++i) SFRON_CHECK_ARG(((uintptr_t)dst_base[i] & 15) == 0 && dst_layer_stride[i] % 4 == 0 && dst_ld[i] % 4 == 0);
-  SFRON_CHECK_ARG(D <= 4 * 512);
-  hipLaunchKernelGGL(k_reduce_slots, dim3(groups, n_slots), dim3(cdiv(D / 4, 64) * 64), 0, (hipStream_t)stream, parts, slot_stride,
+  const int threads = D / 4 <= 512 ? cdiv(D / 4, 64) * 64 : 512;          // wider rows: the kernel loops over column groups of 2048
+  hipLaunchKernelGGL(k_reduce_slots, dim3(groups, n_slots), dim3(threads), 0, (hipStream_t)stream, parts, slot_stride,
                      per_group, D, a);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;

@@ -361,8 +361,13 @@ class DitEngine:
                               (b + lay["fc1_b"], b + lay["fc1_b"] + F), (b + lay["fc2_b"], b + lay["fc2_b"] + D)]
                 spans.append((lay["fin_w"], self.n_trainable))
                 covered = sum(hi - lo for lo, hi in spans) + NM * D + L * (3 * D * D + D * D + 2 * F * D)
-                # arena padding (tensor offsets are multiples of 8) holds zero gradients: a span may include it, none may be missing
-                assert covered <= self.n_trainable and all(lo % 4 == 0 and (hi - lo) % 4 == 0 for lo, hi in spans), "sumsq plan: layout"
+                # arena padding (tensor offsets are multiples of 8) holds zero gradients: a span may include it.  None may be MISSING: every
+                # trainable element is in a span, in the adaLN matrix or in a block weight -- so what the list does not cover can only be the
+                # padding between a block's tensors (< 8 elements behind each of its 8 tensors).  A tensor added to a block or to the layout
+                # later fails here instead of dropping out of the clip norm silently.
+                missing = self.n_trainable - covered
+                assert 0 <= missing < 8 * 8 * L + 64 and all(lo % 4 == 0 and (hi - lo) % 4 == 0 for lo, hi in spans), \
+                    f"sumsq plan: {missing} trainable elements are in no span / GEMM (layout changed?)"
                 rows = []
                 for lo, hi in spans:
                     for s0 in range(lo, hi, 16384):               # one workgroup per piece: short pieces, many workgroups
@@ -375,6 +380,10 @@ class DitEngine:
         """One-shot: the next backward pass through this engine leaves the masked sums of squares of its block weight gradients in ``partials``
         (fp64, fused_sumsq_plan()["n_gemm"] entries)."""
         check(_lib.lib().sfron_aux_arm_sumsq(self.aux, ptr(mask_arena), ptr(partials)), "aux_arm_sumsq")
+
+    def disarm_sumsq(self):
+        """Clear a pending arm_sumsq (a pass that raised before its backward must not leave the raw pointer on the handle)."""
+        check(_lib.lib().sfron_aux_arm_sumsq(self.aux, None, None), "aux_arm_sumsq(disarm)")
 
     def scatter_late_bias(self):
         check(_lib.lib().sfron_dit_scatter_late_bias(ctypes.byref(self.cfg), ptr(self.late_bias), ptr(self.grads), stream_ptr()),

@@ -443,7 +443,12 @@ class DiTSFRon:
             if self._sq_buf is None or self._sq_buf.numel() < need:
                 self._sq_buf = torch.empty(need, dtype=torch.float64, device=eng.device)
             eng.arm_sumsq(self.opt.mask, self._sq_buf[:sq_plan["n_gemm"]])        # consumed by the forget pass's backward
-        mse_f, vb_f = self._pass(forget, y_f, sign * self.forget_alpha, factored_ada=True, block_ready=ready, async_exchange=dp_sync)
+        try:
+            mse_f, vb_f = self._pass(forget, y_f, sign * self.forget_alpha, factored_ada=True, block_ready=ready, async_exchange=dp_sync)
+        except BaseException:
+            if sq_plan is not None:
+                eng.disarm_sumsq()           # the one-shot was not consumed: no later backward may write through it
+            raise
         if sq_plan is not None and self.opt.lowrank is not None:
             self.opt.fused_sumsq = dict(partials=self._sq_buf[:sq_plan["n_gemm"]], buffer=self._sq_buf, ranges=sq_plan["ranges"],
                                         n_ranges=sq_plan["n_ranges"])

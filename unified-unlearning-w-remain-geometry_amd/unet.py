@@ -885,7 +885,11 @@ class Conditional_Model(_TapeNet):
         o_t, co_b = self._conv3(a, B, h.H, h.W, "conv_out", h.H, h.W)
         out = torch.empty(B, self.out_ch, h.H, h.W, dtype=torch.float32, device=dev)
         check(L.sfron_rows_to_nchw(ptr(o_t), v["cop"], B, self.out_ch, h.H * h.W, ptr(out), stream_ptr()), "rows_to_nchw")
-        if recorded and drop_plan is None:               # first pass at this batch size: remember what the pass asks for
+        # first pass at this batch size: remember what the pass asks for.  Never while a stream is capturing (graphs.StageGraph re-captures
+        # without a warm-up pass when the input signature changes, e.g. a new batch size): the table's host-to-device copy is illegal
+        # there, and a table allocated inside the capture would live in the graph's private pool, which other stages overwrite.
+        # Such a pass keeps its per-mask launches (all capturable); the next eager pass at this batch size builds the plan.
+        if recorded and drop_plan is None and not torch.cuda.is_current_stream_capturing():
             items, off = [], 0
             for sl_, n in recorded:
                 items.append((sl_, n, off))
