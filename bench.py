@@ -246,6 +246,8 @@ def other_configs(dev, latent, budget_s=75.0):
             ("config5_dit_xl2_fp8_bs32", lambda: _dit_leg("DiT-XL/2", 32, latent, dev, True, 20, 6)),
             ("config1_ddpm_cifar10_bs64_50steps", lambda: _ddpm_leg(dev)),
             ("config4_sd_v1_unet", lambda: _sd_leg(dev))]
+    if os.environ.get("SFRON_BENCH_LEGS"):                  # diagnosis knob (tools only): which legs, in which order ("config5,config2")
+        legs = [lg for key in os.environ["SFRON_BENCH_LEGS"].split(",") for lg in legs if lg[0].startswith(key)]
     for name, fn in legs:
         if time.perf_counter() - t_start > budget_s:
             out[name] = {"skipped": f"time budget of {budget_s:.0f} s used up by the legs before it"}

@@ -635,9 +635,16 @@ def test_xl2_fifty_sfron_iterations_from_a_settled_state():
     assert runner.opt.step_count == 2 * WARM + 100
     moved = abs(rows[-1][1] - rows[0][1])
     print(f"held-out eps-MSE of the fp32 oracle moved by {moved:.2e} over the 50 compared iterations", flush=True)
-    # PROVISIONAL (first measurement pending): the north-star's own number
+    # Measured on MI355X (round 6, gpurun_out/r06a/settled.log -> profiles/r06_xl2_settled.txt): the held-out eps-MSE of the fp32 oracle is 0.275
+    # and moves by 7.5e-3 over the 50 compared iterations; HIP - fp32 oracle = +4.4e-5 / +6.1e-5 / +1.3e-5 at iterations 0 / 10 / 50, the
+    # bf16-operand oracle +4.5e-5 / +6.9e-5 / +1.4e-5, HIP - bf16-operand oracle -1.0e-6 / -7.9e-6 / -1.2e-6.
+    #   * the north-star's own number, as stated: |HIP - fp32 reference path| < 1e-4 at every checkpoint (not derived from the measurement);
+    #   * HIP against the bf16-operand oracle: 2e-5 (2.5 x the worst measured) -- the implementation's share of the gap, an order of magnitude
+    #     below the operand type's.
     for it, f32, d_b16, d_hip, d_hb in rows:
         assert abs(d_hip) < 1e-4, (it, d_hip, d_b16, d_hb)
+        assert abs(d_hb) < 2e-5, (it, d_hb)
+    assert moved < 0.05, moved                 # the regime this test is about: a loss that moves slowly
 
 
 @pytest.mark.gpu
