@@ -143,6 +143,7 @@ def _dit_leg(model_name, batch, latent, dev, fp8, steps, warmup):
     t0 = time.perf_counter()
     for i in range(steps):
         out = runner.step(*bt[i % 2])
+    runner.sync_sweep()              # the last step's block sweep is launched by the NEXT forward pass or by this call: it belongs to the timed steps
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     runner.guard.poll(block=True)
@@ -415,6 +416,8 @@ def main():
         _lib.lib().sfron_attn_fwd_form(int(os.environ["SFRON_BENCH_ATTN_FWD"]))
     if os.environ.get("SFRON_BENCH_EARLY_ADA"):             # A-B knob (tools only): 0 = the adaLN matrix's share of the clip norm on the caller's stream
         runner.opt.early_ada = os.environ["SFRON_BENCH_EARLY_ADA"] != "0"
+    if os.environ.get("SFRON_BENCH_DEFER_SWEEP"):           # A-B knob (tools only): 0 = start the beside-forward sweep before the pass's prologue (round 5)
+        runner.defer_sweep_launch = os.environ["SFRON_BENCH_DEFER_SWEEP"] != "0"
     if os.environ.get("SFRON_BENCH_SWEEP_BESIDE"):          # tuning knob (tools only): "workgroups,head"
         runner.sweep_beside_wg, runner.sweep_beside_head = (int(v) for v in os.environ["SFRON_BENCH_SWEEP_BESIDE"].split(","))
 
@@ -454,6 +457,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = runner.step(*batches[i % pool])
+    runner.sync_sweep()             # the last step's remain-stage block sweep (left to the next forward pass to launch) belongs to the timed region
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -599,6 +599,18 @@ int sfron_dit_forward_fp8(const sfron_dit_cfg* cfg, const float* params, const u
                           const float* w_scales, const float* act_scales, const float* x_t, const int64_t* t, const int64_t* y,
                           const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out,
                           void* const* block_ready /* as sfron_dit_forward_after, or NULL */, void* stream);
+/* The forward pass in two calls (round 6).  phase 1 = only what stands in front of block 0 -- patch embedding, timestep / label embedders,
+ * the adaLN modulation of every block: the "conditioning prologue", a chain of ten small dependent launches; phase 2 = only the blocks and
+ * the final layer, on the workspace the phase-1 call filled (same arguments).  A caller whose optimizer sweep of the block ranges runs beside
+ * the pass on another stream (block_ready) starts that sweep BETWEEN the two calls: beside a bandwidth-heavy sweep every boundary between two
+ * small dependent launches costs 60-100 us instead of ~5 (profiles/r06_stage_boundary.txt).  phase 1 ignores block_ready / probe / out. */
+int sfron_dit_forward_phase(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
+                            const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
+                            void* const* block_ready /* or NULL */, void* probe /* or NULL */, int phase /* 1 | 2 */, void* stream);
+int sfron_dit_forward_fp8_phase(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const uint8_t* params_e4m3,
+                                const float* w_scales, const float* act_scales, const float* x_t, const int64_t* t, const int64_t* y,
+                                const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out,
+                                void* const* block_ready /* or NULL */, int phase /* 1 | 2 */, void* stream);
 /* Same as sfron_dit_forward, with HIP events recorded (on `stream`) around the fc1 GEMM of block 0 -- the
  * dominant kernel class -- into `probe` (may be NULL).  Used by bench.py for the live roofline measurement. */
 int sfron_dit_forward_probed(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
@@ -646,6 +658,10 @@ int sfron_aux_arm_sumsq(void* aux, const uint8_t* mask_arena, double* partials);
  * beside it on another stream (the host mirror does: -0.12 ms per step; sweeping the matrix itself there measured slower).  No-op before
  * the first backward pass.  Replaces nothing in the reference: scheduling of DiT/forget.py:293-298. */
 int sfron_aux_wait_ada(void* aux, void* stream);
+/* Orders `stream` behind the point of the LAST sfron_dit_backward_dp call with ada_dmod_out / ada_sc_out through this handle at which those two
+ * factors are complete (earlier than sfron_aux_wait_ada: the dgrad through the adaLN Linear is still to come).  sfron_sumsq_lowrank reads
+ * nothing else.  No-op before the first such pass. */
+int sfron_aux_wait_ada_factors(void* aux, void* stream);
 int sfron_aux_destroy(void* aux);
 
 #ifdef __cplusplus

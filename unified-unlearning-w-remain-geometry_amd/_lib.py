@@ -206,12 +206,15 @@ _PROTOS.update({
     "sfron_dit_scatter_late_bias": (c_int, [POINTER(DitCfg), _P, _P, _S]),
     "sfron_aux_create": (c_int, [POINTER(c_void_p)]),
     "sfron_aux_destroy": (c_int, [c_void_p]),
+    "sfron_aux_wait_ada_factors": (c_int, [c_void_p, c_void_p]),
     "sfron_aux_set_probe": (c_int, [c_void_p, c_void_p]),
     "sfron_aux_arm_sumsq": (c_int, [c_void_p, _P, _P]),
     "sfron_aux_wait_ada": (c_int, [c_void_p, _S]),
     "sfron_fp8_activation_amax": (c_int, [POINTER(c_float), c_int, c_void_p]),
     "sfron_dit_forward_probed": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_dit_forward_after": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _S]),
+    "sfron_dit_forward_phase": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _S]),
+    "sfron_dit_forward_fp8_phase": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, POINTER(c_float), _P, _P, _P, _P, _P, _P, _P, _P, c_int, _S]),
     "sfron_dit_fp8_workspace_bytes": (c_int64, [POINTER(DitCfg)]),
     "sfron_dit_forward_fp8": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, POINTER(c_float), _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_probe_create": (c_int, [c_int, POINTER(c_void_p)]),

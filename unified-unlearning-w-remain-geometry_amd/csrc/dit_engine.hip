@@ -10,6 +10,8 @@
 //   final linear W,b | (frozen) pos_embed.
 // The adaLN weights are contiguous so that the modulation of every block is ONE GEMM
 // [B,D]x[D,(6L+2)D]: c = t_emb + y_emb is the same for all blocks (models.py:243-246).
+#include <mutex>
+#include <vector>
 #include "common.h"
 #include "../../include/sfron.h"
 
@@ -238,13 +240,39 @@ static int ablate_mask() {
 // ---- aux: a side stream + events so the weight-gradient GEMMs (which nothing downstream in the backward chain
 // depends on) run concurrently with the dgrad / elementwise chain and fill the CUs its tile counts leave idle
 struct Probe;
-struct Aux { hipStream_t side, side2; hipEvent_t produced[4], consumed[8], done, join2, ada_ready; Probe* probe; const uint8_t* sq_mask; double* sq_partials; };
+struct Aux { hipStream_t side, side2; hipEvent_t produced[4], consumed[8], done, join2, ada_ready, ada_factors; Probe* probe; const uint8_t* sq_mask; double* sq_partials; int dev; };
+
+// The two weight-gradient streams of a handle come from a per-device FREE LIST and go back to it when the handle is destroyed: a process
+// that builds one engine after another (bench.py's configuration legs, set_batch_size(), a test session) keeps running on the SAME
+// two HIP streams.  Measured (profiles/r06_fp8_leg.txt): the runtime maps streams onto four hardware queues; with streams created and
+// destroyed per engine, the third runner of a process got its weight-gradient stream onto a queue it shares with another stream of the
+// step and ran 4 ms / step slower (DiT-XL/2 fp8: 63.8 ms against 59.3 as the first runner).  Two LIVE handles never share a pair.
+namespace {
+struct StreamPair { int dev; hipStream_t a, b; };
+std::mutex g_pairs_mu;
+std::vector<StreamPair> g_free_pairs;
+}  // namespace
 
 int sfron_aux_create(void** aux) {
   SFRON_CHECK_ARG(aux);
   Aux* a = new Aux{};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+  a->dev = dev;
+  bool reused = false;
+  if (!(ablate_mask() & 4)) {
+    std::lock_guard<std::mutex> lk(g_pairs_mu);
+    for (size_t i = 0; i < g_free_pairs.size(); ++i)
+      if (g_free_pairs[i].dev == dev) {
+        a->side = g_free_pairs[i].a; a->side2 = g_free_pairs[i].b;
+        g_free_pairs.erase(g_free_pairs.begin() + i);
+        reused = true;
+        break;
+      }
+  }
   // equal priority with the caller's stream measured best (89.8 ms/step; lowest priority 92.8, highest 95.1)
-  if (ablate_mask() & 4) {       // A-B knob: side stream at the lowest priority
+  if (reused) {
+  } else if (ablate_mask() & 4) {       // A-B knob: side stream at the lowest priority
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     if (hipStreamCreateWithPriority(&a->side, hipStreamNonBlocking, lo) != hipSuccess) return (int)hipGetLastError();
@@ -255,19 +283,26 @@ int sfron_aux_create(void** aux) {
     if (hipEventCreateWithFlags(&a->consumed[i], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
   if (hipEventCreateWithFlags(&a->done, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
   // second weight-gradient stream: the 36-tile proj weight gradient runs BESIDE the 108-tile qkv one (see dit_backward_impl)
-  if (ablate_mask() & 4) {
+  if (reused) {
+  } else if (ablate_mask() & 4) {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     if (hipStreamCreateWithPriority(&a->side2, hipStreamNonBlocking, lo) != hipSuccess) return (int)hipGetLastError();
   } else if (hipStreamCreateWithFlags(&a->side2, hipStreamNonBlocking) != hipSuccess) return (int)hipGetLastError();
   if (hipEventCreateWithFlags(&a->join2, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
   if (hipEventCreateWithFlags(&a->ada_ready, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+  if (hipEventCreateWithFlags(&a->ada_factors, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
   *aux = a;
   return SFRON_OK;
 }
 int sfron_aux_wait_ada(void* aux, void* stream) {
   SFRON_CHECK_ARG(aux);
   if (hipStreamWaitEvent((hipStream_t)stream, ((Aux*)aux)->ada_ready, 0) != hipSuccess) return (int)hipGetLastError();
+  return SFRON_OK;
+}
+int sfron_aux_wait_ada_factors(void* aux, void* stream) {
+  SFRON_CHECK_ARG(aux);
+  if (hipStreamWaitEvent((hipStream_t)stream, ((Aux*)aux)->ada_factors, 0) != hipSuccess) return (int)hipGetLastError();
   return SFRON_OK;
 }
 int sfron_aux_destroy(void* aux) {
@@ -279,8 +314,18 @@ int sfron_aux_destroy(void* aux) {
   (void)hipEventDestroy(a->done);
   (void)hipEventDestroy(a->join2);
   (void)hipEventDestroy(a->ada_ready);
-  (void)hipStreamDestroy(a->side);
-  (void)hipStreamDestroy(a->side2);
+  (void)hipEventDestroy(a->ada_factors);
+  if (ablate_mask() & 4) {
+    (void)hipStreamDestroy(a->side);
+    (void)hipStreamDestroy(a->side2);
+  } else {
+    // back to the free list, behind everything the handle's owner queued on them (the next owner starts its passes with an event wait on
+    // its own stream, not on whatever the previous owner left here)
+    (void)hipStreamSynchronize(a->side);
+    (void)hipStreamSynchronize(a->side2);
+    std::lock_guard<std::mutex> lk(g_pairs_mu);
+    g_free_pairs.push_back(StreamPair{a->dev, a->side, a->side2});
+  }
   delete a;
   return SFRON_OK;
 }
@@ -365,7 +410,7 @@ static size_t fp8_ws(const Dims& d, char* base, Fp8Ctx* f) {
 
 static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
                             const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
-                            void* probe, const Fp8Ctx* f8, void* stream, void* const* block_wait = nullptr);
+                            void* probe, const Fp8Ctx* f8, void* stream, void* const* block_wait = nullptr, int phase = 0);
 
 int sfron_dit_forward(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
                       const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out, void* stream) {
@@ -385,15 +430,41 @@ int sfron_dit_forward_after(const sfron_dit_cfg* cfg, const float* params, const
   return dit_forward_impl(cfg, params, params_bf16, x_t, t, y, drop, workspace, out, probe, nullptr, stream, block_ready);
 }
 
+int sfron_dit_forward_phase(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
+                            const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
+                            void* const* block_ready, void* probe, int phase, void* stream) {
+  SFRON_CHECK_ARG(phase == 1 || phase == 2);
+  return dit_forward_impl(cfg, params, params_bf16, x_t, t, y, drop, workspace, out, probe, nullptr, stream, block_ready, phase);
+}
+
 int64_t sfron_dit_fp8_workspace_bytes(const sfron_dit_cfg* cfg) {
   Dims d;
   if (make_dims(cfg, d) != SFRON_OK) return -1;
   return (int64_t)fp8_ws(d, nullptr, nullptr);
 }
 
+static int dit_forward_fp8_impl(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const uint8_t* params_e4m3,
+                                const float* w_scales, const float* act_scales, const float* x_t, const int64_t* t, const int64_t* y,
+                                const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out, void* const* block_ready, int phase,
+                                void* stream);
 int sfron_dit_forward_fp8(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const uint8_t* params_e4m3,
                           const float* w_scales, const float* act_scales, const float* x_t, const int64_t* t, const int64_t* y,
                           const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out, void* const* block_ready, void* stream) {
+  return dit_forward_fp8_impl(cfg, params, params_bf16, params_e4m3, w_scales, act_scales, x_t, t, y, drop, workspace, workspace_e4m3, out,
+                              block_ready, 0, stream);
+}
+int sfron_dit_forward_fp8_phase(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const uint8_t* params_e4m3,
+                                const float* w_scales, const float* act_scales, const float* x_t, const int64_t* t, const int64_t* y,
+                                const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out, void* const* block_ready, int phase,
+                                void* stream) {
+  SFRON_CHECK_ARG(phase == 1 || phase == 2);
+  return dit_forward_fp8_impl(cfg, params, params_bf16, params_e4m3, w_scales, act_scales, x_t, t, y, drop, workspace, workspace_e4m3, out,
+                              block_ready, phase, stream);
+}
+static int dit_forward_fp8_impl(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const uint8_t* params_e4m3,
+                                const float* w_scales, const float* act_scales, const float* x_t, const int64_t* t, const int64_t* y,
+                                const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out, void* const* block_ready, int phase,
+                                void* stream) {
   Dims d;
   RUN(make_dims(cfg, d));
   SFRON_CHECK_ARG(params_e4m3 && w_scales && act_scales && workspace_e4m3);
@@ -403,12 +474,12 @@ int sfron_dit_forward_fp8(const sfron_dit_cfg* cfg, const float* params, const u
     return SFRON_ERR_UNSUPPORTED;
   Fp8Ctx f{params_e4m3, w_scales, act_scales[0], act_scales[1], act_scales[2], nullptr, nullptr, nullptr};
   (void)fp8_ws(d, (char*)workspace_e4m3, &f);
-  return dit_forward_impl(cfg, params, params_bf16, x_t, t, y, drop, workspace, out, nullptr, &f, stream, block_ready);
+  return dit_forward_impl(cfg, params, params_bf16, x_t, t, y, drop, workspace, out, nullptr, &f, stream, block_ready, phase);
 }
 
 static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
                             const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
-                            void* probe, const Fp8Ctx* f8, void* stream, void* const* block_wait) {
+                            void* probe, const Fp8Ctx* f8, void* stream, void* const* block_wait, int phase) {
   Dims d;
   RUN(make_dims(cfg, d));
   SFRON_CHECK_ARG(params && params_bf16 && x_t && t && y && workspace && out);
@@ -418,6 +489,11 @@ static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const
   const int M = d.M, D = d.D, T = d.T, NM = d.NM;
   sfron_gemm_desc g;
 
+  // phase 1 = only what stands in front of block 0 (the conditioning prologue: a chain of ten small dependent launches + the adaLN product),
+  // phase 2 = only the blocks and the final layer on the workspace a phase-1 call filled, 0 = both.  A caller whose optimizer sweep runs
+  // beside this pass on another stream starts that sweep BETWEEN the two calls: beside a bandwidth-heavy sweep every boundary between two of
+  // the prologue's small launches costs 60-100 us instead of ~5 (profiles/r06_stage_boundary.txt), ~0.5 ms per pass.
+  if (phase != 2) {
   // x = x_embedder(x) + pos_embed                                        (models.py:240)
   RUN(sfron_patchify(x_t, d.B, d.C, d.S, d.S, d.p, 0, (uint16_t*)w.patches, d.Kp, stream));
   g = fwd_desc(w.patches, wb + P.pe_w, M, D, d.Kp);
@@ -437,6 +513,8 @@ static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const
   g = fwd_desc(w.sc, wb + P.ada_w, d.B, NM, D);
   g.epilogue = SFRON_EPI_F32; g.bias = params + P.ada_b; g.c_f32 = w.mod; g.ldc_f32 = NM;
   RUN(sfron_gemm_bf16(&g, stream));
+  }
+  if (phase == 1) return SFRON_OK;
 
   // x_next = x + gate * (X W^T + b), branch output saved for the backward pass (models.py:120-121): one product with the gated-residual
   // epilogue, or -- few-tile shapes -- a split-K product + its finish kernel
@@ -831,6 +909,9 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     // the global batch, instead of all-reducing the 892 MB result that only becomes final here, in the tail of the pass
     if (hipMemcpyAsync(ada_dmod_out, w.dmod_bf, (size_t)B * NM * 2, hipMemcpyDeviceToDevice, hs) != hipSuccess) return (int)hipGetLastError();
     if (hipMemcpyAsync(ada_sc_out, w.sc, (size_t)B * D * 2, hipMemcpyDeviceToDevice, hs) != hipSuccess) return (int)hipGetLastError();
+    // the two factors are complete: the clip norm's share of the adaLN matrix (sfron_sumsq_lowrank reads nothing else) may start on another
+    // stream now, beside the dgrad through the adaLN Linear and the embedders' backward (sfron_aux_wait_ada_factors)
+    if (ax) (void)hipEventRecord(ax->ada_factors, hs);
   } else {
     g = wgrad_desc(w.dmod_bf, w.sc, B, NM, D, grads + P.ada_w);
     RUN(sfron_gemm_bf16(&g, stream));

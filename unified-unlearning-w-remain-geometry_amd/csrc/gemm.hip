@@ -337,13 +337,18 @@ __global__ __launch_bounds__(NT) void k_gemm(GemmArgs g) {
 // staging, twelve 1 KB loads in flight per wave.  The activations (32 x K bf16, zero rows beyond M) sit in LDS once per workgroup, rows
 // padded by 16 bytes (row stride = 4 banks mod 64: a 16-lane group's ds_read_b128 covers the 64 banks exactly).  A lane ends up with
 // C[m = lane & 15 (+ 16)][n0 + 4 g .. + 3]: 16-byte stores.  Each wave walks `ntw` consecutive 16-row tiles of W.
-constexpr int SK_KB = 12;
-__global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs g, int ntw) {
+// Round 6: EIGHT waves per workgroup over the same activation image (was four): a wave's loop is issue twelve 1 KB loads -> wait for all of
+// them -> 24 MFMAs -> next group, i.e. bursts of 12 KB separated by a full memory latency; the activations' 74 KB of LDS allow two workgroups
+// per CU either way, so the wave count per workgroup is what sets the bytes in flight per CU (96 -> 192 KB).  (A software-pipelined stream
+// of groups in ONE wave was built first: hipcc drains vmcnt(0) at the loop header of a loop that carries loads in flight and the second
+// group waited for the first.)  Same products in the same order per output element: bit-identical.
+constexpr int SK_KB = 12, SK_NW = 8;
+__global__ __launch_bounds__(SK_NW * 64) void k_gemm_skinny(GemmArgs g, int ntw) {
   extern __shared__ __attribute__((aligned(16))) __bf16 sk_a[];          // [32][K + 8]
   const int K = g.K, ldl = K + 8, kc = K >> 3;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int e = tid; e < 32 * kc; e += 256) {
+  for (int e = tid; e < 32 * kc; e += SK_NW * 64) {
     const int m = e / kc, c = e - m * kc;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (m < g.M) v = *reinterpret_cast<const uint4*>(g.A + (size_t)m * g.lda + c * 8);
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs g, int ntw) {
   const __bf16* const a0p = sk_a + r * ldl + 8 * q;
   const __bf16* const a1p = sk_a + (16 + r) * ldl + 8 * q;
   for (int t = 0; t < ntw; ++t) {
-    const int nt = (blockIdx.x * 4 + wave) * ntw + t;                      // wave-uniform
+    const int nt = (blockIdx.x * SK_NW + wave) * ntw + t;                  // wave-uniform
     if (nt >= ntiles) break;
     const __bf16* const wrow = g.B + (size_t)(nt * 16 + r) * g.ldb + 8 * q;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -385,7 +390,7 @@ inline bool skinny_ok(const GemmArgs& g) {
 }
 inline int launch_skinny(const GemmArgs& g, hipStream_t s) {
   const int ntiles = g.N / 16;
-  int ntw = cdiv(ntiles, 4 * 512);                    // one round of two workgroups per CU where the problem is that large
+  int ntw = cdiv(ntiles, SK_NW * 512);                // one round of two workgroups per CU where the problem is that large
   if (ntw < 1) ntw = 1;
   const size_t lds = (size_t)32 * (g.K + 8) * sizeof(__bf16);
   // once per process, for the largest K this kernel takes (skinny_ok): the attribute call in front of EVERY launch left the stream idle for
@@ -393,7 +398,7 @@ inline int launch_skinny(const GemmArgs& g, hipStream_t s) {
   static const int lds_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 32 * (2048 + 8) * (int)sizeof(__bf16)) == hipSuccess ? SFRON_OK : (int)hipGetLastError();
   if (lds_rc != SFRON_OK) return lds_rc;
-  hipLaunchKernelGGL(k_gemm_skinny, dim3(cdiv(ntiles, 4 * ntw)), dim3(256), lds, s, g, ntw);
+  hipLaunchKernelGGL(k_gemm_skinny, dim3(cdiv(ntiles, SK_NW * ntw)), dim3(SK_NW * 64), lds, s, g, ntw);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SFRON_OK : (int)e;
 }

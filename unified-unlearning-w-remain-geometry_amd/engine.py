@@ -9,7 +9,7 @@ from collections import OrderedDict
 
 import torch
 
-from . import _lib
+from . import _lib, streams
 from ._lib import check, ptr, stream_ptr
 
 _LAYOUT_KEYS = ["total", "trainable", "pe_w", "pe_b", "t0_w", "t0_b", "t2_w", "t2_b", "table", "ada_w", "ada_b",
@@ -222,7 +222,7 @@ class DitEngine:
         if getattr(self, "_bs", None) is None:
             L, lay = self.cfg.depth, self.layout
             evs = [torch.cuda.Event(enable_timing=False) for _ in range(L)]
-            st = torch.cuda.Stream(device=self.device)
+            st = streams.get("sweep", self.device)          # process-wide: see streams.py
             for e in evs:
                 e.record(st)
             self._bs = dict(ranges=[(lay["blocks"] + l * lay["blk_stride"], lay["blocks"] + (l + 1) * lay["blk_stride"]) for l in range(L)],
@@ -240,19 +240,39 @@ class DitEngine:
     def drain_sweep(self):
         """The runner leaves the remain-stage AdamW of the block ranges in flight on the sweep stream when step() returns (the next
         step's forward pass waits block by block); every OTHER reader of the parameters / optimizer state goes through here first."""
+        fn = self._shared.pop("deferred", None)
+        if fn is not None:
+            fn()                               # a block sweep whose launch was left to the next forward pass (step.py): launch it now
         st = self._shared["sweep"]
         if st is not None:
             torch.cuda.current_stream().wait_stream(st)
             self._shared["sweep"] = None
 
-    def forward(self, x_t, t, y, drop=None, out=None, block_ready=None):
-        """block_ready: ctypes array of depth hipEvent_t handles -- block l waits for entry l before it touches its weights."""
+    def forward(self, x_t, t, y, drop=None, out=None, block_ready=None, between=None):
+        """block_ready: ctypes array of depth hipEvent_t handles -- block l waits for entry l before it touches its weights.
+        between (with block_ready): a callable run BETWEEN the conditioning prologue and block 0 (sfron_dit_forward_phase): the runner starts
+        the block sweep that goes beside this pass there -- behind the prologue's chain of small launches, not beside it (step.py)."""
         if out is None:
             out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
         if x_t.shape[0] != self.cfg.batch:
             raise _lib.SfronError(f"engine was built for batch {self.cfg.batch}, got {x_t.shape[0]}")
         if block_ready is None:
+            assert between is None
             self.drain_sweep()                 # a block sweep may still be rewriting the weights on its own stream (step.py)
+        if between is not None:
+            L, f = _lib.lib(), self.fp8
+            for phase in (1, 2):
+                if f is None:
+                    check(L.sfron_dit_forward_phase(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(x_t), ptr(t), ptr(y),
+                                                    ptr(drop), ptr(self.workspace), ptr(out), block_ready, self.probe, phase, stream_ptr()),
+                          "dit_forward_phase")
+                else:
+                    check(L.sfron_dit_forward_fp8_phase(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(f["w8"]),
+                                                        ptr(f["scales"]), f["act"], ptr(x_t), ptr(t), ptr(y), ptr(drop), ptr(self.workspace),
+                                                        ptr(f["ws"]), ptr(out), block_ready, phase, stream_ptr()), "dit_forward_fp8_phase")
+                if phase == 1:
+                    between()
+            return out
         if block_ready is not None and self.fp8 is None:
             check(_lib.lib().sfron_dit_forward_after(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(x_t), ptr(t), ptr(y),
                                                      ptr(drop), ptr(self.workspace), ptr(out), block_ready, self.probe, stream_ptr()),
@@ -332,12 +352,18 @@ class DitEngine:
         check(_lib.lib().sfron_dit_backward_dp(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(d_out), ptr(y),
                                                ptr(drop), ptr(self.workspace), ptr(self.grads), self.aux, None, None, ptr(dmod), ptr(sc),
                                                stream_ptr()), "dit_backward (factored adaLN gradient)")
-        return dict(lo=self.layout["ada_w"], NM=dmod.shape[1], D=self.cfg.hidden, dmod=dmod, sc=sc, R=self.cfg.batch, wait=self.ada_wait)
+        return dict(lo=self.layout["ada_w"], NM=dmod.shape[1], D=self.cfg.hidden, dmod=dmod, sc=sc, R=self.cfg.batch, wait=self.ada_wait,
+                    wait_factors=self.ada_wait_factors)
 
     def ada_wait(self, stream):
         """Order ``stream`` (a torch stream) behind the point of the last backward pass after which nothing reads the adaLN matrix and its two
         gradient factors are complete (sfron_aux_wait_ada): what is left of the pass then is the embedders' backward."""
         check(_lib.lib().sfron_aux_wait_ada(self.aux, ctypes.c_void_p(stream.cuda_stream)), "aux_wait_ada")
+
+    def ada_wait_factors(self, stream):
+        """Order ``stream`` behind the point of the last backward_factored_ada pass at which the two gradient factors are complete
+        (sfron_aux_wait_ada_factors: earlier than ada_wait -- the dgrad through the adaLN Linear and the embedders' backward are still to come)."""
+        check(_lib.lib().sfron_aux_wait_ada_factors(self.aux, ctypes.c_void_p(stream.cuda_stream)), "aux_wait_ada_factors")
 
     # ------------------------------------------------------------------ clip norm taken where the gradients are produced
     def fused_sumsq_plan(self):

@@ -11,7 +11,7 @@ minibatch; gradients are scaled by 1/global_batch in the loss kernel and SUM-all
 import torch
 import torch.distributed as dist
 
-from . import _lib, dp, guard, ops, sweep
+from . import _lib, dp, guard, ops, streams, sweep
 
 
 def build_mask_arena(engine, mask):
@@ -64,6 +64,7 @@ class DiTSFRon:
         # opt-in: the remain-stage sweep of the block ranges runs beside the NEXT step's forget forward pass; step() then returns with it in
         # flight -- read parameters / optimizer state through this runner (state_dict / checkpoint / sync()), not from the raw arenas
         self.sweep_across_steps = False
+        self.defer_sweep_launch = True      # a beside-forward sweep starts behind that pass's conditioning prologue (A-B knob: False = before it)
         # single-process runs: the forget stage's clip norm (forget.py:293-298) is taken where the gradients are produced -- the block
         # weight-gradient GEMMs leave the masked sums of squares of their tiles (engine.arm_sumsq), one small launch covers biases /
         # embedders / final layer, the rank-(batch) adaLN range is summed from its factors: no pass over the 1.8 GB block range of the arena
@@ -153,7 +154,7 @@ class DiTSFRon:
         stage -- their AdamW + EMA run while the later buckets are still on the links.  Same collectives in the same order on
         every rank."""
         if self._comm is None:
-            self._comm = torch.cuda.Stream()
+            self._comm = streams.get("comm")
         g = self.model.engine.grads
         cur = torch.cuda.current_stream()
         self._comm.wait_stream(cur)
@@ -222,7 +223,7 @@ class DiTSFRon:
         eng = self.model.engine
         evs = eng.dp_setup()
         if self._comm is None:
-            self._comm = torch.cuda.Stream()
+            self._comm = streams.get("comm")
         main = torch.cuda.current_stream()
         eng.backward_dp(d_out, y, drop)
         for l in reversed(range(len(evs))):
@@ -266,7 +267,7 @@ class DiTSFRon:
         self.model.set_batch_size(half)
         e0 = self.model.engine
         e1 = e0.sibling(half)
-        self._chains = (e0, e1, torch.cuda.Stream(), torch.cuda.Stream())
+        self._chains = (e0, e1, streams.get("chain0"), streams.get("chain1"))
         self.opt.g = e0.grads[:e0.n_trainable]
         self.opt.g2 = e1.grads[:e1.n_trainable]
 
@@ -316,7 +317,7 @@ class DiTSFRon:
         y_safe, b["t"] = self.guard.check_inputs(y, b["t"], self.model.num_classes, self.diffusion.num_timesteps)
         return b, y_safe
 
-    def _pass(self, batch, y, sign_alpha, factored_ada=False, block_ready=None, async_exchange=False):
+    def _pass(self, batch, y, sign_alpha, factored_ada=False, block_ready=None, async_exchange=False, between=None):
         """factored_ada (single process, single chain -- what step() uses): the backward pass leaves the adaLN_modulation weight
         gradient as its two bf16 factors and the next optimizer sweep forms the rank-(batch) product itself (engine.
         backward_factored_ada, csrc/sweep.hip k_adam_lowrank): 892 MB less to write and 892 MB (forget stage: twice) less to read
@@ -327,7 +328,7 @@ class DiTSFRon:
         eng, diff = self.model.engine, self.diffusion
         n_global = batch["x0"].shape[0] * self.world
         x_t = diff.q_sample(batch["x0"], batch["t"], batch["noise"])
-        out = eng.forward(x_t, batch["t"], y, batch.get("drop"), block_ready=block_ready)
+        out = eng.forward(x_t, batch["t"], y, batch.get("drop"), block_ready=block_ready, between=between if block_ready is not None else None)
         mse, vb, d_out = diff.loss_fwd_bwd(out, batch["x0"], batch["t"], batch["noise"], sign_alpha / n_global)
         if self._overlap_enabled():
             self._backward_allreduce_overlapped(d_out, y, batch.get("drop"), factored_ada=factored_ada and self.factored_ada)
@@ -433,8 +434,10 @@ class DiTSFRon:
             self._ready_owner = None
             if owner is eng and getattr(eng, "_sweep_pending", None) is not None:
                 ready = handles
+        between_f = None
         if ready is not None:
             eng._sweep_pending = None          # this forward pass waits for the sweep block by block; its backward pass starts behind all of it
+            between_f = eng._shared.pop("deferred", None)      # ... and launches it itself, behind its conditioning prologue (see below)
         sq_plan = None
         if (self.fuse_clip_norm and self.grad_clip is not None and self.micro == 1 and self.factored_ada and not self._dp_active()):
             sq_plan = eng.fused_sumsq_plan()
@@ -444,7 +447,8 @@ class DiTSFRon:
                 self._sq_buf = torch.empty(need, dtype=torch.float64, device=eng.device)
             eng.arm_sumsq(self.opt.mask, self._sq_buf[:sq_plan["n_gemm"]])        # consumed by the forget pass's backward
         try:
-            mse_f, vb_f = self._pass(forget, y_f, sign * self.forget_alpha, factored_ada=True, block_ready=ready, async_exchange=dp_sync)
+            mse_f, vb_f = self._pass(forget, y_f, sign * self.forget_alpha, factored_ada=True, block_ready=ready, async_exchange=dp_sync,
+                                     between=between_f)
         except BaseException:
             if sq_plan is not None:
                 eng.disarm_sumsq()           # the one-shot was not consumed: no later backward may write through it
@@ -468,8 +472,11 @@ class DiTSFRon:
         # the single-process kernel sequence plus the collectives)
         if self.micro == 1 and dp_sync is False and (self.sweep_beside_forward or fused_q):
             bs = self.model.engine.block_sweep_setup()
+            # defer: the ranges that go to the second stream are LAUNCHED by the forward pass they run beside, between its conditioning prologue
+            # (ten small dependent launches in front of block 0) and block 0 -- beside a bandwidth-heavy sweep each boundary of that chain
+            # costs 60-100 us instead of ~5 (profiles/r06_stage_boundary.txt: ~0.5 ms per pass); the blocks wait for their events as before
             split = dict(ranges=bs["ranges"], stream=bs["stream"] if self.sweep_beside_forward else None, events=bs["events"],
-                         max_workgroups=self.sweep_beside_wg, head=self.sweep_beside_head, quant=quant)
+                         max_workgroups=self.sweep_beside_wg, head=self.sweep_beside_head, quant=quant, defer=self.defer_sweep_launch)
         self._fp8_before_sweep(fused_q)
         pipe, self._pipeline = self._pipeline, None
         self.opt.step(max_norm=self.grad_clip, use_mask=True, split=split, pipeline=pipe)   # forget.py:289-299
@@ -477,7 +484,7 @@ class DiTSFRon:
             self.model.engine.fp8_requantize()
         beside = split is not None and split["stream"] is not None
         mse_r, vb_r = self._pass(remain, remain["y"], 1.0, factored_ada=True, block_ready=bs["handles"] if beside else None,
-                                 async_exchange=dp_sync)
+                                 async_exchange=dp_sync, between=self.opt.take_deferred())
         pipe, self._pipeline = self._pipeline, None
         nt = eng.n_trainable
         self._fp8_before_sweep(fused_q)
@@ -487,13 +494,16 @@ class DiTSFRon:
         across = beside and self.sweep_across_steps
         if across:
             split_r = dict(ranges=bs["ranges"], stream=bs["stream"], events=bs["events"], max_workgroups=self.sweep_beside_wg,
-                           head=self.sweep_beside_head, quant=quant)
+                           head=self.sweep_beside_head, quant=quant, defer=self.defer_sweep_launch)
         else:
             split_r = dict(ranges=bs["ranges"], stream=None, quant=quant) if fused_q else None
         self.opt.step(max_norm=None, use_mask=False, ema=self.ema[:nt], ema_decay=self.ema_decay, ema_mode=1,   # :320,322
                       split=split_r, pipeline=pipe)
         if across:
             self._ready_owner, eng._sweep_pending = (eng, bs["handles"]), bs["stream"]
+            fn = self.opt.take_deferred()
+            if fn is not None:
+                eng._shared["deferred"] = fn       # launched by the next step's forward pass (or by drain_sweep, whichever comes first)
         if self.fp8 and not fused_q:
             self.model.engine.fp8_requantize()
         if eng.n_total > nt:

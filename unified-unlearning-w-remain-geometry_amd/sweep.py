@@ -8,7 +8,7 @@ import math
 
 import torch
 
-from . import _lib
+from . import _lib, streams
 from ._lib import check, ptr, stream_ptr
 
 
@@ -54,6 +54,11 @@ class FlatAdam:
         self._partials = torch.empty(L.sfron_sweep_partials_len(), dtype=torch.float64, device=params.device)
         self.stats = torch.zeros(4, dtype=torch.float32, device=params.device)
 
+    def take_deferred(self):
+        """The side-stream part of the last step(split=dict(defer=True, ...)), as a callable to run once (None if nothing was deferred)."""
+        fn, self.deferred = getattr(self, "deferred", None), None
+        return fn
+
     def _segments(self, exclude=None):
         """[(lo, hi, lowrank?)] covering the arena (minus ``exclude`` = (lo, hi), which must not cut the low-rank matrix): one flat
         segment, or flat / rank-R / flat around the low-rank matrix."""
@@ -76,11 +81,12 @@ class FlatAdam:
     def _early_stream(self, q):
         """The stream for work on the adaLN matrix that may start before the backward pass has ended (``q`` = the low-rank description with the
         engine's ``wait`` hook, single-process passes only), ordered behind that point; None = no such hook: the current stream."""
-        if not self.early_ada or q is None or q.get("wait") is None:
+        wait = None if q is None else (q.get("wait_factors") or q.get("wait"))      # the norm reads the two factors only
+        if not self.early_ada or wait is None:
             return None
         if self._ada_stream is None:
-            self._ada_stream = torch.cuda.Stream()
-        q["wait"](self._ada_stream)
+            self._ada_stream = streams.get("ada", self.p.device)       # process-wide: see streams.py
+        wait(self._ada_stream)
         return self._ada_stream
 
     def _join(self, side):
@@ -214,21 +220,29 @@ class FlatAdam:
                                                          ptr(sl(mask, tlo, thi)), ptr(stats), thi - tlo, b1, b2, self.eps, step_size, bc2_sqrt,
                                                          decay_mul, ptr(sl(self.w_bf16, tlo, thi)), ptr(sl(ema, tlo, thi)), float(ema_decay), emode,
                                                          ptr(quant["w8"][tlo:thi]), ptr(quant["scales"][si:si + 1]), wg, sp), "masked_clip_adam_q")
-                if side is not None:
-                    ready = _t.cuda.Event()
-                    ready.record(cur)
-                    side.wait_event(ready)
                 cur_p = ctypes.c_void_p(cur.cuda_stream)
                 side_p = ctypes.c_void_p(side.cuda_stream) if side is not None else None
-                for i in range(len(rngs)):
-                    if i < head:
-                        if i >= first_own:
-                            sweep_range(i, cur_p, 0)
-                        if side is not None:
-                            split["events"][i].record(cur)
-                    else:
+                for i in range(min(head, len(rngs))):
+                    if i >= first_own:
+                        sweep_range(i, cur_p, 0)
+                    if side is not None:
+                        split["events"][i].record(cur)
+
+                def launch_side():
+                    """the ranges that go beside the next forward pass: behind everything the current stream holds AT THIS CALL"""
+                    if side is not None and head < len(rngs):
+                        ready = _t.cuda.Event()
+                        ready.record(_t.cuda.current_stream())
+                        side.wait_event(ready)
+                    for i in range(head, len(rngs)):
                         sweep_range(i, side_p, cap)
                         split["events"][i].record(side)
+                if split.get("defer") and side is not None and head < len(rngs):
+                    # the caller launches them itself, behind the conditioning prologue of the forward pass they run beside (step.py:
+                    # beside a sweep every boundary of that chain of small launches costs 60-100 us instead of ~5)
+                    self.deferred = launch_side
+                else:
+                    launch_side()
             self.lowrank = None
         self.fused_sumsq = None
         if ev is not None:
