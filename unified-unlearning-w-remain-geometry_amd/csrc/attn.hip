@@ -270,10 +270,17 @@ __device__ long long* d_attn_clk = nullptr;
 // QT = 2 the WHOLE head at T = 256, so its K / V chunks are brought in once, not once per query block (per CU the memory-bound start of a round
 // moves 73 KB instead of 110, profiles/r04_attn_phases.txt).  Same products, same order per row: bit-identical -- and slower (one workgroup
 // per CU instead of two, eight waves behind each chunk's barrier): kept as a form the tests compare, not taken by rule.
-template <int HDP, int KS, int NDT, int QT, int NWV = 4>
+// NIT = 2 (round 6, the rule at T = 256): ONE workgroup walks the NIT consecutive query blocks of a head as one stream of NIT * T / 64 chunks through
+// the same ring -- the next block's first K / V chunks (the SAME K / V: L2 hits) arrive while the current block finishes, its Q fragments are
+// requested under the current block's last chunk, and the current block's output stores drain under the next block's first chunk.  A launch is
+// then one round of resident workgroups (DiT-XL/2: 512 = two per CU) instead of two rounds that each pay the memory-bound prologue
+// (profiles/r04_attn_phases.txt: 2.6 of the 10.5 us a workgroup lives, + 0.9 us of epilogue).  Same products, same chunk order, same softmax
+// arithmetic per row: bit-identical to NIT = 1.
+template <int HDP, int KS, int NDT, int QT, int NWV = 4, int NIT = 1>
 __global__ __launch_bounds__(NWV * 64) void k_attn_fwd(const __bf16* __restrict__ qkv, __bf16* __restrict__ o,
                                                        float* __restrict__ lse, int T, int H, int hd, float scale) {
   static_assert(NWV == 4 || NWV == FNW, "four or eight waves");
+  static_assert(NIT == 1 || NWV == 4, "several query blocks per workgroup: four-wave form only");
   extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
   Ring<HDP> ring{smem};
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
@@ -282,14 +289,14 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_fwd(const __bf16* __restrict_
   // 1-D grid.  Workgroup ids go round-robin over the 8 XCDs: id -> (id & 7) * (n / 8) + (id >> 3) gives each XCD one contiguous run of
   // (batch, head, query block) triples, so the query blocks of a head (same K / V) and the neighbouring heads of a sample (neighbouring
   // 144-B column slices of the same rows: shared 128-B lines) meet in ONE L2
-  const int nblk = gridDim.x, nqb = T / (NWV * 16 * QT);
+  const int nblk = gridDim.x, nqb = T / (NWV * 16 * QT * NIT);
   const int wid = (nblk & 7) == 0 ? (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   const int bh = wid / nqb, b = bh / H, h = bh % H;
   const int D = H * hd, ld = 3 * D;
-  const int q0 = (wid % nqb) * (NWV * 16 * QT) + wave * (16 * QT);
+  const int qbase = (wid % nqb) * (NWV * 16 * QT * NIT) + wave * (16 * QT);        // + it * NWV * 16 * QT for query block `it` of this workgroup
   const __bf16* base = qkv + (size_t)b * T * ld + h * hd;
   const float c = scale * LOG2E;
-  const int nchunk = T / 64;
+  const int nchunk = T / 64, total = NIT * nchunk;                                  // chunks per query block / per workgroup
 
   const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(base + D), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(base + 2 * D), 0, 0x7fffffff, 0x00020000);
@@ -298,8 +305,8 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_fwd(const __bf16* __restrict_
   if constexpr (NWV == 4) dma.init(ld, hd, wave, lane);
   else dma8.init([&](int) { return ld; }, hd, wave, lane);
   constexpr int PER_CHUNK = NWV == 4 ? Ring<HDP>::PER_CHUNK : GroupDma<HDP, 2>::PER_WAVE;      // DMA instructions per wave and chunk
-  auto issue = [&](int ch) {
-    const int slot = ch % NSLOT, soff = ch * 64 * ld * 2;
+  auto issue = [&](int gch) {                          // gch: position in the workgroup's chunk stream; the K / V chunk is gch % nchunk
+    const int slot = gch % NSLOT, soff = (NIT == 1 ? gch : gch % nchunk) * 64 * ld * 2;
     if constexpr (NWV == 4) {
       dma.issue(rsK, soff, ring.img(slot, 0), wave);
       dma.issue(rsV, soff, ring.img(slot, 1), wave);
@@ -314,14 +321,14 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_fwd(const __bf16* __restrict_
   };
   // the Q fragments go out BEFORE the LDS-DMA of the first two K / V chunks: vector-memory operations retire in order, so loads
   // issued behind the DMA would keep the first S = Q K^T waiting for chunk 1 as well
-  bf16x8 fq[QT][KS];
+  bf16x8 fq[QT][KS], fqn[QT][KS];
 #pragma unroll
   for (int qi = 0; qi < QT; ++qi)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) fq[qi][ks] = frag_rows_global(base, ld, q0 + 16 * qi, ks, hd, lane);
+    for (int ks = 0; ks < KS; ++ks) fq[qi][ks] = frag_rows_global(base, ld, qbase + 16 * qi, ks, hd, lane);
   ATTN_STAMP_P(1);
   issue(0);                              // first two chunks stream in while the pads are zeroed
-  if (nchunk > 1) issue(1);
+  if (total > 1) issue(1);
   ATTN_STAMP_P(2);
   zero_pads<HDP, NWV * 64, 2>(smem, NSLOT, hd, tid);       // the K images (even ring images); V is read by columns only
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // pad zeros written before the first barrier of the loop
@@ -329,6 +336,9 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_fwd(const __bf16* __restrict_
 
   f32x4 oacc[QT][NDT];
   float m[QT], l[QT];
+#pragma unroll 1
+  for (int it = 0; it < NIT; ++it) {
+  const int q0 = qbase + it * (NWV * 16 * QT);
 #pragma unroll
   for (int qi = 0; qi < QT; ++qi) {
     m[qi] = -INFINITY; l[qi] = 0.f;
@@ -337,13 +347,25 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_fwd(const __bf16* __restrict_
   }
 
   for (int kc = 0; kc < nchunk; ++kc) {
-    if (kc + 1 < nchunk) wait_vmcnt<PER_CHUNK>(); else wait_vmcnt<0>();
+    const int gc = it * nchunk + kc;
+    // chunk gc has landed.  Younger vector-memory operations of this wave: the DMA of chunk gc + 1 and -- across a query-block boundary -- the
+    // previous block's output stores and this block's Q fragments, all issued BEHIND that DMA; waiting until no more than one chunk's DMA
+    // instructions are outstanding therefore only waits for more than is needed (operations retire in order)
+    if (gc + 1 < total) wait_vmcnt<PER_CHUNK>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (kc == 0) ATTN_STAMP_P(4);
-    if (kc < 5) ATTN_STAMP_L(1 + kc);
-    if (kc + 2 < nchunk) issue(kc + 2);
-    const __bf16* iK = ring.img(kc % NSLOT, 0);
-    const __bf16* iV = ring.img(kc % NSLOT, 1);
+    if (gc == 0) ATTN_STAMP_P(4);
+    if (gc < 5) ATTN_STAMP_L(1 + gc);
+    if (gc + 2 < total) issue(gc + 2);
+    if constexpr (NIT > 1) {
+      if (kc == nchunk - 1 && it + 1 < NIT) {              // the next query block's Q fragments, requested under this block's last chunk
+#pragma unroll
+        for (int qi = 0; qi < QT; ++qi)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) fqn[qi][ks] = frag_rows_global(base, ld, q0 + NWV * 16 * QT + 16 * qi, ks, hd, lane);
+      }
+    }
+    const __bf16* iK = ring.img(gc % NSLOT, 0);
+    const __bf16* iV = ring.img(gc % NSLOT, 1);
     f32x4 s[QT][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -420,6 +442,15 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_fwd(const __bf16* __restrict_
     store_tiles<NDT>(orow, ov, hd, g);
     if (g == 0) lse[(size_t)bh * T + q] = m[qi] * scale + logf(lt);
   }
+  if constexpr (NIT > 1) {
+    if (it + 1 < NIT) {
+#pragma unroll
+      for (int qi = 0; qi < QT; ++qi)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) fq[qi][ks] = fqn[qi][ks];
+    }
+  }
+  }   // query blocks of this workgroup
   ATTN_STAMP(6);
 }
 
@@ -1160,6 +1191,7 @@ template __global__ void k_attn_bwd_fused<96, 3, 5, 1>(const __bf16*, const __bf
   template __global__ void k_attn_fwd<HDP, KS, NDT, 1>(const __bf16*, __bf16*, float*, int, int, int, float);      \
   template __global__ void k_attn_fwd<HDP, KS, NDT, 2>(const __bf16*, __bf16*, float*, int, int, int, float);      \
   template __global__ void k_attn_fwd<HDP, KS, NDT, 2, 8>(const __bf16*, __bf16*, float*, int, int, int, float);   \
+  template __global__ void k_attn_fwd<HDP, KS, NDT, 2, 4, 2>(const __bf16*, __bf16*, float*, int, int, int, float); \
   template __global__ void k_attn_bwd_dq<HDP, KS, NDT, 1>(const __bf16*, const __bf16*, const __bf16*, const float*, float*, __bf16*, int, int, int, float); \
   template __global__ void k_attn_bwd_dq<HDP, KS, NDT, 2>(const __bf16*, const __bf16*, const __bf16*, const float*, float*, __bf16*, int, int, int, float); \
   template __global__ void k_attn_bwd_dkv<HDP, KS, NDT, 1>(const __bf16*, const __bf16*, const float*, const float*, __bf16*, int, int, int, float);
@@ -1286,7 +1318,7 @@ namespace {
 // 0 / 1 = fused backward where the sequence length allows it; 2 = always the two-kernel form (tests compare the two)
 int g_bwd_form = 0;
 
-// process-wide: 0 = by rule (k_attn_fwd8 for sequences of 512 tokens or more -- the LDM UNet's 1024 / 4096: 467 -> 391 us at T = 4096; at the
+// process-wide: 0 = by rule (two query blocks per workgroup at T = 256, round 6; k_attn_fwd8 for sequences of 512 tokens or more -- the LDM UNet's 1024 / 4096: 467 -> 391 us at T = 4096; at the
 // DiT's 256 tokens the eight-wave form is 9 % faster alone, 31.5 -> 28.6 us, and 0.4 ms per step SLOWER inside the step), 4 / 8 = force (A-B)
 int g_fwd_form = 0;
 template <int HDP> size_t lds_bytes(int extra_floats) { return NSLOT * 2 * 64 * HDP * sizeof(__bf16) + extra_floats * sizeof(float); }
@@ -1307,6 +1339,9 @@ int launch_fwd(const __bf16* qkv, __bf16* o, float* lse, int B, int T, int H, in
                                                        // 29.9 us against 27.3 alone, +0.2 ms in the step: one workgroup per CU, eight waves per barrier
     int rc = set_lds(&k_attn_fwd<HDP, KS, NDT, 2, 8>, lds); if (rc) return rc;
     hipLaunchKernelGGL((k_attn_fwd<HDP, KS, NDT, 2, 8>), dim3(T / 256 * B * H), dim3(512), lds, s, qkv, o, lse, T, H, hd, scale);
+  } else if (T % 256 == 0 && g_fwd_form == 0) {        // round 6: both 128-row query blocks of a head in one workgroup (one resident round)
+    int rc = set_lds(&k_attn_fwd<HDP, KS, NDT, 2, 4, 2>, lds); if (rc) return rc;
+    hipLaunchKernelGGL((k_attn_fwd<HDP, KS, NDT, 2, 4, 2>), dim3(T / 256 * B * H), dim3(NT), lds, s, qkv, o, lse, T, H, hd, scale);
   } else if (T % 128 == 0) {
     int rc = set_lds(&k_attn_fwd<HDP, KS, NDT, 2>, lds); if (rc) return rc;
     hipLaunchKernelGGL((k_attn_fwd<HDP, KS, NDT, 2>), dim3(T / 128 * B * H), dim3(NT), lds, s, qkv, o, lse, T, H, hd, scale);
