@@ -137,15 +137,15 @@ def test_conditioning_and_layout():
 def test_attention_forward_eight_wave_form_is_bit_identical(B, T, H, hd):
     """k_attn_fwd8 (round 4: eight waves of 16 query rows per workgroup, sixteen waves per CU) and the whole-head form (eight waves of 32
     rows: form 16, taken where the sequence is a multiple of 256 rows) against the four-wave kernel: the same products and the same softmax
-    arithmetic per row -> the same bits in O and LSE.  Round 6: form 0 = the rule -- at T = 256 / 512-free multiples of 256 one workgroup
-    walks both 128-row query blocks of a head as one chunk stream (k_attn_fwd<..., NIT = 2>) -- is in the comparison too."""
+    arithmetic per row -> the same bits in O and LSE.  Round 6: form 2 -- where T is a multiple of 256 one workgroup walks both 128-row query
+    blocks of a head as one chunk stream (k_attn_fwd<..., NIT = 2>) -- and form 0 (the rule) are in the comparison too."""
     from sfron import _lib, ops
     L = _lib.lib()
     gen = torch.Generator().manual_seed(T * H + hd)
     D = H * hd
     qkv = (torch.randn(B * T, 3 * D, generator=gen) * 1.5).to(torch.bfloat16).to(DEV)
     res = []
-    for form in (4, 8, 16, 0):
+    for form in (4, 8, 16, 2, 0):
         old = L.sfron_attn_fwd_form(form)
         try:
             o, lse = ops.attn_fwd(qkv, B, T, H, hd)
@@ -157,6 +157,7 @@ def test_attention_forward_eight_wave_form_is_bit_identical(B, T, H, hd):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1])
     assert torch.equal(res[0][0], res[3][0]) and torch.equal(res[0][1], res[3][1])
+    assert torch.equal(res[0][0], res[4][0]) and torch.equal(res[0][1], res[4][1])
 
 
 @pytest.mark.parametrize("B,T,H,hd", [(2, 64, 2, 64), (1, 128, 3, 72), (2, 256, 2, 72), (1, 256, 4, 64), (1, 192, 1, 64),

@@ -22,7 +22,7 @@ def timeit(fn, iters=20):
 from sfron import _lib
 o, lse = ops.attn_fwd(qkv, B, T, H, hd)
 fl = 4.0 * B * H * T * T * hd
-for form in (4, 8, 16, 0):          # 0 = the rule (round 6 at T = 256: both query blocks of a head in one workgroup)
+for form in (4, 8, 16, 2):          # 2 = both query blocks of a head in one workgroup (round 6)
     _lib.lib().sfron_attn_fwd_form(form)
     ms = timeit(lambda: ops.attn_fwd(qkv, B, T, H, hd))
     print(f"attn fwd  B{B} T{T} H{H} hd{hd}, form {form}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s")

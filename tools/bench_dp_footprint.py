@@ -20,7 +20,11 @@ import torch
 from sfron import data, diffusion, dit, step
 
 dev = torch.device("cuda:0")
-foot = ctypes.CDLL(os.path.join(ROOT, "tools", "probes", "libdpfoot.so"))
+_so = os.path.join(ROOT, "tools", "probes", "libdpfoot.so")
+if not os.path.exists(_so):          # (git-ignored; hipcc cross-compiles it anywhere)
+    import subprocess
+    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", _so, os.path.join(ROOT, "tools", "probes", "dp_footprint.hip")], check=True)
+foot = ctypes.CDLL(_so)
 foot.dp_footprint.restype = ctypes.c_int
 foot.dp_footprint.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 

@@ -270,7 +270,7 @@ __device__ long long* d_attn_clk = nullptr;
 // QT = 2 the WHOLE head at T = 256, so its K / V chunks are brought in once, not once per query block (per CU the memory-bound start of a round
 // moves 73 KB instead of 110, profiles/r04_attn_phases.txt).  Same products, same order per row: bit-identical -- and slower (one workgroup
 // per CU instead of two, eight waves behind each chunk's barrier): kept as a form the tests compare, not taken by rule.
-// NIT = 2 (round 6, the rule at T = 256): ONE workgroup walks the NIT consecutive query blocks of a head as one stream of NIT * T / 64 chunks through
+// NIT = 2 (round 6, sfron_attn_fwd_form(2); a form the tests compare, not the rule): ONE workgroup walks the NIT consecutive query blocks of a head as one stream of NIT * T / 64 chunks through
 // the same ring -- the next block's first K / V chunks (the SAME K / V: L2 hits) arrive while the current block finishes, its Q fragments are
 // requested under the current block's last chunk, and the current block's output stores drain under the next block's first chunk.  A launch is
 // then one round of resident workgroups (DiT-XL/2: 512 = two per CU) instead of two rounds that each pay the memory-bound prologue
@@ -1318,7 +1318,7 @@ namespace {
 // 0 / 1 = fused backward where the sequence length allows it; 2 = always the two-kernel form (tests compare the two)
 int g_bwd_form = 0;
 
-// process-wide: 0 = by rule (two query blocks per workgroup at T = 256, round 6; k_attn_fwd8 for sequences of 512 tokens or more -- the LDM UNet's 1024 / 4096: 467 -> 391 us at T = 4096; at the
+// process-wide: 0 = by rule (k_attn_fwd8 for sequences of 512 tokens or more -- the LDM UNet's 1024 / 4096: 467 -> 391 us at T = 4096; at the
 // DiT's 256 tokens the eight-wave form is 9 % faster alone, 31.5 -> 28.6 us, and 0.4 ms per step SLOWER inside the step), 4 / 8 = force (A-B)
 int g_fwd_form = 0;
 template <int HDP> size_t lds_bytes(int extra_floats) { return NSLOT * 2 * 64 * HDP * sizeof(__bf16) + extra_floats * sizeof(float); }
@@ -1339,7 +1339,10 @@ int launch_fwd(const __bf16* qkv, __bf16* o, float* lse, int B, int T, int H, in
                                                        // 29.9 us against 27.3 alone, +0.2 ms in the step: one workgroup per CU, eight waves per barrier
     int rc = set_lds(&k_attn_fwd<HDP, KS, NDT, 2, 8>, lds); if (rc) return rc;
     hipLaunchKernelGGL((k_attn_fwd<HDP, KS, NDT, 2, 8>), dim3(T / 256 * B * H), dim3(512), lds, s, qkv, o, lse, T, H, hd, scale);
-  } else if (T % 256 == 0 && g_fwd_form == 0) {        // round 6: both 128-row query blocks of a head in one workgroup (one resident round)
+  } else if (T % 256 == 0 && g_fwd_form == 2) {        // round 6: both 128-row query blocks of a head in one workgroup (one resident round of 512 at
+                                                       // DiT-XL/2): measured, not the rule -- 30.5 us against 27.5 alone, 62.26 / 62.74 against 62.63 / 62.79 ms
+                                                       // per step (profiles/r06_ab_log.txt): with 1 024 workgroups the second round's prologues
+                                                       // already run under the first round's last chunks
     int rc = set_lds(&k_attn_fwd<HDP, KS, NDT, 2, 4, 2>, lds); if (rc) return rc;
     hipLaunchKernelGGL((k_attn_fwd<HDP, KS, NDT, 2, 4, 2>), dim3(T / 256 * B * H), dim3(NT), lds, s, qkv, o, lse, T, H, hd, scale);
   } else if (T % 128 == 0) {
@@ -1421,7 +1424,7 @@ int sfron_dbg_attn_clock(long long* out, int n_wg) {
 
 /* test hook: 2 = force the two-kernel backward (dQ, then dK/dV) for every T; 0 = default (fused where T is 128 or 256) */
 int sfron_attn_bwd_form(int form) { const int old = g_bwd_form; g_bwd_form = form; return old; }
-int sfron_attn_fwd_form(int form) { const int old = g_fwd_form; g_fwd_form = (form == 4 || form == 8 || form == 16) ? form : 0; return old; }
+int sfron_attn_fwd_form(int form) { const int old = g_fwd_form; g_fwd_form = (form == 2 || form == 4 || form == 8 || form == 16) ? form : 0; return old; }
 
 int sfron_attn_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* delta_scratch,
                    uint16_t* dqkv, int B, int T, int H, int hd, void* stream) {
