@@ -542,7 +542,8 @@ int sfron_attn_bwd_bias(const uint16_t* qkv, const uint16_t* o, const uint16_t* 
 int sfron_attn_bwd_form(int form);
 /* test / A-B hook: 0 (default) = by rule (eight waves of 16 query rows per workgroup for sequences of 512 tokens or more, four waves of 32
  * rows below), 4 / 8 / 16 = force the four-wave / eight-wave 16-row / eight-wave 32-row (one workgroup per 256 query rows; measured slower)
- * form where the sequence length allows it (bit-identical results); returns the previous setting */
+ * form, 2 (round 6) = four waves walking BOTH 128-row query blocks of a head as one chunk stream where the sequence is a multiple of 256 rows
+ * (measured: not faster) -- each where the sequence length allows it (bit-identical results); returns the previous setting */
 int sfron_attn_fwd_form(int form);
 /* Process-wide form of the three-slot GEMM tiles (256 x 144 forward / dgrad, 192 x 192 weight gradient): 4 = four extra LOADER waves per
  * workgroup issue every LDS-DMA piece and the eight multiplying waves none (csrc/gemm.hip k_gemm_pipe NL; taken by the dgrad and

@@ -192,11 +192,14 @@ def test_remain_sweep_beside_the_next_step_gives_the_same_state(fp8):
     bat = lambda it: (data.synthetic_batch(6, it, "forget", **kw), data.synthetic_batch(6, it, "remain", **kw))
     hp = dict(lr=2e-4, forget_alpha=0.3, grad_clip=1.0, ema_decay=0.99, mask=None, unlearn_loss="ga", forget_class=3)
 
-    def run(across):
+    def run(across, defer=False):
         _, model = build_pair(cfg, B, seed=29)
         runner = step.DiTSFRon(model, diffusion.create_diffusion(""), fp8=fp8, **hp)     # fp8: the sweeps also rewrite the e4m3 shadow
         assert runner.sweep_across_steps is False          # opt-in
         runner.sweep_across_steps = across
+        # round 6: the second-stream launches of a beside-forward sweep issued by the forward pass itself, between its conditioning prologue
+        # and block 0 (sfron_dit_forward_phase); the sweep left across the step boundary is handed to the next step's pass or to drain_sweep
+        runner.defer_sweep_launch = defer
         for it in range(4):
             runner.step(*bat(it))
         if across:
@@ -208,13 +211,14 @@ def test_remain_sweep_beside_the_next_step_gives_the_same_state(fp8):
         eng = model.engine
         return (eng.params.clone(), runner.opt.m.clone(), runner.opt.v.clone(), runner.ema.clone(), eng.params_bf16.clone(), ck)
 
-    a, b = run(False), run(True)
-    for x, y in zip(a[:5], b[:5]):
-        assert torch.equal(x, y)
-    for k in a[5]["model"]:
-        assert torch.equal(a[5]["model"][k], b[5]["model"][k])
-    for k in a[5]["ema"]:
-        assert torch.equal(a[5]["ema"][k], b[5]["ema"][k])
+    a = run(False)
+    for b in (run(True), run(True, defer=True), run(False, defer=True)):
+        for x, y in zip(a[:5], b[:5]):
+            assert torch.equal(x, y)
+        for k in a[5]["model"]:
+            assert torch.equal(a[5]["model"][k], b[5]["model"][k])
+        for k in a[5]["ema"]:
+            assert torch.equal(a[5]["ema"][k], b[5]["ema"][k])
 
 
 def test_batch_size_change_while_the_remain_sweep_is_in_flight():

@@ -64,7 +64,9 @@ class DiTSFRon:
         # opt-in: the remain-stage sweep of the block ranges runs beside the NEXT step's forget forward pass; step() then returns with it in
         # flight -- read parameters / optimizer state through this runner (state_dict / checkpoint / sync()), not from the raw arenas
         self.sweep_across_steps = False
-        self.defer_sweep_launch = True      # a beside-forward sweep starts behind that pass's conditioning prologue (A-B knob: False = before it)
+        # True: a beside-forward sweep is launched BEHIND that pass's conditioning prologue (engine.forward(between=...)).  Measured neutral
+        # without a profiler (profiles/r06_ab_log.txt) and it puts 26 Python-issued launches on the critical path: off by default.
+        self.defer_sweep_launch = False
         # single-process runs: the forget stage's clip norm (forget.py:293-298) is taken where the gradients are produced -- the block
         # weight-gradient GEMMs leave the masked sums of squares of their tiles (engine.arm_sumsq), one small launch covers biases /
         # embedders / final layer, the rank-(batch) adaLN range is summed from its factors: no pass over the 1.8 GB block range of the arena
