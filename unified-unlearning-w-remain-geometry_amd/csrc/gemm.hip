@@ -1429,14 +1429,29 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
     // (The residual loads stay per 16-row block.  Issuing all MT x NT of the tile up front saves one exposed latency -- and takes the 256 x 144
     // kernel from 206 to 234 registers = 240 allocated: two of its waves then leave a SIMD 32 registers, the parameter sweep that runs
     // beside the forward pass needs 48 per wave and loses every CU this kernel is on: +2.7 ms per step, profiles/r04_ab_log.txt.)
+    // Round 6: the residual rows of block mt + 1 are requested WHILE block mt is finished -- piece nt of the next block right behind the
+    // point where piece nt of this block (accumulator + residual: eight registers) dies, so the register count does not grow -- instead of
+    // after this block's stores: one exposed memory latency per tile instead of MT.  (one_sample only: with several samples per tile the gate
+    // rows change per block and the loop keeps the round-5 order.)  Same arithmetic: the same bits.
+    float4 xr[2][NT];
+#ifdef SFRON_TUNE_GATE_RES_R5           // A-B build only (tools/build_variant.sh): the round-5 order, one exposed latency per 16-row block
+    const bool pipe = false;
+#else
+    const bool pipe = one_sample;
+#endif
+    if (pipe) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) xr[0][nt] = *reinterpret_cast<const float4*>(g.resid + (size_t)row_b * g.ldcf + col_b + nt * 16);
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int row = row_b + mt * 16;
-      float4 xr[NT];
+      if (!pipe) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        xr[nt] = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldcf + col_b + nt * 16);
-        if (!one_sample) gt[nt] = *reinterpret_cast<const float4*>(g.gate + (size_t)(row / g.T) * g.ldgate + col_b + nt * 16);
+        for (int nt = 0; nt < NT; ++nt) {
+          xr[mt & 1][nt] = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldcf + col_b + nt * 16);
+          if (!one_sample) gt[nt] = *reinterpret_cast<const float4*>(g.gate + (size_t)(row / g.T) * g.ldgate + col_b + nt * 16);
+        }
       }
       const bool wide = (g.ldaux & 7) == 0 && !(g.nt_out & 1);
       bf16x4 ab[NT];
@@ -1449,7 +1464,9 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
         else if (g.bias) v += as4(*reinterpret_cast<const float4*>(g.bias + col));
         ab[nt] = f2bf4(v);
         if (!wide) nt_store(reinterpret_cast<bf16x4*>(g.aux + (size_t)row * g.ldaux + col), ab[nt], g.nt_out & 1);
-        const f32x4 x = as4(xr[nt]) + as4(gt[nt]) * v;
+        const f32x4 x = as4(xr[mt & 1][nt]) + as4(gt[nt]) * v;
+        if (pipe && mt + 1 < MT)
+          xr[(mt + 1) & 1][nt] = *reinterpret_cast<const float4*>(g.resid + (size_t)(row + 16) * g.ldcf + col);
         *reinterpret_cast<f32x4*>(g.Cf + (size_t)row * g.ldcf + col) = x;
       }
       if (wide) {                                  // the bf16 branch output (read again by the backward pass): 16-byte pieces
