@@ -256,7 +256,7 @@ def test_ddpm_sfron_trajectory_vs_reference_fixture():
 
 
 # ------------------------------------------------------------------------------------------------ LDM UNetModel
-SD_GRAD_NORM_TOL, SD_GRAD_REL_TOL = 6e-2, 6e-2      # PROVISIONAL until the round-6 measurement
+SD_GRAD_NORM_TOL, SD_GRAD_REL_TOL = 2.3e-2, 4.6e-2      # 2 x measured on MI355X (round 6): 0.0115 / 0.0230 (were 6e-2 / 6e-2)
 SD_TINY = dict(in_channels=4, out_channels=4, model_channels=32, attention_resolutions=(2, 1), num_res_blocks=1, channel_mult=(1, 2), num_heads=2,
                transformer_depth=1, context_dim=24)
 
@@ -363,12 +363,12 @@ def test_sd_nsfw_removal_trajectory_vs_reference_fixture(method):
     wr = sorted(cs.items(), key=lambda kv: -abs(kv[1][1] - 1.0))[:3]
     print(f"SD {method}: {len(cs)} tensors (+ {len(zero)} with an exactly-zero gradient), min update cosine {worst[0][1][0]:.4f} ({worst[0][0]}), "
           f"worst norm ratio {wr[0][1][1]:.4f} ({wr[0][0]})")
-    mats = [n for n in cs if U[f"{method}::upd::{n}"].ndim >= 2]
+    mats = [n for n in cs if sd0[n].dim() >= 2]          # (the fixture stores the updates flattened: the shape is the parameter's)
     wm = min((cs[n][0], n) for n in mats)
     wmr = max((abs(cs[n][1] - 1.0), n) for n in mats)
     print(f"SD {method}: {len(mats)} matrices: min update cosine {wm[0]:.4f} ({wm[1]}), worst norm error {wmr[0]:.4f} ({wmr[1]})")
     for n, (cos, ratio, rms) in cs.items():
         assert rms > 0.05, (n, rms)
-        matrix = U[f"{method}::upd::{n}"].ndim >= 2
+        matrix = sd0[n].dim() >= 2
         assert cos >= (SD_UPDATE_COS_MIN_MATRIX if matrix else SD_UPDATE_COS_MIN)[method], (n, cos, worst)
         assert abs(ratio - 1.0) < (SD_UPDATE_NORM_TOL_MATRIX if matrix else SD_UPDATE_NORM_TOL)[method], (n, ratio, wr)
