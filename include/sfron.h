@@ -245,15 +245,19 @@ int sfron_fp8_quant_tensors(const float* params, const int64_t* table, int n_ten
 int sfron_fp8_update_scales(uint32_t* amax_bits, int n_tensors, float* scales, void* stream);
 /* How much of the e4m3 range the ACTIVATIONS of config 5 used since the last reset: out3[site] (HOST out) = max |x * scale| over every value
  * quantised at site 0 = sfron_ln_modulate_fwd_q's output, 1 = sfron_cast_e4m3, 2 = the e4m3 GELU output of sfron_fp8_gemm (c_e4m3).  The
- * conversion saturates at 448: a value above it means values WERE clipped (the reference has no fp8 path: nothing there to mirror).  Process-
- * wide counters; synchronises `stream`.  reset != 0 clears them. */
-int sfron_fp8_activation_amax(float* out3 /* HOST out, 3 floats */, int reset, void* stream);
+ * conversion saturates at 448: a value above it means values WERE clipped (the reference has no fp8 path: nothing there to mirror).  The
+ * three words are the CALLER's (round 6): a zero-initialised DEVICE uint32 [3] handed as `act_amax` to every quantising entry point
+ * (sfron_ln_modulate_fwd_q, sfron_cast_e4m3, sfron_fp8_gemm_desc.act_amax, sfron_dit_forward_fp8; NULL there = no tracking); this call
+ * copies them to the host (synchronises `stream`) and, with reset != 0, clears them. */
+int sfron_fp8_activation_amax(uint32_t* act_amax, float* out3 /* HOST out, 3 floats */, int reset, void* stream);
 
 /* dst[i] = e4m3(src[i] * scale); src bf16 (src_is_bf16 = 1) or fp32; n % 8 == 0 */
-int sfron_cast_e4m3(const void* src, int src_is_bf16, int64_t n, float scale, uint8_t* dst, void* stream);
+int sfron_cast_e4m3(const void* src, int src_is_bf16, int64_t n, float scale, uint8_t* dst, uint32_t* act_amax /* DEVICE [3] or NULL */,
+                    void* stream);
 /* sfron_ln_modulate_fwd that also writes out_e4m3 = e4m3(value * e4m3_scale) from the fp32 value (the A operand of the next GEMM) */
 int sfron_ln_modulate_fwd_q(const float* x, const float* shift, const float* scale, int ldmod, int tokens, int M, int D, uint16_t* out,
-                            uint8_t* out_e4m3, float e4m3_scale, float* mean, float* rstd, void* stream);
+                            uint8_t* out_e4m3, float e4m3_scale, float* mean, float* rstd, uint32_t* act_amax /* DEVICE [3] or NULL */,
+                            void* stream);
 
 /* C[M][N] = (A8[M][K] . B8[N][K]^T) / (a_scale * *w_scale) + bias with one of the block's epilogues:
  *   SFRON_EPI_BF16      c_bf16 = result                                                   (qkv)
@@ -276,6 +280,8 @@ typedef struct sfron_fp8_gemm_desc {
   const float* resid;                /* NULL = in place */
   const float* gate; int ldgate;
   int tokens;
+  uint32_t* act_amax;                /* DEVICE uint32 [3] or NULL: the caller's activation-range words (sfron_fp8_activation_amax); the e4m3
+                                        GELU output (c_e4m3) raises word 2 */
 } sfron_fp8_gemm_desc;
 int sfron_fp8_gemm_supported(int M, int N, int K);
 int sfron_fp8_gemm(const sfron_fp8_gemm_desc* desc /* HOST pointer */, void* stream);
@@ -597,7 +603,8 @@ int sfron_dit_forward_after(const sfron_dit_cfg* cfg, const float* params, const
  * Returns SFRON_ERR_UNSUPPORTED when a block GEMM shape is not a multiple of the fp8 tile (sfron_fp8_gemm_supported). */
 int64_t sfron_dit_fp8_workspace_bytes(const sfron_dit_cfg* cfg);
 int sfron_dit_forward_fp8(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const uint8_t* params_e4m3,
-                          const float* w_scales, const float* act_scales, const float* x_t, const int64_t* t, const int64_t* y,
+                          const float* w_scales, const float* act_scales, uint32_t* act_amax /* DEVICE [3] or NULL */, const float* x_t,
+                          const int64_t* t, const int64_t* y,
                           const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out,
                           void* const* block_ready /* as sfron_dit_forward_after, or NULL */, void* stream);
 /* The forward pass in two calls (round 6).  phase 1 = only what stands in front of block 0 -- patch embedding, timestep / label embedders,
@@ -609,7 +616,8 @@ int sfron_dit_forward_phase(const sfron_dit_cfg* cfg, const float* params, const
                             const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
                             void* const* block_ready /* or NULL */, void* probe /* or NULL */, int phase /* 1 | 2 */, void* stream);
 int sfron_dit_forward_fp8_phase(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const uint8_t* params_e4m3,
-                                const float* w_scales, const float* act_scales, const float* x_t, const int64_t* t, const int64_t* y,
+                                const float* w_scales, const float* act_scales, uint32_t* act_amax /* DEVICE [3] or NULL */, const float* x_t,
+                          const int64_t* t, const int64_t* y,
                                 const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out,
                                 void* const* block_ready /* or NULL */, int phase /* 1 | 2 */, void* stream);
 /* Same as sfron_dit_forward, with HIP events recorded (on `stream`) around the fc1 GEMM of block 0 -- the
@@ -663,6 +671,10 @@ int sfron_aux_wait_ada(void* aux, void* stream);
  * factors are complete (earlier than sfron_aux_wait_ada: the dgrad through the adaLN Linear is still to come).  sfron_sumsq_lowrank reads
  * nothing else.  No-op before the first such pass. */
 int sfron_aux_wait_ada_factors(void* aux, void* stream);
+/* The handle's two weight-gradient streams (hipStream_t, owned by the library: read-only use).  For callers that put work of their own beside a
+ * backward pass -- a gradient exchange, a sweep -- and must pick a stream that does NOT share a hardware queue with these two: the runtime maps
+ * streams onto four hardware queues and two streams on one queue serialise (profiles/r06_hw_queues.txt; the host mirror probes: streams.py). */
+int sfron_aux_streams(void* aux, void** side /* HOST out */, void** side2 /* HOST out */);
 int sfron_aux_destroy(void* aux);
 
 #ifdef __cplusplus

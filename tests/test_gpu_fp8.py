@@ -34,13 +34,13 @@ def test_e4m3_quantisers_bit_exact_vs_torch():
     x[:8] = torch.tensor([0.0, -0.0, 448.0, -448.0, 449.0, 1e6, 2.0 ** -9, 2.0 ** -10])
     for scale in (1.0, 8.0, 0.25):
         out = torch.empty(x.numel(), dtype=torch.uint8, device=DEV)
-        check(L.sfron_cast_e4m3(ptr(x.to(DEV)), 0, x.numel(), scale, ptr(out), stream_ptr()), "cast_e4m3")
+        check(L.sfron_cast_e4m3(ptr(x.to(DEV)), 0, x.numel(), scale, ptr(out), None, stream_ptr()), "cast_e4m3")
         want = fp8_ref.e4m3_bytes(x, scale)
         got = out.cpu()
         # +0 / -0 are the same value; everything else bit for bit
         assert ((got == want) | (((got & 0x7F) == 0) & ((want & 0x7F) == 0))).all(), (got != want).sum()
         xb = x.to(torch.bfloat16)
-        check(L.sfron_cast_e4m3(ptr(xb.to(DEV)), 1, x.numel(), scale, ptr(out), stream_ptr()), "cast_e4m3")
+        check(L.sfron_cast_e4m3(ptr(xb.to(DEV)), 1, x.numel(), scale, ptr(out), None, stream_ptr()), "cast_e4m3")
         want = fp8_ref.e4m3_bytes(xb.float(), scale)
         got = out.cpu()
         assert ((got == want) | (((got & 0x7F) == 0) & ((want & 0x7F) == 0))).all()
@@ -100,8 +100,8 @@ def test_fp8_gemm_epilogues_vs_torch(M, N, K):
     W = torch.randn(N, K, device=DEV, generator=g) * 0.03
     bias = torch.randn(N, device=DEV, generator=g) * 0.1
     A8, B8 = torch.empty(M, K, dtype=torch.uint8, device=DEV), torch.empty(N, K, dtype=torch.uint8, device=DEV)
-    check(L.sfron_cast_e4m3(ptr(X), 0, X.numel(), sa, ptr(A8), stream_ptr()), "cast")
-    check(L.sfron_cast_e4m3(ptr(W), 0, W.numel(), sw, ptr(B8), stream_ptr()), "cast")
+    check(L.sfron_cast_e4m3(ptr(X), 0, X.numel(), sa, ptr(A8), None, stream_ptr()), "cast")
+    check(L.sfron_cast_e4m3(ptr(W), 0, W.numel(), sw, ptr(B8), None, stream_ptr()), "cast")
     Xq = A8.view(torch.float8_e4m3fn).float() / sa
     Wq = B8.view(torch.float8_e4m3fn).float() / sw
     want = Xq @ Wq.t() + bias
@@ -380,18 +380,20 @@ def test_activation_range_is_reported_and_flags_saturation():
     from sfron import _lib, ops
     L = _lib.lib()
     out = (ctypes.c_float * 3)()
-    assert L.sfron_fp8_activation_amax(out, 1, None) == 0                      # reset
+    words = torch.zeros(3, dtype=torch.int32, device=DEV)                      # the caller's counters (round 6: no library-global state)
+    wp = ctypes.c_void_p(words.data_ptr())
+    assert L.sfron_fp8_activation_amax(wp, out, 1, None) == 0                  # reset
     n = 4096
     x = torch.linspace(-3.0, 5.0, n, device=DEV)
     dst = torch.empty(n, dtype=torch.uint8, device=DEV)
-    assert L.sfron_cast_e4m3(ctypes.c_void_p(x.data_ptr()), 0, n, ctypes.c_float(32.0), ctypes.c_void_p(dst.data_ptr()), None) == 0
-    assert L.sfron_fp8_activation_amax(out, 0, None) == 0
+    assert L.sfron_cast_e4m3(ctypes.c_void_p(x.data_ptr()), 0, n, ctypes.c_float(32.0), ctypes.c_void_p(dst.data_ptr()), wp, None) == 0
+    assert L.sfron_fp8_activation_amax(wp, out, 0, None) == 0
     assert out[0] == 0.0 and out[2] == 0.0 and abs(out[1] - 160.0) < 1e-3        # 5 * 32: inside the range
     xb = (x * 4).to(torch.bfloat16)                                              # up to 20 * 32 = 640 > 448: clipped
-    assert L.sfron_cast_e4m3(ctypes.c_void_p(xb.data_ptr()), 1, n, ctypes.c_float(32.0), ctypes.c_void_p(dst.data_ptr()), None) == 0
-    assert L.sfron_fp8_activation_amax(out, 1, None) == 0
+    assert L.sfron_cast_e4m3(ctypes.c_void_p(xb.data_ptr()), 1, n, ctypes.c_float(32.0), ctypes.c_void_p(dst.data_ptr()), wp, None) == 0
+    assert L.sfron_fp8_activation_amax(wp, out, 1, None) == 0
     assert abs(out[1] - 640.0) < 1.0
-    assert L.sfron_fp8_activation_amax(out, 0, None) == 0
+    assert L.sfron_fp8_activation_amax(wp, out, 0, None) == 0
     assert out[0] == 0.0 and out[1] == 0.0 and out[2] == 0.0                     # the read above reset them
     # through the engine: a small DiT forward pass in fp8 fills all three sites; random-init activations stay inside the range
     from sfron import dit

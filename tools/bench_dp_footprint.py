@@ -52,7 +52,8 @@ def main():
     kw = dict(global_batch=32, num_classes=1000, forget_class=207)
     bt = [tuple({k: v.to(dev) for k, v in data.synthetic_batch(5, i, s, **kw).items()} for s in ("forget", "remain")) for i in range(4)]
     from sfron import streams
-    side = streams.get("comm")           # the stream the data-parallel runner puts its collectives on (step.py)
+    # the stream the data-parallel runner puts its collectives on (step.py): probed to run beside the caller's and the weight-gradient streams
+    side = streams.get("comm", beside=[torch.cuda.current_stream()] + eng.side_streams())
     nbytes = eng.n_trainable * 4 // 16 * 16
     src = torch.empty(nbytes, dtype=torch.uint8, device=dev).zero_()
     dst = torch.empty(nbytes, dtype=torch.uint8, device=dev).zero_()

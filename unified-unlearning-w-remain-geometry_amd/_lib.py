@@ -112,14 +112,14 @@ class Fp8GemmDesc(ctypes.Structure):
     _fields_ = [("A", c_void_p), ("B", c_void_p), ("M", c_int), ("N", c_int), ("K", c_int), ("w_scale", c_void_p), ("a_scale", c_float),
                 ("epilogue", c_int), ("bias", c_void_p), ("c_bf16", c_void_p), ("ldc_bf16", c_int), ("aux", c_void_p), ("ldaux", c_int),
                 ("c_e4m3", c_void_p), ("c_e4m3_scale", c_float), ("c_f32", c_void_p), ("ldc_f32", c_int), ("resid", c_void_p),
-                ("gate", c_void_p), ("ldgate", c_int), ("tokens", c_int)]
+                ("gate", c_void_p), ("ldgate", c_int), ("tokens", c_int), ("act_amax", c_void_p)]
 
 
 _PROTOS.update({
     "sfron_fp8_quant_tensors": (c_int, [_P, _P, c_int, _P, _P, _P, c_int, _S]),
     "sfron_fp8_update_scales": (c_int, [_P, c_int, _P, _S]),
-    "sfron_cast_e4m3": (c_int, [_P, c_int, c_int64, c_float, _P, _S]),
-    "sfron_ln_modulate_fwd_q": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _S]),
+    "sfron_cast_e4m3": (c_int, [_P, c_int, c_int64, c_float, _P, _P, _S]),
+    "sfron_ln_modulate_fwd_q": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _S]),
     "sfron_fp8_gemm_supported": (c_int, [c_int, c_int, c_int]),
     "sfron_fp8_gemm": (c_int, [POINTER(Fp8GemmDesc), _S]),
 })
@@ -207,16 +207,17 @@ _PROTOS.update({
     "sfron_aux_create": (c_int, [POINTER(c_void_p)]),
     "sfron_aux_destroy": (c_int, [c_void_p]),
     "sfron_aux_wait_ada_factors": (c_int, [c_void_p, c_void_p]),
+    "sfron_aux_streams": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p)]),
     "sfron_aux_set_probe": (c_int, [c_void_p, c_void_p]),
     "sfron_aux_arm_sumsq": (c_int, [c_void_p, _P, _P]),
     "sfron_aux_wait_ada": (c_int, [c_void_p, _S]),
-    "sfron_fp8_activation_amax": (c_int, [POINTER(c_float), c_int, c_void_p]),
+    "sfron_fp8_activation_amax": (c_int, [_P, POINTER(c_float), c_int, c_void_p]),
     "sfron_dit_forward_probed": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_dit_forward_after": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_dit_forward_phase": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _S]),
-    "sfron_dit_forward_fp8_phase": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, POINTER(c_float), _P, _P, _P, _P, _P, _P, _P, _P, c_int, _S]),
+    "sfron_dit_forward_fp8_phase": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, POINTER(c_float), _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _S]),
     "sfron_dit_fp8_workspace_bytes": (c_int64, [POINTER(DitCfg)]),
-    "sfron_dit_forward_fp8": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, POINTER(c_float), _P, _P, _P, _P, _P, _P, _P, _P, _S]),
+    "sfron_dit_forward_fp8": (c_int, [POINTER(DitCfg), _P, _P, _P, _P, POINTER(c_float), _P, _P, _P, _P, _P, _P, _P, _P, _P, _S]),
     "sfron_probe_create": (c_int, [c_int, POINTER(c_void_p)]),
     "sfron_probe_reset": (c_int, [c_void_p]),
     "sfron_probe_read": (c_int, [c_void_p, POINTER(c_int), POINTER(c_double)]),

@@ -300,6 +300,11 @@ int sfron_aux_wait_ada(void* aux, void* stream) {
   if (hipStreamWaitEvent((hipStream_t)stream, ((Aux*)aux)->ada_ready, 0) != hipSuccess) return (int)hipGetLastError();
   return SFRON_OK;
 }
+int sfron_aux_streams(void* aux, void** side, void** side2) {
+  SFRON_CHECK_ARG(aux && side && side2);
+  *side = (void*)((Aux*)aux)->side; *side2 = (void*)((Aux*)aux)->side2;
+  return SFRON_OK;
+}
 int sfron_aux_wait_ada_factors(void* aux, void* stream) {
   SFRON_CHECK_ARG(aux);
   if (hipStreamWaitEvent((hipStream_t)stream, ((Aux*)aux)->ada_factors, 0) != hipSuccess) return (int)hipGetLastError();
@@ -399,6 +404,7 @@ int sfron_probe_destroy(void* probe) {
 struct Fp8Ctx {
   const uint8_t* w8; const float* w_scales; float s_x, s_o, s_h;
   uint8_t *xmod8, *o8, *h8;
+  uint32_t* act_amax;            // the caller's activation-range words (sfron_fp8_activation_amax), or null
 };
 static size_t fp8_ws(const Dims& d, char* base, Fp8Ctx* f) {
   size_t o = 0;
@@ -444,25 +450,25 @@ int64_t sfron_dit_fp8_workspace_bytes(const sfron_dit_cfg* cfg) {
 }
 
 static int dit_forward_fp8_impl(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const uint8_t* params_e4m3,
-                                const float* w_scales, const float* act_scales, const float* x_t, const int64_t* t, const int64_t* y,
+                                const float* w_scales, const float* act_scales, uint32_t* act_amax, const float* x_t, const int64_t* t, const int64_t* y,
                                 const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out, void* const* block_ready, int phase,
                                 void* stream);
 int sfron_dit_forward_fp8(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const uint8_t* params_e4m3,
-                          const float* w_scales, const float* act_scales, const float* x_t, const int64_t* t, const int64_t* y,
+                          const float* w_scales, const float* act_scales, uint32_t* act_amax, const float* x_t, const int64_t* t, const int64_t* y,
                           const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out, void* const* block_ready, void* stream) {
-  return dit_forward_fp8_impl(cfg, params, params_bf16, params_e4m3, w_scales, act_scales, x_t, t, y, drop, workspace, workspace_e4m3, out,
+  return dit_forward_fp8_impl(cfg, params, params_bf16, params_e4m3, w_scales, act_scales, act_amax, x_t, t, y, drop, workspace, workspace_e4m3, out,
                               block_ready, 0, stream);
 }
 int sfron_dit_forward_fp8_phase(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const uint8_t* params_e4m3,
-                                const float* w_scales, const float* act_scales, const float* x_t, const int64_t* t, const int64_t* y,
+                                const float* w_scales, const float* act_scales, uint32_t* act_amax, const float* x_t, const int64_t* t, const int64_t* y,
                                 const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out, void* const* block_ready, int phase,
                                 void* stream) {
   SFRON_CHECK_ARG(phase == 1 || phase == 2);
-  return dit_forward_fp8_impl(cfg, params, params_bf16, params_e4m3, w_scales, act_scales, x_t, t, y, drop, workspace, workspace_e4m3, out,
+  return dit_forward_fp8_impl(cfg, params, params_bf16, params_e4m3, w_scales, act_scales, act_amax, x_t, t, y, drop, workspace, workspace_e4m3, out,
                               block_ready, phase, stream);
 }
 static int dit_forward_fp8_impl(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const uint8_t* params_e4m3,
-                                const float* w_scales, const float* act_scales, const float* x_t, const int64_t* t, const int64_t* y,
+                                const float* w_scales, const float* act_scales, uint32_t* act_amax, const float* x_t, const int64_t* t, const int64_t* y,
                                 const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out, void* const* block_ready, int phase,
                                 void* stream) {
   Dims d;
@@ -472,7 +478,7 @@ static int dit_forward_fp8_impl(const sfron_dit_cfg* cfg, const float* params, c
   if (!sfron_fp8_gemm_supported(d.M, 3 * d.D, d.D) || !sfron_fp8_gemm_supported(d.M, d.D, d.D) || !sfron_fp8_gemm_supported(d.M, d.F, d.D) ||
       !sfron_fp8_gemm_supported(d.M, d.D, d.F))
     return SFRON_ERR_UNSUPPORTED;
-  Fp8Ctx f{params_e4m3, w_scales, act_scales[0], act_scales[1], act_scales[2], nullptr, nullptr, nullptr};
+  Fp8Ctx f{params_e4m3, w_scales, act_scales[0], act_scales[1], act_scales[2], nullptr, nullptr, nullptr, act_amax};
   (void)fp8_ws(d, (char*)workspace_e4m3, &f);
   return dit_forward_impl(cfg, params, params_bf16, x_t, t, y, drop, workspace, out, nullptr, &f, stream, block_ready, phase);
 }
@@ -551,21 +557,22 @@ static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const
       auto g8 = [&](const uint8_t* A, int64_t w_off, int N, int K, const float* wsc, float asc, int epi) {
         sfron_fp8_gemm_desc q{};
         q.A = A; q.B = f8->w8 + w_off; q.M = M; q.N = N; q.K = K; q.w_scale = wsc; q.a_scale = asc; q.epilogue = epi; q.tokens = T;
+        q.act_amax = f8->act_amax;
         return q;
       };
       RUN(sfron_ln_modulate_fwd_q(x0, mod, mod + D, NM, T, M, D, (uint16_t*)xmod1, f8->xmod8, f8->s_x, w.mean + (size_t)(2 * l) * M,
-                                  w.rstd + (size_t)(2 * l) * M, stream));
+                                  w.rstd + (size_t)(2 * l) * M, f8->act_amax, stream));
       sfron_fp8_gemm_desc q = g8(f8->xmod8, pb + P.o_qkv_w, 3 * D, D, ws + 0, f8->s_x, SFRON_EPI_BF16);
       q.bias = params + pb + P.o_qkv_b; q.c_bf16 = (uint16_t*)qkv; q.ldc_bf16 = 3 * D;
       RUN(sfron_fp8_gemm(&q, stream));
       RUN(sfron_attn_fwd((const uint16_t*)qkv, (uint16_t*)o, w.lse + (size_t)l * d.B * d.H * T, d.B, T, d.H, d.hd, stream));
-      RUN(sfron_cast_e4m3(o, 1, (int64_t)M * D, f8->s_o, f8->o8, stream));
+      RUN(sfron_cast_e4m3(o, 1, (int64_t)M * D, f8->s_o, f8->o8, f8->act_amax, stream));
       q = g8(f8->o8, pb + P.o_proj_w, D, D, ws + 1, f8->s_o, SFRON_EPI_GATE_RES);
       q.bias = params + pb + P.o_proj_b; q.c_f32 = x1; q.ldc_f32 = D; q.resid = x0; q.aux = (uint16_t*)a1; q.ldaux = D;
       q.gate = mod + 2 * D; q.ldgate = NM;
       RUN(sfron_fp8_gemm(&q, stream));
       RUN(sfron_ln_modulate_fwd_q(x1, mod + 3 * D, mod + 4 * D, NM, T, M, D, (uint16_t*)xmod2, f8->xmod8, f8->s_x,
-                                  w.mean + (size_t)(2 * l + 1) * M, w.rstd + (size_t)(2 * l + 1) * M, stream));
+                                  w.mean + (size_t)(2 * l + 1) * M, w.rstd + (size_t)(2 * l + 1) * M, f8->act_amax, stream));
       q = g8(f8->xmod8, pb + P.o_fc1_w, d.F, D, ws + 2, f8->s_x, SFRON_EPI_GELU);
       q.bias = params + pb + P.o_fc1_b; q.c_bf16 = (uint16_t*)h; q.ldc_bf16 = d.F; q.aux = (uint16_t*)hpre; q.ldaux = d.F;
       q.c_e4m3 = f8->h8; q.c_e4m3_scale = f8->s_h;

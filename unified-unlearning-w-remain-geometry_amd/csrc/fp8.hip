@@ -36,18 +36,19 @@ __device__ __forceinline__ float sat8(float x) { return fminf(fmaxf(x, -E4M3_MAX
 // nothing else would tell a run on real weights that its LN + modulate outputs left the range.  Every kernel that quantises an activation
 // keeps the maximum of |x * scale| per thread (one v_max per value), a wave reduces it and ONE lane per wave raises the site's word with
 // atomicMax on the bit pattern (non-negative floats order like unsigned integers).  sfron_fp8_activation_amax reads (and resets) the three
-// words: a value above 448 means that values were clipped since the last reset.  Process-wide, like the form knobs of this file.
+// words: a value above 448 means that values were clipped since the last reset.  The three words belong to the CALLER (round 6: a device
+// array handed to every quantising entry point, NULL = no tracking; rounds 4-5 kept them in a __device__ global of the library).
 // site 0 = LN + modulate output (the A operand of qkv / fc1), 1 = sfron_cast_e4m3 (attention output -> proj), 2 = GELU output (-> fc2)
-__device__ unsigned int g_act_amax[3];
 __device__ __forceinline__ void amax4(float& m, float a, float b, float c, float d) {
   m = fmaxf(m, fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d))));
 }
-__device__ __forceinline__ void amax_report(int site, float m) {
+__device__ __forceinline__ void amax_report(unsigned int* words, int site, float m) {
+  if (!words) return;                          // kernel-uniform
   m = wave_max(m);
   // the atomic only when this wave would RAISE the word: thousands of waves hitting one address serialise in L2 (the unconditional form cost
   // config 5 six ms per step); a stale read of the word can only cause a surplus atomic, never a lost maximum
-  if ((threadIdx.x & 63) == 0 && m > __uint_as_float(__builtin_nontemporal_load(&g_act_amax[site])))
-    atomicMax(&g_act_amax[site], __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0 && m > __uint_as_float(__builtin_nontemporal_load(&words[site])))
+    atomicMax(&words[site], __float_as_uint(m));
 }
 // four fp32 -> four e4m3 bytes (little endian: a in bits 0..7)
 __device__ __forceinline__ uint32_t pack_e4m3(float a, float b, float c, float d) {
@@ -97,7 +98,7 @@ __global__ void k_fp8_update_scales(unsigned* __restrict__ amax_bits, int n, flo
   amax_bits[t] = 0u;
 }
 
-__global__ __launch_bounds__(TPB) void k_cast_e4m3_bf16(const __bf16* __restrict__ src, int64_t n, float scale, uint8_t* __restrict__ dst) {
+__global__ __launch_bounds__(TPB) void k_cast_e4m3_bf16(const __bf16* __restrict__ src, int64_t n, float scale, uint8_t* __restrict__ dst, unsigned int* amax) {
   const int64_t n8 = n >> 3;
   float am = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (int64_t)gridDim.x * TPB) {
@@ -110,9 +111,9 @@ __global__ __launch_bounds__(TPB) void k_cast_e4m3_bf16(const __bf16* __restrict
     o.y = pack_e4m3(f4, f5, f6, f7);
     reinterpret_cast<uint2*>(dst)[i] = o;
   }
-  amax_report(1, am);
+  amax_report(amax, 1, am);
 }
-__global__ __launch_bounds__(TPB) void k_cast_e4m3_f32(const float* __restrict__ src, int64_t n, float scale, uint8_t* __restrict__ dst) {
+__global__ __launch_bounds__(TPB) void k_cast_e4m3_f32(const float* __restrict__ src, int64_t n, float scale, uint8_t* __restrict__ dst, unsigned int* amax) {
   const int64_t n4 = n >> 2;
   float am = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(TPB) void k_cast_e4m3_f32(const float* __restrict__
     amax4(am, v.x * scale, v.y * scale, v.z * scale, v.w * scale);
     reinterpret_cast<uint32_t*>(dst)[i] = pack_e4m3(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
   }
-  amax_report(1, am);
+  amax_report(amax, 1, am);
 }
 
 // ---------------------------------------------------------------- LayerNorm + modulate with the e4m3 copy (norm.hip's k_ln_mod_fwd + one store)
@@ -135,7 +136,7 @@ template <int RPW>
 __global__ __launch_bounds__(TPB) void k_ln_mod_fwd_q(const float* __restrict__ x, const float* __restrict__ shift,
                                                       const float* __restrict__ scale, int ldmod, int T, int M, int D,
                                                       __bf16* __restrict__ out, uint8_t* __restrict__ out8, float s8,
-                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, unsigned int* amax) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int row0 = (blockIdx.x * 4 + wave) * RPW;
   if (row0 >= M) return;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(TPB) void k_ln_mod_fwd_q(const float* __restrict__ 
       __builtin_amdgcn_raw_buffer_store_b32(pack_e4m3(o0 * s8, o1 * s8, o2 * s8, o3 * s8), r8, lane * 4 + 256 * i, 0, 0);
     }
   }
-  amax_report(0, am);
+  amax_report(amax, 0, am);
 }
 
 // ---------------------------------------------------------------- fp8 x fp8 GEMM
@@ -202,6 +203,7 @@ struct Gemm8Args {
   uint8_t* C8; float c8_scale;            // EPI_GELU: e4m3(gelu(result) * c8_scale) -- the A operand of fc2
   float* Cf; int ldcf; const float* resid;      // EPI_GATE_RES: Cf = resid + gate * result
   const float* gate; int ldgate; int T;
+  unsigned int* act_amax;                 // the caller's activation-range words (site 2 is raised by EPI_GELU's e4m3 output), or null
 };
 enum { E8_BF16 = 0, E8_GELU = 2, E8_GATE_RES = 3 };
 
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(512 + 64 * NL) void k_gemm8(Gemm8Args g) {
       if constexpr (NT8 & 1) *reinterpret_cast<uint32_t*>(r8 + n0 + (NT8 - 1) * 16 + 4 * fg) = c8[NT8 - 1];
     }
   }
-  if constexpr (EPI == E8_GELU) amax_report(2, act_am);
+  if constexpr (EPI == E8_GELU) amax_report(g.act_amax, 2, act_am);
 }
 template __global__ void k_gemm8<E8_BF16, 8>(Gemm8Args);
 template __global__ void k_gemm8<E8_GELU, 8>(Gemm8Args);
@@ -472,6 +474,7 @@ int sfron_fp8_gemm(const sfron_fp8_gemm_desc* d, void* stream) {
   g.Cb = (__bf16*)d->c_bf16; g.ldcb = d->ldc_bf16; g.aux = (__bf16*)d->aux; g.ldaux = d->ldaux; g.C8 = d->c_e4m3; g.c8_scale = d->c_e4m3_scale;
   g.Cf = d->c_f32; g.ldcf = d->ldc_f32; g.resid = d->resid ? d->resid : d->c_f32; g.gate = d->gate; g.ldgate = d->ldgate;
   g.T = d->tokens > 0 ? d->tokens : 1;
+  g.act_amax = d->act_amax;
   hipStream_t s = (hipStream_t)stream;
   switch (d->epilogue) {
     case SFRON_EPI_BF16:
@@ -506,45 +509,41 @@ int sfron_fp8_update_scales(uint32_t* amax_bits, int n_tensors, float* scales, v
   return SFRON_OK;
 }
 
-int sfron_fp8_activation_amax(float* out3, int reset, void* stream) {
-  SFRON_CHECK_ARG(out3);
+int sfron_fp8_activation_amax(uint32_t* act_amax, float* out3, int reset, void* stream) {
+  SFRON_CHECK_ARG(act_amax && out3);
   hipStream_t s = (hipStream_t)stream;
   unsigned int bits[3] = {0u, 0u, 0u};
-  if (hipMemcpyFromSymbolAsync(bits, HIP_SYMBOL(g_act_amax), sizeof(bits), 0, hipMemcpyDeviceToHost, s) != hipSuccess) return (int)hipGetLastError();
+  if (hipMemcpyAsync(bits, act_amax, sizeof(bits), hipMemcpyDeviceToHost, s) != hipSuccess) return (int)hipGetLastError();
   if (hipStreamSynchronize(s) != hipSuccess) return (int)hipGetLastError();
   for (int i = 0; i < 3; ++i) { float f; memcpy(&f, &bits[i], sizeof(f)); out3[i] = f; }
-  if (reset) {
-    const unsigned int z[3] = {0u, 0u, 0u};
-    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_act_amax), z, sizeof(z), 0, hipMemcpyHostToDevice, s) != hipSuccess) return (int)hipGetLastError();
-    if (hipStreamSynchronize(s) != hipSuccess) return (int)hipGetLastError();
-  }
+  if (reset && hipMemsetAsync(act_amax, 0, sizeof(bits), s) != hipSuccess) return (int)hipGetLastError();
   return SFRON_OK;
 }
 
-int sfron_cast_e4m3(const void* src, int src_is_bf16, int64_t n, float scale, uint8_t* dst, void* stream) {
+int sfron_cast_e4m3(const void* src, int src_is_bf16, int64_t n, float scale, uint8_t* dst, uint32_t* act_amax, void* stream) {
   SFRON_CHECK_ARG(src && dst && n >= 0 && n % 8 == 0 && scale > 0.f && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0);
   if (src_is_bf16)
-    hipLaunchKernelGGL(k_cast_e4m3_bf16, dim3(grid_for(n >> 3)), dim3(TPB), 0, (hipStream_t)stream, (const __bf16*)src, n, scale, dst);
+    hipLaunchKernelGGL(k_cast_e4m3_bf16, dim3(grid_for(n >> 3)), dim3(TPB), 0, (hipStream_t)stream, (const __bf16*)src, n, scale, dst, act_amax);
   else
-    hipLaunchKernelGGL(k_cast_e4m3_f32, dim3(grid_for(n >> 2)), dim3(TPB), 0, (hipStream_t)stream, (const float*)src, n, scale, dst);
+    hipLaunchKernelGGL(k_cast_e4m3_f32, dim3(grid_for(n >> 2)), dim3(TPB), 0, (hipStream_t)stream, (const float*)src, n, scale, dst, act_amax);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }
 
 int sfron_ln_modulate_fwd_q(const float* x, const float* shift, const float* scale, int ldmod, int tokens, int M, int D, uint16_t* out,
-                            uint8_t* out_e4m3, float e4m3_scale, float* mean, float* rstd, void* stream) {
+                            uint8_t* out_e4m3, float e4m3_scale, float* mean, float* rstd, uint32_t* act_amax, void* stream) {
   SFRON_CHECK_ARG(x && shift && scale && out && out_e4m3 && mean && rstd && M > 0 && tokens > 0 && e4m3_scale > 0.f);
   SFRON_CHECK_ARG(D % 4 == 0 && D <= 64 * 4 * NCHQ && ldmod % 4 == 0);
   SFRON_CHECK_ARG((((uintptr_t)x | (uintptr_t)shift | (uintptr_t)scale) & 15) == 0 && ((uintptr_t)out & 7) == 0 && ((uintptr_t)out_e4m3 & 3) == 0);
   if (M >= 8192 && tokens % 4 == 0)
     hipLaunchKernelGGL(k_ln_mod_fwd_q<4>, dim3(cdiv(M, 16)), dim3(TPB), 0, (hipStream_t)stream, x, shift, scale, ldmod, tokens, M, D, (__bf16*)out,
-                     out_e4m3, e4m3_scale, mean, rstd);
+                     out_e4m3, e4m3_scale, mean, rstd, act_amax);
   else if (M >= 4096 && tokens % 2 == 0)
     hipLaunchKernelGGL(k_ln_mod_fwd_q<2>, dim3(cdiv(M, 8)), dim3(TPB), 0, (hipStream_t)stream, x, shift, scale, ldmod, tokens, M, D, (__bf16*)out,
-                     out_e4m3, e4m3_scale, mean, rstd);
+                     out_e4m3, e4m3_scale, mean, rstd, act_amax);
   else
     hipLaunchKernelGGL(k_ln_mod_fwd_q<1>, dim3(cdiv(M, 4)), dim3(TPB), 0, (hipStream_t)stream, x, shift, scale, ldmod, tokens, M, D, (__bf16*)out,
-                     out_e4m3, e4m3_scale, mean, rstd);
+                     out_e4m3, e4m3_scale, mean, rstd, act_amax);
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

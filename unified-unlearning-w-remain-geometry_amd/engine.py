@@ -173,6 +173,8 @@ class DitEngine:
             w8=torch.zeros(self.n_total, dtype=torch.uint8, device=self.device),
             scales=torch.ones(len(rows), dtype=torch.float32, device=self.device),
             amax=torch.zeros(len(rows), dtype=torch.int32, device=self.device),
+            # this engine's activation-range words (three uint32 the quantising kernels raise with atomicMax: fp8_activation_range)
+            act_amax=torch.zeros(3, dtype=torch.int32, device=self.device),
             ws=torch.empty(ws, dtype=torch.uint8, device=self.device))
         self.fp8_requantize(fresh=True)
         return self
@@ -181,9 +183,10 @@ class DitEngine:
         """How much of the e4m3 range the activations used since the last reset (the activation scales are static and the conversion
         saturates silently): dict site -> max |x * scale| / 448 for the LayerNorm+modulate outputs, the attention output and gelu(fc1), plus
         ``saturated`` (any site above 1: values were clipped -- raise the matching entry of FP8_ACT_SCALES' divisor, i.e. pass a smaller
-        scale to enable_fp8(act_scales=...)).  Process-wide counters (include/sfron.h sfron_fp8_activation_amax); synchronises the stream."""
+        scale to enable_fp8(act_scales=...)).  The counters are this engine's own (round 6: a device array handed to every quantising launch,
+        include/sfron.h sfron_fp8_activation_amax; engines that share a shadow -- a sibling() -- share them); synchronises the stream."""
         out = (ctypes.c_float * 3)()
-        check(_lib.lib().sfron_fp8_activation_amax(out, int(bool(reset)), stream_ptr()), "fp8_activation_amax")
+        check(_lib.lib().sfron_fp8_activation_amax(ptr(self.fp8["act_amax"]), out, int(bool(reset)), stream_ptr()), "fp8_activation_amax")
         r = {"ln_modulate": out[0] / 448.0, "attention_out": out[1] / 448.0, "gelu": out[2] / 448.0}
         r["saturated"] = any(v > 1.0 for v in r.values())
         return r
@@ -222,7 +225,8 @@ class DitEngine:
         if getattr(self, "_bs", None) is None:
             L, lay = self.cfg.depth, self.layout
             evs = [torch.cuda.Event(enable_timing=False) for _ in range(L)]
-            st = streams.get("sweep", self.device)          # process-wide: see streams.py
+            # process-wide, probed to run beside the caller's stream (the pass it overlaps) and the weight-gradient streams: see streams.py
+            st = streams.get("sweep", self.device, beside=[torch.cuda.current_stream()] + self.side_streams())
             for e in evs:
                 e.record(st)
             self._bs = dict(ranges=[(lay["blocks"] + l * lay["blk_stride"], lay["blocks"] + (l + 1) * lay["blk_stride"]) for l in range(L)],
@@ -268,7 +272,7 @@ class DitEngine:
                           "dit_forward_phase")
                 else:
                     check(L.sfron_dit_forward_fp8_phase(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(f["w8"]),
-                                                        ptr(f["scales"]), f["act"], ptr(x_t), ptr(t), ptr(y), ptr(drop), ptr(self.workspace),
+                                                        ptr(f["scales"]), f["act"], ptr(f["act_amax"]), ptr(x_t), ptr(t), ptr(y), ptr(drop), ptr(self.workspace),
                                                         ptr(f["ws"]), ptr(out), block_ready, phase, stream_ptr()), "dit_forward_fp8_phase")
                 if phase == 1:
                     between()
@@ -281,7 +285,7 @@ class DitEngine:
         if getattr(self, "fp8", None) is not None:
             f = self.fp8
             check(_lib.lib().sfron_dit_forward_fp8(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(f["w8"]),
-                                                   ptr(f["scales"]), f["act"], ptr(x_t), ptr(t), ptr(y), ptr(drop), ptr(self.workspace),
+                                                   ptr(f["scales"]), f["act"], ptr(f["act_amax"]), ptr(x_t), ptr(t), ptr(y), ptr(drop), ptr(self.workspace),
                                                    ptr(f["ws"]), ptr(out), block_ready, stream_ptr()), "dit_forward_fp8")
             return out
         check(_lib.lib().sfron_dit_forward_probed(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(x_t),
@@ -353,12 +357,21 @@ class DitEngine:
                                                ptr(drop), ptr(self.workspace), ptr(self.grads), self.aux, None, None, ptr(dmod), ptr(sc),
                                                stream_ptr()), "dit_backward (factored adaLN gradient)")
         return dict(lo=self.layout["ada_w"], NM=dmod.shape[1], D=self.cfg.hidden, dmod=dmod, sc=sc, R=self.cfg.batch, wait=self.ada_wait,
-                    wait_factors=self.ada_wait_factors)
+                    wait_factors=self.ada_wait_factors, beside=self.side_streams())
 
     def ada_wait(self, stream):
         """Order ``stream`` (a torch stream) behind the point of the last backward pass after which nothing reads the adaLN matrix and its two
         gradient factors are complete (sfron_aux_wait_ada): what is left of the pass then is the embedders' backward."""
         check(_lib.lib().sfron_aux_wait_ada(self.aux, ctypes.c_void_p(stream.cuda_stream)), "aux_wait_ada")
+
+    def side_streams(self):
+        """The library's two weight-gradient streams of this engine as torch streams (read-only use: what a caller's own side stream must
+        not share a hardware queue with -- streams.py)."""
+        if getattr(self, "_side_streams", None) is None:
+            a, b = ctypes.c_void_p(), ctypes.c_void_p()
+            check(_lib.lib().sfron_aux_streams(self.aux, ctypes.byref(a), ctypes.byref(b)), "aux_streams")
+            self._side_streams = [torch.cuda.ExternalStream(a.value, device=self.device), torch.cuda.ExternalStream(b.value, device=self.device)]
+        return list(self._side_streams)
 
     def ada_wait_factors(self, stream):
         """Order ``stream`` behind the point of the last backward_factored_ada pass at which the two gradient factors are complete

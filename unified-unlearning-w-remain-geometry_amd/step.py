@@ -156,7 +156,7 @@ class DiTSFRon:
         stage -- their AdamW + EMA run while the later buckets are still on the links.  Same collectives in the same order on
         every rank."""
         if self._comm is None:
-            self._comm = streams.get("comm")
+            self._comm = streams.get("comm", beside=[torch.cuda.current_stream()] + self.model.engine.side_streams())
         g = self.model.engine.grads
         cur = torch.cuda.current_stream()
         self._comm.wait_stream(cur)
@@ -225,7 +225,7 @@ class DiTSFRon:
         eng = self.model.engine
         evs = eng.dp_setup()
         if self._comm is None:
-            self._comm = streams.get("comm")
+            self._comm = streams.get("comm", beside=[torch.cuda.current_stream()] + self.model.engine.side_streams())
         main = torch.cuda.current_stream()
         eng.backward_dp(d_out, y, drop)
         for l in reversed(range(len(evs))):

@@ -1,27 +1,91 @@
-"""Process-wide named side streams, one set per device.
+"""Process-wide named side streams, one set per device, each PROBED to run beside the streams it must not serialise with.
 
 Every runner of this package overlaps work on a handful of extra streams (the optimizer sweep beside the next forward pass, the clip
-norm's adaLN share beside the embedders' backward, the gradient exchange, the two micro-batch chains).  The HIP runtime maps streams onto
-a few hardware queues; two streams of one step that land on the same queue serialise.  When each runner took fresh streams
-(``torch.cuda.Stream()`` hands out the next entry of torch's 32-stream pool), the THIRD runner of a process -- bench.py's configuration
-legs, a test session -- could end up with a colliding pair and ran measurably slower than the same runner in a fresh process
-(profiles/r06_fp8_leg.txt: DiT-XL/2 fp8 63.8 ms / step as the third runner, 59.3 as the first; DiT-B/4 10.1 against 9.2).  So the streams
-are taken ONCE per (device, name) and every runner reuses them -- a later runner sees what the first one saw.  Runners of one process run
-one after another; two engines that do run concurrently (micro-batch chains) ask for different names.  The library's own two
-weight-gradient streams follow the same rule (csrc/dit_engine.hip: free list in sfron_aux_create / _destroy).
+norm's adaLN share beside the embedders' backward, the gradient exchange beside the backward pass, the two micro-batch chains).  The HIP
+runtime maps streams onto FOUR hardware queues (per priority); two streams on one queue serialise, whatever events say.  Two failures of
+"take the next torch.cuda.Stream()" were measured in round 6:
+  * the THIRD runner of a process (bench.py's configuration legs) got a colliding pair and ran 4 ms / step slower than the same runner in a
+    fresh process (profiles/r06_fp8_leg.txt) -- so a named stream is taken ONCE per (device, name) and every runner reuses it;
+  * the data-parallel exchange stream landed on the hardware queue of the engine's second weight-gradient stream: a stand-in for the
+    exchange's footprint slowed the step by exactly its own duration, i.e. the "overlapped" exchange did not overlap at all
+    (profiles/r06_hw_queues.txt) -- so a named stream is CHOSEN by a probe: a spin kernel on the candidate and one on each stream it has to
+    run beside; if the pair takes about one spin the queues are independent, about two and they are shared.  (Raising the runtime's queue
+    count instead, GPU_MAX_HW_QUEUES = 8, makes the headline step 14 ms slower.)
+The library's own two weight-gradient streams follow the reuse rule too (csrc/dit_engine.hip: free list in sfron_aux_create / _destroy).
 """
+import time
+
 import torch
 
 _streams = {}
+_probed = set()            # keys of streams that were chosen by the probe (candidates for later names)
+_SPIN = 400_000            # cycles per probe kernel (~0.2 ms): long against a launch, short against everything else
+_CANDIDATES = 12
 
 
-def get(name, device=None):
-    """The process-wide stream ``name`` of ``device`` (default: the current device), created on first use."""
+def _spin_pair_ms(a, b):
+    """Wall time of one spin kernel on ``a`` and one on ``b`` launched back to back (min of 3), in ms."""
+    best = None
+    for _ in range(3):
+        a.synchronize(); b.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(_SPIN)
+        with torch.cuda.stream(b):
+            torch.cuda._sleep(_SPIN)
+        a.synchronize(); b.synchronize()
+        dt = (time.perf_counter() - t0) * 1e3
+        best = dt if best is None else min(best, dt)
+    return best
+
+
+def runs_beside(cand, others):
+    """True if a spin on ``cand`` overlaps a spin on each of ``others`` (independent hardware queues)."""
+    if not others:
+        return True
+    one = _spin_pair_ms(cand, cand) / 2.0            # two spins on ONE stream are serial by definition: half of it is one spin
+    for o in others:
+        if o is None or o.cuda_stream == cand.cuda_stream:
+            return False
+        if _spin_pair_ms(cand, o) > 1.5 * one:
+            return False
+    return True
+
+
+def get(name, device=None, beside=()):
+    """The process-wide stream ``name`` of ``device`` (default: the current device).  On first use a stream is chosen that runs beside every
+    stream in ``beside`` (torch streams; None entries ignored) -- the first of up to 12 candidates that passes the probe, else the last one
+    tried -- and the choice is kept for the life of the process.  A stream already chosen under another name is a candidate again: names
+    whose work never overlaps in time (the beside-forward sweep, the clip norm's adaLN share, the gradient exchange) may end up on ONE stream
+    when the queues are taken -- which is what four hardware queues and three busy streams leave."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
     key = (dev.index, name)
     st = _streams.get(key)
-    if st is None:
-        st = _streams[key] = torch.cuda.Stream(device=dev)
+    if st is not None:
+        return st
+    beside = [s for s in beside if s is not None]
+    with torch.cuda.device(dev):
+        if not beside:                                   # nothing to run beside (the micro-batch chains): a stream of its own
+            st = torch.cuda.Stream(device=dev)
+        else:
+            cands = []                                   # streams that already passed a probe first (distinct ones)
+            for k, s in _streams.items():
+                if k[0] == dev.index and k in _probed and all(s.cuda_stream != c.cuda_stream for c in cands):
+                    cands.append(s)
+            st = None
+            for i in range(_CANDIDATES):
+                c = cands[i] if i < len(cands) else torch.cuda.Stream(device=dev)
+                st = c
+                if runs_beside(c, beside):
+                    break
+    if beside:
+        _probed.add(key)
+    _streams[key] = st
     return st
+
+
+def describe():
+    """{(device index, name): stream pointer} of what has been chosen so far (bench.py prints it)."""
+    return {f"{d}:{n}": int(s.cuda_stream) for (d, n), s in _streams.items()}

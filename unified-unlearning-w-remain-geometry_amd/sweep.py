@@ -85,7 +85,9 @@ class FlatAdam:
         if not self.early_ada or wait is None:
             return None
         if self._ada_stream is None:
-            self._ada_stream = streams.get("ada", self.p.device)       # process-wide: see streams.py
+            import torch as _t
+            # process-wide, probed to run beside the caller's stream and the engine's weight-gradient streams: see streams.py
+            self._ada_stream = streams.get("ada", self.p.device, beside=[_t.cuda.current_stream()] + list(q.get("beside", ())))
         wait(self._ada_stream)
         return self._ada_stream
 
