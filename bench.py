@@ -9,7 +9,7 @@ remain fwd/bwd -> AdamW, EMA; synthetic latents / labels / timesteps / noise alr
 Weak scaling: every rank runs batch 32 (global batch 32*N), gradients SUM-all-reduced over RCCL; "value" counts the batch-32 steps
 of ALL ranks per second (N x the iteration rate), "ms_per_step" is the wall time of one synchronous iteration.
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline"     -- the kernel with the largest share of GPU time (profiles/r05_kernel_table.md): the weight-gradient GEMM
+  "roofline"     -- the kernel with the largest share of GPU time (profiles/r06_kernel_table.md): the weight-gradient GEMM
                     (one kernel for the four products dW = dY^T X of a block), timed live with HIP event pairs recorded on the
                     weight-gradient stream it is launched on (all four GEMMs of every 9th block of every backward pass inside
                     the timed region); "others" holds the same measurement for the fc1 forward GEMM (main stream) and an "hbm"
@@ -495,7 +495,7 @@ def main():
     step_flops = 6.0 * fwd_per_sample * args.batch
     ms_per_step = elapsed / args.steps * 1e3
 
-    # dominant kernel by GPU time (profiles/r05_kernel_table.md): the weight-gradient GEMM k_gemm_pipe<4,2,3,6,true,true,1,2,2>, one
+    # dominant kernel by GPU time (profiles/r06_kernel_table.md): the weight-gradient GEMM k_gemm_pipe<4,2,3,6,true,true,1,2,2>, one
     # kernel name for the four shapes dW = dY^T X of a block (qkv 65.2, proj 21.7, fc1 87.0, fc2 87.0 GFLOP): the probe brackets all
     # four, so the mean launch does their mean
     wg_flops = 0.25 * (2.0 * M * 3 * D * D + 2.0 * M * D * D + 2 * 2.0 * M * F * D)
@@ -523,12 +523,12 @@ def main():
             if j.get("csrc_sha") == tree_sha:
                 return j.get(key)
         return None
-    traffic = committed_traffic("r05_wgrad_traffic.json")
+    traffic = committed_traffic("r06_wgrad_traffic.json")
 
     def sane_sweep_traffic():
         """the committed PMC figure of all sweeps of a step, or None with the reason when it cannot be true: scaled to the remain-stage
         sweep timed above it must not imply more than the HBM peak (round 3's figure did: its tool divided by the wrong step count)"""
-        tr, alg = committed_traffic("r05_sweep_traffic.json", "traffic_bytes_per_step"), committed_traffic("r05_sweep_traffic.json", "algorithmic_bytes_per_step")
+        tr, alg = committed_traffic("r06_sweep_traffic.json", "traffic_bytes_per_step"), committed_traffic("r06_sweep_traffic.json", "algorithmic_bytes_per_step")
         if tr is None or alg is None or sw_ach is None:
             return tr, alg, None
         implied = tr / alg * sw_ach
@@ -593,7 +593,7 @@ def main():
                          "kernel": "k_gemm_pipe<4,2,3,6,true,true,1,2,2,false,4> = 192x192 tile, three LDS slots, eight multiplying waves + four loader waves "
                                    "that issue the LDS-DMA: the weight "
                                    f"gradients dW = dY^T X of a block (qkv [{3 * D}x{D}], proj [{D}x{D}], fc1 [{F}x{D}], fc2 [{D}x{F}], contraction over "
-                                   f"{M} token rows; mean {wg_flops / 1e9:.1f} GFLOP per launch); largest share of GPU time (profiles/r05_kernel_table.md); "
+                                   f"{M} token rows; mean {wg_flops / 1e9:.1f} GFLOP per launch); largest share of GPU time (profiles/r06_kernel_table.md); "
                                    "it runs on the weight-gradient stream BESIDE the dgrad chain, so its duration is shared-CU time",
                          "achieved": wg_ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": wg_ach / MFMA_BF16_PEAK_TFLOPS,
                          "traffic": traffic, "flops_per_launch": wg_flops, "avg_launch_ms": wg_ms, "launches_timed": n_wp,
@@ -601,7 +601,7 @@ def main():
                              "fwd_fc1_gelu": {"bound": "mfma", "kernel": f"k_gemm_pipe<4,2,4,6,false,false,2,1,2>: Mlp.fc1 + GELU-tanh [{M}x{D}]x[{D}x{F}], block 0 of "
                                               "every forward pass (main stream, nothing beside it; not launched by the fp8 path)", "achieved": achieved if n_probe else None,
                                               "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": (achieved / MFMA_BF16_PEAK_TFLOPS) if n_probe else None,
-                                              "traffic": committed_traffic("r05_fc1_traffic.json") if n_probe else None,
+                                              "traffic": committed_traffic("r06_fc1_traffic.json") if n_probe else None,
                                               "flops_per_launch": fc1_flops, "avg_launch_ms": avg_ms, "launches_timed": n_probe},
                              "hbm": {"bound": "hbm", "kernel": "remain-stage parameter sweep: k_masked_clip_adam (AdamW + EMA + bf16 shadow, 38 B/param) over the flat arenas "
                                      "+ k_adam_lowrank over the adaLN matrix (gradient formed from its two factors: 34 B/param)", "achieved": sw_ach, "peak": HBM_PEAK_GBS,
