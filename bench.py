@@ -416,6 +416,11 @@ def main():
         _lib.lib().sfron_attn_fwd_form(int(os.environ["SFRON_BENCH_ATTN_FWD"]))
     if os.environ.get("SFRON_BENCH_EARLY_ADA"):             # A-B knob (tools only): 0 = the adaLN matrix's share of the clip norm on the caller's stream
         runner.opt.early_ada = os.environ["SFRON_BENCH_EARLY_ADA"] != "0"
+    if os.environ.get("SFRON_BENCH_ZERO_WS"):               # timing experiments with builds that skip a store: the workspace starts as finite numbers
+        model.engine.workspace.zero_()
+    if os.environ.get("SFRON_BENCH_SWEEP_PRIORITY"):        # A-B knob (tools only): torch stream priority of the beside-forward sweep stream
+        from sfron import streams as _st
+        _st.PRIORITY["sweep"] = int(os.environ["SFRON_BENCH_SWEEP_PRIORITY"])
     if os.environ.get("SFRON_BENCH_DEFER_SWEEP"):           # A-B knob (tools only): 0 = start the beside-forward sweep before the pass's prologue (round 5)
         runner.defer_sweep_launch = os.environ["SFRON_BENCH_DEFER_SWEEP"] != "0"
     if os.environ.get("SFRON_BENCH_SWEEP_BESIDE"):          # tuning knob (tools only): "workgroups,head"

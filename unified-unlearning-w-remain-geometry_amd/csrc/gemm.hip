@@ -1507,12 +1507,14 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
 #pragma unroll
         for (int np = 0; np < NP; ++np) *reinterpret_cast<uint4*>(crow + col_p + np * 32) = pair_pack(ob[2 * np], ob[2 * np + 1]);
         if constexpr (NT & 1) *reinterpret_cast<bf16x4*>(crow + col_b + (NT - 1) * 16) = ob[NT - 1];
+#ifndef SFRON_TUNE_NO_HPRE_STORE          // timing experiment only (tools/build_variant.sh; wrong gradients): what would fc1 cost without its second output?
         if constexpr (EPI == EPI_GELU) {
           __bf16* const arow = g.aux + (size_t)row * g.ldaux;
 #pragma unroll
           for (int np = 0; np < NP; ++np) *reinterpret_cast<uint4*>(arow + col_p + np * 32) = pair_pack(hb[2 * np], hb[2 * np + 1]);
           if constexpr (NT & 1) *reinterpret_cast<bf16x4*>(arow + col_b + (NT - 1) * 16) = hb[NT - 1];
         }
+#endif
       }
     }
   } else {

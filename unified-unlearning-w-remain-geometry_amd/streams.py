@@ -52,6 +52,9 @@ def runs_beside(cand, others):
     return True
 
 
+PRIORITY = {}              # name -> torch stream priority for streams created under that name (A-B knob of the tools; empty = default)
+
+
 def get(name, device=None, beside=()):
     """The process-wide stream ``name`` of ``device`` (default: the current device).  On first use a stream is chosen that runs beside every
     stream in ``beside`` (torch streams; None entries ignored) -- the first of up to 12 candidates that passes the probe, else the last one
@@ -67,8 +70,9 @@ def get(name, device=None, beside=()):
         return st
     beside = [s for s in beside if s is not None]
     with torch.cuda.device(dev):
+        mk = lambda: torch.cuda.Stream(device=dev, priority=PRIORITY[name]) if name in PRIORITY else torch.cuda.Stream(device=dev)
         if not beside:                                   # nothing to run beside (the micro-batch chains): a stream of its own
-            st = torch.cuda.Stream(device=dev)
+            st = mk()
         else:
             cands = []                                   # streams that already passed a probe first (distinct ones)
             for k, s in _streams.items():
@@ -76,7 +80,7 @@ def get(name, device=None, beside=()):
                     cands.append(s)
             st = None
             for i in range(_CANDIDATES):
-                c = cands[i] if i < len(cands) else torch.cuda.Stream(device=dev)
+                c = cands[i] if (i < len(cands) and name not in PRIORITY) else mk()
                 st = c
                 if runs_beside(c, beside):
                     break
