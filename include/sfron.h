@@ -14,9 +14,13 @@
  * State: every tensor, workspace, stream and event belongs to the caller or to a handle the caller creates (sfron_aux_create,
  * sfron_probe_create); entry points are re-entrant per stream.  Process-wide state is limited to (a) three SCHEDULE switches --
  * sfron_gemm_loader_waves, sfron_attn_fwd_form, sfron_attn_bwd_form: each picks between schedules that give the same bits (the tests
- * compare them), so no result depends on them; not thread-safe, meant for tests and A-B timing -- and (b) the fp8 activation-range
- * counters behind sfron_fp8_activation_amax (diagnostic: written by the config-5 quantising kernels, read by no kernel; engines of one
- * process share them).  One host thread per device drives the library.
+ * compare them), so no result depends on them (sfron_attn_bwd_form: the same values to fp32 rounding); not thread-safe, meant for tests
+ * and A-B timing -- and (b) since ABI 15 a per-device FREE LIST of weight-gradient stream pairs: sfron_aux_destroy returns a handle's two HIP
+ * streams to it (drained) and the next sfron_aux_create on that device takes them instead of creating new ones, so that a process that builds
+ * one engine after another keeps running on the same streams (the runtime maps streams onto four hardware queues; a later handle with fresh
+ * streams can land on a queue another stream of the step uses: measured 4 ms per step, profiles/r06_fp8_leg.txt).  Two live handles never
+ * share a pair.  The fp8 activation-range counters (rounds 4-5: a __device__ global) are a caller-owned device array since ABI 15
+ * (sfron_fp8_activation_amax).  One host thread per device drives the library.
  */
 #ifndef SFRON_H
 #define SFRON_H
