@@ -177,7 +177,15 @@ enum {
   SFRON_EPI_GATE_RES = 3, /* aux = bf16(result); c_f32[row,col] = resid[row,col] + gate[row/tokens, col] * result
                              -- x = x + gate * branch(x)  (DiT/models.py:120-121)                          */
   SFRON_EPI_DGELU = 4,    /* c_bf16 = result * gelu_tanh'(aux)                           -- fc2 dgrad + act' */
-  SFRON_EPI_POS = 5       /* c_f32 = result + pos[row % tokens, col]    -- x_embedder(x) + pos_embed (:240) */
+  SFRON_EPI_POS = 5,      /* c_f32 = result + pos[row % tokens, col]    -- x_embedder(x) + pos_embed (:240) */
+  /* Round 6: the GELU pair with `aux` = gelu_tanh'(result) as ONE BYTE per element instead of the bf16 pre-activation: `aux` then points to a
+   * uint8 [M][ldaux] array, code = round((g' + 0.15) * 196), g' = code / 196 - 0.15 (GELU'_tanh lies in [-0.129, 1.129]; step 0.0051, i.e.
+   * <= 0.0026 absolute -- the size of what the bf16 rounding of the pre-activation does to GELU').  fc1 writes 113 instead of 151 MB per
+   * block at DiT-XL/2, the fc2 dgrad reads half as much and evaluates no exp.  Only where sfron_gemm_gelu_q_supported(M, N, K) (the 256 x 192
+   * pipelined tile: M % 256 == 0, N % 192 == 0, K % 128 == 0, ldc_bf16 % 8 == 0, ldaux % 8 == 0), otherwise SFRON_ERR_UNSUPPORTED; a forward
+   * pass that wrote codes must be followed by the _Q dgrad (the two arrays are not interchangeable). */
+  SFRON_EPI_GELU_Q = 7,   /* aux(u8) = code(gelu_tanh'(result)), c_bf16 = gelu_tanh(result)          -- Mlp.fc1+act */
+  SFRON_EPI_DGELU_Q = 8   /* c_bf16 = result * decode(aux(u8))                                 -- fc2 dgrad + act' */
 };
 typedef struct sfron_gemm_desc {
   const uint16_t* A; const uint16_t* B;
@@ -219,6 +227,7 @@ int sfron_gemm_bf16(const sfron_gemm_desc* desc /* HOST pointer */, void* stream
 /* number of partial rows an EPI_DGELU product of this shape writes to col_partials (M / 256), 0 = shape unsupported: use sfron_colsum */
 int sfron_gemm_dgelu_colpart_rows(int M, int N, int K);
 /* 1 when a weight-gradient GEMM dW[M][N] = dY[K][M]^T X[K][N] of this shape can also produce a_rowsum (else use sfron_colsum) */
+int sfron_gemm_gelu_q_supported(int M, int N, int K);     /* 1 = SFRON_EPI_GELU_Q / _DGELU_Q take this (rows, hidden, contraction) shape */
 int sfron_gemm_rowsum_supported(int M, int N, int K);
 /* Finish of a split-K product (sfron_gemm_desc.split_k > 1 leaves n_splits fp32 slabs, split_stride elements apart): the slabs summed in index
  * order (bitwise reproducible) and written (a) as bf16 [n] -- an input gradient that the next product reads as its operand (autograd of the
@@ -286,6 +295,9 @@ typedef struct sfron_fp8_gemm_desc {
   int tokens;
   uint32_t* act_amax;                /* DEVICE uint32 [3] or NULL: the caller's activation-range words (sfron_fp8_activation_amax); the e4m3
                                         GELU output (c_e4m3) raises word 2 */
+  int aux_q;                         /* SFRON_EPI_GELU only, 1 = `aux` receives gelu_tanh'(result) as one byte per element (uint8 [M][ldaux],
+                                        the code of SFRON_EPI_GELU_Q) instead of the bf16 pre-activation: for a backward pass on
+                                        SFRON_EPI_DGELU_Q */
 } sfron_fp8_gemm_desc;
 int sfron_fp8_gemm_supported(int M, int N, int K);
 int sfron_fp8_gemm(const sfron_fp8_gemm_desc* desc /* HOST pointer */, void* stream);

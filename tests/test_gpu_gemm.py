@@ -122,6 +122,60 @@ def test_epilogues():
     np.testing.assert_allclose(xo.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("M,F,D", [(512, 384, 256), (1024, 4608, 1152), (2048, 3072, 768)])
+def test_gelu_pair_with_the_derivative_as_one_byte(M, F, D):
+    """Round 6: SFRON_EPI_GELU_Q / SFRON_EPI_DGELU_Q (include/sfron.h) -- fc1 + GELU whose second output is gelu_tanh'(pre-activation) as ONE
+    byte per element, code = round((g' + 0.15) * 196), and the fc2 dgrad that multiplies by the decoded byte.
+      * the GELU output is bit-identical to SFRON_EPI_GELU's (same operations on the same accumulators);
+      * every code decodes to within one half step (0.0026) + fp32 noise of gelu_tanh'(fp32 pre-activation);
+      * the dgrad against torch autograd on the fp32 pre-activation: the same bound as the bf16-pre-activation form states in
+        test_fused_epilogues, and against that form on the same inputs far inside it;
+      * the dgrad's column partials (fc1.bias gradient) are offered as for SFRON_EPI_DGELU;
+      * shapes off the 256 x 192 pipelined tile are refused, not mis-computed."""
+    import torch.nn.functional as Fn
+    from sfron import _lib, ops
+    from sfron._lib import SfronError
+    L = _lib.lib()
+    assert L.sfron_gemm_gelu_q_supported(M, F, D) == 1 and L.sfron_gemm_gelu_q_supported(128, F, D) == 0 and L.sfron_gemm_gelu_q_supported(M, F + 64, D) == 0
+    gen = torch.Generator().manual_seed(M + F)
+    X, W1 = _rand((M, D), gen).to(DEV), _rand((F, D), gen, 0.06).to(DEV)
+    b1 = (torch.randn(F, generator=gen) * 0.2).to(DEV)
+    pre = X.float() @ W1.float().t() + b1                                    # fp32 pre-activation (what the accumulators hold)
+    H0, aux0 = torch.empty(M, F, dtype=torch.bfloat16, device=DEV), torch.empty(M, F, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(X, W1, M, F, D, epilogue=_lib.EPI_GELU, bias=b1, c_bf16=H0, aux=aux0)
+    H1, codes = torch.empty(M, F, dtype=torch.bfloat16, device=DEV), torch.full((M, F), 255, dtype=torch.uint8, device=DEV)
+    ops.gemm(X, W1, M, F, D, epilogue=_lib.EPI_GELU_Q, bias=b1, c_bf16=H1, aux=codes)
+    torch.cuda.synchronize()
+    assert torch.equal(H0, H1)
+    p64 = pre.double().requires_grad_(True)
+    Fn.gelu(p64, approximate="tanh").sum().backward()
+    gprime = p64.grad.float()
+    dec = codes.float() / 196.0 - 0.15
+    assert int(codes.max()) <= 251 and float((dec - gprime).abs().max()) < 0.5 / 196.0 + 2e-4
+    # backward: dX = (dY W2) * gelu'(pre)
+    dY, W2 = _rand((M, D), gen, 0.1).to(DEV), _rand((D, F), gen, 0.06).to(DEV)
+    want = (dY.float() @ W2.float()) * gprime
+    dq = torch.empty(M, F, dtype=torch.bfloat16, device=DEV)
+    rows = L.sfron_gemm_dgelu_colpart_rows(M, F, D)
+    part = torch.zeros(max(rows, 1), F, dtype=torch.float32, device=DEV)
+    ops.gemm(dY, W2, M, F, D, b_t=True, epilogue=_lib.EPI_DGELU_Q, c_bf16=dq, aux=codes, col_partials=part if rows else None)
+    d0 = torch.empty(M, F, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(dY, W2, M, F, D, b_t=True, epilogue=_lib.EPI_DGELU, c_bf16=d0, aux=aux0)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dq.float().cpu().numpy(), want.cpu().numpy(), rtol=1e-2, atol=2e-3)
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
+    print(f"dgrad with one-byte GELU' [{M}x{F}x{D}]: rel-L2 vs fp32 autograd {rel(dq, want):.2e} (bf16 pre-activation form {rel(d0, want):.2e}); "
+          f"the two forms differ by {rel(dq, d0):.2e}")
+    assert rel(dq, want) < 6e-3 and rel(dq, d0) < 6e-3
+    if rows:
+        np.testing.assert_allclose(part.sum(0).cpu().numpy(), want.sum(0).cpu().numpy(), rtol=2e-2, atol=2e-2 * float(want.abs().sum(0).mean()))
+    for bad in (dict(M=128), dict(F=F + 64)):
+        m2, f2 = bad.get("M", M), bad.get("F", F)
+        with pytest.raises(SfronError):
+            ops.gemm(X[:m2], _rand((f2, D), gen, 0.06).to(DEV), m2, f2, D, epilogue=_lib.EPI_GELU_Q, bias=None,
+                     c_bf16=torch.empty(m2, f2, dtype=torch.bfloat16, device=DEV), aux=torch.empty(m2, f2, dtype=torch.uint8, device=DEV))
+
+
 def test_gemm_rejects_bad_args():
     from sfron import ops, _lib
     A = torch.zeros(128, 60, dtype=torch.bfloat16, device=DEV)

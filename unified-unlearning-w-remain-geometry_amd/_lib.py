@@ -65,9 +65,11 @@ class GemmDesc(ctypes.Structure):
 
 
 EPI_BF16, EPI_F32, EPI_GELU, EPI_GATE_RES, EPI_DGELU, EPI_POS = range(6)
+EPI_GELU_Q, EPI_DGELU_Q = 7, 8          # round 6: GELU' as one byte per element (include/sfron.h)
 
 _PROTOS["sfron_gemm_bf16"] = (c_int, [POINTER(GemmDesc), _S])
 _PROTOS["sfron_gemm_rowsum_supported"] = (c_int, [c_int, c_int, c_int])
+_PROTOS["sfron_gemm_gelu_q_supported"] = (c_int, [c_int, c_int, c_int])
 _PROTOS["sfron_gemm_sumsq_partials"] = (c_int, [c_int, c_int, c_int])
 _PROTOS["sfron_split_sum_bf16"] = (c_int, [_P, c_int, c_int64, c_int64, _P, _S])
 _PROTOS["sfron_split_gate_res"] = (c_int, [_P, c_int, c_int64, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int, _S])
@@ -112,7 +114,7 @@ class Fp8GemmDesc(ctypes.Structure):
     _fields_ = [("A", c_void_p), ("B", c_void_p), ("M", c_int), ("N", c_int), ("K", c_int), ("w_scale", c_void_p), ("a_scale", c_float),
                 ("epilogue", c_int), ("bias", c_void_p), ("c_bf16", c_void_p), ("ldc_bf16", c_int), ("aux", c_void_p), ("ldaux", c_int),
                 ("c_e4m3", c_void_p), ("c_e4m3_scale", c_float), ("c_f32", c_void_p), ("ldc_f32", c_int), ("resid", c_void_p),
-                ("gate", c_void_p), ("ldgate", c_int), ("tokens", c_int), ("act_amax", c_void_p)]
+                ("gate", c_void_p), ("ldgate", c_int), ("tokens", c_int), ("act_amax", c_void_p), ("aux_q", c_int)]
 
 
 _PROTOS.update({

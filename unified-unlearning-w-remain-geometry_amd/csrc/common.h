@@ -109,6 +109,37 @@ __device__ __forceinline__ f32x4 gelu_tanh_grad4(f32x4 x) {
   const f32x4 du2 = __builtin_elementwise_fma(t, splat4(6.0f * k0 * k1), splat4(2.0f * k0));
   return __builtin_elementwise_fma((x * s) * (e * s), du2, s);
 }
+// GELU and its derivative from ONE exp / rcp pair (operation for operation gelu_tanh4 and gelu_tanh_grad4: the same bits as either alone).
+__device__ __forceinline__ void gelu_tanh_both4(f32x4 x, f32x4& y, f32x4& dy) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  const float c0 = -2.0f * 1.4426950408889634f * k0, c1 = c0 * k1;
+  const f32x4 t = x * x;
+  const f32x4 a = x * __builtin_elementwise_fma(t, splat4(c1), splat4(c0));
+  const f32x4 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1]), __builtin_amdgcn_exp2f(a[2]), __builtin_amdgcn_exp2f(a[3])};
+  const f32x4 d = splat4(1.0f) + e;
+  const f32x4 s = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
+  const f32x4 du2 = __builtin_elementwise_fma(t, splat4(6.0f * k0 * k1), splat4(2.0f * k0));
+  y = x * s;
+  dy = __builtin_elementwise_fma(y * (e * s), du2, s);
+}
+// GELU'(x) as ONE byte (round 6: the second output of fc1 + GELU, sfron_gemm_desc SFRON_EPI_GELU_Q / SFRON_EPI_DGELU_Q).  GELU'_tanh takes
+// values in [-0.1290, 1.1290]; code = round((g' + 0.15) * 196) in 0 .. 251, g' = code / 196 - 0.15: a step of 0.0051, i.e. at most 0.0026 of
+// absolute error -- the size of what the bf16 rounding of x (2^-9 relative) does to GELU'(x) through GELU'' (<= 0.5 |x| 2^-9 ~ 0.001 |x|).
+// v_cvt_pk_u8_f32 rounds to nearest and saturates to 0 .. 255.
+constexpr float GELUQ_SCALE = 196.0f, GELUQ_OFF = 0.15f;
+__device__ __forceinline__ unsigned geluq_pack4(f32x4 dy) {
+  const f32x4 c = __builtin_elementwise_fma(dy, splat4(GELUQ_SCALE), splat4(GELUQ_OFF * GELUQ_SCALE));
+  unsigned w = 0;
+  w = __builtin_amdgcn_cvt_pk_u8_f32(c[0], 0, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(c[1], 1, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(c[2], 2, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(c[3], 3, w);
+  return w;
+}
+__device__ __forceinline__ f32x4 geluq_unpack4(unsigned w) {
+  const f32x4 c = {(float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24)};     // v_cvt_f32_ubyte0..3
+  return __builtin_elementwise_fma(c, splat4(1.0f / GELUQ_SCALE), splat4(-GELUQ_OFF));
+}
 __device__ __forceinline__ f32x4 bf2f4(bf16x4 h) { return f32x4{bf2f(h[0]), bf2f(h[1]), bf2f(h[2]), bf2f(h[3])}; }
 __device__ __forceinline__ bf16x4 f2bf4(f32x4 v) { return bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; }
 __device__ __forceinline__ f32x4 as4(float4 b) { return f32x4{b.x, b.y, b.z, b.w}; }
@@ -148,6 +179,10 @@ __device__ __forceinline__ void pair_unpack(uint4 v, bf16x4& a, bf16x4& b) {
   permlane16_swap(ua.y, ub.y);
   a = __builtin_bit_cast(bf16x4, ua); b = __builtin_bit_cast(bf16x4, ub);
 }
+
+// the same piece map for ONE-byte elements: a lane's 4 bytes of tile k and of tile k + 1 -> its 8 contiguous bytes at pair_col(g)
+__device__ __forceinline__ uint2 pair_pack8(unsigned a, unsigned b) { permlane16_swap(a, b); return make_uint2(a, b); }
+__device__ __forceinline__ void pair_unpack8(uint2 v, unsigned& a, unsigned& b) { a = v.x; b = v.y; permlane16_swap(a, b); }
 
 // ---- a completion event carried by the producing kernel's own dispatch ----------------------------------------------------------
 // hipEventRecord puts a marker packet into the stream behind the kernel it follows: ~5 us of the main stream per hand-off to the

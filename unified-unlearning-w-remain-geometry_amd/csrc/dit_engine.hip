@@ -400,6 +400,18 @@ int sfron_probe_destroy(void* probe) {
   return SFRON_OK;
 }
 
+// Round 6: where the fc1 / fc2 shapes run on the 256 x 192 pipelined tile (every registry model at 256 px and batch >= 8), the second output of
+// fc1 + GELU -- which only the fc2 dgrad's GELU' reads -- is GELU'(pre-activation) as ONE byte per element (SFRON_EPI_GELU_Q / _DGELU_Q) instead
+// of the bf16 pre-activation; the block's `hpre` slot then holds M * F bytes of codes.  The SAME rule decides in the forward passes (bf16 and
+// fp8) and in the backward pass.  -DSFRON_TUNE_NO_GELU_Q (A-B builds, tools/build_variant.sh) keeps the bf16 pre-activation everywhere.
+static bool use_gelu_q(const Dims& d) {
+#ifdef SFRON_TUNE_NO_GELU_Q
+  return false;
+#else
+  return sfron_gemm_gelu_q_supported(d.M, d.F, d.D) != 0;
+#endif
+}
+
 // config 5: e4m3 weight shadow + scales + the e4m3 activation scratch of ONE block (only the forward GEMMs read them)
 struct Fp8Ctx {
   const uint8_t* w8; const float* w_scales; float s_x, s_o, s_h;
@@ -575,6 +587,7 @@ static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const
                                   w.mean + (size_t)(2 * l + 1) * M, w.rstd + (size_t)(2 * l + 1) * M, f8->act_amax, stream));
       q = g8(f8->xmod8, pb + P.o_fc1_w, d.F, D, ws + 2, f8->s_x, SFRON_EPI_GELU);
       q.bias = params + pb + P.o_fc1_b; q.c_bf16 = (uint16_t*)h; q.ldc_bf16 = d.F; q.aux = (uint16_t*)hpre; q.ldaux = d.F;
+      q.aux_q = use_gelu_q(d) ? 1 : 0;
       q.c_e4m3 = f8->h8; q.c_e4m3_scale = f8->s_h;
       RUN(sfron_fp8_gemm(&q, stream));
       q = g8(f8->h8, pb + P.o_fc2_w, D, d.F, ws + 3, f8->s_h, SFRON_EPI_GATE_RES);
@@ -595,7 +608,7 @@ static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const
     RUN(sfron_ln_modulate_fwd(x1, mod + 3 * D, mod + 4 * D, NM, T, M, D, (uint16_t*)xmod2, w.mean + (size_t)(2 * l + 1) * M,
                               w.rstd + (size_t)(2 * l + 1) * M, stream));
     g = fwd_desc(xmod2, wb + pb + P.o_fc1_w, M, d.F, D);
-    g.epilogue = SFRON_EPI_GELU; g.bias = params + pb + P.o_fc1_b; g.c_bf16 = (uint16_t*)h; g.ldc_bf16 = d.F;
+    g.epilogue = use_gelu_q(d) ? SFRON_EPI_GELU_Q : SFRON_EPI_GELU; g.bias = params + pb + P.o_fc1_b; g.c_bf16 = (uint16_t*)h; g.ldc_bf16 = d.F;
     g.aux = (uint16_t*)hpre; g.ldaux = d.F;
     Probe* pr = (Probe*)probe;
     const bool probing = pr && l == 0 && pr->used < pr->cap;
@@ -808,7 +821,7 @@ static int dit_backward_impl(const sfron_dit_cfg* cfg, const float* params, cons
     }
     before_overwrite(1, l);
     g = dgrad_desc(w.d_br[pl], wb + pb + P.o_fc2_w, M, D, d.F);
-    g.epilogue = SFRON_EPI_DGELU; g.c_bf16 = (uint16_t*)w.d_hpre[pl]; g.ldc_bf16 = d.F; g.aux = (uint16_t*)hpre; g.ldaux = d.F;
+    g.epilogue = use_gelu_q(d) ? SFRON_EPI_DGELU_Q : SFRON_EPI_DGELU; g.c_bf16 = (uint16_t*)w.d_hpre[pl]; g.ldc_bf16 = d.F; g.aux = (uint16_t*)hpre; g.ldaux = d.F;
     // fc1.bias gradient = column sums of d_hpre: the epilogue that produces d_hpre leaves per-tile-row partials (fp32, before the
     // bf16 rounding); the side stream only adds the M / 256 partial rows (was: a second 75 MB pass over d_hpre per block)
     float* const bp_fc1 = w.bpart + (size_t)pl * fc1_rows * d.F;

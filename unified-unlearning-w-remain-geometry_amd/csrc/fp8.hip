@@ -204,6 +204,7 @@ struct Gemm8Args {
   float* Cf; int ldcf; const float* resid;      // EPI_GATE_RES: Cf = resid + gate * result
   const float* gate; int ldgate; int T;
   unsigned int* act_amax;                 // the caller's activation-range words (site 2 is raised by EPI_GELU's e4m3 output), or null
+  int aux_q;                              // EPI_GELU: aux = GELU'(pre-activation) as one byte per element (common.h geluq_pack4), uint8 [M][ldaux]
 };
 enum { E8_BF16 = 0, E8_GELU = 2, E8_GATE_RES = 3 };
 
@@ -344,6 +345,7 @@ __global__ __launch_bounds__(512 + 64 * NL) void k_gemm8(Gemm8Args g) {
     float4 gtv[EPI == E8_GATE_RES ? NH : 1], xrv[EPI == E8_GATE_RES ? NH : 1];
     bf16x4 ob[NT8], ab[NT8];
     unsigned c8[NT8];
+    [[maybe_unused]] unsigned q8[EPI == E8_GELU ? NT8 : 1];
 #pragma unroll
     for (int nt = 0; nt < NT8; ++nt) {
       if constexpr (EPI == E8_GATE_RES) {
@@ -368,8 +370,16 @@ __global__ __launch_bounds__(512 + 64 * NL) void k_gemm8(Gemm8Args g) {
       if constexpr (EPI == E8_BF16) {
         ob[nt] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
       } else if constexpr (EPI == E8_GELU) {
-        ab[nt] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        const float h0 = gelu_tanh(v[0]), h1 = gelu_tanh(v[1]), h2 = gelu_tanh(v[2]), h3 = gelu_tanh(v[3]);
+        float h0, h1, h2, h3;
+        if (g.aux_q) {                              // kernel-uniform: the backward pass reads GELU'(v) as bytes (SFRON_EPI_DGELU_Q)
+          f32x4 y, dy;
+          gelu_tanh_both4(v, y, dy);
+          h0 = y[0]; h1 = y[1]; h2 = y[2]; h3 = y[3];
+          q8[nt] = geluq_pack4(dy);
+        } else {
+          ab[nt] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+          h0 = gelu_tanh(v[0]); h1 = gelu_tanh(v[1]); h2 = gelu_tanh(v[2]); h3 = gelu_tanh(v[3]);
+        }
         ob[nt] = bf16x4{f2bf(h0), f2bf(h1), f2bf(h2), f2bf(h3)};
         amax4(act_am, h0 * g.c8_scale, h1 * g.c8_scale, h2 * g.c8_scale, h3 * g.c8_scale);
         c8[nt] = pack_e4m3(h0 * g.c8_scale, h1 * g.c8_scale, h2 * g.c8_scale, h3 * g.c8_scale);
@@ -394,7 +404,15 @@ __global__ __launch_bounds__(512 + 64 * NL) void k_gemm8(Gemm8Args g) {
       }
     };
     if constexpr (EPI == E8_BF16 || EPI == E8_GELU) put(g.Cb, g.ldcb, ob);
-    if constexpr (EPI == E8_GELU || EPI == E8_GATE_RES) put(g.aux, g.ldaux, ab);
+    if constexpr (EPI == E8_GATE_RES) put(g.aux, g.ldaux, ab);
+    if constexpr (EPI == E8_GELU) {
+      if (g.aux_q) {
+        uint8_t* const rq = reinterpret_cast<uint8_t*>(g.aux) + (size_t)row * g.ldaux;
+#pragma unroll
+        for (int np = 0; np < NT8 / 2; ++np) *reinterpret_cast<uint2*>(rq + colp + np * 32) = pair_pack8(q8[2 * np], q8[2 * np + 1]);
+        if constexpr (NT8 & 1) *reinterpret_cast<uint32_t*>(rq + n0 + (NT8 - 1) * 16 + 4 * fg) = q8[NT8 - 1];
+      } else put(g.aux, g.ldaux, ab);
+    }
     if constexpr (EPI == E8_GELU) {
       uint8_t* const r8 = g.C8 + (size_t)row * g.N;
 #pragma unroll
@@ -475,6 +493,8 @@ int sfron_fp8_gemm(const sfron_fp8_gemm_desc* d, void* stream) {
   g.Cf = d->c_f32; g.ldcf = d->ldc_f32; g.resid = d->resid ? d->resid : d->c_f32; g.gate = d->gate; g.ldgate = d->ldgate;
   g.T = d->tokens > 0 ? d->tokens : 1;
   g.act_amax = d->act_amax;
+  g.aux_q = d->aux_q;
+  if (d->aux_q) SFRON_CHECK_ARG(d->epilogue == SFRON_EPI_GELU && d->ldaux % 8 == 0 && ((uintptr_t)d->aux & 7) == 0);
   hipStream_t s = (hipStream_t)stream;
   switch (d->epilogue) {
     case SFRON_EPI_BF16:

@@ -64,7 +64,10 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int NT = 256;
 constexpr int TILE_ELEMS = 128 * 64;   // both image kinds hold 8192 bf16 = 16 KiB
 
-enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_GATE_RES = 3, EPI_DGELU = 4, EPI_POS = 5, EPI_SUMSQ = 6 };
+enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_GATE_RES = 3, EPI_DGELU = 4, EPI_POS = 5, EPI_SUMSQ = 6,
+       // round 6, the 256 x 192 pipelined tile only: EPI_GELU / EPI_DGELU whose `aux` is GELU'(pre-activation) as ONE byte per element
+       // (common.h geluq_pack4) instead of the bf16 pre-activation: fc1 writes 113 instead of 151 MB, the fc2 dgrad reads half and has no exp
+       EPI_GELUQ = 7, EPI_DGELUQ = 8 };
 
 
 
@@ -1020,7 +1023,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
         if (kt + 2 < nkl) stage(slot, kb + (kt + 2) * BK);
         slot = slot == 2 ? 0 : slot + 1;
       }
-      if constexpr (EPI == EPI_DGELU) {                        // the consumers' column-partial reduction meets at two more barriers
+      if constexpr (EPI == EPI_DGELU || EPI == EPI_DGELUQ) {    // the consumers' column-partial reduction meets at two more barriers
         if (g.colpart) { __syncthreads(); __syncthreads(); }
       }
       if constexpr (EPI == EPI_F32 && A_TR && B_TR) {          // ... and so does the masked sum of squares of a weight gradient
@@ -1343,10 +1346,24 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
   const int lane_g = lane >> 4;
   const int col_p = n0 + wn * NT * 16 + pair_col(lane_g);          // this lane's column of a tile PAIR's 16-byte piece (+ nt * 16)
   constexpr int NP = NT / 2;                                       // tile pairs; tile NT - 1 is alone when NT is odd
-  if constexpr (EPI == EPI_DGELU) {
-    const bool wide = ((g.ldaux | g.ldcb) & 7) == 0;
-    bf16x4 hx[MT][NT];
-    if (wide) {
+  if constexpr (EPI == EPI_DGELU || EPI == EPI_DGELUQ) {
+    const bool wide = ((g.ldaux | g.ldcb) & 7) == 0;              // (EPI_DGELUQ: guaranteed by the launcher)
+    bf16x4 hx[EPI == EPI_DGELUQ ? 1 : MT][NT];
+    unsigned hq[EPI == EPI_DGELUQ ? MT : 1][NT];                  // EPI_DGELUQ: this lane's four GELU' codes of tile (mt, nt)
+    if constexpr (EPI == EPI_DGELUQ) {
+      static_assert(!(NT & 1), "byte-coded GELU': tile pairs only");
+      const uint8_t* const aq = reinterpret_cast<const uint8_t*>(g.aux);
+      uint2 hp8[MT][NP];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int np = 0; np < NP; ++np)
+          hp8[mt][np] = *reinterpret_cast<const uint2*>(aq + (size_t)(row_b + mt * 16) * g.ldaux + col_p + np * 32);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int np = 0; np < NP; ++np) pair_unpack8(hp8[mt][np], hq[mt][2 * np], hq[mt][2 * np + 1]);
+    } else if (wide) {
       uint4 hp[MT][NP > 0 ? NP : 1];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -1376,8 +1393,9 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const f32x4 v = acc[mt][nt] * g.alpha;
-        const bf16x4 h = hx[mt][nt];
-        const f32x4 r = v * gelu_tanh_grad4(bf2f4(h));
+        f32x4 r;
+        if constexpr (EPI == EPI_DGELUQ) r = v * geluq_unpack4(hq[mt][nt]);
+        else r = v * gelu_tanh_grad4(bf2f4(hx[mt][nt]));
         cs[nt] += r;
         ob[nt] = f2bf4(r);
       }
@@ -1476,8 +1494,8 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
         if constexpr (NT & 1) *reinterpret_cast<bf16x4*>(arow + col_b + (NT - 1) * 16) = ab[NT - 1];
       }
     }
-  } else if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
-    const bool wide = (g.ldcb & 7) == 0 && (EPI != EPI_GELU || ((g.ldaux & 7) == 0 && !(g.nt_out & 1)));
+  } else if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_GELUQ) {
+    const bool wide = EPI == EPI_GELUQ || ((g.ldcb & 7) == 0 && (EPI != EPI_GELU || ((g.ldaux & 7) == 0 && !(g.nt_out & 1))));
     if (!wide) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -1490,6 +1508,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
       for (int mt = 0; mt < MT; ++mt) {
         const int row = row_b + mt * 16;
         bf16x4 ob[NT], hb[EPI == EPI_GELU ? NT : 1];
+        unsigned qb[EPI == EPI_GELUQ ? NT : 1];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           f32x4 v = acc[mt][nt] * g.alpha;
@@ -1499,6 +1518,11 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
           if constexpr (EPI == EPI_GELU) {
             hb[nt] = f2bf4(v);                                  // pre-activation (the backward pass reads it)
             ob[nt] = f2bf4(gelu_tanh4(v));
+          } else if constexpr (EPI == EPI_GELUQ) {
+            f32x4 y, dy;
+            gelu_tanh_both4(v, y, dy);                          // the backward pass reads GELU'(v), one byte each
+            ob[nt] = f2bf4(y);
+            qb[nt] = geluq_pack4(dy);
           } else {
             ob[nt] = f2bf4(v);
           }
@@ -1507,6 +1531,12 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
 #pragma unroll
         for (int np = 0; np < NP; ++np) *reinterpret_cast<uint4*>(crow + col_p + np * 32) = pair_pack(ob[2 * np], ob[2 * np + 1]);
         if constexpr (NT & 1) *reinterpret_cast<bf16x4*>(crow + col_b + (NT - 1) * 16) = ob[NT - 1];
+        if constexpr (EPI == EPI_GELUQ) {
+          static_assert(EPI != EPI_GELUQ || !(NT & 1), "byte-coded GELU': tile pairs only");
+          uint8_t* const qrow = reinterpret_cast<uint8_t*>(g.aux) + (size_t)row * g.ldaux;
+#pragma unroll
+          for (int np = 0; np < NP; ++np) *reinterpret_cast<uint2*>(qrow + col_p + np * 32) = pair_pack8(qb[EPI == EPI_GELUQ ? 2 * np : 0], qb[EPI == EPI_GELUQ ? 2 * np + 1 : 0]);
+        }
 #ifndef SFRON_TUNE_NO_HPRE_STORE          // timing experiment only (tools/build_variant.sh; wrong gradients): what would fc1 cost without its second output?
         if constexpr (EPI == EPI_GELU) {
           __bf16* const arow = g.aux + (size_t)row * g.ldaux;
@@ -1600,6 +1630,8 @@ SFRON_INST_PIPE(2, 2, 8, 6)
 SFRON_INST_PIPE1(4, 2, 4, 6)
 SFRON_INST_PIPE1(4, 2, 3, 6)
 #undef SFRON_INST_PIPE1
+template __global__ void k_gemm_pipe<4, 2, 4, 6, false, false, EPI_GELUQ, 1>(GemmArgs);   // fc1 + GELU, GELU' as bytes (round 6)
+template __global__ void k_gemm_pipe<4, 2, 4, 6, false, true, EPI_DGELUQ, 1>(GemmArgs);   // fc2 dgrad * GELU' from the bytes
 template __global__ void k_gemm_pipe<4, 2, 3, 6, true, true, 0, 2>(GemmArgs);    // 192x192, three slots: weight gradients
 template __global__ void k_gemm_pipe<4, 2, 3, 6, true, true, 1, 2>(GemmArgs);
 template __global__ void k_gemm_pipe<4, 2, 3, 6, true, true, 1, 2, 2, true>(GemmArgs);   // ... + bias row sums
@@ -1817,6 +1849,8 @@ int dispatch_layout(int a_tr, int b_tr, const GemmArgs& g, hipStream_t s, int fo
 }  // namespace
 
 extern "C" int sfron_gemm_rowsum_supported(int M, int N, int K) { return rowsum_ok(M, N, K) ? 1 : 0; }
+// SFRON_EPI_GELU_Q / SFRON_EPI_DGELU_Q run on the 256 x 192 pipelined tile with the interleaved schedule only (an even number of 64-deep k-tiles)
+extern "C" int sfron_gemm_gelu_q_supported(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && M % 256 == 0 && N % 192 == 0 && K % 128 == 0 ? 1 : 0; }
 
 // Weight gradients dW[M][N] = dY[K][M]^T X[K][N] whose automatic tile is the 192 x 192 pipelined one can also leave the masked sum of squares of
 // their output, one fp64 partial per tile: returns the number of partials (M / 192 * N / 192), or 0 when the shape goes another way.
@@ -1903,7 +1937,7 @@ int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
   g.bsum = nullptr;
   g.colpart = nullptr;
   if (d->col_partials) {      // only the auto-dispatched 256-row pipelined tiles form it (sfron_gemm_dgelu_colpart_rows)
-    SFRON_CHECK_ARG(d->epilogue == SFRON_EPI_DGELU && d->split_k <= 1 && d->tile_hint == 0);
+    SFRON_CHECK_ARG((d->epilogue == SFRON_EPI_DGELU || d->epilogue == SFRON_EPI_DGELU_Q) && d->split_k <= 1 && d->tile_hint == 0);
     if (sfron_gemm_dgelu_colpart_rows(d->M, d->N, d->K) == 0) return SFRON_ERR_UNSUPPORTED;
     g.colpart = d->col_partials;
   }
@@ -1943,6 +1977,16 @@ int sfron_gemm_bf16(const sfron_gemm_desc* d, void* stream) {
     case SFRON_EPI_DGELU:
       SFRON_CHECK_ARG(g.Cb && g.aux && g.ldcb % 4 == 0 && g.ldaux % 4 == 0 && !d->a_transposed && d->b_transposed);
       return launch_any<false, true, EPI_DGELU>(g, s, force);
+    case SFRON_EPI_GELU_Q:
+      SFRON_CHECK_ARG(g.Cb && g.aux && g.ldcb % 8 == 0 && g.ldaux % 8 == 0 && !d->a_transposed && !d->b_transposed && d->split_k <= 1 && force == 0);
+      SFRON_CHECK_ARG((((uintptr_t)g.aux | (uintptr_t)g.Cb) & 15) == 0);
+      if (!sfron_gemm_gelu_q_supported(d->M, d->N, d->K)) return SFRON_ERR_UNSUPPORTED;
+      return launch_pipe<4, 2, 4, 6, false, false, EPI_GELUQ, 1>(g, s);
+    case SFRON_EPI_DGELU_Q:
+      SFRON_CHECK_ARG(g.Cb && g.aux && g.ldcb % 8 == 0 && g.ldaux % 8 == 0 && !d->a_transposed && d->b_transposed && d->split_k <= 1 && force == 0);
+      SFRON_CHECK_ARG((((uintptr_t)g.aux | (uintptr_t)g.Cb) & 15) == 0);
+      if (!sfron_gemm_gelu_q_supported(d->M, d->N, d->K)) return SFRON_ERR_UNSUPPORTED;
+      return launch_pipe<4, 2, 4, 6, false, true, EPI_DGELUQ, 1>(g, s);
     case SFRON_EPI_POS:
       SFRON_CHECK_ARG(g.Cf && g.pos && g.ldcf % 4 == 0 && !d->a_transposed && !d->b_transposed);
       if (force == 0 && shortk_ok(g)) return launch_shortk(g, s);          // the patch embedding: K = 16
