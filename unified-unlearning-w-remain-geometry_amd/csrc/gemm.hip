@@ -1293,8 +1293,15 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
     }
     static_for<NM>([&](auto ic) { mfma1(f1, ic); });
     bsum_step(f1, bs_c);
-    // the asm MFMAs are invisible to hipcc's hazard recogniser: let the last results land before the epilogue reads them
+    // the asm MFMAs are invisible to hipcc's hazard recogniser: let the last results land before the epilogue reads them.  The padding must
+    // also be a SCHEDULING barrier: a volatile asm keeps its place among other volatile asm only, and hipcc is free to hoist the epilogue's
+    // arithmetic on the accumulators (ordinary VALU code that merely depends on the MFMA statements' outputs) above it.  Round 6: in the
+    // EPI_GELUQ instantiation it did -- ~300 instructions of GELU arithmetic in front of the two s_nop -- and the kernel returned a few
+    // thousand wrong elements per launch whenever another stream's traffic delayed the last MFMAs (tools/diag_geluq.py; the bit-for-bit
+    // soak test caught it).  The other instantiations happened to keep the order; all of them are pinned now.
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 #ifdef SFRON_DEBUG_KNOBS
     if (g.dbg_clk && tid == 0 && blockIdx.y == 0) {            // (memory nothing else reads: the stamps never reach an output)
       const long long dt = __builtin_amdgcn_s_memtime() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
