@@ -603,7 +603,7 @@ def main():
                          "achieved": wg_ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": wg_ach / MFMA_BF16_PEAK_TFLOPS,
                          "traffic": traffic, "flops_per_launch": wg_flops, "avg_launch_ms": wg_ms, "launches_timed": n_wp,
                          "others": {
-                             "fwd_fc1_gelu": {"bound": "mfma", "kernel": f"k_gemm_pipe<4,2,4,6,false,false,2,1,2>: Mlp.fc1 + GELU-tanh [{M}x{D}]x[{D}x{F}], block 0 of "
+                             "fwd_fc1_gelu": {"bound": "mfma", "kernel": f"k_gemm_pipe<4,2,4,6,false,false,7,1,2>: Mlp.fc1 + GELU-tanh [{M}x{D}]x[{D}x{F}] (second output: GELU' as one byte per element), block 0 of "
                                               "every forward pass (main stream, nothing beside it; not launched by the fp8 path)", "achieved": achieved if n_probe else None,
                                               "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": (achieved / MFMA_BF16_PEAK_TFLOPS) if n_probe else None,
                                               "traffic": committed_traffic("r06_fc1_traffic.json") if n_probe else None,

@@ -26,8 +26,8 @@ RULES = [
     (r"k_gemm_pipe<4, 2, 3, 6, true, true, 1, 2, 2, true>", "wgrad qkv/fc1 + bias row sums (192x192, 3 slots)", "mfma", (QKV + FC1) / 2, "mean of qkv 65.2 / fc1 87.0 GFLOP"),
     (r"k_gemm_pipe<4, 2, 3, 6, true, true, 1, 2, 2(, false)?(, \d)?>", "wgrad qkv/proj/fc1/fc2 (192x192, 3 slots, loader waves)", "mfma", None, "mean of 65.2 / 21.7 / 87.0 / 87.0 GFLOP"),
     (r"k_gemm_pipe<8, 1, 2, 9, false, true, 0, 2, 3", "dgrad qkv/proj/fc1 -> 1152 wide (256x144)", "mfma", (QKV + PROJ + FC1) / 3, "mean of 65.2 / 21.7 / 87.0"),
-    (r"k_gemm_pipe<4, 2, 4, 6, false, true, 4, 1, 2", "dgrad fc2 + GELU' (256x192)", "mfma", FC2, ""),
-    (r"k_gemm_pipe<4, 2, 4, 6, false, false, 2, 1, 2", "fwd fc1 + GELU (256x192)", "mfma", FC1, ""),
+    (r"k_gemm_pipe<4, 2, 4, 6, false, true, [48], 1, 2", "dgrad fc2 + GELU' (256x192; round 6: GELU' read as one byte per element)", "mfma", FC2, ""),
+    (r"k_gemm_pipe<4, 2, 4, 6, false, false, [27], 1, 2", "fwd fc1 + GELU (256x192; round 6: second output = GELU' as one byte per element)", "mfma", FC1, ""),
     (r"k_gemm_pipe<8, 1, 2, 9, false, false, 0, 2, 3", "fwd qkv (256x144)", "mfma", QKV, ""),
     (r"k_gemm_pipe<8, 1, 2, 9, false, false, 3, 2, 3", "fwd proj/fc2 + gated residual (256x144)", "mfma", (PROJ + FC2) / 2, "mean of 21.7 / 87.0"),
     (r"k_attn_fwd", "attention forward", "mfma", ATT_F, "4 T^2 hd per (batch, head)"),

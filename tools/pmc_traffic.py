@@ -22,7 +22,8 @@ for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recurs
 M, D, F = 8192, 1152, 4608
 nt = 674_834_720
 probes = {"wgrad": ("k_gemm_pipe<4, 2, 3, 6, true, true, 1, 2, 2", 0.25 * sum(2 * M * (n + k) + 4 * n * k for n, k in ((3 * D, D), (D, D), (F, D), (D, F)))),
-          "fc1": ("k_gemm_pipe<4, 2, 4, 6, false, false, 2, 1, 2", 2 * (M * D + F * D + 2 * M * F)),
+          # round 6: fc1 + GELU writes its second output as ONE byte per element (SFRON_EPI_GELU_Q): X, W1, h (bf16) + codes (u8)
+          "fc1": ("k_gemm_pipe<4, 2, 4, 6, false, false, 7, 1, 2", 2 * (M * D + F * D + M * F) + M * F),
           "sweep": ("k_masked_clip_adam", None)}
 sha = csrc_sha()
 # the parameter sweeps of a whole step (norm pre-pass + forget-stage AdamW + remain-stage AdamW / EMA, flat and rank-R kernels): totals
