@@ -1494,12 +1494,14 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void k_gemm_pipe(GemmArgs g) {
           xr[(mt + 1) & 1][nt] = *reinterpret_cast<const float4*>(g.resid + (size_t)(row + 16) * g.ldcf + col);
         *reinterpret_cast<f32x4*>(g.Cf + (size_t)row * g.ldcf + col) = x;
       }
+#ifndef SFRON_TUNE_NO_BRANCH                       // timing experiment only (wrong d gate): what does the saved branch output cost?
       if (wide) {                                  // the bf16 branch output (read again by the backward pass): 16-byte pieces
         __bf16* const arow = g.aux + (size_t)row * g.ldaux;
 #pragma unroll
         for (int np = 0; np < NP; ++np) *reinterpret_cast<uint4*>(arow + col_p + np * 32) = pair_pack(ab[2 * np], ab[2 * np + 1]);
         if constexpr (NT & 1) *reinterpret_cast<bf16x4*>(arow + col_b + (NT - 1) * 16) = ab[NT - 1];
       }
+#endif
     }
   } else if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_GELUQ) {
     const bool wide = EPI == EPI_GELUQ || ((g.ldcb & 7) == 0 && (EPI != EPI_GELU || ((g.ldaux & 7) == 0 && !(g.nt_out & 1))));

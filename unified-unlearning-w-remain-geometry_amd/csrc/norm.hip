@@ -206,7 +206,11 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_num_vgpr(SFRON_ROWBWD_VG
     RowRegs xr, prev;                            // LN: x, then xhat | the dx row before this kernel (LN: if accumulate)
     float mean = 0.f, rstd = 0.f, m1 = 0.f, m2 = 0.f;
     if constexpr (LN) { mean = a.mean[row]; rstd = a.rstd[row]; }     // first: loads return in order, and these are needed first
+#ifdef SFRON_TUNE_NO_BRANCH                        // timing experiment only (wrong d gate)
+    if constexpr (GATE) { for (int i = 0; i < NCH; ++i) braw.v[i] = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f}; }
+#else
     if constexpr (GATE) ldb(a.branch + (size_t)row * D, braw);
+#endif
     const __amdgpu_buffer_rsrc_t rs_dx = row_rsrc(a.dx + (size_t)row * D, D * 4);
     if constexpr (LN) {
       ldf(a.x + (size_t)row * D, xr);
