@@ -423,6 +423,8 @@ def main():
         _st.PRIORITY["sweep"] = int(os.environ["SFRON_BENCH_SWEEP_PRIORITY"])
     if os.environ.get("SFRON_BENCH_DEFER_SWEEP"):           # A-B knob (tools only): 0 = start the beside-forward sweep before the pass's prologue (round 5)
         runner.defer_sweep_launch = os.environ["SFRON_BENCH_DEFER_SWEEP"] != "0"
+    if os.environ.get("SFRON_BENCH_ADA_SIDE"):              # A-B knob (tools only): the adaLN sweep on the sweep stream, the next pass's prologue beside it
+        runner.ada_side = os.environ["SFRON_BENCH_ADA_SIDE"] != "0"
     if os.environ.get("SFRON_BENCH_SWEEP_BESIDE"):          # tuning knob (tools only): "workgroups,head"
         runner.sweep_beside_wg, runner.sweep_beside_head = (int(v) for v in os.environ["SFRON_BENCH_SWEEP_BESIDE"].split(","))
 

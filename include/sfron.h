@@ -627,15 +627,18 @@ int sfron_dit_forward_fp8(const sfron_dit_cfg* cfg, const float* params, const u
  * the adaLN modulation of every block: the "conditioning prologue", a chain of ten small dependent launches; phase 2 = only the blocks and
  * the final layer, on the workspace the phase-1 call filled (same arguments).  A caller whose optimizer sweep of the block ranges runs beside
  * the pass on another stream (block_ready) starts that sweep BETWEEN the two calls: beside a bandwidth-heavy sweep every boundary between two
- * small dependent launches costs 60-100 us instead of ~5 (profiles/r06_stage_boundary.txt).  phase 1 ignores block_ready / probe / out. */
+ * small dependent launches costs 60-100 us instead of ~5 (profiles/r06_stage_boundary.txt).  phase 1 ignores block_ready / probe / out.
+ * phase 3 = phase 1 without its last launch -- the adaLN product silu(c) W_ada^T + b, the only launch in front of block 0 that reads the
+ * adaLN_modulation matrix (DiT/models.py:113-116,119) -- and phase 4 = that launch alone (ABI 16): a caller whose optimizer sweep of that
+ * matrix runs on another stream issues phase 3 beside it, orders `stream` behind the sweep, then phase 4 and phase 2. */
 int sfron_dit_forward_phase(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
                             const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
-                            void* const* block_ready /* or NULL */, void* probe /* or NULL */, int phase /* 1 | 2 */, void* stream);
+                            void* const* block_ready /* or NULL */, void* probe /* or NULL */, int phase /* 1 | 2 | 3 | 4 */, void* stream);
 int sfron_dit_forward_fp8_phase(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const uint8_t* params_e4m3,
                                 const float* w_scales, const float* act_scales, uint32_t* act_amax /* DEVICE [3] or NULL */, const float* x_t,
                           const int64_t* t, const int64_t* y,
                                 const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out,
-                                void* const* block_ready /* or NULL */, int phase /* 1 | 2 */, void* stream);
+                                void* const* block_ready /* or NULL */, int phase /* 1 | 2 | 3 | 4 */, void* stream);
 /* Same as sfron_dit_forward, with HIP events recorded (on `stream`) around the fc1 GEMM of block 0 -- the
  * dominant kernel class -- into `probe` (may be NULL).  Used by bench.py for the live roofline measurement. */
 int sfron_dit_forward_probed(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,

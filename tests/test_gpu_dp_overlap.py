@@ -192,7 +192,7 @@ def test_remain_sweep_beside_the_next_step_gives_the_same_state(fp8):
     bat = lambda it: (data.synthetic_batch(6, it, "forget", **kw), data.synthetic_batch(6, it, "remain", **kw))
     hp = dict(lr=2e-4, forget_alpha=0.3, grad_clip=1.0, ema_decay=0.99, mask=None, unlearn_loss="ga", forget_class=3)
 
-    def run(across, defer=False):
+    def run(across, defer=False, ada_side=False):
         _, model = build_pair(cfg, B, seed=29)
         runner = step.DiTSFRon(model, diffusion.create_diffusion(""), fp8=fp8, **hp)     # fp8: the sweeps also rewrite the e4m3 shadow
         assert runner.sweep_across_steps is False          # opt-in
@@ -200,8 +200,15 @@ def test_remain_sweep_beside_the_next_step_gives_the_same_state(fp8):
         # round 6: the second-stream launches of a beside-forward sweep issued by the forward pass itself, between its conditioning prologue
         # and block 0 (sfron_dit_forward_phase); the sweep left across the step boundary is handed to the next step's pass or to drain_sweep
         runner.defer_sweep_launch = defer
+        # round 6 (late): the adaLN matrix's sweep on the sweep stream in front of the block ranges, the next pass's prologue beside it and its
+        # adaLN product behind an event (sfron_dit_forward_phase 3 / 4); one head block, so that a range does go to the second stream at depth 2
+        runner.ada_side = ada_side
+        if ada_side:
+            runner.sweep_beside_head = 1
         for it in range(4):
             runner.step(*bat(it))
+        if ada_side:
+            assert model.engine._shared.get("ada_done") is not None or not across
         if across:
             assert runner._ready_owner is not None and model.engine._sweep_pending is not None
         ck = runner.checkpoint()                           # drains the sweep before it reads
@@ -212,7 +219,8 @@ def test_remain_sweep_beside_the_next_step_gives_the_same_state(fp8):
         return (eng.params.clone(), runner.opt.m.clone(), runner.opt.v.clone(), runner.ema.clone(), eng.params_bf16.clone(), ck)
 
     a = run(False)
-    for b in (run(True), run(True, defer=True), run(False, defer=True)):
+    for b in (run(True), run(True, defer=True), run(False, defer=True), run(False, ada_side=True), run(True, ada_side=True),
+              run(True, defer=True, ada_side=True)):
         for x, y in zip(a[:5], b[:5]):
             assert torch.equal(x, y)
         for k in a[5]["model"]:

@@ -14,7 +14,7 @@ class SfronError(RuntimeError):
 
 
 _lib = None
-ABI_VERSION = 15          # == sfron_abi_version() of the library these ctypes structs / prototypes were written for (checked on load)
+ABI_VERSION = 16          # == sfron_abi_version() of the library these ctypes structs / prototypes were written for (checked on load)
 
 _P = c_void_p     # device pointer
 _S = c_void_p     # hipStream_t

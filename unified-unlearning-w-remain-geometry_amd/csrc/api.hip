@@ -2,7 +2,7 @@
 #include "common.h"
 #include "../../include/sfron.h"
 extern "C" {
-int sfron_abi_version(void) { return 15; }
+int sfron_abi_version(void) { return 16; }
 const char* sfron_build_arch(void) { return "gfx950"; }
 }
 

@@ -451,7 +451,7 @@ int sfron_dit_forward_after(const sfron_dit_cfg* cfg, const float* params, const
 int sfron_dit_forward_phase(const sfron_dit_cfg* cfg, const float* params, const uint16_t* params_bf16, const float* x_t,
                             const int64_t* t, const int64_t* y, const uint8_t* drop, void* workspace, float* out,
                             void* const* block_ready, void* probe, int phase, void* stream) {
-  SFRON_CHECK_ARG(phase == 1 || phase == 2);
+  SFRON_CHECK_ARG(phase >= 1 && phase <= 4);
   return dit_forward_impl(cfg, params, params_bf16, x_t, t, y, drop, workspace, out, probe, nullptr, stream, block_ready, phase);
 }
 
@@ -475,7 +475,7 @@ int sfron_dit_forward_fp8_phase(const sfron_dit_cfg* cfg, const float* params, c
                                 const float* w_scales, const float* act_scales, uint32_t* act_amax, const float* x_t, const int64_t* t, const int64_t* y,
                                 const uint8_t* drop, void* workspace, void* workspace_e4m3, float* out, void* const* block_ready, int phase,
                                 void* stream) {
-  SFRON_CHECK_ARG(phase == 1 || phase == 2);
+  SFRON_CHECK_ARG(phase >= 1 && phase <= 4);
   return dit_forward_fp8_impl(cfg, params, params_bf16, params_e4m3, w_scales, act_scales, act_amax, x_t, t, y, drop, workspace, workspace_e4m3, out,
                               block_ready, phase, stream);
 }
@@ -511,7 +511,10 @@ static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const
   // phase 2 = only the blocks and the final layer on the workspace a phase-1 call filled, 0 = both.  A caller whose optimizer sweep runs
   // beside this pass on another stream starts that sweep BETWEEN the two calls: beside a bandwidth-heavy sweep every boundary between two of
   // the prologue's small launches costs 60-100 us instead of ~5 (profiles/r06_stage_boundary.txt), ~0.5 ms per pass.
-  if (phase != 2) {
+  // phase 3 = phase 1 without its last launch, the adaLN product -- the only launch of the prologue that reads the adaLN matrix; phase 4 = that
+  // launch alone.  A caller whose optimizer sweep of that matrix (a third of the parameters, ~1.1 ms) runs on another stream issues phase 3
+  // beside it, then orders this stream behind the sweep, then phase 4 and phase 2 (engine.forward(ada_ready=...)).
+  if (phase != 2 && phase != 4) {
   // x = x_embedder(x) + pos_embed                                        (models.py:240)
   RUN(sfron_patchify(x_t, d.B, d.C, d.S, d.S, d.p, 0, (uint16_t*)w.patches, d.Kp, stream));
   g = fwd_desc(w.patches, wb + P.pe_w, M, D, d.Kp);
@@ -528,11 +531,13 @@ static int dit_forward_impl(const sfron_dit_cfg* cfg, const float* params, const
   RUN(sfron_gemm_bf16(&g, stream));
   // c = t + y_embedder(y); SiLU(c) feeds every adaLN_modulation           (models.py:242-243,114,132)
   RUN(sfron_cond_fwd(w.temb, params + P.table, y, drop, d.ncls, d.B, D, w.c, (uint16_t*)w.sc, stream));
+  }
+  if (phase != 2 && phase != 3) {
   g = fwd_desc(w.sc, wb + P.ada_w, d.B, NM, D);
   g.epilogue = SFRON_EPI_F32; g.bias = params + P.ada_b; g.c_f32 = w.mod; g.ldc_f32 = NM;
   RUN(sfron_gemm_bf16(&g, stream));
   }
-  if (phase == 1) return SFRON_OK;
+  if (phase == 1 || phase == 3 || phase == 4) return SFRON_OK;
 
   // x_next = x + gate * (X W^T + b), branch output saved for the backward pass (models.py:120-121): one product with the gated-residual
   // epilogue, or -- few-tile shapes -- a split-K product + its finish kernel

@@ -252,10 +252,13 @@ class DitEngine:
             torch.cuda.current_stream().wait_stream(st)
             self._shared["sweep"] = None
 
-    def forward(self, x_t, t, y, drop=None, out=None, block_ready=None, between=None):
+    def forward(self, x_t, t, y, drop=None, out=None, block_ready=None, between=None, ada_ready=None):
         """block_ready: ctypes array of depth hipEvent_t handles -- block l waits for entry l before it touches its weights.
         between (with block_ready): a callable run BETWEEN the conditioning prologue and block 0 (sfron_dit_forward_phase): the runner starts
-        the block sweep that goes beside this pass there -- behind the prologue's chain of small launches, not beside it (step.py)."""
+        the block sweep that goes beside this pass there -- behind the prologue's chain of small launches, not beside it (step.py).
+        ada_ready (with block_ready): a torch event behind the optimizer sweep of the adaLN matrix, which the runner put on the sweep stream
+        (FlatAdam.step(split[ada_side])): everything in front of the adaLN product is issued first -- it runs beside that sweep --, then this
+        stream waits for the event, then the product and the blocks."""
         if out is None:
             out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
         if x_t.shape[0] != self.cfg.batch:
@@ -263,9 +266,13 @@ class DitEngine:
         if block_ready is None:
             assert between is None
             self.drain_sweep()                 # a block sweep may still be rewriting the weights on its own stream (step.py)
-        if between is not None:
+        if ada_ready is not None:
+            assert block_ready is not None
+        if between is not None or ada_ready is not None:
             L, f = _lib.lib(), self.fp8
-            for phase in (1, 2):
+            for phase in ((1, 2) if ada_ready is None else (3, 4, 2)):
+                if phase == 4:
+                    torch.cuda.current_stream().wait_event(ada_ready)
                 if f is None:
                     check(L.sfron_dit_forward_phase(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(x_t), ptr(t), ptr(y),
                                                     ptr(drop), ptr(self.workspace), ptr(out), block_ready, self.probe, phase, stream_ptr()),
@@ -274,7 +281,7 @@ class DitEngine:
                     check(L.sfron_dit_forward_fp8_phase(ctypes.byref(self.cfg), ptr(self.params), ptr(self.params_bf16), ptr(f["w8"]),
                                                         ptr(f["scales"]), f["act"], ptr(f["act_amax"]), ptr(x_t), ptr(t), ptr(y), ptr(drop), ptr(self.workspace),
                                                         ptr(f["ws"]), ptr(out), block_ready, phase, stream_ptr()), "dit_forward_fp8_phase")
-                if phase == 1:
+                if phase in (1, 4) and between is not None:
                     between()
             return out
         if block_ready is not None and self.fp8 is None:

@@ -67,6 +67,11 @@ class DiTSFRon:
         # True: a beside-forward sweep is launched BEHIND that pass's conditioning prologue (engine.forward(between=...)).  Measured neutral
         # without a profiler (profiles/r06_ab_log.txt) and it puts 26 Python-issued launches on the critical path: off by default.
         self.defer_sweep_launch = False
+        # True: a beside-forward sweep also takes the adaLN matrix (a third of the parameters) to the sweep stream, in front of the block ranges,
+        # at full grid; the head ranges, the next pass's noising and its conditioning prologue (~20 small launches) run beside it and the pass
+        # waits for it in front of its adaLN product (sfron_dit_forward_phase 3 / 4).  Same kernels on the same operands: bit-identical.
+        # One box, alternating, six pairs: -0.17 ... -0.32 ms per step (profiles/r06_ab_log.txt).
+        self.ada_side = True
         # single-process runs: the forget stage's clip norm (forget.py:293-298) is taken where the gradients are produced -- the block
         # weight-gradient GEMMs leave the masked sums of squares of their tiles (engine.arm_sumsq), one small launch covers biases /
         # embedders / final layer, the rank-(batch) adaLN range is summed from its factors: no pass over the 1.8 GB block range of the arena
@@ -319,7 +324,7 @@ class DiTSFRon:
         y_safe, b["t"] = self.guard.check_inputs(y, b["t"], self.model.num_classes, self.diffusion.num_timesteps)
         return b, y_safe
 
-    def _pass(self, batch, y, sign_alpha, factored_ada=False, block_ready=None, async_exchange=False, between=None):
+    def _pass(self, batch, y, sign_alpha, factored_ada=False, block_ready=None, async_exchange=False, between=None, ada_ready=None):
         """factored_ada (single process, single chain -- what step() uses): the backward pass leaves the adaLN_modulation weight
         gradient as its two bf16 factors and the next optimizer sweep forms the rank-(batch) product itself (engine.
         backward_factored_ada, csrc/sweep.hip k_adam_lowrank): 892 MB less to write and 892 MB (forget stage: twice) less to read
@@ -330,7 +335,8 @@ class DiTSFRon:
         eng, diff = self.model.engine, self.diffusion
         n_global = batch["x0"].shape[0] * self.world
         x_t = diff.q_sample(batch["x0"], batch["t"], batch["noise"])
-        out = eng.forward(x_t, batch["t"], y, batch.get("drop"), block_ready=block_ready, between=between if block_ready is not None else None)
+        out = eng.forward(x_t, batch["t"], y, batch.get("drop"), block_ready=block_ready, between=between if block_ready is not None else None,
+                          ada_ready=ada_ready if block_ready is not None else None)
         mse, vb, d_out = diff.loss_fwd_bwd(out, batch["x0"], batch["t"], batch["noise"], sign_alpha / n_global)
         if self._overlap_enabled():
             self._backward_allreduce_overlapped(d_out, y, batch.get("drop"), factored_ada=factored_ada and self.factored_ada)
@@ -437,6 +443,9 @@ class DiTSFRon:
             if owner is eng and getattr(eng, "_sweep_pending", None) is not None:
                 ready = handles
         between_f = None
+        ada_f = eng._shared.pop("ada_done", None)              # the adaLN sweep the last step() left on the sweep stream (ada_side)
+        if ready is None:
+            ada_f = None                       # nothing in flight that this pass may run beside (a drain orders it behind the whole stream)
         if ready is not None:
             eng._sweep_pending = None          # this forward pass waits for the sweep block by block; its backward pass starts behind all of it
             between_f = eng._shared.pop("deferred", None)      # ... and launches it itself, behind its conditioning prologue (see below)
@@ -450,7 +459,7 @@ class DiTSFRon:
             eng.arm_sumsq(self.opt.mask, self._sq_buf[:sq_plan["n_gemm"]])        # consumed by the forget pass's backward
         try:
             mse_f, vb_f = self._pass(forget, y_f, sign * self.forget_alpha, factored_ada=True, block_ready=ready, async_exchange=dp_sync,
-                                     between=between_f)
+                                     between=between_f, ada_ready=ada_f)
         except BaseException:
             if sq_plan is not None:
                 eng.disarm_sumsq()           # the one-shot was not consumed: no later backward may write through it
@@ -478,7 +487,8 @@ class DiTSFRon:
             # (ten small dependent launches in front of block 0) and block 0 -- beside a bandwidth-heavy sweep each boundary of that chain
             # costs 60-100 us instead of ~5 (profiles/r06_stage_boundary.txt: ~0.5 ms per pass); the blocks wait for their events as before
             split = dict(ranges=bs["ranges"], stream=bs["stream"] if self.sweep_beside_forward else None, events=bs["events"],
-                         max_workgroups=self.sweep_beside_wg, head=self.sweep_beside_head, quant=quant, defer=self.defer_sweep_launch)
+                         max_workgroups=self.sweep_beside_wg, head=self.sweep_beside_head, quant=quant, defer=self.defer_sweep_launch,
+                         ada_side=self.ada_side)
         self._fp8_before_sweep(fused_q)
         pipe, self._pipeline = self._pipeline, None
         self.opt.step(max_norm=self.grad_clip, use_mask=True, split=split, pipeline=pipe)   # forget.py:289-299
@@ -486,7 +496,8 @@ class DiTSFRon:
             self.model.engine.fp8_requantize()
         beside = split is not None and split["stream"] is not None
         mse_r, vb_r = self._pass(remain, remain["y"], 1.0, factored_ada=True, block_ready=bs["handles"] if beside else None,
-                                 async_exchange=dp_sync, between=self.opt.take_deferred())
+                                 async_exchange=dp_sync, between=self.opt.take_deferred(),
+                                 ada_ready=split.get("ada_done") if beside else None)
         pipe, self._pipeline = self._pipeline, None
         nt = eng.n_trainable
         self._fp8_before_sweep(fused_q)
@@ -496,13 +507,15 @@ class DiTSFRon:
         across = beside and self.sweep_across_steps
         if across:
             split_r = dict(ranges=bs["ranges"], stream=bs["stream"], events=bs["events"], max_workgroups=self.sweep_beside_wg,
-                           head=self.sweep_beside_head, quant=quant, defer=self.defer_sweep_launch)
+                           head=self.sweep_beside_head, quant=quant, defer=self.defer_sweep_launch, ada_side=self.ada_side)
         else:
             split_r = dict(ranges=bs["ranges"], stream=None, quant=quant) if fused_q else None
         self.opt.step(max_norm=None, use_mask=False, ema=self.ema[:nt], ema_decay=self.ema_decay, ema_mode=1,   # :320,322
                       split=split_r, pipeline=pipe)
         if across:
             self._ready_owner, eng._sweep_pending = (eng, bs["handles"]), bs["stream"]
+            if split_r.get("ada_done") is not None:
+                eng._shared["ada_done"] = split_r["ada_done"]
             fn = self.opt.take_deferred()
             if fn is not None:
                 eng._shared["deferred"] = fn       # launched by the next step's forward pass (or by drain_sweep, whichever comes first)

@@ -191,13 +191,29 @@ class FlatAdam:
                 head = int(split.get("head", 0)) if side is not None else len(rngs)
                 first_own = 0 if quant is not None else head
                 excl = (rngs[first_own][0], rngs[-1][1]) if first_own < len(rngs) else None
+            # ada_side: the adaLN matrix (a third of the parameters, ~1.1 ms at the HBM rate) is swept on the second stream, in FRONT of the block
+            # ranges that go there, at full grid: what this stream still holds -- the head ranges, then the next pass's noising and conditioning
+            # prologue, ~20 small launches -- runs beside it; the pass waits for split["ada_done"] in front of its adaLN product (engine.forward)
+            ada_side = (split is not None and excl is not None and bool(split.get("ada_side")) and split.get("stream") is not None
+                        and head < len(rngs))
+            if split is not None:
+                split["ada_done"] = None
             for lo, hi, lr in self._segments(excl):
                 if lr:
                     q = self.lowrank
+                    sp = stream_ptr()
+                    if ada_side:
+                        fork = _t.cuda.Event()
+                        fork.record(_t.cuda.current_stream())       # behind the clip coefficient and everything that read the old matrix
+                        split["stream"].wait_event(fork)
+                        sp = ctypes.c_void_p(split["stream"].cuda_stream)
                     check(L.sfron_adam_lowrank(ptr(self.p[lo:hi]), ptr(self.m[lo:hi]), ptr(self.v[lo:hi]), ptr(sl(mask, lo, hi)), ptr(stats),
                                                ptr(q["dmod"]), ptr(q["sc"]), q["R"], q["NM"], q["D"], b1, b2, self.eps, step_size, bc2_sqrt,
                                                decay_mul, ptr(sl(self.w_bf16, lo, hi)), ptr(sl(ema, lo, hi)), float(ema_decay), emode,
-                                               stream_ptr()), "adam_lowrank")
+                                               sp), "adam_lowrank")
+                    if ada_side:
+                        split["ada_done"] = _t.cuda.Event()
+                        split["ada_done"].record(split["stream"])
                 else:
                     check(L.sfron_masked_clip_adam(ptr(self.p[lo:hi]), ptr(self.g[lo:hi]), ptr(sl(self.g2, lo, hi)), ptr(self.m[lo:hi]),
                                                    ptr(self.v[lo:hi]), ptr(sl(mask, lo, hi)), ptr(stats), hi - lo, b1, b2, self.eps,
