@@ -119,17 +119,19 @@ def test_conv3x3_forward_dgrad_wgrad(form):
     np.testing.assert_allclose(_nchw(ds.cpu(), B, H, H).numpy(), xt.grad.numpy(), rtol=3e-4, atol=3e-4 * math.sqrt(9 * co))
 
 
-@pytest.mark.parametrize("form", ["rows", "slabs"])
+@pytest.mark.parametrize("form", ["rows", "slabs", "rows64"])
 @pytest.mark.parametrize("C,HW,swish,drop", [(128, 64, 1, False), (256, 16, 1, True), (64, 256, 0, False), (384, 64, 1, True), (320, 1024, 1, False),
                                              (1280, 64, 1, True), (2560, 16, 1, False)])
 def test_groupnorm_swish_dropout_fwd_bwd(C, HW, swish, drop, form):
-    """form "rows": the row-coalesced two-phase kernels (scratch given); "slabs": the per-(sample, group) kernels (no scratch).
+    """form "rows": the row-coalesced two-phase kernels (scratch given); "slabs": the per-(sample, group) kernels (no scratch); "rows64": batch 64,
+    where the rule takes the one-launch form (k_gn3_*: a workgroup per sample and block of whole groups; round 6) for every shape here.
     Channels per group 2 .. 80, including the LDM widths (10, 40, 80: not powers of two) and more than 1024 channels."""
     from sfron import _lib
     from sfron._lib import check, ptr, stream_ptr
     L = _lib.lib()
     g = torch.Generator().manual_seed(C + HW)
-    B = 3
+    B = 64 if form == "rows64" else 3
+    form = "rows" if form == "rows64" else form
     x = torch.randn(B * HW, C, generator=g) * 1.5 + 0.3
     gamma, beta = torch.randn(C, generator=g) * 0.5 + 1.0, torch.randn(C, generator=g) * 0.2
     mask = (torch.rand(B * HW, C, generator=g) > 0.1).to(torch.uint8) if drop else None

@@ -1304,6 +1304,211 @@ __global__ __launch_bounds__(GNB) void k_gn2_bwd_apply(const float* __restrict__
   }
 }
 
+// ---- GroupNorm in ONE launch per direction (round 6): a workgroup owns one sample and a block of `gpb` whole groups = Cs = gpb * C / G
+// consecutive channels over ALL pixels -- statistics and normalisation never leave the workgroup, so the two phases of the k_gn2 pair (and the
+// ~5 us boundary between two dependent launches, which at the 16 x 16 ... 4 x 4 levels of the DDPM U-Net is as long as either phase) become
+// two passes of one kernel over a slab of at most 128 KB that the second pass finds in L2.  B * G / gpb workgroups (DDPM batch 64: 256 .. 1024):
+// the chip stays full, which one workgroup per sample (round 5, profiles/r05_ab_log.txt) did not manage.  Rows are runs of Cs floats
+// (>= 64 bytes), read as float4 by (row replica r, quad q) threads.  The same arithmetic per element as k_gn2_*; the sums run over this
+// workgroup's rows in a fixed order (replica r takes rows r, r + rpp, ...; replicas, then channels, are added in index order): bitwise
+// reproducible, not bit-identical to the chunked pair.
+constexpr int GN3_T = 1024;
+struct Gn3Map {
+  int b, g0, c0, Cs, qpr, rpp, q, r;
+  bool on;
+  __device__ __forceinline__ void init(int C, int G, int gpb) {
+    const int ncb = G / gpb, cg = C / G;
+    b = blockIdx.x / ncb;
+    g0 = (blockIdx.x - b * ncb) * gpb; c0 = g0 * cg; Cs = gpb * cg; qpr = Cs >> 2; rpp = GN3_T / qpr;
+    r = threadIdx.x / qpr; q = threadIdx.x - r * qpr; on = r < rpp;
+  }
+};
+__global__ __launch_bounds__(GN3_T) void k_gn3_fwd(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   int HW, int C, int G, int gpb, float eps, int swish, const uint8_t* __restrict__ mask,
+                                                   float drop_scale, __bf16* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
+  __shared__ double shd[GN3_T * 4 * 2];         // [rpp][Cs][2], rpp * Cs <= 4 * GN3_T
+  __shared__ float st[2][64];
+  Gn3Map m; m.init(C, G, gpb);
+  const int cg = C / G;
+  const float* xb = x + (size_t)m.b * HW * ldx + m.c0 + 4 * m.q;
+  double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
+  if (m.on) {
+#pragma unroll 8
+    for (int p = m.r; p < HW; p += m.rpp) {
+      const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)p * ldx);
+      s[0] += v.x; ss[0] += (double)v.x * v.x; s[1] += v.y; ss[1] += (double)v.y * v.y;
+      s[2] += v.z; ss[2] += (double)v.z * v.z; s[3] += v.w; ss[3] += (double)v.w * v.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      shd[((size_t)m.r * m.Cs + 4 * m.q + e) * 2] = s[e]; shd[((size_t)m.r * m.Cs + 4 * m.q + e) * 2 + 1] = ss[e];
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, per = m.rpp * cg;
+  for (int g = threadIdx.x >> 6; g < gpb; g += GN3_T / 64) {      // one wave per group at a time, as k_gn2_stats
+    double a = 0.0, q = 0.0;
+    for (int i = lane; i < per; i += 64) {
+      const int r = i / cg, c = g * cg + (i - r * cg);
+      a += shd[((size_t)r * m.Cs + c) * 2]; q += shd[((size_t)r * m.Cs + c) * 2 + 1];
+    }
+    a = wave_sum_d(a); q = wave_sum_d(q);
+    if (lane == 0) {
+      const double n = (double)HW * cg, mu = a / n;
+      double var = q / n - mu * mu;                 // biased variance, as torch.nn.GroupNorm
+      var = var < 0 ? 0 : var;
+      st[0][g] = (float)mu; st[1][g] = (float)(1.0 / sqrt(var + (double)eps));
+      mean[m.b * G + m.g0 + g] = st[0][g]; rstd[m.b * G + m.g0 + g] = st[1][g];
+    }
+  }
+  __syncthreads();
+  if (!m.on) return;
+  float mu[4], rs[4], ga[4], be[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = 4 * m.q + e, gi = c / cg;
+    mu[e] = st[0][gi]; rs[e] = st[1][gi]; ga[e] = gamma[m.c0 + c]; be[e] = beta[m.c0 + c];
+  }
+  __bf16* yb = y + (size_t)m.b * HW * C + m.c0 + 4 * m.q;
+  const uint8_t* mb = mask ? mask + (size_t)m.b * HW * C + m.c0 + 4 * m.q : nullptr;
+#pragma unroll 8
+  for (int p = m.r; p < HW; p += m.rpp) {
+    const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)p * ldx);
+    float z[4] = {v.x, v.y, v.z, v.w};
+    uchar4 mk = make_uchar4(1, 1, 1, 1);
+    if (mb) mk = *reinterpret_cast<const uchar4*>(mb + (size_t)p * C);
+    const uint8_t mke[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = (z[e] - mu[e]) * rs[e] * ga[e] + be[e];
+      if (swish) t = silu(t);
+      if (mb) t = mke[e] ? t * drop_scale : 0.f;
+      z[e] = t;
+    }
+    *reinterpret_cast<bf16x4*>(yb + (size_t)p * C) = bf16x4{f2bf(z[0]), f2bf(z[1]), f2bf(z[2]), f2bf(z[3])};
+  }
+}
+// backward of the same decomposition: pass 1 = per-channel sums of dz xhat and dz over the sample (the parameter-gradient partials pg / pb of
+// this sample, complete here) -> the group means k1, k2; pass 2 = dx (+)= rstd (dz gamma - k1 - xhat k2), every output form of k_gn2_bwd_apply
+// (fp32 with accumulate / extra, bf16 operand copy, per-sample column sums: colpart keeps the caller's [B][nchunk][C] layout -- chunk 0 gets the
+// sample's sum, the other chunks zeros)
+__global__ __launch_bounds__(GN3_T) void k_gn3_bwd(const float* __restrict__ dy, const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                   int HW, int C, int G, int gpb, int swish, const uint8_t* __restrict__ mask, float drop_scale,
+                                                   float* __restrict__ dx, int lddx, int accumulate, float* __restrict__ pg, float* __restrict__ pb,
+                                                   const float* __restrict__ extra, int ldextra, __bf16* __restrict__ dx16,
+                                                   float* __restrict__ colpart, int nchunk) {
+  __shared__ float shf[GN3_T * 4 * 2];          // [rpp][Cs][2]; afterwards [rpp][Cs] column sums
+  __shared__ float chs[GN3_T * 4 * 2 / (GN3_T / 256)];          // [Cs][2] channel sums, Cs <= 1024
+  __shared__ float kk[2 * 64];
+  Gn3Map m; m.init(C, G, gpb);
+  const int cg = C / G;
+  float mu[4], rs[4], ga[4], be[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = 4 * m.q + e, gi = m.g0 + c / cg;
+    mu[e] = 0.f; rs[e] = 0.f; ga[e] = 0.f; be[e] = 0.f;
+    if (m.on) { mu[e] = mean[m.b * G + gi]; rs[e] = rstd[m.b * G + gi]; ga[e] = gamma[m.c0 + c]; be[e] = beta[m.c0 + c]; }
+  }
+  const float* xb = x + (size_t)m.b * HW * ldx + m.c0 + 4 * m.q;
+  const float* dyb = dy + (size_t)m.b * HW * C + m.c0 + 4 * m.q;
+  const uint8_t* mb = mask ? mask + (size_t)m.b * HW * C + m.c0 + 4 * m.q : nullptr;
+  if (m.on) {
+    float ca[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int p = m.r; p < HW; p += m.rpp) {
+      const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)p * ldx);
+      const float4 dv = *reinterpret_cast<const float4*>(dyb + (size_t)p * C);
+      uchar4 mk = make_uchar4(1, 1, 1, 1);
+      if (mb) mk = *reinterpret_cast<const uchar4*>(mb + (size_t)p * C);
+      const float xv[4] = {v.x, v.y, v.z, v.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+      const uint8_t mke[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xv[e] - mu[e]) * rs[e];
+        float d = dd[e];
+        if (mb) d = mke[e] ? d * drop_scale : 0.f;
+        if (swish) d *= silu_grad(xh * ga[e] + be[e]);
+        ca[e] += d * xh; cb[e] += d;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      shf[((size_t)m.r * m.Cs + 4 * m.q + e) * 2] = ca[e]; shf[((size_t)m.r * m.Cs + 4 * m.q + e) * 2 + 1] = cb[e];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < m.Cs; c += GN3_T) {
+    float a = 0.f, q = 0.f;
+    for (int r = 0; r < m.rpp; ++r) { a += shf[((size_t)r * m.Cs + c) * 2]; q += shf[((size_t)r * m.Cs + c) * 2 + 1]; }
+    chs[2 * c] = a; chs[2 * c + 1] = q;
+    pg[(size_t)m.b * C + m.c0 + c] = a; pb[(size_t)m.b * C + m.c0 + c] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x < gpb) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int c = threadIdx.x * cg; c < (threadIdx.x + 1) * cg; ++c) { const float g1 = gamma[m.c0 + c]; t1 += g1 * chs[2 * c + 1]; t2 += g1 * chs[2 * c]; }
+    const float inv = 1.0f / ((float)HW * (float)cg);
+    kk[2 * threadIdx.x] = t1 * inv; kk[2 * threadIdx.x + 1] = t2 * inv;
+  }
+  __syncthreads();
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  if (m.on) {
+    float k1[4], k2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int gi = (4 * m.q + e) / cg; k1[e] = kk[2 * gi]; k2[e] = kk[2 * gi + 1]; }
+    float* dxb = dx ? dx + (size_t)m.b * HW * lddx + m.c0 + 4 * m.q : nullptr;
+    __bf16* d16b = dx16 ? dx16 + (size_t)m.b * HW * C + m.c0 + 4 * m.q : nullptr;
+    const float* exb = extra ? extra + (size_t)m.b * HW * ldextra + m.c0 + 4 * m.q : nullptr;
+#pragma unroll 4
+    for (int p = m.r; p < HW; p += m.rpp) {
+      const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)p * ldx);
+      const float4 dv = *reinterpret_cast<const float4*>(dyb + (size_t)p * C);
+      uchar4 mk = make_uchar4(1, 1, 1, 1);
+      if (mb) mk = *reinterpret_cast<const uchar4*>(mb + (size_t)p * C);
+      const float xv[4] = {v.x, v.y, v.z, v.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+      const uint8_t mke[4] = {mk.x, mk.y, mk.z, mk.w};
+      float4* op = dxb ? reinterpret_cast<float4*>(dxb + (size_t)p * lddx) : nullptr;
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+      if (accumulate) { const float4 c = *op; o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w; }
+      if (exb) {
+        const float4 c = *reinterpret_cast<const float4*>(exb + (size_t)p * ldextra);
+        o[0] += c.x; o[1] += c.y; o[2] += c.z; o[3] += c.w;
+      }
+      const bool acc = accumulate || exb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xv[e] - mu[e]) * rs[e];
+        float d = dd[e];
+        if (mb) d = mke[e] ? d * drop_scale : 0.f;
+        if (swish) d *= silu_grad(xh * ga[e] + be[e]);
+        const float vv = rs[e] * (d * ga[e] - k1[e] - xh * k2[e]);
+        o[e] = acc ? o[e] + vv : vv;
+      }
+      if (op) *op = make_float4(o[0], o[1], o[2], o[3]);
+      if (d16b) *reinterpret_cast<bf16x4*>(d16b + (size_t)p * C) = bf16x4{f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+      if (colpart) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cs[e] += o[e];
+      }
+    }
+  }
+  if (colpart) {
+    __syncthreads();                            // every reader of shf's channel partials is done
+    if (m.on) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) shf[(size_t)m.r * m.Cs + 4 * m.q + e] = cs[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < m.Cs; c += GN3_T) {
+      float a = 0.f;
+      for (int r = 0; r < m.rpp; ++r) a += shf[(size_t)r * m.Cs + c];
+      colpart[((size_t)m.b * nchunk) * C + m.c0 + c] = a;
+      for (int k = 1; k < nchunk; ++k) colpart[((size_t)m.b * nchunk + k) * C + m.c0 + c] = 0.f;
+    }
+  }
+}
+
 // ---- softmax over rows of length n (fp32 in, bf16 out), one wave per row; backward dS = scale * P * (dP - sum(P dP))
 // rows of `n` stored elements of which the first `nv` are keys (the rest is padding of the context length: probability 0)
 __global__ __launch_bounds__(TPB) void k_softmax_fwd(const float* __restrict__ s, int64_t rows, int n, int nv, float scale, __bf16* __restrict__ p) {
@@ -2194,6 +2399,15 @@ int sfron_rows_to_nchw(const float* rows, int ld, int B, int C, int HW, float* x
   return SFRON_OK;
 }
 
+// debug build only (tools/ A-B runs): SFRON_GN_ONE_LAUNCH=0 in the environment keeps every GroupNorm on the two-phase pair
+static bool gn3_off() {
+#ifdef SFRON_DEBUG_KNOBS
+  static const bool v = [] { const char* e = getenv("SFRON_GN_ONE_LAUNCH"); return e && e[0] == '0'; }();
+  return v;
+#else
+  return false;
+#endif
+}
 /* scratch (bytes) the row-coalesced GroupNorm needs for a [B][HW][C] activation: per-chunk partial sums (forward fp64 per group,
  * backward fp32 per channel) */
 int64_t sfron_groupnorm_scratch_bytes(int B, int HW, int C, int groups) {
@@ -2205,6 +2419,27 @@ int64_t sfron_groupnorm_scratch_bytes(int B, int HW, int C, int groups) {
 static bool gn2_ok(int ldx, int ld2, int C, int groups, const void* scratch) {
   return scratch && C % 4 == 0 && ldx % 4 == 0 && ld2 % 4 == 0 && C <= GN_MAXQ * 4 * GNB && groups <= 64 && ((uintptr_t)scratch & 15) == 0;
 }
+// groups per workgroup of the one-launch form (k_gn3_*), 0 = the two-phase pair: whole groups whose channels form float4 quads and runs that are
+// multiples of half a cache line (a 96-byte run straddles lines: measured 1.7x slower than the pair), at least 192 workgroups, and a slab of at
+// most 128 KB per workgroup (its second pass is an L2 hit) -- or, with eight groups in whole-line runs, up to 512 KB (second pass from the
+// Infinity Cache, as the pair's)
+static int gn3_gpb(int B, int HW, int C, int groups) {
+  if (gn3_off()) return 0;
+  const int cg = C / groups;
+  for (const int gpb : {8, 4, 2, 1}) {
+    if (groups % gpb) continue;
+    const int Cs = gpb * cg;
+    if (Cs % 16 || Cs > 1024) continue;
+    if ((int64_t)HW * Cs * 4 > (128 << 10)) continue;
+    if ((int64_t)B * (groups / gpb) < 192) continue;
+    return gpb;
+  }
+  if (groups % 8 == 0) {
+    const int Cs = 8 * cg;
+    if (Cs % 32 == 0 && Cs <= 1024 && (int64_t)HW * Cs * 4 <= (512 << 10) && (int64_t)B * (groups / 8) >= 192) return 8;
+  }
+  return 0;
+}
 static size_t gn2_lds(int C, int elem) {
   const int qpr = C / 4, qw = qpr < GNB ? qpr : GNB, rpp = GNB / qw;
   return (size_t)rpp * C * 2 * elem;
@@ -2214,6 +2449,12 @@ int sfron_groupnorm_fwd(const float* x, int ldx, const float* gamma, const float
                         void* stream) {
   SFRON_CHECK_ARG(x && gamma && beta && y && mean && rstd && groups > 0 && C % groups == 0 && ldx >= C && C / groups <= TPB);
   if (gn2_ok(ldx, C, C, groups, scratch) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 && (!drop_mask || ((uintptr_t)drop_mask & 3) == 0)) {
+    if (const int gpb = gn3_gpb(B, HW, C, groups)) {
+      hipLaunchKernelGGL(k_gn3_fwd, dim3(B * (groups / gpb)), dim3(GN3_T), 0, (hipStream_t)stream, x, ldx, gamma, beta, HW, C, groups, gpb, eps, swish,
+                         drop_mask, drop_scale, (__bf16*)y, mean, rstd);
+      SFRON_LAUNCH_STATUS();
+      return SFRON_OK;
+    }
     const int nchunk = gn_chunks(B, HW);
     hipLaunchKernelGGL(k_gn2_stats, dim3(B * nchunk), dim3(GNB), gn2_lds(C, sizeof(double)), (hipStream_t)stream, x, ldx, HW, C, groups, nchunk,
                        (double*)scratch);
@@ -2250,6 +2491,12 @@ int sfron_groupnorm_bwd_res(const float* dy, const float* x, int ldx, const floa
     extra = nullptr; accumulate = 1;
   }
   if (fused) {
+    if (const int gpb = gn3_gpb(B, HW, C, groups)) {
+      hipLaunchKernelGGL(k_gn3_bwd, dim3(B * (groups / gpb)), dim3(GN3_T), 0, (hipStream_t)stream, dy, x, ldx, gamma, beta, mean, rstd, HW, C, groups, gpb,
+                         swish, drop_mask, drop_scale, dx, lddx, accumulate, part_gamma, part_beta, extra, ld_extra, (__bf16*)nullptr, (float*)nullptr, 1);
+      SFRON_LAUNCH_STATUS();
+      return SFRON_OK;
+    }
     const int nchunk = gn_chunks(B, HW);
     hipLaunchKernelGGL(k_gn2_bwd_stats, dim3(B * nchunk), dim3(GNB), gn2_lds(C, sizeof(float)), (hipStream_t)stream, dy, x, ldx, gamma, beta, mean, rstd,
                        HW, C, groups, swish, drop_mask, drop_scale, nchunk, (float*)scratch);
@@ -2279,6 +2526,13 @@ int sfron_groupnorm_bwd_cast(const float* dy, const float* x, int ldx, const flo
   SFRON_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)scratch) & 15) == 0 && ((uintptr_t)dx_bf16 & 7) == 0 &&
                   (!drop_mask || ((uintptr_t)drop_mask & 3) == 0));
   const int nchunk = gn_chunks(B, HW);
+  if (const int gpb = gn3_gpb(B, HW, C, groups)) {
+    hipLaunchKernelGGL(k_gn3_bwd, dim3(B * (groups / gpb)), dim3(GN3_T), 0, (hipStream_t)stream, dy, x, ldx, gamma, beta, mean, rstd, HW, C, groups, gpb,
+                       swish, drop_mask, drop_scale, (float*)nullptr, C, 0, part_gamma, part_beta, (const float*)nullptr, 0, (__bf16*)dx_bf16,
+                       col_partials, nchunk);
+    SFRON_LAUNCH_STATUS();
+    return SFRON_OK;
+  }
   hipLaunchKernelGGL(k_gn2_bwd_stats, dim3(B * nchunk), dim3(GNB), gn2_lds(C, sizeof(float)), (hipStream_t)stream, dy, x, ldx, gamma, beta, mean, rstd,
                      HW, C, groups, swish, drop_mask, drop_scale, nchunk, (float*)scratch);
   SFRON_LAUNCH_STATUS();
