@@ -490,6 +490,13 @@ int sfron_ln_gate_bwd(const uint16_t* d_out, const float* x, const float* mean, 
 /* out[g * ldout + c] (+)= sum_{j < per_group} partials[(g * per_group + j) * D + c]   (fixed order, reproducible) */
 int sfron_reduce_chunks(const float* partials, int groups, int per_group, int D, float* out, int ldout, int accumulate,
                         void* stream);
+/* MANY fixed-order reductions in ONE launch (round 6): item i computes out[g * ldout + c] = sum_{j < per_group} partials[(g * per_group + j) * D + c]
+ * for g < groups, c < D -- exactly what sfron_reduce_chunks(partials, groups, per_group, D, out, ldout, 0) computes, in the same order, bit for
+ * bit.  `items` is a HOST array: the items travel by value in the kernel arguments (120 per launch), so there is no device table to build or to
+ * keep alive and the call may be captured into a graph.  The parameter-gradient finishes of a U-Net backward pass (GroupNorm / LayerNorm affine
+ * gradients, bias gradients, per-sample projection gradients: ~190 launches of ~5 us per DDPM step) are collected by the tape and issued once. */
+typedef struct sfron_reduce_item { const float* partials; float* out; int groups, per_group, D, ldout; } sfron_reduce_item;
+int sfron_reduce_batch(const sfron_reduce_item* items /* HOST */, int n_items, void* stream);
 /* two partial buffers in one launch: out0[g*ld0 + c] = sum_j p0[(g*per_group + j)*D + c], out1 likewise from p1 */
 int sfron_reduce2(const float* p0, const float* p1, int groups, int per_group, int D, float* out0, int ld0, float* out1,
                   int ld1, void* stream);

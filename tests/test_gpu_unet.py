@@ -506,6 +506,60 @@ def test_unet_draws_its_dropout_masks_in_one_launch_from_the_second_pass_on():
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("B", [8, 64])
+def test_parameter_gradient_finishes_in_one_launch_equal_the_separate_launches(B):
+    """sfron_reduce_batch (round 6): the fixed-order sums that finish GroupNorm affine gradients, conv1 bias gradients and the per-sample
+    projection gradients are collected by the tape and issued as one launch per backward pass (items by value in the kernel arguments).  Each
+    item is summed in the order its own sfron_reduce_chunks launch would use: every gradient equals the unbatched pass bit for bit -- at
+    batch 8 (two-phase GroupNorm, chunked partials) and at batch 64 (one-launch GroupNorm, the wide reduction form)."""
+    _, model = _pair(dict(SMALL, dropout=0.0), seed=43)
+    model.train()
+    g = torch.Generator().manual_seed(3)
+    x, t = torch.randn(B, 3, 16, 16, generator=g).to(DEV), torch.randint(0, 1000, (B,), generator=g).float().to(DEV)
+    c, keep = torch.randint(0, 10, (B,), generator=g).to(DEV), torch.ones(B, dtype=torch.uint8, device=DEV)
+    w = torch.randn(B, 3, 16, 16, generator=g).to(DEV)
+    grads = {}
+    assert model.BATCH_REDUCTIONS is True
+    try:
+        for batched in (True, False, True):
+            model.BATCH_REDUCTIONS = batched
+            model.grads.fill_(float("nan"))
+            out, bwd = model._run(x, t, c, keep, None, need_grad=True)
+            bwd(w.clone())
+            assert model._red is None
+            grads.setdefault(batched, []).append(model.grads.clone())
+    finally:
+        model.BATCH_REDUCTIONS = True
+    for n in model.index:
+        a, b, a2 = (model.view(v, n) for v in (grads[True][0], grads[False][0], grads[True][1]))
+        assert torch.isfinite(a).all(), n
+        assert torch.equal(a, b) and torch.equal(a, a2), n
+
+
+def test_reduce_batch_many_items_of_both_forms():
+    """More items than one launch carries (120), both summation forms, odd widths, strided outputs: against sfron_reduce_chunks item by item."""
+    import ctypes
+    from sfron import _lib
+    from sfron._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(9)
+    shapes = [(1, 64, 128), (1, 512, 320), (64, 8, 256), (3, 5, 7), (1, 1, 1280), (2, 130, 66), (1, 96, 1000)] * 20      # 140 items
+    items, want, keep = (_lib.ReduceItem * len(shapes))(), [], []
+    for it, (groups, per, D) in zip(items, shapes):
+        P = torch.randn(groups * per, D, generator=g).to(DEV)
+        ld = D + 4
+        o1 = torch.full((groups, ld), 7.0, device=DEV)
+        o2 = torch.full((groups, ld), 7.0, device=DEV)
+        check(L.sfron_reduce_chunks(ptr(P), groups, per, D, o1.data_ptr(), ld, 0, stream_ptr()), "reduce_chunks")
+        it.partials, it.out, it.groups, it.per_group, it.D, it.ldout = P.data_ptr(), o2.data_ptr(), groups, per, D, ld
+        want.append(o1); keep.append((P, o2))
+    check(L.sfron_reduce_batch(ctypes.cast(items, ctypes.c_void_p), len(shapes), stream_ptr()), "reduce_batch")
+    torch.cuda.synchronize()
+    for o1, (_, o2) in zip(want, keep):
+        assert torch.equal(o1, o2)
+    assert L.sfron_reduce_batch(None, 1, stream_ptr()) != 0
+
+
 def test_unet_forward_backward_bitwise_reproducible():
     """Three repetitions of the same forward + backward with different garbage in freed memory in between: every output and every
     gradient bit agrees (no floating-point atomics, no read of uninitialised scratch; the up-path GroupNorms have 12 channels per

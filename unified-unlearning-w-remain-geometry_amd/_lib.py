@@ -85,6 +85,7 @@ _PROTOS.update({
     "sfron_weighted_reduce": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, _S]),
     "sfron_reduce_slots": (c_int, [_P, ctypes.c_long, c_int, c_int, c_int, c_int, POINTER(c_void_p), POINTER(ctypes.c_long),
                                    POINTER(c_int), _S]),
+    "sfron_reduce_batch": (c_int, [_P, c_int, _S]),
     "sfron_reduce2": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _S]),
     "sfron_gated_bias_grads": (c_int, [_P, _P, c_int, ctypes.c_long, ctypes.c_long, c_int, c_int, c_int, _P, ctypes.c_long,
                                        ctypes.c_long, ctypes.c_long, _S]),
@@ -136,6 +137,11 @@ class BGemmDesc(ctypes.Structure):
                 ("bias", c_void_p), ("c_bf16", c_void_p), ("c_f32", c_void_p), ("ldc", c_int), ("resid", c_void_p),
                 ("sample_vec", c_void_p), ("ld_vec", c_int), ("rows_per_sample", c_int), ("accumulate", c_int),
                 ("split_ws", c_void_p), ("split_ws_slabs", c_int)]
+
+
+class ReduceItem(ctypes.Structure):
+    """Mirror of sfron_reduce_item."""
+    _fields_ = [("partials", c_void_p), ("out", c_void_p), ("groups", c_int), ("per_group", c_int), ("D", c_int), ("ldout", c_int)]
 
 
 class ConvDesc(ctypes.Structure):

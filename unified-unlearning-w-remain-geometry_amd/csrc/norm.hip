@@ -359,12 +359,75 @@ __global__ __launch_bounds__(64 * RC_WAVES) void k_reduce_chunks_wide(const floa
 }
 // which of the two forms a reduction takes (a pure function of its shape: the same call always sums in the same order)
 static inline bool reduce_chunks_wide(int groups, int per_group, int D) { return per_group >= 64 && (long)cdiv(D, 64) * groups <= 512; }
+__device__ __forceinline__ bool reduce_chunks_wide_d(int groups, int per_group, int D) { return per_group >= 64 && (long)((D + 63) / 64) * groups <= 512; }
 static inline void launch_reduce_chunks(const float* partials, int groups, int per_group, int D, float* out, int ldout, int accumulate,
                                         hipStream_t hs) {
   if (reduce_chunks_wide(groups, per_group, D))
     hipLaunchKernelGGL(k_reduce_chunks_wide, dim3(cdiv(D, 64), groups), dim3(64 * RC_WAVES), 0, hs, partials, per_group, D, out, ldout, accumulate);
   else
     hipLaunchKernelGGL(k_reduce_chunks, dim3(cdiv(D, TPB), groups), dim3(TPB), 0, hs, partials, per_group, D, out, ldout, accumulate);
+}
+
+// MANY such reductions in one launch (round 6): the items travel BY VALUE in the kernel arguments (no table in memory: nothing to build, copy
+// or keep alive, and a captured graph node holds its own copy), blockIdx.y picks the item.  Each item is summed in the order its own launch
+// would use -- the rule above picks the form from the item's shape -- so a batch gives, bit for bit, what the separate launches give.
+constexpr int RB_ITEMS = 120;                    // 120 x 32 bytes of the 4 KB a kernel may take as arguments
+struct ReducePack { sfron_reduce_item it[RB_ITEMS]; };
+__global__ __launch_bounds__(64 * RC_WAVES) void k_reduce_batch(ReducePack pack) {
+  __shared__ float sh[RC_WAVES][64];
+  const sfron_reduce_item it = pack.it[blockIdx.y];
+  const int per = it.per_group, D = it.D;
+  if (reduce_chunks_wide_d(it.groups, per, D)) {
+    const int ncb = (D + 63) / 64;
+    if ((int)blockIdx.x >= it.groups * ncb) return;                  // uniform per workgroup
+    const int g = blockIdx.x / ncb, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (blockIdx.x - g * ncb) * 64 + lane;
+    const int j0 = (int)((long)per * wave / RC_WAVES), j1 = (int)((long)per * (wave + 1) / RC_WAVES);
+    float s = 0.f;
+    if (c < D) {
+      const float* p = it.partials + (size_t)g * per * D + c;
+      int j = j0;
+      for (; j + 8 <= j1; j += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(j + u) * D];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; j < j1; ++j) s += p[(size_t)j * D];
+    }
+    sh[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < D) {
+      float a = sh[0][lane];
+#pragma unroll
+      for (int w = 1; w < RC_WAVES; ++w) a += sh[w][lane];
+      it.out[(size_t)g * it.ldout + c] = a;
+    }
+    return;
+  }
+  const long idx = (long)blockIdx.x * (64 * RC_WAVES) + threadIdx.x;
+  if (idx >= (long)it.groups * D) return;
+  const int g = (int)(idx / D), c = (int)(idx - (long)g * D);
+  const float* p = it.partials + (size_t)g * per * D + c;
+  float s = 0.f;
+  int j = 0;
+  for (; j + 16 <= per; j += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(j + u) * D];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += v[u];
+  }
+  for (; j + 4 <= per; j += 4) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = p[(size_t)(j + u) * D];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += v[u];
+  }
+  for (; j < per; ++j) s += p[(size_t)j * D];
+  it.out[(size_t)g * it.ldout + c] = s;
 }
 
 // out[c] = sum_b w[b * ldw + c] * sum_{j < per_group} P[(b * per_group + j) * D + c]   (bias grad behind a gate)
@@ -710,6 +773,29 @@ int sfron_reduce_chunks(const float* partials, int groups, int per_group, int D,
   SFRON_CHECK_ARG(partials && out && groups > 0 && per_group > 0 && D > 0);
   launch_reduce_chunks(partials, groups, per_group, D, out, ldout, accumulate, (hipStream_t)stream);
   SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_reduce_batch(const sfron_reduce_item* items, int n_items, void* stream) {
+  SFRON_CHECK_ARG(items && n_items > 0);
+  for (int i = 0; i < n_items; ++i)
+    SFRON_CHECK_ARG(items[i].partials && items[i].out && items[i].groups > 0 && items[i].per_group > 0 && items[i].D > 0 && items[i].ldout >= items[i].D);
+  for (int i0 = 0; i0 < n_items; i0 += RB_ITEMS) {
+    const int n = n_items - i0 < RB_ITEMS ? n_items - i0 : RB_ITEMS;
+    ReducePack pack;
+    long gx = 1;
+    for (int i = 0; i < n; ++i) {
+      const sfron_reduce_item& it = items[i0 + i];
+      pack.it[i] = it;
+      const long need = reduce_chunks_wide(it.groups, it.per_group, it.D) ? (long)it.groups * cdiv(it.D, 64)
+                                                                           : ((long)it.groups * it.D + 64 * RC_WAVES - 1) / (64 * RC_WAVES);
+      gx = need > gx ? need : gx;
+    }
+    for (int i = n; i < RB_ITEMS; ++i) pack.it[i] = pack.it[0];      // never indexed (blockIdx.y < n); defined bytes for the argument copy
+    SFRON_CHECK_ARG(gx <= 0x7fffffffL);
+    hipLaunchKernelGGL(k_reduce_batch, dim3((unsigned)gx, n), dim3(64 * RC_WAVES), 0, (hipStream_t)stream, pack);
+    SFRON_LAUNCH_STATUS();
+  }
   return SFRON_OK;
 }
 

@@ -181,7 +181,8 @@ class UNetModel(_TapeNet):
             check(_L().sfron_layernorm_bwd_res(ptr(dy), ptr(x.t), gam, ptr(mean), ptr(rstd), rows, D, ptr(g), acc, ptr(extra), ptr(pg), ptr(pb),
                                                stream_ptr()), "layernorm_bwd")
             if trains:
-                check(_L().sfron_reduce2(ptr(pg), ptr(pb), 1, nblk, D, self._g(name + ".weight"), D, self._g(name + ".bias"), D, stream_ptr()), "reduce2")
+                self._reduce(pg, 1, nblk, D, self._g(name + ".weight"), D)
+                self._reduce(pb, 1, nblk, D, self._g(name + ".bias"), D)
         return y, bwd
 
     def _mha(self, q, ldq, k, ldk, v, ldv, B, N, Lk, Lv, C, keep):
@@ -408,12 +409,18 @@ class UNetModel(_TapeNet):
             dr = torch.empty(B * h.H * h.W, v["cop"], dtype=torch.float32, device=dev)
             check(L.sfron_nchw_to_rows_f32(ptr(d_out.float().contiguous()), B, self.out_channels, h.H * h.W, v["cop"], ptr(dr), stream_ptr()),
                   "nchw_to_rows_f32")
-            gn_b(co_b(dr))
-            hook = getattr(self, "_tape_hook", None)           # debugging aid: called after every backward step
-            for i, step in enumerate(reversed(tape)):
-                step()
-                if hook is not None:
-                    hook(i, step)
+            self._reduce_begin()
+            try:
+                gn_b(co_b(dr))
+                hook = getattr(self, "_tape_hook", None)           # debugging aid: called after every backward step
+                for i, step in enumerate(reversed(tape)):
+                    step()
+                    if hook is not None:
+                        hook(i, step)
+            except BaseException:
+                self._red = None
+                raise
+            self._reduce_flush()                                   # every collected parameter-gradient finish, d_proj's slices included
             dpb = cast_rows(d_proj, PT, B, PT, dev)
             from .unet import colsum_f32
             colsum_f32(d_proj, B, PT, PT, self.grads.data_ptr() + 4 * self.proj_b_off, self._cs)
