@@ -434,6 +434,10 @@ int sfron_cast_rows_bf16(const float* x, int ldx, int64_t rows, int C, uint16_t*
  * `Linear` backward); partials: scratch of max_partials * C floats */
 int sfron_cast_rows_colsum(const float* x, int ldx, int64_t rows, int C, uint16_t* y, float* partials, int max_partials, float* colsum,
                            void* stream);
+/* The first half of sfron_cast_rows_colsum alone (round 6): y and the column-sum partials [*chunks_out][C]; the caller finishes with
+ * sfron_reduce_chunks(partials, 1, *chunks_out, C, colsum, C, 0) -- or collects that finish into a sfron_reduce_batch launch. */
+int sfron_cast_rows_colsum_partials(const float* x, int ldx, int64_t rows, int C, uint16_t* y, float* partials, int max_partials,
+                                    int* chunks_out /* HOST */, void* stream);
 /* y[r][0..C) (+)= x[r][0..C): channel-slice copies of torch.cat(dim=1) and its backward (:404) */
 /* keep mask of nn.Dropout(p) (DDPM/models/diffusion.py:131), 1 = kept with probability 1 - p: a counter-based draw keyed by
  * (seed, counter[0] on the device, salt, element); the caller advances the device counter once per pass */

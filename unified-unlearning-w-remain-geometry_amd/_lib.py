@@ -185,6 +185,7 @@ _PROTOS.update({
     "sfron_pool2_sum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _S]),
     "sfron_cast_rows_bf16": (c_int, [_P, c_int, c_int64, c_int, _P, _S]),
     "sfron_cast_rows_colsum": (c_int, [_P, c_int, c_int64, c_int, _P, _P, c_int, _P, _S]),
+    "sfron_cast_rows_colsum_partials": (c_int, [_P, c_int, c_int64, c_int, _P, _P, c_int, POINTER(c_int), _S]),
     "sfron_dropout_mask": (c_int, [ctypes.c_uint64, _P, c_int64, c_int64, c_float, _P, _S]),
     "sfron_dropout_mask_batch": (c_int, [ctypes.c_uint64, _P, _P, c_int, c_int64, c_float, _P, _S]),
     "sfron_conv_wprep_tiles": (c_int, [c_int, c_int]),

@@ -2667,7 +2667,15 @@ int sfron_cast_rows_bf16(const float* x, int ldx, int64_t rows, int C, uint16_t*
  * gradient); partials: scratch of at least max_partials * C floats */
 int sfron_cast_rows_colsum(const float* x, int ldx, int64_t rows, int C, uint16_t* y, float* partials, int max_partials, float* colsum,
                            void* stream) {
-  SFRON_CHECK_ARG(x && y && partials && colsum && rows > 0 && C > 0 && ldx >= C && max_partials > 0);
+  SFRON_CHECK_ARG(colsum);
+  int chunks = 0;
+  const int rc = sfron_cast_rows_colsum_partials(x, ldx, rows, C, y, partials, max_partials, &chunks, stream);
+  if (rc) return rc;
+  return sfron_reduce_chunks(partials, 1, chunks, C, colsum, C, 0, stream);
+}
+int sfron_cast_rows_colsum_partials(const float* x, int ldx, int64_t rows, int C, uint16_t* y, float* partials, int max_partials,
+                                    int* chunks_out, void* stream) {
+  SFRON_CHECK_ARG(x && y && partials && chunks_out && rows > 0 && C > 0 && ldx >= C && max_partials > 0);
   SFRON_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 7) == 0);
   // about 512 workgroups over (column blocks x row chunks), at least 32 rows per chunk, within the caller's scratch
   int64_t chunks = 512 / ((C + 255) / 256);
@@ -2679,7 +2687,8 @@ int sfron_cast_rows_colsum(const float* x, int ldx, int64_t rows, int C, uint16_
   hipLaunchKernelGGL((k_cast_rows4<true>), dim3((C + 255) / 256, (unsigned)chunks), dim3(TPB), 0, (hipStream_t)stream, x, ldx, rows, C, rpb, (__bf16*)y,
                      partials);
   SFRON_LAUNCH_STATUS();
-  return sfron_reduce_chunks(partials, 1, (int)chunks, C, colsum, C, 0, stream);
+  *chunks_out = (int)chunks;
+  return SFRON_OK;
 }
 int sfron_dropout_mask(uint64_t seed, const int64_t* counter, int64_t salt, int64_t n, float p, uint8_t* mask, void* stream) {
   SFRON_CHECK_ARG(counter && mask && n > 0 && p >= 0.f && p < 1.f && (((uintptr_t)mask) & 3) == 0);

@@ -302,6 +302,21 @@ class _TapeNet(nn.Module):
             return
         check(_L().sfron_reduce_chunks(ptr(partials), groups, per_group, D, out_addr, ldout, 0, stream_ptr()), "reduce_chunks")
 
+    def _cast_rows_colsum(self, x, ldx, rows, C, colsum_out):
+        """bf16 copy of fp32 rows + their column sums -> colsum_out (a bias gradient); inside a backward pass the sums' finish joins the pass's one
+        reduction launch (partials in a buffer of their own until then)."""
+        dev = self.device_
+        if self._red is None:
+            return cast_rows_colsum(x, ldx, rows, C, dev, colsum_out, self._cs)
+        y = torch.empty(rows, C, dtype=torch.bfloat16, device=dev)
+        nmax = max(1, min(512 // ((C + 255) // 256), (rows + 31) // 32))
+        part = torch.empty(nmax * C, dtype=torch.float32, device=dev)
+        nch = ctypes.c_int(0)
+        check(_L().sfron_cast_rows_colsum_partials(_addr(x), ldx, rows, C, ptr(y), ptr(part), nmax, ctypes.byref(nch), stream_ptr()),
+              "cast_rows_colsum_partials")
+        self._reduce(part, 1, nch.value, C, _addr(colsum_out), C)
+        return y
+
     def _reduce_begin(self):
         self._red = [] if self.BATCH_REDUCTIONS else None
 
@@ -389,7 +404,7 @@ class _TapeNet(nn.Module):
             if d_bf is not None:
                 dyb = d_bf
             elif trains and v["cop"] == v["co"] and v["co"] % 4 == 0:
-                dyb = cast_rows_colsum(d_out, v["cop"], rows, v["cop"], dev, self._g(name + ".bias"), self._cs)     # bf16 operand + bias gradient
+                dyb = self._cast_rows_colsum(d_out, v["cop"], rows, v["cop"], self._g(name + ".bias"))     # bf16 operand + bias gradient
             else:
                 dyb = cast_rows(d_out, v["cop"], rows, v["cop"], dev)
             if not trains or d_bf is not None:
@@ -454,7 +469,7 @@ class _TapeNet(nn.Module):
             leaves the product as bf16 [rows][cin] (its consumer is another product's operand: the rounding a cast pass would do)."""
             fused = d_bf is None and bias and not frozen and cout % 4 == 0 and ld_d % 4 == 0 and not isinstance(d_out, int)
             if fused:
-                d_bf = cast_rows_colsum(d_out, ld_d, rows, cout, dev, gb, self._cs)
+                d_bf = self._cast_rows_colsum(d_out, ld_d, rows, cout, gb)
             elif d_bf is None:
                 d_bf = cast_rows(d_out, ld_d, rows, cout, dev)
             if frozen:
