@@ -372,6 +372,13 @@ int sfron_conv_wprep_batch(const sfron_wprep_item* items_dev, int n_items, int n
 /* dw_gemm [n_slabs][c_out_p..][taps][c_in_p] -> OIHW gradient [c_out][c_in][taps] (overwrite; the slabs are added in order) */
 int sfron_conv_wgrad_scatter(const float* dw_gemm, int c_out, int c_in, int taps, int c_in_p, int n_slabs, int64_t slab_stride,
                              float* dw_oihw, void* stream);
+/* The scatters of MANY kernel gradients in ONE launch (round 6): item i is sfron_conv_wgrad_scatter(dw_gemm, c_out, c_in, taps, c_in_p, n_slabs,
+ * slab_stride, dw_oihw), bit for bit.  `items` is a HOST array (the items travel by value in the kernel arguments, 80 per launch; capturable).
+ * A U-Net backward pass keeps each layer's slabs in a buffer of the layer's own and issues the scatters once, behind its last product. */
+typedef struct sfron_wgrad_scatter_item {
+  const float* dw_gemm; float* dw_oihw; int64_t slab_stride; int c_out, c_in, taps, c_in_p, n_slabs, reserved;
+} sfron_wgrad_scatter_item;
+int sfron_conv_wgrad_scatter_batch(const sfron_wgrad_scatter_item* items /* HOST */, int n_items, void* stream);
 
 int sfron_nchw_to_rows_bf16(const float* x, int B, int C, int HW, int c_pad, uint16_t* rows, void* stream);
 int sfron_nchw_to_rows_f32(const float* x, int B, int C, int HW, int ld, float* rows, void* stream);

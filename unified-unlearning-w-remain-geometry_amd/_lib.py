@@ -86,6 +86,7 @@ _PROTOS.update({
     "sfron_reduce_slots": (c_int, [_P, ctypes.c_long, c_int, c_int, c_int, c_int, POINTER(c_void_p), POINTER(ctypes.c_long),
                                    POINTER(c_int), _S]),
     "sfron_reduce_batch": (c_int, [_P, c_int, _S]),
+    "sfron_conv_wgrad_scatter_batch": (c_int, [_P, c_int, _S]),
     "sfron_reduce2": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _S]),
     "sfron_gated_bias_grads": (c_int, [_P, _P, c_int, ctypes.c_long, ctypes.c_long, c_int, c_int, c_int, _P, ctypes.c_long,
                                        ctypes.c_long, ctypes.c_long, _S]),
@@ -142,6 +143,12 @@ class BGemmDesc(ctypes.Structure):
 class ReduceItem(ctypes.Structure):
     """Mirror of sfron_reduce_item."""
     _fields_ = [("partials", c_void_p), ("out", c_void_p), ("groups", c_int), ("per_group", c_int), ("D", c_int), ("ldout", c_int)]
+
+
+class WgradScatterItem(ctypes.Structure):
+    """Mirror of sfron_wgrad_scatter_item."""
+    _fields_ = [("dw_gemm", c_void_p), ("dw_oihw", c_void_p), ("slab_stride", c_int64), ("c_out", c_int), ("c_in", c_int), ("taps", c_int),
+                ("c_in_p", c_int), ("n_slabs", c_int), ("reserved", c_int)]
 
 
 class ConvDesc(ctypes.Structure):

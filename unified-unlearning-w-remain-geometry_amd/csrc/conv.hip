@@ -834,14 +834,13 @@ __global__ __launch_bounds__(TPB) void k_conv_wprep9_batch(const sfron_wprep_ite
   wprep9_tile(it.w, it.co, it.ci, it.co_p, it.ci_p, (__bf16*)it.fwd, (__bf16*)it.dgr, (local % tx) * 32, (local / tx) * 32, t);
 }
 // weight gradient fp32 [nslab][Co_p][taps][Ci_p] (GEMM output, split-K slabs) -> OIHW gradient (overwrite; slabs added in order)
-__global__ __launch_bounds__(TPB) void k_conv_wgrad_scatter(const float* __restrict__ g, int Co, int Ci, int taps, int Ci_p, int nslab,
-                                                            int64_t slab_stride, float* __restrict__ dw) {
+__device__ __forceinline__ void wgrad_scatter_block(const float* __restrict__ g, int Co, int Ci, int taps, int Ci_p, int nslab,
+                                                    int64_t slab_stride, float* __restrict__ dw, int co, int ci0, float* sh) {
   // one workgroup per (64 input channels, output channel): thread (tap group tg, channel c) sums the slabs of taps tg, tg + 4, tg + 8
   // (reads coalesced along ci), the [ci][tap] block is turned through LDS (row stride = taps, odd: no bank conflicts) and leaves as
   // one contiguous run of the OIHW gradient
   constexpr int CB = 64, TG = TPB / CB;
-  __shared__ float sh[CB * 9];
-  const int co = blockIdx.y, ci0 = blockIdx.x * CB, c = threadIdx.x % CB, tg = threadIdx.x / CB;
+  const int c = threadIdx.x % CB, tg = threadIdx.x / CB;
   const int nci = min(CB, Ci - ci0);
   if (c < nci)
     for (int t = tg; t < taps; t += TG) {
@@ -861,6 +860,22 @@ __global__ __launch_bounds__(TPB) void k_conv_wgrad_scatter(const float* __restr
   __syncthreads();
   float* o = dw + ((int64_t)co * Ci + ci0) * taps;
   for (int k = threadIdx.x; k < nci * taps; k += TPB) o[k] = sh[k];
+}
+__global__ __launch_bounds__(TPB) void k_conv_wgrad_scatter(const float* __restrict__ g, int Co, int Ci, int taps, int Ci_p, int nslab,
+                                                            int64_t slab_stride, float* __restrict__ dw) {
+  __shared__ float sh[64 * 9];
+  wgrad_scatter_block(g, Co, Ci, taps, Ci_p, nslab, slab_stride, dw, blockIdx.y, blockIdx.x * 64, sh);
+}
+// the scatters of MANY kernel gradients in one launch (round 6): the items travel by value in the kernel arguments, as k_reduce_batch's
+constexpr int WS_ITEMS = 80;                     // 80 x 48 bytes of the 4 KB of kernel arguments
+struct ScatterPack { sfron_wgrad_scatter_item it[WS_ITEMS]; };
+__global__ __launch_bounds__(TPB) void k_conv_wgrad_scatter_batch(ScatterPack pack) {
+  __shared__ float sh[64 * 9];
+  const sfron_wgrad_scatter_item it = pack.it[blockIdx.y];
+  const int ncb = (it.c_in + 63) / 64;
+  if ((int)blockIdx.x >= ncb * it.c_out) return;                  // uniform per workgroup
+  const int co = blockIdx.x / ncb, ci0 = (blockIdx.x - co * ncb) * 64;
+  wgrad_scatter_block(it.dw_gemm, it.c_out, it.c_in, it.taps, it.c_in_p, it.n_slabs, it.slab_stride, it.dw_oihw, co, ci0, sh);
 }
 
 // ---- layout: NCHW fp32 image <-> NHWC rows
@@ -2377,6 +2392,28 @@ int sfron_conv_wgrad_scatter(const float* dw_gemm, int c_out, int c_in, int taps
   hipLaunchKernelGGL(k_conv_wgrad_scatter, dim3((c_in + 63) / 64, c_out), dim3(TPB), 0, (hipStream_t)stream, dw_gemm,
                      c_out, c_in, taps, c_in_p, n_slabs, slab_stride, dw_oihw);
   SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+int sfron_conv_wgrad_scatter_batch(const sfron_wgrad_scatter_item* items, int n_items, void* stream) {
+  SFRON_CHECK_ARG(items && n_items > 0);
+  for (int i = 0; i < n_items; ++i)
+    SFRON_CHECK_ARG(items[i].dw_gemm && items[i].dw_oihw && items[i].n_slabs >= 1 && items[i].taps >= 1 && items[i].taps <= 9 && items[i].c_out > 0 &&
+                    items[i].c_in > 0 && items[i].c_in_p >= items[i].c_in);
+  for (int i0 = 0; i0 < n_items; i0 += WS_ITEMS) {
+    const int n = n_items - i0 < WS_ITEMS ? n_items - i0 : WS_ITEMS;
+    ScatterPack pack;
+    long gx = 1;
+    for (int i = 0; i < n; ++i) {
+      pack.it[i] = items[i0 + i];
+      const long need = (long)((items[i0 + i].c_in + 63) / 64) * items[i0 + i].c_out;
+      gx = need > gx ? need : gx;
+    }
+    for (int i = n; i < WS_ITEMS; ++i) pack.it[i] = pack.it[0];
+    SFRON_CHECK_ARG(gx <= 0x7fffffffL);
+    hipLaunchKernelGGL(k_conv_wgrad_scatter_batch, dim3((unsigned)gx, n), dim3(TPB), 0, (hipStream_t)stream, pack);
+    SFRON_LAUNCH_STATUS();
+  }
   return SFRON_OK;
 }
 

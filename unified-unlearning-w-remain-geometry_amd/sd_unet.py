@@ -418,7 +418,7 @@ class UNetModel(_TapeNet):
                     if hook is not None:
                         hook(i, step)
             except BaseException:
-                self._red = None
+                self._red = self._scat = None
                 raise
             self._reduce_flush()                                   # every collected parameter-gradient finish, d_proj's slices included
             dpb = cast_rows(d_proj, PT, B, PT, dev)

@@ -294,7 +294,9 @@ class _TapeNet(nn.Module):
     # them (self._red is a list while one runs) and issues them as ONE sfron_reduce_batch launch -- the same sums in the same order, ~190
     # launches of ~5 us fewer per DDPM step.  Outside a backward pass (self._red is None) a reduction is launched where it is asked for.
     _red = None
+    _scat = None
     BATCH_REDUCTIONS = True
+    SCATTER_BATCH_MAX_BYTES = 64 << 20      # slabs of a layer above this (the LDM UNet's 1280-wide kernels) are scattered at once, from the Infinity Cache
 
     def _reduce(self, partials, groups, per_group, D, out_addr, ldout):
         if self._red is not None:
@@ -319,9 +321,16 @@ class _TapeNet(nn.Module):
 
     def _reduce_begin(self):
         self._red = [] if self.BATCH_REDUCTIONS else None
+        self._scat = []
 
     def _reduce_flush(self):
         items, self._red = self._red, None
+        scat, self._scat = self._scat, None
+        if scat:
+            arr = (_lib.WgradScatterItem * len(scat))()
+            for a, (buf, out_addr, slab, co, ci, taps, cip, nsl) in zip(arr, scat):
+                a.dw_gemm, a.dw_oihw, a.slab_stride, a.c_out, a.c_in, a.taps, a.c_in_p, a.n_slabs = buf.data_ptr(), out_addr, slab, co, ci, taps, cip, nsl
+            check(_L().sfron_conv_wgrad_scatter_batch(ctypes.cast(arr, ctypes.c_void_p), len(scat), stream_ptr()), "conv_wgrad_scatter_batch")
         if not items:
             return
         arr = (_lib.ReduceItem * len(items))()
@@ -421,12 +430,23 @@ class _TapeNet(nn.Module):
                 wd = _conv_desc(B, hs, ws, v["cip"], ho, wo, v["cop"], 9, stride, pad, up, 0)
                 nsl = _L().sfron_conv_wgrad_splits(ctypes.byref(wd))
                 slab = v["cop"] * 9 * v["cip"]
-                if self._dw.numel() < nsl * slab:
-                    self._dw_retired.append(self._dw)   # a captured stage graph may still write through the old address
-                    self._dw = torch.empty(nsl * slab, dtype=torch.float32, device=dev)
-                check(_L().sfron_conv_wgrad(ctypes.byref(wd), ptr(dyb), v["cop"], ptr(src), ptr(self._dw), stream_ptr()), "conv_wgrad")
-                check(_L().sfron_conv_wgrad_scatter(ptr(self._dw), v["co"], v["ci"], 9, v["cip"], nsl, slab, self._g(name + ".weight"),
-                                                    stream_ptr()), "conv_wgrad_scatter")
+                if self._red is not None and nsl * slab * 4 <= self.SCATTER_BATCH_MAX_BYTES:
+                    # inside a backward pass: the slabs stay in a buffer of this layer's own and their scatter into the OIHW gradient joins the
+                    # pass's one scatter launch (~100 launches of ~7 us fewer per DDPM step; the price: 1.2 GB of slabs at DDPM batch 64)
+                    buf = v.get("dwbuf")
+                    if buf is None or buf.numel() < nsl * slab:
+                        if buf is not None:
+                            self._dw_retired.append(buf)   # a captured stage graph may still write through the old address
+                        buf = v["dwbuf"] = torch.empty(nsl * slab, dtype=torch.float32, device=dev)
+                    check(_L().sfron_conv_wgrad(ctypes.byref(wd), ptr(dyb), v["cop"], ptr(src), ptr(buf), stream_ptr()), "conv_wgrad")
+                    self._scat.append((buf, self._g(name + ".weight"), slab, v["co"], v["ci"], 9, v["cip"], nsl))
+                else:
+                    if self._dw.numel() < nsl * slab:
+                        self._dw_retired.append(self._dw)   # a captured stage graph may still write through the old address
+                        self._dw = torch.empty(nsl * slab, dtype=torch.float32, device=dev)
+                    check(_L().sfron_conv_wgrad(ctypes.byref(wd), ptr(dyb), v["cop"], ptr(src), ptr(self._dw), stream_ptr()), "conv_wgrad")
+                    check(_L().sfron_conv_wgrad_scatter(ptr(self._dw), v["co"], v["ci"], 9, v["cip"], nsl, slab, self._g(name + ".weight"),
+                                                        stream_ptr()), "conv_wgrad_scatter")
             if not want_dsrc or v["dgr"] is None:
                 return None
             if stride == 2:        # Downsample: gradient = flipped kernel over the zero-dilated dY, padding 2 - pad
@@ -955,7 +975,7 @@ class Conditional_Model(_TapeNet):
                     if hook is not None:
                         hook(i, step)
             except BaseException:
-                self._red = None
+                self._red = self._scat = None
                 raise
             self._reduce_flush()                                   # every collected parameter-gradient finish, d_proj's slices included
             # ---- temb_cemb_proj of all blocks, then the two embedding MLPs
