@@ -347,6 +347,11 @@ typedef struct sfron_conv_desc {
   int accumulate;
   float* split_ws; int split_ws_slabs;   /* optional fp32 scratch [split_ws_slabs][rows * n_out]: a forward / input-gradient conv with few
                                        output tiles and a deep contraction then splits the contraction over the chip */
+  int* split_pending;               /* optional HOST int (ABI 16): when the call splits its contraction (and ld_out == n_out) it leaves
+                                       *split_pending (> 0) slabs [rows * n_out] in split_ws and does NOT launch the pass that adds them and
+                                       applies bias / sample_vec / resid -- the caller hands them to a GroupNorm that finishes the sum itself
+                                       (sfron_split_src, sfron_groupnorm_*_src) or to sfron_split_finish; 0 = the output is complete.
+                                       NULL = always complete. */
 } sfron_conv_desc;
 /* out[p][n] = sum_{tap, c} src[src(p, tap)][c] * w[n][tap][c]; w bf16 [n_out][taps][c_src] (sfron_conv_wprep's "fwd" layout;
  * the input gradient calls this on dY with the "dgrad" layout) */
@@ -408,6 +413,32 @@ int sfron_groupnorm_bwd_res(const float* dy, const float* x, int ldx, const floa
 int sfron_groupnorm_bwd_cast(const float* dy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
                              const float* rstd, int B, int HW, int C, int groups, int swish, const uint8_t* drop_mask, float drop_scale,
                              uint16_t* dx_bf16, float* col_partials, float* part_gamma, float* part_beta, void* scratch, void* stream);
+
+/* The GroupNorm INPUT as an unfinished split-K result (round 6, ABI 16): element (row, c) = sum_{s < n_slabs} slabs[s * slab_stride + row * C + c]
+ * (in index order) + bias[c] + sample_vec[(row / (rows per sample)) * ld_vec + c] + resid[row * ld_resid + c] -- what the finish launch of a
+ * split convolution (sfron_conv_desc.split_pending) would have written.  The one-launch GroupNorm (sfron_groupnorm_one_launch(B, HW, C, groups)
+ * != 0: a workgroup per sample and block of whole groups) forms each element in its first pass and STORES it to the tensor the finish would have
+ * filled (x of the forward pass / dy of the backward pass, row stride C: every later reader finds it there), so that launch no longer exists:
+ * the same bits as sfron_split_finish followed by sfron_groupnorm_fwd / _bwd_res / _bwd_cast.  Returns SFRON_ERR_UNSUPPORTED (nothing launched)
+ * when the shape does not take the one-launch form: the caller then calls sfron_split_finish and the plain entry point. */
+typedef struct sfron_split_src {
+  const float* slabs; int n_slabs; int64_t slab_stride;
+  const float* bias; const float* sample_vec; int ld_vec; const float* resid; int ld_resid;    /* each optional */
+} sfron_split_src;
+int sfron_split_finish(const sfron_split_src* src /* HOST */, int64_t rows, int C, int rows_per_sample, float* out_f32, uint16_t* out_bf16,
+                       int ld_out, void* stream);
+int sfron_groupnorm_one_launch(int B, int HW, int C, int groups);
+int sfron_groupnorm_fwd_src(const sfron_split_src* src /* HOST */, float* x /* [B * HW][C], written */, const float* gamma, const float* beta, int B,
+                            int HW, int C, int groups, float eps, int swish, const uint8_t* drop_mask, float drop_scale, uint16_t* y, float* mean,
+                            float* rstd, void* stream);
+int sfron_groupnorm_bwd_res_src(const sfron_split_src* src /* HOST */, float* dy /* [B * HW][C], written */, const float* x, int ldx,
+                                const float* gamma, const float* beta, const float* mean, const float* rstd, int B, int HW, int C, int groups,
+                                int swish, const uint8_t* drop_mask, float drop_scale, float* dx, int lddx, int accumulate, const float* extra,
+                                int ld_extra, float* part_gamma, float* part_beta, void* stream);
+int sfron_groupnorm_bwd_cast_src(const sfron_split_src* src /* HOST */, float* dy /* [B * HW][C], written */, const float* x, int ldx,
+                                 const float* gamma, const float* beta, const float* mean, const float* rstd, int B, int HW, int C, int groups,
+                                 int swish, const uint8_t* drop_mask, float drop_scale, uint16_t* dx_bf16, float* col_partials,
+                                 float* part_gamma, float* part_beta, void* stream);
 int sfron_groupnorm_bwd_cast_ok(int ldx, int C, int groups);
 int sfron_groupnorm_chunks(int B, int HW);
 int64_t sfron_groupnorm_scratch_bytes(int B, int HW, int C, int groups);

@@ -506,6 +506,120 @@ def test_unet_draws_its_dropout_masks_in_one_launch_from_the_second_pass_on():
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("C,HW,nsl,drop", [(256, 64, 3, True), (256, 256, 2, False), (512, 16, 6, False), (128, 256, 1, True), (384, 64, 4, False)])
+def test_groupnorm_finishes_a_split_convolution_itself(C, HW, nsl, drop):
+    """sfron_groupnorm_{fwd,bwd_res,bwd_cast}_src (round 6): the GroupNorm input handed over as the unfinished result of a split-K product
+    (n slabs + bias + per-sample vector + residual).  The one-launch kernels form each element in their first pass and store it where the
+    finish launch would have: x / dy, y, mean, rstd, dx (with accumulate and the extra term), the bf16 operand form, its column sums and the
+    parameter-gradient partials all equal sfron_split_finish followed by the plain entry point, bit for bit."""
+    import ctypes
+    from sfron import _lib
+    from sfron._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    B = 64
+    assert L.sfron_groupnorm_one_launch(B, HW, C, 32) == 1 and L.sfron_groupnorm_one_launch(2, 4096, 320, 32) == 0
+    g = torch.Generator().manual_seed(C + HW + nsl)
+    rows = B * HW
+    slabs = (torch.randn(nsl, rows, C, generator=g) * 0.7).to(DEV)
+    bias, vec, resid = torch.randn(C, generator=g).to(DEV), torch.randn(B, C + 8, generator=g).to(DEV), torch.randn(rows, C, generator=g).to(DEV)
+    gamma, beta = (torch.randn(C, generator=g) * 0.5 + 1.0).to(DEV), (torch.randn(C, generator=g) * 0.2).to(DEV)
+    mask = (torch.rand(rows, C, generator=g) > 0.1).to(torch.uint8).to(DEV) if drop else None
+    scale = 1.0 / 0.9 if drop else 1.0
+
+    def source(with_extras):
+        src = _lib.SplitSrc()
+        src.slabs, src.n_slabs, src.slab_stride = slabs.data_ptr(), nsl, rows * C
+        if with_extras:
+            src.bias, src.sample_vec, src.ld_vec, src.resid, src.ld_resid = bias.data_ptr(), vec.data_ptr(), C + 8, resid.data_ptr(), C
+        return src
+
+    ws = torch.empty(L.sfron_groupnorm_scratch_bytes(B, HW, C, 32) // 8 + 2, dtype=torch.float64, device=DEV)
+    # ---- forward
+    src = source(True)
+    x0 = torch.full((rows, C), float("nan"), device=DEV)
+    check(L.sfron_split_finish(ctypes.byref(src), rows, C, HW, ptr(x0), None, C, stream_ptr()), "split_finish")
+    want = slabs.double().sum(0) + bias.double() + vec[:, :C].double().repeat_interleave(HW, 0) + resid.double()
+    np.testing.assert_allclose(x0.cpu().numpy(), want.float().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    y0, m0, r0 = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV), torch.empty(B * 32, device=DEV), torch.empty(B * 32, device=DEV)
+    check(L.sfron_groupnorm_fwd(ptr(x0), C, ptr(gamma), ptr(beta), B, HW, C, 32, 1e-6, 1, ptr(mask), scale, ptr(y0), ptr(m0), ptr(r0), ptr(ws),
+                                stream_ptr()), "gn_fwd")
+    x1 = torch.full((rows, C), float("nan"), device=DEV)
+    y1, m1, r1 = torch.empty_like(y0), torch.empty_like(m0), torch.empty_like(r0)
+    check(L.sfron_groupnorm_fwd_src(ctypes.byref(src), ptr(x1), ptr(gamma), ptr(beta), B, HW, C, 32, 1e-6, 1, ptr(mask), scale, ptr(y1), ptr(m1), ptr(r1),
+                                    stream_ptr()), "gn_fwd_src")
+    for a, b in ((x0, x1), (y0, y1), (m0, m1), (r0, r1)):
+        assert torch.equal(a, b)
+    # ---- backward, fp32 form with accumulate + extra: dy = the slabs alone (an input-gradient convolution has no epilogue terms)
+    src = source(False)
+    dy0 = torch.full((rows, C), float("nan"), device=DEV)
+    check(L.sfron_split_finish(ctypes.byref(src), rows, C, HW, ptr(dy0), None, C, stream_ptr()), "split_finish")
+    extra = torch.randn(rows, C + 4, generator=g).to(DEV)
+    dx0, pg0, pb0 = torch.full((rows, C), 0.5, device=DEV), torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV)
+    check(L.sfron_groupnorm_bwd_res(ptr(dy0), ptr(x0), C, ptr(gamma), ptr(beta), ptr(m0), ptr(r0), B, HW, C, 32, 1, ptr(mask), scale, ptr(dx0), C, 1,
+                                    ptr(extra), C + 4, ptr(pg0), ptr(pb0), ptr(ws), stream_ptr()), "gn_bwd_res")
+    dy1 = torch.full((rows, C), float("nan"), device=DEV)
+    dx1, pg1, pb1 = torch.full((rows, C), 0.5, device=DEV), torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV)
+    check(L.sfron_groupnorm_bwd_res_src(ctypes.byref(src), ptr(dy1), ptr(x0), C, ptr(gamma), ptr(beta), ptr(m0), ptr(r0), B, HW, C, 32, 1, ptr(mask), scale,
+                                        ptr(dx1), C, 1, ptr(extra), C + 4, ptr(pg1), ptr(pb1), stream_ptr()), "gn_bwd_res_src")
+    for a, b in ((dy0, dy1), (dx0, dx1), (pg0, pg1), (pb0, pb1)):
+        assert torch.equal(a, b)
+    # ---- backward, bf16 operand form + column sums
+    nch = L.sfron_groupnorm_chunks(B, HW)
+    d16a, cpa = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV), torch.full((B * nch, C), float("nan"), device=DEV)
+    check(L.sfron_groupnorm_bwd_cast(ptr(dy0), ptr(x0), C, ptr(gamma), ptr(beta), ptr(m0), ptr(r0), B, HW, C, 32, 1, ptr(mask), scale, ptr(d16a), ptr(cpa),
+                                     ptr(pg0), ptr(pb0), ptr(ws), stream_ptr()), "gn_bwd_cast")
+    dy2 = torch.full((rows, C), float("nan"), device=DEV)
+    d16b, cpb = torch.empty_like(d16a), torch.full((B * nch, C), float("nan"), device=DEV)
+    check(L.sfron_groupnorm_bwd_cast_src(ctypes.byref(src), ptr(dy2), ptr(x0), C, ptr(gamma), ptr(beta), ptr(m0), ptr(r0), B, HW, C, 32, 1, ptr(mask), scale,
+                                         ptr(d16b), ptr(cpb), ptr(pg1), ptr(pb1), stream_ptr()), "gn_bwd_cast_src")
+    for a, b in ((dy0, dy2), (d16a, d16b), (cpa, cpb), (pg0, pg1), (pb0, pb1)):
+        assert torch.equal(a, b)
+    # a shape outside the one-launch rule: nothing launched, the caller falls back
+    small = _lib.SplitSrc()
+    small.slabs, small.n_slabs, small.slab_stride = slabs.data_ptr(), 1, 2 * HW * C
+    assert L.sfron_groupnorm_fwd_src(ctypes.byref(small), ptr(x1), ptr(gamma), ptr(beta), 2, HW, C, 32, 1e-6, 1, None, 1.0, ptr(y1), ptr(m1), ptr(r1),
+                                     stream_ptr()) == 1002
+
+
+def test_resblock_groupnorms_absorb_the_split_finishes_bitwise():
+    """ResnetBlocks at a DDPM width (256 channels, 8 x 8, batch 64: the 3 x 3 convolutions and their input-gradient convolutions split their
+    contraction): with _TapeNet.FUSE_SPLIT_FINISH the finish launches between a convolution and the GroupNorm that follows are gone -- norm2
+    forms conv1's output, norm2's / norm1's backward form the two input gradients -- and the output and every gradient equal the unfused
+    tape bit for bit."""
+    from sfron import unet
+    cfg = dict(ch=128, ch_mult=(2,), num_res_blocks=1, attn_resolutions=(), dropout=0.0, resolution=8, n_classes=10)      # (the class only runs at ch = 128)
+    _, model = _pair(cfg, seed=47)
+    model.train()
+    g = torch.Generator().manual_seed(4)
+    B = 64
+    x, t = torch.randn(B, 3, 8, 8, generator=g).to(DEV), torch.randint(0, 1000, (B,), generator=g).float().to(DEV)
+    c, keep = torch.randint(0, 10, (B,), generator=g).to(DEV), torch.ones(B, dtype=torch.uint8, device=DEV)
+    w = torch.randn(B, 3, 8, 8, generator=g).to(DEV)
+    res, calls, real = {}, {"n": 0}, unet.split_source
+
+    def counting(*a, **k):
+        r = real(*a, **k)
+        calls["n"] += r is not None
+        return r
+    try:
+        unet.split_source = counting
+        for fuse in (True, False, True):
+            model.FUSE_SPLIT_FINISH = fuse
+            model.grads.fill_(float("nan"))
+            n0 = calls["n"]
+            out, bwd = model._run(x, t, c, keep, None, need_grad=True)
+            bwd(w.clone())
+            res.setdefault(fuse, []).append((out.clone(), model.grads.clone(), calls["n"] - n0))
+    finally:
+        unet.split_source = real
+        model.FUSE_SPLIT_FINISH = True
+    assert res[True][0][2] >= 6 and res[False][0][2] == 0          # the fused tape did hand split results to GroupNorms
+    for a, b in ((res[True][0], res[False][0]), (res[True][0], res[True][1])):
+        assert torch.isfinite(a[0]).all() and torch.equal(a[0], b[0])
+        bad = [n for n in model.index if not torch.equal(model.view(a[1], n), model.view(b[1], n))]
+        assert not bad, bad[:8]
+
+
 @pytest.mark.parametrize("B", [8, 64])
 def test_parameter_gradient_finishes_in_one_launch_equal_the_separate_launches(B):
     """sfron_reduce_batch (round 6): the fixed-order sums that finish GroupNorm affine gradients, conv1 bias gradients and the per-sample

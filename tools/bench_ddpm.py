@@ -9,6 +9,8 @@ ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--eager", action="store_true", help="no HIP-graph replay of the stages")
 a = ap.parse_args()
 from sfron import ddpm, unet
+if os.environ.get("SFRON_FUSE_SPLIT_FINISH"):       # A-B knob: 0 = every split convolution finishes its own output (before round 6, late)
+    unet._TapeNet.FUSE_SPLIT_FINISH = os.environ["SFRON_FUSE_SPLIT_FINISH"] != "0"
 if os.environ.get("SFRON_BATCH_REDUCTIONS"):        # A-B knob: 0 = every parameter-gradient finish as its own launch (before round 6)
     unet._TapeNet.BATCH_REDUCTIONS = os.environ["SFRON_BATCH_REDUCTIONS"] != "0"
 if os.environ.get("SFRON_LOADER_WAVES"):            # A-B knob: 10 = convolution tiles in the shared-wave form

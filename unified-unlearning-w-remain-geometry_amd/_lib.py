@@ -85,6 +85,12 @@ _PROTOS.update({
     "sfron_weighted_reduce": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, _S]),
     "sfron_reduce_slots": (c_int, [_P, ctypes.c_long, c_int, c_int, c_int, c_int, POINTER(c_void_p), POINTER(ctypes.c_long),
                                    POINTER(c_int), _S]),
+    "sfron_split_finish": (c_int, [_P, c_int64, c_int, c_int, _P, _P, c_int, _S]),
+    "sfron_groupnorm_one_launch": (c_int, [c_int, c_int, c_int, c_int]),
+    "sfron_groupnorm_fwd_src": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, c_float, _P, _P, _P, _S]),
+    "sfron_groupnorm_bwd_res_src": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, c_int, c_int, _P,
+                                            c_int, _P, _P, _S]),
+    "sfron_groupnorm_bwd_cast_src": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, _P, _P, _P, _S]),
     "sfron_reduce_batch": (c_int, [_P, c_int, _S]),
     "sfron_conv_wgrad_scatter_batch": (c_int, [_P, c_int, _S]),
     "sfron_reduce2": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _S]),
@@ -157,7 +163,13 @@ class ConvDesc(ctypes.Structure):
                 ("n_out", c_int), ("taps", c_int), ("stride", c_int), ("pad", c_int), ("upsample", c_int), ("dilate", c_int),
                 ("bias", c_void_p), ("resid", c_void_p), ("sample_vec", c_void_p), ("ld_vec", c_int),
                 ("out_bf16", c_void_p), ("out_f32", c_void_p), ("ld_out", c_int), ("accumulate", c_int),
-                ("split_ws", c_void_p), ("split_ws_slabs", c_int)]
+                ("split_ws", c_void_p), ("split_ws_slabs", c_int), ("split_pending", POINTER(c_int))]
+
+
+class SplitSrc(ctypes.Structure):
+    """Mirror of sfron_split_src."""
+    _fields_ = [("slabs", c_void_p), ("n_slabs", c_int), ("slab_stride", c_int64), ("bias", c_void_p), ("sample_vec", c_void_p), ("ld_vec", c_int),
+                ("resid", c_void_p), ("ld_resid", c_int)]
 
 
 _PROTOS.update({

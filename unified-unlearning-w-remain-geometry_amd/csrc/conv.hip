@@ -1328,6 +1328,33 @@ __global__ __launch_bounds__(GNB) void k_gn2_bwd_apply(const float* __restrict__
 // workgroup's rows in a fixed order (replica r takes rows r, r + rpp, ...; replicas, then channels, are added in index order): bitwise
 // reproducible, not bit-identical to the chunked pair.
 constexpr int GN3_T = 1024;
+// the GroupNorm INPUT (forward: x, backward: dy) as the still unfinished result of a split-K product (round 6): n slabs [rows][C] to be added in
+// index order, + bias[c] + vec[sample][c] + resid[row][c] -- element for element what k_split_finish4 writes.  The one-launch kernels form each
+// element in their first pass, store it to the tensor the finish launch would have filled (their own second pass and every later reader find
+// it there), and the finish launch between the product and the GroupNorm no longer exists.  slabs == nullptr: the input is a finished tensor.
+struct Gn3Src {
+  const float* slabs; int n; int64_t stride;
+  const float* bias; const float* vec; int ldvec; const float* resid; int ldresid;
+};
+__device__ __forceinline__ float4 gn3_src_quad(const Gn3Src& s, int64_t row, int b, int c, int C) {
+  const float* p = s.slabs + row * C + c;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  int sl = 0;
+  for (; sl + 4 <= s.n; sl += 4) {                // four slab loads in flight, added in slab order
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (sl + u) * s.stride);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+  }
+  for (; sl < s.n; ++sl) { const float4 v = *reinterpret_cast<const float4*>(p + sl * s.stride); a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (s.bias) b4 = *reinterpret_cast<const float4*>(s.bias + c);
+  a.x += b4.x; a.y += b4.y; a.z += b4.z; a.w += b4.w;
+  if (s.vec) { const float4 v = *reinterpret_cast<const float4*>(s.vec + (int64_t)b * s.ldvec + c); a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+  if (s.resid) { const float4 v = *reinterpret_cast<const float4*>(s.resid + row * s.ldresid + c); a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+  return a;
+}
 struct Gn3Map {
   int b, g0, c0, Cs, qpr, rpp, q, r;
   bool on;
@@ -1338,22 +1365,35 @@ struct Gn3Map {
     r = threadIdx.x / qpr; q = threadIdx.x - r * qpr; on = r < rpp;
   }
 };
+template <bool SRC>
 __global__ __launch_bounds__(GN3_T) void k_gn3_fwd(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    int HW, int C, int G, int gpb, float eps, int swish, const uint8_t* __restrict__ mask,
-                                                   float drop_scale, __bf16* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
+                                                   float drop_scale, __bf16* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                   Gn3Src src) {
   __shared__ double shd[GN3_T * 4 * 2];         // [rpp][Cs][2], rpp * Cs <= 4 * GN3_T
   __shared__ float st[2][64];
   Gn3Map m; m.init(C, G, gpb);
   const int cg = C / G;
   const float* xb = x + (size_t)m.b * HW * ldx + m.c0 + 4 * m.q;
   double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
-  if (m.on) {
+  if (SRC && m.on) {                              // x is still S slabs: finish it here (ldx == C), this thread's quads, for its own second pass
+    float* xw = const_cast<float*>(xb);
+#pragma unroll 2
+    for (int p = m.r; p < HW; p += m.rpp) {
+      const float4 v = gn3_src_quad(src, (int64_t)m.b * HW + p, m.b, m.c0 + 4 * m.q, C);
+      *reinterpret_cast<float4*>(xw + (size_t)p * ldx) = v;
+      s[0] += v.x; ss[0] += (double)v.x * v.x; s[1] += v.y; ss[1] += (double)v.y * v.y;
+      s[2] += v.z; ss[2] += (double)v.z * v.z; s[3] += v.w; ss[3] += (double)v.w * v.w;
+    }
+  } else if (!SRC && m.on) {
 #pragma unroll 8
     for (int p = m.r; p < HW; p += m.rpp) {
       const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)p * ldx);
       s[0] += v.x; ss[0] += (double)v.x * v.x; s[1] += v.y; ss[1] += (double)v.y * v.y;
       s[2] += v.z; ss[2] += (double)v.z * v.z; s[3] += v.w; ss[3] += (double)v.w * v.w;
     }
+  }
+  if (m.on) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       shd[((size_t)m.r * m.Cs + 4 * m.q + e) * 2] = s[e]; shd[((size_t)m.r * m.Cs + 4 * m.q + e) * 2 + 1] = ss[e];
@@ -1407,12 +1447,13 @@ __global__ __launch_bounds__(GN3_T) void k_gn3_fwd(const float* __restrict__ x, 
 // this sample, complete here) -> the group means k1, k2; pass 2 = dx (+)= rstd (dz gamma - k1 - xhat k2), every output form of k_gn2_bwd_apply
 // (fp32 with accumulate / extra, bf16 operand copy, per-sample column sums: colpart keeps the caller's [B][nchunk][C] layout -- chunk 0 gets the
 // sample's sum, the other chunks zeros)
+template <bool SRC>
 __global__ __launch_bounds__(GN3_T) void k_gn3_bwd(const float* __restrict__ dy, const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                    int HW, int C, int G, int gpb, int swish, const uint8_t* __restrict__ mask, float drop_scale,
                                                    float* __restrict__ dx, int lddx, int accumulate, float* __restrict__ pg, float* __restrict__ pb,
                                                    const float* __restrict__ extra, int ldextra, __bf16* __restrict__ dx16,
-                                                   float* __restrict__ colpart, int nchunk) {
+                                                   float* __restrict__ colpart, int nchunk, Gn3Src src) {
   __shared__ float shf[GN3_T * 4 * 2];          // [rpp][Cs][2]; afterwards [rpp][Cs] column sums
   __shared__ float chs[GN3_T * 4 * 2 / (GN3_T / 256)];          // [Cs][2] channel sums, Cs <= 1024
   __shared__ float kk[2 * 64];
@@ -1430,10 +1471,15 @@ __global__ __launch_bounds__(GN3_T) void k_gn3_bwd(const float* __restrict__ dy,
   const uint8_t* mb = mask ? mask + (size_t)m.b * HW * C + m.c0 + 4 * m.q : nullptr;
   if (m.on) {
     float ca[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
+#pragma unroll SRC ? 2 : 8
     for (int p = m.r; p < HW; p += m.rpp) {
       const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)p * ldx);
-      const float4 dv = *reinterpret_cast<const float4*>(dyb + (size_t)p * C);
+      float4 dv;
+      if constexpr (SRC) {                          // dy is still S slabs (an input-gradient convolution): finished here, stored for pass 2
+        dv = gn3_src_quad(src, (int64_t)m.b * HW + p, m.b, m.c0 + 4 * m.q, C);
+        *reinterpret_cast<float4*>(const_cast<float*>(dyb) + (size_t)p * C) = dv;
+      } else
+        dv = *reinterpret_cast<const float4*>(dyb + (size_t)p * C);
       uchar4 mk = make_uchar4(1, 1, 1, 1);
       if (mb) mk = *reinterpret_cast<const uchar4*>(mb + (size_t)p * C);
       const float xv[4] = {v.x, v.y, v.z, v.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
@@ -2254,6 +2300,7 @@ static int conv_geom(const sfron_conv_desc* d, ConvGeom& c, int src_c) {
 /* forward (and, with re-laid weights + flipped taps, input gradient): out[p][n] = sum_{tap, c} src[src(p, tap)][c] w[n][tap][c] */
 int sfron_conv_fwd(const sfron_conv_desc* d, const uint16_t* src, const uint16_t* w, void* stream) {
   SFRON_CHECK_ARG(d && src && w && d->n_out % 4 == 0);
+  if (d->split_pending) *d->split_pending = 0;
   BGemmArgs g{};
   int rc = conv_geom(d, g.cg, d->c_src); if (rc) return rc;
   g.A = (const __bf16*)src; g.B = (const __bf16*)w;
@@ -2297,7 +2344,12 @@ int sfron_conv_fwd(const sfron_conv_desc* d, const uint16_t* src, const uint16_t
       if (rc) return rc;
       const bool al = (((uintptr_t)d->split_ws | (uintptr_t)g.bias | (uintptr_t)g.vec | (uintptr_t)g.resid | (uintptr_t)g.Cf) & 15) == 0 &&
                       (((uintptr_t)g.Cb) & 7) == 0;
-      if (g.N % 4 == 0 && d->ld_out % 4 == 0 && (!g.vec || g.ldvec % 4 == 0) && al) {
+      const bool quads = g.N % 4 == 0 && d->ld_out % 4 == 0 && (!g.vec || g.ldvec % 4 == 0) && al;
+      if (quads && d->split_pending && d->ld_out == g.N) {   // the caller's GroupNorm finishes the sum itself (sfron_groupnorm_*_src)
+        *d->split_pending = used;
+        return SFRON_OK;
+      }
+      if (quads) {
         const int cb = (g.N / 4 + TPB - 1) / TPB;
         int chunks = 2048 / cb; if (chunks > g.M) chunks = g.M; if (chunks < 1) chunks = 1;
         const int rpb = (g.M + chunks - 1) / chunks;
@@ -2487,8 +2539,8 @@ int sfron_groupnorm_fwd(const float* x, int ldx, const float* gamma, const float
   SFRON_CHECK_ARG(x && gamma && beta && y && mean && rstd && groups > 0 && C % groups == 0 && ldx >= C && C / groups <= TPB);
   if (gn2_ok(ldx, C, C, groups, scratch) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 && (!drop_mask || ((uintptr_t)drop_mask & 3) == 0)) {
     if (const int gpb = gn3_gpb(B, HW, C, groups)) {
-      hipLaunchKernelGGL(k_gn3_fwd, dim3(B * (groups / gpb)), dim3(GN3_T), 0, (hipStream_t)stream, x, ldx, gamma, beta, HW, C, groups, gpb, eps, swish,
-                         drop_mask, drop_scale, (__bf16*)y, mean, rstd);
+      hipLaunchKernelGGL(k_gn3_fwd<false>, dim3(B * (groups / gpb)), dim3(GN3_T), 0, (hipStream_t)stream, x, ldx, gamma, beta, HW, C, groups, gpb, eps, swish,
+                         drop_mask, drop_scale, (__bf16*)y, mean, rstd, Gn3Src{});
       SFRON_LAUNCH_STATUS();
       return SFRON_OK;
     }
@@ -2529,8 +2581,9 @@ int sfron_groupnorm_bwd_res(const float* dy, const float* x, int ldx, const floa
   }
   if (fused) {
     if (const int gpb = gn3_gpb(B, HW, C, groups)) {
-      hipLaunchKernelGGL(k_gn3_bwd, dim3(B * (groups / gpb)), dim3(GN3_T), 0, (hipStream_t)stream, dy, x, ldx, gamma, beta, mean, rstd, HW, C, groups, gpb,
-                         swish, drop_mask, drop_scale, dx, lddx, accumulate, part_gamma, part_beta, extra, ld_extra, (__bf16*)nullptr, (float*)nullptr, 1);
+      hipLaunchKernelGGL(k_gn3_bwd<false>, dim3(B * (groups / gpb)), dim3(GN3_T), 0, (hipStream_t)stream, dy, x, ldx, gamma, beta, mean, rstd, HW, C, groups, gpb,
+                         swish, drop_mask, drop_scale, dx, lddx, accumulate, part_gamma, part_beta, extra, ld_extra, (__bf16*)nullptr, (float*)nullptr, 1,
+                         Gn3Src{});
       SFRON_LAUNCH_STATUS();
       return SFRON_OK;
     }
@@ -2564,9 +2617,9 @@ int sfron_groupnorm_bwd_cast(const float* dy, const float* x, int ldx, const flo
                   (!drop_mask || ((uintptr_t)drop_mask & 3) == 0));
   const int nchunk = gn_chunks(B, HW);
   if (const int gpb = gn3_gpb(B, HW, C, groups)) {
-    hipLaunchKernelGGL(k_gn3_bwd, dim3(B * (groups / gpb)), dim3(GN3_T), 0, (hipStream_t)stream, dy, x, ldx, gamma, beta, mean, rstd, HW, C, groups, gpb,
+    hipLaunchKernelGGL(k_gn3_bwd<false>, dim3(B * (groups / gpb)), dim3(GN3_T), 0, (hipStream_t)stream, dy, x, ldx, gamma, beta, mean, rstd, HW, C, groups, gpb,
                        swish, drop_mask, drop_scale, (float*)nullptr, C, 0, part_gamma, part_beta, (const float*)nullptr, 0, (__bf16*)dx_bf16,
-                       col_partials, nchunk);
+                       col_partials, nchunk, Gn3Src{});
     SFRON_LAUNCH_STATUS();
     return SFRON_OK;
   }
@@ -2577,6 +2630,75 @@ int sfron_groupnorm_bwd_cast(const float* dy, const float* x, int ldx, const flo
   hipLaunchKernelGGL(k_gn2_bwd_apply, dim3(B * nchunk), dim3(GNB), lds, (hipStream_t)stream, dy, x, ldx, gamma, beta, mean, rstd, HW, C, groups, swish,
                      drop_mask, drop_scale, nchunk, (const float*)scratch, (float*)nullptr, C, 0, part_gamma, part_beta, (const float*)nullptr, 0,
                      (__bf16*)dx_bf16, col_partials);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+
+// ---- the GroupNorm input as an unfinished split-K result (sfron_split_src)
+static bool split_src_ok(const sfron_split_src* s, int C) {
+  return s && s->slabs && s->n_slabs >= 1 && s->slab_stride > 0 && C % 4 == 0 && (((uintptr_t)s->slabs | (uintptr_t)s->bias | (uintptr_t)s->sample_vec |
+         (uintptr_t)s->resid) & 15) == 0 && s->slab_stride % 4 == 0 && (!s->sample_vec || s->ld_vec % 4 == 0) && (!s->resid || s->ld_resid % 4 == 0);
+}
+static Gn3Src gn3_src(const sfron_split_src* s) {
+  return Gn3Src{s->slabs, s->n_slabs, s->slab_stride, s->bias, s->sample_vec, s->ld_vec, s->resid, s->ld_resid};
+}
+int sfron_split_finish(const sfron_split_src* src, int64_t rows, int C, int rows_per_sample, float* out_f32, uint16_t* out_bf16, int ld_out,
+                       void* stream) {
+  SFRON_CHECK_ARG(split_src_ok(src, C) && rows > 0 && rows <= 0x7fffffff && rows_per_sample > 0 && ((out_f32 != nullptr) != (out_bf16 != nullptr)) &&
+                  ld_out >= C && ld_out % 4 == 0);
+  SFRON_CHECK_ARG(!src->resid || src->ld_resid == ld_out);
+  SFRON_CHECK_ARG((((uintptr_t)out_f32) & 15) == 0 && (((uintptr_t)out_bf16) & 7) == 0);
+  const int cb = (C / 4 + TPB - 1) / TPB;
+  int chunks = 2048 / cb; if (chunks > rows) chunks = (int)rows; if (chunks < 1) chunks = 1;
+  const int rpb = (int)((rows + chunks - 1) / chunks);
+  hipLaunchKernelGGL(k_split_finish4, dim3(cb, (unsigned)((rows + rpb - 1) / rpb)), dim3(TPB), 0, (hipStream_t)stream, src->slabs, src->n_slabs,
+                     src->slab_stride, (int)rows, C, src->bias, src->sample_vec, src->ld_vec, rows_per_sample, src->resid, out_f32, (__bf16*)out_bf16,
+                     ld_out, rpb);
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+int sfron_groupnorm_one_launch(int B, int HW, int C, int groups) {
+  return B > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0 && C % 4 == 0 && groups <= 64 && gn3_gpb(B, HW, C, groups) > 0;
+}
+int sfron_groupnorm_fwd_src(const sfron_split_src* src, float* x, const float* gamma, const float* beta, int B, int HW, int C, int groups, float eps,
+                            int swish, const uint8_t* drop_mask, float drop_scale, uint16_t* y, float* mean, float* rstd, void* stream) {
+  SFRON_CHECK_ARG(x && gamma && beta && y && mean && rstd && groups > 0 && C % groups == 0 && split_src_ok(src, C));
+  SFRON_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 && (!drop_mask || ((uintptr_t)drop_mask & 3) == 0) && groups <= 64);
+  SFRON_CHECK_ARG(!src->resid || (const float*)x != src->resid);
+  const int gpb = gn3_gpb(B, HW, C, groups);
+  if (!gpb) return SFRON_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_gn3_fwd<true>, dim3(B * (groups / gpb)), dim3(GN3_T), 0, (hipStream_t)stream, (const float*)x, C, gamma, beta, HW, C, groups, gpb,
+                     eps, swish, drop_mask, drop_scale, (__bf16*)y, mean, rstd, gn3_src(src));
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+int sfron_groupnorm_bwd_res_src(const sfron_split_src* src, float* dy, const float* x, int ldx, const float* gamma, const float* beta,
+                                const float* mean, const float* rstd, int B, int HW, int C, int groups, int swish, const uint8_t* drop_mask,
+                                float drop_scale, float* dx, int lddx, int accumulate, const float* extra, int ld_extra, float* part_gamma,
+                                float* part_beta, void* stream) {
+  SFRON_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && part_gamma && part_beta && groups > 0 && C % groups == 0 && split_src_ok(src, C));
+  SFRON_CHECK_ARG(ldx % 4 == 0 && lddx % 4 == 0 && groups <= 64 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0 &&
+                  (!drop_mask || ((uintptr_t)drop_mask & 3) == 0) && dy != dx);
+  SFRON_CHECK_ARG(!extra || (ld_extra >= C && extra != dx && ld_extra % 4 == 0 && ((uintptr_t)extra & 15) == 0));
+  const int gpb = gn3_gpb(B, HW, C, groups);
+  if (!gpb) return SFRON_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_gn3_bwd<true>, dim3(B * (groups / gpb)), dim3(GN3_T), 0, (hipStream_t)stream, (const float*)dy, x, ldx, gamma, beta, mean, rstd, HW,
+                     C, groups, gpb, swish, drop_mask, drop_scale, dx, lddx, accumulate, part_gamma, part_beta, extra, ld_extra, (__bf16*)nullptr,
+                     (float*)nullptr, 1, gn3_src(src));
+  SFRON_LAUNCH_STATUS();
+  return SFRON_OK;
+}
+int sfron_groupnorm_bwd_cast_src(const sfron_split_src* src, float* dy, const float* x, int ldx, const float* gamma, const float* beta,
+                                 const float* mean, const float* rstd, int B, int HW, int C, int groups, int swish, const uint8_t* drop_mask,
+                                 float drop_scale, uint16_t* dx_bf16, float* col_partials, float* part_gamma, float* part_beta, void* stream) {
+  SFRON_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx_bf16 && col_partials && part_gamma && part_beta && split_src_ok(src, C));
+  SFRON_CHECK_ARG(sfron_groupnorm_bwd_cast_ok(ldx, C, groups) && B > 0 && HW > 0);
+  SFRON_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy) & 15) == 0 && ((uintptr_t)dx_bf16 & 7) == 0 && (!drop_mask || ((uintptr_t)drop_mask & 3) == 0));
+  const int gpb = gn3_gpb(B, HW, C, groups);
+  if (!gpb) return SFRON_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_gn3_bwd<true>, dim3(B * (groups / gpb)), dim3(GN3_T), 0, (hipStream_t)stream, (const float*)dy, x, ldx, gamma, beta, mean, rstd, HW,
+                     C, groups, gpb, swish, drop_mask, drop_scale, (float*)nullptr, C, 0, part_gamma, part_beta, (const float*)nullptr, 0,
+                     (__bf16*)dx_bf16, col_partials, gn_chunks(B, HW), gn3_src(src));
   SFRON_LAUNCH_STATUS();
   return SFRON_OK;
 }

@@ -127,7 +127,7 @@ def _addr(t):
 
 
 def _conv_desc(B, hs, ws, cs, ho, wo, n_out, taps=9, stride=1, pad=1, up=0, dil=0, bias=None, resid=None, vec=None, ld_vec=0,
-               out_bf16=None, out_f32=None, ld_out=None, accumulate=False):
+               out_bf16=None, out_f32=None, ld_out=None, accumulate=False, pending=None):
     d = _lib.ConvDesc()
     d.batch, d.h_src, d.w_src, d.c_src, d.h_out, d.w_out, d.n_out = B, hs, ws, cs, ho, wo, n_out
     d.taps, d.stride, d.pad, d.upsample, d.dilate = taps, stride, pad, up, dil
@@ -139,7 +139,22 @@ def _conv_desc(B, hs, ws, cs, ho, wo, n_out, taps=9, stride=1, pad=1, up=0, dil=
         ws, nsl = _split_scratch(rows * n_out, t)            # few output tiles, deep contraction: split-K slabs
         d.split_ws, d.split_ws_slabs = ws.data_ptr(), nsl
         d._keep = ws
+        if pending is not None:        # a ctypes int: the call may leave its split unfinished for the GroupNorm that follows (split_source)
+            d.split_pending = ctypes.pointer(pending)
     return d
+
+
+def split_source(d, pending, rows, n_out, keep=()):
+    """The unfinished result of a split convolution (sfron_conv_desc.split_pending) as a sfron_split_src for the GroupNorm that consumes it,
+    or None when the call finished its output.  `keep`: tensors the description points at (held by the returned object)."""
+    if pending is None or pending.value <= 0:
+        return None
+    src = _lib.SplitSrc()
+    src.slabs, src.n_slabs, src.slab_stride = d.split_ws, pending.value, rows * n_out
+    src.bias, src.sample_vec, src.ld_vec, src.resid, src.ld_resid = d.bias, d.sample_vec, d.ld_vec, d.resid, n_out
+    src._keep = (d._keep,) + tuple(keep)
+    src._rows_per_sample = d.h_out * d.w_out
+    return src
 
 
 def colsum_f32(x, rows, n, ld, out, scratch):
@@ -338,8 +353,20 @@ class _TapeNet(nn.Module):
             a.partials, a.out, a.groups, a.per_group, a.D, a.ldout = t.data_ptr(), out_addr, groups, per_group, D, ldout
         check(_L().sfron_reduce_batch(ctypes.cast(arr, ctypes.c_void_p), len(items), stream_ptr()), "reduce_batch")
 
-    def _gn(self, tape, x, name, swish, drop_mask=None, eps=None):
-        """y = bf16(act(GroupNorm32(x)) [* dropout]); the backward step adds to x.grad."""
+    def _finish_or_fuse(self, src, t, B, HW, C):
+        """src: an unfinished split-K result that tensor t [B * HW][C] is to be formed from (split_source), or None.  Returns src when the
+        GroupNorm over t takes the one-launch form (which then finishes the sum in its first pass and stores t itself); otherwise launches the
+        finish here and returns None."""
+        if src is None:
+            return None
+        if _L().sfron_groupnorm_one_launch(B, HW, C, 32):
+            return src
+        check(_L().sfron_split_finish(ctypes.byref(src), B * HW, C, src._rows_per_sample, ptr(t), None, C, stream_ptr()), "split_finish")
+        return None
+
+    def _gn(self, tape, x, name, swish, drop_mask=None, eps=None, src=None):
+        """y = bf16(act(GroupNorm32(x)) [* dropout]); the backward step adds to x.grad.
+        src: x.t has not been written yet -- it is this unfinished split-K result (_conv3(defer_finish=True)); the GroupNorm forms and stores it."""
         eps = self.GN_EPS if eps is None else eps
         dev = self.device_
         y = torch.empty(x.rows, x.C, dtype=torch.bfloat16, device=dev)
@@ -349,39 +376,60 @@ class _TapeNet(nn.Module):
         gam, bet = self._p(name + ".weight"), self._p(name + ".bias")
         trains = self._trains(name + ".weight")          # decided when the tape is built; a frozen norm (SD train_method "xattn") skips the
                                                          # reduction of its affine gradients: nothing reads them
-        ws = torch.empty(_L().sfron_groupnorm_scratch_bytes(x.B, x.H * x.W, x.C, 32) // 8 + 2, dtype=torch.float64, device=dev)   # per-chunk partial sums
-        check(_L().sfron_groupnorm_fwd(ptr(x.t), x.C, gam, bet, x.B, x.H * x.W, x.C, 32, eps, int(swish), ptr(drop_mask), scale, ptr(y),
-                                       ptr(mean), ptr(rstd), ptr(ws), stream_ptr()), "groupnorm_fwd")
+        src = self._finish_or_fuse(src, x.t, x.B, x.H * x.W, x.C)
+        if src is not None:
+            check(_L().sfron_groupnorm_fwd_src(ctypes.byref(src), ptr(x.t), gam, bet, x.B, x.H * x.W, x.C, 32, eps, int(swish), ptr(drop_mask), scale,
+                                               ptr(y), ptr(mean), ptr(rstd), stream_ptr()), "groupnorm_fwd_src")
+        else:
+            ws = torch.empty(_L().sfron_groupnorm_scratch_bytes(x.B, x.H * x.W, x.C, 32) // 8 + 2, dtype=torch.float64, device=dev)   # per-chunk partial sums
+            check(_L().sfron_groupnorm_fwd(ptr(x.t), x.C, gam, bet, x.B, x.H * x.W, x.C, 32, eps, int(swish), ptr(drop_mask), scale, ptr(y),
+                                           ptr(mean), ptr(rstd), ptr(ws), stream_ptr()), "groupnorm_fwd")
 
-        def bwd(dy, extra=None, ld_extra=0):
+        def bwd(dy, extra=None, ld_extra=0, src=None):
             """dy: fp32 [rows][C]; extra: fp32 [rows][ld_extra], one more term of x's gradient (the residual branch's) added in
-            the same pass instead of a separate x.grad (+)= extra."""
+            the same pass instead of a separate x.grad (+)= extra.  src: dy has not been written yet (conv backward with defer=True)."""
             gbuf, acc = x.grad_buf()
             pg = torch.empty(x.B, x.C, dtype=torch.float32, device=dev)
             pb = torch.empty_like(pg)
-            ws2 = torch.empty(_L().sfron_groupnorm_scratch_bytes(x.B, x.H * x.W, x.C, 32) // 8 + 2, dtype=torch.float64, device=dev)
-            check(_L().sfron_groupnorm_bwd_res(ptr(dy), ptr(x.t), x.C, gam, bet, ptr(mean), ptr(rstd), x.B, x.H * x.W, x.C, 32, int(swish),
-                                               ptr(drop_mask), scale, ptr(gbuf), x.C, acc, ptr(extra), ld_extra, ptr(pg), ptr(pb), ptr(ws2),
-                                               stream_ptr()), "groupnorm_bwd")
+            src = self._finish_or_fuse(src, dy, x.B, x.H * x.W, x.C)
+            if src is not None and (extra is None or (ld_extra % 4 == 0 and extra.data_ptr() % 16 == 0)):
+                check(_L().sfron_groupnorm_bwd_res_src(ctypes.byref(src), ptr(dy), ptr(x.t), x.C, gam, bet, ptr(mean), ptr(rstd), x.B, x.H * x.W, x.C, 32,
+                                                       int(swish), ptr(drop_mask), scale, ptr(gbuf), x.C, acc, ptr(extra), ld_extra, ptr(pg), ptr(pb),
+                                                       stream_ptr()), "groupnorm_bwd_src")
+            else:
+                if src is not None:
+                    check(_L().sfron_split_finish(ctypes.byref(src), x.rows, x.C, src._rows_per_sample, ptr(dy), None, x.C, stream_ptr()), "split_finish")
+                ws2 = torch.empty(_L().sfron_groupnorm_scratch_bytes(x.B, x.H * x.W, x.C, 32) // 8 + 2, dtype=torch.float64, device=dev)
+                check(_L().sfron_groupnorm_bwd_res(ptr(dy), ptr(x.t), x.C, gam, bet, ptr(mean), ptr(rstd), x.B, x.H * x.W, x.C, 32, int(swish),
+                                                   ptr(drop_mask), scale, ptr(gbuf), x.C, acc, ptr(extra), ld_extra, ptr(pg), ptr(pb), ptr(ws2),
+                                                   stream_ptr()), "groupnorm_bwd")
             if trains:
                 self._reduce(pg, 1, x.B, x.C, self._g(name + ".weight"), x.C)
                 self._reduce(pb, 1, x.B, x.C, self._g(name + ".bias"), x.C)
 
-        def bwd_cast(dy):
+        def bwd_cast(dy, src=None):
             """For an x that only this norm consumes and that a convolution produced: x's gradient as that convolution's bf16 d_out
             operand plus its column sums per (sample, pixel chunk) -- (d_x bf16 [rows][C], partials fp32 [B][chunks][C], chunks) --
-            without an fp32 x.grad; None when the shape is not eligible (the caller then takes bwd and casts)."""
+            without an fp32 x.grad; None when the shape is not eligible (the caller then takes bwd and casts; a pending dy is finished first)."""
             if not _L().sfron_groupnorm_bwd_cast_ok(x.C, x.C, 32):
+                if src is not None:
+                    check(_L().sfron_split_finish(ctypes.byref(src), x.rows, x.C, src._rows_per_sample, ptr(dy), None, x.C, stream_ptr()), "split_finish")
                 return None
+            src = self._finish_or_fuse(src, dy, x.B, x.H * x.W, x.C)
             nch = _L().sfron_groupnorm_chunks(x.B, x.H * x.W)
             d16 = torch.empty(x.rows, x.C, dtype=torch.bfloat16, device=dev)
             cpart = torch.empty(x.B * nch, x.C, dtype=torch.float32, device=dev)
             pg = torch.empty(x.B, x.C, dtype=torch.float32, device=dev)
             pb = torch.empty_like(pg)
-            ws2 = torch.empty(_L().sfron_groupnorm_scratch_bytes(x.B, x.H * x.W, x.C, 32) // 8 + 2, dtype=torch.float64, device=dev)
-            check(_L().sfron_groupnorm_bwd_cast(ptr(dy), ptr(x.t), x.C, gam, bet, ptr(mean), ptr(rstd), x.B, x.H * x.W, x.C, 32, int(swish),
-                                                ptr(drop_mask), scale, ptr(d16), ptr(cpart), ptr(pg), ptr(pb), ptr(ws2), stream_ptr()),
-                  "groupnorm_bwd_cast")
+            if src is not None:
+                check(_L().sfron_groupnorm_bwd_cast_src(ctypes.byref(src), ptr(dy), ptr(x.t), x.C, gam, bet, ptr(mean), ptr(rstd), x.B, x.H * x.W, x.C,
+                                                        32, int(swish), ptr(drop_mask), scale, ptr(d16), ptr(cpart), ptr(pg), ptr(pb), stream_ptr()),
+                      "groupnorm_bwd_cast_src")
+            else:
+                ws2 = torch.empty(_L().sfron_groupnorm_scratch_bytes(x.B, x.H * x.W, x.C, 32) // 8 + 2, dtype=torch.float64, device=dev)
+                check(_L().sfron_groupnorm_bwd_cast(ptr(dy), ptr(x.t), x.C, gam, bet, ptr(mean), ptr(rstd), x.B, x.H * x.W, x.C, 32, int(swish),
+                                                    ptr(drop_mask), scale, ptr(d16), ptr(cpart), ptr(pg), ptr(pb), ptr(ws2), stream_ptr()),
+                      "groupnorm_bwd_cast")
             if trains:
                 self._reduce(pg, 1, x.B, x.C, self._g(name + ".weight"), x.C)
                 self._reduce(pb, 1, x.B, x.C, self._g(name + ".bias"), x.C)
@@ -389,9 +437,12 @@ class _TapeNet(nn.Module):
         bwd.cast = bwd_cast
         return y, bwd
 
-    def _conv3(self, src, B, hs, ws, name, ho, wo, stride=1, pad=1, up=0, vec=None, ld_vec=0, resid=None):
+    FUSE_SPLIT_FINISH = True     # False (tools / tests): every split convolution finishes its own output, as before round 6
+
+    def _conv3(self, src, B, hs, ws, name, ho, wo, stride=1, pad=1, up=0, vec=None, ld_vec=0, resid=None, defer_finish=False):
         """3x3 convolution of a bf16 NHWC source -> fp32 rows [B*ho*wo][Cout_p]; returns (out, backward(d_out fp32) -> d_src fp32
-        at the source resolution, or None for the input layer)."""
+        at the source resolution, or None for the input layer).  defer_finish (the caller hands `out` to a GroupNorm next): returns
+        (out, backward, source) -- source = the unfinished split-K result `out` is to be formed from (split_source), or None."""
         v = self.conv3[name]
         dev = self.device_
         rows = B * ho * wo
@@ -401,15 +452,18 @@ class _TapeNet(nn.Module):
         else:                                        # conv_out: 3 output channels computed as 8 (zero rows / zero bias beyond Cout)
             bias = torch.zeros(v["cop"], dtype=torch.float32, device=dev)
             bias[:v["co"]] = self.view(self.params, name + ".bias")
+        pend = ctypes.c_int(0) if defer_finish and self.FUSE_SPLIT_FINISH else None
         d = _conv_desc(B, hs, ws, v["cip"], ho, wo, v["cop"], 9, stride, pad, up, 0, bias=bias, resid=resid, vec=vec, ld_vec=ld_vec,
-                       out_f32=out, ld_out=v["cop"])
+                       out_f32=out, ld_out=v["cop"], pending=pend)
         check(_L().sfron_conv_fwd(ctypes.byref(d), ptr(src), ptr(v["fwd"]), stream_ptr()), "conv_fwd")
+        out_src = split_source(d, pend, rows, v["cop"], keep=(bias, resid, vec))
 
         trains = self._trains(name + ".weight")          # decided when the tape is built, not when it runs
 
-        def bwd(d_out, want_dsrc=True, d_bf=None):
+        def bwd(d_out, want_dsrc=True, d_bf=None, defer=False):
             """d_bf: d_out as the bf16 operand [rows][Cout_p] when the caller has it already (then d_out is not read and the bias
-            gradient is the caller's: _resblock forms both in the GroupNorm backward, sfron_groupnorm_bwd_cast)."""
+            gradient is the caller's: _resblock forms both in the GroupNorm backward, sfron_groupnorm_bwd_cast).
+            defer (the caller hands the result to a GroupNorm backward next): returns (d_src, source) as _conv3(defer_finish=True)."""
             if d_bf is not None:
                 dyb = d_bf
             elif trains and v["cop"] == v["co"] and v["co"] % 4 == 0:
@@ -448,24 +502,25 @@ class _TapeNet(nn.Module):
                     check(_L().sfron_conv_wgrad_scatter(ptr(self._dw), v["co"], v["ci"], 9, v["cip"], nsl, slab, self._g(name + ".weight"),
                                                         stream_ptr()), "conv_wgrad_scatter")
             if not want_dsrc or v["dgr"] is None:
-                return None
+                return (None, None) if defer else None
             if stride == 2:        # Downsample: gradient = flipped kernel over the zero-dilated dY, padding 2 - pad
                 ds = torch.empty(B * hs * ws, v["ci"], dtype=torch.float32, device=dev)
                 dd = _conv_desc(B, ho, wo, v["cop"], hs, ws, v["ci"], 9, 1, 2 - pad, 0, 1, out_f32=ds, ld_out=v["ci"])
                 check(_L().sfron_conv_fwd(ctypes.byref(dd), ptr(dyb), ptr(v["dgr"]), stream_ptr()), "conv_dgrad")
-                return ds
+                return (ds, None) if defer else ds
             if up:                 # Upsample (:56-60): gradient wrt the upsampled image, summed over each 2x2 block
                 du = torch.empty(rows, v["ci"], dtype=torch.float32, device=dev)
                 dd = _conv_desc(B, ho, wo, v["cop"], ho, wo, v["ci"], 9, 1, 1, 0, 0, out_f32=du, ld_out=v["ci"])
                 check(_L().sfron_conv_fwd(ctypes.byref(dd), ptr(dyb), ptr(v["dgr"]), stream_ptr()), "conv_dgrad")
                 ds = torch.empty(B * hs * ws, v["ci"], dtype=torch.float32, device=dev)
                 check(_L().sfron_pool2_sum(ptr(du), B, hs, ws, v["ci"], ptr(ds), 0, stream_ptr()), "pool2_sum")
-                return ds
+                return (ds, None) if defer else ds
             ds = torch.empty(rows, v["ci"], dtype=torch.float32, device=dev)
-            dd = _conv_desc(B, ho, wo, v["cop"], ho, wo, v["ci"], 9, 1, 1, 0, 0, out_f32=ds, ld_out=v["ci"])
+            pend_b = ctypes.c_int(0) if defer and self.FUSE_SPLIT_FINISH else None
+            dd = _conv_desc(B, ho, wo, v["cop"], ho, wo, v["ci"], 9, 1, 1, 0, 0, out_f32=ds, ld_out=v["ci"], pending=pend_b)
             check(_L().sfron_conv_fwd(ctypes.byref(dd), ptr(dyb), ptr(v["dgr"]), stream_ptr()), "conv_dgrad")
-            return ds
-        return out, bwd
+            return (ds, split_source(dd, pend_b, rows, v["ci"])) if defer else ds
+        return (out, bwd, out_src) if defer_finish else (out, bwd)
 
     def _linear(self, x_bf, rows, name, cin, cout, out=None, ldc=None, resid=None, x_lda=None, w_ptr=None, b_ptr=None, g_w=None, g_b=None,
                 bias=True):
@@ -523,9 +578,14 @@ class _TapeNet(nn.Module):
         dev, B, H, W = self.device_, x.B, x.H, x.W
         a1, gn1_b = self._gn(tape, x, n_norm1, True)
         c0, _ = self.proj_slices[name]
-        h1_t, conv1_b = self._conv3(a1, B, H, W, n_conv1, H, W, vec=proj.data_ptr() + 4 * c0, ld_vec=self.proj_total)
+        v1 = self.conv3[n_conv1]
+        fuse1 = v1["cop"] == v1["co"] == cout           # h1 has one consumer, norm2, which then also finishes conv1's split-K sum (if any)
+        if fuse1:
+            h1_t, conv1_b, h1_src = self._conv3(a1, B, H, W, n_conv1, H, W, vec=proj.data_ptr() + 4 * c0, ld_vec=self.proj_total, defer_finish=True)
+        else:
+            (h1_t, conv1_b), h1_src = self._conv3(a1, B, H, W, n_conv1, H, W, vec=proj.data_ptr() + 4 * c0, ld_vec=self.proj_total), None
         h1 = Act(h1_t, B, H, W, cout)
-        a2, gn2_b = self._gn(tape, h1, n_norm2, True, drop_mask)
+        a2, gn2_b = self._gn(tape, h1, n_norm2, True, drop_mask, src=h1_src)
         if cin != cout:
             xb = cast_rows(x.t, cin, x.rows, cin, dev)
             sc, sc_b = self._linear(xb, x.rows, n_short, cin, cout)
@@ -534,14 +594,19 @@ class _TapeNet(nn.Module):
         out_t, conv2_b = self._conv3(a2, B, H, W, n_conv2, H, W, resid=sc)
         out = Act(out_t, B, H, W, cout)
 
-        v1 = self.conv3[n_conv1]
         trains1 = self._trains(n_conv1 + ".weight")       # decided when the tape is built, as in _conv3
+        v2 = self.conv3[n_conv2]
+        defer2 = v2["ci"] == cout and v2["ci"] % 4 == 0   # conv2's input gradient is [rows][cout] contiguous: norm2's backward may finish it
+        defer1 = v1["ci"] == cin and cin % 4 == 0
+        use_cast = v1["cop"] == v1["co"] == cout and bool(_L().sfron_groupnorm_bwd_cast_ok(cout, cout, 32))
 
         def bwd():
             d_out = out.grad
-            d_a2 = conv2_b(d_out)
+            # (the shortcut first: a pending split result lives in the stream's shared slab scratch, which the next split product overwrites --
+            # nothing may run between a deferring convolution and the GroupNorm that finishes it)
             d_skip = d_out if sc_b is None else sc_b(d_out, cout)      # the shortcut's share of x.grad: added by norm1's backward pass below
-            fused = gn2_b.cast(d_a2) if v1["cop"] == v1["co"] == cout else None
+            d_a2, a2_src = conv2_b(d_out, defer=True) if defer2 else (conv2_b(d_out), None)
+            fused = gn2_b.cast(d_a2, src=a2_src) if use_cast else None       # (eligible shape: never None)
             if fused is not None:
                 # h1 = conv1(.) + proj has one consumer (norm2): its gradient leaves norm2's backward pass as conv1's bf16 d_out,
                 # with column sums per (sample, chunk) that finish as d_proj's slice (per sample) and conv1's bias gradient (all)
@@ -549,14 +614,14 @@ class _TapeNet(nn.Module):
                 self._reduce(cpart, B, nch, cout, d_proj.data_ptr() + 4 * c0, self.proj_total)
                 if trains1:
                     self._reduce(cpart, 1, B * nch, cout, self._g(n_conv1 + ".bias"), cout)
-                d_a1 = conv1_b(None, d_bf=dh1_bf)
+                d_a1, a1_src = conv1_b(None, d_bf=dh1_bf, defer=True) if defer1 else (conv1_b(None, d_bf=dh1_bf), None)
             else:
-                gn2_b(d_a2)                               # -> h1.grad
+                gn2_b(d_a2, src=a2_src)                   # -> h1.grad
                 dh1 = h1.grad
                 check(_L().sfron_sample_colsum(ptr(dh1), cout, B, H * W, cout, d_proj.data_ptr() + 4 * c0, self.proj_total, ptr(self._cs),
                                                self._cs.numel(), stream_ptr()), "sample_colsum")
-                d_a1 = conv1_b(dh1)
-            gn1_b(d_a1, d_skip, cin)                      # -> x.grad (+)= d_skip + norm1's gradient
+                d_a1, a1_src = conv1_b(dh1, defer=True) if defer1 else (conv1_b(dh1), None)
+            gn1_b(d_a1, d_skip, cin, src=a1_src)          # -> x.grad (+)= d_skip + norm1's gradient
         tape.append(bwd)
         return out
 
