@@ -15,6 +15,7 @@ def hook(i, step):
         cv = inspect.getclosurevars(step)
         print("first NaN in the gradient arena after backward step", i, step.__name__, {k: (v if isinstance(v, (str, int)) else type(v).__name__) for k, v in cv.nonlocals.items()})
 model._tape_hook = hook
+model.BATCH_REDUCTIONS = False          # the hook looks at the gradient arena after every step: every finish launched where it is asked for
 out, out_ref = T._fwd_bwd_both(ref, model, cfg, B, seed=11, p_drop=p)
 rows = []
 for (n, pp), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
