@@ -5,6 +5,7 @@ import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
+sys.path.insert(0, os.path.join(ROOT, "tools")); import ab_lib; ab_lib.select()     # SFRON_LIB_NAME: another build of the library
 ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=20); ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--eager", action="store_true", help="no HIP-graph replay of the stages")
 a = ap.parse_args()

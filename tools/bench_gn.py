@@ -4,8 +4,9 @@ takes it, microseconds per launch by HIP events, algorithmic bytes (forward: x f
 written + pg / pb) and the rate they imply.   python tools/bench_gn.py [--reps 20]"""
 import argparse, ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
+import ab_lib; ab_lib.select()          # SFRON_LIB_NAME=libsfron_<variant>.so: another build of the library (tools/build_variant.sh)
 from sfron import _lib
 from sfron._lib import check, ptr, stream_ptr
 ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=20); a = ap.parse_args()
