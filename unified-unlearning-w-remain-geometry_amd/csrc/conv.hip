@@ -2512,9 +2512,6 @@ static bool gn2_ok(int ldx, int ld2, int C, int groups, const void* scratch) {
 // multiples of half a cache line (a 96-byte run straddles lines: measured 1.7x slower than the pair), at least 192 workgroups, and a slab of at
 // most 128 KB per workgroup (its second pass is an L2 hit) -- or, with eight groups in whole-line runs, up to 512 KB (second pass from the
 // Infinity Cache, as the pair's)
-#ifndef SFRON_GN3_SLAB_KB
-#define SFRON_GN3_SLAB_KB 128     // tools/build_variant.sh A-B: 64 (second pass from L2 at the 32 x 32 levels, half-line runs)
-#endif
 static int gn3_gpb(int B, int HW, int C, int groups) {
   if (gn3_off()) return 0;
   const int cg = C / groups;
@@ -2522,7 +2519,7 @@ static int gn3_gpb(int B, int HW, int C, int groups) {
     if (groups % gpb) continue;
     const int Cs = gpb * cg;
     if (Cs % 16 || Cs > 1024) continue;
-    if ((int64_t)HW * Cs * 4 > ((int64_t)SFRON_GN3_SLAB_KB << 10)) continue;
+    if ((int64_t)HW * Cs * 4 > (128 << 10)) continue;
     if ((int64_t)B * (groups / gpb) < 192) continue;
     return gpb;
   }
